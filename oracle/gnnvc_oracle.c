@@ -1,0 +1,267 @@
+/*
+ * gnnvc_oracle.c — CPU restatement of the reference GNN forward (see header).
+ * TEST INFRASTRUCTURE ONLY; not linked into the product.
+ *
+ * Build: gcc -O2 -mavx2 -mfma -ffp-contract=off -fopenmp (oracle/Makefile).
+ * -ffp-contract=off: the only fused operations are the explicit fmaf() calls,
+ * every other add / divide is separately rounded exactly as written.
+ */
+#include "gnnvc_oracle.h"
+
+#include <ctype.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---------------------------------------------------------------- parser */
+
+typedef struct {
+    const char *p, *end;
+} cursor;
+
+static int next_token(cursor *c, char *buf, size_t cap) {
+    while (c->p < c->end && isspace((unsigned char)*c->p)) c->p++;
+    if (c->p >= c->end) return 0;
+    size_t i = 0;
+    while (c->p < c->end && !isspace((unsigned char)*c->p)) {
+        if (i + 1 < cap) buf[i++] = *c->p;
+        c->p++;
+    }
+    buf[i] = 0;
+    return 1;
+}
+
+static int next_size(cursor *c, uint32_t *v) {
+    char t[64];
+    if (!next_token(c, t, sizeof t)) return 0;
+    char *e;
+    unsigned long x = strtoul(t, &e, 10);
+    if (*e) return 0;
+    *v = (uint32_t)x;
+    return 1;
+}
+
+/* matrix operator>> (src/matrix.cpp:97-104): "<h> <w>" then h*w floats. */
+static float *read_matrix(cursor *c, uint32_t *h, uint32_t *w) {
+    if (!next_size(c, h) || !next_size(c, w)) return NULL;
+    size_t cnt = (size_t)*h * *w;
+    float *d = (float *)malloc((cnt ? cnt : 1) * sizeof(float));
+    char t[64];
+    for (size_t i = 0; i < cnt; i++) {
+        if (!next_token(c, t, sizeof t)) { free(d); return NULL; }
+        d[i] = strtof(t, NULL); /* istream >> float rounds like strtof */
+    }
+    return d;
+}
+
+/* gnn::operator>> (src/gnn_inference.cpp:120-139). */
+oracle_model *oracle_model_parse(const char *text, size_t len) {
+    cursor c = {text, text + len};
+    oracle_model *m = (oracle_model *)calloc(1, sizeof *m);
+    char t[64];
+    uint32_t n;
+    m->weight_scale = 120.0f;
+    if (!next_token(&c, m->name, sizeof m->name) || !next_size(&c, &n) ||
+        !next_token(&c, t, sizeof t))
+        goto fail;
+    m->layers = (oracle_layer *)calloc(n ? n : 1, sizeof(oracle_layer));
+    for (uint32_t i = 0; i < n; i++) {
+        if (!next_token(&c, t, sizeof t)) goto fail;
+        oracle_layer *l = &m->layers[m->n_layers];
+        if (!strcmp(t, "Linear_Layer")) {
+            uint32_t bh, bw;
+            l->kind = ORACLE_LAYER_LINEAR;
+            if (!next_token(&c, t, sizeof t)) goto fail; /* "Weights:" */
+            l->W = read_matrix(&c, &l->k, &l->m);
+            if (!l->W) goto fail;
+            m->n_layers++;
+            if (!next_token(&c, t, sizeof t)) goto fail; /* "Bias:" */
+            l->bias = read_matrix(&c, &bh, &bw);
+            if (!l->bias || bh != 1 || bw != l->m) goto fail;
+        } else if (!strcmp(t, "Graph_Layer")) {
+            l->kind = ORACLE_LAYER_GRAPH;
+            m->n_layers++;
+        } else if (!strcmp(t, "ReLU_Activation")) {
+            l->kind = ORACLE_LAYER_RELU;
+            m->n_layers++;
+        } else if (!strcmp(t, "Sigmoid_Activation")) {
+            l->kind = ORACLE_LAYER_SIGMOID;
+            m->n_layers++;
+        } /* unknown tokens are skipped, as the reference's if-chain does */
+    }
+    return m;
+fail:
+    oracle_model_free(m);
+    return NULL;
+}
+
+void oracle_model_free(oracle_model *m) {
+    if (!m) return;
+    for (int i = 0; m->layers && i < m->n_layers; i++) {
+        free(m->layers[i].W);
+        free(m->layers[i].bias);
+    }
+    free(m->layers);
+    free(m);
+}
+
+/* model::set_weight_scale (src/gnn_inference.cpp:83-90) */
+void oracle_model_set_weight_scale(oracle_model *m, float ws) { m->weight_scale = ws; }
+
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ---------------------------------------------------------------- layers */
+
+/* graph_layer::forward (src/gnn_inference.cpp:27-42).
+ * out is zero-filled (:28-29); out[u][0:f] accumulates in[v][0:f] over adj(u)
+ * in stored order, one rounded fp32 add per neighbour starting from 0.0f
+ * (:33-36); in[u] is copied to out[u][f:2f] (:37); then degree, W/ws, NW/ws
+ * are written at columns f+1, f+2, f+3 (:38-40) — for f=16 these overwrite
+ * copied columns 17..19 and columns 32..34 stay zero. */
+static void graph_row(const oracle_graph *g, float ws, uint32_t f, const float *in,
+                      float *out, uint32_t u) {
+    const uint32_t wd = 2 * f + 3;
+    float *o = out + (size_t)u * wd;
+    for (uint32_t j = 0; j < wd; j++) o[j] = 0.0f;
+    for (uint64_t e = g->rowptr[u]; e < g->rowptr[u + 1]; e++) {
+        const float *r = in + (size_t)g->col[e] * f;
+        for (uint32_t j = 0; j < f; j++) o[j] = o[j] + r[j];
+    }
+    const float *self = in + (size_t)u * f;
+    for (uint32_t j = 0; j < f; j++) o[f + j] = self[j];
+    o[f + 1] = (float)(uint32_t)(g->rowptr[u + 1] - g->rowptr[u]);
+    o[f + 2] = (float)g->w[u] / ws;
+    o[f + 3] = (float)g->nw[u] / ws;
+}
+
+void oracle_graph_layer(const oracle_graph *g, float ws, uint32_t f, const float *in,
+                        float *out, int parallel_rows) {
+    if (parallel_rows) {
+#pragma omp parallel for schedule(dynamic, 1024)
+        for (int64_t u = 0; u < (int64_t)g->n; u++) graph_row(g, ws, f, in, out, (uint32_t)u);
+    } else {
+        /* as shipped: the reference's "#pragma omp parallel for" is inert
+         * (Makefile has no -fopenmp), so the aggregation is serial. */
+        for (uint32_t u = 0; u < g->n; u++) graph_row(g, ws, f, in, out, u);
+    }
+}
+
+/* linear_layer::forward (src/gnn_inference.cpp:20-25): dot(in, W, out) with
+ * beta = 0 (src/matrix.cpp:106-122 -> cblas_sgemm row-major, no transposes),
+ * then a separately rounded per-row bias add.  SGEMM restated as a
+ * sequential-k fmaf chain from +0.0f per output.  Rows are independent, so
+ * the row-parallel loop gives the same bits with any thread count (OpenBLAS
+ * is the reference's only multi-threaded piece). */
+void oracle_linear_layer(uint32_t n, uint32_t k, uint32_t m, const float *in,
+                         const float *W, const float *bias, float *out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; i++) {
+        const float *a = in + (size_t)i * k;
+        float *o = out + (size_t)i * m;
+        float acc[64];
+        if (m <= 64) {
+            for (uint32_t j = 0; j < m; j++) acc[j] = 0.0f;
+            for (uint32_t kk = 0; kk < k; kk++) {
+                const float av = a[kk];
+                const float *wr = W + (size_t)kk * m;
+                for (uint32_t j = 0; j < m; j++) acc[j] = fmaf(av, wr[j], acc[j]);
+            }
+            for (uint32_t j = 0; j < m; j++) o[j] = acc[j] + bias[j];
+        } else {
+            for (uint32_t j = 0; j < m; j++) {
+                float s = 0.0f;
+                for (uint32_t kk = 0; kk < k; kk++) s = fmaf(a[kk], W[(size_t)kk * m + j], s);
+                o[j] = s + bias[j];
+            }
+        }
+    }
+}
+
+/* ReLU::forward (src/gnn_inference.cpp:44-47): std::max(x, 0.0f) — returns x
+ * unless x < 0 (so -0.0f and NaN pass through like std::max does). */
+void oracle_relu(size_t count, const float *in, float *out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)count; i++) {
+        float x = in[i];
+        out[i] = (x < 0.0f) ? 0.0f : x;
+    }
+}
+
+/* sigmoid::forward (src/gnn_inference.cpp:49-52): host libm expf. */
+void oracle_sigmoid(size_t count, const float *in, float *out) {
+    for (size_t i = 0; i < count; i++) out[i] = 1.0f / (1.0f + expf(-in[i]));
+}
+
+void oracle_neighbourhood_weights(uint32_t n, const uint64_t *rowptr, const uint32_t *col,
+                                  const uint32_t *w, uint32_t *nw) {
+    for (uint32_t u = 0; u < n; u++) {
+        uint32_t s = 0;
+        for (uint64_t e = rowptr[u]; e < rowptr[u + 1]; e++) s += w[col[e]];
+        nw[u] = s;
+    }
+}
+
+/* model::predict (src/gnn_inference.cpp:67-81): copy the input, run the
+ * layers in order ping-ponging two buffers. */
+int oracle_predict(const oracle_model *m, const oracle_graph *g, uint32_t in_width,
+                   const float *in, float *out, uint32_t *out_width, int stop_after,
+                   int flags) {
+    if (!m || m->n_layers <= 0) return -1;
+    const uint32_t n = g->n;
+    uint32_t maxw = in_width, wd = in_width;
+    for (int i = 0; i < m->n_layers; i++) {
+        const oracle_layer *l = &m->layers[i];
+        if (l->kind == ORACLE_LAYER_LINEAR) {
+            if (l->k != wd) return -2;
+            wd = l->m;
+        } else if (l->kind == ORACLE_LAYER_GRAPH) {
+            wd = 2 * wd + 3;
+        }
+        if (wd > maxw) maxw = wd;
+    }
+    size_t cap = (size_t)(n ? n : 1) * maxw;
+    float *a = (float *)malloc(cap * sizeof(float));
+    float *b = (float *)malloc(cap * sizeof(float));
+    if (!a || !b) { free(a); free(b); return -3; }
+    memcpy(a, in, (size_t)n * in_width * sizeof(float));
+    wd = in_width;
+    int last = (stop_after < 0 || stop_after >= m->n_layers) ? m->n_layers - 1 : stop_after;
+    for (int i = 0; i <= last; i++) {
+        const oracle_layer *l = &m->layers[i];
+        switch (l->kind) {
+        case ORACLE_LAYER_LINEAR:
+            oracle_linear_layer(n, l->k, l->m, a, l->W, l->bias, b);
+            wd = l->m;
+            break;
+        case ORACLE_LAYER_GRAPH:
+            oracle_graph_layer(g, m->weight_scale, wd, a, b, flags & 1);
+            wd = 2 * wd + 3;
+            break;
+        case ORACLE_LAYER_RELU:
+            oracle_relu((size_t)n * wd, a, b);
+            break;
+        case ORACLE_LAYER_SIGMOID:
+            oracle_sigmoid((size_t)n * wd, a, b);
+            break;
+        default:
+            free(a); free(b);
+            return -4;
+        }
+        float *t = a; a = b; b = t;
+    }
+    memcpy(out, a, (size_t)n * wd * sizeof(float));
+    if (out_width) *out_width = wd;
+    free(a);
+    free(b);
+    return 0;
+}
