@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py — GNN forward edges/s on the metric graph (BASELINE.json).
+
+One step = one full forward (3 fused stages: graph layer + dense layers) over
+the synthetic Erdős–Rényi graph with 10 M vertices / 100 M undirected edges
+(weights U[20,120]), device-resident in HBM when the timed region
+starts.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL),
+the graph 1-D vertex-partitioned, the N x 16 fp32 feature rows all-gathered over
+xGMI between stages; total work is fixed, so scaling is "strong".
+
+Prints ONE JSON line on rank 0 (contract in the project brief):
+  value      = undirected edges / second, whole job
+  roofline   = the dominant kernel's algorithmic HBM bytes / its mean launch
+               duration (HIP events on the launch stream, live) vs 8 TB/s
+  cpu_baseline = the oracle (bit-equal CPU port of the reference path) timed on
+               this host on a bounded sample graph of the same distribution
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # name: (n, m, seed)
+    "er10m": (10_000_000, 100_000_000, 10),   # the metric graph
+    "er1m": (1_000_000, 10_000_000, 2),
+    "er100k": (100_000, 1_000_000, 1),
+}
+
+
+def stage_bytes(stage: int, n: int, nnz: int) -> int:
+    """Algorithmic HBM bytes of one fused stage (u32 indices,
+    fp32 features, no cache-reuse credit)."""
+    if stage == 0:    # nnz*(col 4 + x 4) + N*(rowptr 4 + x 4 + W 4 + NW 4) + N*64 written
+        return nnz * 8 + n * 16 + n * 64
+    if stage == 1:    # nnz*(4 + 64) + N*(rowptr 4 + own row 64 + W 4 + NW 4) + N*64 written
+        return nnz * 68 + n * 76 + n * 64
+    return nnz * 68 + n * 76 + n * 4  # last stage writes one score per vertex
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="er10m", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", default="2000000x20000000",
+                    help="n x m of the CPU-baseline sample graph")
+    ap.add_argument("--host-path", action="store_true",
+                    help="also time the host-pointer path (PCIe inclusive), reported separately")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run "
+              f"--nproc-per-node {args.gpus} (WORLD_SIZE={world})", file=sys.stderr)
+        return 2
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU: the engine has no CPU fallback", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import gnn_mwvc_amd as G
+    from tools import graphgen_torch as ggt
+
+    n, m, seed = WORKLOADS[args.workload]
+    t0 = time.time()
+    g = ggt.erdos_renyi(n, m, seed, dev)   # every rank builds the same graph (same Philox stream)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t0
+
+    eng = G.Engine(G.default_model_text(), device=local_rank)
+    assert eng.fused and eng.num_stages == 3
+    eng.set_weight_scale(g.ws)
+    eng.attach_graph_device(g.n, g.nnz, g.rowptr.data_ptr(), g.col.data_ptr(), g.w.data_ptr(),
+                            g.nw.data_ptr(), keepalive=g)
+    stream = torch.cuda.current_stream()
+    eng.set_stream(stream.cuda_stream)
+
+    x = g.x().contiguous()
+
+    # 1-D vertex partition: equal 64-aligned row blocks (ER is degree-uniform, so
+    # this is nnz-balanced too); rank r owns rows [lo, hi).
+    rpr = ((g.n + world - 1) // world + 63) // 64 * 64
+    lo, hi = min(rank * rpr, g.n), min((rank + 1) * rpr, g.n)
+    # feature buffers: (rows + pad) x 16 fp32, row g.n (the gather's pad row) stays zero
+    hbuf = [torch.zeros((world * rpr + 64, 16), dtype=torch.float32, device=dev) for _ in range(2)]
+    sc_full = torch.zeros(world * rpr + 64, dtype=torch.float32, device=dev)
+    lg_full = torch.zeros(world * rpr + 64, dtype=torch.float32, device=dev)
+
+    # HIP events on the launch stream around every stage launch of the timed region
+    # (the engine launches on torch's current stream, so torch events bracket its kernels)
+    stage_evt = [[torch.cuda.Event(enable_timing=True) for _ in range(6)]
+                 for _ in range(args.steps)]
+
+    def step(k: int | None):
+        ev = stage_evt[k] if k is not None else None
+        src = x
+        for st in range(3):
+            last = st == 2
+            dst = sc_full if last else hbuf[st]
+            if ev:
+                ev[2 * st].record(stream)
+            eng.stage_forward_device(st, lo, hi, src.data_ptr(), dst.data_ptr(),
+                                     lg_full.data_ptr() if last else 0)
+            if ev:
+                ev[2 * st + 1].record(stream)
+            if world > 1:
+                # exchange: every rank needs every row of the next stage's input (and,
+                # after the last stage, predict hands every caller all N scores)
+                flat = dst[: world * rpr]
+                dist.all_gather_into_tensor(flat, flat[rank * rpr:(rank + 1) * rpr])
+            src = dst
+
+    for _ in range(args.warmup):
+        step(None)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    stage_ms = [sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for ev in stage_evt) / args.steps
+                for i in range(3)]
+    scores, logits = sc_full[: g.n], lg_full[: g.n]
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    edges_per_s = g.n_edges / (elapsed / args.steps)
+
+    rows = hi - lo
+    local_nnz = int(g.rowptr[hi].item()) - int(g.rowptr[lo].item())
+    dom = max(range(3), key=lambda i: stage_ms[i])
+    dom_bytes = stage_bytes(dom, rows, local_nnz)
+    achieved = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9
+    fwd_bytes = sum(stage_bytes(i, g.n, g.nnz) for i in range(3))
+    kernel_names = ["k_stage_f1<32,32,16>", "k_stage_f16<32,32,16>", "k_stage_f16<32,16,1,sigmoid>"]
+
+    out = {
+        "metric": "GNN forward edges/sec", "value": edges_per_s, "unit": "edges/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"erdos-renyi n={g.n} m={g.n_edges} seed={seed} weights U[20,120]",
+                   "graph": args.workload, "partition": f"1d-vertex x{world}",
+                   "exchange": "none" if world == 1 else "all-gather N x16 fp32 after stages 0 and 1"},
+        "roofline": {"bound": "hbm", "kernel": kernel_names[dom], "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "algorithmic_bytes_per_launch": dom_bytes,
+                     "kernel_ms": stage_ms[dom],
+                     "forward_bytes": fwd_bytes,
+                     "forward_frac": fwd_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world},
+        "stage_ms": stage_ms, "graph_build_s": t_gen,
+    }
+
+    if rank == 0 and world == 1:
+        if args.host_path:
+            # PCIe-inclusive path (host x in, host scores + logits out); never `value`
+            import numpy as np
+            xh = x.cpu().numpy()
+            eng.forward(xh)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                eng.forward(xh)
+            out["host_path_ms"] = (time.perf_counter() - t1) * 1e3 / 3
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"], out["parity"] = cpu_baseline(args, dev, eng, ggt)
+
+    if rank == 0:
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def cpu_baseline(args, dev, eng, ggt):
+    """The oracle (bit-equal CPU port of the reference path, as shipped: serial
+    aggregation, threaded dense layers) timed on this host, on a bounded sample of
+    the same graph family; the GPU logits on the same sample are checked against it."""
+    import numpy as np
+    import torch
+    import gnn_mwvc_amd as G
+    from oracle import oracle_py
+
+    sn, sm = (int(v) for v in args.cpu_sample.split("x"))
+    gs = ggt.erdos_renyi(sn, sm, 99, dev)
+    hg = gs.to_host()
+    om = oracle_py.OracleModel(G.default_model_text())
+    om.set_weight_scale(hg.ws)
+    xh = hg.x()
+    om.predict(hg, xh)                         # warm-up (page faults, thread pool)
+    times = []
+    want = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        want = om.predict(hg, xh, stop_after=om.n_layers - 2)[:, 0]
+        times.append(time.perf_counter() - t0)
+    t_cpu = sorted(times)[0]
+    # parity of the GPU path on the same sample
+    eng.set_weight_scale(gs.ws)
+    eng.attach_graph_device(gs.n, gs.nnz, gs.rowptr.data_ptr(), gs.col.data_ptr(),
+                            gs.w.data_ptr(), gs.nw.data_ptr(), keepalive=gs)
+    sc = torch.zeros(gs.n, dtype=torch.float32, device=dev)
+    lg = torch.zeros(gs.n, dtype=torch.float32, device=dev)
+    eng.forward_device(gs.x().contiguous().data_ptr(), sc.data_ptr(), lg.data_ptr())
+    eng.synchronize()
+    got = lg.cpu().numpy()
+    mism = int((got.view(np.uint32) != want.view(np.uint32)).sum())
+    base = {"value": hg.n_edges / t_cpu, "unit": "edges/s", "cores": oracle_py.num_threads(),
+            "kind": "port",
+            "sample": f"erdos-renyi n={sn} m={hg.n_edges} (same generator, seed 99), one forward, "
+                      f"best of 2 after a warm-up; aggregation serial as the reference ships it, "
+                      f"dense layers on {oracle_py.num_threads()} OpenMP threads",
+            "seconds": t_cpu}
+    parity = {"sample_vertices": sn, "logit_bit_mismatches_vs_oracle": mism}
+    return base, parity
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,673 @@
+// gnnvc_engine.cpp — host side of libgnnvc_hip.so: the C ABI of include/gnnvc.h.
+//
+// Holds the parsed model (the reference's text format, reference
+// src/gnn_inference.cpp:120-139), the device copy of the graph view, the
+// feature buffers, and sequences the stages like model::predict does
+// (reference src/gnn_inference.cpp:67-81).  All arithmetic happens in the HIP
+// kernels of gnnvc_kernels.hip; there is no CPU fallback here.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/gnnvc.h"
+#include "gnnvc_kernels.h"
+
+using gnnvc::GraphDev;
+using gnnvc::StagePlan;
+
+namespace {
+
+enum LayerKind { kLinear = 0, kGraph = 1, kRelu = 2, kSigmoid = 3 };
+
+struct Layer {
+    LayerKind kind;
+    uint32_t k = 0, m = 0;          // linear: W is k x m
+    std::vector<float> W, bias;     // host copies
+    size_t w_off = 0, b_off = 0;    // float offsets in the device parameter buffer
+};
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;  // elements
+    hipError_t reserve(size_t count) {
+        if (count <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t rc = hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(count, 1) * sizeof(T));
+        if (rc == hipSuccess) cap = count;
+        return rc;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct gnnvc_engine {
+    int device = 0;
+    std::string name;
+    std::vector<Layer> layers;
+    std::vector<StagePlan> stages;  // non-empty iff fused
+    int in_width = 1, out_width = 1;
+    int max_width = 1;
+    bool ends_in_sigmoid = false;
+    float ws = 120.0f;  // graph_layer::WEIGHT_SCALE default (reference include/gnn_inference.hpp:25)
+
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::vector<hipEvent_t> ev;  // stage boundaries of the last forward
+    int ev_count = 0;
+
+    DevBuf<float> params;
+    // graph
+    GraphDev g;
+    bool have_graph = false;
+    DevBuf<uint32_t> rowptr, col, w, nw;
+    // feature buffers
+    DevBuf<float> x, h[2], scores, logits;
+    DevBuf<float> scratch[2];  // layer-level entry points / unfused path
+
+    std::string err;
+};
+
+namespace {
+
+int fail(gnnvc_engine *e, int code, const char *fmt, ...) {
+    if (e) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        e->err = buf;
+    }
+    return code;
+}
+
+#define HIP_TRY(e, call)                                                                   \
+    do {                                                                                   \
+        hipError_t rc_ = (call);                                                           \
+        if (rc_ != hipSuccess)                                                             \
+            return fail((e), rc_ == hipErrorOutOfMemory ? GNNVC_ERR_NOMEM : GNNVC_ERR_DEVICE, \
+                        "%s: %s", #call, hipGetErrorString(rc_));                          \
+    } while (0)
+
+// ---- model text ------------------------------------------------------------
+struct Cursor {
+    const char *p, *end;
+    bool token(std::string &out) {
+        while (p < end && isspace((unsigned char)*p)) ++p;
+        if (p >= end) return false;
+        const char *s = p;
+        while (p < end && !isspace((unsigned char)*p)) ++p;
+        out.assign(s, p);
+        return true;
+    }
+    bool size(uint32_t &v) {
+        std::string t;
+        if (!token(t)) return false;
+        char *q = nullptr;
+        unsigned long x = strtoul(t.c_str(), &q, 10);
+        if (!q || *q) return false;
+        v = (uint32_t)x;
+        return true;
+    }
+    // matrix text: "<h> <w>" then h*w numbers (reference src/matrix.cpp:97-104)
+    bool matrix(uint32_t &h, uint32_t &w, std::vector<float> &d) {
+        if (!size(h) || !size(w)) return false;
+        if ((uint64_t)h * w > (1u << 26)) return false;
+        d.resize((size_t)h * w);
+        std::string t;
+        for (auto &v : d) {
+            if (!token(t)) return false;
+            v = strtof(t.c_str(), nullptr);  // same rounding as istream >> float
+        }
+        return true;
+    }
+};
+
+int parse_model(gnnvc_engine *e, const char *text, size_t len) {
+    Cursor c{text, text + len};
+    std::string t;
+    uint32_t n = 0;
+    if (!c.token(e->name) || !c.size(n) || !c.token(t))
+        return fail(e, GNNVC_ERR_INVALID, "model header: expected '<name> <n> Layers'");
+    if (n > 4096) return fail(e, GNNVC_ERR_INVALID, "implausible layer count %u", n);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!c.token(t)) return fail(e, GNNVC_ERR_INVALID, "model text ends after %u of %u layers", i, n);
+        Layer l;
+        if (t == "Linear_Layer") {
+            uint32_t bh = 0, bw = 0;
+            l.kind = kLinear;
+            if (!c.token(t) || !c.matrix(l.k, l.m, l.W))
+                return fail(e, GNNVC_ERR_INVALID, "layer %u: malformed weight matrix", i);
+            if (!c.token(t) || !c.matrix(bh, bw, l.bias) || bh != 1 || bw != l.m)
+                return fail(e, GNNVC_ERR_INVALID, "layer %u: malformed bias", i);
+        } else if (t == "Graph_Layer") {
+            l.kind = kGraph;
+        } else if (t == "ReLU_Activation") {
+            l.kind = kRelu;
+        } else if (t == "Sigmoid_Activation") {
+            l.kind = kSigmoid;
+        } else {
+            continue;  // the reference's if-chain ignores unknown records
+        }
+        e->layers.push_back(std::move(l));
+    }
+    if (e->layers.empty()) return fail(e, GNNVC_ERR_INVALID, "model has no layers");
+    return GNNVC_OK;
+}
+
+// Widths through the network; decides fused vs layer-by-layer.
+int plan_model(gnnvc_engine *e) {
+    // input width: a leading graph layer accepts any width; a leading linear fixes it.
+    int wd = 1;
+    for (const auto &l : e->layers) {
+        if (l.kind == kLinear) { wd = (int)l.k; break; }
+        if (l.kind == kGraph) { wd = 1; break; }
+    }
+    // walk back from the first linear through graph layers: k = 2*w + 3
+    {
+        int first_lin = -1, graphs_before = 0;
+        for (size_t i = 0; i < e->layers.size(); ++i) {
+            if (e->layers[i].kind == kLinear) { first_lin = (int)i; break; }
+            if (e->layers[i].kind == kGraph) ++graphs_before;
+        }
+        if (first_lin >= 0) {
+            int k = (int)e->layers[first_lin].k;
+            for (int gq = 0; gq < graphs_before; ++gq) {
+                if ((k - 3) % 2 != 0 || k < 5) return fail(e, GNNVC_ERR_INVALID, "inconsistent layer widths");
+                k = (k - 3) / 2;
+            }
+            wd = k;
+        }
+    }
+    e->in_width = wd;
+    e->max_width = wd;
+    size_t off = 0;
+    for (auto &l : e->layers) {
+        if (l.kind == kLinear) {
+            if ((int)l.k != wd) return fail(e, GNNVC_ERR_INVALID, "linear layer expects %u inputs, gets %d", l.k, wd);
+            wd = (int)l.m;
+            l.w_off = off; off += l.W.size();
+            l.b_off = off; off += l.bias.size();
+        } else if (l.kind == kGraph) {
+            wd = 2 * wd + 3;
+        }
+        e->max_width = std::max(e->max_width, wd);
+    }
+    e->out_width = wd;
+    e->ends_in_sigmoid = e->layers.back().kind == kSigmoid;
+
+    // fused plan: (Graph, Linear, ReLU, Linear, ReLU, Linear, ReLU|Sigmoid)+
+    std::vector<StagePlan> st;
+    size_t i = 0;
+    int f = e->in_width;
+    bool ok = e->layers.size() % 7 == 0;
+    while (ok && i < e->layers.size()) {
+        const Layer *L = &e->layers[i];
+        ok = L[0].kind == kGraph && L[1].kind == kLinear && L[2].kind == kRelu &&
+             L[3].kind == kLinear && L[4].kind == kRelu && L[5].kind == kLinear &&
+             (L[6].kind == kRelu || L[6].kind == kSigmoid);
+        if (!ok) break;
+        StagePlan sp;
+        sp.f = f;
+        sp.n1 = (int)L[1].m; sp.n2 = (int)L[3].m; sp.n3 = (int)L[5].m;
+        sp.sigmoid_last = L[6].kind == kSigmoid;
+        sp.param_offset = L[1].w_off;
+        // the parameter buffer is laid out in layer order, so W1 b1 W2 b2 W3 b3 are contiguous
+        sp.variant = gnnvc::stage_variant(sp.f, sp.n1, sp.n2, sp.n3, sp.sigmoid_last);
+        const bool last = (i + 7 == e->layers.size());
+        ok = sp.variant >= 0 && (int)L[1].k == 2 * f + 3 && (sp.sigmoid_last ? last : true) &&
+             (last || sp.n3 == 16);
+        st.push_back(sp);
+        f = sp.n3;
+        i += 7;
+    }
+    if (ok && !st.empty() && st.back().sigmoid_last) e->stages = std::move(st);
+    return GNNVC_OK;
+}
+
+int upload_params(gnnvc_engine *e) {
+    std::vector<float> flat;
+    for (const auto &l : e->layers)
+        if (l.kind == kLinear) {
+            flat.insert(flat.end(), l.W.begin(), l.W.end());
+            flat.insert(flat.end(), l.bias.begin(), l.bias.end());
+        }
+    HIP_TRY(e, e->params.reserve(flat.size() + 64));
+    if (!flat.empty())
+        HIP_TRY(e, hipMemcpy(e->params.p, flat.data(), flat.size() * sizeof(float), hipMemcpyHostToDevice));
+    return GNNVC_OK;
+}
+
+int use_device(gnnvc_engine *e) {
+    HIP_TRY(e, hipSetDevice(e->device));
+    return GNNVC_OK;
+}
+
+int reserve_features(gnnvc_engine *e, uint32_t n) {
+    const size_t rows = (size_t)n + 1;
+    HIP_TRY(e, e->x.reserve(rows * (size_t)e->in_width));
+    HIP_TRY(e, e->scores.reserve(rows * (size_t)e->out_width));
+    HIP_TRY(e, e->logits.reserve(rows * (size_t)e->out_width));
+    if (!e->stages.empty()) {
+        for (auto &b : e->h) HIP_TRY(e, b.reserve(rows * 16));
+    }
+    return GNNVC_OK;
+}
+
+int ensure_events(gnnvc_engine *e, size_t count) {
+    while (e->ev.size() < count) {
+        hipEvent_t v;
+        HIP_TRY(e, hipEventCreate(&v));
+        e->ev.push_back(v);
+    }
+    return GNNVC_OK;
+}
+
+// Layer-by-layer forward on device buffers (any model).
+int forward_unfused(gnnvc_engine *e, const float *d_x, float *d_out, float *d_logits) {
+    const uint32_t n = e->g.n;
+    const size_t cap = ((size_t)n + 1) * (size_t)e->max_width;
+    for (auto &s : e->scratch) HIP_TRY(e, s.reserve(cap));
+    const float *cur = d_x;
+    int wd = e->in_width, pp = 0;
+    for (size_t i = 0; i < e->layers.size(); ++i) {
+        const Layer &l = e->layers[i];
+        const bool last = i + 1 == e->layers.size();
+        float *dst = last ? d_out : e->scratch[pp].p;
+        switch (l.kind) {
+        case kGraph:
+            HIP_TRY(e, gnnvc::launch_graph_layer(e->g, e->ws, (uint32_t)wd, cur, dst, e->stream));
+            wd = 2 * wd + 3;
+            break;
+        case kLinear:
+            HIP_TRY(e, gnnvc::launch_linear(n, l.k, l.m, cur, e->params.p + l.w_off,
+                                            e->params.p + l.b_off, dst, e->stream));
+            wd = (int)l.m;
+            break;
+        case kRelu:
+            HIP_TRY(e, gnnvc::launch_relu((size_t)n * wd, cur, dst, e->stream));
+            break;
+        case kSigmoid:
+            if (last && d_logits)
+                HIP_TRY(e, hipMemcpyAsync(d_logits, cur, (size_t)n * wd * sizeof(float),
+                                          hipMemcpyDeviceToDevice, e->stream));
+            HIP_TRY(e, gnnvc::launch_sigmoid((size_t)n * wd, cur, dst, e->stream));
+            break;
+        }
+        cur = dst;
+        pp ^= 1;
+    }
+    return GNNVC_OK;
+}
+
+}  // namespace
+
+// ============================================================================ ABI
+
+extern "C" {
+
+int gnnvc_abi_version(void) { return GNNVC_ABI_VERSION; }
+
+const char *gnnvc_strerror(int code) {
+    switch (code) {
+    case GNNVC_OK: return "ok";
+    case GNNVC_ERR_INVALID: return "invalid argument or malformed model";
+    case GNNVC_ERR_DEVICE: return "HIP device unavailable or HIP call failed";
+    case GNNVC_ERR_NOMEM: return "out of memory";
+    case GNNVC_ERR_STATE: return "call out of order";
+    case GNNVC_ERR_UNSUPPORTED: return "unsupported model or size";
+    default: return "unknown error";
+    }
+}
+
+const char *gnnvc_last_error(const gnnvc_engine *e) { return e ? e->err.c_str() : ""; }
+
+int gnnvc_create(gnnvc_engine **out, const char *model_text, size_t len, int device) {
+    if (!out || !model_text) return GNNVC_ERR_INVALID;
+    *out = nullptr;
+    gnnvc_engine *e = new (std::nothrow) gnnvc_engine();
+    if (!e) return GNNVC_ERR_NOMEM;
+    int rc = GNNVC_OK;
+    try {
+        e->device = device;
+        rc = parse_model(e, model_text, len);
+        if (rc == GNNVC_OK) rc = plan_model(e);
+        if (rc == GNNVC_OK) {
+            int count = 0;
+            if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+                rc = fail(e, GNNVC_ERR_DEVICE, "no HIP device %d (found %d) — this engine has no CPU path", device, count);
+        }
+        if (rc == GNNVC_OK) rc = use_device(e);
+        if (rc == GNNVC_OK) {
+            if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess)
+                rc = fail(e, GNNVC_ERR_DEVICE, "hipStreamCreate failed");
+            e->stream = e->own_stream;
+        }
+        if (rc == GNNVC_OK) rc = upload_params(e);
+    } catch (const std::bad_alloc &) {
+        rc = GNNVC_ERR_NOMEM;
+    } catch (...) {
+        rc = GNNVC_ERR_INVALID;
+    }
+    if (rc != GNNVC_OK) {
+        // keep the message reachable for the caller through stderr: there is no engine to ask
+        if (!e->err.empty()) fprintf(stderr, "gnnvc_create: %s\n", e->err.c_str());
+        gnnvc_destroy(e);
+        return rc;
+    }
+    *out = e;
+    return GNNVC_OK;
+}
+
+void gnnvc_destroy(gnnvc_engine *e) {
+    if (!e) return;
+    if (e->own_stream) {
+        (void)hipSetDevice(e->device);
+        (void)hipStreamSynchronize(e->own_stream);
+    }
+    e->params.release();
+    e->rowptr.release(); e->col.release(); e->w.release(); e->nw.release();
+    e->x.release(); e->h[0].release(); e->h[1].release();
+    e->scores.release(); e->logits.release();
+    e->scratch[0].release(); e->scratch[1].release();
+    for (auto v : e->ev) (void)hipEventDestroy(v);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    delete e;
+}
+
+int gnnvc_set_weight_scale(gnnvc_engine *e, float ws) {
+    if (!e) return GNNVC_ERR_INVALID;
+    e->ws = ws;
+    return GNNVC_OK;
+}
+
+int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream) {
+    if (!e) return GNNVC_ERR_INVALID;
+    e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+    return GNNVC_OK;
+}
+
+int gnnvc_num_layers(const gnnvc_engine *e) { return e ? (int)e->layers.size() : GNNVC_ERR_INVALID; }
+int gnnvc_is_fused(const gnnvc_engine *e) { return e ? (e->stages.empty() ? 0 : 1) : GNNVC_ERR_INVALID; }
+int gnnvc_in_width(const gnnvc_engine *e) { return e ? e->in_width : GNNVC_ERR_INVALID; }
+int gnnvc_out_width(const gnnvc_engine *e) { return e ? e->out_width : GNNVC_ERR_INVALID; }
+int gnnvc_num_stages(const gnnvc_engine *e) { return e ? (int)e->stages.size() : GNNVC_ERR_INVALID; }
+
+int gnnvc_stage_widths(const gnnvc_engine *e, int stage, int *in_width, int *out_width) {
+    if (!e || stage < 0 || stage >= (int)e->stages.size()) return GNNVC_ERR_INVALID;
+    if (in_width) *in_width = e->stages[stage].f;
+    if (out_width) *out_width = e->stages[stage].n3;
+    return GNNVC_OK;
+}
+
+int gnnvc_upload_graph(gnnvc_engine *e, uint32_t n, const uint64_t *rowptr, const uint32_t *col,
+                       const uint32_t *w, const uint32_t *nw) {
+    if (!e) return GNNVC_ERR_INVALID;
+    if (n && (!rowptr || !w || !nw)) return fail(e, GNNVC_ERR_INVALID, "null graph arrays");
+    int rc = use_device(e);
+    if (rc) return rc;
+    const uint64_t nnz = n ? rowptr[n] : 0;
+    if (nnz >= 0xFFFFFFFFull - GNNVC_COL_PAD)
+        return fail(e, GNNVC_ERR_UNSUPPORTED, "nnz %llu does not fit 32-bit row pointers", (unsigned long long)nnz);
+    if (nnz && !col) return fail(e, GNNVC_ERR_INVALID, "null column array");
+    try {
+        std::vector<uint32_t> rp32((size_t)n + 1, 0);
+        for (uint32_t i = 0; i <= n && n; ++i) {
+            if (i && rowptr[i] < rowptr[i - 1]) return fail(e, GNNVC_ERR_INVALID, "rowptr not monotone at %u", i);
+            rp32[i] = (uint32_t)rowptr[i];
+        }
+        if (n && rowptr[0] != 0) return fail(e, GNNVC_ERR_INVALID, "rowptr[0] must be 0");
+        HIP_TRY(e, e->rowptr.reserve((size_t)n + 1));
+        HIP_TRY(e, e->col.reserve(nnz + GNNVC_COL_PAD));
+        HIP_TRY(e, e->w.reserve(n));
+        HIP_TRY(e, e->nw.reserve(n));
+        // everything below is stream-ordered with earlier forwards on e->stream
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        HIP_TRY(e, hipMemcpy(e->rowptr.p, rp32.data(), rp32.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (nnz) HIP_TRY(e, hipMemcpy(e->col.p, col, nnz * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMemset(e->col.p + nnz, 0, GNNVC_COL_PAD * sizeof(uint32_t)));
+        if (n) {
+            HIP_TRY(e, hipMemcpy(e->w.p, w, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+            HIP_TRY(e, hipMemcpy(e->nw.p, nw, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+    } catch (const std::bad_alloc &) {
+        return fail(e, GNNVC_ERR_NOMEM, "host allocation failed");
+    }
+    e->g = GraphDev{n, nnz, e->rowptr.p, e->col.p, e->w.p, e->nw.p};
+    e->have_graph = true;
+    return reserve_features(e, n);
+}
+
+int gnnvc_attach_graph_device(gnnvc_engine *e, uint32_t n, uint64_t nnz, const uint32_t *d_rowptr,
+                              const uint32_t *d_col, const uint32_t *d_w, const uint32_t *d_nw) {
+    if (!e) return GNNVC_ERR_INVALID;
+    if (n && (!d_rowptr || !d_col || !d_w || !d_nw)) return fail(e, GNNVC_ERR_INVALID, "null device graph arrays");
+    if (nnz >= 0xFFFFFFFFull - GNNVC_COL_PAD) return fail(e, GNNVC_ERR_UNSUPPORTED, "nnz too large");
+    int rc = use_device(e);
+    if (rc) return rc;
+    e->g = GraphDev{n, nnz, d_rowptr, d_col, d_w, d_nw};
+    e->have_graph = true;
+    return reserve_features(e, n);
+}
+
+int gnnvc_stage_forward_device(gnnvc_engine *e, int stage, uint32_t row_lo, uint32_t row_hi,
+                               const float *d_in, float *d_out, float *d_logits) {
+    if (!e) return GNNVC_ERR_INVALID;
+    if (!e->have_graph) return fail(e, GNNVC_ERR_STATE, "no graph attached");
+    if (stage < 0 || stage >= (int)e->stages.size()) return fail(e, GNNVC_ERR_INVALID, "stage %d out of range", stage);
+    if (row_lo > row_hi || row_hi > e->g.n) return fail(e, GNNVC_ERR_INVALID, "row range [%u,%u) outside graph of %u", row_lo, row_hi, e->g.n);
+    if (row_lo == row_hi) return GNNVC_OK;
+    if (!d_in || !d_out) return fail(e, GNNVC_ERR_INVALID, "null feature buffers");
+    int rc = use_device(e);
+    if (rc) return rc;
+    HIP_TRY(e, gnnvc::launch_stage(e->stages[stage], e->g, e->ws, e->params.p, d_in, d_out, d_logits,
+                                   row_lo, row_hi, e->stream));
+    return GNNVC_OK;
+}
+
+int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, float *d_logits) {
+    if (!e) return GNNVC_ERR_INVALID;
+    if (!e->have_graph) return fail(e, GNNVC_ERR_STATE, "no graph attached");
+    const uint32_t n = e->g.n;
+    e->ev_count = 0;
+    if (n == 0) return GNNVC_OK;
+    if (!d_x || !d_scores) return fail(e, GNNVC_ERR_INVALID, "null feature buffers");
+    int rc = use_device(e);
+    if (rc) return rc;
+    if (e->stages.empty()) {
+        rc = ensure_events(e, 2);
+        if (rc) return rc;
+        HIP_TRY(e, hipEventRecord(e->ev[0], e->stream));
+        rc = forward_unfused(e, d_x, d_scores, d_logits);
+        if (rc) return rc;
+        HIP_TRY(e, hipEventRecord(e->ev[1], e->stream));
+        e->ev_count = 2;
+        return GNNVC_OK;
+    }
+    const size_t ns = e->stages.size();
+    rc = ensure_events(e, ns + 1);
+    if (rc) return rc;
+    // pad rows (index n) of the 16-wide feature buffers must read as zero
+    for (auto &b : e->h) HIP_TRY(e, gnnvc::launch_zero_pad_row(b.p, n, 16, e->stream));
+    const float *cur = d_x;
+    HIP_TRY(e, hipEventRecord(e->ev[0], e->stream));
+    for (size_t s = 0; s < ns; ++s) {
+        const bool last = s + 1 == ns;
+        float *dst = last ? d_scores : e->h[s & 1].p;
+        HIP_TRY(e, gnnvc::launch_stage(e->stages[s], e->g, e->ws, e->params.p, cur, dst,
+                                       last ? d_logits : nullptr, 0, n, e->stream));
+        HIP_TRY(e, hipEventRecord(e->ev[s + 1], e->stream));
+        cur = dst;
+    }
+    e->ev_count = (int)ns + 1;
+    return GNNVC_OK;
+}
+
+int gnnvc_forward(gnnvc_engine *e, const float *x, float *scores, float *logits) {
+    if (!e) return GNNVC_ERR_INVALID;
+    if (!e->have_graph) return fail(e, GNNVC_ERR_STATE, "no graph attached");
+    const uint32_t n = e->g.n;
+    if (n == 0) return GNNVC_OK;
+    if (!x || !scores) return fail(e, GNNVC_ERR_INVALID, "null host buffers");
+    int rc = use_device(e);
+    if (rc) return rc;
+    const size_t in_b = (size_t)n * e->in_width * sizeof(float);
+    const size_t out_b = (size_t)n * e->out_width * sizeof(float);
+    HIP_TRY(e, hipMemcpyAsync(e->x.p, x, in_b, hipMemcpyHostToDevice, e->stream));
+    const bool want_logits = logits && e->ends_in_sigmoid;
+    rc = gnnvc_forward_device(e, e->x.p, e->scores.p, want_logits ? e->logits.p : nullptr);
+    if (rc) return rc;
+    HIP_TRY(e, hipMemcpyAsync(scores, e->scores.p, out_b, hipMemcpyDeviceToHost, e->stream));
+    if (want_logits)
+        HIP_TRY(e, hipMemcpyAsync(logits, e->logits.p, out_b, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return GNNVC_OK;
+}
+
+int gnnvc_synchronize(gnnvc_engine *e) {
+    if (!e) return GNNVC_ERR_INVALID;
+    int rc = use_device(e);
+    if (rc) return rc;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return GNNVC_OK;
+}
+
+int gnnvc_last_forward_ms(gnnvc_engine *e, float *total_ms, float *stage_ms, int max_stages) {
+    if (!e) return GNNVC_ERR_INVALID;
+    if (e->ev_count < 2) return fail(e, GNNVC_ERR_STATE, "no timed forward yet");
+    int rc = use_device(e);
+    if (rc) return rc;
+    HIP_TRY(e, hipEventSynchronize(e->ev[e->ev_count - 1]));
+    if (total_ms) HIP_TRY(e, hipEventElapsedTime(total_ms, e->ev[0], e->ev[e->ev_count - 1]));
+    for (int s = 0; stage_ms && s < max_stages && s + 1 < e->ev_count; ++s)
+        HIP_TRY(e, hipEventElapsedTime(&stage_ms[s], e->ev[s], e->ev[s + 1]));
+    return GNNVC_OK;
+}
+
+// ---- layer-level entry points (host pointers in, host pointers out) ------------
+
+static int run_host_op(gnnvc_engine *e, size_t in_count, const float *in, size_t out_count,
+                       float *out, bool out_is_input,
+                       hipError_t (*op)(gnnvc_engine *, const float *, float *, void *), void *ctx) {
+    int rc = use_device(e);
+    if (rc) return rc;
+    HIP_TRY(e, e->scratch[0].reserve(in_count));
+    HIP_TRY(e, e->scratch[1].reserve(out_count));
+    if (in_count)
+        HIP_TRY(e, hipMemcpyAsync(e->scratch[0].p, in, in_count * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    if (out_is_input && out_count)
+        HIP_TRY(e, hipMemcpyAsync(e->scratch[1].p, out, out_count * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, op(e, e->scratch[0].p, e->scratch[1].p, ctx));
+    if (out_count)
+        HIP_TRY(e, hipMemcpyAsync(out, e->scratch[1].p, out_count * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return GNNVC_OK;
+}
+
+int gnnvc_graph_layer_forward(gnnvc_engine *e, uint32_t f, const float *in, float *out) {
+    if (!e) return GNNVC_ERR_INVALID;
+    if (!e->have_graph) return fail(e, GNNVC_ERR_STATE, "no graph attached");
+    if (f == 0) return fail(e, GNNVC_ERR_INVALID, "zero feature width");
+    const uint32_t n = e->g.n;
+    if (n == 0) return GNNVC_OK;
+    if (!in || !out) return fail(e, GNNVC_ERR_INVALID, "null host buffers");
+    struct Ctx { uint32_t f; } ctx{f};
+    return run_host_op(e, (size_t)n * f, in, (size_t)n * (2 * f + 3), out, false,
+                       [](gnnvc_engine *en, const float *di, float *dout, void *c) {
+                           return gnnvc::launch_graph_layer(en->g, en->ws, ((Ctx *)c)->f, di, dout, en->stream);
+                       }, &ctx);
+}
+
+int gnnvc_linear_forward(gnnvc_engine *e, uint32_t n, uint32_t k, uint32_t m, const float *in,
+                         const float *W, const float *bias, float *out) {
+    if (!e) return GNNVC_ERR_INVALID;
+    if ((size_t)n * m == 0) return GNNVC_OK;
+    if (!in || !W || !bias || !out) return fail(e, GNNVC_ERR_INVALID, "null host buffers");
+    int rc = use_device(e);
+    if (rc) return rc;
+    DevBuf<float> dW;
+    HIP_TRY(e, dW.reserve((size_t)k * m + m));
+    rc = GNNVC_OK;
+    hipError_t h1 = hipMemcpy(dW.p, W, (size_t)k * m * sizeof(float), hipMemcpyHostToDevice);
+    hipError_t h2 = hipMemcpy(dW.p + (size_t)k * m, bias, (size_t)m * sizeof(float), hipMemcpyHostToDevice);
+    if (h1 != hipSuccess || h2 != hipSuccess) {
+        dW.release();
+        return fail(e, GNNVC_ERR_DEVICE, "parameter upload failed");
+    }
+    struct Ctx { uint32_t n, k, m; const float *W; } ctx{n, k, m, dW.p};
+    rc = run_host_op(e, (size_t)n * k, in, (size_t)n * m, out, false,
+                     [](gnnvc_engine *en, const float *di, float *dout, void *c) {
+                         auto *x = (Ctx *)c;
+                         return gnnvc::launch_linear(x->n, x->k, x->m, di, x->W, x->W + (size_t)x->k * x->m, dout, en->stream);
+                     }, &ctx);
+    dW.release();
+    return rc;
+}
+
+int gnnvc_relu_forward(gnnvc_engine *e, size_t count, const float *in, float *out) {
+    if (!e) return GNNVC_ERR_INVALID;
+    if (!count) return GNNVC_OK;
+    if (!in || !out) return fail(e, GNNVC_ERR_INVALID, "null host buffers");
+    struct Ctx { size_t n; } ctx{count};
+    return run_host_op(e, count, in, count, out, false,
+                       [](gnnvc_engine *en, const float *di, float *dout, void *c) {
+                           return gnnvc::launch_relu(((Ctx *)c)->n, di, dout, en->stream);
+                       }, &ctx);
+}
+
+int gnnvc_sigmoid_forward(gnnvc_engine *e, size_t count, const float *in, float *out) {
+    if (!e) return GNNVC_ERR_INVALID;
+    if (!count) return GNNVC_OK;
+    if (!in || !out) return fail(e, GNNVC_ERR_INVALID, "null host buffers");
+    struct Ctx { size_t n; } ctx{count};
+    return run_host_op(e, count, in, count, out, false,
+                       [](gnnvc_engine *en, const float *di, float *dout, void *c) {
+                           return gnnvc::launch_sigmoid(((Ctx *)c)->n, di, dout, en->stream);
+                       }, &ctx);
+}
+
+int gnnvc_sgemm(gnnvc_engine *e, int trans_a, int trans_b, uint32_t m, uint32_t n, uint32_t k,
+                const float *A, uint32_t lda, const float *B, uint32_t ldb, float beta, float *C,
+                uint32_t ldc) {
+    if (!e) return GNNVC_ERR_INVALID;
+    if ((size_t)m * n == 0) return GNNVC_OK;
+    if (!C || (k && (!A || !B))) return fail(e, GNNVC_ERR_INVALID, "null host buffers");
+    const size_t a_rows = trans_a ? k : m, b_rows = trans_b ? n : k;
+    const size_t a_cols = trans_a ? m : k, b_cols = trans_b ? k : n;
+    if (lda < a_cols || ldb < b_cols || ldc < n) return fail(e, GNNVC_ERR_INVALID, "leading dimension too small");
+    int rc = use_device(e);
+    if (rc) return rc;
+    DevBuf<float> dB;
+    HIP_TRY(e, dB.reserve(b_rows * ldb + 1));
+    if (b_rows && hipMemcpy(dB.p, B, b_rows * ldb * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        dB.release();
+        return fail(e, GNNVC_ERR_DEVICE, "B upload failed");
+    }
+    struct Ctx { int ta, tb; uint32_t m, n, k, lda, ldb, ldc; float beta; const float *B; } ctx{
+        trans_a, trans_b, m, n, k, lda, ldb, ldc, beta, dB.p};
+    rc = run_host_op(e, a_rows * lda, A, (size_t)m * ldc, C, true,
+                     [](gnnvc_engine *en, const float *dA, float *dC, void *c) {
+                         auto *x = (Ctx *)c;
+                         return gnnvc::launch_sgemm(x->ta, x->tb, x->m, x->n, x->k, dA, x->lda, x->B, x->ldb,
+                                                    x->beta, dC, x->ldc, en->stream);
+                     }, &ctx);
+    dB.release();
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,57 @@
+// gnnvc_kernels.h — launch interface between the engine (host logic) and the
+// gfx950 kernels in gnnvc_kernels.hip.  Internal; the public boundary is
+// include/gnnvc.h.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace gnnvc {
+
+// Device view of what the forward reads from reduction_graph
+// (reference include/reduction_graph.hpp:141-158,693-704).
+struct GraphDev {
+    uint32_t n = 0;
+    uint64_t nnz = 0;
+    const uint32_t *rowptr = nullptr;  // n + 1
+    const uint32_t *col = nullptr;     // nnz + GNNVC_COL_PAD (pad content irrelevant)
+    const uint32_t *w = nullptr;       // n
+    const uint32_t *nw = nullptr;      // n
+};
+
+// One fused stage = graph layer (input width F) followed by up to three dense
+// layers.  Parameter block layout in device memory (floats):
+//   W1[K1 x N1] b1[N1] W2[N1 x N2] b2[N2] W3[N2 x N3] b3[N3],  K1 = 2F + 3.
+struct StagePlan {
+    int f = 0;                // graph-layer input width: 1 or 16
+    int n1 = 0, n2 = 0, n3 = 0;
+    int sigmoid_last = 0;     // last activation is a sigmoid (else ReLU)
+    size_t param_offset = 0;  // float offset of W1 in the engine's parameter buffer
+    int variant = -1;         // index into the compiled instantiations, -1 = none
+};
+
+// Returns the instantiation index for a stage shape, or -1.
+int stage_variant(int f, int n1, int n2, int n3, int sigmoid_last);
+
+// Fused stage over rows [row_lo, row_hi).  in: F=1 -> n floats; F=16 -> (n+1) x 16
+// with a zero last row.  out: (n+1) x n3 rows (n3 = 16) or, for the sigmoid
+// stage, out = scores[n], logits optional.
+hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
+                        const float *in, float *out, float *logits, uint32_t row_lo,
+                        uint32_t row_hi, hipStream_t stream);
+
+// Layer-by-layer kernels (any model; also the layer-level ABI entry points).
+hipError_t launch_graph_layer(const GraphDev &g, float ws, uint32_t f, const float *in,
+                              float *out, hipStream_t stream);
+hipError_t launch_linear(uint32_t n, uint32_t k, uint32_t m, const float *in, const float *W,
+                         const float *bias, float *out, hipStream_t stream);
+hipError_t launch_relu(size_t count, const float *in, float *out, hipStream_t stream);
+hipError_t launch_sigmoid(size_t count, const float *in, float *out, hipStream_t stream);
+hipError_t launch_sgemm(int ta, int tb, uint32_t m, uint32_t n, uint32_t k, const float *A,
+                        uint32_t lda, const float *B, uint32_t ldb, float beta, float *C,
+                        uint32_t ldc, hipStream_t stream);
+
+// u64 host rowptr -> u32 device rowptr happens on the host; this zero-fills
+// the pad row of a feature matrix: rows [n, n+1) of an (n+1) x width buffer.
+hipError_t launch_zero_pad_row(float *buf, uint32_t n, uint32_t width, hipStream_t stream);
+
+}  // namespace gnnvc

@@ -1,0 +1,416 @@
+// gnnvc_kernels.hip — gfx950 (MI355X, CDNA4) kernels of the GNN-VC forward.
+//
+// What is computed follows the reference bit for bit:
+//   graph_layer::forward   reference src/gnn_inference.cpp:27-42
+//   linear_layer::forward  reference src/gnn_inference.cpp:20-25 (+ dot(), src/matrix.cpp:106-122)
+//   ReLU / sigmoid         reference src/gnn_inference.cpp:44-52
+// How it is computed is MI355X-first: one fused kernel per "stage" (graph
+// layer + the dense layers up to the next graph layer), wave64 tiles of 64
+// vertices, a quad of lanes per gathered 64-byte feature row, the activations
+// of a vertex kept in registers across the dense layers, weights fetched
+// through the scalar cache, outputs transposed through LDS so every global
+// store is a full 64-byte row.
+//
+// Compile with -ffp-contract=off: the only fused multiply-adds are the explicit
+// __builtin_fmaf calls; every other add / divide is separately rounded.
+#include <hip/hip_runtime.h>
+
+#include "gnnvc_kernels.h"
+
+namespace gnnvc {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;              // 4 waves, each wave owns one 64-vertex tile
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kPitch = 20;               // LDS row pitch in floats (80 B keeps b128 accesses conflict-free)
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS operations of one wave execute in program order; this only stops the
+    // compiler from moving LDS accesses across the hand-off point.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// std::max(x, 0.0f) of the reference (src/gnn_inference.cpp:46): (x < 0) ? 0 : x.
+__device__ __forceinline__ float relu_ref(float x) { return (x < 0.0f) ? 0.0f : x; }
+
+// 1.0f / (1.0f + expf(-x)) (src/gnn_inference.cpp:51).
+__device__ __forceinline__ float sigmoid_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// out[j] = act( fma-chain_k( in[k] * W[k][j] ) + b[j] ): per output one
+// sequential-k chain from +0.0f (what cblas_sgemm computes at these sizes),
+// then a separately rounded bias add.  W and b are wave-uniform addresses, so
+// they are fetched with scalar loads and feed v_fma as SGPR operands.
+template <int K, int KUSED, int N, int ACT>
+__device__ __forceinline__ void dense(const float (&in)[K], float (&out)[N],
+                                      const float *__restrict__ W, const float *__restrict__ b) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) out[j] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KUSED; ++k) {
+        const float a = in[k];
+#pragma unroll
+        for (int j = 0; j < N; ++j) out[j] = __builtin_fmaf(a, W[k * N + j], out[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const float t = out[j] + b[j];
+        out[j] = (ACT == 0) ? relu_ref(t) : t;
+    }
+}
+
+// XCD-aware tile mapping.  Workgroups are dealt round-robin over the 8 XCDs
+// (block b shares an L2 with block b + 8), so XCD-group x = b % 8 walks the
+// x-th contiguous eighth of the tile range: rows a graph stores close together
+// are gathered through the same L2.
+__device__ __forceinline__ uint32_t tile_for_wave(uint32_t ntiles) {
+    const uint32_t per_xcd = (ntiles + 7u) / 8u;
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t slot = (blockIdx.x >> 3) * kWavesPerBlock + (threadIdx.x >> 6);
+    return (slot < per_xcd) ? xcd * per_xcd + slot : 0xFFFFFFFFu;
+}
+
+// ------------------------------------------------------------------ stage, F = 16
+// Parameters: W1[35 x N1] b1 W2[N1 x N2] b2 W3[N2 x N3] b3.  Input columns of
+// the first dense layer after the reference's column layout (f = 16):
+//   0..15 aggregate, 16 = h[0], 17 = degree, 18 = W/ws, 19 = NW/ws,
+//   20..31 = h[4..15], 32..34 = +0.0 (never written; their k-terms are exact
+//   no-ops in the fma chain and are skipped).
+template <int N1, int N2, int N3, bool SIGMOID, int S>
+__global__ __launch_bounds__(kBlock) void k_stage_f16(
+        GraphDev g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
+        float *__restrict__ logits, const float *__restrict__ P, uint32_t row_lo,
+        uint32_t row_hi) {
+    __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kWave * kPitch];
+    const int lane = threadIdx.x & 63;
+    float *T = lds[threadIdx.x >> 6];
+    const uint32_t ntiles = (row_hi - row_lo + kWave - 1) / kWave;
+    const uint32_t tile = tile_for_wave(ntiles);
+    if (tile >= ntiles) return;
+    const uint32_t v0 = row_lo + tile * kWave;
+
+    // lane-per-vertex view of the tile
+    const uint32_t u = v0 + lane;
+    const bool valid = u < row_hi;
+    const uint32_t uc = valid ? u : row_hi - 1;
+    const uint32_t rs = g.rowptr[uc];
+    const uint32_t re = valid ? g.rowptr[uc + 1] : rs;
+
+    // ---- gather: quad q of lanes owns vertices v0 + 16p + q (p = 0..3) and
+    // sums their neighbour rows in CSR order, lane c holding floats 4c..4c+3.
+    const int q = lane >> 2, c = lane & 3;
+    uint32_t b[4], e[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        b[p] = __shfl(rs, 16 * p + q);
+        e[p] = __shfl(re, 16 * p + q);
+    }
+    float4 acc[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t zrow = g.n;  // all-zero pad row: x + 0.0f == x exactly
+    while ((b[0] < e[0]) | (b[1] < e[1]) | (b[2] < e[2]) | (b[3] < e[3])) {
+        uint32_t idx[4][S];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const uint32_t ee = b[p] + s;
+                const uint32_t cv = g.col[ee];  // col is padded: ee < nnz + S
+                idx[p][s] = (ee < e[p]) ? cv : zrow;
+            }
+        float4 r[4][S];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int s = 0; s < S; ++s) r[p][s] = fin[(size_t)idx[p][s] * 4 + c];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                acc[p].x += r[p][s].x;
+                acc[p].y += r[p][s].y;
+                acc[p].z += r[p][s].z;
+                acc[p].w += r[p][s].w;
+            }
+            const uint32_t nb = b[p] + S;
+            b[p] = nb < e[p] ? nb : e[p];
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        *reinterpret_cast<float4 *>(&T[(16 * p + q) * kPitch + 4 * c]) = acc[p];
+    wave_lds_sync();
+
+    // ---- dense layers: one lane per vertex, activations in registers.
+    float x0[32];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 a = *reinterpret_cast<const float4 *>(&T[lane * kPitch + 4 * i]);
+        x0[4 * i + 0] = a.x; x0[4 * i + 1] = a.y; x0[4 * i + 2] = a.z; x0[4 * i + 3] = a.w;
+    }
+    {
+        const float4 h0 = fin[(size_t)uc * 4 + 0];
+        const float4 h1 = fin[(size_t)uc * 4 + 1];
+        const float4 h2 = fin[(size_t)uc * 4 + 2];
+        const float4 h3 = fin[(size_t)uc * 4 + 3];
+        x0[16] = h0.x;
+        x0[17] = (float)(re - rs);
+        x0[18] = (float)g.w[uc] / ws;
+        x0[19] = (float)g.nw[uc] / ws;
+        x0[20] = h1.x; x0[21] = h1.y; x0[22] = h1.z; x0[23] = h1.w;
+        x0[24] = h2.x; x0[25] = h2.y; x0[26] = h2.z; x0[27] = h2.w;
+        x0[28] = h3.x; x0[29] = h3.y; x0[30] = h3.z; x0[31] = h3.w;
+    }
+    const float *W1 = P, *b1 = W1 + 35 * N1;
+    const float *W2 = b1 + N1, *b2 = W2 + N1 * N2;
+    const float *W3 = b2 + N2, *b3 = W3 + N2 * N3;
+    float x1[N1], x2[N2], x3[N3];
+    dense<32, 32, N1, 0>(x0, x1, W1, b1);
+    dense<N1, N1, N2, 0>(x1, x2, W2, b2);
+    dense<N2, N2, N3, SIGMOID ? 1 : 0>(x2, x3, W3, b3);
+
+    if constexpr (SIGMOID) {
+        static_assert(N3 == 1, "sigmoid stage ends in one output");
+        if (valid) {
+            if (logits) logits[u] = x3[0];
+            fout[u] = sigmoid_ref(x3[0]);
+        }
+    } else {
+        static_assert(N3 == 16, "feature stages emit 16 floats per vertex");
+        // transpose through LDS: every global store instruction writes 16 full rows
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4 *>(&T[lane * kPitch + 4 * i]) =
+                make_float4(x3[4 * i], x3[4 * i + 1], x3[4 * i + 2], x3[4 * i + 3]);
+        wave_lds_sync();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const uint32_t row = v0 + 16 * p + q;
+            const float4 o = *reinterpret_cast<const float4 *>(&T[(16 * p + q) * kPitch + 4 * c]);
+            if (row < row_hi) reinterpret_cast<float4 *>(fout)[(size_t)row * 4 + c] = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ stage, F = 1
+// First dense layer input (f = 1): [aggregate, x, degree, W/ws, NW/ws].
+template <int N1, int N2, int N3, int S>
+__global__ __launch_bounds__(kBlock) void k_stage_f1(
+        GraphDev g, float ws, const float *__restrict__ xin, float *__restrict__ fout,
+        const float *__restrict__ P, uint32_t row_lo, uint32_t row_hi) {
+    __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kWave * kPitch];
+    const int lane = threadIdx.x & 63;
+    float *T = lds[threadIdx.x >> 6];
+    const uint32_t ntiles = (row_hi - row_lo + kWave - 1) / kWave;
+    const uint32_t tile = tile_for_wave(ntiles);
+    if (tile >= ntiles) return;
+    const uint32_t v0 = row_lo + tile * kWave;
+    const uint32_t u = v0 + lane;
+    const bool valid = u < row_hi;
+    const uint32_t uc = valid ? u : row_hi - 1;
+    const uint32_t rs = g.rowptr[uc];
+    const uint32_t re = valid ? g.rowptr[uc + 1] : rs;
+
+    float agg = 0.0f;
+    for (uint32_t eb = rs; eb < re; eb += S) {
+        float xs[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const uint32_t ee = eb + s;
+            const uint32_t cv = g.col[ee];  // padded
+            const float v = xin[(ee < re) ? cv : uc];
+            xs[s] = (ee < re) ? v : 0.0f;  // agg is never -0.0f, so + 0.0f is exact
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) agg += xs[s];
+    }
+    float x0[5];
+    x0[0] = agg;
+    x0[1] = xin[uc];
+    x0[2] = (float)(re - rs);
+    x0[3] = (float)g.w[uc] / ws;
+    x0[4] = (float)g.nw[uc] / ws;
+    const float *W1 = P, *b1 = W1 + 5 * N1;
+    const float *W2 = b1 + N1, *b2 = W2 + N1 * N2;
+    const float *W3 = b2 + N2, *b3 = W3 + N2 * N3;
+    float x1[N1], x2[N2], x3[N3];
+    dense<5, 5, N1, 0>(x0, x1, W1, b1);
+    dense<N1, N1, N2, 0>(x1, x2, W2, b2);
+    dense<N2, N2, N3, 0>(x2, x3, W3, b3);
+    static_assert(N3 == 16, "feature stages emit 16 floats per vertex");
+    const int q = lane >> 2, c = lane & 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<float4 *>(&T[lane * kPitch + 4 * i]) =
+            make_float4(x3[4 * i], x3[4 * i + 1], x3[4 * i + 2], x3[4 * i + 3]);
+    wave_lds_sync();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const uint32_t row = v0 + 16 * p + q;
+        const float4 o = *reinterpret_cast<const float4 *>(&T[(16 * p + q) * kPitch + 4 * c]);
+        if (row < row_hi) reinterpret_cast<float4 *>(fout)[(size_t)row * 4 + c] = o;
+    }
+}
+
+// ------------------------------------------------------------------ layer-by-layer kernels
+// One thread per output element; exact, simple, used for models that do not
+// match a fused plan and for the layer-level ABI.
+__global__ void k_graph_layer(GraphDev g, float ws, uint32_t f, const float *__restrict__ in,
+                              float *__restrict__ out) {
+    const uint32_t wd = 2 * f + 3;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)g.n * wd) return;
+    const uint32_t u = (uint32_t)(gid / wd), j = (uint32_t)(gid % wd);
+    const uint32_t rs = g.rowptr[u], re = g.rowptr[u + 1];
+    float v = 0.0f;
+    if (j < f) {
+        for (uint32_t e = rs; e < re; ++e) v = v + in[(size_t)g.col[e] * f + j];
+    } else if (j < 2 * f) {
+        v = in[(size_t)u * f + (j - f)];
+    }
+    // written last in the reference, so they win over the copied columns
+    if (j == f + 1) v = (float)(re - rs);
+    if (j == f + 2) v = (float)g.w[u] / ws;
+    if (j == f + 3) v = (float)g.nw[u] / ws;
+    out[gid] = v;
+}
+
+__global__ void k_linear(uint32_t n, uint32_t k, uint32_t m, const float *__restrict__ in,
+                         const float *__restrict__ W, const float *__restrict__ bias,
+                         float *__restrict__ out) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)n * m) return;
+    const uint32_t i = (uint32_t)(gid / m), j = (uint32_t)(gid % m);
+    float acc = 0.0f;
+    for (uint32_t kk = 0; kk < k; ++kk)
+        acc = __builtin_fmaf(in[(size_t)i * k + kk], W[(size_t)kk * m + j], acc);
+    out[gid] = acc + bias[j];
+}
+
+__global__ void k_relu(size_t count, const float *__restrict__ in, float *__restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (size_t)gridDim.x * blockDim.x)
+        out[i] = relu_ref(in[i]);
+}
+
+__global__ void k_sigmoid(size_t count, const float *__restrict__ in, float *__restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (size_t)gridDim.x * blockDim.x)
+        out[i] = sigmoid_ref(in[i]);
+}
+
+__global__ void k_sgemm(int ta, int tb, uint32_t m, uint32_t n, uint32_t k,
+                        const float *__restrict__ A, uint32_t lda, const float *__restrict__ B,
+                        uint32_t ldb, float beta, float *__restrict__ C, uint32_t ldc) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)m * n) return;
+    const uint32_t i = (uint32_t)(gid / n), j = (uint32_t)(gid % n);
+    float acc = 0.0f;
+    for (uint32_t kk = 0; kk < k; ++kk) {
+        const float a = ta ? A[(size_t)kk * lda + i] : A[(size_t)i * lda + kk];
+        const float b = tb ? B[(size_t)j * ldb + kk] : B[(size_t)kk * ldb + j];
+        acc = __builtin_fmaf(a, b, acc);
+    }
+    float *c = &C[(size_t)i * ldc + j];
+    *c = (beta == 0.0f) ? acc : __builtin_fmaf(beta, *c, acc);
+}
+
+__global__ void k_zero_row(float *buf, uint32_t n, uint32_t width) {
+    if (threadIdx.x < width) buf[(size_t)n * width + threadIdx.x] = 0.0f;
+}
+
+inline unsigned blocks_for(size_t work, unsigned block) {
+    return (unsigned)((work + block - 1) / block);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------- launchers
+
+int stage_variant(int f, int n1, int n2, int n3, int sigmoid_last) {
+    if (f == 1 && n1 == 32 && n2 == 32 && n3 == 16 && !sigmoid_last) return 0;
+    if (f == 16 && n1 == 32 && n2 == 32 && n3 == 16 && !sigmoid_last) return 1;
+    if (f == 16 && n1 == 32 && n2 == 16 && n3 == 1 && sigmoid_last) return 2;
+    return -1;
+}
+
+hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
+                        const float *in, float *out, float *logits, uint32_t row_lo,
+                        uint32_t row_hi, hipStream_t stream) {
+    if (row_hi <= row_lo) return hipSuccess;
+    const uint32_t ntiles = (row_hi - row_lo + kWave - 1) / kWave;
+    const uint32_t per_xcd = (ntiles + 7) / 8;
+    const uint32_t blocks_per_xcd = (per_xcd + kWavesPerBlock - 1) / kWavesPerBlock;
+    const dim3 grid(blocks_per_xcd * 8), block(kBlock);
+    const float *P = params + sp.param_offset;
+    switch (sp.variant) {
+    case 0:
+        hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4>), grid, block, 0, stream, g, ws, in, out, P,
+                           row_lo, row_hi);
+        break;
+    case 1:
+        hipLaunchKernelGGL((k_stage_f16<32, 32, 16, false, 2>), grid, block, 0, stream, g, ws,
+                           reinterpret_cast<const float4 *>(in), out, nullptr, P, row_lo, row_hi);
+        break;
+    case 2:
+        hipLaunchKernelGGL((k_stage_f16<32, 16, 1, true, 2>), grid, block, 0, stream, g, ws,
+                           reinterpret_cast<const float4 *>(in), out, logits, P, row_lo, row_hi);
+        break;
+    default:
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_graph_layer(const GraphDev &g, float ws, uint32_t f, const float *in,
+                              float *out, hipStream_t stream) {
+    const size_t work = (size_t)g.n * (2 * f + 3);
+    if (!work) return hipSuccess;
+    hipLaunchKernelGGL(k_graph_layer, dim3(blocks_for(work, 256)), dim3(256), 0, stream, g, ws, f,
+                       in, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_linear(uint32_t n, uint32_t k, uint32_t m, const float *in, const float *W,
+                         const float *bias, float *out, hipStream_t stream) {
+    const size_t work = (size_t)n * m;
+    if (!work) return hipSuccess;
+    hipLaunchKernelGGL(k_linear, dim3(blocks_for(work, 256)), dim3(256), 0, stream, n, k, m, in,
+                       W, bias, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_relu(size_t count, const float *in, float *out, hipStream_t stream) {
+    if (!count) return hipSuccess;
+    const unsigned nb = (unsigned)((count + 255) / 256 < 8192 ? (count + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_relu, dim3(nb), dim3(256), 0, stream, count, in, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_sigmoid(size_t count, const float *in, float *out, hipStream_t stream) {
+    if (!count) return hipSuccess;
+    const unsigned nb = (unsigned)((count + 255) / 256 < 8192 ? (count + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_sigmoid, dim3(nb), dim3(256), 0, stream, count, in, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_sgemm(int ta, int tb, uint32_t m, uint32_t n, uint32_t k, const float *A,
+                        uint32_t lda, const float *B, uint32_t ldb, float beta, float *C,
+                        uint32_t ldc, hipStream_t stream) {
+    const size_t work = (size_t)m * n;
+    if (!work) return hipSuccess;
+    hipLaunchKernelGGL(k_sgemm, dim3(blocks_for(work, 256)), dim3(256), 0, stream, ta, tb, m, n, k,
+                       A, lda, B, ldb, beta, C, ldc);
+    return hipGetLastError();
+}
+
+hipError_t launch_zero_pad_row(float *buf, uint32_t n, uint32_t width, hipStream_t stream) {
+    hipLaunchKernelGGL(k_zero_row, dim3(1), dim3(64), 0, stream, buf, n, width);
+    return hipGetLastError();
+}
+
+}  // namespace gnnvc

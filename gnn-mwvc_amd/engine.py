@@ -1,0 +1,256 @@
+"""ctypes binding of libgnnvc_hip.so — the C ABI declared in include/gnnvc.h.
+
+Python here is plumbing for tests and the bench; the product is the shared
+library.  There is no CPU fallback: if the library is missing or no HIP device
+is present, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import pathlib
+import subprocess
+
+import numpy as np
+
+_PKG = pathlib.Path(__file__).resolve().parent
+_LIB = _PKG / "libgnnvc_hip.so"
+
+# every symbol include/gnnvc.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "gnnvc_abi_version", "gnnvc_strerror", "gnnvc_last_error", "gnnvc_create", "gnnvc_destroy",
+    "gnnvc_set_weight_scale", "gnnvc_set_stream", "gnnvc_num_layers", "gnnvc_is_fused",
+    "gnnvc_in_width", "gnnvc_out_width", "gnnvc_upload_graph", "gnnvc_attach_graph_device",
+    "gnnvc_forward", "gnnvc_forward_device", "gnnvc_num_stages", "gnnvc_stage_widths",
+    "gnnvc_stage_forward_device", "gnnvc_synchronize", "gnnvc_last_forward_ms",
+    "gnnvc_graph_layer_forward", "gnnvc_linear_forward", "gnnvc_relu_forward",
+    "gnnvc_sigmoid_forward", "gnnvc_sgemm",
+]
+COL_PAD = 64
+
+
+class GnnvcError(RuntimeError):
+    def __init__(self, code: int, detail: str = ""):
+        self.code = code
+        super().__init__(f"gnnvc error {code}: {detail}")
+
+
+def library_path() -> pathlib.Path:
+    return _LIB
+
+
+def build_library(force: bool = False) -> pathlib.Path:
+    """hipcc --offload-arch=gfx950 build of csrc/ (cross-compiles without a GPU)."""
+    srcs = [_PKG / "csrc" / n for n in ("gnnvc_kernels.hip", "gnnvc_engine.cpp", "gnnvc_kernels.h")]
+    srcs.append(_PKG.parent / "include" / "gnnvc.h")
+    stale = (not _LIB.exists()) or any(s.stat().st_mtime > _LIB.stat().st_mtime for s in srcs)
+    if force or stale:
+        r = subprocess.run(["make", "-C", str(_PKG / "csrc")], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("building libgnnvc_hip.so failed:\n" + r.stdout + r.stderr)
+    return _LIB
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB.exists():
+        raise FileNotFoundError(f"{_LIB} not built: run `make -C {_PKG / 'csrc'}` "
+                                "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(str(_LIB))
+    vp, u32, u64, f32p = C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p
+    L.gnnvc_abi_version.restype = C.c_int
+    L.gnnvc_strerror.restype = C.c_char_p
+    L.gnnvc_strerror.argtypes = [C.c_int]
+    L.gnnvc_last_error.restype = C.c_char_p
+    L.gnnvc_last_error.argtypes = [vp]
+    L.gnnvc_create.argtypes = [C.POINTER(vp), C.c_char_p, C.c_size_t, C.c_int]
+    L.gnnvc_destroy.argtypes = [vp]
+    L.gnnvc_destroy.restype = None
+    L.gnnvc_set_weight_scale.argtypes = [vp, C.c_float]
+    L.gnnvc_set_stream.argtypes = [vp, vp]
+    for name in ("gnnvc_num_layers", "gnnvc_is_fused", "gnnvc_in_width", "gnnvc_out_width",
+                 "gnnvc_num_stages", "gnnvc_synchronize"):
+        getattr(L, name).argtypes = [vp]
+    L.gnnvc_stage_widths.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.gnnvc_upload_graph.argtypes = [vp, u32, vp, vp, vp, vp]
+    L.gnnvc_attach_graph_device.argtypes = [vp, u32, u64, vp, vp, vp, vp]
+    L.gnnvc_forward.argtypes = [vp, f32p, f32p, f32p]
+    L.gnnvc_forward_device.argtypes = [vp, f32p, f32p, f32p]
+    L.gnnvc_stage_forward_device.argtypes = [vp, C.c_int, u32, u32, f32p, f32p, f32p]
+    L.gnnvc_last_forward_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
+    L.gnnvc_graph_layer_forward.argtypes = [vp, u32, f32p, f32p]
+    L.gnnvc_linear_forward.argtypes = [vp, u32, u32, u32, f32p, f32p, f32p, f32p]
+    L.gnnvc_relu_forward.argtypes = [vp, C.c_size_t, f32p, f32p]
+    L.gnnvc_sigmoid_forward.argtypes = [vp, C.c_size_t, f32p, f32p]
+    L.gnnvc_sgemm.argtypes = [vp, C.c_int, C.c_int, u32, u32, u32, f32p, u32, f32p, u32, C.c_float,
+                              f32p, u32]
+    for name in ABI_SYMBOLS:
+        if name not in ("gnnvc_strerror", "gnnvc_last_error", "gnnvc_destroy"):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def default_model_text() -> str:
+    return (_PKG / "data" / "mwvc_model.txt").read_text()
+
+
+def _np_ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One engine = one model on one GPU (mirrors `gnn::model`)."""
+
+    def __init__(self, model_text: str | None = None, device: int = 0):
+        self._L = load_library()
+        self._h = C.c_void_p()
+        raw = (model_text if model_text is not None else default_model_text()).encode()
+        rc = self._L.gnnvc_create(C.byref(self._h), raw, len(raw), device)
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise GnnvcError(rc, self._L.gnnvc_strerror(rc).decode())
+        self.n = 0
+        self._keep = None
+
+    # -- plumbing
+    def _check(self, rc: int):
+        if rc != 0:
+            raise GnnvcError(rc, self._L.gnnvc_last_error(self._h).decode()
+                             or self._L.gnnvc_strerror(rc).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.gnnvc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- model
+    @property
+    def num_layers(self) -> int:
+        return self._L.gnnvc_num_layers(self._h)
+
+    @property
+    def fused(self) -> bool:
+        return bool(self._L.gnnvc_is_fused(self._h))
+
+    @property
+    def in_width(self) -> int:
+        return self._L.gnnvc_in_width(self._h)
+
+    @property
+    def out_width(self) -> int:
+        return self._L.gnnvc_out_width(self._h)
+
+    @property
+    def num_stages(self) -> int:
+        return self._L.gnnvc_num_stages(self._h)
+
+    def stage_widths(self, stage: int):
+        a, b = C.c_int(), C.c_int()
+        self._check(self._L.gnnvc_stage_widths(self._h, stage, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def set_weight_scale(self, ws: float):
+        self._check(self._L.gnnvc_set_weight_scale(self._h, C.c_float(ws)))
+
+    def set_stream(self, hip_stream: int | None):
+        self._check(self._L.gnnvc_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    # -- graph
+    def upload_graph(self, g):
+        """g: tools.graphgen.CsrGraph-like (n, rowptr u64, col u32, w u32, nw u32), host arrays."""
+        rowptr = np.ascontiguousarray(g.rowptr, dtype=np.uint64)
+        col = np.ascontiguousarray(g.col, dtype=np.uint32)
+        w = np.ascontiguousarray(g.w, dtype=np.uint32)
+        nw = np.ascontiguousarray(g.nw, dtype=np.uint32)
+        self._check(self._L.gnnvc_upload_graph(self._h, g.n, _np_ptr(rowptr), _np_ptr(col),
+                                               _np_ptr(w), _np_ptr(nw)))
+        self.n = g.n
+
+    def attach_graph_device(self, n: int, nnz: int, rowptr_ptr: int, col_ptr: int, w_ptr: int,
+                            nw_ptr: int, keepalive=None):
+        self._check(self._L.gnnvc_attach_graph_device(self._h, n, nnz, rowptr_ptr, col_ptr, w_ptr,
+                                                      nw_ptr))
+        self.n = n
+        self._keep = keepalive
+
+    # -- forward
+    def forward(self, x: np.ndarray, want_logits: bool = True):
+        """Host forward: returns (scores[n, out_width], logits or None)."""
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(self.n, self.in_width)
+        scores = np.empty((self.n, self.out_width), dtype=np.float32)
+        logits = np.empty((self.n, self.out_width), dtype=np.float32) if want_logits else None
+        self._check(self._L.gnnvc_forward(self._h, _np_ptr(x), _np_ptr(scores),
+                                          _np_ptr(logits) if want_logits else None))
+        return scores, logits
+
+    def forward_device(self, x_ptr: int, scores_ptr: int, logits_ptr: int = 0):
+        self._check(self._L.gnnvc_forward_device(self._h, x_ptr, scores_ptr, logits_ptr or None))
+
+    def stage_forward_device(self, stage: int, row_lo: int, row_hi: int, in_ptr: int, out_ptr: int,
+                             logits_ptr: int = 0):
+        self._check(self._L.gnnvc_stage_forward_device(self._h, stage, row_lo, row_hi, in_ptr,
+                                                       out_ptr, logits_ptr or None))
+
+    def synchronize(self):
+        self._check(self._L.gnnvc_synchronize(self._h))
+
+    def last_forward_ms(self):
+        total = C.c_float()
+        stages = (C.c_float * 8)()
+        self._check(self._L.gnnvc_last_forward_ms(self._h, C.byref(total), stages, 8))
+        ns = max(self.num_stages, 1)
+        return total.value, [stages[i] for i in range(ns)]
+
+    # -- layer-level entry points
+    def graph_layer(self, h: np.ndarray) -> np.ndarray:
+        h = np.ascontiguousarray(h, dtype=np.float32).reshape(self.n, -1)
+        f = h.shape[1]
+        out = np.empty((self.n, 2 * f + 3), dtype=np.float32)
+        self._check(self._L.gnnvc_graph_layer_forward(self._h, f, _np_ptr(h), _np_ptr(out)))
+        return out
+
+    def linear(self, h: np.ndarray, W: np.ndarray, bias: np.ndarray) -> np.ndarray:
+        h = np.ascontiguousarray(h, dtype=np.float32)
+        W = np.ascontiguousarray(W, dtype=np.float32)
+        bias = np.ascontiguousarray(bias, dtype=np.float32)
+        out = np.empty((h.shape[0], W.shape[1]), dtype=np.float32)
+        self._check(self._L.gnnvc_linear_forward(self._h, h.shape[0], W.shape[0], W.shape[1],
+                                                 _np_ptr(h), _np_ptr(W), _np_ptr(bias), _np_ptr(out)))
+        return out
+
+    def relu(self, h: np.ndarray) -> np.ndarray:
+        h = np.ascontiguousarray(h, dtype=np.float32)
+        out = np.empty_like(h)
+        self._check(self._L.gnnvc_relu_forward(self._h, h.size, _np_ptr(h), _np_ptr(out)))
+        return out
+
+    def sigmoid(self, h: np.ndarray) -> np.ndarray:
+        h = np.ascontiguousarray(h, dtype=np.float32)
+        out = np.empty_like(h)
+        self._check(self._L.gnnvc_sigmoid_forward(self._h, h.size, _np_ptr(h), _np_ptr(out)))
+        return out
+
+    def sgemm(self, A: np.ndarray, B: np.ndarray, C_in: np.ndarray | None = None, beta: float = 0.0,
+              trans_a: bool = False, trans_b: bool = False) -> np.ndarray:
+        A = np.ascontiguousarray(A, dtype=np.float32)
+        B = np.ascontiguousarray(B, dtype=np.float32)
+        m = A.shape[1] if trans_a else A.shape[0]
+        k = A.shape[0] if trans_a else A.shape[1]
+        n = B.shape[0] if trans_b else B.shape[1]
+        out = (np.zeros((m, n), dtype=np.float32) if C_in is None
+               else np.ascontiguousarray(C_in, dtype=np.float32).copy())
+        self._check(self._L.gnnvc_sgemm(self._h, int(trans_a), int(trans_b), m, n, k, _np_ptr(A),
+                                        A.shape[1], _np_ptr(B), B.shape[1], C.c_float(beta),
+                                        _np_ptr(out), n))
+        return out

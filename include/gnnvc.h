@@ -1,0 +1,157 @@
+/*
+ * gnnvc.h — C ABI of the MI355X GNN-VC scoring engine (libgnnvc_hip.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of KennethLangedal/GNN-MWVC:
+ * the GNN forward `gnn::model::predict` and the layer `forward()`s it runs
+ * (reference src/gnn_inference.cpp:20-81, include/gnn_inference.hpp:11-59) plus
+ * the OpenBLAS seam `dot()` (reference src/matrix.cpp:106-122).  Plain
+ * pointers and sizes only; no C++ or torch types.  Every entry point returns
+ * GNNVC_OK (0) or a negative error code, never throws, and treats N = 0 as a
+ * successful no-op (the reference calls predict with an empty graph at the end
+ * of every run, src/GNN_VC.cpp:192 / SURVEY.md §3.2).
+ *
+ * There is no CPU fallback behind this ABI: without a HIP device every compute
+ * entry point returns GNNVC_ERR_DEVICE.
+ *
+ * Numerics contract: logits — the input of the final sigmoid —
+ * are bit-identical to the reference's on the same inputs (CSR-order fp32
+ * neighbour sums, sequential-k fused-multiply-add chains, separately rounded
+ * bias adds).  Device-side scores apply 1/(1+exp(-x)) with a device exp that is
+ * a restatement of glibc's expf; hosts that need the reference's exact scores
+ * apply their own libm to the logits (the C++ wrapper does).
+ *
+ * The reference-side binding a maintainer would add is shown in INTEGRATION.md.
+ */
+#ifndef GNNVC_H
+#define GNNVC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNNVC_ABI_VERSION 1
+
+enum {
+    GNNVC_OK = 0,
+    GNNVC_ERR_INVALID = -1,     /* bad argument / malformed model text */
+    GNNVC_ERR_DEVICE = -2,      /* no HIP device, or a HIP call failed */
+    GNNVC_ERR_NOMEM = -3,       /* host or device allocation failed */
+    GNNVC_ERR_STATE = -4,       /* call out of order (e.g. forward before a graph) */
+    GNNVC_ERR_UNSUPPORTED = -5  /* model / size outside what the engine handles */
+};
+
+typedef struct gnnvc_engine gnnvc_engine;
+
+int gnnvc_abi_version(void);
+const char *gnnvc_strerror(int code);
+/* Detail of the last failure on this engine (empty string if none). */
+const char *gnnvc_last_error(const gnnvc_engine *e);
+
+/* ---- model ----------------------------------------------------------------
+ * gnnvc_create replaces `istream >> gnn::model` (reference
+ * src/gnn_inference.cpp:120-139 + src/matrix.cpp:97-104): `model_text` is the
+ * reference's text format (`<name> <n> Layers`, then Linear_Layer / Graph_Layer /
+ * ReLU_Activation / Sigmoid_Activation records).  `device` is the HIP device
+ * ordinal.  The parameters are uploaded once. */
+int gnnvc_create(gnnvc_engine **out, const char *model_text, size_t len, int device);
+void gnnvc_destroy(gnnvc_engine *e);
+
+/* model::set_weight_scale (reference src/gnn_inference.cpp:83-90): sets
+ * graph_layer::WEIGHT_SCALE of every graph layer (default 120). */
+int gnnvc_set_weight_scale(gnnvc_engine *e, float ws);
+
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of
+ * the engine's own stream.  NULL restores the engine's stream. */
+int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
+
+/* Model introspection (what model::layers holds). */
+int gnnvc_num_layers(const gnnvc_engine *e);
+/* 1 if the model matches the fused 3-stage plan, 0 if it runs layer by layer. */
+int gnnvc_is_fused(const gnnvc_engine *e);
+/* Width of the forward's input / output rows. */
+int gnnvc_in_width(const gnnvc_engine *e);
+int gnnvc_out_width(const gnnvc_engine *e);
+
+/* ---- graph hand-off ---------------------------------------------------------
+ * What the forward reads from reduction_graph<uint32_t,uint32_t> (reference
+ * include/reduction_graph.hpp: size() :141, begin(u)/end(u) :693-704, D :144,
+ * W :147-151, NW :154-158): vertices 0..n-1, adj(u) = col[rowptr[u]..rowptr[u+1])
+ * in the graph's stored order (that order is the fp32 summation order), the
+ * vertex weights and the neighbourhood weights.  Host pointers; copied to the
+ * device.  nnz = rowptr[n] must be < 2^32. */
+int gnnvc_upload_graph(gnnvc_engine *e, uint32_t n, const uint64_t *rowptr,
+                       const uint32_t *col, const uint32_t *w, const uint32_t *nw);
+
+/* Zero-copy variant for callers whose CSR already lives in device memory
+ * (multi-GPU shards, device-side generators): d_rowptr is uint32[n+1], d_col is
+ * uint32[nnz + GNNVC_COL_PAD] (the pad entries may hold anything), d_w / d_nw are
+ * uint32[n].  The caller keeps them alive until the next attach/upload/destroy. */
+#define GNNVC_COL_PAD 64
+int gnnvc_attach_graph_device(gnnvc_engine *e, uint32_t n, uint64_t nnz,
+                              const uint32_t *d_rowptr, const uint32_t *d_col,
+                              const uint32_t *d_w, const uint32_t *d_nw);
+
+/* ---- forward ----------------------------------------------------------------
+ * gnnvc_forward replaces model::predict (reference src/gnn_inference.cpp:67-81)
+ * for host callers: x is n x in_width (n x 1 for the shipped model:
+ * x[u] = (float)W(u)/ws, reference src/GNN_VC.cpp:189-191), scores is
+ * n x out_width.  `logits` (optional, may be NULL) receives the input of the
+ * final sigmoid when the model ends in one. */
+int gnnvc_forward(gnnvc_engine *e, const float *x, float *scores, float *logits);
+
+/* Device-resident forward: all pointers are device memory; asynchronous on
+ * the engine's stream.  d_logits may be NULL. */
+int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, float *d_logits);
+
+/* One fused stage (graph layer + the dense layers up to the next graph
+ * layer) over the vertex range [row_lo, row_hi) — the unit a 1-D
+ * vertex-partitioned multi-GPU run executes between feature exchanges.
+ * d_in is the full (n + 1) x in_width feature matrix whose LAST row is all
+ * zeros (the gather reads it for masked lanes); d_out is the full
+ * (n + 1) x out_width matrix of which only rows [row_lo, row_hi) are written.
+ * d_logits (stage with a final sigmoid only, may be NULL) likewise.
+ * Asynchronous on the engine's stream. */
+int gnnvc_num_stages(const gnnvc_engine *e);
+int gnnvc_stage_widths(const gnnvc_engine *e, int stage, int *in_width, int *out_width);
+int gnnvc_stage_forward_device(gnnvc_engine *e, int stage, uint32_t row_lo, uint32_t row_hi,
+                               const float *d_in, float *d_out, float *d_logits);
+
+/* Wait for everything queued on the engine's stream. */
+int gnnvc_synchronize(gnnvc_engine *e);
+
+/* hipEvent timings of the last gnnvc_forward / gnnvc_forward_device on the
+ * engine's stream: total and per stage, in milliseconds (waits for them). */
+int gnnvc_last_forward_ms(gnnvc_engine *e, float *total_ms, float *stage_ms, int max_stages);
+
+/* ---- layer-level entry points (host pointers) ------------------------------
+ * One call per reference layer forward(); used by the C++ mirror of the
+ * reference's layer structs and by the per-layer parity tests. */
+
+/* graph_layer::forward (reference src/gnn_inference.cpp:27-42) on the graph
+ * currently uploaded: in is n x f, out is n x (2f+3), ws as set. */
+int gnnvc_graph_layer_forward(gnnvc_engine *e, uint32_t f, const float *in, float *out);
+
+/* linear_layer::forward (reference src/gnn_inference.cpp:20-25): out = in*W + bias,
+ * in n x k, W k x m row-major, bias m. */
+int gnnvc_linear_forward(gnnvc_engine *e, uint32_t n, uint32_t k, uint32_t m,
+                         const float *in, const float *W, const float *bias, float *out);
+
+/* ReLU::forward / sigmoid::forward (reference src/gnn_inference.cpp:44-52). */
+int gnnvc_relu_forward(gnnvc_engine *e, size_t count, const float *in, float *out);
+int gnnvc_sigmoid_forward(gnnvc_engine *e, size_t count, const float *in, float *out);
+
+/* dot() (reference src/matrix.cpp:106-122, the cblas_sgemm seam):
+ * C = op(A) * op(B) + beta * C, row-major, op = transpose when the flag is set;
+ * m, n, k are the dimensions AFTER op.  Each output is one sequential-k fmaf
+ * chain from +0.0f; with beta != 0 the old C is then added as fma(beta, C, acc). */
+int gnnvc_sgemm(gnnvc_engine *e, int trans_a, int trans_b, uint32_t m, uint32_t n, uint32_t k,
+                const float *A, uint32_t lda, const float *B, uint32_t ldb, float beta,
+                float *C, uint32_t ldc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNNVC_H */
