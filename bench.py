@@ -94,7 +94,11 @@ def main() -> int:
     eng.set_weight_scale(g.ws)
     eng.attach_graph_device(g.n, g.nnz, g.rowptr.data_ptr(), g.col.data_ptr(), g.w.data_ptr(),
                             g.nw.data_ptr(), keepalive=g)
-    stream = torch.cuda.current_stream()
+    # a dedicated HIP stream shared by torch (events, collectives) and the engine;
+    # torch's default stream has the NULL handle, which the ABI reads as "engine's own"
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     eng.set_stream(stream.cuda_stream)
 
     x = g.x().contiguous()

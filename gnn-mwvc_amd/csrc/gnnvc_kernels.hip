@@ -15,6 +15,7 @@
 // __builtin_fmaf calls; every other add / divide is separately rounded.
 #include <hip/hip_runtime.h>
 
+#include "expf_glibc.h"
 #include "gnnvc_kernels.h"
 
 namespace gnnvc {
@@ -36,8 +37,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 // std::max(x, 0.0f) of the reference (src/gnn_inference.cpp:46): (x < 0) ? 0 : x.
 __device__ __forceinline__ float relu_ref(float x) { return (x < 0.0f) ? 0.0f : x; }
 
-// 1.0f / (1.0f + expf(-x)) (src/gnn_inference.cpp:51).
-__device__ __forceinline__ float sigmoid_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
+// 1.0f / (1.0f + expf(-x)) (src/gnn_inference.cpp:51) with glibc's expf restated
+// in fp64 (expf_glibc.h): same bits as the host libm the reference links.
+__device__ __forceinline__ float sigmoid_ref(float x) { return 1.0f / (1.0f + expf_glibc(-x)); }
 
 // out[j] = act( fma-chain_k( in[k] * W[k][j] ) + b[j] ): per output one
 // sequential-k chain from +0.0f (what cblas_sgemm computes at these sizes),

@@ -156,13 +156,15 @@ def test_stage_api_row_ranges(engine, oracle_model):
     sc = torch.zeros(g.n, dtype=torch.float32, device=dev)
     lg = torch.zeros(g.n, dtype=torch.float32, device=dev)
     cuts = [0, 1, 64, 1000, 1777, g.n]
-    engine.set_stream(torch.cuda.current_stream().cuda_stream)
+    side = torch.cuda.Stream(device=dev)   # a caller-owned stream (NULL would mean the engine's own)
+    side.wait_stream(torch.cuda.current_stream())
+    engine.set_stream(side.cuda_stream)
     try:
         for st, (src, dst) in enumerate(((x, h1), (h1, h2), (h2, sc))):
             for lo, hi in zip(cuts[:-1], cuts[1:]):
                 engine.stage_forward_device(st, lo, hi, src.data_ptr(), dst.data_ptr(),
                                             lg.data_ptr() if st == 2 else 0)
-        torch.cuda.synchronize()
+        side.synchronize()
     finally:
         engine.set_stream(None)
     want_h1 = oracle_model.predict(g, g.x(), stop_after=6)
