@@ -57,6 +57,13 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: torch bundles its own libamdhip64; importing torch first
+    # makes this library bind to the runtime torch uses (loading ours first leaves torch
+    # without a usable device).  Python callers here always sit next to torch.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not _LIB.exists():
         raise FileNotFoundError(f"{_LIB} not built: run `make -C {_PKG / 'csrc'}` "
                                 "(or __graft_entry__.build()); there is no CPU fallback")

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""PMC probe: the metric graph, one calibration copy of known size, a few forwards.
+Run under `rocprofv3 --pmc ... --output-format csv -d <dir> -- python3 tools/pmc_probe.py`
+(counters in their own run, never together with a trace domain).  The calibration
+kernel reads and writes exactly CALIB_BYTES so the FETCH_SIZE / WRITE_SIZE scale on
+gfx950 can be checked against a known byte count in the same run."""
+import argparse
+import pathlib
+import sys
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+CALIB_BYTES = 1 << 30
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--m", type=int, default=100_000_000)
+    ap.add_argument("--forwards", type=int, default=2)
+    a = ap.parse_args()
+    import torch
+    import gnn_mwvc_amd as G
+    from tools import graphgen_torch as ggt
+    dev = torch.device("cuda", 0)
+    g = ggt.erdos_renyi(a.n, a.m, 10, dev)
+    eng = G.Engine(G.default_model_text(), device=0)
+    eng.set_weight_scale(g.ws)
+    eng.attach_graph_device(g.n, g.nnz, g.rowptr.data_ptr(), g.col.data_ptr(), g.w.data_ptr(),
+                            g.nw.data_ptr(), keepalive=g)
+    x = g.x().contiguous()
+    sc = torch.zeros(g.n, dtype=torch.float32, device=dev)
+    lg = torch.zeros(g.n, dtype=torch.float32, device=dev)
+    # calibration: a streaming copy of exactly CALIB_BYTES (reads 1 GiB, writes 1 GiB)
+    src = torch.empty(CALIB_BYTES // 4, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    torch.cuda.synchronize()
+    torch.add(src, 1.0, out=dst)   # the only 'CUDAFunctorOnSelf_add<float>' kernel of the run
+    torch.cuda.synchronize()
+    for _ in range(a.forwards):
+        eng.forward_device(x.data_ptr(), sc.data_ptr(), lg.data_ptr())
+        eng.synchronize()
+    print("probe done", g.n, g.nnz)
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
