@@ -166,7 +166,7 @@ int parse_model(gnnvc_engine *e, const char *text, size_t len) {
         }
         e->layers.push_back(std::move(l));
     }
-    if (e->layers.empty()) return fail(e, GNNVC_ERR_INVALID, "model has no layers");
+    // zero layers is allowed: an engine used only for the layer-level entry points
     return GNNVC_OK;
 }
 
@@ -209,13 +209,13 @@ int plan_model(gnnvc_engine *e) {
         e->max_width = std::max(e->max_width, wd);
     }
     e->out_width = wd;
-    e->ends_in_sigmoid = e->layers.back().kind == kSigmoid;
+    e->ends_in_sigmoid = !e->layers.empty() && e->layers.back().kind == kSigmoid;
 
     // fused plan: (Graph, Linear, ReLU, Linear, ReLU, Linear, ReLU|Sigmoid)+
     std::vector<StagePlan> st;
     size_t i = 0;
     int f = e->in_width;
-    bool ok = e->layers.size() % 7 == 0;
+    bool ok = !e->layers.empty() && e->layers.size() % 7 == 0;
     while (ok && i < e->layers.size()) {
         const Layer *L = &e->layers[i];
         ok = L[0].kind == kGraph && L[1].kind == kLinear && L[2].kind == kRelu &&
@@ -485,6 +485,7 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
     if (!e->have_graph) return fail(e, GNNVC_ERR_STATE, "no graph attached");
     const uint32_t n = e->g.n;
     e->ev_count = 0;
+    if (e->layers.empty()) return fail(e, GNNVC_ERR_STATE, "engine was created without a model");
     if (n == 0) return GNNVC_OK;
     if (!d_x || !d_scores) return fail(e, GNNVC_ERR_INVALID, "null feature buffers");
     int rc = use_device(e);

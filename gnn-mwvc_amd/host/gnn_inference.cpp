@@ -1,0 +1,273 @@
+// gnn_inference.cpp — host mirror of the reference's GNN layer structs and
+// gnn::model (reference src/gnn_inference.cpp), bound to the MI355X engine.
+//
+//   model::predict          -> gnnvc_upload_graph + gnnvc_forward   (reference :67-81)
+//   graph_layer::forward    -> gnnvc_graph_layer_forward            (reference :27-42)
+//   linear_layer::forward   -> gnnvc_linear_forward                 (reference :20-25)
+//   ReLU / sigmoid::forward -> gnnvc_relu_forward / gnnvc_sigmoid_forward (:44-52)
+//
+// Compiles against this directory's headers or, for the drop-in check, against
+// the reference's own include/ (the class layouts are the same).  No arithmetic
+// of the forward happens in this file except the final host-libm sigmoid on the
+// device logits, which is what makes the scores bit-identical to the reference's
+// on the host it runs on.
+#include <gnn_inference.hpp>  // angle brackets: the -I order decides (reference headers in the drop-in build)
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iomanip>
+#include <iostream>
+#include <limits>
+#include <map>
+#include <mutex>
+#include <random>
+#include <sstream>
+
+#include "gnnvc.h"
+#include "gnnvc_host.hpp"
+
+// ------------------------------------------------------------------ glue
+
+namespace gnnvc_host {
+
+int device_ordinal() {
+    const char *s = std::getenv("GNNVC_DEVICE");
+    return s ? std::atoi(s) : 0;
+}
+
+void check(int rc, const char *what, const gnnvc_engine *e) {
+    if (rc == GNNVC_OK) return;
+    std::fprintf(stderr, "gnnvc: %s failed: %s%s%s\n", what, gnnvc_strerror(rc),
+                 (e && *gnnvc_last_error(e)) ? " — " : "", e ? gnnvc_last_error(e) : "");
+    std::abort();  // never fall back to a CPU computation
+}
+
+gnnvc_engine *ops_engine() {
+    static gnnvc_engine *eng = [] {
+        gnnvc_engine *e = nullptr;
+        static const char kEmpty[] = "ops 0 Layers\n";
+        check(gnnvc_create(&e, kEmpty, sizeof kEmpty - 1, device_ordinal()), "gnnvc_create(ops)");
+        return e;
+    }();
+    return eng;
+}
+
+}  // namespace gnnvc_host
+
+using namespace gnn;
+using gnnvc_host::check;
+
+namespace {
+
+template <class... Fs>
+struct visitor : Fs... {
+    using Fs::operator()...;
+};
+template <class... Fs>
+visitor(Fs...) -> visitor<Fs...>;
+
+const float *cdata(const matrix &m) { return (m.get_height() && m.get_width()) ? &*m.begin(0) : nullptr; }
+float *mdata(matrix &m) { return (m.get_height() && m.get_width()) ? &*m.begin(0) : nullptr; }
+
+// The graph view the forward reads, packed to contiguous CSR through the
+// non-mutating accessors (begin(u)/end(u), W, NW — never D(u)/g[u], which move
+// the reference's hidden cursor, include/reduction_graph.hpp:144,240-245).
+struct PackedGraph {
+    std::vector<uint64_t> rowptr;
+    std::vector<uint32_t> col, w, nw;
+    template <class G>
+    explicit PackedGraph(const G &g) {
+        const uint32_t n = g.size();
+        rowptr.resize((size_t)n + 1);
+        w.resize(n);
+        nw.resize(n);
+        rowptr[0] = 0;
+        for (uint32_t u = 0; u < n; ++u) {
+            rowptr[u + 1] = rowptr[u] + (uint64_t)(g.end(u) - g.begin(u));
+            w[u] = g.W(u);
+            nw[u] = g.NW(u);
+        }
+        col.resize(rowptr[n]);
+        for (uint32_t u = 0; u < n; ++u) std::copy(g.begin(u), g.end(u), col.begin() + rowptr[u]);
+    }
+};
+
+// Lossless text of a model in the reference's format (9 significant digits
+// round-trip fp32), used to hand the layers to gnnvc_create.
+std::string exact_text(const std::string &name, const std::vector<component> &layers) {
+    std::ostringstream os;
+    os << std::setprecision(std::numeric_limits<float>::max_digits10);
+    os << (name.empty() ? std::string("model") : name) << "\n" << layers.size() << " Layers\n";
+    auto put = [&](const matrix &m) {
+        os << m.get_height() << " " << m.get_width() << "\n";
+        for (size_t i = 0; i < m.get_height(); ++i) {
+            for (auto it = m.begin(i); it != m.end(i); ++it) os << *it << " ";
+            os << "\n";
+        }
+    };
+    for (const auto &l : layers)
+        std::visit(visitor{[&](const linear_layer &c) {
+                               os << "Linear_Layer\nWeights: ";
+                               put(c.W);
+                               os << "Bias: ";
+                               put(c.bias);
+                           },
+                           [&](const graph_layer &) { os << "Graph_Layer\n"; },
+                           [&](const ReLU &) { os << "ReLU_Activation\n"; },
+                           [&](const sigmoid &) { os << "Sigmoid_Activation\n"; }},
+                   l);
+    return os.str();
+}
+
+// One engine per model object, rebuilt when the parameters change.
+struct Bound {
+    gnnvc_engine *eng = nullptr;
+    std::string text;
+};
+std::mutex g_mu;
+std::map<const void *, Bound> g_bound;
+
+gnnvc_engine *engine_for(const void *key, const std::string &name, const std::vector<component> &layers) {
+    std::string text = exact_text(name, layers);
+    std::lock_guard<std::mutex> lk(g_mu);
+    Bound &b = g_bound[key];
+    if (b.eng && b.text == text) return b.eng;
+    if (b.eng) gnnvc_destroy(b.eng);
+    b.eng = nullptr;
+    check(gnnvc_create(&b.eng, text.data(), text.size(), gnnvc_host::device_ordinal()), "gnnvc_create(model)");
+    b.text = std::move(text);
+    return b.eng;
+}
+
+float scale_of(const std::vector<component> &layers) {
+    for (const auto &l : layers)
+        if (const auto *gl = std::get_if<graph_layer>(&l)) return gl->WEIGHT_SCALE;
+    return 120.0f;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ layers
+
+// Same initialisation as the reference's training-time constructor (:7-18):
+// uniform(-lim, lim), lim = 1/sqrt(dim_in + 1), mt19937(seed), weights then bias.
+linear_layer::linear_layer(size_t dim_in, size_t dim_out, size_t seed) : W(dim_in, dim_out), bias(1, dim_out) {
+    const float lim = 1.0 / std::sqrt(dim_in + 1);
+    std::mt19937 gen(seed);
+    std::uniform_real_distribution<float> dist(-lim, lim);
+    for (size_t i = 0; i < dim_in; ++i)
+        for (size_t j = 0; j < dim_out; ++j) W(i, j) = dist(gen);
+    for (size_t j = 0; j < dim_out; ++j) bias(0, j) = dist(gen);
+}
+
+void linear_layer::forward(const matrix &in, matrix &out) const {
+    out.resize(in.get_height(), W.get_width());
+    if (!in.get_height()) return;
+    gnnvc_engine *e = gnnvc_host::ops_engine();
+    check(gnnvc_linear_forward(e, (uint32_t)in.get_height(), (uint32_t)W.get_height(), (uint32_t)W.get_width(),
+                               cdata(in), cdata(W), cdata(bias), mdata(out)),
+          "gnnvc_linear_forward", e);
+}
+
+void graph_layer::forward(const matrix &in, matrix &out, const reduction_graph<Tn, Tw> &g) const {
+    out.resize(in.get_height(), in.get_width() * 2 + 3);
+    if (!in.get_height()) return;
+    gnnvc_engine *e = gnnvc_host::ops_engine();
+    PackedGraph pg(g);
+    check(gnnvc_set_weight_scale(e, WEIGHT_SCALE), "gnnvc_set_weight_scale", e);
+    check(gnnvc_upload_graph(e, g.size(), pg.rowptr.data(), pg.col.data(), pg.w.data(), pg.nw.data()),
+          "gnnvc_upload_graph", e);
+    check(gnnvc_graph_layer_forward(e, (uint32_t)in.get_width(), cdata(in), mdata(out)),
+          "gnnvc_graph_layer_forward", e);
+}
+
+void ReLU::forward(const matrix &in, matrix &out) const {
+    out.resize(in.get_height(), in.get_width());
+    gnnvc_engine *e = gnnvc_host::ops_engine();
+    check(gnnvc_relu_forward(e, in.get_height() * in.get_width(), cdata(in), mdata(out)), "gnnvc_relu_forward", e);
+}
+
+void sigmoid::forward(const matrix &in, matrix &out) const {
+    out.resize(in.get_height(), in.get_width());
+    gnnvc_engine *e = gnnvc_host::ops_engine();
+    check(gnnvc_sigmoid_forward(e, in.get_height() * in.get_width(), cdata(in), mdata(out)),
+          "gnnvc_sigmoid_forward", e);
+}
+
+// ------------------------------------------------------------------ model
+
+model::model(std::string name) : name(std::move(name)) {}
+
+void model::add_layer(const component &c) { layers.push_back(c); }
+
+void model::set_weight_scale(float ws) {
+    for (auto &l : layers)
+        if (auto *gl = std::get_if<graph_layer>(&l)) gl->WEIGHT_SCALE = ws;
+}
+
+void model::predict(const matrix &in, matrix &out, const reduction_graph<Tn, Tw> &g) const {
+    gnnvc_engine *e = engine_for(this, name, layers);
+    const uint32_t n = g.size();
+    const int ow = gnnvc_out_width(e);
+    out.resize(n, (size_t)ow);
+    if (n == 0) return;  // the reference calls predict on the empty graph at the end of every run
+    if (in.get_height() != n || (int)in.get_width() != gnnvc_in_width(e)) {
+        std::fprintf(stderr, "gnn::model::predict: input is %zux%zu, expected %ux%d\n", in.get_height(),
+                     in.get_width(), n, gnnvc_in_width(e));
+        std::abort();
+    }
+    PackedGraph pg(g);
+    check(gnnvc_set_weight_scale(e, scale_of(layers)), "gnnvc_set_weight_scale", e);
+    check(gnnvc_upload_graph(e, n, pg.rowptr.data(), pg.col.data(), pg.w.data(), pg.nw.data()),
+          "gnnvc_upload_graph", e);
+    const bool sig = !layers.empty() && std::holds_alternative<sigmoid>(layers.back());
+    in_copy.resize(n, (size_t)ow);  // the reference's scratch member: holds the logits here
+    check(gnnvc_forward(e, cdata(in), mdata(out), sig ? mdata(in_copy) : nullptr), "gnnvc_forward", e);
+    if (sig) {
+        // exact parity route: host libm on the bit-exact device logits (reference :51)
+        for (size_t i = 0; i < (size_t)n * ow; ++i) {
+            const float x = *(in_copy.begin(0) + i);
+            *(out.begin(0) + i) = 1.0f / (1.0f + expf(-x));
+        }
+    }
+}
+
+// ------------------------------------------------------------------ text format
+
+std::ostream &gnn::operator<<(std::ostream &os, const model &m) {
+    os << m.name << std::endl << m.layers.size() << " Layers" << std::endl;
+    for (const auto &l : m.layers)
+        std::visit(visitor{[&](const linear_layer &c) {
+                               os << "Linear_Layer" << std::endl
+                                  << "Weights: " << c.W << std::endl
+                                  << "Bias: " << c.bias << std::endl
+                                  << std::endl;
+                           },
+                           [&](const graph_layer &) { os << "Graph_Layer" << std::endl << std::endl; },
+                           [&](const ReLU &) { os << "ReLU_Activation" << std::endl << std::endl; },
+                           [&](const sigmoid &) { os << "Sigmoid_Activation" << std::endl << std::endl; }},
+                   l);
+    return os;
+}
+
+std::istream &gnn::operator>>(std::istream &is, model &m) {
+    size_t count = 0;
+    std::string word;
+    is >> m.name >> count >> word;  // "<name> <n> Layers"
+    while (count-- && (is >> word)) {
+        if (word == "Linear_Layer") {
+            linear_layer l;
+            is >> word >> l.W >> word >> l.bias;  // "Weights:" matrix "Bias:" matrix
+            m.layers.emplace_back(std::move(l));
+        } else if (word == "Graph_Layer") {
+            m.layers.emplace_back(graph_layer{});
+        } else if (word == "ReLU_Activation") {
+            m.layers.emplace_back(ReLU{});
+        } else if (word == "Sigmoid_Activation") {
+            m.layers.emplace_back(sigmoid{});
+        }
+    }
+    return is;
+}

@@ -1,0 +1,19 @@
+// gnnvc_host.hpp — glue shared by the host mirror's translation units: the
+// process-wide engine used by the layer-level entry points and the loud-failure
+// policy (the reference signals no errors, src/GNN_VC.cpp prints and returns; a
+// missing GPU library must not silently produce numbers, so we abort).
+#pragma once
+#include "gnnvc.h"
+
+namespace gnnvc_host {
+
+// Engine without a model, for dot() and the per-layer forward()s.  Device from
+// GNNVC_DEVICE (default 0).
+gnnvc_engine *ops_engine();
+
+// Aborts with a message when rc != GNNVC_OK.
+void check(int rc, const char *what, const gnnvc_engine *e = nullptr);
+
+int device_ordinal();
+
+}  // namespace gnnvc_host

@@ -1,0 +1,72 @@
+// ref_harness.cpp — C entry points around the REFERENCE's own layer code, for
+// tests (oracle/_ref/ref_layers.so).  Compiled against /root/reference/include
+// and linked with the reference's src/gnn_inference.cpp (compiled where it lies)
+// and this repo's matrix translation unit; see oracle/Makefile.  No reference
+// source is copied: this file only calls the reference's public interface.
+#include <cstdint>
+#include <cstring>
+#include <sstream>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "gnn_inference.hpp"
+
+namespace {
+reduction_graph<uint32_t, uint32_t> make_graph(uint32_t n, const uint64_t *rowptr, const uint32_t *col,
+                                                const uint32_t *w) {
+    std::vector<uint32_t> weights(w, w + n);
+    std::vector<std::pair<uint32_t, uint32_t>> edges;
+    for (uint32_t u = 0; u < n; ++u)
+        for (uint64_t e = rowptr[u]; e < rowptr[u + 1]; ++e)
+            if (col[e] > u) edges.push_back({u, col[e]});
+    return reduction_graph<uint32_t, uint32_t>(weights, edges);  // sorted by construction
+}
+}  // namespace
+
+extern "C" {
+
+// reference gnn::model::predict on a CSR graph; out has n floats.
+// n_layers_keep < 0 keeps every layer, otherwise truncates the model text's
+// layer count (e.g. 20 of 21 drops the final sigmoid -> logits).
+int ref_predict(const char *model_text, int n_layers_keep, float ws, uint32_t n, const uint64_t *rowptr,
+                const uint32_t *col, const uint32_t *w, const float *x, float *out, uint32_t *out_width) {
+    std::string text(model_text);
+    if (n_layers_keep >= 0) {
+        // header is "<name> <n> Layers": rewrite the count; the parser stops after that many records
+        std::istringstream hs(text);
+        std::string name, cnt;
+        hs >> name >> cnt;
+        const size_t pos = text.find(cnt, name.size());
+        text.replace(pos, cnt.size(), std::to_string(n_layers_keep));
+    }
+    gnn::model m;
+    std::istringstream is(text);
+    is >> m;
+    m.set_weight_scale(ws);
+    auto g = make_graph(n, rowptr, col, w);
+    matrix in(n, 1), res;
+    for (uint32_t u = 0; u < n; ++u) in(u, 0) = x[u];
+    m.predict(in, res, g);
+    *out_width = (uint32_t)res.get_width();
+    for (size_t i = 0; i < res.get_height(); ++i)
+        for (size_t j = 0; j < res.get_width(); ++j) out[i * res.get_width() + j] = res(i, j);
+    return 0;
+}
+
+// reference gnn::graph_layer::forward
+int ref_graph_layer(float ws, uint32_t n, uint32_t f, const uint64_t *rowptr, const uint32_t *col,
+                    const uint32_t *w, const float *in, float *out) {
+    auto g = make_graph(n, rowptr, col, w);
+    gnn::graph_layer gl;
+    gl.WEIGHT_SCALE = ws;
+    matrix a(n, f), res;
+    for (uint32_t u = 0; u < n; ++u)
+        for (uint32_t j = 0; j < f; ++j) a(u, j) = in[(size_t)u * f + j];
+    gl.forward(a, res, g);
+    for (size_t i = 0; i < res.get_height(); ++i)
+        for (size_t j = 0; j < res.get_width(); ++j) out[i * res.get_width() + j] = res(i, j);
+    return (int)res.get_width();
+}
+
+}  // extern "C"

@@ -1,0 +1,155 @@
+/*
+ * gnnvc_abi_oracle.c — TEST DOUBLE of the C ABI (include/gnnvc.h) served by the
+ * CPU oracle.  Lives under tests/ and is linked ONLY into the link-level
+ * drop-in checks of oracle/_ref (CPU container, no GPU): it lets the reference's
+ * own driver run against this repo's host mirror so the boundary can be checked
+ * end to end.  The product library (libgnnvc_hip.so) contains none of this and
+ * has no CPU path.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "gnnvc.h"
+#include "gnnvc_oracle.h"
+
+struct gnnvc_engine {
+    oracle_model *m;
+    uint32_t n;
+    uint64_t *rowptr;
+    uint32_t *col, *w, *nw;
+    int in_w, out_w, sig;
+    unsigned long forwards;
+};
+
+static void widths(gnnvc_engine *e) {
+    int wd = 1, k0 = -1, graphs = 0;
+    for (int i = 0; i < e->m->n_layers && k0 < 0; i++) {
+        if (e->m->layers[i].kind == ORACLE_LAYER_LINEAR) k0 = (int)e->m->layers[i].k;
+        else if (e->m->layers[i].kind == ORACLE_LAYER_GRAPH) graphs++;
+    }
+    if (k0 >= 0) { wd = k0; while (graphs--) wd = (wd - 3) / 2; }
+    e->in_w = wd;
+    for (int i = 0; i < e->m->n_layers; i++) {
+        if (e->m->layers[i].kind == ORACLE_LAYER_LINEAR) wd = (int)e->m->layers[i].m;
+        else if (e->m->layers[i].kind == ORACLE_LAYER_GRAPH) wd = 2 * wd + 3;
+    }
+    e->out_w = wd;
+    e->sig = e->m->n_layers > 0 && e->m->layers[e->m->n_layers - 1].kind == ORACLE_LAYER_SIGMOID;
+}
+
+int gnnvc_abi_version(void) { return GNNVC_ABI_VERSION; }
+const char *gnnvc_strerror(int code) { return code == 0 ? "ok" : "error (oracle-backed test double)"; }
+const char *gnnvc_last_error(const gnnvc_engine *e) { (void)e; return ""; }
+
+int gnnvc_create(gnnvc_engine **out, const char *text, size_t len, int device) {
+    (void)device;
+    gnnvc_engine *e = (gnnvc_engine *)calloc(1, sizeof *e);
+    e->m = oracle_model_parse(text, len);
+    if (!e->m) { free(e); return GNNVC_ERR_INVALID; }
+    widths(e);
+    *out = e;
+    return GNNVC_OK;
+}
+
+static void drop_graph(gnnvc_engine *e) {
+    free(e->rowptr); free(e->col); free(e->w); free(e->nw);
+    e->rowptr = NULL; e->col = e->w = e->nw = NULL;
+}
+
+void gnnvc_destroy(gnnvc_engine *e) {
+    if (!e) return;
+    if (getenv("GNNVC_TEST_DOUBLE_TRACE")) fprintf(stderr, "gnnvc test double: %lu forwards\n", e->forwards);
+    drop_graph(e);
+    oracle_model_free(e->m);
+    free(e);
+}
+
+int gnnvc_set_weight_scale(gnnvc_engine *e, float ws) { oracle_model_set_weight_scale(e->m, ws); return GNNVC_OK; }
+int gnnvc_in_width(const gnnvc_engine *e) { return e->in_w; }
+int gnnvc_out_width(const gnnvc_engine *e) { return e->out_w; }
+
+static void *dup(const void *p, size_t bytes) {
+    void *q = malloc(bytes ? bytes : 1);
+    if (bytes) memcpy(q, p, bytes);
+    return q;
+}
+
+int gnnvc_upload_graph(gnnvc_engine *e, uint32_t n, const uint64_t *rowptr, const uint32_t *col,
+                       const uint32_t *w, const uint32_t *nw) {
+    drop_graph(e);
+    e->n = n;
+    uint64_t zero = 0;
+    e->rowptr = (uint64_t *)dup(n ? rowptr : &zero, ((size_t)n + 1) * 8);
+    e->col = (uint32_t *)dup(col, (size_t)(n ? rowptr[n] : 0) * 4);
+    e->w = (uint32_t *)dup(w, (size_t)n * 4);
+    e->nw = (uint32_t *)dup(nw, (size_t)n * 4);
+    return GNNVC_OK;
+}
+
+static oracle_graph view(const gnnvc_engine *e) {
+    oracle_graph g = {e->n, e->rowptr, e->col, e->w, e->nw};
+    return g;
+}
+
+int gnnvc_forward(gnnvc_engine *e, const float *x, float *scores, float *logits) {
+    if (!e->rowptr) return GNNVC_ERR_STATE;
+    if (e->n == 0) return GNNVC_OK;
+    if (getenv("GNNVC_TEST_DOUBLE_TRACE")) fprintf(stderr, "gnnvc test double: forward N=%u nnz=%llu\n", e->n, (unsigned long long)e->rowptr[e->n]);
+    e->forwards++;
+    oracle_graph g = view(e);
+    uint32_t wd = 0;
+    float *tmp = (float *)malloc((size_t)e->n * 35 * sizeof(float) + 64);
+    int rc = oracle_predict(e->m, &g, (uint32_t)e->in_w, x, tmp, &wd, -1, 0);
+    if (rc == 0) memcpy(scores, tmp, (size_t)e->n * wd * sizeof(float));
+    if (rc == 0 && logits && e->sig) {
+        rc = oracle_predict(e->m, &g, (uint32_t)e->in_w, x, tmp, &wd, e->m->n_layers - 2, 0);
+        if (rc == 0) memcpy(logits, tmp, (size_t)e->n * wd * sizeof(float));
+    }
+    free(tmp);
+    return rc == 0 ? GNNVC_OK : GNNVC_ERR_INVALID;
+}
+
+int gnnvc_graph_layer_forward(gnnvc_engine *e, uint32_t f, const float *in, float *out) {
+    if (!e->rowptr) return GNNVC_ERR_STATE;
+    oracle_graph g = view(e);
+    oracle_graph_layer(&g, e->m->weight_scale, f, in, out, 0);
+    return GNNVC_OK;
+}
+
+int gnnvc_linear_forward(gnnvc_engine *e, uint32_t n, uint32_t k, uint32_t m, const float *in,
+                         const float *W, const float *bias, float *out) {
+    (void)e;
+    oracle_linear_layer(n, k, m, in, W, bias, out);
+    return GNNVC_OK;
+}
+
+int gnnvc_relu_forward(gnnvc_engine *e, size_t count, const float *in, float *out) {
+    (void)e;
+    oracle_relu(count, in, out);
+    return GNNVC_OK;
+}
+
+int gnnvc_sigmoid_forward(gnnvc_engine *e, size_t count, const float *in, float *out) {
+    (void)e;
+    oracle_sigmoid(count, in, out);
+    return GNNVC_OK;
+}
+
+int gnnvc_sgemm(gnnvc_engine *e, int ta, int tb, uint32_t m, uint32_t n, uint32_t k, const float *A,
+                uint32_t lda, const float *B, uint32_t ldb, float beta, float *C, uint32_t ldc) {
+    (void)e;
+    for (uint32_t i = 0; i < m; i++)
+        for (uint32_t j = 0; j < n; j++) {
+            float acc = 0.0f;
+            for (uint32_t kk = 0; kk < k; kk++) {
+                float a = ta ? A[(size_t)kk * lda + i] : A[(size_t)i * lda + kk];
+                float b = tb ? B[(size_t)j * ldb + kk] : B[(size_t)kk * ldb + j];
+                acc = fmaf(a, b, acc);
+            }
+            float *c = &C[(size_t)i * ldc + j];
+            *c = (beta == 0.0f) ? acc : fmaf(beta, *c, acc);
+        }
+    return GNNVC_OK;
+}

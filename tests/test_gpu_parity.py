@@ -242,3 +242,26 @@ def test_errors(engine):
         engine.stage_forward_device(0, 0, g.n + 1, 1, 1)   # row range outside the graph
     with pytest.raises(G.GnnvcError):
         engine.stage_forward_device(7, 0, g.n, 1, 1)       # no such stage
+
+
+# ---------------------------------------------------------------- host C++ mirror
+
+def test_host_mirror_predict(oracle_model, model_text, tmp_path):
+    """gnn::model::predict of the C++ host mirror (same signature as the reference's)
+    through libgnnvc_hip.so: scores bit-identical to the oracle's host-libm scores."""
+    import pathlib
+    import subprocess
+    pkg = pathlib.Path(__file__).resolve().parent.parent / "gnn-mwvc_amd"
+    tool = pkg / "gnnvc_predict"
+    if not tool.exists():
+        r = subprocess.run(["make", "-C", str(pkg / "host")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    g = gg.erdos_renyi(5000, 30000, 21)
+    (tmp_path / "g.metis").write_text(gg.metis_text(g))
+    (tmp_path / "m.txt").write_text(model_text)
+    r = subprocess.run([str(tool), str(tmp_path / "m.txt"), str(tmp_path / "g.metis"),
+                        str(tmp_path / "s.f32")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.fromfile(tmp_path / "s.f32", dtype=np.float32)
+    oracle_model.set_weight_scale(g.ws)
+    assert np.array_equal(bits(got), bits(oracle_model.scores(g)))
