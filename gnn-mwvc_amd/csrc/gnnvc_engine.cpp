@@ -432,6 +432,10 @@ int gnnvc_upload_graph(gnnvc_engine *e, uint32_t n, const uint64_t *rowptr, cons
             rp32[i] = (uint32_t)rowptr[i];
         }
         if (n && rowptr[0] != 0) return fail(e, GNNVC_ERR_INVALID, "rowptr[0] must be 0");
+        // a column id >= n would send the gather to a wild address on the device
+        for (uint64_t i = 0; i < nnz; ++i)
+            if (col[i] >= n) return fail(e, GNNVC_ERR_INVALID, "col[%llu] = %u is not a vertex of this graph (n = %u)",
+                                         (unsigned long long)i, col[i], n);
         HIP_TRY(e, e->rowptr.reserve((size_t)n + 1));
         HIP_TRY(e, e->col.reserve(nnz + GNNVC_COL_PAD));
         HIP_TRY(e, e->w.reserve(n));

@@ -25,7 +25,6 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kBlock = 256;              // 4 waves, each wave owns one 64-vertex tile
 constexpr int kWavesPerBlock = kBlock / kWave;
-constexpr int kPitch = 20;               // LDS row pitch in floats (80 B keeps b128 accesses conflict-free)
 
 __device__ __forceinline__ void wave_lds_sync() {
     // LDS operations of one wave execute in program order; this only stops the
@@ -74,6 +73,31 @@ __device__ __forceinline__ uint32_t tile_for_wave(uint32_t ntiles) {
     return (slot < per_xcd) ? xcd * per_xcd + slot : 0xFFFFFFFFu;
 }
 
+// ------------------------------------------------------------------ per-wave LDS region
+// One region per wave, reused over the life of a tile:
+//   1. column-index stage: the tile's slice of `col` (all entries of its 64 rows),
+//      fetched with full-line coalesced loads so every 128-byte line of `col` is
+//      requested from L2 exactly once per tile;
+//   2. dense-layer input tile: 64 rows x 29 floats [aggregate 0..15 | h0, h4..h15];
+//   3. output tile: 64 rows x 17 floats, read back row-wise for full-row stores.
+constexpr int kRegionFloats = 1856;          // 7424 B per wave, 29 KiB per workgroup
+constexpr int kInPitch = 29;                 // odd pitch: conflict-free ds_read_b32 down a column
+constexpr int kOutPitch = 17;
+constexpr uint32_t kStageCap = 1792 - 4;     // most col entries a tile may stage (7 x 256 minus alignment slack)
+static_assert(kWave * kInPitch <= kRegionFloats && 1792 <= kRegionFloats, "region too small");
+
+// Stage col[c0, c1) of this wave's tile into LDS.  Returns the entry index that
+// LDS slot 0 corresponds to (c0 rounded down to a 16-byte boundary).
+__device__ __forceinline__ uint32_t stage_cols(const uint32_t *__restrict__ col, uint32_t c0,
+                                               uint32_t c1, uint32_t *stage, int lane) {
+    const uint32_t base = c0 & ~3u;
+    for (uint32_t off = base + 4u * lane; off < c1; off += 256u) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(col + off);  // col is padded past nnz
+        *reinterpret_cast<uint4 *>(stage + (off - base)) = v;
+    }
+    return base;
+}
+
 // ------------------------------------------------------------------ stage, F = 16
 // Parameters: W1[35 x N1] b1 W2[N1 x N2] b2 W3[N2 x N3] b3.  Input columns of
 // the first dense layer after the reference's column layout (f = 16):
@@ -85,9 +109,10 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
         GraphDev g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
         float *__restrict__ logits, const float *__restrict__ P, uint32_t row_lo,
         uint32_t row_hi) {
-    __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kWave * kPitch];
+    __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kRegionFloats];
     const int lane = threadIdx.x & 63;
     float *T = lds[threadIdx.x >> 6];
+    uint32_t *stage = reinterpret_cast<uint32_t *>(T);
     const uint32_t ntiles = (row_hi - row_lo + kWave - 1) / kWave;
     const uint32_t tile = tile_for_wave(ntiles);
     if (tile >= ntiles) return;
@@ -99,20 +124,37 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
     const uint32_t uc = valid ? u : row_hi - 1;
     const uint32_t rs = g.rowptr[uc];
     const uint32_t re = valid ? g.rowptr[uc + 1] : rs;
+    const float f_deg = (float)(re - rs);
+    const float f_w = (float)g.w[uc] / ws;
+    const float f_nw = (float)g.nw[uc] / ws;
 
-    // ---- gather: quad q of lanes owns vertices v0 + 16p + q (p = 0..3) and
-    // sums their neighbour rows in CSR order, lane c holding floats 4c..4c+3.
+    // the tile's slice of col: [c0, c1) — rows are contiguous in CSR
+    const uint32_t c0 = __builtin_amdgcn_readfirstlane(rs);
+    const uint32_t vend = (v0 + kWave < row_hi) ? v0 + kWave : row_hi;
+    const uint32_t c1 = g.rowptr[vend];   // wave-uniform: end of the tile's last valid row
+    const bool staged = (c1 - c0) <= kStageCap;
+    uint32_t sbase = 0;
+    if (staged) sbase = stage_cols(g.col, c0, c1, stage, lane);
+
+    // ---- quad layout: quad q of lanes owns vertices v0 + 16p + q (p = 0..3),
+    // lane c of the quad holds floats 4c..4c+3 of a 64-byte feature row.
     const int q = lane >> 2, c = lane & 3;
     uint32_t b[4], e[4];
+    float4 self[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         b[p] = __shfl(rs, 16 * p + q);
         e[p] = __shfl(re, 16 * p + q);
+        const uint32_t row = v0 + 16 * p + q;
+        self[p] = fin[(size_t)(row < row_hi ? row : row_hi - 1) * 4 + c];  // own rows: 16 full rows per load
     }
     float4 acc[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
     const uint32_t zrow = g.n;  // all-zero pad row: x + 0.0f == x exactly
+    wave_lds_sync();            // staged indices visible to the whole wave
+
+    // ---- gather: neighbour rows summed in CSR order, S rows per vertex in flight
     while ((b[0] < e[0]) | (b[1] < e[1]) | (b[2] < e[2]) | (b[3] < e[3])) {
         uint32_t idx[4][S];
 #pragma unroll
@@ -120,7 +162,8 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 const uint32_t ee = b[p] + s;
-                const uint32_t cv = g.col[ee];  // col is padded: ee < nnz + S
+                // staged: ee - sbase < 1792 + S always (ee <= c1 + S - 1); slots past c1 hold junk, masked below
+                const uint32_t cv = staged ? stage[ee - sbase] : g.col[ee];
                 idx[p][s] = (ee < e[p]) ? cv : zrow;
             }
         float4 r[4][S];
@@ -141,30 +184,35 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
             b[p] = nb < e[p] ? nb : e[p];
         }
     }
+
+    // ---- hand over to the lane-per-vertex layout through the LDS tile
+    wave_lds_sync();  // every lane is done with the index stage before it is overwritten
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
-        *reinterpret_cast<float4 *>(&T[(16 * p + q) * kPitch + 4 * c]) = acc[p];
+    for (int p = 0; p < 4; ++p) {
+        float *row = &T[(16 * p + q) * kInPitch];
+        row[4 * c + 0] = acc[p].x; row[4 * c + 1] = acc[p].y;
+        row[4 * c + 2] = acc[p].z; row[4 * c + 3] = acc[p].w;
+        if (c == 0) {
+            row[16] = self[p].x;                 // h[0]; h[1..3] are overwritten by degree / weights
+        } else {
+            float *d = &row[17 + 4 * (c - 1)];   // h[4..15]
+            d[0] = self[p].x; d[1] = self[p].y; d[2] = self[p].z; d[3] = self[p].w;
+        }
+    }
     wave_lds_sync();
 
     // ---- dense layers: one lane per vertex, activations in registers.
     float x0[32];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float4 a = *reinterpret_cast<const float4 *>(&T[lane * kPitch + 4 * i]);
-        x0[4 * i + 0] = a.x; x0[4 * i + 1] = a.y; x0[4 * i + 2] = a.z; x0[4 * i + 3] = a.w;
-    }
     {
-        const float4 h0 = fin[(size_t)uc * 4 + 0];
-        const float4 h1 = fin[(size_t)uc * 4 + 1];
-        const float4 h2 = fin[(size_t)uc * 4 + 2];
-        const float4 h3 = fin[(size_t)uc * 4 + 3];
-        x0[16] = h0.x;
-        x0[17] = (float)(re - rs);
-        x0[18] = (float)g.w[uc] / ws;
-        x0[19] = (float)g.nw[uc] / ws;
-        x0[20] = h1.x; x0[21] = h1.y; x0[22] = h1.z; x0[23] = h1.w;
-        x0[24] = h2.x; x0[25] = h2.y; x0[26] = h2.z; x0[27] = h2.w;
-        x0[28] = h3.x; x0[29] = h3.y; x0[30] = h3.z; x0[31] = h3.w;
+        const float *row = &T[lane * kInPitch];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) x0[j] = row[j];
+        x0[16] = row[16];
+        x0[17] = f_deg;
+        x0[18] = f_w;
+        x0[19] = f_nw;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) x0[20 + j] = row[17 + j];
     }
     const float *W1 = P, *b1 = W1 + 35 * N1;
     const float *W2 = b1 + N1, *b2 = W2 + N1 * N2;
@@ -185,14 +233,13 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
         // transpose through LDS: every global store instruction writes 16 full rows
         wave_lds_sync();
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4 *>(&T[lane * kPitch + 4 * i]) =
-                make_float4(x3[4 * i], x3[4 * i + 1], x3[4 * i + 2], x3[4 * i + 3]);
+        for (int j = 0; j < 16; ++j) T[lane * kOutPitch + j] = x3[j];
         wave_lds_sync();
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const uint32_t row = v0 + 16 * p + q;
-            const float4 o = *reinterpret_cast<const float4 *>(&T[(16 * p + q) * kPitch + 4 * c]);
+            const float *src = &T[(16 * p + q) * kOutPitch + 4 * c];
+            const float4 o = make_float4(src[0], src[1], src[2], src[3]);
             if (row < row_hi) reinterpret_cast<float4 *>(fout)[(size_t)row * 4 + c] = o;
         }
     }
@@ -204,9 +251,10 @@ template <int N1, int N2, int N3, int S>
 __global__ __launch_bounds__(kBlock) void k_stage_f1(
         GraphDev g, float ws, const float *__restrict__ xin, float *__restrict__ fout,
         const float *__restrict__ P, uint32_t row_lo, uint32_t row_hi) {
-    __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kWave * kPitch];
+    __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kRegionFloats];
     const int lane = threadIdx.x & 63;
     float *T = lds[threadIdx.x >> 6];
+    uint32_t *stage = reinterpret_cast<uint32_t *>(T);
     const uint32_t ntiles = (row_hi - row_lo + kWave - 1) / kWave;
     const uint32_t tile = tile_for_wave(ntiles);
     if (tile >= ntiles) return;
@@ -217,13 +265,24 @@ __global__ __launch_bounds__(kBlock) void k_stage_f1(
     const uint32_t rs = g.rowptr[uc];
     const uint32_t re = valid ? g.rowptr[uc + 1] : rs;
 
+    const uint32_t c0 = __builtin_amdgcn_readfirstlane(rs);
+    const uint32_t vend = (v0 + kWave < row_hi) ? v0 + kWave : row_hi;
+    const uint32_t c1 = g.rowptr[vend];   // wave-uniform: end of the tile's last valid row
+    const bool staged = (c1 - c0) <= kStageCap;
+    uint32_t sbase = 0;
+    if (staged) sbase = stage_cols(g.col, c0, c1, stage, lane);
+    const float xself = xin[uc];
+    const float f_w = (float)g.w[uc] / ws;
+    const float f_nw = (float)g.nw[uc] / ws;
+    wave_lds_sync();
+
     float agg = 0.0f;
     for (uint32_t eb = rs; eb < re; eb += S) {
         float xs[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const uint32_t ee = eb + s;
-            const uint32_t cv = g.col[ee];  // padded
+            const uint32_t cv = staged ? stage[ee - sbase] : g.col[ee];
             const float v = xin[(ee < re) ? cv : uc];
             xs[s] = (ee < re) ? v : 0.0f;  // agg is never -0.0f, so + 0.0f is exact
         }
@@ -232,10 +291,10 @@ __global__ __launch_bounds__(kBlock) void k_stage_f1(
     }
     float x0[5];
     x0[0] = agg;
-    x0[1] = xin[uc];
+    x0[1] = xself;
     x0[2] = (float)(re - rs);
-    x0[3] = (float)g.w[uc] / ws;
-    x0[4] = (float)g.nw[uc] / ws;
+    x0[3] = f_w;
+    x0[4] = f_nw;
     const float *W1 = P, *b1 = W1 + 5 * N1;
     const float *W2 = b1 + N1, *b2 = W2 + N1 * N2;
     const float *W3 = b2 + N2, *b3 = W3 + N2 * N3;
@@ -245,15 +304,15 @@ __global__ __launch_bounds__(kBlock) void k_stage_f1(
     dense<N2, N2, N3, 0>(x2, x3, W3, b3);
     static_assert(N3 == 16, "feature stages emit 16 floats per vertex");
     const int q = lane >> 2, c = lane & 3;
+    wave_lds_sync();  // index stage is dead; reuse the region as the output tile
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        *reinterpret_cast<float4 *>(&T[lane * kPitch + 4 * i]) =
-            make_float4(x3[4 * i], x3[4 * i + 1], x3[4 * i + 2], x3[4 * i + 3]);
+    for (int j = 0; j < 16; ++j) T[lane * kOutPitch + j] = x3[j];
     wave_lds_sync();
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const uint32_t row = v0 + 16 * p + q;
-        const float4 o = *reinterpret_cast<const float4 *>(&T[(16 * p + q) * kPitch + 4 * c]);
+        const float *src = &T[(16 * p + q) * kOutPitch + 4 * c];
+        const float4 o = make_float4(src[0], src[1], src[2], src[3]);
         if (row < row_hi) reinterpret_cast<float4 *>(fout)[(size_t)row * 4 + c] = o;
     }
 }
