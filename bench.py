@@ -103,38 +103,34 @@ def main() -> int:
 
     x = g.x().contiguous()
 
-    # 1-D vertex partition: equal 64-aligned row blocks (ER is degree-uniform, so
-    # this is nnz-balanced too); rank r owns rows [lo, hi).
-    rpr = ((g.n + world - 1) // world + 63) // 64 * 64
-    lo, hi = min(rank * rpr, g.n), min((rank + 1) * rpr, g.n)
-    # feature buffers: (rows + pad) x 16 fp32, row g.n (the gather's pad row) stays zero
-    hbuf = [torch.zeros((world * rpr + 64, 16), dtype=torch.float32, device=dev) for _ in range(2)]
-    sc_full = torch.zeros(world * rpr + 64, dtype=torch.float32, device=dev)
-    lg_full = torch.zeros(world * rpr + 64, dtype=torch.float32, device=dev)
+    # 1-D vertex partition: equal 64-aligned row blocks (ER is degree-uniform, so this is
+    # nnz-balanced too); rank r owns rows [lo, hi).  Buffers, stage sequencing and the
+    # inter-stage exchange live in gnn-mwvc_amd/distributed.py.
+    from gnn_mwvc_amd import distributed as D
+    bounds = D.partition_bounds(g.n, world, None, "rows")
+    lo, hi = bounds[rank]
+    bufs = D.ForwardBuffers.allocate(g.n, bounds, dev)
+
+    def stage_fn(st, r0, r1, src, dst, lg):
+        eng.stage_forward_device(st, r0, r1, src.data_ptr(), dst.data_ptr(),
+                                 lg.data_ptr() if lg is not None else 0)
 
     # HIP events on the launch stream around every stage launch of the timed region
-    # (the engine launches on torch's current stream, so torch events bracket its kernels)
+    # (the engine launches on this torch stream, so torch events bracket its kernels)
     stage_evt = [[torch.cuda.Event(enable_timing=True) for _ in range(6)]
                  for _ in range(args.steps)]
 
     def step(k: int | None):
-        ev = stage_evt[k] if k is not None else None
-        src = x
-        for st in range(3):
-            last = st == 2
-            dst = sc_full if last else hbuf[st]
-            if ev:
-                ev[2 * st].record(stream)
-            eng.stage_forward_device(st, lo, hi, src.data_ptr(), dst.data_ptr(),
-                                     lg_full.data_ptr() if last else 0)
-            if ev:
-                ev[2 * st + 1].record(stream)
-            if world > 1:
-                # exchange: every rank needs every row of the next stage's input (and,
-                # after the last stage, predict hands every caller all N scores)
-                flat = dst[: world * rpr]
-                dist.all_gather_into_tensor(flat, flat[rank * rpr:(rank + 1) * rpr])
-            src = dst
+        hook = None
+        if k is not None:
+            ev = stage_evt[k]
+
+            def hook(st, phase):
+                if phase == "begin":
+                    ev[2 * st].record(stream)
+                elif phase == "computed":
+                    ev[2 * st + 1].record(stream)
+        D.partitioned_forward(stage_fn, 3, x, bufs, bounds, rank, on_stage=hook, gather_logits=False)
 
     for _ in range(args.warmup):
         step(None)
@@ -157,7 +153,6 @@ def main() -> int:
 
     stage_ms = [sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for ev in stage_evt) / args.steps
                 for i in range(3)]
-    scores, logits = sc_full[: g.n], lg_full[: g.n]
 
     ms_per_step = elapsed * 1e3 / args.steps
     edges_per_s = g.n_edges / (elapsed / args.steps)

@@ -1,0 +1,160 @@
+"""1-D vertex-partitioned forward across the GPUs of one node.
+
+One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI on the
+GPU box, "gloo" in the CPU tests).  Every rank holds the whole CSR (global column
+ids) and full-size feature buffers; rank r computes the rows [lo_r, hi_r) of each
+fused stage, then the ranks exchange their freshly written rows so that every
+rank holds the complete input of the next stage — an all-gather of the N x 16
+fp32 feature matrix after stages 0 and 1 and of the N scores after the last
+stage.  Each row is still summed on one GPU in CSR order, so results are
+bit-identical to the single-GPU forward.
+
+There is no reference counterpart (the reference is single-process); the
+arithmetic is `gnn::model::predict` (reference src/gnn_inference.cpp:67-81)
+unchanged.
+
+The stage executor is injected: on a GPU it is `Engine.stage_forward_device`
+(HIP kernels); the CPU tests inject a checker-backed one.  This module itself
+never computes a stage and never imports the oracle.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Callable, List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+ALIGN = 64  # a wave tile; keeps every rank's tiles full except the last one's tail
+
+
+def partition_bounds(n: int, world: int, rowptr=None, mode: str = "rows") -> List[Tuple[int, int]]:
+    """Contiguous row ranges [lo, hi) per rank, boundaries multiples of ALIGN.
+
+    mode "rows": equal row counts (shards equal-sized -> one all_gather_into_tensor).
+    mode "nnz":  equal CSR entries per rank (prefix-sum split of rowptr), for skewed
+                 graphs; shards become uneven -> exchanged by direct sends.
+    """
+    if world <= 0:
+        raise ValueError("world must be positive")
+    if mode == "rows" or rowptr is None or n == 0:
+        per = ((n + world - 1) // world + ALIGN - 1) // ALIGN * ALIGN if n else 0
+        cuts = [min(r * per, n) for r in range(world + 1)]
+    elif mode == "nnz":
+        rp = torch.as_tensor(rowptr).to(torch.int64).cpu()
+        nnz = int(rp[n])
+        cuts = [0]
+        for r in range(1, world):
+            target = nnz * r // world
+            v = int(torch.searchsorted(rp, torch.tensor([target], dtype=torch.int64)).item())
+            v = min(max((v + ALIGN // 2) // ALIGN * ALIGN, cuts[-1]), n)
+            cuts.append(v)
+        cuts.append(n)
+    else:
+        raise ValueError(f"unknown partition mode {mode!r}")
+    cuts[-1] = n
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+@dataclasses.dataclass
+class ForwardBuffers:
+    """Full-size buffers every rank owns.  Feature buffers have `rows_alloc` rows;
+    row n (the gather's pad row) and everything after it stay zero."""
+    n: int
+    rows_alloc: int
+    feat: List[torch.Tensor]   # two (rows_alloc, 16) fp32 ping-pong buffers
+    scores: torch.Tensor       # (rows_alloc,) fp32
+    logits: torch.Tensor       # (rows_alloc,) fp32
+
+    @staticmethod
+    def allocate(n: int, bounds: Sequence[Tuple[int, int]], device) -> "ForwardBuffers":
+        world = len(bounds)
+        equal = _equal_shard_rows(n, bounds)
+        rows = (world * equal if equal else n) + ALIGN
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=device)
+        return ForwardBuffers(n, rows, [z(rows, 16), z(rows, 16)], z(rows), z(rows))
+
+
+def _equal_shard_rows(n: int, bounds: Sequence[Tuple[int, int]]) -> int:
+    """Rows per shard if the partition is the equal-rows one (last shard may be short), else 0."""
+    world = len(bounds)
+    per = bounds[0][1] - bounds[0][0]
+    if per == 0 or per % ALIGN:
+        return 0 if world > 1 else max(per, 0)
+    for r, (lo, hi) in enumerate(bounds):
+        if lo != min(r * per, n) or hi != min((r + 1) * per, n):
+            return 0
+    return per
+
+
+def exchange_rows(buf: torch.Tensor, bounds: Sequence[Tuple[int, int]], rank: int, n: int,
+                  group=None, method: str = "auto") -> None:
+    """Make rows [lo_r, hi_r) written by each rank r visible on every rank, in place.
+
+    "allgather": equal shards -> one in-place all_gather_into_tensor (RCCL picks the
+                 xGMI schedule).
+    "p2p":       any shard sizes -> every rank sends its shard straight to each peer
+                 and receives theirs, all transfers in one group (full-mesh: one
+                 xGMI link per peer, no ring).
+    """
+    world = len(bounds)
+    if world == 1:
+        return
+    per = _equal_shard_rows(n, bounds)
+    if method == "auto":
+        method = "allgather" if per else "p2p"
+    if method == "allgather":
+        if not per:
+            raise ValueError("all_gather_into_tensor needs the equal-rows partition")
+        flat = buf[: world * per]
+        dist.all_gather_into_tensor(flat, flat[rank * per:(rank + 1) * per], group=group)
+        return
+    if method != "p2p":
+        raise ValueError(f"unknown exchange method {method!r}")
+    lo, hi = bounds[rank]
+    ops = []
+    for peer in range(world):
+        if peer == rank:
+            continue
+        plo, phi = bounds[peer]
+        if hi > lo:
+            ops.append(dist.P2POp(dist.isend, buf[lo:hi], peer, group))
+        if phi > plo:
+            ops.append(dist.P2POp(dist.irecv, buf[plo:phi], peer, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
+StageFn = Callable[[int, int, int, torch.Tensor, torch.Tensor, "torch.Tensor | None"], None]
+
+
+def partitioned_forward(stage_fn: StageFn, num_stages: int, x: torch.Tensor, bufs: ForwardBuffers,
+                        bounds: Sequence[Tuple[int, int]], rank: int, group=None,
+                        exchange: str = "auto", on_stage=None,
+                        gather_logits: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Run every fused stage on this rank's rows and exchange between stages.
+
+    stage_fn(stage, lo, hi, src, dst, logits_or_None) computes rows [lo, hi) of `dst`
+    from the full `src`.  Returns (scores[:n], logits[:n]) — complete on every rank,
+    like `predict` hands every caller all N scores.
+    on_stage(stage, phase) is an optional hook ("begin" | "computed" | "exchanged")
+    used by the bench to drop timing events on the stream.
+    """
+    lo, hi = bounds[rank]
+    src = x
+    for st in range(num_stages):
+        last = st == num_stages - 1
+        dst = bufs.scores if last else bufs.feat[st & 1]
+        if on_stage:
+            on_stage(st, "begin")
+        stage_fn(st, lo, hi, src, dst, bufs.logits if last else None)
+        if on_stage:
+            on_stage(st, "computed")
+        exchange_rows(dst, bounds, rank, bufs.n, group, exchange)
+        if last and gather_logits:   # the exact-parity route applies the host sigmoid to the logits
+            exchange_rows(bufs.logits, bounds, rank, bufs.n, group, exchange)
+        if on_stage:
+            on_stage(st, "exchanged")
+        src = dst
+    return bufs.scores[: bufs.n], bufs.logits[: bufs.n]
