@@ -57,6 +57,8 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="2000000x20000000",
                     help="n x m of the CPU-baseline sample graph")
+    ap.add_argument("--no-blocked", action="store_true", help="disable the column-blocked F=1 stage (A/B)")
+    ap.add_argument("--block-cols", type=int, default=0)
     ap.add_argument("--host-path", action="store_true",
                     help="also time the host-pointer path (PCIe inclusive), reported separately")
     args = ap.parse_args()
@@ -92,8 +94,15 @@ def main() -> int:
     eng = G.Engine(G.default_model_text(), device=local_rank)
     assert eng.fused and eng.num_stages == 3
     eng.set_weight_scale(g.ws)
+    if args.no_blocked:
+        eng.set_option("blocked_stage0", 0)
+    if args.block_cols:
+        eng.set_option("block_cols", args.block_cols)
+    t0 = time.time()
     eng.attach_graph_device(g.n, g.nnz, g.rowptr.data_ptr(), g.col.data_ptr(), g.w.data_ptr(),
                             g.nw.data_ptr(), keepalive=g)
+    eng.synchronize()
+    t_attach = time.time() - t0   # includes building the column-blocked index (once per graph)
     # a dedicated HIP stream shared by torch (events, collectives) and the engine;
     # torch's default stream has the NULL handle, which the ABI reads as "engine's own"
     stream = torch.cuda.Stream(device=dev)
@@ -179,7 +188,9 @@ def main() -> int:
                      "kernel_ms": stage_ms[dom],
                      "forward_bytes": fwd_bytes,
                      "forward_frac": fwd_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world},
-        "stage_ms": stage_ms, "graph_build_s": t_gen,
+        "stage_ms": stage_ms, "graph_build_s": t_gen, "graph_attach_s": t_attach,
+        "plan": {"blocked_stage0": bool(eng.get_info("blocked_stage0_active")),
+                 "column_blocks": eng.get_info("blocked_blocks"), "block_cols": eng.get_info("block_cols")},
     }
 
     if rank == 0 and world == 1:

@@ -79,6 +79,15 @@ struct gnnvc_engine {
     DevBuf<float> x, h[2], scores, logits;
     DevBuf<float> scratch[2];  // layer-level entry points / unfused path
 
+    // column-blocked plan of the F = 1 stage (built per graph, see gnnvc_kernels.hip)
+    int opt_blocked = 1;            // option "blocked_stage0"
+    uint32_t opt_block_cols = 0;    // option "block_cols" (0 = default)
+    uint32_t opt_blocked_min_n = 1u << 20;  // below this x fits the L2s anyway
+    bool blocked_ready = false;
+    uint32_t blk_count = 0, blk_cols = 0;
+    DevBuf<uint32_t> blk_ptr, blk_col, blk_scratch, blk_flag;
+    DevBuf<float> blk_acc;
+
     std::string err;
 };
 
@@ -258,6 +267,47 @@ int use_device(gnnvc_engine *e) {
     return GNNVC_OK;
 }
 
+// Column-blocked index of the current graph (stage 0 only).  Not used when the
+// model is not fused, the graph is small, or a row's block ids are not monotone.
+int build_blocked(gnnvc_engine *e) {
+    e->blocked_ready = false;
+    const GraphDev &g = e->g;
+    if (!e->opt_blocked || e->stages.empty() || e->stages[0].f != 1 || e->stages[0].variant != 0) return GNNVC_OK;
+    if (g.n < e->opt_blocked_min_n || g.nnz == 0) return GNNVC_OK;
+    const uint32_t wb = e->opt_block_cols ? e->opt_block_cols : (512u << 10);  // 2 MiB of x per block
+    const uint32_t nb = (g.n + wb - 1) / wb;
+    if (nb < 2 || nb > 4096) return GNNVC_OK;
+    const size_t elems = (size_t)nb * g.n + 1;
+    HIP_TRY(e, e->blk_ptr.reserve(elems));
+    HIP_TRY(e, e->blk_col.reserve(g.nnz + GNNVC_COL_PAD));
+    HIP_TRY(e, e->blk_scratch.reserve(gnnvc::blocked_scan_scratch_elems(elems)));
+    HIP_TRY(e, e->blk_flag.reserve(1));
+    HIP_TRY(e, e->blk_acc.reserve(g.n));
+    HIP_TRY(e, gnnvc::build_blocked_index(g, wb, nb, e->blk_ptr.p, e->blk_col.p, e->blk_scratch.p,
+                                          e->blk_flag.p, e->stream));
+    HIP_TRY(e, hipMemsetAsync(e->blk_col.p + g.nnz, 0, GNNVC_COL_PAD * sizeof(uint32_t), e->stream));
+    uint32_t bad = 1;
+    HIP_TRY(e, hipMemcpyAsync(&bad, e->blk_flag.p, sizeof bad, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (bad) return GNNVC_OK;  // rows not block-monotone: the blocked order would differ from CSR order
+    e->blk_count = nb;
+    e->blk_cols = wb;
+    e->blocked_ready = true;
+    return GNNVC_OK;
+}
+
+// stage launcher shared by the whole-forward and the per-stage entry points
+int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float *in, float *out, float *logits) {
+    if (stage == 0 && e->blocked_ready) {
+        HIP_TRY(e, gnnvc::launch_stage0_blocked(e->stages[0], e->g, e->ws, e->params.p, in, out, lo, hi,
+                                                e->blk_count, e->blk_ptr.p, e->blk_col.p, e->blk_acc.p,
+                                                e->stream));
+        return GNNVC_OK;
+    }
+    HIP_TRY(e, gnnvc::launch_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi, e->stream));
+    return GNNVC_OK;
+}
+
 int reserve_features(gnnvc_engine *e, uint32_t n) {
     const size_t rows = (size_t)n + 1;
     HIP_TRY(e, e->x.reserve(rows * (size_t)e->in_width));
@@ -385,6 +435,8 @@ void gnnvc_destroy(gnnvc_engine *e) {
     e->x.release(); e->h[0].release(); e->h[1].release();
     e->scores.release(); e->logits.release();
     e->scratch[0].release(); e->scratch[1].release();
+    e->blk_ptr.release(); e->blk_col.release(); e->blk_scratch.release(); e->blk_flag.release();
+    e->blk_acc.release();
     for (auto v : e->ev) (void)hipEventDestroy(v);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
@@ -399,6 +451,26 @@ int gnnvc_set_weight_scale(gnnvc_engine *e, float ws) {
 int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream) {
     if (!e) return GNNVC_ERR_INVALID;
     e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+    return GNNVC_OK;
+}
+
+int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
+    if (!e || !key) return GNNVC_ERR_INVALID;
+    const std::string k(key);
+    if (k == "blocked_stage0") e->opt_blocked = value != 0;
+    else if (k == "block_cols") e->opt_block_cols = value > 0 ? (uint32_t)value : 0;
+    else if (k == "blocked_min_n") e->opt_blocked_min_n = value > 0 ? (uint32_t)value : 0;
+    else return fail(e, GNNVC_ERR_INVALID, "unknown option '%s'", key);
+    return GNNVC_OK;
+}
+
+int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
+    if (!e || !key || !value) return GNNVC_ERR_INVALID;
+    const std::string k(key);
+    if (k == "blocked_stage0_active") *value = e->blocked_ready ? 1 : 0;
+    else if (k == "blocked_blocks") *value = e->blocked_ready ? (long)e->blk_count : 0;
+    else if (k == "block_cols") *value = e->blocked_ready ? (long)e->blk_cols : 0;
+    else return GNNVC_ERR_INVALID;
     return GNNVC_OK;
 }
 
@@ -454,7 +526,9 @@ int gnnvc_upload_graph(gnnvc_engine *e, uint32_t n, const uint64_t *rowptr, cons
     }
     e->g = GraphDev{n, nnz, e->rowptr.p, e->col.p, e->w.p, e->nw.p};
     e->have_graph = true;
-    return reserve_features(e, n);
+    rc = reserve_features(e, n);
+    if (rc) return rc;
+    return build_blocked(e);
 }
 
 int gnnvc_attach_graph_device(gnnvc_engine *e, uint32_t n, uint64_t nnz, const uint32_t *d_rowptr,
@@ -466,7 +540,9 @@ int gnnvc_attach_graph_device(gnnvc_engine *e, uint32_t n, uint64_t nnz, const u
     if (rc) return rc;
     e->g = GraphDev{n, nnz, d_rowptr, d_col, d_w, d_nw};
     e->have_graph = true;
-    return reserve_features(e, n);
+    rc = reserve_features(e, n);
+    if (rc) return rc;
+    return build_blocked(e);
 }
 
 int gnnvc_stage_forward_device(gnnvc_engine *e, int stage, uint32_t row_lo, uint32_t row_hi,
@@ -479,9 +555,7 @@ int gnnvc_stage_forward_device(gnnvc_engine *e, int stage, uint32_t row_lo, uint
     if (!d_in || !d_out) return fail(e, GNNVC_ERR_INVALID, "null feature buffers");
     int rc = use_device(e);
     if (rc) return rc;
-    HIP_TRY(e, gnnvc::launch_stage(e->stages[stage], e->g, e->ws, e->params.p, d_in, d_out, d_logits,
-                                   row_lo, row_hi, e->stream));
-    return GNNVC_OK;
+    return run_stage(e, stage, row_lo, row_hi, d_in, d_out, d_logits);
 }
 
 int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, float *d_logits) {
@@ -514,8 +588,8 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
     for (size_t s = 0; s < ns; ++s) {
         const bool last = s + 1 == ns;
         float *dst = last ? d_scores : e->h[s & 1].p;
-        HIP_TRY(e, gnnvc::launch_stage(e->stages[s], e->g, e->ws, e->params.p, cur, dst,
-                                       last ? d_logits : nullptr, 0, n, e->stream));
+        rc = run_stage(e, (int)s, 0, n, cur, dst, last ? d_logits : nullptr);
+        if (rc) return rc;
         HIP_TRY(e, hipEventRecord(e->ev[s + 1], e->stream));
         cur = dst;
     }

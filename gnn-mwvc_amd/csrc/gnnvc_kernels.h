@@ -39,6 +39,19 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
                         const float *in, float *out, float *logits, uint32_t row_lo,
                         uint32_t row_hi, hipStream_t stream);
 
+// Column-blocked F = 1 stage (bit-identical to launch_stage on stage 0; see the kernels).
+// bp: uint32[nblocks * n + 1] block-major entry pointers, colb: uint32[nnz + pad] re-bucketed
+// columns, acc: float[n] running sums.  *bad_flag != 0 after the build means the graph's
+// rows are not block-monotone and the plan must not be used.
+size_t blocked_scan_scratch_elems(size_t n_elems);
+hipError_t build_blocked_index(const GraphDev &g, uint32_t wb, uint32_t nblocks, uint32_t *bp,
+                               uint32_t *colb, uint32_t *scratch, uint32_t *bad_flag,
+                               hipStream_t stream);
+hipError_t launch_stage0_blocked(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
+                                 const float *x, float *out, uint32_t row_lo, uint32_t row_hi,
+                                 uint32_t nblocks, const uint32_t *bp, const uint32_t *colb, float *acc,
+                                 hipStream_t stream);
+
 // Layer-by-layer kernels (any model; also the layer-level ABI entry points).
 hipError_t launch_graph_layer(const GraphDev &g, float ws, uint32_t f, const float *in,
                               float *out, hipStream_t stream);

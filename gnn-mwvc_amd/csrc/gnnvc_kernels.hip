@@ -247,10 +247,16 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
 
 // ------------------------------------------------------------------ stage, F = 1
 // First dense layer input (f = 1): [aggregate, x, degree, W/ws, NW/ws].
+// `ep` / `ecol` say which CSR entries this launch sums: the whole rows
+// (ep = g.rowptr, ecol = g.col, acc_in = nullptr) or, in the column-blocked plan,
+// the rows' entries of the LAST column block with the partial sums of the earlier
+// blocks arriving in acc_in (same add sequence as the unblocked loop).
 template <int N1, int N2, int N3, int S>
 __global__ __launch_bounds__(kBlock) void k_stage_f1(
         GraphDev g, float ws, const float *__restrict__ xin, float *__restrict__ fout,
-        const float *__restrict__ P, uint32_t row_lo, uint32_t row_hi) {
+        const float *__restrict__ P, uint32_t row_lo, uint32_t row_hi,
+        const uint32_t *__restrict__ ep, const uint32_t *__restrict__ ecol,
+        const float *__restrict__ acc_in) {
     __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kRegionFloats];
     const int lane = threadIdx.x & 63;
     float *T = lds[threadIdx.x >> 6];
@@ -262,27 +268,28 @@ __global__ __launch_bounds__(kBlock) void k_stage_f1(
     const uint32_t u = v0 + lane;
     const bool valid = u < row_hi;
     const uint32_t uc = valid ? u : row_hi - 1;
-    const uint32_t rs = g.rowptr[uc];
-    const uint32_t re = valid ? g.rowptr[uc + 1] : rs;
+    const uint32_t rs = ep[uc];
+    const uint32_t re = valid ? ep[uc + 1] : rs;
+    const float f_deg = (float)(g.rowptr[uc + 1] - g.rowptr[uc]);
 
     const uint32_t c0 = __builtin_amdgcn_readfirstlane(rs);
     const uint32_t vend = (v0 + kWave < row_hi) ? v0 + kWave : row_hi;
-    const uint32_t c1 = g.rowptr[vend];   // wave-uniform: end of the tile's last valid row
+    const uint32_t c1 = ep[vend];   // wave-uniform: end of the tile's last valid row
     const bool staged = (c1 - c0) <= kStageCap;
     uint32_t sbase = 0;
-    if (staged) sbase = stage_cols(g.col, c0, c1, stage, lane);
+    if (staged) sbase = stage_cols(ecol, c0, c1, stage, lane);
     const float xself = xin[uc];
     const float f_w = (float)g.w[uc] / ws;
     const float f_nw = (float)g.nw[uc] / ws;
+    float agg = acc_in ? acc_in[uc] : 0.0f;
     wave_lds_sync();
 
-    float agg = 0.0f;
     for (uint32_t eb = rs; eb < re; eb += S) {
         float xs[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const uint32_t ee = eb + s;
-            const uint32_t cv = staged ? stage[ee - sbase] : g.col[ee];
+            const uint32_t cv = staged ? stage[ee - sbase] : ecol[ee];
             const float v = xin[(ee < re) ? cv : uc];
             xs[s] = (ee < re) ? v : 0.0f;  // agg is never -0.0f, so + 0.0f is exact
         }
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(kBlock) void k_stage_f1(
     float x0[5];
     x0[0] = agg;
     x0[1] = xself;
-    x0[2] = (float)(re - rs);
+    x0[2] = f_deg;
     x0[3] = f_w;
     x0[4] = f_nw;
     const float *W1 = P, *b1 = W1 + 5 * N1;
@@ -315,6 +322,104 @@ __global__ __launch_bounds__(kBlock) void k_stage_f1(
         const float4 o = make_float4(src[0], src[1], src[2], src[3]);
         if (row < row_hi) reinterpret_cast<float4 *>(fout)[(size_t)row * 4 + c] = o;
     }
+}
+
+// ------------------------------------------------------------------ column-blocked F = 1 aggregation
+// The F = 1 gather reads 4 useful bytes per random 128-byte line of x; with x
+// (4 N bytes) far beyond the 4 MiB L2 of an XCD every read goes to the fabric.
+// Column blocking makes it cache-resident: vertices are cut into blocks of `wb`
+// columns (an x slice of 4 wb bytes that stays in every XCD's L2), the CSR is
+// re-bucketed once per graph into block-major order (colb, with entry pointers
+// bp[k*N + u]), and one launch per block adds that block's entries to a running
+// sum per row.  Because every row's entries are visited in their stored order
+// (block ids are non-decreasing along a row — checked when the index is built —
+// and entries keep their order inside a block), the fp32 add sequence per row is
+// exactly the unblocked one: results are bit-identical.
+
+// pass 1: cnt[k*N + u] = entries of row u in block k (buffer pre-zeroed); flags a
+// row whose block ids decrease (then the blocked plan is not exact and is not used).
+__global__ void k_blk_count(GraphDev g, uint32_t wb, uint32_t *__restrict__ cnt,
+                            uint32_t *__restrict__ bad) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= g.n) return;
+    const uint32_t rs = g.rowptr[u], re = g.rowptr[u + 1];
+    uint32_t kcur = 0, run = 0;
+    for (uint32_t e = rs; e < re; ++e) {
+        const uint32_t k = g.col[e] / wb;
+        if (k != kcur) {
+            if (k < kcur) atomicOr(bad, 1u);
+            if (run) cnt[(size_t)kcur * g.n + u] = run;
+            kcur = k;
+            run = 0;
+        }
+        ++run;
+    }
+    if (run) cnt[(size_t)kcur * g.n + u] = run;
+}
+
+// pass 3: scatter the entries to block-major order (bp = exclusive scan of cnt).
+__global__ void k_blk_scatter(GraphDev g, uint32_t wb, const uint32_t *__restrict__ bp,
+                              uint32_t *__restrict__ colb) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= g.n) return;
+    const uint32_t rs = g.rowptr[u], re = g.rowptr[u + 1];
+    uint32_t kcur = 0xFFFFFFFFu, dst = 0;
+    for (uint32_t e = rs; e < re; ++e) {
+        const uint32_t c = g.col[e];
+        const uint32_t k = c / wb;
+        if (k != kcur) {
+            kcur = k;
+            dst = bp[(size_t)k * g.n + u];
+        }
+        colb[dst++] = c;
+    }
+}
+
+// exclusive scan of uint32 (three-kernel chunked scan; chunk = 256 threads x 16)
+constexpr int kScanPer = 16, kScanChunk = 256 * kScanPer;
+__global__ __launch_bounds__(256) void k_scan_chunks(uint32_t *__restrict__ data, size_t n,
+                                                     uint32_t *__restrict__ sums) {
+    __shared__ uint32_t part[256];
+    const size_t base = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * kScanPer;
+    uint32_t v[kScanPer], tot = 0;
+#pragma unroll
+    for (int i = 0; i < kScanPer; ++i) {
+        v[i] = (base + i < n) ? data[base + i] : 0u;
+        tot += v[i];
+    }
+    part[threadIdx.x] = tot;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {   // Hillis-Steele inclusive scan of the 256 partials
+        const uint32_t t = (threadIdx.x >= (unsigned)off) ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - tot;      // exclusive prefix of this thread inside the chunk
+#pragma unroll
+    for (int i = 0; i < kScanPer; ++i) {
+        if (base + i < n) data[base + i] = run;
+        run += v[i];
+    }
+    if (threadIdx.x == 255) sums[blockIdx.x] = part[255];
+}
+__global__ void k_scan_add(uint32_t *__restrict__ data, size_t n, const uint32_t *__restrict__ offs) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) data[i] += offs[i / kScanChunk];
+}
+
+// one launch per column block except the last: acc[u] (+)= sum of x over row u's entries in block k
+__global__ __launch_bounds__(256) void k_blk_accumulate(const uint32_t *__restrict__ bpk,
+                                                        const uint32_t *__restrict__ colb,
+                                                        const float *__restrict__ xin,
+                                                        float *__restrict__ acc, uint32_t row_lo,
+                                                        uint32_t row_hi, int first) {
+    const uint32_t u = row_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= row_hi) return;
+    const uint32_t s = bpk[u], t = bpk[u + 1];
+    float a = first ? 0.0f : acc[u];
+    for (uint32_t e = s; e < t; ++e) a += xin[colb[e]];
+    acc[u] = a;
 }
 
 // ------------------------------------------------------------------ layer-by-layer kernels
@@ -411,7 +516,7 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
     switch (sp.variant) {
     case 0:
         hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4>), grid, block, 0, stream, g, ws, in, out, P,
-                           row_lo, row_hi);
+                           row_lo, row_hi, g.rowptr, g.col, static_cast<const float *>(nullptr));
         break;
     case 1:
         hipLaunchKernelGGL((k_stage_f16<32, 32, 16, false, 2>), grid, block, 0, stream, g, ws,
@@ -466,6 +571,59 @@ hipError_t launch_sgemm(int ta, int tb, uint32_t m, uint32_t n, uint32_t k, cons
     if (!work) return hipSuccess;
     hipLaunchKernelGGL(k_sgemm, dim3(blocks_for(work, 256)), dim3(256), 0, stream, ta, tb, m, n, k,
                        A, lda, B, ldb, beta, C, ldc);
+    return hipGetLastError();
+}
+
+// ---- column-blocked stage 0 ----------------------------------------------------------
+static hipError_t scan_u32(uint32_t *data, size_t n, uint32_t *scratch, hipStream_t stream) {
+    // scratch needs ceil(n/chunk) + ceil(that/chunk) + ... entries (callers reserve n/2048 + 8192)
+    if (n == 0) return hipSuccess;
+    const size_t chunks = (n + kScanChunk - 1) / kScanChunk;
+    hipLaunchKernelGGL(k_scan_chunks, dim3((unsigned)chunks), dim3(256), 0, stream, data, n, scratch);
+    if (chunks > 1) {
+        hipError_t rc = scan_u32(scratch, chunks, scratch + chunks, stream);
+        if (rc != hipSuccess) return rc;
+        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, data, n,
+                           scratch);
+    }
+    return hipGetLastError();
+}
+
+size_t blocked_scan_scratch_elems(size_t n_elems) { return n_elems / 2048 + 8192; }
+
+hipError_t build_blocked_index(const GraphDev &g, uint32_t wb, uint32_t nblocks, uint32_t *bp,
+                               uint32_t *colb, uint32_t *scratch, uint32_t *bad_flag,
+                               hipStream_t stream) {
+    const size_t elems = (size_t)nblocks * g.n + 1;
+    hipError_t rc = hipMemsetAsync(bp, 0, elems * sizeof(uint32_t), stream);
+    if (rc != hipSuccess) return rc;
+    rc = hipMemsetAsync(bad_flag, 0, sizeof(uint32_t), stream);
+    if (rc != hipSuccess) return rc;
+    const unsigned nb = (g.n + 255) / 256;
+    hipLaunchKernelGGL(k_blk_count, dim3(nb), dim3(256), 0, stream, g, wb, bp, bad_flag);
+    rc = scan_u32(bp, elems, scratch, stream);
+    if (rc != hipSuccess) return rc;
+    hipLaunchKernelGGL(k_blk_scatter, dim3(nb), dim3(256), 0, stream, g, wb, bp, colb);
+    return hipGetLastError();
+}
+
+hipError_t launch_stage0_blocked(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
+                                 const float *x, float *out, uint32_t row_lo, uint32_t row_hi,
+                                 uint32_t nblocks, const uint32_t *bp, const uint32_t *colb, float *acc,
+                                 hipStream_t stream) {
+    if (row_hi <= row_lo) return hipSuccess;
+    if (sp.variant != 0) return hipErrorInvalidValue;
+    const unsigned nb = (row_hi - row_lo + 255) / 256;
+    for (uint32_t k = 0; k + 1 < nblocks; ++k)
+        hipLaunchKernelGGL(k_blk_accumulate, dim3(nb), dim3(256), 0, stream, bp + (size_t)k * g.n, colb, x,
+                           acc, row_lo, row_hi, k == 0 ? 1 : 0);
+    const uint32_t ntiles = (row_hi - row_lo + kWave - 1) / kWave;
+    const uint32_t per_xcd = (ntiles + 7) / 8;
+    const uint32_t blocks_per_xcd = (per_xcd + kWavesPerBlock - 1) / kWavesPerBlock;
+    hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4>), dim3(blocks_per_xcd * 8), dim3(kBlock), 0, stream, g, ws,
+                       x, out, params + sp.param_offset, row_lo, row_hi,
+                       bp + (size_t)(nblocks - 1) * g.n, colb,
+                       nblocks > 1 ? static_cast<const float *>(acc) : static_cast<const float *>(nullptr));
     return hipGetLastError();
 }
 

@@ -18,7 +18,7 @@ _LIB = _PKG / "libgnnvc_hip.so"
 # every symbol include/gnnvc.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "gnnvc_abi_version", "gnnvc_strerror", "gnnvc_last_error", "gnnvc_create", "gnnvc_destroy",
-    "gnnvc_set_weight_scale", "gnnvc_set_stream", "gnnvc_num_layers", "gnnvc_is_fused",
+    "gnnvc_set_weight_scale", "gnnvc_set_stream", "gnnvc_set_option", "gnnvc_get_info", "gnnvc_num_layers", "gnnvc_is_fused",
     "gnnvc_in_width", "gnnvc_out_width", "gnnvc_upload_graph", "gnnvc_attach_graph_device",
     "gnnvc_forward", "gnnvc_forward_device", "gnnvc_num_stages", "gnnvc_stage_widths",
     "gnnvc_stage_forward_device", "gnnvc_synchronize", "gnnvc_last_forward_ms",
@@ -79,6 +79,8 @@ def load_library():
     L.gnnvc_destroy.restype = None
     L.gnnvc_set_weight_scale.argtypes = [vp, C.c_float]
     L.gnnvc_set_stream.argtypes = [vp, vp]
+    L.gnnvc_set_option.argtypes = [vp, C.c_char_p, C.c_long]
+    L.gnnvc_get_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_long)]
     for name in ("gnnvc_num_layers", "gnnvc_is_fused", "gnnvc_in_width", "gnnvc_out_width",
                  "gnnvc_num_stages", "gnnvc_synchronize"):
         getattr(L, name).argtypes = [vp]
@@ -169,6 +171,14 @@ class Engine:
 
     def set_weight_scale(self, ws: float):
         self._check(self._L.gnnvc_set_weight_scale(self._h, C.c_float(ws)))
+
+    def set_option(self, key: str, value: int):
+        self._check(self._L.gnnvc_set_option(self._h, key.encode(), value))
+
+    def get_info(self, key: str) -> int:
+        v = C.c_long(0)
+        self._check(self._L.gnnvc_get_info(self._h, key.encode(), C.byref(v)))
+        return v.value
 
     def set_stream(self, hip_stream: int | None):
         self._check(self._L.gnnvc_set_stream(self._h, C.c_void_p(hip_stream or 0)))

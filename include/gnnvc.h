@@ -67,6 +67,15 @@ int gnnvc_set_weight_scale(gnnvc_engine *e, float ws);
  * the engine's own stream.  NULL restores the engine's stream. */
 int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
 
+/* Tuning options (take effect at the next graph upload / attach):
+ *   "blocked_stage0" 0|1  column-blocked plan of the F = 1 stage (default 1; results are
+ *                         bit-identical either way, it only changes memory traffic)
+ *   "block_cols"     n    vertices per column block (default 524288 = 2 MiB of x)
+ *   "blocked_min_n"  n    graphs with fewer vertices are not blocked (default 2^20)
+ * gnnvc_get_info keys: "blocked_stage0_active", "blocked_blocks", "block_cols". */
+int gnnvc_set_option(gnnvc_engine *e, const char *key, long value);
+int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value);
+
 /* Model introspection (what model::layers holds). */
 int gnnvc_num_layers(const gnnvc_engine *e);
 /* 1 if the model matches the fused 3-stage plan, 0 if it runs layer by layer. */

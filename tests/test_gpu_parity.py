@@ -265,3 +265,67 @@ def test_host_mirror_predict(oracle_model, model_text, tmp_path):
     got = np.fromfile(tmp_path / "s.f32", dtype=np.float32)
     oracle_model.set_weight_scale(g.ws)
     assert np.array_equal(bits(got), bits(oracle_model.scores(g)))
+
+
+# ---------------------------------------------------------------- column-blocked F = 1 stage
+
+@pytest.mark.parametrize("block_cols", [64, 1000, 4096, 1 << 19])
+def test_blocked_stage0_is_bit_identical(model_text, oracle_model, block_cols):
+    """The column-blocked plan re-buckets the CSR per column block; every row's adds must
+    still happen in stored order, so logits stay bit-identical (forced on small graphs)."""
+    import gnn_mwvc_amd as G
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_option("blocked_min_n", 0)
+        e.set_option("block_cols", block_cols)
+        graphs = [gg.erdos_renyi(5000, 40000, 31), gg.hub_graph(20000, 60000, 3, 4096, seed=7),
+                  gg.rmat(11, 8, 3), gg.from_edge_list(130, [(0, i) for i in range(1, 40)], list(range(20, 150)))]
+        for g in graphs:
+            e.set_weight_scale(g.ws)
+            oracle_model.set_weight_scale(g.ws)
+            e.upload_graph(g)
+            want_active = 1 if (g.n + block_cols - 1) // block_cols >= 2 else 0
+            assert e.get_info("blocked_stage0_active") == want_active
+            _, logits = e.forward(g.x())
+            assert np.array_equal(bits(logits[:, 0]), bits(oracle_model.logits(g)))
+            # stage output alone (h1) and a row sub-range through the stage entry point
+            import torch
+            dev = torch.device("cuda:0")
+            x = torch.from_numpy(g.x()).to(dev)
+            h1 = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+            mid = (g.n // 2) // 64 * 64
+            for lo, hi in ((0, mid), (mid, g.n)):
+                e.stage_forward_device(0, lo, hi, x.data_ptr(), h1.data_ptr())
+            e.synchronize()
+            assert np.array_equal(bits(h1[:-1].cpu().numpy()), bits(oracle_model.predict(g, g.x(), stop_after=6)))
+    finally:
+        e.close()
+
+
+def test_unsorted_adjacency_falls_back_to_stored_order(model_text, oracle_model):
+    """Stored order is the contract.  With neighbour lists in descending order the blocked
+    plan would change the add order, so the engine must not use it."""
+    import gnn_mwvc_amd as G
+    g = gg.erdos_renyi(4000, 30000, 33)
+    rp = g.rowptr.astype(np.int64)
+    col = g.col.copy()
+    for u in range(g.n):
+        col[rp[u]:rp[u + 1]] = col[rp[u]:rp[u + 1]][::-1]
+    g2 = gg.CsrGraph(g.n, g.rowptr, col, g.w, g.nw)
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_option("blocked_min_n", 0)
+        e.set_option("block_cols", 256)
+        e.set_weight_scale(g2.ws)
+        oracle_model.set_weight_scale(g2.ws)
+        e.upload_graph(g2)
+        assert e.get_info("blocked_stage0_active") == 0
+        _, logits = e.forward(g2.x())
+        want = oracle_model.logits(g2)
+        assert np.array_equal(bits(logits[:, 0]), bits(want))
+        # and the order does matter: the sorted graph gives (slightly) different logits
+        oracle_model.set_weight_scale(g.ws)
+        assert not np.array_equal(bits(want), bits(oracle_model.logits(g)))
+    finally:
+        e.close()
