@@ -31,11 +31,28 @@ if str(ROOT) not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 WORKLOADS = {
-    # name: (n, m, seed)
+    # Erdős–Rényi: (n, m, seed)
     "er10m": (10_000_000, 100_000_000, 10),   # the metric graph
     "er1m": (1_000_000, 10_000_000, 2),
     "er100k": (100_000, 1_000_000, 1),
+    # the other BASELINE.json configs (parity-test cases; selectable here for profiling)
+    "rmat22": ("rmat", 22, 16, 22),
+    "rmat20": ("rmat", 20, 16, 20),
+    "powerlaw1m": ("powerlaw", 1_000_000, 16.0, 2.1, 8, 65536, 5),
 }
+
+
+def build_workload(name, ggt, dev):
+    spec = WORKLOADS[name]
+    if spec[0] == "rmat":
+        _, scale, ef, seed = spec
+        return ggt.rmat(scale, ef, seed, dev), f"r-mat scale={scale} edge_factor={ef} seed={seed} weights U[20,120]"
+    if spec[0] == "powerlaw":
+        _, n, deg, expo, hubs, hd, seed = spec
+        return (ggt.power_law_hubs(n, deg, expo, hubs, hd, seed, dev),
+                f"chung-lu power-law n={n} avg_deg={deg} exp={expo} + {hubs} hubs of degree {hd} seed={seed}")
+    n, m, seed = spec
+    return ggt.erdos_renyi(n, m, seed, dev), f"erdos-renyi n={n} m={m} seed={seed} weights U[20,120]"
 
 
 def stage_bytes(stage: int, n: int, nnz: int) -> int:
@@ -59,6 +76,7 @@ def main() -> int:
                     help="n x m of the CPU-baseline sample graph")
     ap.add_argument("--no-blocked", action="store_true", help="disable the column-blocked F=1 stage (A/B)")
     ap.add_argument("--block-cols", type=int, default=0)
+    ap.add_argument("--long-threshold", type=int, default=-1, help="degree at which a row gets its own workgroup")
     ap.add_argument("--host-path", action="store_true",
                     help="also time the host-pointer path (PCIe inclusive), reported separately")
     args = ap.parse_args()
@@ -85,9 +103,8 @@ def main() -> int:
     import gnn_mwvc_amd as G
     from tools import graphgen_torch as ggt
 
-    n, m, seed = WORKLOADS[args.workload]
     t0 = time.time()
-    g = ggt.erdos_renyi(n, m, seed, dev)   # every rank builds the same graph (same Philox stream)
+    g, workload_desc = build_workload(args.workload, ggt, dev)   # every rank builds the same graph (same Philox stream)
     torch.cuda.synchronize()
     t_gen = time.time() - t0
 
@@ -98,6 +115,8 @@ def main() -> int:
         eng.set_option("blocked_stage0", 0)
     if args.block_cols:
         eng.set_option("block_cols", args.block_cols)
+    if args.long_threshold >= 0:
+        eng.set_option("long_row_threshold", args.long_threshold)
     t0 = time.time()
     eng.attach_graph_device(g.n, g.nnz, g.rowptr.data_ptr(), g.col.data_ptr(), g.w.data_ptr(),
                             g.nw.data_ptr(), keepalive=g)
@@ -179,7 +198,7 @@ def main() -> int:
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"erdos-renyi n={g.n} m={g.n_edges} seed={seed} weights U[20,120]",
+        "config": {"workload": workload_desc, "vertices": g.n, "edges": g.n_edges,
                    "graph": args.workload, "partition": f"1d-vertex x{world}",
                    "exchange": "none" if world == 1 else "all-gather N x16 fp32 after stages 0 and 1"},
         "roofline": {"bound": "hbm", "kernel": kernel_names[dom], "achieved": achieved,
@@ -190,7 +209,8 @@ def main() -> int:
                      "forward_frac": fwd_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world},
         "stage_ms": stage_ms, "graph_build_s": t_gen, "graph_attach_s": t_attach,
         "plan": {"blocked_stage0": bool(eng.get_info("blocked_stage0_active")),
-                 "column_blocks": eng.get_info("blocked_blocks"), "block_cols": eng.get_info("block_cols")},
+                 "column_blocks": eng.get_info("blocked_blocks"), "block_cols": eng.get_info("block_cols"),
+                 "long_rows": eng.get_info("long_rows"), "long_row_threshold": eng.get_info("long_row_threshold")},
     }
 
     if rank == 0 and world == 1:

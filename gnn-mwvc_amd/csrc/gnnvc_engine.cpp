@@ -88,6 +88,13 @@ struct gnnvc_engine {
     DevBuf<uint32_t> blk_ptr, blk_col, blk_scratch, blk_flag;
     DevBuf<float> blk_acc;
 
+    // long rows (degree >= long_thresh): one workgroup each, on aux_stream beside the tile kernel
+    uint32_t opt_long_thresh = 512;   // option "long_row_threshold" (0 = off)
+    uint32_t long_thresh = 0xFFFFFFFFu, n_long = 0;
+    DevBuf<uint32_t> long_list, long_count;
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+
     std::string err;
 };
 
@@ -267,6 +274,29 @@ int use_device(gnnvc_engine *e) {
     return GNNVC_OK;
 }
 
+// Rows the tile kernels hand to the long-row kernels (per graph).
+int find_long(gnnvc_engine *e) {
+    e->n_long = 0;
+    e->long_thresh = 0xFFFFFFFFu;
+    const GraphDev &g = e->g;
+    if (!e->opt_long_thresh || e->stages.empty() || g.n == 0) return GNNVC_OK;
+    HIP_TRY(e, e->long_list.reserve(g.n));
+    HIP_TRY(e, e->long_count.reserve(1));
+    HIP_TRY(e, gnnvc::find_long_rows(g, e->opt_long_thresh, e->long_list.p, e->long_count.p, e->stream));
+    uint32_t cnt = 0;
+    HIP_TRY(e, hipMemcpyAsync(&cnt, e->long_count.p, sizeof cnt, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (cnt == 0) return GNNVC_OK;   // nothing long: the tile kernels keep every row
+    if (!e->aux_stream) {
+        HIP_TRY(e, hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking));
+        HIP_TRY(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+        HIP_TRY(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    }
+    e->n_long = cnt;
+    e->long_thresh = e->opt_long_thresh;
+    return GNNVC_OK;
+}
+
 // Column-blocked index of the current graph (stage 0 only).  Not used when the
 // model is not fused, the graph is small, or a row's block ids are not monotone.
 int build_blocked(gnnvc_engine *e) {
@@ -283,8 +313,8 @@ int build_blocked(gnnvc_engine *e) {
     HIP_TRY(e, e->blk_scratch.reserve(gnnvc::blocked_scan_scratch_elems(elems)));
     HIP_TRY(e, e->blk_flag.reserve(1));
     HIP_TRY(e, e->blk_acc.reserve(g.n));
-    HIP_TRY(e, gnnvc::build_blocked_index(g, wb, nb, e->blk_ptr.p, e->blk_col.p, e->blk_scratch.p,
-                                          e->blk_flag.p, e->stream));
+    HIP_TRY(e, gnnvc::build_blocked_index(g, wb, nb, e->long_thresh, e->blk_ptr.p, e->blk_col.p,
+                                          e->blk_scratch.p, e->blk_flag.p, e->stream));
     HIP_TRY(e, hipMemsetAsync(e->blk_col.p + g.nnz, 0, GNNVC_COL_PAD * sizeof(uint32_t), e->stream));
     uint32_t bad = 1;
     HIP_TRY(e, hipMemcpyAsync(&bad, e->blk_flag.p, sizeof bad, hipMemcpyDeviceToHost, e->stream));
@@ -298,13 +328,23 @@ int build_blocked(gnnvc_engine *e) {
 
 // stage launcher shared by the whole-forward and the per-stage entry points
 int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float *in, float *out, float *logits) {
+    const bool longs = e->n_long > 0;
+    if (longs) {   // fork: the long rows of this stage run beside the tile kernel
+        HIP_TRY(e, hipEventRecord(e->ev_fork, e->stream));
+        HIP_TRY(e, hipStreamWaitEvent(e->aux_stream, e->ev_fork, 0));
+        HIP_TRY(e, gnnvc::launch_long_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi,
+                                            e->long_list.p, e->n_long, e->aux_stream));
+        HIP_TRY(e, hipEventRecord(e->ev_join, e->aux_stream));
+    }
     if (stage == 0 && e->blocked_ready) {
         HIP_TRY(e, gnnvc::launch_stage0_blocked(e->stages[0], e->g, e->ws, e->params.p, in, out, lo, hi,
                                                 e->blk_count, e->blk_ptr.p, e->blk_col.p, e->blk_acc.p,
-                                                e->stream));
-        return GNNVC_OK;
+                                                e->long_thresh, e->stream));
+    } else {
+        HIP_TRY(e, gnnvc::launch_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi,
+                                       e->long_thresh, e->stream));
     }
-    HIP_TRY(e, gnnvc::launch_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi, e->stream));
+    if (longs) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));   // join
     return GNNVC_OK;
 }
 
@@ -437,6 +477,10 @@ void gnnvc_destroy(gnnvc_engine *e) {
     e->scratch[0].release(); e->scratch[1].release();
     e->blk_ptr.release(); e->blk_col.release(); e->blk_scratch.release(); e->blk_flag.release();
     e->blk_acc.release();
+    e->long_list.release(); e->long_count.release();
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->aux_stream) { (void)hipStreamSynchronize(e->aux_stream); (void)hipStreamDestroy(e->aux_stream); }
     for (auto v : e->ev) (void)hipEventDestroy(v);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
@@ -460,6 +504,7 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     if (k == "blocked_stage0") e->opt_blocked = value != 0;
     else if (k == "block_cols") e->opt_block_cols = value > 0 ? (uint32_t)value : 0;
     else if (k == "blocked_min_n") e->opt_blocked_min_n = value > 0 ? (uint32_t)value : 0;
+    else if (k == "long_row_threshold") e->opt_long_thresh = value > 0 ? (uint32_t)value : 0;
     else return fail(e, GNNVC_ERR_INVALID, "unknown option '%s'", key);
     return GNNVC_OK;
 }
@@ -470,6 +515,8 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
     if (k == "blocked_stage0_active") *value = e->blocked_ready ? 1 : 0;
     else if (k == "blocked_blocks") *value = e->blocked_ready ? (long)e->blk_count : 0;
     else if (k == "block_cols") *value = e->blocked_ready ? (long)e->blk_cols : 0;
+    else if (k == "long_rows") *value = (long)e->n_long;
+    else if (k == "long_row_threshold") *value = e->n_long ? (long)e->long_thresh : 0;
     else return GNNVC_ERR_INVALID;
     return GNNVC_OK;
 }
@@ -528,6 +575,8 @@ int gnnvc_upload_graph(gnnvc_engine *e, uint32_t n, const uint64_t *rowptr, cons
     e->have_graph = true;
     rc = reserve_features(e, n);
     if (rc) return rc;
+    rc = find_long(e);
+    if (rc) return rc;
     return build_blocked(e);
 }
 
@@ -541,6 +590,8 @@ int gnnvc_attach_graph_device(gnnvc_engine *e, uint32_t n, uint64_t nnz, const u
     e->g = GraphDev{n, nnz, d_rowptr, d_col, d_w, d_nw};
     e->have_graph = true;
     rc = reserve_features(e, n);
+    if (rc) return rc;
+    rc = find_long(e);
     if (rc) return rc;
     return build_blocked(e);
 }

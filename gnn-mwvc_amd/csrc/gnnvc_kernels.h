@@ -37,20 +37,29 @@ int stage_variant(int f, int n1, int n2, int n3, int sigmoid_last);
 // stage, out = scores[n], logits optional.
 hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
                         const float *in, float *out, float *logits, uint32_t row_lo,
-                        uint32_t row_hi, hipStream_t stream);
+                        uint32_t row_hi, uint32_t long_thresh, hipStream_t stream);
+
+// Long rows (degree >= thresh): listed once per graph, then one workgroup per row per
+// stage (same CSR-order sums).  The tile kernels above skip those rows when given the
+// same threshold; pass 0xFFFFFFFF to make them handle every row.
+hipError_t find_long_rows(const GraphDev &g, uint32_t thresh, uint32_t *list, uint32_t *count,
+                          hipStream_t stream);
+hipError_t launch_long_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
+                             const float *in, float *out, float *logits, uint32_t row_lo, uint32_t row_hi,
+                             const uint32_t *list, uint32_t n_long, hipStream_t stream);
 
 // Column-blocked F = 1 stage (bit-identical to launch_stage on stage 0; see the kernels).
 // bp: uint32[nblocks * n + 1] block-major entry pointers, colb: uint32[nnz + pad] re-bucketed
 // columns, acc: float[n] running sums.  *bad_flag != 0 after the build means the graph's
 // rows are not block-monotone and the plan must not be used.
 size_t blocked_scan_scratch_elems(size_t n_elems);
-hipError_t build_blocked_index(const GraphDev &g, uint32_t wb, uint32_t nblocks, uint32_t *bp,
-                               uint32_t *colb, uint32_t *scratch, uint32_t *bad_flag,
+hipError_t build_blocked_index(const GraphDev &g, uint32_t wb, uint32_t nblocks, uint32_t long_thresh,
+                               uint32_t *bp, uint32_t *colb, uint32_t *scratch, uint32_t *bad_flag,
                                hipStream_t stream);
 hipError_t launch_stage0_blocked(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
                                  const float *x, float *out, uint32_t row_lo, uint32_t row_hi,
                                  uint32_t nblocks, const uint32_t *bp, const uint32_t *colb, float *acc,
-                                 hipStream_t stream);
+                                 uint32_t long_thresh, hipStream_t stream);
 
 // Layer-by-layer kernels (any model; also the layer-level ABI entry points).
 hipError_t launch_graph_layer(const GraphDev &g, float ws, uint32_t f, const float *in,

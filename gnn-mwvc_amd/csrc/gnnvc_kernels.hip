@@ -108,7 +108,7 @@ template <int N1, int N2, int N3, bool SIGMOID, int S>
 __global__ __launch_bounds__(kBlock) void k_stage_f16(
         GraphDev g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
         float *__restrict__ logits, const float *__restrict__ P, uint32_t row_lo,
-        uint32_t row_hi) {
+        uint32_t row_hi, uint32_t long_thresh) {
     __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kRegionFloats];
     const int lane = threadIdx.x & 63;
     float *T = lds[threadIdx.x >> 6];
@@ -123,8 +123,12 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
     const bool valid = u < row_hi;
     const uint32_t uc = valid ? u : row_hi - 1;
     const uint32_t rs = g.rowptr[uc];
-    const uint32_t re = valid ? g.rowptr[uc + 1] : rs;
-    const float f_deg = (float)(re - rs);
+    const uint32_t re_full = valid ? g.rowptr[uc + 1] : rs;
+    // rows of degree >= long_thresh belong to the long-row kernel (k_long_f16): no gather,
+    // no store for them here
+    const bool mine = valid && (re_full - rs) < long_thresh;
+    const uint32_t re = mine ? re_full : rs;
+    const float f_deg = (float)(re_full - rs);
     const float f_w = (float)g.w[uc] / ws;
     const float f_nw = (float)g.nw[uc] / ws;
 
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
 
     if constexpr (SIGMOID) {
         static_assert(N3 == 1, "sigmoid stage ends in one output");
-        if (valid) {
+        if (mine) {
             if (logits) logits[u] = x3[0];
             fout[u] = sigmoid_ref(x3[0]);
         }
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
             const uint32_t row = v0 + 16 * p + q;
             const float *src = &T[(16 * p + q) * kOutPitch + 4 * c];
             const float4 o = make_float4(src[0], src[1], src[2], src[3]);
-            if (row < row_hi) reinterpret_cast<float4 *>(fout)[(size_t)row * 4 + c] = o;
+            if (__shfl((int)mine, 16 * p + q)) reinterpret_cast<float4 *>(fout)[(size_t)row * 4 + c] = o;
         }
     }
 }
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(kBlock) void k_stage_f1(
         GraphDev g, float ws, const float *__restrict__ xin, float *__restrict__ fout,
         const float *__restrict__ P, uint32_t row_lo, uint32_t row_hi,
         const uint32_t *__restrict__ ep, const uint32_t *__restrict__ ecol,
-        const float *__restrict__ acc_in) {
+        const float *__restrict__ acc_in, uint32_t long_thresh) {
     __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kRegionFloats];
     const int lane = threadIdx.x & 63;
     float *T = lds[threadIdx.x >> 6];
@@ -268,9 +272,11 @@ __global__ __launch_bounds__(kBlock) void k_stage_f1(
     const uint32_t u = v0 + lane;
     const bool valid = u < row_hi;
     const uint32_t uc = valid ? u : row_hi - 1;
+    const uint32_t deg = g.rowptr[uc + 1] - g.rowptr[uc];
+    const bool mine = valid && deg < long_thresh;   // long rows belong to k_long_f1
     const uint32_t rs = ep[uc];
-    const uint32_t re = valid ? ep[uc + 1] : rs;
-    const float f_deg = (float)(g.rowptr[uc + 1] - g.rowptr[uc]);
+    const uint32_t re = mine ? ep[uc + 1] : rs;
+    const float f_deg = (float)deg;
 
     const uint32_t c0 = __builtin_amdgcn_readfirstlane(rs);
     const uint32_t vend = (v0 + kWave < row_hi) ? v0 + kWave : row_hi;
@@ -320,8 +326,145 @@ __global__ __launch_bounds__(kBlock) void k_stage_f1(
         const uint32_t row = v0 + 16 * p + q;
         const float *src = &T[(16 * p + q) * kOutPitch + 4 * c];
         const float4 o = make_float4(src[0], src[1], src[2], src[3]);
-        if (row < row_hi) reinterpret_cast<float4 *>(fout)[(size_t)row * 4 + c] = o;
+        if (__shfl((int)mine, 16 * p + q)) reinterpret_cast<float4 *>(fout)[(size_t)row * 4 + c] = o;
     }
+}
+
+// ------------------------------------------------------------------ long rows
+// A row of degree d costs the tile kernels d / S dependent gather rounds, so one
+// hub would hold its wave (and the kernel's tail) for milliseconds.  Rows of
+// degree >= long_thresh are therefore listed once per graph and each gets a whole
+// workgroup: all 256 threads fetch neighbour rows, 256 per round, into a
+// double-buffered LDS slab while the next round's loads are in flight, and ONE
+// lane per feature column adds the slab's rows in CSR order — the same sequential
+// fp32 add chain as everywhere else, so results stay bit-identical.  The row's
+// dense layers then run on one lane.  Runs on a second stream beside the tile
+// kernel of the same stage (disjoint output rows).
+__global__ void k_find_long(GraphDev g, uint32_t thresh, uint32_t *__restrict__ list,
+                            uint32_t *__restrict__ count) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= g.n) return;
+    if (g.rowptr[u + 1] - g.rowptr[u] >= thresh) list[atomicAdd(count, 1u)] = u;
+}
+
+constexpr int kLongChunk = 256;
+
+template <int N1, int N2, int N3, bool SIGMOID>
+__global__ __launch_bounds__(256) void k_long_f16(
+        GraphDev g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
+        float *__restrict__ logits, const float *__restrict__ P, uint32_t row_lo, uint32_t row_hi,
+        const uint32_t *__restrict__ list) {
+    __shared__ __attribute__((aligned(16))) float slab[2][kLongChunk * 16];
+    const uint32_t u = list[blockIdx.x];
+    if (u < row_lo || u >= row_hi) return;   // block-uniform
+    const int tid = threadIdx.x, q = tid >> 2, c = tid & 3;
+    const uint32_t rs = g.rowptr[u], re = g.rowptr[u + 1];
+    const uint32_t deg = re - rs;
+    const uint32_t nchunks = (deg + kLongChunk - 1) / kLongChunk;
+    const uint32_t zrow = g.n;
+    float4 r[4];
+    auto fetch = [&](uint32_t ch) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t e = rs + ch * kLongChunk + q + 64 * j;
+            const uint32_t idx = (e < re) ? g.col[e] : zrow;
+            r[j] = fin[(size_t)idx * 4 + c];
+        }
+    };
+    float acc = 0.0f;   // threads 0..15: feature column tid
+    fetch(0);
+    for (uint32_t ch = 0; ch < nchunks; ++ch) {
+        float *buf = slab[ch & 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(&buf[(q + 64 * j) * 16 + 4 * c]) = r[j];
+        __syncthreads();
+        if (ch + 1 < nchunks) fetch(ch + 1);   // in flight while the adds below run
+        if (tid < 16) {
+            const uint32_t left = deg - ch * kLongChunk;
+            const uint32_t cnt = left < (uint32_t)kLongChunk ? left : (uint32_t)kLongChunk;
+            for (uint32_t k = 0; k < cnt; ++k) acc += buf[k * 16 + tid];
+        }
+        // one barrier per round is enough: slab[ch & 1] is rewritten in round ch + 2, after
+        // every thread has passed the barrier of round ch + 1, which the adders reach last
+    }
+    __syncthreads();
+    if (tid < 16) slab[0][tid] = acc;
+    __syncthreads();
+    if (tid != 0) return;
+    float x0[32];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x0[j] = slab[0][j];
+    const float4 h0 = fin[(size_t)u * 4 + 0], h1 = fin[(size_t)u * 4 + 1];
+    const float4 h2 = fin[(size_t)u * 4 + 2], h3 = fin[(size_t)u * 4 + 3];
+    x0[16] = h0.x;
+    x0[17] = (float)deg;
+    x0[18] = (float)g.w[u] / ws;
+    x0[19] = (float)g.nw[u] / ws;
+    x0[20] = h1.x; x0[21] = h1.y; x0[22] = h1.z; x0[23] = h1.w;
+    x0[24] = h2.x; x0[25] = h2.y; x0[26] = h2.z; x0[27] = h2.w;
+    x0[28] = h3.x; x0[29] = h3.y; x0[30] = h3.z; x0[31] = h3.w;
+    const float *W1 = P, *b1 = W1 + 35 * N1;
+    const float *W2 = b1 + N1, *b2 = W2 + N1 * N2;
+    const float *W3 = b2 + N2, *b3 = W3 + N2 * N3;
+    float x1[N1], x2[N2], x3[N3];
+    dense<32, 32, N1, 0>(x0, x1, W1, b1);
+    dense<N1, N1, N2, 0>(x1, x2, W2, b2);
+    dense<N2, N2, N3, SIGMOID ? 1 : 0>(x2, x3, W3, b3);
+    if constexpr (SIGMOID) {
+        if (logits) logits[u] = x3[0];
+        fout[u] = sigmoid_ref(x3[0]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < N3; ++j) fout[(size_t)u * N3 + j] = x3[j];
+    }
+}
+
+template <int N1, int N2, int N3>
+__global__ __launch_bounds__(256) void k_long_f1(
+        GraphDev g, float ws, const float *__restrict__ xin, float *__restrict__ fout,
+        const float *__restrict__ P, uint32_t row_lo, uint32_t row_hi,
+        const uint32_t *__restrict__ list) {
+    __shared__ float slab[2][kLongChunk];
+    const uint32_t u = list[blockIdx.x];
+    if (u < row_lo || u >= row_hi) return;
+    const int tid = threadIdx.x;
+    const uint32_t rs = g.rowptr[u], re = g.rowptr[u + 1];
+    const uint32_t deg = re - rs;
+    const uint32_t nchunks = (deg + kLongChunk - 1) / kLongChunk;
+    float v = 0.0f;
+    auto fetch = [&](uint32_t ch) {
+        const uint32_t e = rs + ch * kLongChunk + tid;
+        v = (e < re) ? xin[g.col[e]] : 0.0f;
+    };
+    float agg = 0.0f;
+    fetch(0);
+    for (uint32_t ch = 0; ch < nchunks; ++ch) {
+        float *buf = slab[ch & 1];
+        buf[tid] = v;
+        __syncthreads();
+        if (ch + 1 < nchunks) fetch(ch + 1);
+        if (tid == 0) {
+            const uint32_t left = deg - ch * kLongChunk;
+            const uint32_t cnt = left < (uint32_t)kLongChunk ? left : (uint32_t)kLongChunk;
+            for (uint32_t k = 0; k < cnt; ++k) agg += buf[k];
+        }
+    }
+    if (tid != 0) return;
+    float x0[5];
+    x0[0] = agg;
+    x0[1] = xin[u];
+    x0[2] = (float)deg;
+    x0[3] = (float)g.w[u] / ws;
+    x0[4] = (float)g.nw[u] / ws;
+    const float *W1 = P, *b1 = W1 + 5 * N1;
+    const float *W2 = b1 + N1, *b2 = W2 + N1 * N2;
+    const float *W3 = b2 + N2, *b3 = W3 + N2 * N3;
+    float x1[N1], x2[N2], x3[N3];
+    dense<5, 5, N1, 0>(x0, x1, W1, b1);
+    dense<N1, N1, N2, 0>(x1, x2, W2, b2);
+    dense<N2, N2, N3, 0>(x2, x3, W3, b3);
+#pragma unroll
+    for (int j = 0; j < N3; ++j) fout[(size_t)u * N3 + j] = x3[j];
 }
 
 // ------------------------------------------------------------------ column-blocked F = 1 aggregation
@@ -338,11 +481,12 @@ __global__ __launch_bounds__(kBlock) void k_stage_f1(
 
 // pass 1: cnt[k*N + u] = entries of row u in block k (buffer pre-zeroed); flags a
 // row whose block ids decrease (then the blocked plan is not exact and is not used).
-__global__ void k_blk_count(GraphDev g, uint32_t wb, uint32_t *__restrict__ cnt,
+__global__ void k_blk_count(GraphDev g, uint32_t wb, uint32_t long_thresh, uint32_t *__restrict__ cnt,
                             uint32_t *__restrict__ bad) {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= g.n) return;
     const uint32_t rs = g.rowptr[u], re = g.rowptr[u + 1];
+    if (re - rs >= long_thresh) return;   // long rows are summed by k_long_f1, not per block
     uint32_t kcur = 0, run = 0;
     for (uint32_t e = rs; e < re; ++e) {
         const uint32_t k = g.col[e] / wb;
@@ -358,11 +502,12 @@ __global__ void k_blk_count(GraphDev g, uint32_t wb, uint32_t *__restrict__ cnt,
 }
 
 // pass 3: scatter the entries to block-major order (bp = exclusive scan of cnt).
-__global__ void k_blk_scatter(GraphDev g, uint32_t wb, const uint32_t *__restrict__ bp,
-                              uint32_t *__restrict__ colb) {
+__global__ void k_blk_scatter(GraphDev g, uint32_t wb, uint32_t long_thresh,
+                              const uint32_t *__restrict__ bp, uint32_t *__restrict__ colb) {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= g.n) return;
     const uint32_t rs = g.rowptr[u], re = g.rowptr[u + 1];
+    if (re - rs >= long_thresh) return;
     uint32_t kcur = 0xFFFFFFFFu, dst = 0;
     for (uint32_t e = rs; e < re; ++e) {
         const uint32_t c = g.col[e];
@@ -408,7 +553,10 @@ __global__ void k_scan_add(uint32_t *__restrict__ data, size_t n, const uint32_t
     if (i < n) data[i] += offs[i / kScanChunk];
 }
 
-// one launch per column block except the last: acc[u] (+)= sum of x over row u's entries in block k
+// one launch per column block except the last: acc[u] (+)= sum of x over row u's entries in
+// block k, in stored order.  A row has only a few entries per block; the first four are
+// fetched together (index loads, then x loads, in parallel) so a thread pays two memory
+// latencies instead of two per entry.
 __global__ __launch_bounds__(256) void k_blk_accumulate(const uint32_t *__restrict__ bpk,
                                                         const uint32_t *__restrict__ colb,
                                                         const float *__restrict__ xin,
@@ -418,7 +566,20 @@ __global__ __launch_bounds__(256) void k_blk_accumulate(const uint32_t *__restri
     if (u >= row_hi) return;
     const uint32_t s = bpk[u], t = bpk[u + 1];
     float a = first ? 0.0f : acc[u];
-    for (uint32_t e = s; e < t; ++e) a += xin[colb[e]];
+    if (s == t) {
+        if (first) acc[u] = a;
+        return;
+    }
+    constexpr int U = 4;
+    uint32_t c[U];
+    float v[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) c[i] = colb[s + i];            // colb is padded past nnz
+#pragma unroll
+    for (int i = 0; i < U; ++i) v[i] = xin[(s + i < t) ? c[i] : c[0]];
+#pragma unroll
+    for (int i = 0; i < U; ++i) a += (s + i < t) ? v[i] : 0.0f;  // a is never -0.0f: + 0.0f is exact
+    for (uint32_t e = s + U; e < t; ++e) a += xin[colb[e]];
     acc[u] = a;
 }
 
@@ -506,7 +667,7 @@ int stage_variant(int f, int n1, int n2, int n3, int sigmoid_last) {
 
 hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
                         const float *in, float *out, float *logits, uint32_t row_lo,
-                        uint32_t row_hi, hipStream_t stream) {
+                        uint32_t row_hi, uint32_t long_thresh, hipStream_t stream) {
     if (row_hi <= row_lo) return hipSuccess;
     const uint32_t ntiles = (row_hi - row_lo + kWave - 1) / kWave;
     const uint32_t per_xcd = (ntiles + 7) / 8;
@@ -516,15 +677,15 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
     switch (sp.variant) {
     case 0:
         hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4>), grid, block, 0, stream, g, ws, in, out, P,
-                           row_lo, row_hi, g.rowptr, g.col, static_cast<const float *>(nullptr));
+                           row_lo, row_hi, g.rowptr, g.col, static_cast<const float *>(nullptr), long_thresh);
         break;
     case 1:
         hipLaunchKernelGGL((k_stage_f16<32, 32, 16, false, 2>), grid, block, 0, stream, g, ws,
-                           reinterpret_cast<const float4 *>(in), out, nullptr, P, row_lo, row_hi);
+                           reinterpret_cast<const float4 *>(in), out, nullptr, P, row_lo, row_hi, long_thresh);
         break;
     case 2:
         hipLaunchKernelGGL((k_stage_f16<32, 16, 1, true, 2>), grid, block, 0, stream, g, ws,
-                           reinterpret_cast<const float4 *>(in), out, logits, P, row_lo, row_hi);
+                           reinterpret_cast<const float4 *>(in), out, logits, P, row_lo, row_hi, long_thresh);
         break;
     default:
         return hipErrorInvalidValue;
@@ -591,8 +752,8 @@ static hipError_t scan_u32(uint32_t *data, size_t n, uint32_t *scratch, hipStrea
 
 size_t blocked_scan_scratch_elems(size_t n_elems) { return n_elems / 2048 + 8192; }
 
-hipError_t build_blocked_index(const GraphDev &g, uint32_t wb, uint32_t nblocks, uint32_t *bp,
-                               uint32_t *colb, uint32_t *scratch, uint32_t *bad_flag,
+hipError_t build_blocked_index(const GraphDev &g, uint32_t wb, uint32_t nblocks, uint32_t long_thresh,
+                               uint32_t *bp, uint32_t *colb, uint32_t *scratch, uint32_t *bad_flag,
                                hipStream_t stream) {
     const size_t elems = (size_t)nblocks * g.n + 1;
     hipError_t rc = hipMemsetAsync(bp, 0, elems * sizeof(uint32_t), stream);
@@ -600,17 +761,17 @@ hipError_t build_blocked_index(const GraphDev &g, uint32_t wb, uint32_t nblocks,
     rc = hipMemsetAsync(bad_flag, 0, sizeof(uint32_t), stream);
     if (rc != hipSuccess) return rc;
     const unsigned nb = (g.n + 255) / 256;
-    hipLaunchKernelGGL(k_blk_count, dim3(nb), dim3(256), 0, stream, g, wb, bp, bad_flag);
+    hipLaunchKernelGGL(k_blk_count, dim3(nb), dim3(256), 0, stream, g, wb, long_thresh, bp, bad_flag);
     rc = scan_u32(bp, elems, scratch, stream);
     if (rc != hipSuccess) return rc;
-    hipLaunchKernelGGL(k_blk_scatter, dim3(nb), dim3(256), 0, stream, g, wb, bp, colb);
+    hipLaunchKernelGGL(k_blk_scatter, dim3(nb), dim3(256), 0, stream, g, wb, long_thresh, bp, colb);
     return hipGetLastError();
 }
 
 hipError_t launch_stage0_blocked(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
                                  const float *x, float *out, uint32_t row_lo, uint32_t row_hi,
                                  uint32_t nblocks, const uint32_t *bp, const uint32_t *colb, float *acc,
-                                 hipStream_t stream) {
+                                 uint32_t long_thresh, hipStream_t stream) {
     if (row_hi <= row_lo) return hipSuccess;
     if (sp.variant != 0) return hipErrorInvalidValue;
     const unsigned nb = (row_hi - row_lo + 255) / 256;
@@ -623,7 +784,41 @@ hipError_t launch_stage0_blocked(const StagePlan &sp, const GraphDev &g, float w
     hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4>), dim3(blocks_per_xcd * 8), dim3(kBlock), 0, stream, g, ws,
                        x, out, params + sp.param_offset, row_lo, row_hi,
                        bp + (size_t)(nblocks - 1) * g.n, colb,
-                       nblocks > 1 ? static_cast<const float *>(acc) : static_cast<const float *>(nullptr));
+                       nblocks > 1 ? static_cast<const float *>(acc) : static_cast<const float *>(nullptr),
+                       long_thresh);
+    return hipGetLastError();
+}
+
+// ---- long rows --------------------------------------------------------------------------
+hipError_t find_long_rows(const GraphDev &g, uint32_t thresh, uint32_t *list, uint32_t *count,
+                          hipStream_t stream) {
+    hipError_t rc = hipMemsetAsync(count, 0, sizeof(uint32_t), stream);
+    if (rc != hipSuccess || g.n == 0) return rc;
+    hipLaunchKernelGGL(k_find_long, dim3((g.n + 255) / 256), dim3(256), 0, stream, g, thresh, list, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_long_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
+                             const float *in, float *out, float *logits, uint32_t row_lo, uint32_t row_hi,
+                             const uint32_t *list, uint32_t n_long, hipStream_t stream) {
+    if (n_long == 0 || row_hi <= row_lo) return hipSuccess;
+    const float *P = params + sp.param_offset;
+    const dim3 grid(n_long), block(256);
+    switch (sp.variant) {
+    case 0:
+        hipLaunchKernelGGL((k_long_f1<32, 32, 16>), grid, block, 0, stream, g, ws, in, out, P, row_lo, row_hi, list);
+        break;
+    case 1:
+        hipLaunchKernelGGL((k_long_f16<32, 32, 16, false>), grid, block, 0, stream, g, ws,
+                           reinterpret_cast<const float4 *>(in), out, nullptr, P, row_lo, row_hi, list);
+        break;
+    case 2:
+        hipLaunchKernelGGL((k_long_f16<32, 16, 1, true>), grid, block, 0, stream, g, ws,
+                           reinterpret_cast<const float4 *>(in), out, logits, P, row_lo, row_hi, list);
+        break;
+    default:
+        return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

@@ -72,7 +72,10 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *                         bit-identical either way, it only changes memory traffic)
  *   "block_cols"     n    vertices per column block (default 524288 = 2 MiB of x)
  *   "blocked_min_n"  n    graphs with fewer vertices are not blocked (default 2^20)
- * gnnvc_get_info keys: "blocked_stage0_active", "blocked_blocks", "block_cols". */
+ *   "long_row_threshold" d  rows of degree >= d get a workgroup of their own (default 512,
+ *                         0 = off); same CSR-order sums, bit-identical results
+ * gnnvc_get_info keys: "blocked_stage0_active", "blocked_blocks", "block_cols", "long_rows",
+ * "long_row_threshold". */
 int gnnvc_set_option(gnnvc_engine *e, const char *key, long value);
 int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value);
 

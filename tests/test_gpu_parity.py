@@ -329,3 +329,49 @@ def test_unsorted_adjacency_falls_back_to_stored_order(model_text, oracle_model)
         assert not np.array_equal(bits(want), bits(oracle_model.logits(g)))
     finally:
         e.close()
+
+
+# ---------------------------------------------------------------- long-row path
+
+@pytest.mark.parametrize("thresh,block_cols", [(8, 0), (64, 0), (300, 0), (0, 0), (16, 512), (1000, 2048)])
+def test_long_row_path_is_bit_identical(model_text, oracle_model, thresh, block_cols):
+    """Rows of degree >= threshold are summed by a workgroup of their own (k_long_*), on a
+    second stream beside the tile kernel — same CSR-order add chain, so same bits; also in
+    combination with the column-blocked stage 0."""
+    import gnn_mwvc_amd as G
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_option("long_row_threshold", thresh)
+        if block_cols:
+            e.set_option("blocked_min_n", 0)
+            e.set_option("block_cols", block_cols)
+        graphs = [gg.hub_graph(20000, 60000, 3, 4096, seed=7), gg.rmat(11, 16, 5),
+                  gg.erdos_renyi(3000, 30000, 41),
+                  gg.from_edge_list(700, [(0, i) for i in range(1, 700)] + [(1, i) for i in range(2, 300)],
+                                    [20 + (i % 101) for i in range(700)])]
+        for g in graphs:
+            e.set_weight_scale(g.ws)
+            oracle_model.set_weight_scale(g.ws)
+            e.upload_graph(g)
+            deg = np.diff(g.rowptr.astype(np.int64))
+            want_long = int((deg >= thresh).sum()) if thresh else 0
+            assert e.get_info("long_rows") == want_long
+            scores, logits = e.forward(g.x())
+            assert np.array_equal(bits(logits[:, 0]), bits(oracle_model.logits(g)))
+            assert ulp(scores[:, 0], oracle_model.scores(g)).max() <= 1
+            # a vertex sub-range through the stage entry point (partitioned execution)
+            import torch
+            dev = torch.device("cuda:0")
+            x = torch.from_numpy(g.x()).to(dev)
+            h1 = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+            h2 = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+            mid = (g.n // 3) // 64 * 64
+            for lo, hi in ((0, mid), (mid, g.n)):
+                e.stage_forward_device(0, lo, hi, x.data_ptr(), h1.data_ptr())
+            for lo, hi in ((0, mid), (mid, g.n)):
+                e.stage_forward_device(1, lo, hi, h1.data_ptr(), h2.data_ptr())
+            e.synchronize()
+            assert np.array_equal(bits(h2[:-1].cpu().numpy()), bits(oracle_model.predict(g, g.x(), stop_after=13)))
+    finally:
+        e.close()

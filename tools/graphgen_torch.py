@@ -92,6 +92,52 @@ def erdos_renyi(n: int, m: int, seed: int, device, lo: int = 20, hi: int = 120) 
     return csr_from_unique_pairs(n, key, w)
 
 
+def rmat(scale: int, edge_factor: int, seed: int, device, a=0.57, b=0.19, c=0.19) -> DeviceCsr:
+    """R-MAT (0.57, 0.19, 0.19, 0.05), duplicates and self-loops removed, symmetrised."""
+    n = 1 << scale
+    m = n * edge_factor
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    u = torch.zeros(m, dtype=torch.int64, device=device)
+    v = torch.zeros(m, dtype=torch.int64, device=device)
+    for bit in range(scale):
+        r = torch.rand(m, generator=gen, device=device)
+        u |= (r >= a + b).to(torch.int64) << bit
+        v |= (((r >= a) & (r < a + b)) | (r >= a + b + c)).to(torch.int64) << bit
+        del r
+    keep = u != v
+    u, v = u[keep], v[keep]
+    key = torch.unique(torch.minimum(u, v) * n + torch.maximum(u, v))
+    del u, v, keep
+    w = torch.randint(20, 121, (n,), generator=gen, device=device, dtype=torch.int64)
+    return csr_from_unique_pairs(n, key, w)
+
+
+def power_law_hubs(n: int, avg_degree: float, exponent: float, hubs: int, hub_degree: int, seed: int,
+                   device) -> DeviceCsr:
+    """Chung-Lu power-law background plus `hubs` vertices of exactly `hub_degree`
+    distinct neighbours (BASELINE.json config 5)."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    ranks = torch.arange(1, n + 1, dtype=torch.float64, device=device)
+    p = ranks ** (-1.0 / (exponent - 1.0))
+    m = int(n * avg_degree / 2)
+    cdf = torch.cumsum(p / p.sum(), 0)
+    draw = lambda: torch.searchsorted(cdf, torch.rand(m, generator=gen, device=device, dtype=torch.float64)).clamp_(max=n - 1)
+    perm = torch.randperm(n, generator=gen, device=device)
+    u, v = perm[draw()], perm[draw()]
+    keep = (u != v) & (u >= hubs) & (v >= hubs)
+    u, v = u[keep], v[keep]
+    hu = torch.arange(hubs, device=device).repeat_interleave(hub_degree)
+    hv = torch.cat([torch.randperm(n - hubs, generator=gen, device=device)[:hub_degree] + hubs
+                    for _ in range(hubs)]) if hubs else torch.zeros(0, dtype=torch.int64, device=device)
+    u = torch.cat([u, hu])
+    v = torch.cat([v, hv])
+    key = torch.unique(torch.minimum(u, v) * n + torch.maximum(u, v))
+    w = torch.randint(20, 121, (n,), generator=gen, device=device, dtype=torch.int64)
+    return csr_from_unique_pairs(n, key, w)
+
+
 def from_host(g, device) -> DeviceCsr:
     """tools.graphgen.CsrGraph -> device CSR."""
     import numpy as np
