@@ -349,8 +349,46 @@ __global__ void k_find_long(GraphDev g, uint32_t thresh, uint32_t *__restrict__ 
 
 constexpr int kLongChunk = 256;
 
+// One round of the long-row kernel: the 1024 rows a workgroup holds in registers (16 per
+// quad: rows q + 64 j of the round) go through the LDS slab 256 at a time and threads
+// 0..15 add them, column by column, in CSR order.
+constexpr int kLongR = 16;
+constexpr uint32_t kLongRound = 64 * kLongR;
+// first-class vector type (HIP's float4 is a struct: arrays of it that live across loop
+// iterations are not promoted to registers)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void long_drain_round(const f32x4 (&rows)[kLongR], float (&slab)[2][kLongChunk * 16],
+                                                 uint32_t left_round, int tid, int q, int c, float &acc) {
+#pragma unroll
+    for (int sub = 0; sub < kLongR / 4; ++sub) {
+        // slab row k of this quarter = neighbour sub*256 + k of the round  <->  (j = 4 sub + k / 64, q = k % 64)
+        if ((uint32_t)(sub * kLongChunk) < left_round) {   // block-uniform
+            float *buf = slab[sub & 1];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                *reinterpret_cast<f32x4 *>(&buf[(q + 64 * jj) * 16 + 4 * c]) = rows[4 * sub + jj];
+            __syncthreads();
+            if (tid < 16) {
+                const uint32_t left = left_round - sub * kLongChunk;
+                const uint32_t cnt = left < (uint32_t)kLongChunk ? left : (uint32_t)kLongChunk;
+                uint32_t k = 0;
+                for (; k + 64 <= cnt; k += 64) {   // 64 LDS reads in flight, then 64 ordered adds:
+                    float t[64];                   // the add chain, not the LDS latency, paces the row
+#pragma unroll
+                    for (int j = 0; j < 64; ++j) t[j] = buf[(k + j) * 16 + tid];
+#pragma unroll
+                    for (int j = 0; j < 64; ++j) acc += t[j];
+                }
+                for (; k < cnt; ++k) acc += buf[k * 16 + tid];
+            }
+            // slab[sub & 1] is rewritten two quarters later, after the barrier of the next
+            // quarter, which the adders reach only when these reads are done
+        }
+    }
+}
+
 template <int N1, int N2, int N3, bool SIGMOID>
-__global__ __launch_bounds__(256) void k_long_f16(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_long_f16(
         GraphDev g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
         float *__restrict__ logits, const float *__restrict__ P, uint32_t row_lo, uint32_t row_hi,
         const uint32_t *__restrict__ list) {
@@ -360,33 +398,44 @@ __global__ __launch_bounds__(256) void k_long_f16(
     const int tid = threadIdx.x, q = tid >> 2, c = tid & 3;
     const uint32_t rs = g.rowptr[u], re = g.rowptr[u + 1];
     const uint32_t deg = re - rs;
-    const uint32_t nchunks = (deg + kLongChunk - 1) / kLongChunk;
     const uint32_t zrow = g.n;
-    float4 r[4];
-    auto fetch = [&](uint32_t ch) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t e = rs + ch * kLongChunk + q + 64 * j;
-            const uint32_t idx = (e < re) ? g.col[e] : zrow;
-            r[j] = fin[(size_t)idx * 4 + c];
-        }
-    };
-    float acc = 0.0f;   // threads 0..15: feature column tid
-    fetch(0);
-    for (uint32_t ch = 0; ch < nchunks; ++ch) {
-        float *buf = slab[ch & 1];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(&buf[(q + 64 * j) * 16 + 4 * c]) = r[j];
-        __syncthreads();
-        if (ch + 1 < nchunks) fetch(ch + 1);   // in flight while the adds below run
-        if (tid < 16) {
-            const uint32_t left = deg - ch * kLongChunk;
-            const uint32_t cnt = left < (uint32_t)kLongChunk ? left : (uint32_t)kLongChunk;
-            for (uint32_t k = 0; k < cnt; ++k) acc += buf[k * 16 + tid];
-        }
-        // one barrier per round is enough: slab[ch & 1] is rewritten in round ch + 2, after
-        // every thread has passed the barrier of round ch + 1, which the adders reach last
+    // Two register sets (A, B) alternate: while one round drains through the slab, the
+    // 1024 row fetches of the next round and the column indices of the round after it are
+    // in flight, so neither memory latency sits on the sequential add chain.
+    constexpr int R = kLongR;
+    constexpr uint32_t kRound = kLongRound;
+    const uint32_t nrounds = (deg + kRound - 1) / kRound;
+    uint32_t idx[R];
+    f32x4 ra[R], rb[R];
+    const f32x4 *__restrict__ fv = reinterpret_cast<const f32x4 *>(fin);
+#define GNNVC_FETCH_IDX(rd_)                                              \
+    _Pragma("unroll") for (int j = 0; j < R; ++j) {                        \
+        const uint32_t e_ = rs + (rd_) * kRound + q + 64 * j;             \
+        idx[j] = g.col[e_ < re ? e_ : re - 1]; /* raw: not consumed until the next round */ \
     }
+#define GNNVC_FETCH_ROWS(dst_, rd_)                                       \
+    _Pragma("unroll") for (int j = 0; j < R; ++j) {                        \
+        const uint32_t e_ = rs + (rd_) * kRound + q + 64 * j;             \
+        dst_[j] = fv[(size_t)((e_ < re) ? idx[j] : zrow) * 4 + c];        \
+    }
+    float acc = 0.0f;   // threads 0..15: feature column tid
+    // Every fetch below is unconditional (past the row's end the indices clamp to its last
+    // entry and the rows to the zero row): only then can the compiler prove how many younger
+    // loads are outstanding and wait for exactly the round being drained (vmcnt is in-order).
+    GNNVC_FETCH_IDX(0u)
+    GNNVC_FETCH_ROWS(ra, 0u)
+    GNNVC_FETCH_IDX(1u)
+    for (uint32_t rd = 0; rd < nrounds; rd += 2) {
+        GNNVC_FETCH_ROWS(rb, rd + 1)
+        GNNVC_FETCH_IDX(rd + 2)
+        long_drain_round(ra, slab, deg - rd * kRound, tid, q, c, acc);
+        if (rd + 1 >= nrounds) break;
+        GNNVC_FETCH_ROWS(ra, rd + 2)
+        GNNVC_FETCH_IDX(rd + 3)
+        long_drain_round(rb, slab, deg - (rd + 1) * kRound, tid, q, c, acc);
+    }
+#undef GNNVC_FETCH_IDX
+#undef GNNVC_FETCH_ROWS
     __syncthreads();
     if (tid < 16) slab[0][tid] = acc;
     __syncthreads();
@@ -424,31 +473,54 @@ __global__ __launch_bounds__(256) void k_long_f1(
         GraphDev g, float ws, const float *__restrict__ xin, float *__restrict__ fout,
         const float *__restrict__ P, uint32_t row_lo, uint32_t row_hi,
         const uint32_t *__restrict__ list) {
-    __shared__ float slab[2][kLongChunk];
+    // a round = 2048 neighbours (8 per thread); values of round r + 1 and column indices of
+    // round r + 2 are in flight while thread 0 adds round r from the LDS slab in CSR order
+    constexpr int R = 8;
+    constexpr uint32_t kRound = 256 * R;
+    __shared__ __attribute__((aligned(16))) float slab[2][kRound];
     const uint32_t u = list[blockIdx.x];
     if (u < row_lo || u >= row_hi) return;
     const int tid = threadIdx.x;
     const uint32_t rs = g.rowptr[u], re = g.rowptr[u + 1];
     const uint32_t deg = re - rs;
-    const uint32_t nchunks = (deg + kLongChunk - 1) / kLongChunk;
-    float v = 0.0f;
-    auto fetch = [&](uint32_t ch) {
-        const uint32_t e = rs + ch * kLongChunk + tid;
-        v = (e < re) ? xin[g.col[e]] : 0.0f;
-    };
-    float agg = 0.0f;
-    fetch(0);
-    for (uint32_t ch = 0; ch < nchunks; ++ch) {
-        float *buf = slab[ch & 1];
-        buf[tid] = v;
-        __syncthreads();
-        if (ch + 1 < nchunks) fetch(ch + 1);
-        if (tid == 0) {
-            const uint32_t left = deg - ch * kLongChunk;
-            const uint32_t cnt = left < (uint32_t)kLongChunk ? left : (uint32_t)kLongChunk;
-            for (uint32_t k = 0; k < cnt; ++k) agg += buf[k];
-        }
+    const uint32_t nrounds = (deg + kRound - 1) / kRound;
+    uint32_t idx[R];
+    float v[R];
+#define GNNVC_FETCH_IDX1(rd_)                                             \
+    _Pragma("unroll") for (int j = 0; j < R; ++j) {                        \
+        const uint32_t e_ = rs + (rd_) * kRound + tid + 256 * j;          \
+        idx[j] = g.col[e_ < re ? e_ : re - 1];                            \
     }
+#define GNNVC_FETCH_VAL1(rd_)                                             \
+    _Pragma("unroll") for (int j = 0; j < R; ++j) v[j] = xin[idx[j]]; /* raw: masked when written to the slab */
+    float agg = 0.0f;
+    GNNVC_FETCH_IDX1(0u)
+    GNNVC_FETCH_VAL1(0u)
+    GNNVC_FETCH_IDX1(1u)
+    for (uint32_t rd = 0; rd < nrounds; ++rd) {
+        float *buf = slab[rd & 1];
+#pragma unroll
+        for (int j = 0; j < R; ++j) buf[tid + 256 * j] = v[j];   // entries past the row's end are never added
+        __syncthreads();
+        GNNVC_FETCH_VAL1(rd + 1)      // unconditional (clamped), see k_long_f16
+        GNNVC_FETCH_IDX1(rd + 2)
+        if (tid == 0) {
+            const uint32_t left = deg - rd * kRound;
+            const uint32_t cnt = left < kRound ? left : kRound;
+            uint32_t k = 0;
+            for (; k + 64 <= cnt; k += 64) {
+                float t[64];
+#pragma unroll
+                for (int j = 0; j < 64; ++j) t[j] = buf[k + j];
+#pragma unroll
+                for (int j = 0; j < 64; ++j) agg += t[j];
+            }
+            for (; k < cnt; ++k) agg += buf[k];
+        }
+        // slab[rd & 1] is rewritten in round rd + 2, behind the barrier of round rd + 1
+    }
+#undef GNNVC_FETCH_IDX1
+#undef GNNVC_FETCH_VAL1
     if (tid != 0) return;
     float x0[5];
     x0[0] = agg;
