@@ -77,6 +77,7 @@ def main() -> int:
     ap.add_argument("--no-blocked", action="store_true", help="disable the column-blocked F=1 stage (A/B)")
     ap.add_argument("--block-cols", type=int, default=0)
     ap.add_argument("--long-threshold", type=int, default=-1, help="degree at which a row gets its own workgroup")
+    ap.add_argument("--mfma", type=int, default=-1, help="dense layers: 0 VALU, 1 MFMA everywhere, 2 MFMA in the 16-wide stages (default)")
     ap.add_argument("--host-path", action="store_true",
                     help="also time the host-pointer path (PCIe inclusive), reported separately")
     args = ap.parse_args()
@@ -117,6 +118,8 @@ def main() -> int:
         eng.set_option("block_cols", args.block_cols)
     if args.long_threshold >= 0:
         eng.set_option("long_row_threshold", args.long_threshold)
+    if args.mfma >= 0:
+        eng.set_option("mfma_dense", args.mfma)
     t0 = time.time()
     eng.attach_graph_device(g.n, g.nnz, g.rowptr.data_ptr(), g.col.data_ptr(), g.w.data_ptr(),
                             g.nw.data_ptr(), keepalive=g)
@@ -210,7 +213,7 @@ def main() -> int:
         "stage_ms": stage_ms, "graph_build_s": t_gen, "graph_attach_s": t_attach,
         "plan": {"blocked_stage0": bool(eng.get_info("blocked_stage0_active")),
                  "column_blocks": eng.get_info("blocked_blocks"), "block_cols": eng.get_info("block_cols"),
-                 "long_rows": eng.get_info("long_rows"), "long_row_threshold": eng.get_info("long_row_threshold")},
+                 "mfma_dense": eng.get_info("mfma_dense"), "long_rows": eng.get_info("long_rows"), "long_row_threshold": eng.get_info("long_row_threshold")},
     }
 
     if rank == 0 and world == 1:

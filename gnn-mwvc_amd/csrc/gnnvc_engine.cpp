@@ -88,6 +88,12 @@ struct gnnvc_engine {
     DevBuf<uint32_t> blk_ptr, blk_col, blk_scratch, blk_flag;
     DevBuf<float> blk_acc;
 
+    // option "mfma_dense": dense layers on the matrix cores (bit-identical to the VALU path).
+    // 0 = VALU everywhere, 1 = MFMA everywhere, 2 = MFMA in the F = 16 stages only (default:
+    // the F = 1 stage's first layer has K = 5 and stays on the VALU, and sending its 32
+    // activations through LDS just to reach the matrix layout costs more than it saves)
+    int opt_mfma = 2;
+
     // long rows (degree >= long_thresh): one workgroup each, on aux_stream beside the tile kernel
     uint32_t opt_long_thresh = 512;   // option "long_row_threshold" (0 = off)
     uint32_t long_thresh = 0xFFFFFFFFu, n_long = 0;
@@ -339,10 +345,11 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
     if (stage == 0 && e->blocked_ready) {
         HIP_TRY(e, gnnvc::launch_stage0_blocked(e->stages[0], e->g, e->ws, e->params.p, in, out, lo, hi,
                                                 e->blk_count, e->blk_ptr.p, e->blk_col.p, e->blk_acc.p,
-                                                e->long_thresh, e->stream));
+                                                e->long_thresh, e->opt_mfma == 1, e->stream));
     } else {
+        const bool mfma = e->opt_mfma == 1 || (e->opt_mfma == 2 && e->stages[stage].f == 16);
         HIP_TRY(e, gnnvc::launch_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi,
-                                       e->long_thresh, e->stream));
+                                       e->long_thresh, mfma, e->stream));
     }
     if (longs) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));   // join
     return GNNVC_OK;
@@ -505,6 +512,7 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "block_cols") e->opt_block_cols = value > 0 ? (uint32_t)value : 0;
     else if (k == "blocked_min_n") e->opt_blocked_min_n = value > 0 ? (uint32_t)value : 0;
     else if (k == "long_row_threshold") e->opt_long_thresh = value > 0 ? (uint32_t)value : 0;
+    else if (k == "mfma_dense") e->opt_mfma = (value >= 0 && value <= 2) ? (int)value : 2;
     else return fail(e, GNNVC_ERR_INVALID, "unknown option '%s'", key);
     return GNNVC_OK;
 }
@@ -516,6 +524,7 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
     else if (k == "blocked_blocks") *value = e->blocked_ready ? (long)e->blk_count : 0;
     else if (k == "block_cols") *value = e->blocked_ready ? (long)e->blk_cols : 0;
     else if (k == "long_rows") *value = (long)e->n_long;
+    else if (k == "mfma_dense") *value = e->opt_mfma;
     else if (k == "long_row_threshold") *value = e->n_long ? (long)e->long_thresh : 0;
     else return GNNVC_ERR_INVALID;
     return GNNVC_OK;

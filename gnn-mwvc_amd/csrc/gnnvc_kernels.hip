@@ -78,10 +78,11 @@ __device__ __forceinline__ uint32_t tile_for_wave(uint32_t ntiles) {
 //   1. column-index stage: the tile's slice of `col` (all entries of its 64 rows),
 //      fetched with full-line coalesced loads so every 128-byte line of `col` is
 //      requested from L2 exactly once per tile;
-//   2. dense-layer input tile: 64 rows x 29 floats [aggregate 0..15 | h0, h4..h15];
+//   2. dense-layer input tile: 64 rows x 32 floats in the first layer's k order
+//      [aggregate 0..15 | h0 | degree | W/ws | NW/ws | h4..h15], pitch 33;
 //   3. output tile: 64 rows x 17 floats, read back row-wise for full-row stores.
-constexpr int kRegionFloats = 1856;          // 7424 B per wave, 29 KiB per workgroup
-constexpr int kInPitch = 29;                 // odd pitch: conflict-free ds_read_b32 down a column
+constexpr int kRegionFloats = 2112;          // 8448 B per wave, 33 KiB per workgroup
+constexpr int kInPitch = 33;                 // 32 inputs in k order; odd pitch: conflict-free ds_read_b32 down a column
 constexpr int kOutPitch = 17;
 constexpr uint32_t kStageCap = 1792 - 4;     // most col entries a tile may stage (7 x 256 minus alignment slack)
 static_assert(kWave * kInPitch <= kRegionFloats && 1792 <= kRegionFloats, "region too small");
@@ -98,13 +99,139 @@ __device__ __forceinline__ uint32_t stage_cols(const uint32_t *__restrict__ col,
     return base;
 }
 
+// ------------------------------------------------------------------ dense layers on the matrix cores
+// fp32 MFMA (v_mfma_f32_32x32x2_f32) accumulates k-ordered, one rounding per product:
+// D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)) with k0 supplied by lanes 0-31 and k1 by lanes
+// 32-63 — bit for bit the sequential fmaf chain the reference's SGEMM computes, so the
+// dense layers can run on the matrix pipe without leaving the exact-parity contract.
+//
+// Orientation: H^T = W^T * X^T.  A = W^T (out-feature j on the lane, k on the lane half),
+// B = X^T (vertex on the lane), so a 64-vertex tile is two 32-wide B tiles (vt = 0, 1)
+// sharing every A operand.  The 32x32 result holds, on lane (v = l & 31, h = l >> 5),
+// features j = (r & 3) + 8 (r >> 2) + 4 h of vertex v in registers r = 0..15 — and that is
+// (after one v_permlane32_swap per register pair) exactly the B operand of the NEXT layer in
+// ascending-k order, so activations never leave the registers between layers.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int mfma_feat(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// A operands of a layer with weights W[K x N] (row-major): step s, lane (v, h) -> W[2s + h][v]
+template <int N, int STEPS>
+__device__ __forceinline__ void mfma_load_a(const float *__restrict__ W, int v, int h, float (&a)[16]) {
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) a[s] = (v < N) ? W[(2 * s + h) * N + v] : 0.0f;
+}
+
+// first layer of a chain: B operand straight from the LDS input tile (row = vertex, col = k)
+__device__ __forceinline__ f32x16 mfma_layer_lds(const float *T, int vt, int v, int h, const float (&a)[16]) {
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float *row = &T[(32 * vt + v) * kInPitch + h];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], row[2 * s], acc, 0, 0, 0);
+    return acc;
+}
+
+// separately rounded bias add + activation on a result tile (features >= N are padding)
+template <int N, int ACT>
+__device__ __forceinline__ void mfma_bias_act(f32x16 &d, const float *__restrict__ bias, int h) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if ((r >> 2) * 8 < N) {   // static per r: feature index < N for both halves
+            const float t = d[r] + bias[mfma_feat(r, h)];
+            d[r] = (ACT == 0) ? relu_ref(t) : t;
+        }
+    }
+}
+
+// next layer: the previous result tile (K = 32 or 16 features) becomes the B operand.
+// Registers 4g..4g+3 hold features 8g + {0..3} on the low half and 8g + {4..7} on the high
+// half; swapping the halves of (4g, 4g+1) and (4g+2, 4g+3) yields the pairs (8g, 8g+1),
+// (8g+4, 8g+5) and (8g+2, 8g+3), (8g+6, 8g+7): steps 4g, 4g+2, 4g+1, 4g+3.
+template <int K>
+__device__ __forceinline__ f32x16 mfma_layer_acc(const f32x16 &d, const float (&a)[16]) {
+    float b[16];
+#pragma unroll
+    for (int g = 0; g < K / 8; ++g) {
+        auto p0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d[4 * g + 0]), __float_as_uint(d[4 * g + 1]), false, false);
+        auto p1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d[4 * g + 2]), __float_as_uint(d[4 * g + 3]), false, false);
+        b[4 * g + 0] = __uint_as_float(p0[0]);
+        b[4 * g + 2] = __uint_as_float(p0[1]);
+        b[4 * g + 1] = __uint_as_float(p1[0]);
+        b[4 * g + 3] = __uint_as_float(p1[1]);
+    }
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < K / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+    return acc;
+}
+
+// 16 -> 1 layer on a 16-feature result tile: one k-ordered fma chain per vertex that hops
+// between the two lane halves (features 0-3 low, 4-7 high, 8-11 low, 12-15 high).
+// Returns the pre-bias chain value, valid on the HIGH half lane of each vertex.
+__device__ __forceinline__ float mfma_tail_16to1(const f32x16 &d, const float *__restrict__ W, int h) {
+    float w[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) w[r] = W[mfma_feat(r, h)];
+    float acc = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = __builtin_fmaf(d[r], w[r], acc);          // k 0..3   (low half)
+    float t = __shfl_xor(acc, 32);
+    acc = h ? t : acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = __builtin_fmaf(d[r], w[r], acc);          // k 4..7   (high half)
+    t = __shfl_xor(acc, 32);
+    acc = h ? acc : t;
+#pragma unroll
+    for (int r = 4; r < 8; ++r) acc = __builtin_fmaf(d[r], w[r], acc);          // k 8..11  (low half)
+    t = __shfl_xor(acc, 32);
+    acc = h ? t : acc;
+#pragma unroll
+    for (int r = 4; r < 8; ++r) acc = __builtin_fmaf(d[r], w[r], acc);          // k 12..15 (high half)
+    return acc;
+}
+
+// Layers 2 and 3 of a stage on the matrix cores, given layer-1 result tiles d[vt] (already
+// bias+ReLU'ed), ending either in the 16-float output tile in LDS (row = vertex, pitch 17)
+// or in the per-vertex logit.
+template <int N1, int N2, int N3, bool SIGMOID>
+__device__ __forceinline__ void mfma_tail(f32x16 (&d)[2], const float *__restrict__ W2, const float *__restrict__ b2,
+                                          const float *__restrict__ W3, const float *__restrict__ b3, float *T,
+                                          int v, int h, float (&logit)[2]) {
+    static_assert(N1 == 32, "layer-2 input is a full 32-feature tile");
+    float a[16];
+    mfma_load_a<N2, 16>(W2, v, h, a);
+#pragma unroll
+    for (int vt = 0; vt < 2; ++vt) {
+        d[vt] = mfma_layer_acc<32>(d[vt], a);
+        mfma_bias_act<N2, 0>(d[vt], b2, h);
+    }
+    if constexpr (SIGMOID) {
+        static_assert(N2 == 16 && N3 == 1, "sigmoid tail is 16 -> 1");
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt) logit[vt] = mfma_tail_16to1(d[vt], W3, h) + b3[0];
+    } else {
+        static_assert(N3 == 16, "feature stages emit 16 floats per vertex");
+        mfma_load_a<N3, N2 / 2>(W3, v, h, a);
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt) {
+            d[vt] = mfma_layer_acc<N2>(d[vt], a);
+            mfma_bias_act<N3, 0>(d[vt], b3, h);
+        }
+        wave_lds_sync();   // input tile fully consumed: reuse the region as the output tile
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) T[(32 * vt + v) * kOutPitch + mfma_feat(r, h)] = d[vt][r];
+    }
+}
+
 // ------------------------------------------------------------------ stage, F = 16
 // Parameters: W1[35 x N1] b1 W2[N1 x N2] b2 W3[N2 x N3] b3.  Input columns of
 // the first dense layer after the reference's column layout (f = 16):
 //   0..15 aggregate, 16 = h[0], 17 = degree, 18 = W/ws, 19 = NW/ws,
 //   20..31 = h[4..15], 32..34 = +0.0 (never written; their k-terms are exact
 //   no-ops in the fma chain and are skipped).
-template <int N1, int N2, int N3, bool SIGMOID, int S>
+template <int N1, int N2, int N3, bool SIGMOID, int S, bool MFMA>
 __global__ __launch_bounds__(kBlock) void k_stage_f16(
         GraphDev g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
         float *__restrict__ logits, const float *__restrict__ P, uint32_t row_lo,
@@ -189,7 +316,7 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
         }
     }
 
-    // ---- hand over to the lane-per-vertex layout through the LDS tile
+    // ---- hand over through the LDS tile: 64 rows x 32 inputs in k order
     wave_lds_sync();  // every lane is done with the index stage before it is overwritten
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -199,45 +326,75 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
         if (c == 0) {
             row[16] = self[p].x;                 // h[0]; h[1..3] are overwritten by degree / weights
         } else {
-            float *d = &row[17 + 4 * (c - 1)];   // h[4..15]
+            float *d = &row[20 + 4 * (c - 1)];   // h[4..15]
             d[0] = self[p].x; d[1] = self[p].y; d[2] = self[p].z; d[3] = self[p].w;
         }
     }
+    {   // columns 17..19 come from the lane-per-vertex view (lane L <-> vertex v0 + L)
+        float *row = &T[lane * kInPitch];
+        row[17] = f_deg; row[18] = f_w; row[19] = f_nw;
+    }
     wave_lds_sync();
 
-    // ---- dense layers: one lane per vertex, activations in registers.
-    float x0[32];
-    {
-        const float *row = &T[lane * kInPitch];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) x0[j] = row[j];
-        x0[16] = row[16];
-        x0[17] = f_deg;
-        x0[18] = f_w;
-        x0[19] = f_nw;
-#pragma unroll
-        for (int j = 0; j < 12; ++j) x0[20 + j] = row[17 + j];
-    }
     const float *W1 = P, *b1 = W1 + 35 * N1;
     const float *W2 = b1 + N1, *b2 = W2 + N1 * N2;
     const float *W3 = b2 + N2, *b3 = W3 + N2 * N3;
-    float x1[N1], x2[N2], x3[N3];
-    dense<32, 32, N1, 0>(x0, x1, W1, b1);
-    dense<N1, N1, N2, 0>(x1, x2, W2, b2);
-    dense<N2, N2, N3, SIGMOID ? 1 : 0>(x2, x3, W3, b3);
 
-    if constexpr (SIGMOID) {
-        static_assert(N3 == 1, "sigmoid stage ends in one output");
-        if (mine) {
-            if (logits) logits[u] = x3[0];
-            fout[u] = sigmoid_ref(x3[0]);
+    if constexpr (MFMA) {
+        // ---- dense layers on the matrix cores (see mfma_* above)
+        const int v = lane & 31, h = lane >> 5;
+        f32x16 d[2];
+        {
+            float a[16];
+            mfma_load_a<N1, 16>(W1, v, h, a);   // rows 0..31 of W1; rows 32..34 meet exact zeros
+#pragma unroll
+            for (int vt = 0; vt < 2; ++vt) {
+                d[vt] = mfma_layer_lds(T, vt, v, h, a);
+                mfma_bias_act<N1, 0>(d[vt], b1, h);
+            }
+        }
+        float logit[2] = {0.f, 0.f};
+        mfma_tail<N1, N2, N3, SIGMOID>(d, W2, b2, W3, b3, T, v, h, logit);
+        if constexpr (SIGMOID) {
+            // the chain value of vertex 32 vt + v sits on the high half lane
+#pragma unroll
+            for (int vt = 0; vt < 2; ++vt) {
+                const uint32_t uv = v0 + 32 * vt + v;
+                const int keep = __shfl((int)mine, 32 * vt + v);   // all lanes active: a masked-off source lane reads as 0
+                if (h == 1 && keep) {
+                    if (logits) logits[uv] = logit[vt];
+                    fout[uv] = sigmoid_ref(logit[vt]);
+                }
+            }
         }
     } else {
-        static_assert(N3 == 16, "feature stages emit 16 floats per vertex");
-        // transpose through LDS: every global store instruction writes 16 full rows
-        wave_lds_sync();
+        // ---- dense layers on the VALU: one lane per vertex, activations in registers
+        float x0[32];
+        {
+            const float *row = &T[lane * kInPitch];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) T[lane * kOutPitch + j] = x3[j];
+            for (int j = 0; j < 32; ++j) x0[j] = row[j];
+        }
+        float x1[N1], x2[N2], x3[N3];
+        dense<32, 32, N1, 0>(x0, x1, W1, b1);
+        dense<N1, N1, N2, 0>(x1, x2, W2, b2);
+        dense<N2, N2, N3, SIGMOID ? 1 : 0>(x2, x3, W3, b3);
+        if constexpr (SIGMOID) {
+            static_assert(N3 == 1, "sigmoid stage ends in one output");
+            if (mine) {
+                if (logits) logits[u] = x3[0];
+                fout[u] = sigmoid_ref(x3[0]);
+            }
+        } else {
+            wave_lds_sync();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) T[lane * kOutPitch + j] = x3[j];
+        }
+    }
+
+    if constexpr (!SIGMOID) {
+        static_assert(N3 == 16, "feature stages emit 16 floats per vertex");
+        // the 64 x 16 output tile sits in LDS: every global store instruction writes 16 full rows
         wave_lds_sync();
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -255,7 +412,7 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
 // (ep = g.rowptr, ecol = g.col, acc_in = nullptr) or, in the column-blocked plan,
 // the rows' entries of the LAST column block with the partial sums of the earlier
 // blocks arriving in acc_in (same add sequence as the unblocked loop).
-template <int N1, int N2, int N3, int S>
+template <int N1, int N2, int N3, int S, bool MFMA>
 __global__ __launch_bounds__(kBlock) void k_stage_f1(
         GraphDev g, float ws, const float *__restrict__ xin, float *__restrict__ fout,
         const float *__restrict__ P, uint32_t row_lo, uint32_t row_hi,
@@ -311,15 +468,43 @@ __global__ __launch_bounds__(kBlock) void k_stage_f1(
     const float *W1 = P, *b1 = W1 + 5 * N1;
     const float *W2 = b1 + N1, *b2 = W2 + N1 * N2;
     const float *W3 = b2 + N2, *b3 = W3 + N2 * N3;
-    float x1[N1], x2[N2], x3[N3];
-    dense<5, 5, N1, 0>(x0, x1, W1, b1);
-    dense<N1, N1, N2, 0>(x1, x2, W2, b2);
-    dense<N2, N2, N3, 0>(x2, x3, W3, b3);
+    float x1[N1];
+    dense<5, 5, N1, 0>(x0, x1, W1, b1);   // 5 -> 32 stays on the VALU (K = 5 is not matrix-shaped)
     static_assert(N3 == 16, "feature stages emit 16 floats per vertex");
     const int q = lane >> 2, c = lane & 3;
-    wave_lds_sync();  // index stage is dead; reuse the region as the output tile
+    wave_lds_sync();  // index stage is dead; reuse the region
+    if constexpr (MFMA) {
+        // layer-1 activations through LDS into the matrix-core layout, layers 2-3 as MFMA
 #pragma unroll
-    for (int j = 0; j < 16; ++j) T[lane * kOutPitch + j] = x3[j];
+        for (int j = 0; j < N1; ++j) T[lane * kInPitch + j] = x1[j];
+        wave_lds_sync();
+        const int v = lane & 31, h = lane >> 5;
+        f32x16 d[2];
+        float a[16];
+        mfma_load_a<N2, 16>(W2, v, h, a);
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt) {
+            d[vt] = mfma_layer_lds(T, vt, v, h, a);
+            mfma_bias_act<N2, 0>(d[vt], b2, h);
+        }
+        mfma_load_a<N3, N2 / 2>(W3, v, h, a);
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt) {
+            d[vt] = mfma_layer_acc<N2>(d[vt], a);
+            mfma_bias_act<N3, 0>(d[vt], b3, h);
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) T[(32 * vt + v) * kOutPitch + mfma_feat(r, h)] = d[vt][r];
+    } else {
+        float x2[N2], x3[N3];
+        dense<N1, N1, N2, 0>(x1, x2, W2, b2);
+        dense<N2, N2, N3, 0>(x2, x3, W3, b3);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) T[lane * kOutPitch + j] = x3[j];
+    }
     wave_lds_sync();
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -739,25 +924,39 @@ int stage_variant(int f, int n1, int n2, int n3, int sigmoid_last) {
 
 hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
                         const float *in, float *out, float *logits, uint32_t row_lo,
-                        uint32_t row_hi, uint32_t long_thresh, hipStream_t stream) {
+                        uint32_t row_hi, uint32_t long_thresh, bool mfma, hipStream_t stream) {
     if (row_hi <= row_lo) return hipSuccess;
     const uint32_t ntiles = (row_hi - row_lo + kWave - 1) / kWave;
     const uint32_t per_xcd = (ntiles + 7) / 8;
     const uint32_t blocks_per_xcd = (per_xcd + kWavesPerBlock - 1) / kWavesPerBlock;
     const dim3 grid(blocks_per_xcd * 8), block(kBlock);
     const float *P = params + sp.param_offset;
-    switch (sp.variant) {
+    const float4 *in4 = reinterpret_cast<const float4 *>(in);
+    const float *nofloat = nullptr;
+    switch (sp.variant * 2 + (mfma ? 1 : 0)) {
     case 0:
-        hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4>), grid, block, 0, stream, g, ws, in, out, P,
-                           row_lo, row_hi, g.rowptr, g.col, static_cast<const float *>(nullptr), long_thresh);
+        hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, false>), grid, block, 0, stream, g, ws, in, out, P,
+                           row_lo, row_hi, g.rowptr, g.col, nofloat, long_thresh);
         break;
     case 1:
-        hipLaunchKernelGGL((k_stage_f16<32, 32, 16, false, 2>), grid, block, 0, stream, g, ws,
-                           reinterpret_cast<const float4 *>(in), out, nullptr, P, row_lo, row_hi, long_thresh);
+        hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, true>), grid, block, 0, stream, g, ws, in, out, P,
+                           row_lo, row_hi, g.rowptr, g.col, nofloat, long_thresh);
         break;
     case 2:
-        hipLaunchKernelGGL((k_stage_f16<32, 16, 1, true, 2>), grid, block, 0, stream, g, ws,
-                           reinterpret_cast<const float4 *>(in), out, logits, P, row_lo, row_hi, long_thresh);
+        hipLaunchKernelGGL((k_stage_f16<32, 32, 16, false, 2, false>), grid, block, 0, stream, g, ws, in4, out,
+                           nullptr, P, row_lo, row_hi, long_thresh);
+        break;
+    case 3:
+        hipLaunchKernelGGL((k_stage_f16<32, 32, 16, false, 2, true>), grid, block, 0, stream, g, ws, in4, out,
+                           nullptr, P, row_lo, row_hi, long_thresh);
+        break;
+    case 4:
+        hipLaunchKernelGGL((k_stage_f16<32, 16, 1, true, 2, false>), grid, block, 0, stream, g, ws, in4, out,
+                           logits, P, row_lo, row_hi, long_thresh);
+        break;
+    case 5:
+        hipLaunchKernelGGL((k_stage_f16<32, 16, 1, true, 2, true>), grid, block, 0, stream, g, ws, in4, out,
+                           logits, P, row_lo, row_hi, long_thresh);
         break;
     default:
         return hipErrorInvalidValue;
@@ -843,7 +1042,7 @@ hipError_t build_blocked_index(const GraphDev &g, uint32_t wb, uint32_t nblocks,
 hipError_t launch_stage0_blocked(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
                                  const float *x, float *out, uint32_t row_lo, uint32_t row_hi,
                                  uint32_t nblocks, const uint32_t *bp, const uint32_t *colb, float *acc,
-                                 uint32_t long_thresh, hipStream_t stream) {
+                                 uint32_t long_thresh, bool mfma, hipStream_t stream) {
     if (row_hi <= row_lo) return hipSuccess;
     if (sp.variant != 0) return hipErrorInvalidValue;
     const unsigned nb = (row_hi - row_lo + 255) / 256;
@@ -853,11 +1052,15 @@ hipError_t launch_stage0_blocked(const StagePlan &sp, const GraphDev &g, float w
     const uint32_t ntiles = (row_hi - row_lo + kWave - 1) / kWave;
     const uint32_t per_xcd = (ntiles + 7) / 8;
     const uint32_t blocks_per_xcd = (per_xcd + kWavesPerBlock - 1) / kWavesPerBlock;
-    hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4>), dim3(blocks_per_xcd * 8), dim3(kBlock), 0, stream, g, ws,
-                       x, out, params + sp.param_offset, row_lo, row_hi,
-                       bp + (size_t)(nblocks - 1) * g.n, colb,
-                       nblocks > 1 ? static_cast<const float *>(acc) : static_cast<const float *>(nullptr),
-                       long_thresh);
+    const uint32_t *ep = bp + (size_t)(nblocks - 1) * g.n;
+    const float *acc_in = nblocks > 1 ? acc : nullptr;
+    const dim3 grid(blocks_per_xcd * 8), block(kBlock);
+    if (mfma)
+        hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, true>), grid, block, 0, stream, g, ws, x, out,
+                           params + sp.param_offset, row_lo, row_hi, ep, colb, acc_in, long_thresh);
+    else
+        hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, false>), grid, block, 0, stream, g, ws, x, out,
+                           params + sp.param_offset, row_lo, row_hi, ep, colb, acc_in, long_thresh);
     return hipGetLastError();
 }
 

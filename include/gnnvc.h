@@ -74,7 +74,10 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *   "blocked_min_n"  n    graphs with fewer vertices are not blocked (default 2^20)
  *   "long_row_threshold" d  rows of degree >= d get a workgroup of their own (default 512,
  *                         0 = off); same CSR-order sums, bit-identical results
- * gnnvc_get_info keys: "blocked_stage0_active", "blocked_blocks", "block_cols", "long_rows",
+ *   "mfma_dense"     0|1|2  dense layers on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, a
+ *                         k-ordered fma chain: same bits as the VALU path): 0 = VALU, 1 = MFMA in
+ *                         every stage, 2 = MFMA in the 16-wide stages only (default); immediate
+ * gnnvc_get_info keys: "mfma_dense", "blocked_stage0_active", "blocked_blocks", "block_cols", "long_rows",
  * "long_row_threshold". */
 int gnnvc_set_option(gnnvc_engine *e, const char *key, long value);
 int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value);

@@ -375,3 +375,28 @@ def test_long_row_path_is_bit_identical(model_text, oracle_model, thresh, block_
             assert np.array_equal(bits(h2[:-1].cpu().numpy()), bits(oracle_model.predict(g, g.x(), stop_after=13)))
     finally:
         e.close()
+
+
+# ---------------------------------------------------------------- dense layers: MFMA vs VALU
+
+@pytest.mark.parametrize("mfma", [0, 1, 2])
+def test_dense_layers_mfma_and_valu_are_bit_identical(model_text, oracle_model, mfma):
+    """fp32 MFMA accumulates k-ordered with one rounding per product, i.e. the same fmaf chain
+    as the VALU path and the reference's SGEMM: both variants must reproduce the oracle bits."""
+    import gnn_mwvc_amd as G
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_option("mfma_dense", mfma)
+        assert e.get_info("mfma_dense") == mfma
+        rng = np.random.default_rng(5)
+        for g in (gg.erdos_renyi(10000, 80000, 51), gg.rmat(11, 16, 6),
+                  gg.from_edge_list(65, [(i, i + 1) for i in range(64)], list(range(20, 85)))):
+            e.set_weight_scale(g.ws)
+            oracle_model.set_weight_scale(g.ws)
+            e.upload_graph(g)
+            for x in (g.x(), rng.normal(size=g.n).astype(np.float32)):
+                scores, logits = e.forward(x)
+                assert np.array_equal(bits(logits[:, 0]), bits(oracle_model.logits(g, x)))
+                assert ulp(scores[:, 0], oracle_model.scores(g, x)).max() <= 1
+    finally:
+        e.close()
