@@ -194,8 +194,9 @@ def main() -> int:
     dom_bytes = stage_bytes(dom, rows, local_nnz)
     achieved = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9
     fwd_bytes = sum(stage_bytes(i, g.n, g.nnz) for i in range(3))
-    kernel_names = ["k_stage_f1<32,32,16>", "k_stage_f16<32,32,16>", "k_stage_f16<32,16,1,sigmoid>"]
+    kernel_names = ["k_stage_f1<32,32,16", "k_stage_f16<32,32,16,false", "k_stage_f16<32,16,1,true"]
 
+    traffic, traffic_src = measured_traffic(kernel_names[dom], args.workload)
     out = {
         "metric": "GNN forward edges/sec", "value": edges_per_s, "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -206,7 +207,8 @@ def main() -> int:
                    "exchange": "none" if world == 1 else "all-gather N x16 fp32 after stages 0 and 1"},
         "roofline": {"bound": "hbm", "kernel": kernel_names[dom], "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "algorithmic_bytes_per_launch": dom_bytes,
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": dom_bytes,
                      "kernel_ms": stage_ms[dom],
                      "forward_bytes": fwd_bytes,
                      "forward_frac": fwd_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world},
@@ -235,6 +237,24 @@ def main() -> int:
     if world > 1:
         dist.destroy_process_group()
     return 0
+
+
+def measured_traffic(kernel: str, workload: str):
+    """HBM/fabric bytes per launch of the dominant kernel from the committed PMC summary of the
+    latest round (rocprofv3 --pmc passes of tools/pmc_probe.py on the metric graph; L2->fabric
+    read requests x 128 B, calibrated on a 1 GiB copy in the same run, + WRITE_SIZE).  null when
+    no summary covers this kernel / workload."""
+    if workload != "er10m":
+        return None, None
+    prof = sorted((ROOT / "profiles").glob("r*/pmc_summary.json"))
+    if not prof:
+        return None, None
+    data = json.loads(prof[-1].read_text())
+    want = kernel.replace(" ", "").rstrip(">")
+    for name, ctrs in data.items():
+        if name.replace(" ", "").startswith(want) and "traffic_bytes" in ctrs:
+            return ctrs["traffic_bytes"], str(prof[-1].relative_to(ROOT))
+    return None, None
 
 
 def cpu_baseline(args, dev, eng, ggt):
