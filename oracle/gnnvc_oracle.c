@@ -112,6 +112,14 @@ void oracle_model_free(oracle_model *m) {
 /* model::set_weight_scale (src/gnn_inference.cpp:83-90) */
 void oracle_model_set_weight_scale(oracle_model *m, float ws) { m->weight_scale = ws; }
 
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -102,6 +102,7 @@ int oracle_predict(const oracle_model *m, const oracle_graph *g,
 
 /* Number of worker threads the linear layers use (OpenMP), 1 if built without. */
 int oracle_num_threads(void);
+void oracle_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,7 @@ imports this module.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import pathlib
 import subprocess
 
@@ -46,6 +47,14 @@ def lib():
     global _lib
     if _lib is None:
         build()
+        # Size the OpenMP team to the CPUs this process may really use (a GPU box hands a
+        # 16-CPU share of a 128-thread host; 128 spinning workers on 16 CPUs crawl).
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(avail, 16))))
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         L = C.CDLL(str(_LIB_PATH))
         L.oracle_model_parse.restype = C.POINTER(_Model)
         L.oracle_model_parse.argtypes = [C.c_char_p, C.c_size_t]
@@ -64,6 +73,7 @@ def lib():
         L.oracle_neighbourhood_weights.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p,
                                                    C.c_void_p, C.c_void_p]
         L.oracle_num_threads.restype = C.c_int
+        L.oracle_set_num_threads.argtypes = [C.c_int]
         _lib = L
     return _lib
 
@@ -175,3 +185,7 @@ def sigmoid(h: np.ndarray) -> np.ndarray:
 
 def num_threads() -> int:
     return lib().oracle_num_threads()
+
+
+def set_num_threads(n: int) -> None:
+    lib().oracle_set_num_threads(n)

@@ -1,0 +1,148 @@
+"""Parity at BASELINE.json's full size (Erdős–Rényi 10 M vertices / 100 M edges, built on the
+GPU): the oracle cannot run the whole graph in seconds, so the checks are size-independent
+properties plus EXACT per-row checks on a random sample of vertices:
+
+  * sampled rows: for each sampled vertex and each stage, the oracle recomputes that one row
+    from the device's own stage inputs (its neighbours' rows, in CSR order) — bit-identical;
+  * determinism: two forwards give the same bits;
+  * partition invariance: a stage run over two vertex ranges equals the whole-range run;
+  * plan invariance: column-blocked / MFMA / long-row options do not change a single bit;
+  * scores are sigmoid(logits) and lie in (0, 1).
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle_py
+from tools import graphgen as gg
+
+pytestmark = pytest.mark.gpu
+
+N, M, SEED = 10_000_000, 100_000_000, 10
+SAMPLE = 256
+
+
+@pytest.fixture(scope="module")
+def big():
+    import torch
+    import gnn_mwvc_amd as G
+    from tools import graphgen_torch as ggt
+    dev = torch.device("cuda", 0)
+    g = ggt.erdos_renyi(N, M, SEED, dev)
+    eng = G.Engine(G.default_model_text(), device=0)
+    eng.set_weight_scale(g.ws)
+    eng.attach_graph_device(g.n, g.nnz, g.rowptr.data_ptr(), g.col.data_ptr(), g.w.data_ptr(),
+                            g.nw.data_ptr(), keepalive=g)
+    x = g.x().contiguous()
+    bufs = dict(h1=torch.zeros((g.n + 1, 16), device=dev), h2=torch.zeros((g.n + 1, 16), device=dev),
+                sc=torch.zeros(g.n, device=dev), lg=torch.zeros(g.n, device=dev))
+    torch.cuda.synchronize()   # the engine runs on its own stream: torch's zero-fills must have landed
+    eng.stage_forward_device(0, 0, g.n, x.data_ptr(), bufs["h1"].data_ptr())
+    eng.stage_forward_device(1, 0, g.n, bufs["h1"].data_ptr(), bufs["h2"].data_ptr())
+    eng.stage_forward_device(2, 0, g.n, bufs["h2"].data_ptr(), bufs["sc"].data_ptr(), bufs["lg"].data_ptr())
+    eng.synchronize()
+    yield dict(g=g, eng=eng, x=x, dev=dev, **bufs)
+    eng.close()
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _expected_row(om, stage, u_feat, nbr_feats, deg, w_u, nw_u, ws):
+    """One row of a fused stage from its inputs, with the oracle's layer functions."""
+    d = len(nbr_feats)
+    f = u_feat.shape[0]
+    star = gg.CsrGraph(d + 1, np.array([0, d] + [d] * d, dtype=np.uint64),
+                       np.arange(1, d + 1, dtype=np.uint32),
+                       np.array([w_u] + [0] * d, dtype=np.uint32), np.array([nw_u] + [0] * d, dtype=np.uint32))
+    feats = np.vstack([u_feat.reshape(1, f)] + [nbr_feats.reshape(d, f)]) if d else u_feat.reshape(1, f)
+    a = oracle_py.graph_layer(star, ws, feats.astype(np.float32))[:1]
+    assert a[0, f + 1] == deg
+    params = om.linear_params()[3 * stage: 3 * stage + 3]
+    for i, (W, b) in enumerate(params):
+        a = oracle_py.linear_layer(a, W, b)
+        if not (stage == 2 and i == 2):
+            a = oracle_py.relu(a)
+    return a[0]
+
+
+def test_sampled_rows_are_bit_identical(big, oracle_model):
+    import torch
+    g = big["g"]
+    threads = oracle_py.num_threads()
+    oracle_py.set_num_threads(1)     # one-row problems: a thread team per call would dominate
+    rng = np.random.default_rng(123)
+    sample = np.unique(np.concatenate([rng.integers(0, g.n, SAMPLE), [0, 63, 64, g.n - 1]]))
+    rp = g.rowptr
+    ws = g.ws
+    x = big["x"]
+    stage_in = [x.reshape(-1, 1), big["h1"], big["h2"]]
+    stage_out = [big["h1"], big["h2"], big["lg"].reshape(-1, 1)]
+    checked = 0
+    for u in sample:
+        s, t = int(rp[u]), int(rp[u + 1])
+        nbrs = g.col[s:t].to(torch.int64)
+        w_u = int(g.w[u]) & 0xFFFFFFFF
+        nw_u = int(g.nw[u]) & 0xFFFFFFFF
+        for st in range(3):
+            src = stage_in[st]
+            want = _expected_row(oracle_model, st, src[u].cpu().numpy(), src[nbrs].cpu().numpy(), t - s, w_u,
+                                 nw_u, ws)
+            got = stage_out[st][u].cpu().numpy()
+            assert np.array_equal(bits(got), bits(want)), (int(u), st)
+            checked += 1
+    oracle_py.set_num_threads(threads)
+    assert checked >= 3 * SAMPLE * 0.9
+
+
+def test_scores_are_sigmoid_of_logits(big):
+    lg = big["lg"].cpu().numpy()
+    sc = big["sc"].cpu().numpy()
+    assert np.isfinite(lg).all() and (sc > 0).all() and (sc < 1).all()
+    idx = np.random.default_rng(1).integers(0, lg.size, 2_000_000)
+    want = oracle_py.sigmoid(lg[idx])
+    d = np.abs(sc[idx].view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
+    assert d.max() <= 1
+
+
+def test_deterministic_and_plan_invariant(big):
+    """Same bits across repeated runs and across every execution plan."""
+    import torch
+    import gnn_mwvc_amd as G
+    g, dev = big["g"], big["dev"]
+    ref_lg = big["lg"].clone()
+    sc = torch.zeros(g.n, device=dev)
+    lg = torch.zeros(g.n, device=dev)
+    torch.cuda.synchronize()
+    eng = big["eng"]
+    eng.forward_device(big["x"].data_ptr(), sc.data_ptr(), lg.data_ptr())
+    eng.synchronize()
+    assert torch.equal(lg.view(torch.int32), ref_lg.view(torch.int32))
+    for opts in ({"blocked_stage0": 0, "mfma_dense": 0}, {"mfma_dense": 1, "long_row_threshold": 40},
+                 {"block_cols": 1 << 21, "mfma_dense": 2}):
+        e2 = G.Engine(G.default_model_text(), device=0)
+        try:
+            for k, v in opts.items():
+                e2.set_option(k, v)
+            e2.set_weight_scale(g.ws)
+            e2.attach_graph_device(g.n, g.nnz, g.rowptr.data_ptr(), g.col.data_ptr(), g.w.data_ptr(),
+                                   g.nw.data_ptr(), keepalive=g)
+            lg.zero_()
+            torch.cuda.synchronize()
+            e2.forward_device(big["x"].data_ptr(), sc.data_ptr(), lg.data_ptr())
+            e2.synchronize()
+            assert torch.equal(lg.view(torch.int32), ref_lg.view(torch.int32)), opts
+        finally:
+            e2.close()
+
+
+def test_partition_invariance(big):
+    import torch
+    g, dev, eng = big["g"], big["dev"], big["eng"]
+    h2b = torch.zeros((g.n + 1, 16), device=dev)
+    torch.cuda.synchronize()
+    cut = (g.n // 3) // 64 * 64
+    for lo, hi in ((cut, g.n), (0, cut)):
+        eng.stage_forward_device(1, lo, hi, big["h1"].data_ptr(), h2b.data_ptr())
+    eng.synchronize()
+    assert torch.equal(h2b.view(torch.int32), big["h2"].view(torch.int32))
