@@ -35,6 +35,7 @@ WORKLOADS = {
     "er10m": (10_000_000, 100_000_000, 10),   # the metric graph
     "er1m": (1_000_000, 10_000_000, 2),
     "er100k": (100_000, 1_000_000, 1),
+    "er3m": (3_000_000, 30_000_000, 3),       # feature table (192 MB) fits the Infinity Cache
     # the other BASELINE.json configs (parity-test cases; selectable here for profiling)
     "rmat22": ("rmat", 22, 16, 22),
     "rmat20": ("rmat", 20, 16, 20),
@@ -78,6 +79,12 @@ def main() -> int:
     ap.add_argument("--block-cols", type=int, default=0)
     ap.add_argument("--long-threshold", type=int, default=-1, help="degree at which a row gets its own workgroup")
     ap.add_argument("--mfma", type=int, default=-1, help="dense layers: 0 VALU, 1 MFMA everywhere, 2 MFMA in the 16-wide stages (default)")
+    ap.add_argument("--pipeline-chunks", type=int, default=4,
+                    help="N>1: pieces per stage whose all-gather overlaps the next piece's compute (0/1 = off)")
+    ap.add_argument("--replicate-stage0", type=int, default=-1,
+                    help="N>1: every rank computes all rows of stage 0 and skips the first exchange (-1 = auto)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N>1 (gloo only to rehearse several ranks on ONE GPU)")
     ap.add_argument("--host-path", action="store_true",
                     help="also time the host-pointer path (PCIe inclusive), reported separately")
     args = ap.parse_args()
@@ -95,11 +102,15 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py needs a GPU: the engine has no CPU fallback", file=sys.stderr)
         return 2
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()   # == local_rank on a real multi-GPU node
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import gnn_mwvc_amd as G
     from tools import graphgen_torch as ggt
@@ -109,7 +120,7 @@ def main() -> int:
     torch.cuda.synchronize()
     t_gen = time.time() - t0
 
-    eng = G.Engine(G.default_model_text(), device=local_rank)
+    eng = G.Engine(G.default_model_text(), device=dev_index)
     assert eng.fused and eng.num_stages == 3
     eng.set_weight_scale(g.ws)
     if args.no_blocked:
@@ -161,7 +172,9 @@ def main() -> int:
                     ev[2 * st].record(stream)
                 elif phase == "computed":
                     ev[2 * st + 1].record(stream)
-        D.partitioned_forward(stage_fn, 3, x, bufs, bounds, rank, on_stage=hook, gather_logits=False)
+        D.partitioned_forward(stage_fn, 3, x, bufs, bounds, rank, on_stage=hook, gather_logits=False,
+                              replicate_stage0=None if args.replicate_stage0 < 0 else bool(args.replicate_stage0),
+                              pipeline_chunks=args.pipeline_chunks)
 
     for _ in range(args.warmup):
         step(None)
@@ -218,6 +231,20 @@ def main() -> int:
                  "mfma_dense": eng.get_info("mfma_dense"), "long_rows": eng.get_info("long_rows"), "long_row_threshold": eng.get_info("long_row_threshold")},
     }
 
+    if world > 1:
+        # self-check: the partitioned result on THIS rank against a plain single-GPU forward of
+        # the same graph on this GPU (outside the timed region)
+        ref_sc = torch.zeros(g.n, dtype=torch.float32, device=dev)
+        ref_lg = torch.zeros(g.n, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        eng.forward_device(x.data_ptr(), ref_sc.data_ptr(), ref_lg.data_ptr())
+        torch.cuda.synchronize()
+        bad = (bufs.scores[: g.n].view(torch.int32) != ref_sc.view(torch.int32)).sum().to(torch.int64)
+        dist.all_reduce(bad, op=dist.ReduceOp.SUM)
+        out["parity"] = {"partitioned_vs_single_gpu_score_bit_mismatches_all_ranks": int(bad.item())}
+        out["config"]["replicate_stage0"] = (D.replicate_first_stage(world) if args.replicate_stage0 < 0
+                                              else bool(args.replicate_stage0))
+        out["config"]["pipeline_chunks"] = args.pipeline_chunks
     if rank == 0 and world == 1:
         if args.host_path:
             # PCIe-inclusive path (host x in, host scores + logits out); never `value`

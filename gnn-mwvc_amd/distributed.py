@@ -126,34 +126,88 @@ def exchange_rows(buf: torch.Tensor, bounds: Sequence[Tuple[int, int]], rank: in
             w.wait()
 
 
+def exchange_rows_pipelined(stage_fn, stage: int, src: torch.Tensor, dst: torch.Tensor, logits,
+                            bounds: Sequence[Tuple[int, int]], rank: int, n: int, chunks: int,
+                            group=None) -> None:
+    """Compute this rank's rows of `stage` in `chunks` pieces and all-gather each piece
+    asynchronously while the next piece is being computed (equal-rows partition only).
+
+    The collective of piece k is issued right after piece k's kernels were queued: the
+    communication stream waits for them through the event torch records at the call, while
+    this stream goes on launching piece k + 1 — RCCL's copies and the gather kernels overlap.
+    All pieces are waited for before returning (the next stage needs every row).
+    """
+    world = len(bounds)
+    per = _equal_shard_rows(n, bounds)
+    lo, hi = bounds[rank]
+    step = max(ALIGN, (per // max(chunks, 1) + ALIGN - 1) // ALIGN * ALIGN)
+    works = []
+    for off in range(0, per, step):
+        size = min(step, per - off)
+        r0, r1 = min(lo + off, hi), min(lo + off + size, hi)
+        if r1 > r0:
+            stage_fn(stage, r0, r1, src, dst, logits)
+        # piece `off` of every rank's (padded) shard: equal sizes, rows past n stay zero
+        outs = [dst[r * per + off: r * per + off + size] for r in range(world)]
+        works.append(dist.all_gather(outs, outs[rank], group=group, async_op=True))
+    for w in works:
+        w.wait()
+
+
 StageFn = Callable[[int, int, int, torch.Tensor, torch.Tensor, "torch.Tensor | None"], None]
+
+
+def replicate_first_stage(world: int) -> bool:
+    """Stage 0 reads only the replicated input x, so every rank can compute ALL of its rows
+    and skip the first N x 16 exchange.  That trades (1 - 1/P) of one cheap stage for one
+    640 MB all-gather: a win while a rank's share of that gather crosses few xGMI links
+    (P <= 4: >= 160 MB per link ~ 2 ms against ~1.6 ms of extra compute), a loss at P = 8."""
+    return 1 < world <= 4
 
 
 def partitioned_forward(stage_fn: StageFn, num_stages: int, x: torch.Tensor, bufs: ForwardBuffers,
                         bounds: Sequence[Tuple[int, int]], rank: int, group=None,
-                        exchange: str = "auto", on_stage=None,
-                        gather_logits: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+                        exchange: str = "auto", on_stage=None, gather_logits: bool = True,
+                        replicate_stage0: "bool | None" = None,
+                        pipeline_chunks: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
     """Run every fused stage on this rank's rows and exchange between stages.
 
     stage_fn(stage, lo, hi, src, dst, logits_or_None) computes rows [lo, hi) of `dst`
     from the full `src`.  Returns (scores[:n], logits[:n]) — complete on every rank,
     like `predict` hands every caller all N scores.
+    replicate_stage0: None = replicate_first_stage(world).
+    pipeline_chunks > 1: overlap each feature exchange with the stage's own compute
+    (exchange_rows_pipelined; equal-rows partition only).
     on_stage(stage, phase) is an optional hook ("begin" | "computed" | "exchanged")
     used by the bench to drop timing events on the stream.
     """
+    world = len(bounds)
     lo, hi = bounds[rank]
+    if replicate_stage0 is None:
+        replicate_stage0 = replicate_first_stage(world)
+    can_pipeline = pipeline_chunks > 1 and world > 1 and _equal_shard_rows(bufs.n, bounds) > 0
     src = x
     for st in range(num_stages):
         last = st == num_stages - 1
         dst = bufs.scores if last else bufs.feat[st & 1]
         if on_stage:
             on_stage(st, "begin")
-        stage_fn(st, lo, hi, src, dst, bufs.logits if last else None)
-        if on_stage:
-            on_stage(st, "computed")
-        exchange_rows(dst, bounds, rank, bufs.n, group, exchange)
-        if last and gather_logits:   # the exact-parity route applies the host sigmoid to the logits
-            exchange_rows(bufs.logits, bounds, rank, bufs.n, group, exchange)
+        if st == 0 and replicate_stage0 and not last:
+            stage_fn(st, 0, bufs.n, src, dst, None)       # every row, no exchange
+            if on_stage:
+                on_stage(st, "computed")
+        elif can_pipeline and not last:
+            exchange_rows_pipelined(stage_fn, st, src, dst, None, bounds, rank, bufs.n,
+                                    pipeline_chunks, group)
+            if on_stage:
+                on_stage(st, "computed")
+        else:
+            stage_fn(st, lo, hi, src, dst, bufs.logits if last else None)
+            if on_stage:
+                on_stage(st, "computed")
+            exchange_rows(dst, bounds, rank, bufs.n, group, exchange)
+            if last and gather_logits:   # the exact-parity route applies the host sigmoid to the logits
+                exchange_rows(bufs.logits, bounds, rank, bufs.n, group, exchange)
         if on_stage:
             on_stage(st, "exchanged")
         src = dst

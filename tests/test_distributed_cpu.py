@@ -49,7 +49,7 @@ def _oracle_stage_fn(g, text):
     return stage_fn
 
 
-def _worker(rank, world, port, mode, exchange, graph_args, q):
+def _worker(rank, world, port, mode, exchange, graph_args, q, replicate=None, chunks=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -62,7 +62,8 @@ def _worker(rank, world, port, mode, exchange, graph_args, q):
         bufs = D.ForwardBuffers.allocate(g.n, bounds, "cpu")
         x = torch.from_numpy(g.x())
         scores, logits = D.partitioned_forward(_oracle_stage_fn(g, text), 3, x, bufs, bounds, rank,
-                                               exchange=exchange)
+                                               exchange=exchange, replicate_stage0=replicate,
+                                               pipeline_chunks=chunks)
         # pad rows of the feature buffers must still be zero (the gather reads row n)
         pad_ok = all(float(f[g.n:].abs().sum()) == 0.0 for f in bufs.feat)
         q.put((rank, scores.numpy().copy(), logits.numpy().copy(), bounds, pad_ok))
@@ -70,17 +71,20 @@ def _worker(rank, world, port, mode, exchange, graph_args, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode,exchange,graph_args", [
-    (2, "rows", "allgather", (3000, 15000, 4)),
-    (2, "rows", "p2p", (3000, 15000, 4)),
-    (3, "nnz", "auto", (5000, 20000, 2, 1500, 9)),     # hub graph: uneven nnz-balanced shards
-    (2, "rows", "auto", (100, 300, 5)),                # second rank's shard is short
+@pytest.mark.parametrize("world,mode,exchange,graph_args,replicate,chunks", [
+    (2, "rows", "allgather", (3000, 15000, 4), False, 0),
+    (2, "rows", "p2p", (3000, 15000, 4), None, 0),        # default: stage 0 replicated at P <= 4
+    (3, "nnz", "auto", (5000, 20000, 2, 1500, 9), False, 0),  # hub graph: uneven nnz-balanced shards
+    (2, "rows", "auto", (100, 300, 5), False, 0),         # second rank's shard is short
+    (2, "rows", "auto", (3000, 15000, 4), False, 4),      # exchanges overlapped with compute, 4 pieces
+    (3, "rows", "auto", (1000, 6000, 8), None, 3),        # replicated stage 0 + pipelined stage 1
 ])
-def test_partitioned_forward_matches_single_process(world, mode, exchange, graph_args, oracle_model):
+def test_partitioned_forward_matches_single_process(world, mode, exchange, graph_args, replicate, chunks,
+                                                    oracle_model):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, exchange, graph_args, q))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, exchange, graph_args, q, replicate, chunks))
              for r in range(world)]
     for p in procs:
         p.start()
