@@ -94,6 +94,18 @@ struct gnnvc_engine {
     // activations through LDS just to reach the matrix layout costs more than it saves)
     int opt_mfma = 2;
 
+    // degree-sorted tile order (16-wide stages, skewed graphs); built per row range on demand
+    int opt_sorted = -1;               // option "sorted_tiles": -1 auto (by measured waste), 0 off, 1 on
+    uint32_t opt_sorted_long_thresh = 1024;   // long-row threshold used with sorted tiles
+    bool sorted_wanted = false;        // decided per graph from the measured tile waste
+    bool sorted_valid = false;         // the cached order below matches (srt_lo, srt_hi) of the current graph
+    bool sorted_use = false;
+    uint32_t srt_lo = 0, srt_hi = 0, srt_n = 0;
+    double srt_waste = 0.0;
+    DevBuf<uint32_t> srt_vertex, srt_hist;
+    DevBuf<uint4> srt_meta;
+    DevBuf<unsigned long long> srt_sum;
+
     // long rows (degree >= long_thresh): one workgroup each, on aux_stream beside the tile kernel
     uint32_t opt_long_thresh = 512;   // option "long_row_threshold" (0 = off)
     uint32_t long_thresh = 0xFFFFFFFFu, n_long = 0;
@@ -284,11 +296,30 @@ int use_device(gnnvc_engine *e) {
 int find_long(gnnvc_engine *e) {
     e->n_long = 0;
     e->long_thresh = 0xFFFFFFFFu;
+    e->sorted_valid = false;   // new graph: any cached tile order is stale
+    e->sorted_use = false;
     const GraphDev &g = e->g;
-    if (!e->opt_long_thresh || e->stages.empty() || g.n == 0) return GNNVC_OK;
+    e->sorted_wanted = false;
+    e->srt_waste = 0.0;
+    if (e->stages.empty() || g.n == 0) return GNNVC_OK;
+    const uint32_t base_thresh = e->opt_long_thresh ? e->opt_long_thresh : 0xFFFFFFFFu;
+    if (e->opt_sorted != 0 && g.nnz) {
+        // lockstep cost of natural 64-row tiles (64 x sum of per-tile maxima) against the useful work
+        HIP_TRY(e, e->srt_sum.reserve(1));
+        HIP_TRY(e, gnnvc::measure_tile_waste(g, 0, g.n, base_thresh, e->srt_sum.p, e->stream));
+        unsigned long long sum_max = 0;
+        HIP_TRY(e, hipMemcpyAsync(&sum_max, e->srt_sum.p, sizeof sum_max, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        e->srt_waste = 64.0 * (double)sum_max / (double)g.nnz;
+        e->sorted_wanted = e->opt_sorted > 0 || e->srt_waste >= 2.0;
+    }
+    if (!e->opt_long_thresh) return GNNVC_OK;
+    // with degree-sorted tiles the tile kernel copes with longer rows, so fewer rows go long
+    const uint32_t thresh = e->sorted_wanted ? std::max(e->opt_long_thresh, e->opt_sorted_long_thresh)
+                                             : e->opt_long_thresh;
     HIP_TRY(e, e->long_list.reserve(g.n));
     HIP_TRY(e, e->long_count.reserve(1));
-    HIP_TRY(e, gnnvc::find_long_rows(g, e->opt_long_thresh, e->long_list.p, e->long_count.p, e->stream));
+    HIP_TRY(e, gnnvc::find_long_rows(g, thresh, e->long_list.p, e->long_count.p, e->stream));
     uint32_t cnt = 0;
     HIP_TRY(e, hipMemcpyAsync(&cnt, e->long_count.p, sizeof cnt, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -299,7 +330,42 @@ int find_long(gnnvc_engine *e) {
         HIP_TRY(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     }
     e->n_long = cnt;
-    e->long_thresh = e->opt_long_thresh;
+    e->long_thresh = thresh;
+    return GNNVC_OK;
+}
+
+// Degree-sorted tile order for rows [lo, hi) of the current graph.  A natural tile of 64
+// consecutive rows costs max-degree gather rounds; when the measured cost (64 x sum of
+// per-tile maxima) exceeds twice the useful work, tiles are formed from a degree-sorted list
+// instead.  Cached per row range; the scan over the degree classes runs on the host.
+int ensure_sorted(gnnvc_engine *e, uint32_t lo, uint32_t hi) {
+    if (e->sorted_valid && e->srt_lo == lo && e->srt_hi == hi) return GNNVC_OK;
+    e->sorted_valid = true;
+    e->sorted_use = false;
+    e->srt_lo = lo;
+    e->srt_hi = hi;
+    e->srt_n = 0;
+    const GraphDev &g = e->g;
+    if (!e->sorted_wanted || hi <= lo || g.nnz == 0) return GNNVC_OK;
+    const uint32_t bins = e->long_thresh < 4096u ? e->long_thresh + 1 : 4096u;
+    HIP_TRY(e, e->srt_hist.reserve(bins));
+    HIP_TRY(e, e->srt_vertex.reserve(hi - lo));
+    HIP_TRY(e, e->srt_meta.reserve(hi - lo));
+    HIP_TRY(e, gnnvc::degree_histogram(g, lo, hi, e->long_thresh, bins, e->srt_hist.p, e->stream));
+    std::vector<uint32_t> hist(bins), start(bins);
+    HIP_TRY(e, hipMemcpyAsync(hist.data(), e->srt_hist.p, bins * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    uint32_t run = 0;
+    for (uint32_t d = bins; d-- > 0;) {   // heaviest degree class first
+        start[d] = run;
+        run += hist[d];
+    }
+    HIP_TRY(e, hipMemcpyAsync(e->srt_hist.p, start.data(), bins * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, gnnvc::degree_scatter(g, lo, hi, e->long_thresh, bins, e->srt_hist.p, e->srt_vertex.p,
+                                     e->srt_meta.p, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));   // `start` is read by the async copy above
+    e->srt_n = run;
+    e->sorted_use = true;
     return GNNVC_OK;
 }
 
@@ -348,8 +414,20 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
                                                 e->long_thresh, e->opt_mfma == 1, e->stream));
     } else {
         const bool mfma = e->opt_mfma == 1 || (e->opt_mfma == 2 && e->stages[stage].f == 16);
+        gnnvc::SortedOrder so;
+        const gnnvc::SortedOrder *sop = nullptr;
+        if (e->stages[stage].f == 16) {
+            int rc = ensure_sorted(e, lo, hi);
+            if (rc) return rc;
+            if (e->sorted_use) {
+                so.n = e->srt_n;
+                so.vertex = e->srt_vertex.p;
+                so.meta = e->srt_meta.p;
+                sop = &so;
+            }
+        }
         HIP_TRY(e, gnnvc::launch_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi,
-                                       e->long_thresh, mfma, e->stream));
+                                       e->long_thresh, mfma, sop, e->stream));
     }
     if (longs) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));   // join
     return GNNVC_OK;
@@ -485,6 +563,7 @@ void gnnvc_destroy(gnnvc_engine *e) {
     e->blk_ptr.release(); e->blk_col.release(); e->blk_scratch.release(); e->blk_flag.release();
     e->blk_acc.release();
     e->long_list.release(); e->long_count.release();
+    e->srt_vertex.release(); e->srt_hist.release(); e->srt_meta.release(); e->srt_sum.release();
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->aux_stream) { (void)hipStreamSynchronize(e->aux_stream); (void)hipStreamDestroy(e->aux_stream); }
@@ -512,7 +591,9 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "block_cols") e->opt_block_cols = value > 0 ? (uint32_t)value : 0;
     else if (k == "blocked_min_n") e->opt_blocked_min_n = value > 0 ? (uint32_t)value : 0;
     else if (k == "long_row_threshold") e->opt_long_thresh = value > 0 ? (uint32_t)value : 0;
+    else if (k == "sorted_long_row_threshold") e->opt_sorted_long_thresh = value > 0 ? (uint32_t)value : 1;
     else if (k == "mfma_dense") e->opt_mfma = (value >= 0 && value <= 2) ? (int)value : 2;
+    else if (k == "sorted_tiles") { e->opt_sorted = value < 0 ? -1 : (value ? 1 : 0); e->sorted_valid = false; }
     else return fail(e, GNNVC_ERR_INVALID, "unknown option '%s'", key);
     return GNNVC_OK;
 }
@@ -525,6 +606,8 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
     else if (k == "block_cols") *value = e->blocked_ready ? (long)e->blk_cols : 0;
     else if (k == "long_rows") *value = (long)e->n_long;
     else if (k == "mfma_dense") *value = e->opt_mfma;
+    else if (k == "sorted_tiles_active") *value = e->sorted_wanted ? 1 : 0;
+    else if (k == "tile_waste_x100") *value = (long)(e->srt_waste * 100.0);
     else if (k == "long_row_threshold") *value = e->n_long ? (long)e->long_thresh : 0;
     else return GNNVC_ERR_INVALID;
     return GNNVC_OK;

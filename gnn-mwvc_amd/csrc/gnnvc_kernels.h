@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
+#include <hip/hip_vector_types.h>
 
 namespace gnnvc {
 
@@ -29,6 +30,13 @@ struct StagePlan {
     int variant = -1;         // index into the compiled instantiations, -1 = none
 };
 
+// Degree-sorted tile order of the non-long rows of one row range (device arrays).
+struct SortedOrder {
+    uint32_t n = 0;                   // entries
+    const uint32_t *vertex = nullptr; // vertex id per entry, degrees descending
+    const uint4 *meta = nullptr;      // {row begin, row end, W, NW} per entry
+};
+
 // Returns the instantiation index for a stage shape, or -1.
 int stage_variant(int f, int n1, int n2, int n3, int sigmoid_last);
 
@@ -37,7 +45,17 @@ int stage_variant(int f, int n1, int n2, int n3, int sigmoid_last);
 // stage, out = scores[n], logits optional.
 hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
                         const float *in, float *out, float *logits, uint32_t row_lo,
-                        uint32_t row_hi, uint32_t long_thresh, bool mfma, hipStream_t stream);
+                        uint32_t row_hi, uint32_t long_thresh, bool mfma, const SortedOrder *so,
+                        hipStream_t stream);
+
+// Building blocks of the degree-sorted order (the prefix over the few thousand degree classes
+// is done on the host).
+hipError_t measure_tile_waste(const GraphDev &g, uint32_t row_lo, uint32_t row_hi, uint32_t long_thresh,
+                              unsigned long long *sum_max, hipStream_t stream);
+hipError_t degree_histogram(const GraphDev &g, uint32_t row_lo, uint32_t row_hi, uint32_t long_thresh,
+                            uint32_t bins, uint32_t *hist, hipStream_t stream);
+hipError_t degree_scatter(const GraphDev &g, uint32_t row_lo, uint32_t row_hi, uint32_t long_thresh,
+                          uint32_t bins, uint32_t *cursor, uint32_t *vertex, void *meta, hipStream_t stream);
 
 // Long rows (degree >= thresh): listed once per graph, then one workgroup per row per
 // stage (same CSR-order sums).  The tile kernels above skip those rows when given the

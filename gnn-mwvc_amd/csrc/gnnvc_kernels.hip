@@ -231,53 +231,80 @@ __device__ __forceinline__ void mfma_tail(f32x16 (&d)[2], const float *__restric
 //   0..15 aggregate, 16 = h[0], 17 = degree, 18 = W/ws, 19 = NW/ws,
 //   20..31 = h[4..15], 32..34 = +0.0 (never written; their k-terms are exact
 //   no-ops in the fma chain and are skipped).
-template <int N1, int N2, int N3, bool SIGMOID, int S, bool MFMA>
+// SORTED: instead of 64 consecutive vertices a tile takes 64 consecutive entries of a
+// degree-sorted vertex list (srt_vertex, with {row begin, row end, W, NW} per entry in
+// srt_meta).  A tile costs max-degree gather rounds whatever the other lanes do, so on
+// skewed graphs tiles of similar degree waste far fewer rounds; rows are then no longer
+// contiguous, so the column indices are read straight from global memory.
+template <int N1, int N2, int N3, bool SIGMOID, int S, bool MFMA, bool SORTED>
 __global__ __launch_bounds__(kBlock) void k_stage_f16(
         GraphDev g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
         float *__restrict__ logits, const float *__restrict__ P, uint32_t row_lo,
-        uint32_t row_hi, uint32_t long_thresh) {
+        uint32_t row_hi, uint32_t long_thresh, const uint32_t *__restrict__ srt_vertex,
+        const uint4 *__restrict__ srt_meta, uint32_t n_sorted) {
     __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kRegionFloats];
     const int lane = threadIdx.x & 63;
     float *T = lds[threadIdx.x >> 6];
     uint32_t *stage = reinterpret_cast<uint32_t *>(T);
-    const uint32_t ntiles = (row_hi - row_lo + kWave - 1) / kWave;
+    const uint32_t ntiles = SORTED ? (n_sorted + kWave - 1) / kWave : (row_hi - row_lo + kWave - 1) / kWave;
     const uint32_t tile = tile_for_wave(ntiles);
     if (tile >= ntiles) return;
-    const uint32_t v0 = row_lo + tile * kWave;
+    const uint32_t v0 = row_lo + tile * kWave;   // natural order only
 
     // lane-per-vertex view of the tile
-    const uint32_t u = v0 + lane;
-    const bool valid = u < row_hi;
-    const uint32_t uc = valid ? u : row_hi - 1;
-    const uint32_t rs = g.rowptr[uc];
-    const uint32_t re_full = valid ? g.rowptr[uc + 1] : rs;
-    // rows of degree >= long_thresh belong to the long-row kernel (k_long_f16): no gather,
-    // no store for them here
-    const bool mine = valid && (re_full - rs) < long_thresh;
-    const uint32_t re = mine ? re_full : rs;
-    const float f_deg = (float)(re_full - rs);
-    const float f_w = (float)g.w[uc] / ws;
-    const float f_nw = (float)g.nw[uc] / ws;
+    uint32_t u, rs, re;
+    bool mine;
+    float f_deg, f_w, f_nw;
+    if constexpr (SORTED) {
+        const uint32_t slot = tile * kWave + lane;
+        mine = slot < n_sorted;                   // long rows and other ranks' rows are not in the list
+        const uint32_t sl = mine ? slot : n_sorted - 1;
+        u = srt_vertex[sl];
+        const uint4 meta = srt_meta[sl];
+        rs = meta.x;
+        re = mine ? meta.y : rs;
+        f_deg = (float)(meta.y - meta.x);
+        f_w = (float)meta.z / ws;
+        f_nw = (float)meta.w / ws;
+    } else {
+        const uint32_t uu = v0 + lane;
+        const bool valid = uu < row_hi;
+        u = valid ? uu : row_hi - 1;
+        rs = g.rowptr[u];
+        const uint32_t re_full = valid ? g.rowptr[u + 1] : rs;
+        // rows of degree >= long_thresh belong to the long-row kernel (k_long_f16): no gather,
+        // no store for them here
+        mine = valid && (re_full - rs) < long_thresh;
+        re = mine ? re_full : rs;
+        f_deg = (float)(re_full - rs);
+        f_w = (float)g.w[u] / ws;
+        f_nw = (float)g.nw[u] / ws;
+    }
 
-    // the tile's slice of col: [c0, c1) — rows are contiguous in CSR
-    const uint32_t c0 = __builtin_amdgcn_readfirstlane(rs);
-    const uint32_t vend = (v0 + kWave < row_hi) ? v0 + kWave : row_hi;
-    const uint32_t c1 = g.rowptr[vend];   // wave-uniform: end of the tile's last valid row
-    const bool staged = (c1 - c0) <= kStageCap;
+    // natural order: the tile's slice of col, [c0, c1), is contiguous in CSR -> stage it in LDS
+    bool staged = false;
     uint32_t sbase = 0;
-    if (staged) sbase = stage_cols(g.col, c0, c1, stage, lane);
+    if constexpr (!SORTED) {
+        const uint32_t c0 = __builtin_amdgcn_readfirstlane(rs);
+        const uint32_t vend = (v0 + kWave < row_hi) ? v0 + kWave : row_hi;
+        const uint32_t c1 = g.rowptr[vend];   // wave-uniform: end of the tile's last valid row
+        staged = (c1 - c0) <= kStageCap;
+        if (staged) sbase = stage_cols(g.col, c0, c1, stage, lane);
+    }
 
-    // ---- quad layout: quad q of lanes owns vertices v0 + 16p + q (p = 0..3),
+    // ---- quad layout: quad q of lanes owns the tile's vertices 16p + q (p = 0..3),
     // lane c of the quad holds floats 4c..4c+3 of a 64-byte feature row.
     const int q = lane >> 2, c = lane & 3;
-    uint32_t b[4], e[4];
+    uint32_t b[4], e[4], urow[4];
+    int okrow[4];
     float4 self[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         b[p] = __shfl(rs, 16 * p + q);
         e[p] = __shfl(re, 16 * p + q);
-        const uint32_t row = v0 + 16 * p + q;
-        self[p] = fin[(size_t)(row < row_hi ? row : row_hi - 1) * 4 + c];  // own rows: 16 full rows per load
+        urow[p] = __shfl(u, 16 * p + q);          // always a valid vertex id (clamped above)
+        okrow[p] = __shfl((int)mine, 16 * p + q);
+        self[p] = fin[(size_t)urow[p] * 4 + c];   // own rows: 16 full rows per load
     }
     float4 acc[4];
 #pragma unroll
@@ -359,7 +386,7 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
             // the chain value of vertex 32 vt + v sits on the high half lane
 #pragma unroll
             for (int vt = 0; vt < 2; ++vt) {
-                const uint32_t uv = v0 + 32 * vt + v;
+                const uint32_t uv = __shfl(u, 32 * vt + v);
                 const int keep = __shfl((int)mine, 32 * vt + v);   // all lanes active: a masked-off source lane reads as 0
                 if (h == 1 && keep) {
                     if (logits) logits[uv] = logit[vt];
@@ -398,10 +425,9 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
         wave_lds_sync();
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const uint32_t row = v0 + 16 * p + q;
             const float *src = &T[(16 * p + q) * kOutPitch + 4 * c];
             const float4 o = make_float4(src[0], src[1], src[2], src[3]);
-            if (__shfl((int)mine, 16 * p + q)) reinterpret_cast<float4 *>(fout)[(size_t)row * 4 + c] = o;
+            if (okrow[p]) reinterpret_cast<float4 *>(fout)[(size_t)urow[p] * 4 + c] = o;
         }
     }
 }
@@ -724,6 +750,50 @@ __global__ __launch_bounds__(256) void k_long_f1(
     for (int j = 0; j < N3; ++j) fout[(size_t)u * N3 + j] = x3[j];
 }
 
+// ------------------------------------------------------------------ degree-sorted tile order
+// (built once per graph and row range when natural tiles would waste most of their rounds)
+// lockstep cost of natural tiles: sum over tiles of the tile's largest (non-long) degree
+__global__ __launch_bounds__(256) void k_tile_waste(GraphDev g, uint32_t row_lo, uint32_t row_hi,
+                                                    uint32_t long_thresh, unsigned long long *__restrict__ sum_max) {
+    const uint32_t u = row_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t d = 0;
+    if (u < row_hi) {
+        d = g.rowptr[u + 1] - g.rowptr[u];
+        if (d >= long_thresh) d = 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_xor(d, off);
+        d = o > d ? o : d;
+    }
+    if ((threadIdx.x & 63) == 0 && d) atomicAdd(sum_max, (unsigned long long)d);
+}
+
+// histogram of min(degree, bins - 1) over the non-long rows of [row_lo, row_hi)
+__global__ __launch_bounds__(256) void k_deg_hist(GraphDev g, uint32_t row_lo, uint32_t row_hi, uint32_t long_thresh,
+                                                  uint32_t bins, uint32_t *__restrict__ hist) {
+    const uint32_t u = row_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= row_hi) return;
+    const uint32_t d = g.rowptr[u + 1] - g.rowptr[u];
+    if (d >= long_thresh) return;
+    atomicAdd(&hist[d < bins ? d : bins - 1], 1u);
+}
+
+// cursor[d] holds the next free slot of degree class d (classes laid out by DEscending degree,
+// so the heaviest tiles are dispatched first); entries carry what the tile kernel needs per vertex
+__global__ __launch_bounds__(256) void k_deg_scatter(GraphDev g, uint32_t row_lo, uint32_t row_hi, uint32_t long_thresh,
+                                                     uint32_t bins, uint32_t *__restrict__ cursor,
+                                                     uint32_t *__restrict__ vertex, uint4 *__restrict__ meta) {
+    const uint32_t u = row_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= row_hi) return;
+    const uint32_t rs = g.rowptr[u], re = g.rowptr[u + 1];
+    const uint32_t d = re - rs;
+    if (d >= long_thresh) return;
+    const uint32_t slot = atomicAdd(&cursor[d < bins ? d : bins - 1], 1u);
+    vertex[slot] = u;
+    meta[slot] = make_uint4(rs, re, g.w[u], g.nw[u]);
+}
+
 // ------------------------------------------------------------------ column-blocked F = 1 aggregation
 // The F = 1 gather reads 4 useful bytes per random 128-byte line of x; with x
 // (4 N bytes) far beyond the 4 MiB L2 of an XCD every read goes to the fabric.
@@ -924,9 +994,12 @@ int stage_variant(int f, int n1, int n2, int n3, int sigmoid_last) {
 
 hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
                         const float *in, float *out, float *logits, uint32_t row_lo,
-                        uint32_t row_hi, uint32_t long_thresh, bool mfma, hipStream_t stream) {
+                        uint32_t row_hi, uint32_t long_thresh, bool mfma, const SortedOrder *so,
+                        hipStream_t stream) {
     if (row_hi <= row_lo) return hipSuccess;
-    const uint32_t ntiles = (row_hi - row_lo + kWave - 1) / kWave;
+    const bool sorted = so && so->n > 0 && sp.f == 16;
+    if (so && so->n == 0 && sp.f == 16) return hipSuccess;   // every row of the range is a long row
+    const uint32_t ntiles = sorted ? (so->n + kWave - 1) / kWave : (row_hi - row_lo + kWave - 1) / kWave;
     const uint32_t per_xcd = (ntiles + 7) / 8;
     const uint32_t blocks_per_xcd = (per_xcd + kWavesPerBlock - 1) / kWavesPerBlock;
     const dim3 grid(blocks_per_xcd * 8), block(kBlock);
@@ -942,22 +1015,27 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
         hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, true>), grid, block, 0, stream, g, ws, in, out, P,
                            row_lo, row_hi, g.rowptr, g.col, nofloat, long_thresh);
         break;
+#define GNNVC_LAUNCH_F16(N2_, N3_, SIG_, MF_, SRT_, LG_)                                              \
+    hipLaunchKernelGGL((k_stage_f16<32, N2_, N3_, SIG_, 2, MF_, SRT_>), grid, block, 0, stream, g, ws, in4, out, \
+                       LG_, P, row_lo, row_hi, long_thresh, sorted ? so->vertex : nullptr,                \
+                       sorted ? so->meta : nullptr, sorted ? so->n : 0u)
     case 2:
-        hipLaunchKernelGGL((k_stage_f16<32, 32, 16, false, 2, false>), grid, block, 0, stream, g, ws, in4, out,
-                           nullptr, P, row_lo, row_hi, long_thresh);
+        if (sorted) GNNVC_LAUNCH_F16(32, 16, false, false, true, nullptr);
+        else GNNVC_LAUNCH_F16(32, 16, false, false, false, nullptr);
         break;
     case 3:
-        hipLaunchKernelGGL((k_stage_f16<32, 32, 16, false, 2, true>), grid, block, 0, stream, g, ws, in4, out,
-                           nullptr, P, row_lo, row_hi, long_thresh);
+        if (sorted) GNNVC_LAUNCH_F16(32, 16, false, true, true, nullptr);
+        else GNNVC_LAUNCH_F16(32, 16, false, true, false, nullptr);
         break;
     case 4:
-        hipLaunchKernelGGL((k_stage_f16<32, 16, 1, true, 2, false>), grid, block, 0, stream, g, ws, in4, out,
-                           logits, P, row_lo, row_hi, long_thresh);
+        if (sorted) GNNVC_LAUNCH_F16(16, 1, true, false, true, logits);
+        else GNNVC_LAUNCH_F16(16, 1, true, false, false, logits);
         break;
     case 5:
-        hipLaunchKernelGGL((k_stage_f16<32, 16, 1, true, 2, true>), grid, block, 0, stream, g, ws, in4, out,
-                           logits, P, row_lo, row_hi, long_thresh);
+        if (sorted) GNNVC_LAUNCH_F16(16, 1, true, true, true, logits);
+        else GNNVC_LAUNCH_F16(16, 1, true, true, false, logits);
         break;
+#undef GNNVC_LAUNCH_F16
     default:
         return hipErrorInvalidValue;
     }
@@ -1061,6 +1139,33 @@ hipError_t launch_stage0_blocked(const StagePlan &sp, const GraphDev &g, float w
     else
         hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, false>), grid, block, 0, stream, g, ws, x, out,
                            params + sp.param_offset, row_lo, row_hi, ep, colb, acc_in, long_thresh);
+    return hipGetLastError();
+}
+
+// ---- degree-sorted tile order ------------------------------------------------------------
+hipError_t measure_tile_waste(const GraphDev &g, uint32_t row_lo, uint32_t row_hi, uint32_t long_thresh,
+                              unsigned long long *sum_max, hipStream_t stream) {
+    hipError_t rc = hipMemsetAsync(sum_max, 0, sizeof(unsigned long long), stream);
+    if (rc != hipSuccess || row_hi <= row_lo) return rc;
+    hipLaunchKernelGGL(k_tile_waste, dim3((row_hi - row_lo + 255) / 256), dim3(256), 0, stream, g, row_lo, row_hi,
+                       long_thresh, sum_max);
+    return hipGetLastError();
+}
+
+hipError_t degree_histogram(const GraphDev &g, uint32_t row_lo, uint32_t row_hi, uint32_t long_thresh,
+                            uint32_t bins, uint32_t *hist, hipStream_t stream) {
+    hipError_t rc = hipMemsetAsync(hist, 0, bins * sizeof(uint32_t), stream);
+    if (rc != hipSuccess || row_hi <= row_lo) return rc;
+    hipLaunchKernelGGL(k_deg_hist, dim3((row_hi - row_lo + 255) / 256), dim3(256), 0, stream, g, row_lo, row_hi,
+                       long_thresh, bins, hist);
+    return hipGetLastError();
+}
+
+hipError_t degree_scatter(const GraphDev &g, uint32_t row_lo, uint32_t row_hi, uint32_t long_thresh,
+                          uint32_t bins, uint32_t *cursor, uint32_t *vertex, void *meta, hipStream_t stream) {
+    if (row_hi <= row_lo) return hipSuccess;
+    hipLaunchKernelGGL(k_deg_scatter, dim3((row_hi - row_lo + 255) / 256), dim3(256), 0, stream, g, row_lo, row_hi,
+                       long_thresh, bins, cursor, vertex, reinterpret_cast<uint4 *>(meta));
     return hipGetLastError();
 }
 

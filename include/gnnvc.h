@@ -77,7 +77,10 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *   "mfma_dense"     0|1|2  dense layers on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, a
  *                         k-ordered fma chain: same bits as the VALU path): 0 = VALU, 1 = MFMA in
  *                         every stage, 2 = MFMA in the 16-wide stages only (default); immediate
- * gnnvc_get_info keys: "mfma_dense", "blocked_stage0_active", "blocked_blocks", "block_cols", "long_rows",
+ *   "sorted_tiles"   -1|0|1  16-wide stages take their 64-vertex tiles from a degree-sorted
+ *                         vertex list instead of 64 consecutive rows (-1 = only when natural tiles
+ *                         would spend more than twice the useful gather rounds, the default)
+ * gnnvc_get_info keys: "mfma_dense", "sorted_tiles_active", "tile_waste_x100", "blocked_stage0_active", "blocked_blocks", "block_cols", "long_rows",
  * "long_row_threshold". */
 int gnnvc_set_option(gnnvc_engine *e, const char *key, long value);
 int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value);

@@ -400,3 +400,52 @@ def test_dense_layers_mfma_and_valu_are_bit_identical(model_text, oracle_model, 
                 assert ulp(scores[:, 0], oracle_model.scores(g, x)).max() <= 1
     finally:
         e.close()
+
+
+# ---------------------------------------------------------------- degree-sorted tiles
+
+@pytest.mark.parametrize("mfma", [0, 2])
+def test_sorted_tiles_are_bit_identical(model_text, oracle_model, mfma):
+    """Tiles taken from a degree-sorted vertex list (skewed graphs) instead of 64 consecutive
+    rows: every row is still summed alone, in CSR order — same bits; also over row sub-ranges."""
+    import torch
+    import gnn_mwvc_amd as G
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_option("sorted_tiles", 1)
+        e.set_option("mfma_dense", mfma)
+        e.set_option("sorted_long_row_threshold", 700)
+        dev = torch.device("cuda:0")
+        for g in (gg.rmat(12, 16, 9), gg.hub_graph(20000, 60000, 3, 4096, seed=7), gg.erdos_renyi(3000, 20000, 61),
+                  gg.from_edge_list(130, [(0, i) for i in range(1, 40)], list(range(20, 150)))):
+            e.set_weight_scale(g.ws)
+            oracle_model.set_weight_scale(g.ws)
+            e.upload_graph(g)
+            assert e.get_info("sorted_tiles_active") == 1
+            scores, logits = e.forward(g.x())
+            assert np.array_equal(bits(logits[:, 0]), bits(oracle_model.logits(g)))
+            assert ulp(scores[:, 0], oracle_model.scores(g)).max() <= 1
+            h1 = torch.zeros((g.n + 1, 16), device=dev)
+            h1[:-1] = torch.from_numpy(oracle_model.predict(g, g.x(), stop_after=6)).to(dev)
+            h2 = torch.zeros((g.n + 1, 16), device=dev)
+            torch.cuda.synchronize()
+            cuts = [0, (g.n // 3) // 64 * 64, g.n]
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                e.stage_forward_device(1, lo, hi, h1.data_ptr(), h2.data_ptr())
+            e.synchronize()
+            assert np.array_equal(bits(h2[:-1].cpu().numpy()), bits(oracle_model.predict(g, g.x(), stop_after=13)))
+    finally:
+        e.close()
+
+
+def test_sorted_tiles_auto_decision(model_text):
+    """Auto mode sorts only when natural tiles would waste more than half of their rounds."""
+    import gnn_mwvc_amd as G
+    e = G.Engine(model_text, device=0)
+    try:
+        e.upload_graph(gg.erdos_renyi(20000, 200000, 71))      # uniform degrees: natural tiles
+        assert e.get_info("sorted_tiles_active") == 0 and 100 <= e.get_info("tile_waste_x100") < 200
+        e.upload_graph(gg.rmat(13, 16, 72))                    # power-law degrees: sorted tiles
+        assert e.get_info("sorted_tiles_active") == 1 and e.get_info("tile_waste_x100") >= 200
+    finally:
+        e.close()
