@@ -79,6 +79,7 @@ def main() -> int:
     ap.add_argument("--block-cols", type=int, default=0)
     ap.add_argument("--long-threshold", type=int, default=-1, help="degree at which a row gets its own workgroup")
     ap.add_argument("--sorted-tiles", type=int, default=-1, help="degree-sorted tiles: -1 auto, 0 off, 1 on")
+    ap.add_argument("--sorted-long-threshold", type=int, default=0)
     ap.add_argument("--mfma", type=int, default=-1, help="dense layers: 0 VALU, 1 MFMA everywhere, 2 MFMA in the 16-wide stages (default)")
     ap.add_argument("--pipeline-chunks", type=int, default=4,
                     help="N>1: pieces per stage whose all-gather overlaps the next piece's compute (0/1 = off)")
@@ -133,6 +134,8 @@ def main() -> int:
     if args.mfma >= 0:
         eng.set_option("mfma_dense", args.mfma)
     eng.set_option("sorted_tiles", args.sorted_tiles)
+    if args.sorted_long_threshold > 0:
+        eng.set_option("sorted_long_row_threshold", args.sorted_long_threshold)
     t0 = time.time()
     eng.attach_graph_device(g.n, g.nnz, g.rowptr.data_ptr(), g.col.data_ptr(), g.w.data_ptr(),
                             g.nw.data_ptr(), keepalive=g)
@@ -232,7 +235,8 @@ def main() -> int:
                  "column_blocks": eng.get_info("blocked_blocks"), "block_cols": eng.get_info("block_cols"),
                  "mfma_dense": eng.get_info("mfma_dense"),
                  "sorted_tiles": bool(eng.get_info("sorted_tiles_active")),
-                 "natural_tile_waste": eng.get_info("tile_waste_x100") / 100.0, "long_rows": eng.get_info("long_rows"), "long_row_threshold": eng.get_info("long_row_threshold")},
+                 "natural_tile_waste": eng.get_info("tile_waste_x100") / 100.0,
+                 "interleaved_tiles": bool(eng.get_info("interleaved_tiles")), "long_rows": eng.get_info("long_rows"), "long_row_threshold": eng.get_info("long_row_threshold")},
     }
 
     if world > 1:

@@ -96,7 +96,8 @@ struct gnnvc_engine {
 
     // degree-sorted tile order (16-wide stages, skewed graphs); built per row range on demand
     int opt_sorted = -1;               // option "sorted_tiles": -1 auto (by measured waste), 0 off, 1 on
-    uint32_t opt_sorted_long_thresh = 1024;   // long-row threshold used with sorted tiles
+    uint32_t opt_sorted_long_thresh = 512;    // long-row threshold used with sorted tiles
+    bool interleave = false;           // deal natural tiles round-robin (work is unevenly spread over the row range)
     bool sorted_wanted = false;        // decided per graph from the measured tile waste
     bool sorted_valid = false;         // the cached order below matches (srt_lo, srt_hi) of the current graph
     bool sorted_use = false;
@@ -301,7 +302,20 @@ int find_long(gnnvc_engine *e) {
     const GraphDev &g = e->g;
     e->sorted_wanted = false;
     e->srt_waste = 0.0;
+    e->interleave = false;
     if (e->stages.empty() || g.n == 0) return GNNVC_OK;
+    if (g.nnz && g.n >= 4096) {
+        // The natural tile map hands each XCD a contiguous eighth of the rows.  If the eighths hold
+        // very different numbers of entries (R-MAT: low ids are the hubs) deal tiles round-robin.
+        uint32_t cut[9];
+        for (int k = 0; k <= 8; ++k)
+            HIP_TRY(e, hipMemcpyAsync(&cut[k], g.rowptr + (size_t)((uint64_t)g.n * k / 8), sizeof(uint32_t),
+                                      hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        uint32_t mx = 0;
+        for (int k = 0; k < 8; ++k) mx = std::max(mx, cut[k + 1] - cut[k]);
+        e->interleave = (double)mx > 1.25 * (double)g.nnz / 8.0;
+    }
     const uint32_t base_thresh = e->opt_long_thresh ? e->opt_long_thresh : 0xFFFFFFFFu;
     if (e->opt_sorted != 0 && g.nnz) {
         // lockstep cost of natural 64-row tiles (64 x sum of per-tile maxima) against the useful work
@@ -411,7 +425,7 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
     if (stage == 0 && e->blocked_ready) {
         HIP_TRY(e, gnnvc::launch_stage0_blocked(e->stages[0], e->g, e->ws, e->params.p, in, out, lo, hi,
                                                 e->blk_count, e->blk_ptr.p, e->blk_col.p, e->blk_acc.p,
-                                                e->long_thresh, e->opt_mfma == 1, e->stream));
+                                                e->long_thresh, e->opt_mfma == 1, e->interleave, e->stream));
     } else {
         const bool mfma = e->opt_mfma == 1 || (e->opt_mfma == 2 && e->stages[stage].f == 16);
         gnnvc::SortedOrder so;
@@ -427,7 +441,7 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
             }
         }
         HIP_TRY(e, gnnvc::launch_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi,
-                                       e->long_thresh, mfma, sop, e->stream));
+                                       e->long_thresh, mfma, sop, e->interleave, e->stream));
     }
     if (longs) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));   // join
     return GNNVC_OK;
@@ -608,6 +622,7 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
     else if (k == "mfma_dense") *value = e->opt_mfma;
     else if (k == "sorted_tiles_active") *value = e->sorted_wanted ? 1 : 0;
     else if (k == "tile_waste_x100") *value = (long)(e->srt_waste * 100.0);
+    else if (k == "interleaved_tiles") *value = e->interleave ? 1 : 0;
     else if (k == "long_row_threshold") *value = e->n_long ? (long)e->long_thresh : 0;
     else return GNNVC_ERR_INVALID;
     return GNNVC_OK;

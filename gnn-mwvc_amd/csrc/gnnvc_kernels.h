@@ -46,7 +46,7 @@ int stage_variant(int f, int n1, int n2, int n3, int sigmoid_last);
 hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
                         const float *in, float *out, float *logits, uint32_t row_lo,
                         uint32_t row_hi, uint32_t long_thresh, bool mfma, const SortedOrder *so,
-                        hipStream_t stream);
+                        bool interleave, hipStream_t stream);
 
 // Building blocks of the degree-sorted order (the prefix over the few thousand degree classes
 // is done on the host).
@@ -77,7 +77,7 @@ hipError_t build_blocked_index(const GraphDev &g, uint32_t wb, uint32_t nblocks,
 hipError_t launch_stage0_blocked(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
                                  const float *x, float *out, uint32_t row_lo, uint32_t row_hi,
                                  uint32_t nblocks, const uint32_t *bp, const uint32_t *colb, float *acc,
-                                 uint32_t long_thresh, bool mfma, hipStream_t stream);
+                                 uint32_t long_thresh, bool mfma, bool interleave, hipStream_t stream);
 
 // Layer-by-layer kernels (any model; also the layer-level ABI entry points).
 hipError_t launch_graph_layer(const GraphDev &g, float ws, uint32_t f, const float *in,

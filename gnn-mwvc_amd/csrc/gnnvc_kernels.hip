@@ -66,7 +66,10 @@ __device__ __forceinline__ void dense(const float (&in)[K], float (&out)[N],
 // (block b shares an L2 with block b + 8), so XCD-group x = b % 8 walks the
 // x-th contiguous eighth of the tile range: rows a graph stores close together
 // are gathered through the same L2.
-__device__ __forceinline__ uint32_t tile_for_wave(uint32_t ntiles) {
+__device__ __forceinline__ uint32_t tile_for_wave(uint32_t ntiles, bool interleave = false) {
+    // interleave: tiles dealt round-robin over the blocks (hence over the XCDs) — used when
+    // contiguous eighths of the tile range carry very different amounts of work
+    if (interleave) return blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const uint32_t per_xcd = (ntiles + 7u) / 8u;
     const uint32_t xcd = blockIdx.x & 7u;
     const uint32_t slot = (blockIdx.x >> 3) * kWavesPerBlock + (threadIdx.x >> 6);
@@ -241,13 +244,16 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
         GraphDev g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
         float *__restrict__ logits, const float *__restrict__ P, uint32_t row_lo,
         uint32_t row_hi, uint32_t long_thresh, const uint32_t *__restrict__ srt_vertex,
-        const uint4 *__restrict__ srt_meta, uint32_t n_sorted) {
+        const uint4 *__restrict__ srt_meta, uint32_t n_sorted, int interleave) {
     __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kRegionFloats];
     const int lane = threadIdx.x & 63;
     float *T = lds[threadIdx.x >> 6];
     uint32_t *stage = reinterpret_cast<uint32_t *>(T);
     const uint32_t ntiles = SORTED ? (n_sorted + kWave - 1) / kWave : (row_hi - row_lo + kWave - 1) / kWave;
-    const uint32_t tile = tile_for_wave(ntiles);
+    // natural order: XCD-contiguous ranges (locality).  Sorted order lists the heaviest tiles
+    // first, so they are dealt round-robin instead — consecutive blocks sit on different XCDs
+    // and every XCD gets the same mix of heavy and light tiles.
+    const uint32_t tile = tile_for_wave(ntiles, SORTED || interleave);
     if (tile >= ntiles) return;
     const uint32_t v0 = row_lo + tile * kWave;   // natural order only
 
@@ -443,13 +449,13 @@ __global__ __launch_bounds__(kBlock) void k_stage_f1(
         GraphDev g, float ws, const float *__restrict__ xin, float *__restrict__ fout,
         const float *__restrict__ P, uint32_t row_lo, uint32_t row_hi,
         const uint32_t *__restrict__ ep, const uint32_t *__restrict__ ecol,
-        const float *__restrict__ acc_in, uint32_t long_thresh) {
+        const float *__restrict__ acc_in, uint32_t long_thresh, int interleave) {
     __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kRegionFloats];
     const int lane = threadIdx.x & 63;
     float *T = lds[threadIdx.x >> 6];
     uint32_t *stage = reinterpret_cast<uint32_t *>(T);
     const uint32_t ntiles = (row_hi - row_lo + kWave - 1) / kWave;
-    const uint32_t tile = tile_for_wave(ntiles);
+    const uint32_t tile = tile_for_wave(ntiles, interleave != 0);
     if (tile >= ntiles) return;
     const uint32_t v0 = row_lo + tile * kWave;
     const uint32_t u = v0 + lane;
@@ -995,7 +1001,7 @@ int stage_variant(int f, int n1, int n2, int n3, int sigmoid_last) {
 hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
                         const float *in, float *out, float *logits, uint32_t row_lo,
                         uint32_t row_hi, uint32_t long_thresh, bool mfma, const SortedOrder *so,
-                        hipStream_t stream) {
+                        bool interleave, hipStream_t stream) {
     if (row_hi <= row_lo) return hipSuccess;
     const bool sorted = so && so->n > 0 && sp.f == 16;
     if (so && so->n == 0 && sp.f == 16) return hipSuccess;   // every row of the range is a long row
@@ -1006,19 +1012,20 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
     const float *P = params + sp.param_offset;
     const float4 *in4 = reinterpret_cast<const float4 *>(in);
     const float *nofloat = nullptr;
+    const int il = interleave ? 1 : 0;
     switch (sp.variant * 2 + (mfma ? 1 : 0)) {
     case 0:
         hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, false>), grid, block, 0, stream, g, ws, in, out, P,
-                           row_lo, row_hi, g.rowptr, g.col, nofloat, long_thresh);
+                           row_lo, row_hi, g.rowptr, g.col, nofloat, long_thresh, il);
         break;
     case 1:
         hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, true>), grid, block, 0, stream, g, ws, in, out, P,
-                           row_lo, row_hi, g.rowptr, g.col, nofloat, long_thresh);
+                           row_lo, row_hi, g.rowptr, g.col, nofloat, long_thresh, il);
         break;
 #define GNNVC_LAUNCH_F16(N2_, N3_, SIG_, MF_, SRT_, LG_)                                              \
     hipLaunchKernelGGL((k_stage_f16<32, N2_, N3_, SIG_, 2, MF_, SRT_>), grid, block, 0, stream, g, ws, in4, out, \
                        LG_, P, row_lo, row_hi, long_thresh, sorted ? so->vertex : nullptr,                \
-                       sorted ? so->meta : nullptr, sorted ? so->n : 0u)
+                       sorted ? so->meta : nullptr, sorted ? so->n : 0u, il)
     case 2:
         if (sorted) GNNVC_LAUNCH_F16(32, 16, false, false, true, nullptr);
         else GNNVC_LAUNCH_F16(32, 16, false, false, false, nullptr);
@@ -1120,7 +1127,7 @@ hipError_t build_blocked_index(const GraphDev &g, uint32_t wb, uint32_t nblocks,
 hipError_t launch_stage0_blocked(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
                                  const float *x, float *out, uint32_t row_lo, uint32_t row_hi,
                                  uint32_t nblocks, const uint32_t *bp, const uint32_t *colb, float *acc,
-                                 uint32_t long_thresh, bool mfma, hipStream_t stream) {
+                                 uint32_t long_thresh, bool mfma, bool interleave, hipStream_t stream) {
     if (row_hi <= row_lo) return hipSuccess;
     if (sp.variant != 0) return hipErrorInvalidValue;
     const unsigned nb = (row_hi - row_lo + 255) / 256;
@@ -1135,10 +1142,10 @@ hipError_t launch_stage0_blocked(const StagePlan &sp, const GraphDev &g, float w
     const dim3 grid(blocks_per_xcd * 8), block(kBlock);
     if (mfma)
         hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, true>), grid, block, 0, stream, g, ws, x, out,
-                           params + sp.param_offset, row_lo, row_hi, ep, colb, acc_in, long_thresh);
+                           params + sp.param_offset, row_lo, row_hi, ep, colb, acc_in, long_thresh, interleave ? 1 : 0);
     else
         hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, false>), grid, block, 0, stream, g, ws, x, out,
-                           params + sp.param_offset, row_lo, row_hi, ep, colb, acc_in, long_thresh);
+                           params + sp.param_offset, row_lo, row_hi, ep, colb, acc_in, long_thresh, interleave ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -342,6 +342,7 @@ def test_long_row_path_is_bit_identical(model_text, oracle_model, thresh, block_
     e = G.Engine(model_text, device=0)
     try:
         e.set_option("long_row_threshold", thresh)
+        e.set_option("sorted_tiles", 0)   # (sorted tiles raise the threshold; covered by their own test)
         if block_cols:
             e.set_option("blocked_min_n", 0)
             e.set_option("block_cols", block_cols)
