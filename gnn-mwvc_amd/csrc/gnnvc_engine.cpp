@@ -96,7 +96,8 @@ struct gnnvc_engine {
 
     // degree-sorted tile order (16-wide stages, skewed graphs); built per row range on demand
     int opt_sorted = -1;               // option "sorted_tiles": -1 auto (by measured waste), 0 off, 1 on
-    uint32_t opt_sorted_long_thresh = 512;    // long-row threshold used with sorted tiles
+    uint32_t opt_sorted_long_thresh = 1024;   // long-row threshold of the 16-wide stages when their tiles are sorted
+    uint32_t thresh_f16 = 0xFFFFFFFFu;        // rows >= this go to k_long_f16 (>= long_thresh, the list's threshold)
     bool interleave = false;           // deal natural tiles round-robin (work is unevenly spread over the row range)
     bool sorted_wanted = false;        // decided per graph from the measured tile waste
     bool sorted_valid = false;         // the cached order below matches (srt_lo, srt_hi) of the current graph
@@ -297,6 +298,7 @@ int use_device(gnnvc_engine *e) {
 int find_long(gnnvc_engine *e) {
     e->n_long = 0;
     e->long_thresh = 0xFFFFFFFFu;
+    e->thresh_f16 = 0xFFFFFFFFu;
     e->sorted_valid = false;   // new graph: any cached tile order is stale
     e->sorted_use = false;
     const GraphDev &g = e->g;
@@ -328,9 +330,11 @@ int find_long(gnnvc_engine *e) {
         e->sorted_wanted = e->opt_sorted > 0 || e->srt_waste >= 2.0;
     }
     if (!e->opt_long_thresh) return GNNVC_OK;
-    // with degree-sorted tiles the tile kernel copes with longer rows, so fewer rows go long
-    const uint32_t thresh = e->sorted_wanted ? std::max(e->opt_long_thresh, e->opt_sorted_long_thresh)
-                                             : e->opt_long_thresh;
+    // One list at the base threshold serves every stage.  With degree-sorted tiles the 16-wide
+    // tile kernel copes with longer rows, so those stages send only rows >= thresh_f16 long
+    // (the others return at once from the long kernel and sit in the sorted tile list instead).
+    const uint32_t thresh = e->opt_long_thresh;
+    e->thresh_f16 = 0xFFFFFFFFu;
     HIP_TRY(e, e->long_list.reserve(g.n));
     HIP_TRY(e, e->long_count.reserve(1));
     HIP_TRY(e, gnnvc::find_long_rows(g, thresh, e->long_list.p, e->long_count.p, e->stream));
@@ -345,6 +349,7 @@ int find_long(gnnvc_engine *e) {
     }
     e->n_long = cnt;
     e->long_thresh = thresh;
+    e->thresh_f16 = e->sorted_wanted ? std::max(thresh, e->opt_sorted_long_thresh) : thresh;
     return GNNVC_OK;
 }
 
@@ -361,11 +366,12 @@ int ensure_sorted(gnnvc_engine *e, uint32_t lo, uint32_t hi) {
     e->srt_n = 0;
     const GraphDev &g = e->g;
     if (!e->sorted_wanted || hi <= lo || g.nnz == 0) return GNNVC_OK;
-    const uint32_t bins = e->long_thresh < 4096u ? e->long_thresh + 1 : 4096u;
+    const uint32_t lt = e->thresh_f16;
+    const uint32_t bins = lt < 4096u ? lt + 1 : 4096u;
     HIP_TRY(e, e->srt_hist.reserve(bins));
     HIP_TRY(e, e->srt_vertex.reserve(hi - lo));
     HIP_TRY(e, e->srt_meta.reserve(hi - lo));
-    HIP_TRY(e, gnnvc::degree_histogram(g, lo, hi, e->long_thresh, bins, e->srt_hist.p, e->stream));
+    HIP_TRY(e, gnnvc::degree_histogram(g, lo, hi, lt, bins, e->srt_hist.p, e->stream));
     std::vector<uint32_t> hist(bins), start(bins);
     HIP_TRY(e, hipMemcpyAsync(hist.data(), e->srt_hist.p, bins * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -375,7 +381,7 @@ int ensure_sorted(gnnvc_engine *e, uint32_t lo, uint32_t hi) {
         run += hist[d];
     }
     HIP_TRY(e, hipMemcpyAsync(e->srt_hist.p, start.data(), bins * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(e, gnnvc::degree_scatter(g, lo, hi, e->long_thresh, bins, e->srt_hist.p, e->srt_vertex.p,
+    HIP_TRY(e, gnnvc::degree_scatter(g, lo, hi, lt, bins, e->srt_hist.p, e->srt_vertex.p,
                                      e->srt_meta.p, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));   // `start` is read by the async copy above
     e->srt_n = run;
@@ -415,11 +421,12 @@ int build_blocked(gnnvc_engine *e) {
 // stage launcher shared by the whole-forward and the per-stage entry points
 int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float *in, float *out, float *logits) {
     const bool longs = e->n_long > 0;
+    const uint32_t thr = (e->stages[stage].f == 16) ? e->thresh_f16 : e->long_thresh;   // this stage's long-row threshold
     if (longs) {   // fork: the long rows of this stage run beside the tile kernel
         HIP_TRY(e, hipEventRecord(e->ev_fork, e->stream));
         HIP_TRY(e, hipStreamWaitEvent(e->aux_stream, e->ev_fork, 0));
         HIP_TRY(e, gnnvc::launch_long_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi,
-                                            e->long_list.p, e->n_long, e->aux_stream));
+                                            e->long_list.p, e->n_long, thr, e->aux_stream));
         HIP_TRY(e, hipEventRecord(e->ev_join, e->aux_stream));
     }
     if (stage == 0 && e->blocked_ready) {
@@ -441,7 +448,7 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
             }
         }
         HIP_TRY(e, gnnvc::launch_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi,
-                                       e->long_thresh, mfma, sop, e->interleave, e->stream));
+                                       thr, mfma, sop, e->interleave, e->stream));
     }
     if (longs) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));   // join
     return GNNVC_OK;

@@ -64,7 +64,7 @@ hipError_t find_long_rows(const GraphDev &g, uint32_t thresh, uint32_t *list, ui
                           hipStream_t stream);
 hipError_t launch_long_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
                              const float *in, float *out, float *logits, uint32_t row_lo, uint32_t row_hi,
-                             const uint32_t *list, uint32_t n_long, hipStream_t stream);
+                             const uint32_t *list, uint32_t n_long, uint32_t min_deg, hipStream_t stream);
 
 // Column-blocked F = 1 stage (bit-identical to launch_stage on stage 0; see the kernels).
 // bp: uint32[nblocks * n + 1] block-major entry pointers, colb: uint32[nnz + pad] re-bucketed

@@ -15,6 +15,8 @@
 // __builtin_fmaf calls; every other add / divide is separately rounded.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "expf_glibc.h"
 #include "gnnvc_kernels.h"
 
@@ -608,13 +610,14 @@ template <int N1, int N2, int N3, bool SIGMOID>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_long_f16(
         GraphDev g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
         float *__restrict__ logits, const float *__restrict__ P, uint32_t row_lo, uint32_t row_hi,
-        const uint32_t *__restrict__ list) {
+        const uint32_t *__restrict__ list, uint32_t min_deg) {
     __shared__ __attribute__((aligned(16))) float slab[2][kLongChunk * 16];
     const uint32_t u = list[blockIdx.x];
     if (u < row_lo || u >= row_hi) return;   // block-uniform
     const int tid = threadIdx.x, q = tid >> 2, c = tid & 3;
     const uint32_t rs = g.rowptr[u], re = g.rowptr[u + 1];
     const uint32_t deg = re - rs;
+    if (deg < min_deg) return;               // listed for another stage's threshold; a tile kernel has it here
     const uint32_t zrow = g.n;
     // Two register sets (A, B) alternate: while one round drains through the slab, the
     // 1024 row fetches of the next round and the column indices of the round after it are
@@ -689,7 +692,7 @@ template <int N1, int N2, int N3>
 __global__ __launch_bounds__(256) void k_long_f1(
         GraphDev g, float ws, const float *__restrict__ xin, float *__restrict__ fout,
         const float *__restrict__ P, uint32_t row_lo, uint32_t row_hi,
-        const uint32_t *__restrict__ list) {
+        const uint32_t *__restrict__ list, uint32_t min_deg) {
     // a round = 2048 neighbours (8 per thread); values of round r + 1 and column indices of
     // round r + 2 are in flight while thread 0 adds round r from the LDS slab in CSR order
     constexpr int R = 8;
@@ -700,6 +703,7 @@ __global__ __launch_bounds__(256) void k_long_f1(
     const int tid = threadIdx.x;
     const uint32_t rs = g.rowptr[u], re = g.rowptr[u + 1];
     const uint32_t deg = re - rs;
+    if (deg < min_deg) return;
     const uint32_t nrounds = (deg + kRound - 1) / kRound;
     uint32_t idx[R];
     float v[R];
@@ -778,11 +782,16 @@ __global__ __launch_bounds__(256) void k_tile_waste(GraphDev g, uint32_t row_lo,
 // histogram of min(degree, bins - 1) over the non-long rows of [row_lo, row_hi)
 __global__ __launch_bounds__(256) void k_deg_hist(GraphDev g, uint32_t row_lo, uint32_t row_hi, uint32_t long_thresh,
                                                   uint32_t bins, uint32_t *__restrict__ hist) {
-    const uint32_t u = row_lo + blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= row_hi) return;
-    const uint32_t d = g.rowptr[u + 1] - g.rowptr[u];
-    if (d >= long_thresh) return;
-    atomicAdd(&hist[d < bins ? d : bins - 1], 1u);
+    __shared__ uint32_t local[4096];   // bins <= 4096: a few degree classes take most rows, so count per block first
+    for (uint32_t i = threadIdx.x; i < bins; i += blockDim.x) local[i] = 0;
+    __syncthreads();
+    for (uint32_t u = row_lo + blockIdx.x * blockDim.x + threadIdx.x; u < row_hi; u += gridDim.x * blockDim.x) {
+        const uint32_t d = g.rowptr[u + 1] - g.rowptr[u];
+        if (d < long_thresh) atomicAdd(&local[d < bins ? d : bins - 1], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < bins; i += blockDim.x)
+        if (local[i]) atomicAdd(&hist[i], local[i]);
 }
 
 // cursor[d] holds the next free slot of degree class d (classes laid out by DEscending degree,
@@ -790,14 +799,31 @@ __global__ __launch_bounds__(256) void k_deg_hist(GraphDev g, uint32_t row_lo, u
 __global__ __launch_bounds__(256) void k_deg_scatter(GraphDev g, uint32_t row_lo, uint32_t row_hi, uint32_t long_thresh,
                                                      uint32_t bins, uint32_t *__restrict__ cursor,
                                                      uint32_t *__restrict__ vertex, uint4 *__restrict__ meta) {
+    // per block: count its rows per class in LDS, reserve one range per class with a single
+    // global atomic, then hand out slots from LDS (global atomics: one per class per block)
+    __shared__ uint32_t local[4096];
+    for (uint32_t i = threadIdx.x; i < bins; i += blockDim.x) local[i] = 0;
+    __syncthreads();
     const uint32_t u = row_lo + blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= row_hi) return;
-    const uint32_t rs = g.rowptr[u], re = g.rowptr[u + 1];
-    const uint32_t d = re - rs;
-    if (d >= long_thresh) return;
-    const uint32_t slot = atomicAdd(&cursor[d < bins ? d : bins - 1], 1u);
-    vertex[slot] = u;
-    meta[slot] = make_uint4(rs, re, g.w[u], g.nw[u]);
+    uint32_t rs = 0, re = 0, cls = 0xFFFFFFFFu, rank_in_block = 0;
+    if (u < row_hi) {
+        rs = g.rowptr[u];
+        re = g.rowptr[u + 1];
+        const uint32_t d = re - rs;
+        if (d < long_thresh) {
+            cls = d < bins ? d : bins - 1;
+            rank_in_block = atomicAdd(&local[cls], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < bins; i += blockDim.x)
+        if (local[i]) local[i] = atomicAdd(&cursor[i], local[i]);   // now the block's base slot of class i
+    __syncthreads();
+    if (cls != 0xFFFFFFFFu) {
+        const uint32_t slot = local[cls] + rank_in_block;
+        vertex[slot] = u;
+        meta[slot] = make_uint4(rs, re, g.w[u], g.nw[u]);
+    }
 }
 
 // ------------------------------------------------------------------ column-blocked F = 1 aggregation
@@ -1163,8 +1189,8 @@ hipError_t degree_histogram(const GraphDev &g, uint32_t row_lo, uint32_t row_hi,
                             uint32_t bins, uint32_t *hist, hipStream_t stream) {
     hipError_t rc = hipMemsetAsync(hist, 0, bins * sizeof(uint32_t), stream);
     if (rc != hipSuccess || row_hi <= row_lo) return rc;
-    hipLaunchKernelGGL(k_deg_hist, dim3((row_hi - row_lo + 255) / 256), dim3(256), 0, stream, g, row_lo, row_hi,
-                       long_thresh, bins, hist);
+    const unsigned nb = std::min<unsigned>((row_hi - row_lo + 255) / 256, 2048u);
+    hipLaunchKernelGGL(k_deg_hist, dim3(nb), dim3(256), 0, stream, g, row_lo, row_hi, long_thresh, bins, hist);
     return hipGetLastError();
 }
 
@@ -1187,21 +1213,22 @@ hipError_t find_long_rows(const GraphDev &g, uint32_t thresh, uint32_t *list, ui
 
 hipError_t launch_long_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
                              const float *in, float *out, float *logits, uint32_t row_lo, uint32_t row_hi,
-                             const uint32_t *list, uint32_t n_long, hipStream_t stream) {
+                             const uint32_t *list, uint32_t n_long, uint32_t min_deg, hipStream_t stream) {
     if (n_long == 0 || row_hi <= row_lo) return hipSuccess;
     const float *P = params + sp.param_offset;
     const dim3 grid(n_long), block(256);
     switch (sp.variant) {
     case 0:
-        hipLaunchKernelGGL((k_long_f1<32, 32, 16>), grid, block, 0, stream, g, ws, in, out, P, row_lo, row_hi, list);
+        hipLaunchKernelGGL((k_long_f1<32, 32, 16>), grid, block, 0, stream, g, ws, in, out, P, row_lo, row_hi, list,
+                           min_deg);
         break;
     case 1:
         hipLaunchKernelGGL((k_long_f16<32, 32, 16, false>), grid, block, 0, stream, g, ws,
-                           reinterpret_cast<const float4 *>(in), out, nullptr, P, row_lo, row_hi, list);
+                           reinterpret_cast<const float4 *>(in), out, nullptr, P, row_lo, row_hi, list, min_deg);
         break;
     case 2:
         hipLaunchKernelGGL((k_long_f16<32, 16, 1, true>), grid, block, 0, stream, g, ws,
-                           reinterpret_cast<const float4 *>(in), out, logits, P, row_lo, row_hi, list);
+                           reinterpret_cast<const float4 *>(in), out, logits, P, row_lo, row_hi, list, min_deg);
         break;
     default:
         return hipErrorInvalidValue;
