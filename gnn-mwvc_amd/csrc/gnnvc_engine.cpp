@@ -84,6 +84,8 @@ struct gnnvc_engine {
     uint32_t opt_block_cols = 0;    // option "block_cols" (0 = default)
     uint32_t opt_blocked_min_n = 1u << 20;  // below this x fits the L2s anyway
     bool blocked_ready = false;
+    bool blocked_tried = false;     // build attempted for the current graph
+    uint32_t graph_uses = 0;        // stage-0 executions on the current graph
     uint32_t blk_count = 0, blk_cols = 0;
     DevBuf<uint32_t> blk_ptr, blk_col, blk_scratch, blk_flag;
     DevBuf<float> blk_acc;
@@ -393,6 +395,7 @@ int ensure_sorted(gnnvc_engine *e, uint32_t lo, uint32_t hi) {
 // model is not fused, the graph is small, or a row's block ids are not monotone.
 int build_blocked(gnnvc_engine *e) {
     e->blocked_ready = false;
+    e->blocked_tried = true;
     const GraphDev &g = e->g;
     if (!e->opt_blocked || e->stages.empty() || e->stages[0].f != 1 || e->stages[0].variant != 0) return GNNVC_OK;
     if (g.n < e->opt_blocked_min_n || g.nnz == 0) return GNNVC_OK;
@@ -428,6 +431,13 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
         HIP_TRY(e, gnnvc::launch_long_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi,
                                             e->long_list.p, e->n_long, thr, e->aux_stream));
         HIP_TRY(e, hipEventRecord(e->ev_join, e->aux_stream));
+    }
+    if (stage == 0) {
+        if (e->graph_uses >= 1 && !e->blocked_tried) {
+            int rc = build_blocked(e);
+            if (rc) return rc;
+        }
+        ++e->graph_uses;
     }
     if (stage == 0 && e->blocked_ready) {
         HIP_TRY(e, gnnvc::launch_stage0_blocked(e->stages[0], e->g, e->ws, e->params.p, in, out, lo, hi,
@@ -658,40 +668,45 @@ int gnnvc_upload_graph(gnnvc_engine *e, uint32_t n, const uint64_t *rowptr, cons
     if (nnz >= 0xFFFFFFFFull - GNNVC_COL_PAD)
         return fail(e, GNNVC_ERR_UNSUPPORTED, "nnz %llu does not fit 32-bit row pointers", (unsigned long long)nnz);
     if (nnz && !col) return fail(e, GNNVC_ERR_INVALID, "null column array");
-    try {
-        std::vector<uint32_t> rp32((size_t)n + 1, 0);
-        for (uint32_t i = 0; i <= n && n; ++i) {
-            if (i && rowptr[i] < rowptr[i - 1]) return fail(e, GNNVC_ERR_INVALID, "rowptr not monotone at %u", i);
-            rp32[i] = (uint32_t)rowptr[i];
-        }
-        if (n && rowptr[0] != 0) return fail(e, GNNVC_ERR_INVALID, "rowptr[0] must be 0");
-        // a column id >= n would send the gather to a wild address on the device
-        for (uint64_t i = 0; i < nnz; ++i)
-            if (col[i] >= n) return fail(e, GNNVC_ERR_INVALID, "col[%llu] = %u is not a vertex of this graph (n = %u)",
-                                         (unsigned long long)i, col[i], n);
-        HIP_TRY(e, e->rowptr.reserve((size_t)n + 1));
-        HIP_TRY(e, e->col.reserve(nnz + GNNVC_COL_PAD));
-        HIP_TRY(e, e->w.reserve(n));
-        HIP_TRY(e, e->nw.reserve(n));
-        // everything below is stream-ordered with earlier forwards on e->stream
+    HIP_TRY(e, e->rowptr.reserve((size_t)n + 1));
+    HIP_TRY(e, e->col.reserve(nnz + GNNVC_COL_PAD));
+    HIP_TRY(e, e->w.reserve(n));
+    HIP_TRY(e, e->nw.reserve(n));
+    HIP_TRY(e, e->blk_flag.reserve(1));
+    // stream-ordered behind earlier forwards; the uint64 row pointers are staged in the scratch
+    // buffer and narrowed on the device, and the sanity checks run there too (a host pass over
+    // 2e8 column ids costs more than the copy)
+    HIP_TRY(e, e->scratch[0].reserve(((size_t)n + 1) * 2));
+    if (n) {
+        HIP_TRY(e, hipMemcpyAsync(e->scratch[0].p, rowptr, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(e, gnnvc::narrow_rowptr(e->scratch[0].p, e->rowptr.p, (size_t)n + 1, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(e->w.p, w, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(e->nw.p, nw, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    } else {
+        HIP_TRY(e, hipMemsetAsync(e->rowptr.p, 0, sizeof(uint32_t), e->stream));
+    }
+    if (nnz) HIP_TRY(e, hipMemcpyAsync(e->col.p, col, nnz * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipMemsetAsync(e->col.p + nnz, 0, GNNVC_COL_PAD * sizeof(uint32_t), e->stream));
+    {
+        const GraphDev cand{n, nnz, e->rowptr.p, e->col.p, e->w.p, e->nw.p};
+        HIP_TRY(e, gnnvc::validate_graph(cand, e->blk_flag.p, e->stream));
+        uint32_t bad = 0;
+        HIP_TRY(e, hipMemcpyAsync(&bad, e->blk_flag.p, sizeof bad, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(e, hipStreamSynchronize(e->stream));
-        HIP_TRY(e, hipMemcpy(e->rowptr.p, rp32.data(), rp32.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        if (nnz) HIP_TRY(e, hipMemcpy(e->col.p, col, nnz * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIP_TRY(e, hipMemset(e->col.p + nnz, 0, GNNVC_COL_PAD * sizeof(uint32_t)));
-        if (n) {
-            HIP_TRY(e, hipMemcpy(e->w.p, w, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
-            HIP_TRY(e, hipMemcpy(e->nw.p, nw, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (bad) {
+            e->have_graph = false;
+            return fail(e, GNNVC_ERR_INVALID, "%s", (bad & 1u) ? "a column id is not a vertex of this graph (col[i] >= n)"
+                                                                 : "row pointers are not monotone from 0 to nnz");
         }
-    } catch (const std::bad_alloc &) {
-        return fail(e, GNNVC_ERR_NOMEM, "host allocation failed");
     }
     e->g = GraphDev{n, nnz, e->rowptr.p, e->col.p, e->w.p, e->nw.p};
     e->have_graph = true;
     rc = reserve_features(e, n);
     if (rc) return rc;
-    rc = find_long(e);
-    if (rc) return rc;
-    return build_blocked(e);
+    e->blocked_ready = false;   // the column-blocked index is built on the graph's SECOND forward:
+    e->blocked_tried = false;   // it costs about as much as it saves on one, and the reference's
+    e->graph_uses = 0;          // driver uses every graph exactly once (src/GNN_VC.cpp:171-192)
+    return find_long(e);
 }
 
 int gnnvc_attach_graph_device(gnnvc_engine *e, uint32_t n, uint64_t nnz, const uint32_t *d_rowptr,
@@ -705,9 +720,10 @@ int gnnvc_attach_graph_device(gnnvc_engine *e, uint32_t n, uint64_t nnz, const u
     e->have_graph = true;
     rc = reserve_features(e, n);
     if (rc) return rc;
-    rc = find_long(e);
-    if (rc) return rc;
-    return build_blocked(e);
+    e->blocked_ready = false;   // the column-blocked index is built on the graph's SECOND forward:
+    e->blocked_tried = false;   // it costs about as much as it saves on one, and the reference's
+    e->graph_uses = 0;          // driver uses every graph exactly once (src/GNN_VC.cpp:171-192)
+    return find_long(e);
 }
 
 int gnnvc_stage_forward_device(gnnvc_engine *e, int stage, uint32_t row_lo, uint32_t row_hi,

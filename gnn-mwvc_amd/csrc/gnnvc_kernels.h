@@ -90,7 +90,12 @@ hipError_t launch_sgemm(int ta, int tb, uint32_t m, uint32_t n, uint32_t k, cons
                         uint32_t lda, const float *B, uint32_t ldb, float beta, float *C,
                         uint32_t ldc, hipStream_t stream);
 
-// u64 host rowptr -> u32 device rowptr happens on the host; this zero-fills
+// Device-side graph checks after an upload (*flags: bit0 column id out of range, bit1 bad
+// row pointers) and the uint64 -> uint32 row-pointer narrowing of the host ABI.
+hipError_t validate_graph(const GraphDev &g, uint32_t *flags, hipStream_t stream);
+hipError_t narrow_rowptr(const void *in_u64, uint32_t *out, size_t count, hipStream_t stream);
+
+// this zero-fills
 // the pad row of a feature matrix: rows [n, n+1) of an (n+1) x width buffer.
 hipError_t launch_zero_pad_row(float *buf, uint32_t n, uint32_t width, hipStream_t stream);
 

@@ -1005,6 +1005,26 @@ __global__ void k_sgemm(int ta, int tb, uint32_t m, uint32_t n, uint32_t k,
     *c = (beta == 0.0f) ? acc : __builtin_fmaf(beta, *c, acc);
 }
 
+// graph sanity on the device (after upload): bit0 = a column id >= n (the gather would read a
+// wild address), bit1 = rowptr not monotone / not ending at nnz
+__global__ __launch_bounds__(256) void k_validate_graph(GraphDev g, uint32_t *__restrict__ flags) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    uint32_t bad = 0;
+    for (size_t i = gid; i < g.nnz; i += step)
+        if (g.col[i] >= g.n) bad |= 1u;
+    for (size_t u = gid; u < g.n; u += step)
+        if (g.rowptr[u] > g.rowptr[u + 1]) bad |= 2u;
+    if (gid == 0 && (g.rowptr[0] != 0 || (uint64_t)g.rowptr[g.n] != g.nnz)) bad |= 2u;
+    if (bad) atomicOr(flags, bad);
+}
+
+// uint64 row pointers (host ABI) -> uint32 (device layout)
+__global__ void k_narrow_rowptr(const unsigned long long *__restrict__ in, uint32_t *__restrict__ out, size_t count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = (uint32_t)in[i];
+}
+
 __global__ void k_zero_row(float *buf, uint32_t n, uint32_t width) {
     if (threadIdx.x < width) buf[(size_t)n * width + threadIdx.x] = 0.0f;
 }
@@ -1233,6 +1253,20 @@ hipError_t launch_long_stage(const StagePlan &sp, const GraphDev &g, float ws, c
     default:
         return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+hipError_t validate_graph(const GraphDev &g, uint32_t *flags, hipStream_t stream) {
+    hipError_t rc = hipMemsetAsync(flags, 0, sizeof(uint32_t), stream);
+    if (rc != hipSuccess || g.n == 0) return rc;
+    hipLaunchKernelGGL(k_validate_graph, dim3(2048), dim3(256), 0, stream, g, flags);
+    return hipGetLastError();
+}
+
+hipError_t narrow_rowptr(const void *in_u64, uint32_t *out, size_t count, hipStream_t stream) {
+    if (!count) return hipSuccess;
+    hipLaunchKernelGGL(k_narrow_rowptr, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const unsigned long long *>(in_u64), out, count);
     return hipGetLastError();
 }
 

@@ -285,8 +285,12 @@ def test_blocked_stage0_is_bit_identical(model_text, oracle_model, block_cols):
             oracle_model.set_weight_scale(g.ws)
             e.upload_graph(g)
             want_active = 1 if (g.n + block_cols - 1) // block_cols >= 2 else 0
-            assert e.get_info("blocked_stage0_active") == want_active
+            # the index is built lazily, on the second forward over the same graph
+            _, first = e.forward(g.x())
+            assert e.get_info("blocked_stage0_active") == 0
             _, logits = e.forward(g.x())
+            assert e.get_info("blocked_stage0_active") == want_active
+            assert np.array_equal(bits(first), bits(logits))
             assert np.array_equal(bits(logits[:, 0]), bits(oracle_model.logits(g)))
             # stage output alone (h1) and a row sub-range through the stage entry point
             import torch
@@ -320,8 +324,9 @@ def test_unsorted_adjacency_falls_back_to_stored_order(model_text, oracle_model)
         e.set_weight_scale(g2.ws)
         oracle_model.set_weight_scale(g2.ws)
         e.upload_graph(g2)
+        e.forward(g2.x())
+        _, logits = e.forward(g2.x())      # second forward: the blocked plan is considered and rejected
         assert e.get_info("blocked_stage0_active") == 0
-        _, logits = e.forward(g2.x())
         want = oracle_model.logits(g2)
         assert np.array_equal(bits(logits[:, 0]), bits(want))
         # and the order does matter: the sorted graph gives (slightly) different logits
