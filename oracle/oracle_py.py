@@ -47,13 +47,6 @@ def lib():
     global _lib
     if _lib is None:
         build()
-        # Size the OpenMP team to the CPUs this process may really use (a GPU box hands a
-        # 16-CPU share of a 128-thread host; 128 spinning workers on 16 CPUs crawl).
-        try:
-            avail = len(os.sched_getaffinity(0))
-        except AttributeError:
-            avail = os.cpu_count() or 1
-        os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(avail, 16))))
         os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         L = C.CDLL(str(_LIB_PATH))
         L.oracle_model_parse.restype = C.POINTER(_Model)
@@ -74,6 +67,16 @@ def lib():
                                                    C.c_void_p, C.c_void_p]
         L.oracle_num_threads.restype = C.c_int
         L.oracle_set_num_threads.argtypes = [C.c_int]
+        # Size the OpenMP team to the CPUs this process may really use: a GPU box hands out a
+        # 16-CPU share of a 128-thread host (a quota, not an affinity mask), and 128 workers on
+        # 16 CPUs crawl.  Set through the API — libgomp may already be loaded (torch), in which
+        # case OMP_NUM_THREADS is no longer read.
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        want = int(os.environ.get("GNNVC_ORACLE_THREADS", "0")) or max(1, min(avail, 16))
+        L.oracle_set_num_threads(want)
         _lib = L
     return _lib
 
