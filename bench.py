@@ -84,7 +84,7 @@ def main() -> int:
     ap.add_argument("--pipeline-chunks", type=int, default=4,
                     help="N>1: pieces per stage whose all-gather overlaps the next piece's compute (0/1 = off)")
     ap.add_argument("--replicate-stage0", type=int, default=-1,
-                    help="N>1: every rank computes all rows of stage 0 and skips the first exchange (-1 = auto)")
+                    help="N>1: 1/0 forces stage 0 replicated / partitioned; -1 = auto (P=2: stages 0,1; P<=4: stage 0)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1 (gloo only to rehearse several ranks on ONE GPU)")
     ap.add_argument("--host-path", action="store_true",
@@ -250,8 +250,8 @@ def main() -> int:
         bad = (bufs.scores[: g.n].view(torch.int32) != ref_sc.view(torch.int32)).sum().to(torch.int64)
         dist.all_reduce(bad, op=dist.ReduceOp.SUM)
         out["parity"] = {"partitioned_vs_single_gpu_score_bit_mismatches_all_ranks": int(bad.item())}
-        out["config"]["replicate_stage0"] = (D.replicate_first_stage(world) if args.replicate_stage0 < 0
-                                              else bool(args.replicate_stage0))
+        out["config"]["replicated_stages"] = sorted(D.replicated_stages(world)) if args.replicate_stage0 < 0 \
+            else ([0] if args.replicate_stage0 else [])
         out["config"]["pipeline_chunks"] = args.pipeline_chunks
     if rank == 0 and world == 1:
         if args.host_path:

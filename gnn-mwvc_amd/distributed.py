@@ -157,25 +157,43 @@ def exchange_rows_pipelined(stage_fn, stage: int, src: torch.Tensor, dst: torch.
 StageFn = Callable[[int, int, int, torch.Tensor, torch.Tensor, "torch.Tensor | None"], None]
 
 
-def replicate_first_stage(world: int) -> bool:
-    """Stage 0 reads only the replicated input x, so every rank can compute ALL of its rows
-    and skip the first N x 16 exchange.  That trades (1 - 1/P) of one cheap stage for one
-    640 MB all-gather: a win while a rank's share of that gather crosses few xGMI links
-    (P <= 4: >= 160 MB per link ~ 2 ms against ~1.6 ms of extra compute), a loss at P = 8."""
-    return 1 < world <= 4
+def replicated_stages(world: int, num_stages: int = 3) -> "set[int]":
+    """Stages every rank computes in full instead of partitioning + exchanging.
+
+    Stage s may be replicated when every earlier stage is (its input is then complete on every
+    rank).  Replicating trades (1 - 1/P) of the stage's compute for one N x 16 all-gather
+    (640 MB on the metric graph).  With P ranks a rank's share of that gather crosses P - 1
+    xGMI links of ~75 GB/s per direction: ~4.2 ms at P = 2, ~2.1 ms at P = 4, ~1 ms at P = 8,
+    against ~2 ms (stage 0) and ~3.8 ms (stage 1) of single-GPU compute:
+      P = 2: replicate stages 0 and 1 (only the last stage is partitioned, only scores travel);
+      P = 3, 4: replicate stage 0;  P >= 5: partition everything.
+    The last stage is never replicated (it would leave nothing to share)."""
+    if world <= 1:
+        return set()
+    if world == 2:
+        return set(range(min(2, num_stages - 1)))
+    if world <= 4:
+        return {0} if num_stages > 1 else set()
+    return set()
+
+
+def replicate_first_stage(world: int) -> bool:   # kept for callers that only ask about stage 0
+    return 0 in replicated_stages(world)
 
 
 def partitioned_forward(stage_fn: StageFn, num_stages: int, x: torch.Tensor, bufs: ForwardBuffers,
                         bounds: Sequence[Tuple[int, int]], rank: int, group=None,
                         exchange: str = "auto", on_stage=None, gather_logits: bool = True,
                         replicate_stage0: "bool | None" = None,
-                        pipeline_chunks: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+                        pipeline_chunks: int = 0,
+                        replicate: "set[int] | None" = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Run every fused stage on this rank's rows and exchange between stages.
 
     stage_fn(stage, lo, hi, src, dst, logits_or_None) computes rows [lo, hi) of `dst`
     from the full `src`.  Returns (scores[:n], logits[:n]) — complete on every rank,
     like `predict` hands every caller all N scores.
-    replicate_stage0: None = replicate_first_stage(world).
+    replicate: stages computed in full on every rank (None = replicated_stages(world));
+    replicate_stage0 (legacy switch): True/False forces {0} / {}.
     pipeline_chunks > 1: overlap each feature exchange with the stage's own compute
     (exchange_rows_pipelined; equal-rows partition only).
     on_stage(stage, phase) is an optional hook ("begin" | "computed" | "exchanged")
@@ -183,8 +201,15 @@ def partitioned_forward(stage_fn: StageFn, num_stages: int, x: torch.Tensor, buf
     """
     world = len(bounds)
     lo, hi = bounds[rank]
-    if replicate_stage0 is None:
-        replicate_stage0 = replicate_first_stage(world)
+    if replicate is None:
+        replicate = replicated_stages(world, num_stages) if replicate_stage0 is None else \
+            ({0} if replicate_stage0 and num_stages > 1 else set())
+    # a stage can only be computed in full if its input is complete everywhere
+    rep, ok = set(), True
+    for st in range(num_stages - 1):
+        ok = ok and st in replicate
+        if ok:
+            rep.add(st)
     can_pipeline = pipeline_chunks > 1 and world > 1 and _equal_shard_rows(bufs.n, bounds) > 0
     src = x
     for st in range(num_stages):
@@ -192,7 +217,7 @@ def partitioned_forward(stage_fn: StageFn, num_stages: int, x: torch.Tensor, buf
         dst = bufs.scores if last else bufs.feat[st & 1]
         if on_stage:
             on_stage(st, "begin")
-        if st == 0 and replicate_stage0 and not last:
+        if st in rep and not last:
             stage_fn(st, 0, bufs.n, src, dst, None)       # every row, no exchange
             if on_stage:
                 on_stage(st, "computed")

@@ -104,6 +104,14 @@ def test_partitioned_forward_matches_single_process(world, mode, exchange, graph
         assert all(lo % D.ALIGN == 0 for lo, _ in bounds)
 
 
+def test_replication_rule():
+    assert D.replicated_stages(1) == set()
+    assert D.replicated_stages(2) == {0, 1}
+    assert D.replicated_stages(4) == {0}
+    assert D.replicated_stages(8) == set()
+    assert D.replicated_stages(2, num_stages=1) == set()
+
+
 def test_partition_bounds_properties():
     g = gg.hub_graph(20000, 60000, 3, 4096, seed=7)
     for world in (1, 2, 4, 8):
