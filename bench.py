@@ -222,7 +222,8 @@ def main() -> int:
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload_desc, "vertices": g.n, "edges": g.n_edges,
                    "graph": args.workload, "partition": f"1d-vertex x{world}",
-                   "exchange": "none" if world == 1 else "all-gather N x16 fp32 after stages 0 and 1"},
+                   "exchange": "none" if world == 1 else "all-gather of N x16 fp32 rows after each partitioned stage, "
+                                                          "N scores at the end"},
         "roofline": {"bound": "hbm", "kernel": kernel_names[dom], "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,

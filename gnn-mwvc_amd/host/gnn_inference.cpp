@@ -8,9 +8,8 @@
 //
 // Compiles against this directory's headers or, for the drop-in check, against
 // the reference's own include/ (the class layouts are the same).  No arithmetic
-// of the forward happens in this file except the final host-libm sigmoid on the
-// device logits, which is what makes the scores bit-identical to the reference's
-// on the host it runs on.
+// of the forward happens in this file (an opt-in GNNVC_HOST_SIGMOID=1 applies the
+// host libm's final sigmoid to the device logits on hosts whose expf differs).
 #include <gnn_inference.hpp>  // angle brackets: the -I order decides (reference headers in the drop-in build)
 
 #include <cmath>
@@ -222,11 +221,18 @@ void model::predict(const matrix &in, matrix &out, const reduction_graph<Tn, Tw>
     check(gnnvc_set_weight_scale(e, scale_of(layers)), "gnnvc_set_weight_scale", e);
     check(gnnvc_upload_graph(e, n, pg.rowptr.data(), pg.col.data(), pg.w.data(), pg.nw.data()),
           "gnnvc_upload_graph", e);
-    const bool sig = !layers.empty() && std::holds_alternative<sigmoid>(layers.back());
-    in_copy.resize(n, (size_t)ow);  // the reference's scratch member: holds the logits here
+    // The scores come straight from the device: its sigmoid evaluates glibc's expf algorithm in
+    // fp64 (csrc/expf_glibc.h), bit-identical to the host libm on x86-64 hosts with FMA.  Hosts
+    // whose libm differs (no FMA, another libc) can set GNNVC_HOST_SIGMOID=1 to have the final
+    // 1/(1+expf(-x)) applied by THEIR libm to the bit-exact device logits instead (reference :51).
+    static const bool host_sigmoid = [] {
+        const char *v = std::getenv("GNNVC_HOST_SIGMOID");
+        return v && *v && *v != '0';
+    }();
+    const bool sig = host_sigmoid && !layers.empty() && std::holds_alternative<sigmoid>(layers.back());
+    if (sig) in_copy.resize(n, (size_t)ow);  // the reference's scratch member: holds the logits here
     check(gnnvc_forward(e, cdata(in), mdata(out), sig ? mdata(in_copy) : nullptr), "gnnvc_forward", e);
     if (sig) {
-        // exact parity route: host libm on the bit-exact device logits (reference :51)
         for (size_t i = 0; i < (size_t)n * ow; ++i) {
             const float x = *(in_copy.begin(0) + i);
             *(out.begin(0) + i) = 1.0f / (1.0f + expf(-x));
