@@ -23,6 +23,8 @@
 #include <mutex>
 #include <random>
 #include <sstream>
+#include <thread>
+#include <algorithm>
 
 #include "gnnvc.h"
 #include "gnnvc_host.hpp"
@@ -70,9 +72,26 @@ visitor(Fs...) -> visitor<Fs...>;
 const float *cdata(const matrix &m) { return (m.get_height() && m.get_width()) ? &*m.begin(0) : nullptr; }
 float *mdata(matrix &m) { return (m.get_height() && m.get_width()) ? &*m.begin(0) : nullptr; }
 
+// Run fn(begin, end) over [0, n) on a few threads (graphs of millions of rows; the pack is
+// the largest host cost of a predict call once the forward itself takes milliseconds).
+template <class Fn>
+void parallel_rows(uint32_t n, Fn fn) {
+    unsigned t = std::thread::hardware_concurrency();
+    t = std::max(1u, std::min(t, 16u));
+    if (n < (1u << 16) || t == 1) {
+        fn(0u, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const uint32_t step = (n + t - 1) / t;
+    for (uint32_t lo = 0; lo < n; lo += step) pool.emplace_back(fn, lo, std::min(n, lo + step));
+    for (auto &th : pool) th.join();
+}
+
 // The graph view the forward reads, packed to contiguous CSR through the
 // non-mutating accessors (begin(u)/end(u), W, NW — never D(u)/g[u], which move
-// the reference's hidden cursor, include/reduction_graph.hpp:144,240-245).
+// the reference's hidden cursor, include/reduction_graph.hpp:144,240-245; the
+// accessors used here are const and safe to call from several threads).
 struct PackedGraph {
     std::vector<uint64_t> rowptr;
     std::vector<uint32_t> col, w, nw;
@@ -83,13 +102,18 @@ struct PackedGraph {
         w.resize(n);
         nw.resize(n);
         rowptr[0] = 0;
-        for (uint32_t u = 0; u < n; ++u) {
-            rowptr[u + 1] = rowptr[u] + (uint64_t)(g.end(u) - g.begin(u));
-            w[u] = g.W(u);
-            nw[u] = g.NW(u);
-        }
+        parallel_rows(n, [&](uint32_t lo, uint32_t hi) {
+            for (uint32_t u = lo; u < hi; ++u) {
+                rowptr[u + 1] = (uint64_t)(g.end(u) - g.begin(u));   // row length, prefix-summed below
+                w[u] = g.W(u);
+                nw[u] = g.NW(u);
+            }
+        });
+        for (uint32_t u = 0; u < n; ++u) rowptr[u + 1] += rowptr[u];
         col.resize(rowptr[n]);
-        for (uint32_t u = 0; u < n; ++u) std::copy(g.begin(u), g.end(u), col.begin() + rowptr[u]);
+        parallel_rows(n, [&](uint32_t lo, uint32_t hi) {
+            for (uint32_t u = lo; u < hi; ++u) std::copy(g.begin(u), g.end(u), col.begin() + rowptr[u]);
+        });
     }
 };
 
