@@ -716,6 +716,19 @@ int gnnvc_attach_graph_device(gnnvc_engine *e, uint32_t n, uint64_t nnz, const u
     if (nnz >= 0xFFFFFFFFull - GNNVC_COL_PAD) return fail(e, GNNVC_ERR_UNSUPPORTED, "nnz too large");
     int rc = use_device(e);
     if (rc) return rc;
+    {   // a column id >= n would send the gather to a wild address: check before accepting the graph
+        const GraphDev cand{n, nnz, d_rowptr, d_col, d_w, d_nw};
+        HIP_TRY(e, e->blk_flag.reserve(1));
+        HIP_TRY(e, gnnvc::validate_graph(cand, e->blk_flag.p, e->stream));
+        uint32_t bad = 0;
+        HIP_TRY(e, hipMemcpyAsync(&bad, e->blk_flag.p, sizeof bad, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        if (bad) {
+            e->have_graph = false;
+            return fail(e, GNNVC_ERR_INVALID, "%s", (bad & 1u) ? "a column id is not a vertex of this graph (col[i] >= n)"
+                                                                 : "row pointers are not monotone from 0 to nnz");
+        }
+    }
     e->g = GraphDev{n, nnz, d_rowptr, d_col, d_w, d_nw};
     e->have_graph = true;
     rc = reserve_features(e, n);

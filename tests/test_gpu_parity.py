@@ -234,6 +234,39 @@ def test_unfused_model_path(model_text, oracle_model):
         e.close()
 
 
+def test_malformed_graphs_are_rejected(model_text):
+    """A column id >= n or broken row pointers would fault the GPU: both entry points refuse them."""
+    import torch
+    import gnn_mwvc_amd as G
+    e = G.Engine(model_text, device=0)
+    try:
+        g = gg.erdos_renyi(500, 2000, 19)
+        e.upload_graph(g)
+        bad = gg.CsrGraph(g.n, g.rowptr, g.col.copy(), g.w, g.nw)
+        bad.col[7] = g.n + 5
+        with pytest.raises(G.GnnvcError) as ei:
+            e.upload_graph(bad)
+        assert ei.value.code == -1
+        rp = g.rowptr.copy()
+        rp[10], rp[11] = rp[11], rp[10] + 0
+        rp[10] = rp[12] + 1
+        with pytest.raises(G.GnnvcError):
+            e.upload_graph(gg.CsrGraph(g.n, rp, g.col, g.w, g.nw))
+        with pytest.raises(G.GnnvcError):           # no usable graph is left behind
+            e.forward(g.x())
+        dev = torch.device("cuda:0")
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+        colpad = np.zeros(g.nnz + 64, dtype=np.uint32)
+        colpad[: g.nnz] = bad.col
+        d = [t(g.rowptr.astype(np.uint32)), t(colpad), t(g.w), t(g.nw)]
+        with pytest.raises(G.GnnvcError):
+            e.attach_graph_device(g.n, g.nnz, *[x.data_ptr() for x in d], keepalive=d)
+        e.upload_graph(g)                           # and a good graph still works afterwards
+        e.forward(g.x())
+    finally:
+        e.close()
+
+
 def test_errors(engine):
     import gnn_mwvc_amd as G
     g = gg.erdos_renyi(100, 300, 18)
