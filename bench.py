@@ -37,6 +37,7 @@ WORKLOADS = {
     "er100k": (100_000, 1_000_000, 1),
     "er3m": (3_000_000, 30_000_000, 3),       # feature table (192 MB) fits the Infinity Cache
     # the other BASELINE.json configs (parity-test cases; selectable here for profiling)
+    "rmat24": ("rmat", 24, 16, 24),
     "rmat22": ("rmat", 22, 16, 22),
     "rmat20": ("rmat", 20, 16, 20),
     "powerlaw1m": ("powerlaw", 1_000_000, 16.0, 2.1, 8, 65536, 5),

@@ -812,6 +812,22 @@ int gnnvc_forward(gnnvc_engine *e, const float *x, float *scores, float *logits)
     return GNNVC_OK;
 }
 
+int gnnvc_reduction_flags(gnnvc_engine *e, uint32_t max_degree, uint8_t *flags) {
+    if (!e) return GNNVC_ERR_INVALID;
+    if (!e->have_graph) return fail(e, GNNVC_ERR_STATE, "no graph attached");
+    const uint32_t n = e->g.n;
+    if (n == 0) return GNNVC_OK;
+    if (!flags) return fail(e, GNNVC_ERR_INVALID, "null flags buffer");
+    int rc = use_device(e);
+    if (rc) return rc;
+    HIP_TRY(e, e->scratch[1].reserve((size_t)n / 4 + 2));   // n bytes
+    uint8_t *d = reinterpret_cast<uint8_t *>(e->scratch[1].p);
+    HIP_TRY(e, gnnvc::launch_reduction_flags(e->g, max_degree, d, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(flags, d, n, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return GNNVC_OK;
+}
+
 int gnnvc_synchronize(gnnvc_engine *e) {
     if (!e) return GNNVC_ERR_INVALID;
     int rc = use_device(e);

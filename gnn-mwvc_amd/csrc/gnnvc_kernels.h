@@ -90,6 +90,9 @@ hipError_t launch_sgemm(int ta, int tb, uint32_t m, uint32_t n, uint32_t k, cons
                         uint32_t lda, const float *B, uint32_t ldb, float beta, float *C,
                         uint32_t ldc, hipStream_t stream);
 
+// Reduction-rule predicates per vertex (one byte each) on the device CSR; see the kernel.
+hipError_t launch_reduction_flags(const GraphDev &g, uint32_t max_degree, uint8_t *flags, hipStream_t stream);
+
 // Device-side graph checks after an upload (*flags: bit0 column id out of range, bit1 bad
 // row pointers) and the uint64 -> uint32 row-pointer narrowing of the host ABI.
 hipError_t validate_graph(const GraphDev &g, uint32_t *flags, hipStream_t stream);

@@ -942,6 +942,77 @@ __global__ __launch_bounds__(256) void k_blk_accumulate(const uint32_t *__restri
     acc[u] = a;
 }
 
+// ------------------------------------------------------------------ reduction-rule predicates (f-2)
+// One vertex-parallel pass over the device CSR that evaluates, for every vertex the
+// reference's reduce_graph would look at (D(u) <= max_degree, include/mwvc_reductions.hpp:344),
+// which of its local rules would fire on the graph as it stands — so the host loop can skip
+// the (vast majority of) vertices where nothing fires and keep applying reductions in the
+// reference's own order.  Pure predicates, bit for bit the reference's:
+//   bit 0 neighborhood_reduction (:131-139)   bit 1 twin_fold (:141-160)
+//   bit 2 domination_reduction   (:162-177)   bit 3 isolated_fold (:270-284)
+//   bit 4 independent_fold       (:246-268)   bits 5, 6: the small-solver rules, "host decides"
+__device__ __forceinline__ bool dev_is_dominating(const GraphDev &g, uint32_t u, uint32_t v) {
+    // reduction_graph::is_dominating (include/reduction_graph.hpp:201-224), same merge loop
+    const uint32_t us = g.rowptr[u], ue = g.rowptr[u + 1], vs = g.rowptr[v], ve = g.rowptr[v + 1];
+    if (ue - us < ve - vs || (uint32_t)(g.w[u] + g.nw[u]) < (uint32_t)(g.w[v] + g.nw[v])) return false;
+    uint32_t f1 = us, f2 = vs;
+    while (f2 != ve) {
+        if (g.col[f2] == u) {
+            ++f2;
+            if (f2 == ve) break;
+        }
+        if (f1 == ue || g.col[f2] < g.col[f1]) return false;
+        if (!(g.col[f1] < g.col[f2])) ++f2;
+        ++f1;
+    }
+    return true;
+}
+
+__device__ __forceinline__ bool dev_is_twin(const GraphDev &g, uint32_t u, uint32_t v) {
+    // reduction_graph::is_twin (include/reduction_graph.hpp:180-186)
+    const uint32_t us = g.rowptr[u], vs = g.rowptr[v];
+    const uint32_t d = g.rowptr[u + 1] - us;
+    if (d != g.rowptr[v + 1] - vs || g.nw[u] != g.nw[v] || u == v) return false;
+    for (uint32_t i = 0; i < d; ++i)
+        if (g.col[us + i] != g.col[vs + i]) return false;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_reduction_flags(GraphDev g, uint32_t max_degree,
+                                                         uint8_t *__restrict__ flags) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= g.n) return;
+    const uint32_t rs = g.rowptr[u], d = g.rowptr[u + 1] - rs;
+    uint32_t f = 0;
+    if (d <= max_degree) {
+        const uint32_t wu = g.w[u], nwu = g.nw[u];
+        f = 0x60u;
+        if (nwu <= wu) f |= 1u;
+        if (d > 0) {
+            const uint32_t last = g.col[rs + d - 1];
+            for (uint32_t e = g.rowptr[last], ee = g.rowptr[last + 1]; e < ee; ++e) {
+                const uint32_t v = g.col[e];
+                if (v != u && dev_is_twin(g, u, v)) { f |= 2u; break; }
+            }
+            bool all = true;
+            uint32_t wmin = g.w[g.col[rs]];
+            for (uint32_t i = 0; i < d; ++i) {
+                const uint32_t v = g.col[rs + i];
+                const uint32_t wv = g.w[v];
+                if (!(f & 4u) && ((wv >= wu && dev_is_dominating(g, u, v)) || (wv <= wu && dev_is_dominating(g, v, u))))
+                    f |= 4u;
+                if (all && !dev_is_dominating(g, v, u)) all = false;
+                wmin = wv < wmin ? wv : wmin;
+            }
+            if (all) f |= 8u;
+            if (wu >= (uint32_t)(nwu - wmin)) f |= 16u;
+        } else {
+            f |= 8u;   // all_of over no neighbours
+        }
+    }
+    flags[u] = (uint8_t)f;
+}
+
 // ------------------------------------------------------------------ layer-by-layer kernels
 // One thread per output element; exact, simple, used for models that do not
 // match a fused plan and for the layer-level ABI.
@@ -1253,6 +1324,12 @@ hipError_t launch_long_stage(const StagePlan &sp, const GraphDev &g, float ws, c
     default:
         return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_reduction_flags(const GraphDev &g, uint32_t max_degree, uint8_t *flags, hipStream_t stream) {
+    if (g.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_reduction_flags, dim3((g.n + 255) / 256), dim3(256), 0, stream, g, max_degree, flags);
     return hipGetLastError();
 }
 

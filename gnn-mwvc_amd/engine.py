@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "gnnvc_set_weight_scale", "gnnvc_set_stream", "gnnvc_set_option", "gnnvc_get_info", "gnnvc_num_layers", "gnnvc_is_fused",
     "gnnvc_in_width", "gnnvc_out_width", "gnnvc_upload_graph", "gnnvc_attach_graph_device",
     "gnnvc_forward", "gnnvc_forward_device", "gnnvc_num_stages", "gnnvc_stage_widths",
-    "gnnvc_stage_forward_device", "gnnvc_synchronize", "gnnvc_last_forward_ms",
+    "gnnvc_stage_forward_device", "gnnvc_reduction_flags", "gnnvc_synchronize", "gnnvc_last_forward_ms",
     "gnnvc_graph_layer_forward", "gnnvc_linear_forward", "gnnvc_relu_forward",
     "gnnvc_sigmoid_forward", "gnnvc_sgemm",
 ]
@@ -90,6 +90,7 @@ def load_library():
     L.gnnvc_forward.argtypes = [vp, f32p, f32p, f32p]
     L.gnnvc_forward_device.argtypes = [vp, f32p, f32p, f32p]
     L.gnnvc_stage_forward_device.argtypes = [vp, C.c_int, u32, u32, f32p, f32p, f32p]
+    L.gnnvc_reduction_flags.argtypes = [vp, u32, vp]
     L.gnnvc_last_forward_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
     L.gnnvc_graph_layer_forward.argtypes = [vp, u32, f32p, f32p]
     L.gnnvc_linear_forward.argtypes = [vp, u32, u32, u32, f32p, f32p, f32p, f32p]
@@ -218,6 +219,11 @@ class Engine:
                              logits_ptr: int = 0):
         self._check(self._L.gnnvc_stage_forward_device(self._h, stage, row_lo, row_hi, in_ptr,
                                                        out_ptr, logits_ptr or None))
+
+    def reduction_flags(self, max_degree: int = 20) -> np.ndarray:
+        flags = np.zeros(self.n, dtype=np.uint8)
+        self._check(self._L.gnnvc_reduction_flags(self._h, max_degree, _np_ptr(flags)))
+        return flags
 
     def synchronize(self):
         self._check(self._L.gnnvc_synchronize(self._h))

@@ -273,3 +273,70 @@ int oracle_predict(const oracle_model *m, const oracle_graph *g, uint32_t in_wid
     free(b);
     return 0;
 }
+
+/* ------------------------------------------------------- reduction predicates (f-2) */
+
+static uint32_t deg_of(const oracle_graph *g, uint32_t u) { return (uint32_t)(g->rowptr[u + 1] - g->rowptr[u]); }
+
+/* reduction_graph::is_dominating (include/reduction_graph.hpp:201-224): N(v) \ {u} subset of N(u),
+ * with the reference's exact merge loop over the two sorted lists. */
+static int is_dominating(const oracle_graph *g, uint32_t u, uint32_t v) {
+    if (deg_of(g, u) < deg_of(g, v) || (uint32_t)(g->w[u] + g->nw[u]) < (uint32_t)(g->w[v] + g->nw[v])) return 0;
+    const uint32_t *f1 = g->col + g->rowptr[u], *l1 = g->col + g->rowptr[u + 1];
+    const uint32_t *f2 = g->col + g->rowptr[v], *l2 = g->col + g->rowptr[v + 1];
+    while (f2 != l2) {
+        if (*f2 == u) {
+            ++f2;
+            if (f2 == l2) break;
+        }
+        if (f1 == l1 || *f2 < *f1) return 0;
+        if (!(*f1 < *f2)) ++f2;
+        ++f1;
+    }
+    return 1;
+}
+
+/* reduction_graph::is_twin (include/reduction_graph.hpp:180-186) */
+static int is_twin(const oracle_graph *g, uint32_t u, uint32_t v) {
+    const uint32_t d = deg_of(g, u);
+    if (d != deg_of(g, v) || g->nw[u] != g->nw[v] || u == v) return 0;
+    return memcmp(g->col + g->rowptr[u], g->col + g->rowptr[v], (size_t)d * sizeof(uint32_t)) == 0;
+}
+
+void oracle_reduction_flags(const oracle_graph *g, uint32_t max_degree, uint8_t *flags) {
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (int64_t uu = 0; uu < (int64_t)g->n; uu++) {
+        const uint32_t u = (uint32_t)uu;
+        const uint32_t d = deg_of(g, u);
+        uint8_t f = 0;
+        if (d <= max_degree) {
+            const uint32_t *adj = g->col + g->rowptr[u];
+            f |= 0x60; /* the two small-solver rules: the host decides */
+            if (g->nw[u] <= g->w[u]) f |= 1u << 0;
+            if (d > 0) {
+                const uint32_t last = adj[d - 1]; /* "first_neighbor = *(end(g[u]) - 1)" (mwvc_reductions.hpp:144) */
+                for (uint64_t e = g->rowptr[last]; e < g->rowptr[last + 1]; e++) {
+                    const uint32_t v = g->col[e];
+                    if (v != u && is_twin(g, u, v)) { f |= 1u << 1; break; }
+                }
+                int all = 1;
+                uint32_t wmin = g->w[adj[0]];
+                for (uint32_t i = 0; i < d; i++) {
+                    const uint32_t v = adj[i];
+                    if (!(f & 4u)) {
+                        if ((g->w[v] >= g->w[u] && is_dominating(g, u, v)) ||
+                            (g->w[v] <= g->w[u] && is_dominating(g, v, u)))
+                            f |= 1u << 2;
+                    }
+                    if (all && !is_dominating(g, v, u)) all = 0;
+                    if (g->w[v] < wmin) wmin = g->w[v];
+                }
+                if (all) f |= 1u << 3;
+                if (g->w[u] >= (uint32_t)(g->nw[u] - wmin)) f |= 1u << 4;
+            } else {
+                f |= 1u << 3; /* std::all_of over no neighbours is true (reduction_graph.hpp:189-199) */
+            }
+        }
+        flags[u] = f;
+    }
+}

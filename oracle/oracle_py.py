@@ -65,6 +65,7 @@ def lib():
         L.oracle_sigmoid.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p]
         L.oracle_neighbourhood_weights.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p,
                                                    C.c_void_p, C.c_void_p]
+        L.oracle_reduction_flags.argtypes = [C.POINTER(_Graph), C.c_uint32, C.c_void_p]
         L.oracle_num_threads.restype = C.c_int
         L.oracle_set_num_threads.argtypes = [C.c_int]
         # Size the OpenMP team to the CPUs this process may really use: a GPU box hands out a
@@ -184,6 +185,15 @@ def sigmoid(h: np.ndarray) -> np.ndarray:
     out = np.empty_like(h)
     lib().oracle_sigmoid(h.size, _ptr(h), _ptr(out))
     return out
+
+
+def reduction_flags(g, max_degree: int = 20) -> np.ndarray:
+    """Reduction-rule predicate bits per vertex (see gnnvc_oracle.h)."""
+    flags = np.zeros(g.n, dtype=np.uint8)
+    gs, keep = _graph_struct(g)
+    lib().oracle_reduction_flags(C.byref(gs), max_degree, _ptr(flags))
+    del keep
+    return flags
 
 
 def num_threads() -> int:

@@ -3,6 +3,7 @@
 // and linked with the reference's src/gnn_inference.cpp (compiled where it lies)
 // and this repo's matrix translation unit; see oracle/Makefile.  No reference
 // source is copied: this file only calls the reference's public interface.
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <sstream>
@@ -67,6 +68,40 @@ int ref_graph_layer(float ws, uint32_t n, uint32_t f, const uint64_t *rowptr, co
     for (size_t i = 0; i < res.get_height(); ++i)
         for (size_t j = 0; j < res.get_width(); ++j) out[i * res.get_width() + j] = res(i, j);
     return (int)res.get_width();
+}
+
+// Reduction-rule predicates evaluated with the REFERENCE's own graph methods
+// (is_twin / is_dominating / is_isolated, include/reduction_graph.hpp:180-224) in the way the rule
+// functions call them (include/mwvc_reductions.hpp:131-284); bits as in oracle_reduction_flags.
+int ref_reduction_flags(uint32_t n, const uint64_t *rowptr, const uint32_t *col, const uint32_t *w,
+                        uint32_t max_degree, uint8_t *flags) {
+    auto g = make_graph(n, rowptr, col, w);
+    for (uint32_t u = 0; u < n; ++u) {
+        uint8_t f = 0;
+        const uint32_t d = g.D(u);
+        if (d <= max_degree) {
+            f |= 0x60;
+            if (g.NW(u) <= g.W(u)) f |= 1u << 0;
+            if (d > 0) {
+                const uint32_t first_neighbor = *(g.end(u) - 1);
+                for (auto it = g.begin(first_neighbor); it != g.end(first_neighbor); ++it)
+                    if (*it != u && g.is_twin(u, *it)) { f |= 1u << 1; break; }
+                for (auto it = g.begin(u); it != g.end(u); ++it) {
+                    const uint32_t v = *it;
+                    if ((g.W(v) >= g.W(u) && g.is_dominating(u, v)) || (g.W(v) <= g.W(u) && g.is_dominating(v, u))) {
+                        f |= 1u << 2;
+                        break;
+                    }
+                }
+                uint32_t wmin = g.W(*g.begin(u));
+                for (auto it = g.begin(u); it != g.end(u); ++it) wmin = std::min<uint32_t>(wmin, g.W(*it));
+                if (g.W(u) >= g.NW(u) - wmin) f |= 1u << 4;
+            }
+            if (g.is_isolated(u)) f |= 1u << 3;
+        }
+        flags[u] = f;
+    }
+    return 0;
 }
 
 }  // extern "C"

@@ -96,6 +96,28 @@ def test_reference_graph_layer_quirk(ref_layers):
         assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("maker", [
+    lambda: gg.erdos_renyi(3000, 6000, 5),                 # sparse: many degree-1/2 vertices, twins, dominations
+    lambda: gg.erdos_renyi(2000, 12000, 6),
+    lambda: gg.rmat(11, 4, 10),
+    lambda: gg.from_edge_list(9, [(0, 1), (0, 2), (1, 2), (3, 4), (3, 5), (4, 5), (5, 6), (7, 8)],
+                              [20, 30, 40, 25, 25, 60, 10, 5, 5]),
+    lambda: gg.from_edge_list(6, [(0, 2), (0, 3), (1, 2), (1, 3), (4, 5)], [10, 10, 20, 20, 7, 7]),  # twins 0 and 1
+])
+def test_reduction_predicates_match_reference_methods(ref_layers, maker):
+    """oracle_reduction_flags against the reference's own is_twin / is_dominating / is_isolated."""
+    g = maker()
+    ref_layers.ref_reduction_flags.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                               C.c_void_p]
+    want = np.zeros(g.n, dtype=np.uint8)
+    rowptr = np.ascontiguousarray(g.rowptr, dtype=np.uint64)
+    ref_layers.ref_reduction_flags(g.n, rowptr.ctypes.data, g.col.ctypes.data, g.w.ctypes.data, 20,
+                                   want.ctypes.data)
+    got = oracle_py.reduction_flags(g, 20)
+    assert np.array_equal(got, want)
+    assert got.max() >= 0x60        # every low-degree vertex carries the two "maybe" bits
+
+
 def _run_cli(binary, graph_path, out_path):
     r = subprocess.run([str(binary), str(graph_path), str(out_path), "0", "-1", "0"],
                        capture_output=True, text=True, timeout=600)

@@ -488,3 +488,18 @@ def test_sorted_tiles_auto_decision(model_text):
         assert e.get_info("sorted_tiles_active") == 1 and e.get_info("tile_waste_x100") >= 200
     finally:
         e.close()
+
+
+# ---------------------------------------------------------------- reduction-rule predicates (f-2)
+
+def test_reduction_flags_match_oracle(engine):
+    """The vertex-parallel predicate pass against the oracle's restatement of the reference's
+    rule predicates (itself checked against the reference's own graph methods on CPU)."""
+    for g in (gg.erdos_renyi(100000, 300000, 1), gg.erdos_renyi(50000, 60000, 2), gg.rmat(14, 4, 3),
+              gg.hub_graph(20000, 30000, 2, 3000, seed=4),
+              gg.from_edge_list(6, [(0, 2), (0, 3), (1, 2), (1, 3), (4, 5)], [10, 10, 20, 20, 7, 7])):
+        engine.upload_graph(g)
+        got = engine.reduction_flags(20)
+        want = oracle_py.reduction_flags(g, 20)
+        assert np.array_equal(got, want)
+    assert engine.reduction_flags(3).max() <= 0x7F
