@@ -399,6 +399,9 @@ int build_blocked(gnnvc_engine *e) {
     const GraphDev &g = e->g;
     if (!e->opt_blocked || e->stages.empty() || e->stages[0].f != 1 || e->stages[0].variant != 0) return GNNVC_OK;
     if (g.n < e->opt_blocked_min_n || g.nnz == 0) return GNNVC_OK;
+    // skewed graphs gather mostly from a few hot (hub) entries of x that stay cached anyway, and
+    // the per-row accumulate passes run in lockstep to each wave's largest count: measured slower
+    if (e->sorted_wanted && e->opt_blocked < 2) return GNNVC_OK;
     const uint32_t wb = e->opt_block_cols ? e->opt_block_cols : (512u << 10);  // 2 MiB of x per block
     const uint32_t nb = (g.n + wb - 1) / wb;
     if (nb < 2 || nb > 4096) return GNNVC_OK;
@@ -618,7 +621,7 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream) {
 int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     if (!e || !key) return GNNVC_ERR_INVALID;
     const std::string k(key);
-    if (k == "blocked_stage0") e->opt_blocked = value != 0;
+    if (k == "blocked_stage0") e->opt_blocked = value < 0 ? 0 : (value > 2 ? 2 : (int)value);   // 2 = also on skewed graphs
     else if (k == "block_cols") e->opt_block_cols = value > 0 ? (uint32_t)value : 0;
     else if (k == "blocked_min_n") e->opt_blocked_min_n = value > 0 ? (uint32_t)value : 0;
     else if (k == "long_row_threshold") e->opt_long_thresh = value > 0 ? (uint32_t)value : 0;
