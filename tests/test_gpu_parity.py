@@ -311,6 +311,7 @@ def test_blocked_stage0_is_bit_identical(model_text, oracle_model, block_cols):
     try:
         e.set_option("blocked_min_n", 0)
         e.set_option("block_cols", block_cols)
+        e.set_option("blocked_stage0", 2)      # also on the skewed sample graphs (off there by default)
         graphs = [gg.erdos_renyi(5000, 40000, 31), gg.hub_graph(20000, 60000, 3, 4096, seed=7),
                   gg.rmat(11, 8, 3), gg.from_edge_list(130, [(0, i) for i in range(1, 40)], list(range(20, 150)))]
         for g in graphs:
@@ -384,6 +385,7 @@ def test_long_row_path_is_bit_identical(model_text, oracle_model, thresh, block_
         if block_cols:
             e.set_option("blocked_min_n", 0)
             e.set_option("block_cols", block_cols)
+            e.set_option("blocked_stage0", 2)
         graphs = [gg.hub_graph(20000, 60000, 3, 4096, seed=7), gg.rmat(11, 16, 5),
                   gg.erdos_renyi(3000, 30000, 41),
                   gg.from_edge_list(700, [(0, i) for i in range(1, 700)] + [(1, i) for i in range(2, 300)],
