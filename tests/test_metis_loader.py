@@ -1,0 +1,94 @@
+"""The fast METIS reader (gnn-mwvc_amd/host/metis_loader.cpp): same edge set
+and weights as the reference's parse_graph (reference src/GNN_VC.cpp:34-91) on well-formed
+files, and the documented semantics (keep neighbours > i, sort, unique) on messy ones."""
+import ctypes as C
+import pathlib
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+from tools import graphgen as gg
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+LIB = ROOT / "gnn-mwvc_amd" / "libgnnvc_metis.so"
+REF = pathlib.Path("/root/reference/src/GNN_VC.cpp")
+
+
+def _load(lib, fn, path, *extra):
+    n, m = C.c_uint32(), C.c_uint64()
+    w, p = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)()
+    rc = getattr(lib, fn)(str(path).encode(), C.byref(n), C.byref(m), C.byref(w), C.byref(p), *extra)
+    if rc != 0:
+        return None
+    weights = np.ctypeslib.as_array(w, shape=(max(n.value, 1),))[: n.value].copy()
+    pairs = np.ctypeslib.as_array(p, shape=(max(2 * m.value, 1),))[: 2 * m.value].reshape(-1, 2).copy()
+    libc = C.CDLL(None)
+    libc.free(w)
+    libc.free(p)
+    return n.value, weights, pairs
+
+
+@pytest.fixture(scope="module")
+def ours():
+    if not LIB.exists() or LIB.stat().st_mtime < (ROOT / "gnn-mwvc_amd" / "host" / "metis_loader.cpp").stat().st_mtime:
+        r = subprocess.run(["make", "-C", str(ROOT / "gnn-mwvc_amd" / "host"), "../libgnnvc_metis.so"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    return C.CDLL(str(LIB))
+
+
+def _expected(g):
+    rp = g.rowptr.astype(np.int64)
+    src = np.repeat(np.arange(g.n), np.diff(rp))
+    keep = g.col.astype(np.int64) > src
+    return np.stack([src[keep], g.col[keep].astype(np.int64)], axis=1).astype(np.uint32)
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_well_formed_files(ours, tmp_path, threads):
+    for g in (gg.erdos_renyi(3000, 15000, 1), gg.rmat(10, 8, 2),
+              gg.from_edge_list(7, [(0, 1), (5, 6)], [20, 30, 40, 50, 60, 70, 80])):
+        path = tmp_path / "g.graph"
+        path.write_text(gg.metis_text(g))
+        got = _load(ours, "gnnvc_host_load_metis", path, C.c_uint(threads))
+        assert got is not None
+        n, w, pairs = got
+        assert n == g.n and np.array_equal(w, g.w) and np.array_equal(pairs, _expected(g))
+
+
+def test_messy_input_semantics(ours, tmp_path):
+    """duplicates, self-loops, unsorted lists, entries listed only by the higher endpoint,
+    a line holding only a weight, CRLF, trailing blanks, no final newline"""
+    text = "5 4 10\r\n10 3 2 2 1\n20 1   \n30 1 5 4\n40\n50 3 1"
+    (tmp_path / "m.graph").write_text(text)
+    n, w, pairs = _load(ours, "gnnvc_host_load_metis", tmp_path / "m.graph", C.c_uint(2))
+    assert n == 5 and w.tolist() == [10, 20, 30, 40, 50]
+    # vertex 1 keeps {2,3} (dup, self-loop dropped); 2 keeps none (1 is lower); 3 keeps {4,5}; 5's "3 1" are lower
+    assert pairs.tolist() == [[0, 1], [0, 2], [2, 3], [2, 4]]
+    g2 = gg.parse_metis(text.replace("\r", ""))
+    assert np.array_equal(pairs, _expected(g2))
+
+
+def test_errors(ours, tmp_path):
+    (tmp_path / "bad.graph").write_text("3 1 10\n5 9\n5\n5\n")     # neighbour id out of range
+    assert _load(ours, "gnnvc_host_load_metis", tmp_path / "bad.graph", C.c_uint(1)) is None
+    assert _load(ours, "gnnvc_host_load_metis", tmp_path / "missing.graph", C.c_uint(1)) is None
+
+
+@pytest.mark.skipif(not REF.exists(), reason="reference sources not mounted here")
+def test_same_result_as_reference_loader(ours, tmp_path):
+    r = subprocess.run(["make", "-C", str(ROOT / "oracle"), "_ref/ref_parse.so"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    ref = C.CDLL(str(ROOT / "oracle" / "_ref" / "ref_parse.so"))
+    g = gg.erdos_renyi(200000, 2000000, 3)
+    path = tmp_path / "big.graph"
+    path.write_text(gg.metis_text(g))
+    t0 = time.perf_counter()
+    a = _load(ours, "gnnvc_host_load_metis", path, C.c_uint(0))
+    t1 = time.perf_counter()
+    b = _load(ref, "ref_parse", path)
+    t2 = time.perf_counter()
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    print(f"\nMETIS 200K/2M: ours {1e3 * (t1 - t0):.0f} ms, reference parse_graph {1e3 * (t2 - t1):.0f} ms")
