@@ -1,0 +1,103 @@
+"""The whole ./GNN_VC run with the HIP engine behind gnn::model::predict (GPU box).
+
+oracle/_ref/GNN_VC_hip is the reference's own driver object (src/GNN_VC.cpp:
+METIS parse, reductions, the predict loop :171-192, local search, result file)
+linked with this repo's host/gnn_inference.cpp + host/matrix.cpp and
+libgnnvc_hip.so — INTEGRATION.md option A, built in the build container by
+`make -C oracle ref` and carried to the GPU box as a binary.  The known answers
+in tests/golden/manifest.json come from the unmodified reference linked to
+OpenBLAS, so equality here is "identical final VC weight" end to end: every
+predict call of the run (shrinking graphs down to the empty one) has to
+reproduce the reference's scores closely enough to take the same decisions,
+and on these inputs it reproduces the result file byte for byte.
+"""
+import hashlib
+import json
+import pathlib
+import subprocess
+
+import numpy as np
+import pytest
+
+from tools import graphgen as gg
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+CLI = ROOT / "oracle" / "_ref" / "GNN_VC_hip"
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not CLI.exists(), reason="oracle/_ref/GNN_VC_hip not built (needs the reference sources)")]
+
+
+@pytest.fixture(scope="module")
+def manifest(golden_dir):
+    return json.loads((golden_dir / "manifest.json").read_text())
+
+
+def _run(graph_path, out_path, timeout=900):
+    r = subprocess.run([str(CLI), str(graph_path), str(out_path), "0", "-1", "0"],
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout.strip()
+
+
+def _graph(spec):
+    p = spec["graph"]
+    if p["kind"] == "erdos_renyi":
+        return gg.erdos_renyi(p["n"], p["m"], p["seed"])
+    if p["kind"] == "hub_graph":
+        return gg.hub_graph(p["n"], p["m"], p["hubs"], p["hub_degree"], seed=p["seed"])
+    raise AssertionError(p["kind"])
+
+
+def test_cli_readme_graph(manifest, tmp_path):
+    (tmp_path / "ex3.graph").write_text("3 2 10\n15 3\n15 3\n20 1 2\n")
+    out = _run(tmp_path / "ex3.graph", tmp_path / "ex3.out")
+    spec = manifest["ex3"]["cli"]
+    assert out.startswith(spec["stdout_prefix"])
+    assert out.split(",")[6] == str(spec["final_cost"])
+    assert [int(v) for v in (tmp_path / "ex3.out").read_text().split()] == spec["cover"]
+
+
+def test_cli_er100k_identical_cover(manifest, golden_dir, tmp_path):
+    spec = manifest["er100k"]
+    g = _graph(spec)
+    text = gg.metis_text(g)
+    assert hashlib.md5(text.encode()).hexdigest() == spec["metis_md5"]
+    (tmp_path / "er100k.graph").write_text(text)
+    out = _run(tmp_path / "er100k.graph", tmp_path / "er100k.out")
+    fields = out.split(",")
+    assert fields[0] == "er100k" and int(fields[1]) == spec["cli"]["final_cost"]
+    raw = (tmp_path / "er100k.out").read_bytes()
+    assert hashlib.md5(raw).hexdigest() == spec["cli"]["result_md5"]
+    cover = np.array(raw.split(), dtype=np.uint8)
+    gold = np.unpackbits(np.fromfile(golden_dir / spec["cli"]["cover_bits_file"], dtype=np.uint8))[: g.n]
+    assert np.array_equal(cover, gold)
+    assert int(g.w[cover == 1].astype(np.int64).sum()) == spec["cli"]["final_cost"]
+
+
+def test_cli_hub200k_identical_weight(manifest, tmp_path):
+    """Three 65536-degree hubs: the long-row kernels sit on this run's predict calls."""
+    spec = manifest["hub200k"]
+    g = _graph(spec)
+    text = gg.metis_text(g)
+    assert hashlib.md5(text.encode()).hexdigest() == spec["metis_md5"]
+    (tmp_path / "hub200k.graph").write_text(text)
+    out = _run(tmp_path / "hub200k.graph", tmp_path / "hub200k.out")
+    fields = out.split(",")
+    assert fields[0] == "hub200k" and int(fields[1]) == spec["cli"]["final_cost"]
+    cover = np.array((tmp_path / "hub200k.out").read_bytes().split(), dtype=np.uint8)
+    assert int(g.w[cover == 1].astype(np.int64).sum()) == spec["cli"]["final_cost"]
+    # it is a vertex cover
+    src = np.repeat(np.arange(g.n), np.diff(g.rowptr.astype(np.int64)))
+    assert np.all((cover[src] == 1) | (cover[g.col] == 1))
+
+
+def test_cli_er1m_identical_result_file(manifest, tmp_path):
+    spec = manifest["er1m"]
+    g = _graph(spec)
+    (tmp_path / "er1m.graph").write_text(gg.metis_text(g))
+    out = _run(tmp_path / "er1m.graph", tmp_path / "er1m.out")
+    fields = out.split(",")
+    assert fields[0] == "er1m" and int(fields[1]) == spec["cli"]["final_cost"]
+    raw = (tmp_path / "er1m.out").read_bytes()
+    assert hashlib.md5(raw).hexdigest() == spec["cli"]["result_md5"]

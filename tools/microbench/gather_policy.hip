@@ -85,7 +85,10 @@ float run(const float4 *tab, const uint32_t *idx, float4 *out, size_t quads, siz
 int main(int argc, char **argv) {
     const size_t rows = (size_t)(argc > 1 ? atof(argv[1]) : 10) * 1000000;
     const size_t gathers_req = (size_t)(argc > 2 ? atof(argv[2]) : 200) * 1000000;
-    const size_t quads = 256 * 16 * 16 * 4;            // 256 CUs x 16 waves x 16 quads x 4
+    // waves per CU in flight (argv[3], default 16): fewer blocks -> fewer resident waves per CU,
+    // to see whether the gather rate is limited by requests in flight or by the fabric
+    const size_t waves_per_cu = argc > 3 ? (size_t)atoi(argv[3]) : 16;
+    const size_t quads = 256 * waves_per_cu * 16 * (argc > 4 ? (size_t)atoi(argv[4]) : 4);   // x oversubscription
     const size_t per_quad = (gathers_req / quads) / 8 * 8;
     const size_t gathers = quads * per_quad;
     float4 *tab, *out; uint32_t *idx;
@@ -93,7 +96,8 @@ int main(int argc, char **argv) {
     hipLaunchKernelGGL(k_fill_tab, dim3(4096), dim3(256), 0, 0, (float *)tab, (rows + 1) * 16);
     hipLaunchKernelGGL(k_fill_idx, dim3(4096), dim3(256), 0, 0, idx, gathers, (uint32_t)rows);
     CK(hipDeviceSynchronize());
-    printf("table %.0f MB, %zu gathers of 64 B (%.2f GB useful)\n", rows * 64 / 1e6, gathers, gathers * 64 / 1e9);
+    printf("table %.0f MB, %zu gathers of 64 B (%.2f GB useful), %zu waves/CU x %zu\n", rows * 64 / 1e6, gathers,
+           gathers * 64 / 1e9, waves_per_cu, quads / (256 * waves_per_cu * 16));
     const char *names[] = {"default", "nt", "sc1", "sc0 sc1", "sc0"};
     float ms[5][2];
     ms[0][0] = run<0, 4>(tab, idx, out, quads, per_quad, 3); ms[0][1] = run<0, 8>(tab, idx, out, quads, per_quad, 3);
