@@ -54,6 +54,28 @@ struct DevBuf {
     }
 };
 
+// Page-locked host staging (graph hand-off: the copy engine reads it directly, no bounce buffer).
+template <class T>
+struct PinBuf {
+    T *p = nullptr;
+    size_t cap = 0;  // elements
+    hipError_t reserve(size_t count) {
+        if (count <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = std::max<size_t>(count + count / 8, 64);   // head-room: the driver's graphs shrink
+        hipError_t rc = hipHostMalloc(reinterpret_cast<void **>(&p), want * sizeof(T), hipHostMallocDefault);
+        if (rc == hipSuccess) cap = want;
+        return rc;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
 }  // namespace
 
 struct gnnvc_engine {
@@ -75,6 +97,12 @@ struct gnnvc_engine {
     GraphDev g;
     bool have_graph = false;
     DevBuf<uint32_t> rowptr, col, w, nw;
+    // staged hand-off (gnnvc_graph_staging .. gnnvc_commit_staged_graph)
+    PinBuf<uint32_t> pin_rowptr, pin_col, pin_w, pin_nw;
+    PinBuf<uint32_t> pin_small;   // host side of small device<->host round trips
+    uint32_t staged_n = 0;
+    uint64_t staged_nnz = 0, staged_sent = 0;   // columns [0, staged_sent) are already on their way
+    bool staging = false;
     // feature buffers
     DevBuf<float> x, h[2], scores, logits;
     DevBuf<float> scratch[2];  // layer-level entry points / unfused path
@@ -98,6 +126,7 @@ struct gnnvc_engine {
 
     // degree-sorted tile order (16-wide stages, skewed graphs); built per row range on demand
     int opt_sorted = -1;               // option "sorted_tiles": -1 auto (by measured waste), 0 off, 1 on
+    uint64_t opt_sorted_min_nnz = 4ull << 20;   // auto mode leaves smaller graphs on natural tiles
     uint32_t opt_sorted_long_thresh = 1024;   // long-row threshold of the 16-wide stages when their tiles are sorted
     uint32_t thresh_f16 = 0xFFFFFFFFu;        // rows >= this go to k_long_f16 (>= long_thresh, the list's threshold)
     bool interleave = false;           // deal natural tiles round-robin (work is unevenly spread over the row range)
@@ -329,7 +358,9 @@ int find_long(gnnvc_engine *e) {
         HIP_TRY(e, hipMemcpyAsync(&sum_max, e->srt_sum.p, sizeof sum_max, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(e, hipStreamSynchronize(e->stream));
         e->srt_waste = 64.0 * (double)sum_max / (double)g.nnz;
-        e->sorted_wanted = e->opt_sorted > 0 || e->srt_waste >= 2.0;
+        // below a few million entries a 16-wide stage takes tens of microseconds either way and the
+        // sort (two kernels and a host round trip) costs more than it saves on a graph used once
+        e->sorted_wanted = e->opt_sorted > 0 || (e->srt_waste >= 2.0 && g.nnz >= e->opt_sorted_min_nnz);
     }
     if (!e->opt_long_thresh) return GNNVC_OK;
     // One list at the base threshold serves every stage.  With degree-sorted tiles the 16-wide
@@ -373,16 +404,19 @@ int ensure_sorted(gnnvc_engine *e, uint32_t lo, uint32_t hi) {
     HIP_TRY(e, e->srt_hist.reserve(bins));
     HIP_TRY(e, e->srt_vertex.reserve(hi - lo));
     HIP_TRY(e, e->srt_meta.reserve(hi - lo));
+    // the scan's host round trip goes through page-locked memory: an async copy to or from
+    // pageable memory above a few KB pins it on the fly, which costs milliseconds the first time
+    HIP_TRY(e, e->pin_small.reserve(2 * (size_t)bins));
+    uint32_t *hist = e->pin_small.p, *start = e->pin_small.p + bins;
     HIP_TRY(e, gnnvc::degree_histogram(g, lo, hi, lt, bins, e->srt_hist.p, e->stream));
-    std::vector<uint32_t> hist(bins), start(bins);
-    HIP_TRY(e, hipMemcpyAsync(hist.data(), e->srt_hist.p, bins * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(hist, e->srt_hist.p, bins * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     uint32_t run = 0;
     for (uint32_t d = bins; d-- > 0;) {   // heaviest degree class first
         start[d] = run;
         run += hist[d];
     }
-    HIP_TRY(e, hipMemcpyAsync(e->srt_hist.p, start.data(), bins * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->srt_hist.p, start, bins * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, gnnvc::degree_scatter(g, lo, hi, lt, bins, e->srt_hist.p, e->srt_vertex.p,
                                      e->srt_meta.p, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));   // `start` is read by the async copy above
@@ -597,6 +631,8 @@ void gnnvc_destroy(gnnvc_engine *e) {
     e->blk_ptr.release(); e->blk_col.release(); e->blk_scratch.release(); e->blk_flag.release();
     e->blk_acc.release();
     e->long_list.release(); e->long_count.release();
+    e->pin_rowptr.release(); e->pin_col.release(); e->pin_w.release(); e->pin_nw.release();
+    e->pin_small.release();
     e->srt_vertex.release(); e->srt_hist.release(); e->srt_meta.release(); e->srt_sum.release();
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
@@ -625,6 +661,7 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "block_cols") e->opt_block_cols = value > 0 ? (uint32_t)value : 0;
     else if (k == "blocked_min_n") e->opt_blocked_min_n = value > 0 ? (uint32_t)value : 0;
     else if (k == "long_row_threshold") e->opt_long_thresh = value > 0 ? (uint32_t)value : 0;
+    else if (k == "sorted_min_nnz") e->opt_sorted_min_nnz = value > 0 ? (uint64_t)value : 0;
     else if (k == "sorted_long_row_threshold") e->opt_sorted_long_thresh = value > 0 ? (uint32_t)value : 1;
     else if (k == "mfma_dense") e->opt_mfma = (value >= 0 && value <= 2) ? (int)value : 2;
     else if (k == "sorted_tiles") { e->opt_sorted = value < 0 ? -1 : (value ? 1 : 0); e->sorted_valid = false; }
@@ -661,6 +698,31 @@ int gnnvc_stage_widths(const gnnvc_engine *e, int stage, int *in_width, int *out
     return GNNVC_OK;
 }
 
+// Common tail of the host hand-offs: device-side sanity checks of the arrays now in
+// e->rowptr/col/w/nw, then make them the engine's graph.
+static int adopt_uploaded(gnnvc_engine *e, uint32_t n, uint64_t nnz) {
+    {
+        const GraphDev cand{n, nnz, e->rowptr.p, e->col.p, e->w.p, e->nw.p};
+        HIP_TRY(e, gnnvc::validate_graph(cand, e->blk_flag.p, e->stream));
+        uint32_t bad = 0;
+        HIP_TRY(e, hipMemcpyAsync(&bad, e->blk_flag.p, sizeof bad, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        if (bad) {
+            e->have_graph = false;
+            return fail(e, GNNVC_ERR_INVALID, "%s", (bad & 1u) ? "a column id is not a vertex of this graph (col[i] >= n)"
+                                                                 : "row pointers are not monotone from 0 to nnz");
+        }
+    }
+    e->g = GraphDev{n, nnz, e->rowptr.p, e->col.p, e->w.p, e->nw.p};
+    e->have_graph = true;
+    int rc = reserve_features(e, n);
+    if (rc) return rc;
+    e->blocked_ready = false;   // the column-blocked index is built on the graph's SECOND forward:
+    e->blocked_tried = false;   // it costs about as much as it saves on one, and the reference's
+    e->graph_uses = 0;          // driver uses every graph exactly once (src/GNN_VC.cpp:171-192)
+    return find_long(e);
+}
+
 int gnnvc_upload_graph(gnnvc_engine *e, uint32_t n, const uint64_t *rowptr, const uint32_t *col,
                        const uint32_t *w, const uint32_t *nw) {
     if (!e) return GNNVC_ERR_INVALID;
@@ -690,26 +752,86 @@ int gnnvc_upload_graph(gnnvc_engine *e, uint32_t n, const uint64_t *rowptr, cons
     }
     if (nnz) HIP_TRY(e, hipMemcpyAsync(e->col.p, col, nnz * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipMemsetAsync(e->col.p + nnz, 0, GNNVC_COL_PAD * sizeof(uint32_t), e->stream));
-    {
-        const GraphDev cand{n, nnz, e->rowptr.p, e->col.p, e->w.p, e->nw.p};
-        HIP_TRY(e, gnnvc::validate_graph(cand, e->blk_flag.p, e->stream));
-        uint32_t bad = 0;
-        HIP_TRY(e, hipMemcpyAsync(&bad, e->blk_flag.p, sizeof bad, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
-        if (bad) {
-            e->have_graph = false;
-            return fail(e, GNNVC_ERR_INVALID, "%s", (bad & 1u) ? "a column id is not a vertex of this graph (col[i] >= n)"
-                                                                 : "row pointers are not monotone from 0 to nnz");
-        }
-    }
-    e->g = GraphDev{n, nnz, e->rowptr.p, e->col.p, e->w.p, e->nw.p};
-    e->have_graph = true;
-    rc = reserve_features(e, n);
+    return adopt_uploaded(e, n, nnz);
+}
+
+/* ---- staged hand-off --------------------------------------------------------
+ * The reference's driver hands predict a freshly mutated graph every call (src/GNN_VC.cpp:171-192)
+ * whose adjacency lives in scattered ranges of one big array (include/reduction_graph.hpp:29-36),
+ * so the host has to pack it.  Packing straight into page-locked memory owned by the engine saves
+ * the allocation + zero fill + page faults of a temporary CSR and the bounce copy of a pageable
+ * upload, and finished pieces of the column array go out while the host packs the next. */
+int gnnvc_graph_staging(gnnvc_engine *e, uint32_t n, uint64_t nnz, uint32_t **rowptr, uint32_t **col,
+                        uint32_t **w, uint32_t **nw) {
+    if (!e) return GNNVC_ERR_INVALID;
+    if (nnz >= 0xFFFFFFFFull - GNNVC_COL_PAD)
+        return fail(e, GNNVC_ERR_UNSUPPORTED, "nnz %llu does not fit 32-bit row pointers", (unsigned long long)nnz);
+    int rc = use_device(e);
     if (rc) return rc;
-    e->blocked_ready = false;   // the column-blocked index is built on the graph's SECOND forward:
-    e->blocked_tried = false;   // it costs about as much as it saves on one, and the reference's
-    e->graph_uses = 0;          // driver uses every graph exactly once (src/GNN_VC.cpp:171-192)
-    return find_long(e);
+    if (e->staging && e->staged_sent && (n != e->staged_n || nnz != e->staged_nnz))
+        return fail(e, GNNVC_ERR_STATE, "staging resized after columns were sent");
+    HIP_TRY(e, e->pin_rowptr.reserve((size_t)n + 1));
+    HIP_TRY(e, e->pin_w.reserve(n));
+    HIP_TRY(e, e->pin_nw.reserve(n));
+    HIP_TRY(e, e->pin_col.reserve(nnz));
+    e->staged_n = n;
+    e->staged_nnz = nnz;
+    if (!e->staging) e->staged_sent = 0;
+    e->staging = true;
+    if (rowptr) *rowptr = e->pin_rowptr.p;
+    if (col) *col = e->pin_col.p;
+    if (w) *w = e->pin_w.p;
+    if (nw) *nw = e->pin_nw.p;
+    return GNNVC_OK;
+}
+
+int gnnvc_staged_columns_ready(gnnvc_engine *e, uint64_t first, uint64_t count) {
+    if (!e) return GNNVC_ERR_INVALID;
+    if (!e->staging) return fail(e, GNNVC_ERR_STATE, "no graph is being staged");
+    if (first != e->staged_sent || first + count > e->staged_nnz)
+        return fail(e, GNNVC_ERR_INVALID, "column pieces must be announced in order (expected offset %llu)",
+                    (unsigned long long)e->staged_sent);
+    if (!count) return GNNVC_OK;
+    int rc = use_device(e);
+    if (rc) return rc;
+    if (!e->staged_sent) {   // first piece: the device array is about to be overwritten
+        e->have_graph = false;
+        HIP_TRY(e, e->col.reserve(e->staged_nnz + GNNVC_COL_PAD));
+    }
+    HIP_TRY(e, hipMemcpyAsync(e->col.p + first, e->pin_col.p + first, count * sizeof(uint32_t), hipMemcpyHostToDevice,
+                              e->stream));
+    e->staged_sent = first + count;
+    return GNNVC_OK;
+}
+
+int gnnvc_commit_staged_graph(gnnvc_engine *e) {
+    if (!e) return GNNVC_ERR_INVALID;
+    if (!e->staging) return fail(e, GNNVC_ERR_STATE, "no graph is being staged");
+    int rc = use_device(e);
+    if (rc) return rc;
+    const uint32_t n = e->staged_n;
+    const uint64_t nnz = e->staged_nnz;
+    e->staging = false;
+    e->have_graph = false;
+    if (n && e->pin_rowptr.p[n] != nnz) return fail(e, GNNVC_ERR_INVALID, "staged rowptr[n] differs from the staged nnz");
+    HIP_TRY(e, e->rowptr.reserve((size_t)n + 1));
+    HIP_TRY(e, e->col.reserve(nnz + GNNVC_COL_PAD));
+    HIP_TRY(e, e->w.reserve(n));
+    HIP_TRY(e, e->nw.reserve(n));
+    HIP_TRY(e, e->blk_flag.reserve(1));
+    if (n) {
+        HIP_TRY(e, hipMemcpyAsync(e->rowptr.p, e->pin_rowptr.p, ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(e->w.p, e->pin_w.p, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(e->nw.p, e->pin_nw.p, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    } else {
+        HIP_TRY(e, hipMemsetAsync(e->rowptr.p, 0, sizeof(uint32_t), e->stream));
+    }
+    if (nnz > e->staged_sent)
+        HIP_TRY(e, hipMemcpyAsync(e->col.p + e->staged_sent, e->pin_col.p + e->staged_sent,
+                                  (nnz - e->staged_sent) * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    e->staged_sent = 0;
+    HIP_TRY(e, hipMemsetAsync(e->col.p + nnz, 0, GNNVC_COL_PAD * sizeof(uint32_t), e->stream));
+    return adopt_uploaded(e, n, nnz);
 }
 
 int gnnvc_attach_graph_device(gnnvc_engine *e, uint32_t n, uint64_t nnz, const uint32_t *d_rowptr,

@@ -20,6 +20,7 @@ ABI_SYMBOLS = [
     "gnnvc_abi_version", "gnnvc_strerror", "gnnvc_last_error", "gnnvc_create", "gnnvc_destroy",
     "gnnvc_set_weight_scale", "gnnvc_set_stream", "gnnvc_set_option", "gnnvc_get_info", "gnnvc_num_layers", "gnnvc_is_fused",
     "gnnvc_in_width", "gnnvc_out_width", "gnnvc_upload_graph", "gnnvc_attach_graph_device",
+    "gnnvc_graph_staging", "gnnvc_staged_columns_ready", "gnnvc_commit_staged_graph",
     "gnnvc_forward", "gnnvc_forward_device", "gnnvc_num_stages", "gnnvc_stage_widths",
     "gnnvc_stage_forward_device", "gnnvc_reduction_flags", "gnnvc_synchronize", "gnnvc_last_forward_ms",
     "gnnvc_graph_layer_forward", "gnnvc_linear_forward", "gnnvc_relu_forward",
@@ -87,6 +88,9 @@ def load_library():
     L.gnnvc_stage_widths.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.gnnvc_upload_graph.argtypes = [vp, u32, vp, vp, vp, vp]
     L.gnnvc_attach_graph_device.argtypes = [vp, u32, u64, vp, vp, vp, vp]
+    L.gnnvc_graph_staging.argtypes = [vp, u32, u64] + [C.POINTER(vp)] * 4
+    L.gnnvc_staged_columns_ready.argtypes = [vp, u64, u64]
+    L.gnnvc_commit_staged_graph.argtypes = [vp]
     L.gnnvc_forward.argtypes = [vp, f32p, f32p, f32p]
     L.gnnvc_forward_device.argtypes = [vp, f32p, f32p, f32p]
     L.gnnvc_stage_forward_device.argtypes = [vp, C.c_int, u32, u32, f32p, f32p, f32p]
@@ -194,6 +198,31 @@ class Engine:
         self._check(self._L.gnnvc_upload_graph(self._h, g.n, _np_ptr(rowptr), _np_ptr(col),
                                                _np_ptr(w), _np_ptr(nw)))
         self.n = g.n
+
+    def upload_graph_staged(self, g, pieces: int = 4):
+        """Same hand-off through the engine's page-locked staging (gnnvc_graph_staging ..
+        gnnvc_commit_staged_graph): the arrays are written into pinned memory and the column array
+        goes out in `pieces` announced pieces."""
+        n, nnz = int(g.n), int(g.rowptr[-1]) if g.n else 0
+        ptr = [C.c_void_p() for _ in range(4)]
+        self._check(self._L.gnnvc_graph_staging(self._h, n, 0, C.byref(ptr[0]), None, C.byref(ptr[2]), C.byref(ptr[3])))
+
+        def view(p, count):
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(count,)) if count else np.zeros(0, np.uint32)
+        if n:
+            view(ptr[0], n + 1)[:] = np.asarray(g.rowptr, dtype=np.uint64).astype(np.uint32)
+            view(ptr[2], n)[:] = g.w
+            view(ptr[3], n)[:] = g.nw
+        self._check(self._L.gnnvc_graph_staging(self._h, n, nnz, None, C.byref(ptr[1]), None, None))
+        col = view(ptr[1], nnz)
+        step = max(1, -(-nnz // max(1, pieces)))
+        for lo in range(0, nnz, step):
+            hi = min(nnz, lo + step)
+            col[lo:hi] = g.col[lo:hi]
+            if hi < nnz:            # the last piece is left to the commit
+                self._check(self._L.gnnvc_staged_columns_ready(self._h, lo, hi - lo))
+        self._check(self._L.gnnvc_commit_staged_graph(self._h))
+        self.n = n
 
     def attach_graph_device(self, n: int, nnz: int, rowptr_ptr: int, col_ptr: int, w_ptr: int,
                             nw_ptr: int, keepalive=None):

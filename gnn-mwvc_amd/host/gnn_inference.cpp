@@ -12,7 +12,11 @@
 // host libm's final sigmoid to the device logits on hosts whose expf differs).
 #include <gnn_inference.hpp>  // angle brackets: the -I order decides (reference headers in the drop-in build)
 
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <cmath>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -72,26 +76,85 @@ visitor(Fs...) -> visitor<Fs...>;
 const float *cdata(const matrix &m) { return (m.get_height() && m.get_width()) ? &*m.begin(0) : nullptr; }
 float *mdata(matrix &m) { return (m.get_height() && m.get_width()) ? &*m.begin(0) : nullptr; }
 
-// Run fn(begin, end) over [0, n) on a few threads (graphs of millions of rows; the pack is
-// the largest host cost of a predict call once the forward itself takes milliseconds).
+unsigned pack_threads() {
+    static const unsigned t = std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
+    return t;
+}
+
+// Persistent helpers for the pack passes: creating a dozen threads three times per predict call
+// costs more than packing a mid-sized graph.  run(job) executes job(worker) on every helper and on
+// the calling thread (worker 0) and returns when all are done.  Leaked on purpose: the helpers
+// sleep on the condition variable until the process exits.
+class PackPool {
+public:
+    static PackPool &get() {
+        static PackPool *pool = new PackPool(pack_threads());
+        return *pool;
+    }
+    unsigned size() const { return (unsigned)helpers_.size() + 1; }
+    void run(const std::function<void(unsigned)> &job) {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job_ = &job;
+            pending_ = (unsigned)helpers_.size();
+            ++generation_;
+        }
+        wake_.notify_all();
+        job(0);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+
+private:
+    explicit PackPool(unsigned t) {
+        for (unsigned i = 1; i < t; ++i) helpers_.emplace_back([this, i] { loop(i); });
+        for (auto &h : helpers_) h.detach();
+    }
+    void loop(unsigned worker) {
+        unsigned long seen = 0;
+        for (;;) {
+            const std::function<void(unsigned)> *job;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                wake_.wait(lk, [&] { return generation_ != seen; });
+                seen = generation_;
+                job = job_;
+            }
+            (*job)(worker);
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    std::vector<std::thread> helpers_;
+    std::mutex mu_;
+    std::condition_variable wake_, done_;
+    const std::function<void(unsigned)> *job_ = nullptr;
+    unsigned pending_ = 0;
+    unsigned long generation_ = 0;
+};
+
+// Run fn(part, begin, end) over [0, n) cut into equal row ranges, one per pool thread.  The cut
+// depends only on n, so two passes see the same parts.
 template <class Fn>
 void parallel_rows(uint32_t n, Fn fn) {
-    unsigned t = std::thread::hardware_concurrency();
-    t = std::max(1u, std::min(t, 16u));
-    if (n < (1u << 16) || t == 1) {
-        fn(0u, n);
+    const unsigned t = pack_threads();
+    if (n < (1u << 15) || t == 1) {
+        fn(0u, 0u, n);
         return;
     }
-    std::vector<std::thread> pool;
     const uint32_t step = (n + t - 1) / t;
-    for (uint32_t lo = 0; lo < n; lo += step) pool.emplace_back(fn, lo, std::min(n, lo + step));
-    for (auto &th : pool) th.join();
+    PackPool::get().run([&](unsigned part) {
+        const uint64_t lo = (uint64_t)part * step;
+        if (lo < n) fn(part, (uint32_t)lo, (uint32_t)std::min<uint64_t>(n, lo + step));
+    });
 }
 
 // The graph view the forward reads, packed to contiguous CSR through the
 // non-mutating accessors (begin(u)/end(u), W, NW — never D(u)/g[u], which move
 // the reference's hidden cursor, include/reduction_graph.hpp:144,240-245; the
 // accessors used here are const and safe to call from several threads).
+// Used by the layer-level graph_layer::forward.
 struct PackedGraph {
     std::vector<uint64_t> rowptr;
     std::vector<uint32_t> col, w, nw;
@@ -102,7 +165,7 @@ struct PackedGraph {
         w.resize(n);
         nw.resize(n);
         rowptr[0] = 0;
-        parallel_rows(n, [&](uint32_t lo, uint32_t hi) {
+        parallel_rows(n, [&](unsigned, uint32_t lo, uint32_t hi) {
             for (uint32_t u = lo; u < hi; ++u) {
                 rowptr[u + 1] = (uint64_t)(g.end(u) - g.begin(u));   // row length, prefix-summed below
                 w[u] = g.W(u);
@@ -111,11 +174,101 @@ struct PackedGraph {
         });
         for (uint32_t u = 0; u < n; ++u) rowptr[u + 1] += rowptr[u];
         col.resize(rowptr[n]);
-        parallel_rows(n, [&](uint32_t lo, uint32_t hi) {
+        parallel_rows(n, [&](unsigned, uint32_t lo, uint32_t hi) {
             for (uint32_t u = lo; u < hi; ++u) std::copy(g.begin(u), g.end(u), col.begin() + rowptr[u]);
         });
     }
 };
+
+// predict's hand-off: the same pack, written straight into the engine's
+// page-locked staging (no temporary CSR to allocate, zero and fault in; no bounce copy), with the
+// column array leaving in pieces while the remaining rows are still being packed.  Returns nnz.
+template <class G>
+uint64_t hand_off_graph(gnnvc_engine *e, const G &g) {
+    const uint32_t n = g.size();
+    uint32_t *rowptr = nullptr, *col = nullptr, *w = nullptr, *nw = nullptr;
+    check(gnnvc_graph_staging(e, n, 0, &rowptr, nullptr, &w, &nw), "gnnvc_graph_staging", e);
+    // lengths, weights; per-part totals -> offsets -> in-place prefix sums
+    std::vector<uint64_t> part_sum(pack_threads() + 1, 0);
+    rowptr[0] = 0;
+    parallel_rows(n, [&](unsigned part, uint32_t lo, uint32_t hi) {
+        uint64_t sum = 0;
+        for (uint32_t u = lo; u < hi; ++u) {
+            const uint64_t len = (uint64_t)(g.end(u) - g.begin(u));
+            rowptr[u + 1] = (uint32_t)len;
+            sum += len;
+            w[u] = g.W(u);
+            nw[u] = g.NW(u);
+        }
+        part_sum[part + 1] = sum;
+    });
+    for (size_t i = 1; i < part_sum.size(); ++i) part_sum[i] += part_sum[i - 1];
+    const uint64_t nnz = part_sum.back();
+    if (nnz >= 0xFFFFFFFFull - 64) {
+        std::fprintf(stderr, "gnn::model::predict: %llu adjacency entries do not fit the engine's 32-bit row pointers\n",
+                     (unsigned long long)nnz);
+        std::abort();
+    }
+    parallel_rows(n, [&](unsigned part, uint32_t lo, uint32_t hi) {
+        uint32_t run = (uint32_t)part_sum[part];
+        for (uint32_t u = lo; u < hi; ++u) {
+            run += rowptr[u + 1];
+            rowptr[u + 1] = run;
+        }
+    });
+    check(gnnvc_graph_staging(e, n, nnz, nullptr, &col, nullptr, nullptr), "gnnvc_graph_staging", e);
+
+    // columns: chunks of ~256 K entries claimed in order by the workers; this thread announces the
+    // finished prefix to the engine a few chunks at a time (all HIP calls stay on this thread)
+    const uint64_t kChunk = 1u << 18, kAnnounce = 1u << 21;
+    const unsigned t = pack_threads();
+    if (nnz < 4 * kChunk || t == 1) {
+        for (uint32_t u = 0; u < n; ++u) std::copy(g.begin(u), g.end(u), col + rowptr[u]);
+    } else {
+        std::vector<uint32_t> cut{0};   // chunk c = rows [cut[c], cut[c+1])
+        while (cut.back() < n) {
+            const uint64_t target = (uint64_t)rowptr[cut.back()] + kChunk;
+            uint32_t r = (uint32_t)(std::lower_bound(rowptr + cut.back() + 1, rowptr + n, target,
+                                                     [](uint32_t a, uint64_t b) { return a < b; }) - rowptr);
+            cut.push_back(std::min(n, std::max(r, cut.back() + 1)));
+        }
+        const size_t chunks = cut.size() - 1;
+        std::vector<std::atomic<uint8_t>> done(chunks);
+        for (auto &d : done) d.store(0, std::memory_order_relaxed);
+        std::atomic<size_t> next{0};
+        auto pack_one = [&]() -> bool {
+            const size_t c = next.fetch_add(1, std::memory_order_relaxed);
+            if (c >= chunks) return false;
+            for (uint32_t u = cut[c]; u < cut[c + 1]; ++u) std::copy(g.begin(u), g.end(u), col + rowptr[u]);
+            done[c].store(1, std::memory_order_release);
+            return true;
+        };
+        auto work = [&] {
+            while (pack_one()) {
+            }
+        };
+        PackPool::get().run([&](unsigned worker) {
+            if (worker) return work();
+            size_t ready = 0;          // chunks [0, ready) are packed
+            uint64_t sent = 0;         // entries already announced
+            while (ready < chunks) {
+                if (done[ready].load(std::memory_order_acquire)) {
+                    ++ready;
+                    const uint64_t upto = rowptr[cut[ready]];
+                    if (upto - sent >= kAnnounce && ready < chunks) {
+                        check(gnnvc_staged_columns_ready(e, sent, upto - sent), "gnnvc_staged_columns_ready", e);
+                        sent = upto;
+                    }
+                } else if (pack_one()) {   // nothing to announce yet: pack a chunk too
+                } else {
+                    std::this_thread::yield();
+                }
+            }
+        });
+    }
+    check(gnnvc_commit_staged_graph(e), "gnnvc_commit_staged_graph", e);
+    return nnz;
+}
 
 // Lossless text of a model in the reference's format (9 significant digits
 // round-trip fp32), used to hand the layers to gnnvc_create.
@@ -241,10 +394,16 @@ void model::predict(const matrix &in, matrix &out, const reduction_graph<Tn, Tw>
                      in.get_width(), n, gnnvc_in_width(e));
         std::abort();
     }
-    PackedGraph pg(g);
+    // GNNVC_TRACE=1: one stderr line per call with the wall time of each hand-off step
+    static const bool trace = [] {
+        const char *v = std::getenv("GNNVC_TRACE");
+        return v && *v && *v != '0';
+    }();
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
     check(gnnvc_set_weight_scale(e, scale_of(layers)), "gnnvc_set_weight_scale", e);
-    check(gnnvc_upload_graph(e, n, pg.rowptr.data(), pg.col.data(), pg.w.data(), pg.nw.data()),
-          "gnnvc_upload_graph", e);
+    const uint64_t nnz = hand_off_graph(e, g);   // pack + copy, overlapped
+    const auto t2 = clk::now();
     // The scores come straight from the device: its sigmoid evaluates glibc's expf algorithm in
     // fp64 (csrc/expf_glibc.h), bit-identical to the host libm on x86-64 hosts with FMA.  Hosts
     // whose libm differs (no FMA, another libc) can set GNNVC_HOST_SIGMOID=1 to have the final
@@ -261,6 +420,19 @@ void model::predict(const matrix &in, matrix &out, const reduction_graph<Tn, Tw>
             const float x = *(in_copy.begin(0) + i);
             *(out.begin(0) + i) = 1.0f / (1.0f + expf(-x));
         }
+    }
+    if (trace) {
+        const auto t3 = clk::now();
+        auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        float dev_ms = 0, st[3] = {0, 0, 0};
+        gnnvc_last_forward_ms(e, &dev_ms, st, 3);
+        long longs = 0, sorted = 0;
+        gnnvc_get_info(e, "long_rows", &longs);
+        gnnvc_get_info(e, "sorted_tiles_active", &sorted);
+        std::fprintf(stderr,
+                     "gnnvc predict n=%u nnz=%llu hand-off=%.3fms forward=%.3fms (device %.3fms: %.3f %.3f %.3f; "
+                     "long rows %ld, sorted tiles %ld)\n",
+                     n, (unsigned long long)nnz, ms(t0, t2), ms(t2, t3), dev_ms, st[0], st[1], st[2], longs, sorted);
     }
 }
 

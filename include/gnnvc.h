@@ -80,6 +80,8 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *   "sorted_tiles"   -1|0|1  16-wide stages take their 64-vertex tiles from a degree-sorted
  *                         vertex list instead of 64 consecutive rows (-1 = only when natural tiles
  *                         would spend more than twice the useful gather rounds, the default)
+ *   "sorted_min_nnz" n     in auto mode, graphs with fewer adjacency entries keep natural tiles
+ *                         (default 4 Mi: the sort costs more than it saves on a graph used once)
  * gnnvc_get_info keys: "mfma_dense", "sorted_tiles_active", "tile_waste_x100", "blocked_stage0_active", "blocked_blocks", "block_cols", "long_rows",
  * "long_row_threshold". */
 int gnnvc_set_option(gnnvc_engine *e, const char *key, long value);
@@ -111,6 +113,25 @@ int gnnvc_upload_graph(gnnvc_engine *e, uint32_t n, const uint64_t *rowptr,
 int gnnvc_attach_graph_device(gnnvc_engine *e, uint32_t n, uint64_t nnz,
                               const uint32_t *d_rowptr, const uint32_t *d_col,
                               const uint32_t *d_w, const uint32_t *d_nw);
+
+/* Staged hand-off (the caller is the pack loop over reduction_graph's
+ * begin(u)/end(u) ranges, include/reduction_graph.hpp:693-704): instead of building a temporary
+ * CSR and passing it to gnnvc_upload_graph, the caller writes the arrays straight into page-locked
+ * memory owned by the engine.  Protocol:
+ *   1. gnnvc_graph_staging(e, n, 0, &rowptr, NULL, &w, &nw): fill w[n], nw[n] and rowptr[n+1]
+ *      (32-bit, rowptr[0] = 0, rowptr[n] = nnz);
+ *   2. gnnvc_graph_staging(e, n, nnz, NULL, &col, NULL, NULL): the vertex arrays keep their contents;
+ *      fill col[nnz] in any order;
+ *   3. optionally, whenever a prefix-contiguous piece [first, first+count) of col is final,
+ *      gnnvc_staged_columns_ready(e, first, count) starts its copy while the caller packs on
+ *      (pieces must be announced in ascending order without gaps);
+ *   4. gnnvc_commit_staged_graph(e) copies the rest, runs the same device-side checks as
+ *      gnnvc_upload_graph and makes the graph current.
+ * The pointers stay valid until the next gnnvc_graph_staging call with larger sizes. */
+int gnnvc_graph_staging(gnnvc_engine *e, uint32_t n, uint64_t nnz, uint32_t **rowptr, uint32_t **col,
+                        uint32_t **w, uint32_t **nw);
+int gnnvc_staged_columns_ready(gnnvc_engine *e, uint64_t first, uint64_t count);
+int gnnvc_commit_staged_graph(gnnvc_engine *e);
 
 /* ---- forward ----------------------------------------------------------------
  * gnnvc_forward replaces model::predict (reference src/gnn_inference.cpp:67-81)

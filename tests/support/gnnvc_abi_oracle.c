@@ -67,6 +67,16 @@ void gnnvc_destroy(gnnvc_engine *e) {
 }
 
 int gnnvc_set_weight_scale(gnnvc_engine *e, float ws) { oracle_model_set_weight_scale(e->m, ws); return GNNVC_OK; }
+int gnnvc_last_forward_ms(gnnvc_engine *e, float *total_ms, float *stage_ms, int max_stages) {
+    (void)e; (void)stage_ms; (void)max_stages;
+    if (total_ms) *total_ms = 0.0f;   /* no device behind the double */
+    return GNNVC_OK;
+}
+int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
+    (void)e; (void)key;
+    if (value) *value = 0;
+    return GNNVC_OK;
+}
 int gnnvc_in_width(const gnnvc_engine *e) { return e->in_w; }
 int gnnvc_out_width(const gnnvc_engine *e) { return e->out_w; }
 
@@ -86,6 +96,47 @@ int gnnvc_upload_graph(gnnvc_engine *e, uint32_t n, const uint64_t *rowptr, cons
     e->w = (uint32_t *)dup(w, (size_t)n * 4);
     e->nw = (uint32_t *)dup(nw, (size_t)n * 4);
     return GNNVC_OK;
+}
+
+/* staged hand-off: plain heap staging, committed through the same path as gnnvc_upload_graph */
+static uint32_t *st_rowptr, *st_col, *st_w, *st_nw;
+static size_t st_ncap, st_zcap;
+static uint32_t st_n;
+static uint64_t st_nnz, st_sent;
+
+int gnnvc_graph_staging(gnnvc_engine *e, uint32_t n, uint64_t nnz, uint32_t **rowptr, uint32_t **col,
+                        uint32_t **w, uint32_t **nw) {
+    (void)e;
+    if ((size_t)n + 1 > st_ncap) {
+        st_ncap = (size_t)n + 1;
+        st_rowptr = (uint32_t *)realloc(st_rowptr, st_ncap * 4);
+        st_w = (uint32_t *)realloc(st_w, st_ncap * 4);
+        st_nw = (uint32_t *)realloc(st_nw, st_ncap * 4);
+    }
+    if (nnz + 1 > st_zcap) {
+        st_zcap = nnz + 1;
+        st_col = (uint32_t *)realloc(st_col, st_zcap * 4);
+    }
+    st_n = n; st_nnz = nnz; st_sent = 0;
+    if (rowptr) *rowptr = st_rowptr;
+    if (col) *col = st_col;
+    if (w) *w = st_w;
+    if (nw) *nw = st_nw;
+    return GNNVC_OK;
+}
+int gnnvc_staged_columns_ready(gnnvc_engine *e, uint64_t first, uint64_t count) {
+    (void)e;
+    if (first != st_sent || first + count > st_nnz) return GNNVC_ERR_INVALID;
+    st_sent = first + count;
+    return GNNVC_OK;
+}
+int gnnvc_commit_staged_graph(gnnvc_engine *e) {
+    uint64_t *rp = (uint64_t *)malloc(((size_t)st_n + 1) * 8);
+    for (size_t i = 0; i <= st_n; i++) rp[i] = st_n ? st_rowptr[i] : 0;
+    if (st_n && rp[st_n] != st_nnz) { free(rp); return GNNVC_ERR_INVALID; }
+    int rc = gnnvc_upload_graph(e, st_n, rp, st_col, st_w, st_nw);
+    free(rp);
+    return rc;
 }
 
 static oracle_graph view(const gnnvc_engine *e) {

@@ -267,6 +267,70 @@ def test_malformed_graphs_are_rejected(model_text):
         e.close()
 
 
+@pytest.mark.parametrize("maker,pieces", [
+    (lambda: gg.erdos_renyi(5000, 40000, 23), 1),
+    (lambda: gg.erdos_renyi(5000, 40000, 23), 7),
+    (lambda: gg.hub_graph(20000, 60000, 3, 4096, seed=7), 3),
+    (lambda: gg.from_edge_list(5, [], [20, 30, 40, 50, 60]), 2),        # no edges at all
+    (lambda: gg.from_edge_list(0, [], []), 1),                          # the empty graph
+])
+def test_staged_hand_off_equals_upload(model_text, oracle_model, maker, pieces):
+    """gnnvc_graph_staging .. gnnvc_commit_staged_graph (f-1) leaves the engine in the same state
+    as gnnvc_upload_graph: same logits, bit for bit, and the staging is reusable for the next graph."""
+    import gnn_mwvc_amd as G
+    e = G.Engine(model_text, device=0)
+    try:
+        for g in (maker(), gg.erdos_renyi(300, 900, 29), maker()):      # grow / shrink / grow again
+            e.set_weight_scale(g.ws)
+            oracle_model.set_weight_scale(g.ws)
+            e.upload_graph_staged(g, pieces=pieces)
+            scores, logits = e.forward(g.x())
+            if g.n == 0:
+                assert scores.shape == (0, 1)
+                continue
+            assert np.array_equal(bits(logits[:, 0]), bits(oracle_model.logits(g)))
+            e.upload_graph(g)
+            _, again = e.forward(g.x())
+            assert np.array_equal(bits(again), bits(logits))
+    finally:
+        e.close()
+
+
+def test_staged_hand_off_errors(model_text):
+    import ctypes as C
+    import gnn_mwvc_amd as G
+    e = G.Engine(model_text, device=0)
+    L, h = e._L, e._h
+    try:
+        assert L.gnnvc_commit_staged_graph(h) == -4                     # nothing staged
+        assert L.gnnvc_staged_columns_ready(h, 0, 1) == -4
+        g = gg.erdos_renyi(500, 2000, 19)
+        ptr = [C.c_void_p() for _ in range(4)]
+        assert L.gnnvc_graph_staging(h, g.n, g.nnz, *[C.byref(p) for p in ptr]) == 0
+        assert all(p.value for p in ptr)
+        assert L.gnnvc_staged_columns_ready(h, 64, 64) == -1            # pieces out of order
+        assert L.gnnvc_staged_columns_ready(h, 0, g.nnz + 1) == -1      # past the end
+        u32 = lambda p, k: np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(k,))
+        u32(ptr[0], g.n + 1)[:] = g.rowptr.astype(np.uint32)
+        u32(ptr[1], g.nnz)[:] = g.col
+        u32(ptr[1], g.nnz)[7] = g.n + 5                                 # a wild column id
+        u32(ptr[2], g.n)[:] = g.w
+        u32(ptr[3], g.n)[:] = g.nw
+        assert L.gnnvc_staged_columns_ready(h, 0, 64) == 0
+        assert L.gnnvc_commit_staged_graph(h) == -1
+        assert b"column id" in L.gnnvc_last_error(h)
+        with pytest.raises(G.GnnvcError):                               # no usable graph is left behind
+            e.n = g.n
+            e.forward(g.x())
+        assert L.gnnvc_graph_staging(h, g.n, g.nnz, None, None, None, None) == 0
+        u32(ptr[0], g.n + 1)[g.n] = g.nnz - 1                           # rowptr[n] != nnz
+        assert L.gnnvc_commit_staged_graph(h) == -1
+        e.upload_graph_staged(g)                                        # and a good graph still works
+        e.forward(g.x())
+    finally:
+        e.close()
+
+
 def test_errors(engine):
     import gnn_mwvc_amd as G
     g = gg.erdos_renyi(100, 300, 18)
@@ -486,8 +550,12 @@ def test_sorted_tiles_auto_decision(model_text):
     try:
         e.upload_graph(gg.erdos_renyi(20000, 200000, 71))      # uniform degrees: natural tiles
         assert e.get_info("sorted_tiles_active") == 0 and 100 <= e.get_info("tile_waste_x100") < 200
-        e.upload_graph(gg.rmat(13, 16, 72))                    # power-law degrees: sorted tiles
-        assert e.get_info("sorted_tiles_active") == 1 and e.get_info("tile_waste_x100") >= 200
+        g = gg.rmat(13, 16, 72)                                # power-law degrees, but a small graph:
+        e.upload_graph(g)                                      # the sort would cost more than it saves
+        assert e.get_info("sorted_tiles_active") == 0 and e.get_info("tile_waste_x100") >= 200
+        e.set_option("sorted_min_nnz", 0)
+        e.upload_graph(g)                                      # without the size gate: sorted tiles
+        assert e.get_info("sorted_tiles_active") == 1
     finally:
         e.close()
 
