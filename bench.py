@@ -87,6 +87,8 @@ def main() -> int:
     ap.add_argument("--replicate-stage0", type=int, default=-1,
                     help="N>1: 1/0 forces stage 0 replicated / partitioned; -1 = auto (P=2: stages 0,1; P<=4: stage 0)")
     ap.add_argument("--partition", default="auto", choices=["auto", "rows", "nnz"])
+    ap.add_argument("--compress-exchange", type=int, default=1,
+                    help="N>1: 1 = ship only the live feature columns between stages (lossless, verified), 0 = full rows")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1 (gloo only to rehearse several ranks on ONE GPU)")
     ap.add_argument("--host-path", action="store_true",
@@ -183,10 +185,14 @@ def main() -> int:
                     ev[2 * st].record(stream)
                 elif phase == "computed":
                     ev[2 * st + 1].record(stream)
+        # verify=False: the dead-column check of the compressed exchange is read once, after the loop
         D.partitioned_forward(stage_fn, 3, x, bufs, bounds, rank, on_stage=hook, gather_logits=False,
                               replicate_stage0=None if args.replicate_stage0 < 0 else bool(args.replicate_stage0),
-                              pipeline_chunks=args.pipeline_chunks)
+                              pipeline_chunks=args.pipeline_chunks, codec=codec, verify=False)
 
+    codec = G.EngineRowCodec(eng) if (world > 1 and args.compress_exchange) else None
+    if codec is not None:
+        step(None)   # first forward on this graph: full rows, records each stage's live columns (not a timed or warm-up step)
     for _ in range(args.warmup):
         step(None)
     torch.cuda.synchronize()
@@ -205,6 +211,8 @@ def main() -> int:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    exchange_ok = D.exchange_verified(bufs) if codec is not None else True   # no shipped row hid a non-zero
 
     stage_ms = [sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for ev in stage_evt) / args.steps
                 for i in range(3)]
@@ -228,8 +236,8 @@ def main() -> int:
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload_desc, "vertices": g.n, "edges": g.n_edges,
                    "graph": args.workload, "partition": f"1d-vertex x{world} ({part_mode}-balanced)",
-                   "exchange": "none" if world == 1 else "all-gather of N x16 fp32 rows after each partitioned stage, "
-                                                          "N scores at the end"},
+                   "exchange": "none" if world == 1 else "all-gather of the N feature rows (16 fp32, or only their live "
+                                                          "columns) after each partitioned stage, N scores at the end"},
         "roofline": {"bound": "hbm", "kernel": kernel_names[dom], "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
@@ -257,9 +265,18 @@ def main() -> int:
         bad = (bufs.scores[: g.n].view(torch.int32) != ref_sc.view(torch.int32)).sum().to(torch.int64)
         dist.all_reduce(bad, op=dist.ReduceOp.SUM)
         out["parity"] = {"partitioned_vs_single_gpu_score_bit_mismatches_all_ranks": int(bad.item())}
-        out["config"]["replicated_stages"] = sorted(D.replicated_stages(world)) if args.replicate_stage0 < 0 \
-            else ([0] if args.replicate_stage0 else [])
+        out["config"]["replicated_stages"] = \
+            sorted(D.plan_replication(world, 3, bufs.live if codec is not None else None)) \
+            if args.replicate_stage0 < 0 else ([0] if args.replicate_stage0 else [])
         out["config"]["pipeline_chunks"] = args.pipeline_chunks
+        out["config"]["compressed_exchange"] = None if codec is None else {
+            "verified_lossless": bool(exchange_ok),
+            "bytes_per_row_shipped_of_64": {str(st): (round(pk.bytes_per_row, 2) if pk is not None else 64)
+                                            for st, pk in sorted(bufs.live.items())},
+            "dense_columns": {str(st): (bin(pk.mask).count("1") if pk is not None else 16)
+                              for st, pk in sorted(bufs.live.items())}}
+        if not exchange_ok:
+            out["invalid"] = "an exception list of the compressed exchange overflowed in the timed region"
     if rank == 0 and world == 1:
         if args.host_path:
             # PCIe-inclusive path (host x in, host scores + logits out); never `value`

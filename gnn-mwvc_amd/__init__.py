@@ -7,5 +7,5 @@ Layout:
   engine.py  ctypes binding of the C ABI (include/gnnvc.h) for tests and the bench
   data/      the trained model in the reference's text format
 """
-from .engine import (Engine, GnnvcError, build_library, default_model_text, library_path,  # noqa: F401
+from .engine import (Engine, EngineRowCodec, GnnvcError, build_library, default_model_text, library_path,  # noqa: F401
                      load_library)

@@ -953,6 +953,75 @@ int gnnvc_reduction_flags(gnnvc_engine *e, uint32_t max_degree, uint8_t *flags) 
     return GNNVC_OK;
 }
 
+// ---- feature-row codec of the inter-GPU exchange (device pointers, asynchronous except live_columns)
+int gnnvc_live_columns(gnnvc_engine *e, const float *d_feat, uint32_t rows, uint32_t width, uint32_t *mask) {
+    if (!e || !mask) return GNNVC_ERR_INVALID;
+    if (width != 16) return fail(e, GNNVC_ERR_UNSUPPORTED, "the row codec handles 16-column feature rows");
+    *mask = 0;
+    if (!rows) return GNNVC_OK;
+    if (!d_feat) return fail(e, GNNVC_ERR_INVALID, "null feature buffer");
+    int rc = use_device(e);
+    if (rc) return rc;
+    HIP_TRY(e, e->blk_flag.reserve(1));
+    HIP_TRY(e, e->pin_small.reserve(16));
+    HIP_TRY(e, gnnvc::live_columns(d_feat, rows, e->blk_flag.p, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, e->blk_flag.p, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    *mask = e->pin_small.p[0];
+    return GNNVC_OK;
+}
+
+int gnnvc_column_counts(gnnvc_engine *e, const float *d_feat, uint32_t rows, uint32_t width, uint64_t *counts) {
+    if (!e || !counts) return GNNVC_ERR_INVALID;
+    if (width != 16) return fail(e, GNNVC_ERR_UNSUPPORTED, "the row codec handles 16-column feature rows");
+    for (int c = 0; c < 16; ++c) counts[c] = 0;
+    if (!rows) return GNNVC_OK;
+    if (!d_feat) return fail(e, GNNVC_ERR_INVALID, "null feature buffer");
+    int rc = use_device(e);
+    if (rc) return rc;
+    HIP_TRY(e, e->srt_sum.reserve(16));
+    HIP_TRY(e, e->pin_small.reserve(64));
+    HIP_TRY(e, gnnvc::column_counts(d_feat, rows, e->srt_sum.p, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, e->srt_sum.p, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    std::memcpy(counts, e->pin_small.p, 16 * sizeof(uint64_t));
+    return GNNVC_OK;
+}
+
+static int codec_args(gnnvc_engine *e, uint32_t width, uint32_t row_lo, uint32_t row_hi, uint32_t mask, uint32_t kp) {
+    if (width != 16) return fail(e, GNNVC_ERR_UNSUPPORTED, "the row codec handles 16-column feature rows");
+    if (row_lo > row_hi) return fail(e, GNNVC_ERR_INVALID, "row range [%u, %u)", row_lo, row_hi);
+    if (mask >> 16) return fail(e, GNNVC_ERR_INVALID, "column mask has bits beyond the row width");
+    if (kp < 4 || kp > 16 || kp % 4 || (uint32_t)__builtin_popcount(mask) > kp)
+        return fail(e, GNNVC_ERR_INVALID, "packed width %u cannot hold %d live columns", kp, __builtin_popcount(mask));
+    return GNNVC_OK;
+}
+
+int gnnvc_pack_rows(gnnvc_engine *e, const float *d_feat, uint32_t width, uint32_t row_lo, uint32_t row_hi,
+                    uint32_t mask, uint32_t kp, float *d_dense, uint32_t *d_exc, uint32_t exc_cap, uint32_t *d_flag) {
+    if (!e) return GNNVC_ERR_INVALID;
+    int rc = codec_args(e, width, row_lo, row_hi, mask, kp);
+    if (rc) return rc;
+    if (!d_flag || (row_lo != row_hi && (!d_feat || !d_dense))) return fail(e, GNNVC_ERR_INVALID, "null device buffers");
+    rc = use_device(e);
+    if (rc) return rc;
+    HIP_TRY(e, gnnvc::pack_rows(d_feat, row_lo, row_hi, mask, kp, d_dense, d_exc, d_exc ? exc_cap : 0, d_flag, e->stream));
+    return GNNVC_OK;
+}
+
+int gnnvc_unpack_rows(gnnvc_engine *e, const float *d_dense, const uint32_t *d_exc, uint32_t exc_cap, uint32_t width,
+                      uint32_t row_lo, uint32_t row_hi, uint32_t mask, uint32_t kp, float *d_feat) {
+    if (!e) return GNNVC_ERR_INVALID;
+    int rc = codec_args(e, width, row_lo, row_hi, mask, kp);
+    if (rc) return rc;
+    if (row_lo == row_hi) return GNNVC_OK;
+    if (!d_feat || !d_dense) return fail(e, GNNVC_ERR_INVALID, "null device buffers");
+    rc = use_device(e);
+    if (rc) return rc;
+    HIP_TRY(e, gnnvc::unpack_rows(d_dense, d_exc, d_exc ? exc_cap : 0, row_lo, row_hi, mask, kp, d_feat, e->stream));
+    return GNNVC_OK;
+}
+
 int gnnvc_synchronize(gnnvc_engine *e) {
     if (!e) return GNNVC_ERR_INVALID;
     int rc = use_device(e);

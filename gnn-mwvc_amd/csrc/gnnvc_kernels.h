@@ -90,6 +90,14 @@ hipError_t launch_sgemm(int ta, int tb, uint32_t m, uint32_t n, uint32_t k, cons
                         uint32_t lda, const float *B, uint32_t ldb, float beta, float *C,
                         uint32_t ldc, hipStream_t stream);
 
+// feature-row codec of the inter-GPU exchange (16-column rows; a piece = dense rows + exception list)
+hipError_t live_columns(const float *feat, size_t rows, uint32_t *mask, hipStream_t stream);
+hipError_t column_counts(const float *feat, size_t rows, unsigned long long *counts, hipStream_t stream);
+hipError_t pack_rows(const float *feat, uint32_t row_lo, uint32_t row_hi, uint32_t mask, uint32_t kp, float *dense,
+                     uint32_t *exc, uint32_t cap, uint32_t *flag, hipStream_t stream);
+hipError_t unpack_rows(const float *dense, const uint32_t *exc, uint32_t cap, uint32_t row_lo, uint32_t row_hi,
+                       uint32_t mask, uint32_t kp, float *feat, hipStream_t stream);
+
 // Reduction-rule predicates per vertex (one byte each) on the device CSR; see the kernel.
 hipError_t launch_reduction_flags(const GraphDev &g, uint32_t max_degree, uint8_t *flags, hipStream_t stream);
 

@@ -978,6 +978,126 @@ __device__ __forceinline__ bool dev_is_twin(const GraphDev &g, uint32_t u, uint3
     return true;
 }
 
+// ---- feature-row codec of the inter-GPU exchange ----------------------------------------------
+// After the ReLU that ends a stage many of the 16 output columns are zero in every row (dead
+// units; which ones depends on the graph).  The ranks exchange only the live columns: rows are
+// packed to `kp` floats (the live columns in ascending order, zero-padded), shipped, and expanded
+// back to 16 columns with +0.0f in the dead ones — lossless as long as the dead columns really
+// are zero, which the pack kernel verifies on every row it ships (flag).
+
+// bit c of *mask: some row of feat[rows x 16] is non-zero in column c
+__global__ __launch_bounds__(256) void k_live_columns(const float4 *__restrict__ feat, size_t quads, uint32_t *mask) {
+    uint32_t bits = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = feat[i];
+        const uint32_t b = (v.x != 0.0f ? 1u : 0u) | (v.y != 0.0f ? 2u : 0u) | (v.z != 0.0f ? 4u : 0u) |
+                           (v.w != 0.0f ? 8u : 0u);
+        bits |= b << (4 * (i & 3));
+    }
+    for (int off = 32; off; off >>= 1) bits |= __shfl_xor(bits, off);
+    if ((threadIdx.x & 63) == 0 && bits) atomicOr(mask, bits);
+}
+
+// counts[c] += rows of feat[rows x 16] that are non-zero in column c
+__global__ __launch_bounds__(256) void k_column_counts(const float4 *__restrict__ feat, size_t quads,
+                                                       unsigned long long *counts) {
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;   // this lane always sees the same column group (stride % 4 == 0)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = feat[i];
+        c0 += v.x != 0.0f;
+        c1 += v.y != 0.0f;
+        c2 += v.z != 0.0f;
+        c3 += v.w != 0.0f;
+    }
+    for (int off = 32; off >= 4; off >>= 1) {
+        c0 += __shfl_xor(c0, off);
+        c1 += __shfl_xor(c1, off);
+        c2 += __shfl_xor(c2, off);
+        c3 += __shfl_xor(c3, off);
+    }
+    const uint32_t lane = threadIdx.x & 63;
+    if (lane < 4) {
+        if (c0) atomicAdd(&counts[4 * lane + 0], (unsigned long long)c0);
+        if (c1) atomicAdd(&counts[4 * lane + 1], (unsigned long long)c1);
+        if (c2) atomicAdd(&counts[4 * lane + 2], (unsigned long long)c2);
+        if (c3) atomicAdd(&counts[4 * lane + 3], (unsigned long long)c3);
+    }
+}
+
+struct ColumnMap {
+    uint8_t col[16];   // col[j] = j-th live column (j < k)
+};
+
+// dense[(row - row_lo) * kp + j] = feat[row][col[j]] (0 for j >= k), rows [row_lo, row_hi); one thread
+// per packed element.  The first four threads of a row also look at its other columns: a non-zero
+// there goes to the exception list exc (word 0 = count, entries of 4 words {row - row_lo, column,
+// value bits, 0} from word 4 on, room for `cap`) — or, without a list / when it is full, raises flag
+// bit 0 / bit 1 and the caller falls back to full rows.
+__global__ __launch_bounds__(256) void k_pack_rows(const float *__restrict__ feat, uint32_t row_lo, uint32_t row_hi,
+                                                   uint32_t mask, uint32_t k, uint32_t kp, ColumnMap map,
+                                                   float *__restrict__ dense, uint32_t *__restrict__ exc, uint32_t cap,
+                                                   uint32_t *flag) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)(row_hi - row_lo) * kp;
+    uint32_t bad = 0;
+    if (i < total) {
+        const uint32_t rel = (uint32_t)(i / kp), j = (uint32_t)(i % kp);
+        const size_t row = (size_t)row_lo + rel;
+        dense[i] = j < k ? feat[row * 16 + map.col[j]] : 0.0f;
+        if (j < 4) {
+            const float4 v = reinterpret_cast<const float4 *>(feat)[row * 4 + j];
+            const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t c = 4 * j + t;
+                if (f[t] != 0.0f && !(mask >> c & 1u)) {
+                    if (!exc) {
+                        bad |= 1u;
+                    } else {
+                        const uint32_t slot = atomicAdd(&exc[0], 1u);
+                        if (slot < cap) {
+                            reinterpret_cast<uint4 *>(exc)[1 + slot] = make_uint4(rel, c, __float_as_uint(f[t]), 0u);
+                        } else {
+                            bad |= 2u;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    for (int off = 32; off; off >>= 1) bad |= __shfl_xor(bad, off);
+    if (bad && (threadIdx.x & 63) == 0) atomicOr(flag, bad);
+}
+
+// feat[row][c] = dense column ? dense[(row - row_lo) * kp + rank(c)] : +0.0f, rows [row_lo, row_hi);
+// one thread per float4
+__global__ __launch_bounds__(256) void k_unpack_rows(const float *__restrict__ dense, uint32_t row_lo, uint32_t row_hi,
+                                                     uint32_t mask, uint32_t kp, float *__restrict__ feat) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)(row_hi - row_lo) * 4) return;
+    const uint32_t rel = (uint32_t)(i >> 2), q = (uint32_t)(i & 3);
+    const float *src = dense + (size_t)rel * kp;
+    float v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const uint32_t c = 4 * q + t;
+        v[t] = (mask >> c & 1u) ? src[__popc(mask & ((1u << c) - 1u))] : 0.0f;
+    }
+    reinterpret_cast<float4 *>(feat)[((size_t)row_lo + rel) * 4 + q] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// the exception list of the same piece, applied after k_unpack_rows (stream order)
+__global__ __launch_bounds__(256) void k_unpack_exceptions(const uint32_t *__restrict__ exc, uint32_t cap, uint32_t row_lo,
+                                                           uint32_t row_hi, float *__restrict__ feat) {
+    const uint32_t count = min(exc[0], cap);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const uint4 en = reinterpret_cast<const uint4 *>(exc)[1 + i];
+        if (en.x < row_hi - row_lo && en.y < 16u)   // never trust a received index with a store
+            feat[((size_t)row_lo + en.x) * 16 + en.y] = __uint_as_float(en.z);
+    }
+}
+
+
 __global__ __launch_bounds__(256) void k_reduction_flags(GraphDev g, uint32_t max_degree,
                                                          uint8_t *__restrict__ flags) {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1323,6 +1443,57 @@ hipError_t launch_long_stage(const StagePlan &sp, const GraphDev &g, float ws, c
         break;
     default:
         return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t live_columns(const float *feat, size_t rows, uint32_t *mask, hipStream_t stream) {
+    hipError_t rc = hipMemsetAsync(mask, 0, sizeof(uint32_t), stream);
+    if (rc != hipSuccess || rows == 0) return rc;
+    const size_t quads = rows * 4;
+    const unsigned blocks = (unsigned)std::min<size_t>((quads + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_live_columns, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const float4 *>(feat), quads, mask);
+    return hipGetLastError();
+}
+
+hipError_t column_counts(const float *feat, size_t rows, unsigned long long *counts, hipStream_t stream) {
+    hipError_t rc = hipMemsetAsync(counts, 0, 16 * sizeof(unsigned long long), stream);
+    if (rc != hipSuccess || rows == 0) return rc;
+    const size_t quads = rows * 4;
+    const unsigned blocks = (unsigned)std::min<size_t>((quads + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_column_counts, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const float4 *>(feat), quads,
+                       counts);
+    return hipGetLastError();
+}
+
+hipError_t pack_rows(const float *feat, uint32_t row_lo, uint32_t row_hi, uint32_t mask, uint32_t kp, float *dense,
+                     uint32_t *exc, uint32_t cap, uint32_t *flag, hipStream_t stream) {
+    if (exc) {
+        hipError_t rc = hipMemsetAsync(exc, 0, 4 * sizeof(uint32_t), stream);
+        if (rc != hipSuccess) return rc;
+    }
+    if (row_hi <= row_lo) return hipSuccess;
+    ColumnMap map{};
+    uint32_t k = 0;
+    for (uint32_t c = 0; c < 16; ++c)
+        if (mask >> c & 1u) map.col[k++] = (uint8_t)c;
+    if (k > kp || kp < 4 || kp > 16) return hipErrorInvalidValue;
+    const size_t total = (size_t)(row_hi - row_lo) * kp;
+    hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, feat, row_lo, row_hi,
+                       mask, k, kp, map, dense, exc, cap, flag);
+    return hipGetLastError();
+}
+
+hipError_t unpack_rows(const float *dense, const uint32_t *exc, uint32_t cap, uint32_t row_lo, uint32_t row_hi,
+                       uint32_t mask, uint32_t kp, float *feat, hipStream_t stream) {
+    if (row_hi <= row_lo) return hipSuccess;
+    if (kp < 4 || kp > 16 || (uint32_t)__builtin_popcount(mask & 0xFFFFu) > kp) return hipErrorInvalidValue;
+    const size_t total = (size_t)(row_hi - row_lo) * 4;
+    hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dense, row_lo, row_hi,
+                       mask & 0xFFFFu, kp, feat);
+    if (exc && cap) {
+        const unsigned blocks = std::min<unsigned>((cap + 255) / 256, 1024);
+        hipLaunchKernelGGL(k_unpack_exceptions, dim3(blocks), dim3(256), 0, stream, exc, cap, row_lo, row_hi, feat);
     }
     return hipGetLastError();
 }

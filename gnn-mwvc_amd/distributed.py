@@ -13,6 +13,16 @@ There is no reference counterpart (the reference is single-process); the
 arithmetic is `gnn::model::predict` (reference src/gnn_inference.cpp:67-81)
 unchanged.
 
+Compressed exchange: after the ReLU that ends a stage most of the N x 16 feature matrix is
+zero — on the metric graph two columns are non-zero in every row, two in about a tenth of the
+rows, five in a handful of rows and seven in none (which, and how dense, depends on the graph).
+Once a forward has counted the non-zeros per column, later forwards on the same graph ship each
+row as its 4, 8 or 12 densest columns plus a short exception list for non-zeros anywhere else,
+and expand on arrival: a quarter of the bytes on the metric graph.  It stays lossless: the pack
+step routes every non-zero it does not ship densely into the list, flags a list that overflows,
+and a forward whose flag is raised is repeated with full rows
+(`partitioned_forward(..., verify=True)`, the default).
+
 The stage executor is injected: on a GPU it is `Engine.stage_forward_device`
 (HIP kernels); the CPU tests inject a checker-backed one.  This module itself
 never computes a stage and never imports the oracle.
@@ -56,6 +66,59 @@ def partition_bounds(n: int, world: int, rowptr=None, mode: str = "rows") -> Lis
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
+@dataclasses.dataclass(frozen=True)
+class Packing:
+    """How one stage's output rows travel: `mask` = the columns shipped densely (kp floats per row,
+    zero padded), `cap` = exception-list entries per piece for non-zeros in any other column."""
+    mask: int
+    kp: int
+    cap: int
+    bytes_per_row: float   # expected, exceptions included (a full row is 64)
+
+    def piece_words(self, dense_rows: int) -> int:
+        return dense_rows * self.kp + 4 + 4 * self.cap
+
+
+EXC_BYTES = 16   # one exception entry: {row, column, value, pad}
+
+
+def choose_packing(counts: Sequence[int], n: int, pieces: int) -> "Packing | None":
+    """Cheapest of kp = 4, 8, 12 dense columns (+ exceptions for the rest) from the per-column
+    non-zero counts of a stage's N x 16 output; None if nothing beats three quarters of a full row.
+    `pieces` = how many pieces (ranks x pipeline chunks) the rows travel in, for the list size."""
+    if n <= 0:
+        return None
+    order = sorted(range(16), key=lambda c: (-int(counts[c]), c))
+    best = None
+    for kp in (4, 8, 12):
+        dense = order[:kp]
+        rest = sum(int(counts[c]) for c in order[kp:])
+        cost = 4.0 * kp + EXC_BYTES * rest / n
+        if best is None or cost < best[0]:
+            best = (cost, kp, dense, rest)
+    cost, kp, dense, rest = best
+    if cost > 48.0:
+        return None
+    mask = sum(1 << c for c in dense if counts[c] > 0)
+    cap = int(2 * rest / max(pieces, 1)) + 1024     # twice the expected share of a piece, plus slack
+    return Packing(mask, kp, cap, cost)
+
+
+class RowCodec:
+    """What the compressed exchange needs from the device side (gnn_mwvc_amd.EngineRowCodec on a
+    GPU; the CPU tests inject a torch one).  A piece `region` is a flat fp32 tensor of
+    Packing.piece_words(dense_rows) words: dense_rows x kp floats, then the exception list."""
+
+    def column_counts(self, feat: torch.Tensor, n: int) -> List[int]:   # non-zeros per column over rows < n
+        raise NotImplementedError
+
+    def pack(self, feat, lo: int, hi: int, pk: Packing, region, dense_rows: int, flag) -> None:
+        raise NotImplementedError
+
+    def unpack(self, region, dense_rows: int, lo: int, hi: int, pk: Packing, feat) -> None:
+        raise NotImplementedError
+
+
 @dataclasses.dataclass
 class ForwardBuffers:
     """Full-size buffers every rank owns.  Feature buffers have `rows_alloc` rows;
@@ -65,6 +128,10 @@ class ForwardBuffers:
     feat: List[torch.Tensor]   # two (rows_alloc, 16) fp32 ping-pong buffers
     scores: torch.Tensor       # (rows_alloc,) fp32
     logits: torch.Tensor       # (rows_alloc,) fp32
+    # compressed exchange
+    packed: "torch.Tensor | None" = None       # flat fp32 staging for the pieces (grown on demand)
+    flag: "torch.Tensor | None" = None         # int32[1]: a pack step could not ship a row losslessly
+    live: "dict[int, Packing | None]" = dataclasses.field(default_factory=dict)   # stage -> packing of its output (None = full rows)
 
     @staticmethod
     def allocate(n: int, bounds: Sequence[Tuple[int, int]], device) -> "ForwardBuffers":
@@ -73,6 +140,18 @@ class ForwardBuffers:
         rows = (world * equal if equal else n) + ALIGN
         z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=device)
         return ForwardBuffers(n, rows, [z(rows, 16), z(rows, 16)], z(rows), z(rows))
+
+    def staging(self, words: int) -> torch.Tensor:
+        dev = self.feat[0].device
+        if self.flag is None:
+            self.flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        if self.packed is None or self.packed.numel() < words:
+            self.packed = torch.zeros(words, dtype=torch.float32, device=dev)
+        return self.packed
+
+    def forget_live_columns(self) -> None:
+        """Call when the graph (or the input) behind these buffers changes."""
+        self.live.clear()
 
 
 def _equal_shard_rows(n: int, bounds: Sequence[Tuple[int, int]]) -> int:
@@ -90,6 +169,8 @@ def _equal_shard_rows(n: int, bounds: Sequence[Tuple[int, int]]) -> int:
 def exchange_rows(buf: torch.Tensor, bounds: Sequence[Tuple[int, int]], rank: int, n: int,
                   group=None, method: str = "auto") -> None:
     """Make rows [lo_r, hi_r) written by each rank r visible on every rank, in place.
+    `buf` is indexed by row along dim 0 (a (rows, 16) feature buffer, a (rows,) score vector or a
+    (rows, kp) view of the packed buffer).
 
     "allgather": equal shards -> one in-place all_gather_into_tensor (RCCL picks the
                  xGMI schedule).
@@ -154,6 +235,79 @@ def exchange_rows_pipelined(stage_fn, stage: int, src: torch.Tensor, dst: torch.
         w.wait()
 
 
+def exchange_rows_packed(codec: RowCodec, bufs: ForwardBuffers, dst: torch.Tensor, pk: Packing,
+                         bounds: Sequence[Tuple[int, int]], rank: int, group=None, method: str = "auto") -> None:
+    """exchange_rows for a feature buffer that travels as `pk`: pack this rank's rows into its
+    region, exchange the regions, expand every peer's region into `dst`."""
+    world = len(bounds)
+    if world == 1:
+        return
+    per = _equal_shard_rows(bufs.n, bounds)
+    if method == "auto":
+        method = "allgather" if per else "p2p"
+    lo, hi = bounds[rank]
+    if method == "allgather":
+        if not per:
+            raise ValueError("all_gather_into_tensor needs the equal-rows partition")
+        rows = [per] * world                      # every region the same size (the last shard may be short)
+    else:
+        rows = [phi - plo for plo, phi in bounds]
+    words = [pk.piece_words(r) for r in rows]
+    start = [sum(words[:r]) for r in range(world + 1)]
+    buf = bufs.staging(start[-1])
+    region = lambda r: buf[start[r]: start[r + 1]]
+    codec.pack(dst, lo, hi, pk, region(rank), rows[rank], bufs.flag)
+    if method == "allgather":
+        dist.all_gather_into_tensor(buf[: start[-1]], region(rank), group=group)
+    else:
+        ops = []
+        for peer in range(world):
+            if peer != rank:
+                ops.append(dist.P2POp(dist.isend, region(rank), peer, group))
+                ops.append(dist.P2POp(dist.irecv, region(peer), peer, group))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    for peer, (plo, phi) in enumerate(bounds):
+        if peer != rank and phi > plo:
+            codec.unpack(region(peer), rows[peer], plo, phi, pk, dst)
+
+
+def exchange_rows_pipelined_packed(codec: RowCodec, stage_fn, stage: int, src: torch.Tensor, dst: torch.Tensor,
+                                   bufs: ForwardBuffers, pk: Packing, bounds: Sequence[Tuple[int, int]], rank: int,
+                                   chunks: int, group=None) -> None:
+    """exchange_rows_pipelined with packed rows: piece k is computed, packed and its all-gather
+    started; while it travels, piece k - 1 is waited for and expanded and piece k + 1 computed."""
+    world = len(bounds)
+    per = _equal_shard_rows(bufs.n, bounds)
+    lo, hi = bounds[rank]
+    step = max(ALIGN, (per // max(chunks, 1) + ALIGN - 1) // ALIGN * ALIGN)
+    pw = pk.piece_words(step)
+    n_pieces = (per + step - 1) // step
+    buf = bufs.staging(n_pieces * world * pw)      # [piece][rank][pw]: one contiguous gather per piece
+
+    def finish(work, k, off, size):
+        work.wait()
+        for peer, (plo, phi) in enumerate(bounds):
+            r0, r1 = min(plo + off, phi), min(plo + off + size, phi)
+            if peer != rank and r1 > r0:
+                codec.unpack(buf[(k * world + peer) * pw: (k * world + peer + 1) * pw], step, r0, r1, pk, dst)
+
+    pending = None
+    for k, off in enumerate(range(0, per, step)):
+        size = min(step, per - off)
+        r0, r1 = min(lo + off, hi), min(lo + off + size, hi)
+        if r1 > r0:
+            stage_fn(stage, r0, r1, src, dst, None)
+        mine = buf[(k * world + rank) * pw: (k * world + rank + 1) * pw]
+        codec.pack(dst, r0, r1, pk, mine, step, bufs.flag)       # an empty range still clears the list header
+        work = dist.all_gather_into_tensor(buf[k * world * pw: (k + 1) * world * pw], mine, group=group, async_op=True)
+        if pending is not None:
+            finish(*pending)
+        pending = (work, k, off, size)
+    if pending is not None:
+        finish(*pending)
+
+
 StageFn = Callable[[int, int, int, torch.Tensor, torch.Tensor, "torch.Tensor | None"], None]
 
 
@@ -177,6 +331,16 @@ def replicated_stages(world: int, num_stages: int = 3) -> "set[int]":
     return set()
 
 
+def plan_replication(world: int, num_stages: int, live: "dict | None" = None) -> "set[int]":
+    """replicated_stages(), revised once the packings are known: when every exchanged stage travels
+    in about half the bytes of full rows or less, the gathers are cheaper than any replicated
+    compute, and every stage is partitioned."""
+    if live is not None and all(live.get(st) is not None and live[st].bytes_per_row <= 34.0
+                                for st in range(num_stages - 1)):
+        return set()
+    return replicated_stages(world, num_stages)
+
+
 def replicate_first_stage(world: int) -> bool:   # kept for callers that only ask about stage 0
     return 0 in replicated_stages(world)
 
@@ -186,7 +350,9 @@ def partitioned_forward(stage_fn: StageFn, num_stages: int, x: torch.Tensor, buf
                         exchange: str = "auto", on_stage=None, gather_logits: bool = True,
                         replicate_stage0: "bool | None" = None,
                         pipeline_chunks: int = 0,
-                        replicate: "set[int] | None" = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                        replicate: "set[int] | None" = None,
+                        codec: "RowCodec | None" = None,
+                        verify: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
     """Run every fused stage on this rank's rows and exchange between stages.
 
     stage_fn(stage, lo, hi, src, dst, logits_or_None) computes rows [lo, hi) of `dst`
@@ -198,12 +364,17 @@ def partitioned_forward(stage_fn: StageFn, num_stages: int, x: torch.Tensor, buf
     (exchange_rows_pipelined; equal-rows partition only).
     on_stage(stage, phase) is an optional hook ("begin" | "computed" | "exchanged")
     used by the bench to drop timing events on the stream.
+    codec: enables the compressed exchange.  The first forward on a graph exchanges full rows and
+    settles each stage's Packing in bufs.live from its per-column non-zero counts; later forwards
+    ship packed rows.  With verify=True (default) the forward ends with exchange_verified(): if any
+    rank's exception list overflowed, every rank goes back to full rows and the forward is repeated.  Callers that pass verify=False (a timed loop) must call
+    exchange_verified() themselves before trusting the results.
     """
     world = len(bounds)
     lo, hi = bounds[rank]
     if replicate is None:
-        replicate = replicated_stages(world, num_stages) if replicate_stage0 is None else \
-            ({0} if replicate_stage0 and num_stages > 1 else set())
+        replicate = plan_replication(world, num_stages, bufs.live if codec is not None else None) \
+            if replicate_stage0 is None else ({0} if replicate_stage0 and num_stages > 1 else set())
     # a stage can only be computed in full if its input is complete everywhere
     rep, ok = set(), True
     for st in range(num_stages - 1):
@@ -211,6 +382,8 @@ def partitioned_forward(stage_fn: StageFn, num_stages: int, x: torch.Tensor, buf
         if ok:
             rep.add(st)
     can_pipeline = pipeline_chunks > 1 and world > 1 and _equal_shard_rows(bufs.n, bounds) > 0
+    used_codec = False
+    pieces = world * (max(pipeline_chunks, 1) if can_pipeline else 1)
     src = x
     for st in range(num_stages):
         last = st == num_stages - 1
@@ -221,19 +394,60 @@ def partitioned_forward(stage_fn: StageFn, num_stages: int, x: torch.Tensor, buf
             stage_fn(st, 0, bufs.n, src, dst, None)       # every row, no exchange
             if on_stage:
                 on_stage(st, "computed")
-        elif can_pipeline and not last:
-            exchange_rows_pipelined(stage_fn, st, src, dst, None, bounds, rank, bufs.n,
-                                    pipeline_chunks, group)
-            if on_stage:
-                on_stage(st, "computed")
+            if codec is not None and world > 1 and st not in bufs.live:
+                bufs.live[st] = choose_packing(codec.column_counts(dst, bufs.n), bufs.n, pieces)
+        elif not last:
+            pk = bufs.live.get(st) if (codec is not None and world > 1) else None
+            pack = pk is not None
+            used_codec = used_codec or pack
+            if can_pipeline:
+                if pack:
+                    exchange_rows_pipelined_packed(codec, stage_fn, st, src, dst, bufs, pk, bounds, rank,
+                                                   pipeline_chunks, group)
+                else:
+                    exchange_rows_pipelined(stage_fn, st, src, dst, None, bounds, rank, bufs.n,
+                                            pipeline_chunks, group)
+                if on_stage:
+                    on_stage(st, "computed")
+            else:
+                stage_fn(st, lo, hi, src, dst, None)
+                if on_stage:
+                    on_stage(st, "computed")
+                if pack:
+                    exchange_rows_packed(codec, bufs, dst, pk, bounds, rank, group, exchange)
+                else:
+                    exchange_rows(dst, bounds, rank, bufs.n, group, exchange)
+            if codec is not None and world > 1 and st not in bufs.live:
+                # every rank now holds the complete, identical dst: count its non-zeros per column
+                # (synchronises; first forward on a graph only) and settle how it travels from now on
+                bufs.live[st] = choose_packing(codec.column_counts(dst, bufs.n), bufs.n, pieces)
         else:
-            stage_fn(st, lo, hi, src, dst, bufs.logits if last else None)
+            stage_fn(st, lo, hi, src, dst, bufs.logits)
             if on_stage:
                 on_stage(st, "computed")
             exchange_rows(dst, bounds, rank, bufs.n, group, exchange)
-            if last and gather_logits:   # the exact-parity route applies the host sigmoid to the logits
+            if gather_logits:   # the exact-parity route applies the host sigmoid to the logits
                 exchange_rows(bufs.logits, bounds, rank, bufs.n, group, exchange)
         if on_stage:
             on_stage(st, "exchanged")
         src = dst
+    if used_codec and verify and not exchange_verified(bufs, group):
+        return partitioned_forward(stage_fn, num_stages, x, bufs, bounds, rank, group, exchange, on_stage,
+                                   gather_logits, replicate_stage0, pipeline_chunks, replicate, codec, verify)
     return bufs.scores[: bufs.n], bufs.logits[: bufs.n]
+
+
+def exchange_verified(bufs: ForwardBuffers, group=None) -> bool:
+    """True if every pack step since the last call shipped its rows losslessly.  Otherwise every rank
+    (they all see the same reduced flag) stops packing for these buffers — full rows from now on —
+    and the caller repeats the forward."""
+    if bufs.flag is None:
+        return True
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(bufs.flag, op=dist.ReduceOp.MAX, group=group)
+    if int(bufs.flag.item()) == 0:
+        return True
+    bufs.flag.zero_()
+    for st in list(bufs.live):
+        bufs.live[st] = None
+    return False

@@ -22,7 +22,8 @@ ABI_SYMBOLS = [
     "gnnvc_in_width", "gnnvc_out_width", "gnnvc_upload_graph", "gnnvc_attach_graph_device",
     "gnnvc_graph_staging", "gnnvc_staged_columns_ready", "gnnvc_commit_staged_graph",
     "gnnvc_forward", "gnnvc_forward_device", "gnnvc_num_stages", "gnnvc_stage_widths",
-    "gnnvc_stage_forward_device", "gnnvc_reduction_flags", "gnnvc_synchronize", "gnnvc_last_forward_ms",
+    "gnnvc_stage_forward_device", "gnnvc_live_columns", "gnnvc_column_counts", "gnnvc_pack_rows", "gnnvc_unpack_rows",
+    "gnnvc_reduction_flags", "gnnvc_synchronize", "gnnvc_last_forward_ms",
     "gnnvc_graph_layer_forward", "gnnvc_linear_forward", "gnnvc_relu_forward",
     "gnnvc_sigmoid_forward", "gnnvc_sgemm",
 ]
@@ -95,6 +96,10 @@ def load_library():
     L.gnnvc_forward_device.argtypes = [vp, f32p, f32p, f32p]
     L.gnnvc_stage_forward_device.argtypes = [vp, C.c_int, u32, u32, f32p, f32p, f32p]
     L.gnnvc_reduction_flags.argtypes = [vp, u32, vp]
+    L.gnnvc_live_columns.argtypes = [vp, f32p, u32, u32, C.POINTER(u32)]
+    L.gnnvc_column_counts.argtypes = [vp, f32p, u32, u32, vp]
+    L.gnnvc_pack_rows.argtypes = [vp, f32p, u32, u32, u32, u32, u32, f32p, vp, u32, vp]
+    L.gnnvc_unpack_rows.argtypes = [vp, f32p, vp, u32, u32, u32, u32, u32, u32, f32p]
     L.gnnvc_last_forward_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
     L.gnnvc_graph_layer_forward.argtypes = [vp, u32, f32p, f32p]
     L.gnnvc_linear_forward.argtypes = [vp, u32, u32, u32, f32p, f32p, f32p, f32p]
@@ -249,6 +254,27 @@ class Engine:
         self._check(self._L.gnnvc_stage_forward_device(self._h, stage, row_lo, row_hi, in_ptr,
                                                        out_ptr, logits_ptr or None))
 
+    # -- feature-row codec of the inter-GPU exchange (device pointers)
+    def live_columns(self, feat_ptr: int, rows: int, width: int = 16) -> int:
+        m = C.c_uint32(0)
+        self._check(self._L.gnnvc_live_columns(self._h, feat_ptr, rows, width, C.byref(m)))
+        return int(m.value)
+
+    def column_counts(self, feat_ptr: int, rows: int, width: int = 16) -> np.ndarray:
+        counts = np.zeros(16, dtype=np.uint64)
+        self._check(self._L.gnnvc_column_counts(self._h, feat_ptr, rows, width, _np_ptr(counts)))
+        return counts
+
+    def pack_rows(self, feat_ptr: int, row_lo: int, row_hi: int, mask: int, kp: int, dense_ptr: int,
+                  flag_ptr: int, exc_ptr: int = 0, exc_cap: int = 0, width: int = 16):
+        self._check(self._L.gnnvc_pack_rows(self._h, feat_ptr, width, row_lo, row_hi, mask, kp, dense_ptr,
+                                            exc_ptr or None, exc_cap, flag_ptr))
+
+    def unpack_rows(self, dense_ptr: int, row_lo: int, row_hi: int, mask: int, kp: int, feat_ptr: int,
+                    exc_ptr: int = 0, exc_cap: int = 0, width: int = 16):
+        self._check(self._L.gnnvc_unpack_rows(self._h, dense_ptr, exc_ptr or None, exc_cap, width, row_lo, row_hi,
+                                              mask, kp, feat_ptr))
+
     def reduction_flags(self, max_degree: int = 20) -> np.ndarray:
         flags = np.zeros(self.n, dtype=np.uint8)
         self._check(self._L.gnnvc_reduction_flags(self._h, max_degree, _np_ptr(flags)))
@@ -306,3 +332,25 @@ class Engine:
                                         A.shape[1], _np_ptr(B), B.shape[1], C.c_float(beta),
                                         _np_ptr(out), n))
         return out
+
+
+class EngineRowCodec:
+    """distributed.RowCodec served by the engine's HIP kernels (tensors are device tensors).
+    A piece region is a flat fp32 tensor: dense_rows x kp floats, then the exception list
+    (4 + 4 * cap 32-bit words)."""
+
+    def __init__(self, engine: "Engine"):
+        self.e = engine
+
+    def column_counts(self, feat, n: int):
+        return [int(v) for v in self.e.column_counts(feat.data_ptr(), n, feat.shape[1])]
+
+    def pack(self, feat, lo: int, hi: int, pk, region, dense_rows: int, flag) -> None:
+        base = region.data_ptr()
+        self.e.pack_rows(feat.data_ptr(), lo, hi, pk.mask, pk.kp, base, flag.data_ptr(),
+                         base + 4 * dense_rows * pk.kp, pk.cap, feat.shape[1])
+
+    def unpack(self, region, dense_rows: int, lo: int, hi: int, pk, feat) -> None:
+        base = region.data_ptr()
+        self.e.unpack_rows(base, lo, hi, pk.mask, pk.kp, feat.data_ptr(), base + 4 * dense_rows * pk.kp, pk.cap,
+                           feat.shape[1])

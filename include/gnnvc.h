@@ -158,6 +158,30 @@ int gnnvc_stage_widths(const gnnvc_engine *e, int stage, int *in_width, int *out
 int gnnvc_stage_forward_device(gnnvc_engine *e, int stage, uint32_t row_lo, uint32_t row_hi,
                                const float *d_in, float *d_out, float *d_logits);
 
+/* ---- feature-row codec for the exchange between vertex-partitioned GPUs --------
+ * No reference counterpart (the reference is single-process).  After the ReLU that ends a fused
+ * stage most entries of the N x 16 feature matrix are zero: on the metric graph two columns are
+ * non-zero in every row, two in about a tenth of the rows, five in a handful of rows and seven in
+ * none (which columns, and how dense, depends on the graph).  A piece of rows [row_lo, row_hi)
+ * travels as
+ *   d_dense  (row_hi - row_lo) x kp floats: the columns of `mask` in ascending order, zero padded
+ *            (kp = 4, 8 or 12), and
+ *   d_exc    an exception list for non-zeros in any other column: word 0 = count, then entries of
+ *            four words {row - row_lo, column, value bits, 0} from word 4 on, room for exc_cap
+ *            entries (4 + 4 * exc_cap words); may be NULL.
+ * gnnvc_unpack_rows rebuilds the 16-float rows, writing +0.0f where nothing was shipped — exactly
+ * the rows a full exchange would have delivered.  gnnvc_pack_rows ORs into *d_flag: bit 0 if a
+ * non-zero fell outside `mask` and there was no list, bit 1 if the list overflowed; the caller then
+ * falls back to full rows.  gnnvc_column_counts gives the per-column non-zero counts from which
+ * the caller chooses mask, kp and exc_cap (synchronous); the other calls are asynchronous on the
+ * engine's stream.  All pointers are device memory. */
+int gnnvc_live_columns(gnnvc_engine *e, const float *d_feat, uint32_t rows, uint32_t width, uint32_t *mask);
+int gnnvc_column_counts(gnnvc_engine *e, const float *d_feat, uint32_t rows, uint32_t width, uint64_t *counts /*[16]*/);
+int gnnvc_pack_rows(gnnvc_engine *e, const float *d_feat, uint32_t width, uint32_t row_lo, uint32_t row_hi,
+                    uint32_t mask, uint32_t kp, float *d_dense, uint32_t *d_exc, uint32_t exc_cap, uint32_t *d_flag);
+int gnnvc_unpack_rows(gnnvc_engine *e, const float *d_dense, const uint32_t *d_exc, uint32_t exc_cap, uint32_t width,
+                      uint32_t row_lo, uint32_t row_hi, uint32_t mask, uint32_t kp, float *d_feat);
+
 /* ---- reduction-rule candidates ------------------------------------
  * One vertex-parallel pass over the uploaded graph that evaluates which local rules of the
  * reference's reduce_graph (include/mwvc_reductions.hpp:335-380) would fire on each vertex as

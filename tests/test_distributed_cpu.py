@@ -49,6 +49,144 @@ def _oracle_stage_fn(g, text):
     return stage_fn
 
 
+class TorchRowCodec(D.RowCodec):
+    """CPU stand-in (tests only) for gnn_mwvc_amd.EngineRowCodec: same contract, torch indexing."""
+
+    @staticmethod
+    def _split(region, dense_rows, pk):
+        dense = region[: dense_rows * pk.kp].view(dense_rows, pk.kp)
+        exc = region[dense_rows * pk.kp: pk.piece_words(dense_rows)].view(torch.int32)
+        return dense, exc
+
+    def column_counts(self, feat, n):
+        return [int((feat[:n, c] != 0).sum()) for c in range(16)]
+
+    def pack(self, feat, lo, hi, pk, region, dense_rows, flag):
+        dense, exc = self._split(region, dense_rows, pk)
+        cols = [c for c in range(16) if pk.mask >> c & 1]
+        other = [c for c in range(16) if not pk.mask >> c & 1]
+        exc[:4] = 0
+        rows = hi - lo
+        if rows <= 0:
+            return
+        dense[:rows] = 0
+        if cols:
+            dense[:rows, : len(cols)] = feat[lo:hi][:, cols]
+        if other:
+            sub = feat[lo:hi][:, other].contiguous()
+            nz = (sub != 0).nonzero()
+            exc[0] = len(nz)
+            m = min(len(nz), pk.cap)
+            if m:
+                en = exc[4: 4 + 4 * pk.cap].view(-1, 4)
+                en[:m, 0] = nz[:m, 0].to(torch.int32)
+                en[:m, 1] = torch.tensor(other, dtype=torch.int32)[nz[:m, 1]]
+                en[:m, 2] = sub[nz[:m, 0], nz[:m, 1]].view(torch.int32)
+                en[:m, 3] = 0
+            if len(nz) > pk.cap:
+                flag |= 2
+
+    def unpack(self, region, dense_rows, lo, hi, pk, feat):
+        dense, exc = self._split(region, dense_rows, pk)
+        cols = [c for c in range(16) if pk.mask >> c & 1]
+        rows = hi - lo
+        feat[lo:hi] = 0
+        if cols:
+            feat[lo:hi, cols] = dense[:rows, : len(cols)]
+        m = min(int(exc[0]), pk.cap)
+        en = exc[4: 4 + 4 * pk.cap].view(-1, 4)[:m]
+        for rel, col, bits_, _ in en.tolist():
+            if rel < rows and col < 16:
+                feat[lo + rel, col] = torch.tensor([bits_], dtype=torch.int32).view(torch.float32)[0]
+
+
+def _codec_worker(rank, world, port, mode, graph_args, chunks, tamper, q):
+    """Two forwards with the compressed exchange: the first settles the packings, the second packs."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import dataclasses
+        import pathlib
+        text = (pathlib.Path(__file__).resolve().parent.parent / "gnn-mwvc_amd" / "data" /
+                "mwvc_model.txt").read_text()
+        g = gg.hub_graph(*graph_args) if len(graph_args) == 5 else gg.erdos_renyi(*graph_args)
+        bounds = D.partition_bounds(g.n, world, g.rowptr, mode)
+        bufs = D.ForwardBuffers.allocate(g.n, bounds, "cpu")
+        x = torch.from_numpy(g.x())
+        fn = _oracle_stage_fn(g, text)
+        codec = TorchRowCodec()
+        kw = dict(replicate=set(), pipeline_chunks=chunks, codec=codec)
+        D.partitioned_forward(fn, 3, x, bufs, bounds, rank, **kw)
+        learned = dict(bufs.live)
+        if tamper and learned[0] is not None:
+            # drop the densest column from the dense set: its values must now travel as exceptions ...
+            pk = learned[0]
+            victim = next(c for c in range(16) if pk.mask >> c & 1)
+            big = bufs.n * 16
+            bufs.live[0] = dataclasses.replace(pk, mask=pk.mask & ~(1 << victim), cap=big if tamper == "list" else 3)
+            # ... and with room for only 3 of them the pack step must raise the flag instead
+        for f in bufs.feat:           # stale rows must not be able to pass for exchanged ones
+            f[: g.n] = 7.0
+        scores, logits = D.partitioned_forward(fn, 3, x, bufs, bounds, rank, **kw)
+        pad_ok = all(float(f[g.n:].abs().sum()) == 0.0 for f in bufs.feat)
+        q.put((rank, scores.numpy().copy(), logits.numpy().copy(), learned, dict(bufs.live), pad_ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode,graph_args,chunks,tamper", [
+    (2, "rows", (3000, 30000, 4), 0, ""),
+    (2, "rows", (3000, 30000, 4), 3, ""),                 # pipelined pieces, packed
+    (3, "nnz", (5000, 20000, 2, 1500, 9), 0, ""),         # uneven shards: packed rows by direct sends
+    (2, "rows", (3000, 30000, 4), 0, "list"),             # a dense column demoted: carried by the exception list
+    (3, "rows", (3000, 30000, 4), 2, "list"),
+    (2, "rows", (3000, 30000, 4), 0, "overflow"),         # list too short -> flagged, forward repeated in full
+    (2, "rows", (3000, 30000, 4), 2, "overflow"),
+])
+def test_compressed_exchange_is_lossless(world, mode, graph_args, chunks, tamper, oracle_model):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_codec_worker, args=(r, world, port, mode, graph_args, chunks, tamper, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = gg.hub_graph(*graph_args) if len(graph_args) == 5 else gg.erdos_renyi(*graph_args)
+    oracle_model.set_weight_scale(g.ws)
+    want_s, want_l = oracle_model.scores(g), oracle_model.logits(g)
+    assert all(r[3] == results[0][3] for r in results)       # every rank settled on the same packings
+    learned = results[0][3]
+    assert set(learned) == {0, 1}
+    assert any(pk is not None for pk in learned.values()), learned   # something was actually packed
+    for rank, s, l, _, live_after, pad_ok in results:
+        assert pad_ok
+        assert np.array_equal(s.view(np.uint32), want_s.view(np.uint32)), f"rank {rank}"
+        assert np.array_equal(l.view(np.uint32), want_l.view(np.uint32)), f"rank {rank}"
+        if tamper == "overflow":
+            assert all(pk is None for pk in live_after.values())   # packing switched off after the hit
+        elif not tamper:
+            assert live_after == learned
+
+
+def test_choose_packing():
+    n = 1000
+    full = [n] * 16
+    assert D.choose_packing(full, n, 4) is None                       # nothing to gain
+    pk = D.choose_packing([n, 70, 0, 130, 0, 1, 0, 0, 1, 0, 1, n, 0, 0, 0, 0], n, 8)   # the metric graph's stage 0
+    assert pk.kp == 4 and pk.mask == (1 << 0 | 1 << 1 | 1 << 3 | 1 << 11) and pk.cap >= 1024
+    assert 16.0 <= pk.bytes_per_row < 16.1
+    pk = D.choose_packing([n] * 6 + [n // 10] * 2 + [0] * 8, n, 2)    # 6 dense + 2 sparse: 8 dense slots, no exceptions
+    assert pk.kp == 8 and bin(pk.mask).count("1") == 8 and pk.bytes_per_row == 32.0
+    pk = D.choose_packing([0] * 16, n, 2)
+    assert pk.kp == 4 and pk.mask == 0
+    assert D.choose_packing([5] * 16, 0, 2) is None
+
+
 def _worker(rank, world, port, mode, exchange, graph_args, q, replicate=None, chunks=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

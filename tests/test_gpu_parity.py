@@ -560,6 +560,92 @@ def test_sorted_tiles_auto_decision(model_text):
         e.close()
 
 
+# ---------------------------------------------------------------- feature-row codec of the exchange
+
+@pytest.mark.parametrize("mask,cap", [(0x0000, 64), (0x080B, 64), (0x0001, 0), (0x8000, 4096), (0x0FF0, 64),
+                                      (0x0FFF, 64), (0x0555, 64)])
+def test_row_codec_round_trip(engine, mask, cap):
+    """gnnvc_column_counts / gnnvc_pack_rows / gnnvc_unpack_rows against numpy: dense columns plus the
+    exception list restore every row exactly; an overflowing list (or none) is flagged."""
+    import torch
+    import gnn_mwvc_amd as G
+    from gnn_mwvc_amd import distributed as D
+    dev = torch.device("cuda:0")
+    rows, lo, hi = 1000, 130, 901
+    rng = np.random.default_rng(mask)
+    a = rng.normal(size=(rows, 16)).astype(np.float32)
+    a[rng.random(a.shape) < 0.3] = 0.0
+    a[5, 3] = -0.0                                                # a negative zero is a zero
+    live = [c for c in range(16) if mask >> c & 1]
+    dead = [c for c in range(16) if not mask >> c & 1]
+    a[:, dead] = 0.0
+    stray = []                                                    # a few non-zeros outside the dense columns
+    if dead and cap:
+        for i, r in enumerate(range(lo + 3, hi, 97)):
+            c = dead[i % len(dead)]
+            a[r, c] = 1.5 + i
+            stray.append((r, c))
+    kp = max(4, (len(live) + 3) // 4 * 4)
+    pk = D.Packing(mask, kp, cap, 0.0)
+    feat = torch.from_numpy(a).to(dev)
+    assert engine.live_columns(feat.data_ptr(), rows) == sum(1 << c for c in range(16) if np.any(a[:, c] != 0))
+    assert [int(v) for v in engine.column_counts(feat.data_ptr(), rows)] == [int((a[:, c] != 0).sum()) for c in range(16)]
+    dense_rows = hi - lo + 5                                      # the dense part may be longer than the piece
+    region = torch.full((pk.piece_words(dense_rows),), 9.0, dtype=torch.float32, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    codec = G.EngineRowCodec(engine)
+    codec.pack(feat, lo, hi, pk, region, dense_rows, flag)
+    engine.synchronize()
+    assert int(flag.item()) == 0
+    p = region.cpu().numpy()
+    d = p[: dense_rows * kp].reshape(dense_rows, kp)
+    assert np.array_equal(bits(d[: hi - lo, : len(live)]), bits(a[lo:hi][:, live]))
+    assert np.all(d[: hi - lo, len(live):] == 0) and np.all(d[hi - lo:] == 9.0)
+    exc = p[dense_rows * kp:].view(np.uint32)
+    assert exc[0] == len(stray)
+    got = {(int(r) + lo, int(c)): v for r, c, v, _ in exc[4: 4 + 4 * len(stray)].reshape(-1, 4)}
+    assert got == {(r, c): int(a[r, c:c + 1].view(np.uint32)[0]) for r, c in stray}
+    out = torch.full((rows, 16), 5.0, dtype=torch.float32, device=dev)
+    codec.unpack(region, dense_rows, lo, hi, pk, out)
+    engine.synchronize()
+    o = out.cpu().numpy()
+    assert np.array_equal(o[lo:hi] == 0, a[lo:hi] == 0)
+    assert np.array_equal(bits(np.where(o[lo:hi] == 0, 0, o[lo:hi])), bits(np.where(a[lo:hi] == 0, 0, a[lo:hi])))
+    assert not np.signbit(o[lo:hi][o[lo:hi] == 0]).any()          # zeros come back as +0.0f
+    assert np.all(o[:lo] == 5.0) and np.all(o[hi:] == 5.0)
+    if dead:
+        # one more stray than the list holds: bit 1; no list at all: bit 0
+        extra = [(r, dead[0]) for r in range(lo, hi) if a[r, dead[0]] == 0][: max(cap - len(stray), 0) + 1]
+        for r, c in extra:
+            feat[r, c] = 1e-30
+        codec.pack(feat, lo, hi, pk, region, dense_rows, flag)
+        engine.synchronize()
+        assert int(flag.item()) == (2 if len(extra) + len(stray) > cap else 0)   # (a 4096-entry list cannot overflow here)
+        flag.zero_()
+        engine.pack_rows(feat.data_ptr(), lo, hi, mask, kp, region.data_ptr(), flag.data_ptr())
+        engine.synchronize()
+        assert int(flag.item()) == 1
+        flag.zero_()
+        for r, c in extra + stray:
+            feat[r, c] = 0.0
+        feat[hi, dead[0]] = 3.0                                   # outside the shipped rows: not this call's business
+        engine.pack_rows(feat.data_ptr(), lo, hi, mask, kp, region.data_ptr(), flag.data_ptr())
+        engine.synchronize()
+        assert int(flag.item()) == 0
+
+
+def test_row_codec_errors(engine):
+    import gnn_mwvc_amd as G
+    with pytest.raises(G.GnnvcError):
+        engine.pack_rows(1, 0, 10, 0xFFFF, 12, 1, 1)              # 16 dense columns do not fit 12
+    with pytest.raises(G.GnnvcError):
+        engine.unpack_rows(1, 0, 10, 0x1, 5, 1)                   # packed width not a multiple of 4
+    with pytest.raises(G.GnnvcError):
+        engine.pack_rows(1, 0, 10, 0x1, 4, 1, 1, width=8)         # only 16-column rows
+    with pytest.raises(G.GnnvcError):
+        engine.pack_rows(1, 10, 5, 0x1, 4, 1, 1)                  # reversed row range
+
+
 # ---------------------------------------------------------------- reduction-rule predicates (f-2)
 
 def test_reduction_flags_match_oracle(engine):

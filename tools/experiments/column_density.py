@@ -1,0 +1,35 @@
+"""Non-zero density of every feature column after stages 0 and 1 (GPU box): the premise of the
+compressed inter-GPU exchange.  usage: python tools/experiments/column_density.py [workload ...]"""
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+import bench  # noqa: E402
+import gnn_mwvc_amd as G  # noqa: E402
+from tools import graphgen_torch as ggt  # noqa: E402
+
+dev = torch.device("cuda:0")
+for wl in sys.argv[1:] or ["er10m"]:
+    g, desc = bench.build_workload(wl, ggt, dev)
+    e = G.Engine(G.default_model_text(), device=0)
+    e.set_weight_scale(g.ws)
+    e.attach_graph_device(g.n, g.nnz, g.rowptr.data_ptr(), g.col.data_ptr(), g.w.data_ptr(), g.nw.data_ptr(), keepalive=g)
+    x = g.x().contiguous()
+    torch.cuda.synchronize()
+    h = [torch.zeros(g.n + 64, 16, device=dev) for _ in range(2)]
+    src = x
+    print(desc)
+    for st in range(2):
+        e.stage_forward_device(st, 0, g.n, src.data_ptr(), h[st].data_ptr(), 0)
+        e.synchronize()
+        c = e.column_counts(h[st].data_ptr(), g.n)
+        ref = (h[st][: g.n] != 0).sum(0).cpu().numpy()
+        assert (c.astype("int64") == ref).all(), (c, ref)
+        print(f"  stage {st}: live mask {e.live_columns(h[st].data_ptr(), g.n):#06x}  counts " +
+              " ".join(f"{int(v)}" for v in c))
+        print("           density " + " ".join(f"{v / g.n:.4f}" for v in c))
+        src = h[st]
+    e.close()
+    del g, h, x
+    torch.cuda.empty_cache()
