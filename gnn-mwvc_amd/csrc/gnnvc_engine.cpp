@@ -1022,6 +1022,25 @@ int gnnvc_unpack_rows(gnnvc_engine *e, const float *d_dense, const uint32_t *d_e
     return GNNVC_OK;
 }
 
+int gnnvc_unpack_gathered(gnnvc_engine *e, const float *d_buf, uint32_t world, uint32_t skip_rank, uint64_t piece_words,
+                          uint32_t dense_rows, uint32_t exc_cap, uint32_t width, uint32_t rows_per_rank, uint32_t row_off,
+                          uint32_t rows, uint32_t n, uint32_t mask, uint32_t kp, float *d_feat) {
+    if (!e) return GNNVC_ERR_INVALID;
+    int rc = codec_args(e, width, 0, rows, mask, kp);
+    if (rc) return rc;
+    if (!world || !rows) return GNNVC_OK;
+    if (!d_buf || !d_feat) return fail(e, GNNVC_ERR_INVALID, "null device buffers");
+    if (rows > dense_rows || piece_words < (uint64_t)dense_rows * kp + (exc_cap ? 4 + 4ull * exc_cap : 0) ||
+        (uint64_t)row_off + rows > rows_per_rank)
+        return fail(e, GNNVC_ERR_INVALID, "piece geometry: %u rows at offset %u of %u per rank, dense part %u rows, %llu words",
+                    rows, row_off, rows_per_rank, dense_rows, (unsigned long long)piece_words);
+    rc = use_device(e);
+    if (rc) return rc;
+    HIP_TRY(e, gnnvc::unpack_gathered(d_buf, world, skip_rank, (size_t)piece_words, dense_rows, exc_cap, rows_per_rank, row_off,
+                                      rows, n, mask, kp, d_feat, e->stream));
+    return GNNVC_OK;
+}
+
 int gnnvc_synchronize(gnnvc_engine *e) {
     if (!e) return GNNVC_ERR_INVALID;
     int rc = use_device(e);

@@ -98,6 +98,10 @@ hipError_t pack_rows(const float *feat, uint32_t row_lo, uint32_t row_hi, uint32
 hipError_t unpack_rows(const float *dense, const uint32_t *exc, uint32_t cap, uint32_t row_lo, uint32_t row_hi,
                        uint32_t mask, uint32_t kp, float *feat, hipStream_t stream);
 
+hipError_t unpack_gathered(const float *buf, uint32_t world, uint32_t skip, size_t piece_words, uint32_t dense_rows,
+                           uint32_t cap, uint32_t per, uint32_t off, uint32_t size, uint32_t n, uint32_t mask, uint32_t kp,
+                           float *feat, hipStream_t stream);
+
 // Reduction-rule predicates per vertex (one byte each) on the device CSR; see the kernel.
 hipError_t launch_reduction_flags(const GraphDev &g, uint32_t max_degree, uint8_t *flags, hipStream_t stream);
 

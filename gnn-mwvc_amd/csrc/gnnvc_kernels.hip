@@ -1086,6 +1086,49 @@ __global__ __launch_bounds__(256) void k_unpack_rows(const float *__restrict__ d
     reinterpret_cast<float4 *>(feat)[((size_t)row_lo + rel) * 4 + q] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// All peers' regions of one all-gathered piece in one launch: blockIdx.y = rank whose region
+// (buf + rank * piece_words) holds its rows [rank * per + off, rank * per + off + size) cut at the end
+// of its shard and at n; `skip` (this rank, whose rows are already in place) is left alone.
+__global__ __launch_bounds__(256) void k_unpack_gathered(const float *__restrict__ buf, uint32_t skip, size_t piece_words,
+                                                         uint32_t per, uint32_t off, uint32_t size, uint32_t n,
+                                                         uint32_t mask, uint32_t kp, float *__restrict__ feat) {
+    const uint32_t peer = blockIdx.y;
+    if (peer == skip) return;
+    const uint64_t lo64 = (uint64_t)peer * per + off;
+    const uint64_t hi64 = min(min(lo64 + size, (uint64_t)(peer + 1) * per), (uint64_t)n);
+    if (lo64 >= hi64) return;
+    const uint32_t row_lo = (uint32_t)lo64, rows = (uint32_t)(hi64 - lo64);
+    const float *dense = buf + (size_t)peer * piece_words;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)rows * 4; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t rel = (uint32_t)(i >> 2), q = (uint32_t)(i & 3);
+        const float *src = dense + (size_t)rel * kp;
+        float v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t c = 4 * q + t;
+            v[t] = (mask >> c & 1u) ? src[__popc(mask & ((1u << c) - 1u))] : 0.0f;
+        }
+        reinterpret_cast<float4 *>(feat)[((size_t)row_lo + rel) * 4 + q] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_unpack_gathered_exceptions(const float *__restrict__ buf, uint32_t skip,
+                                                                    size_t piece_words, uint32_t dense_rows, uint32_t cap,
+                                                                    uint32_t per, uint32_t off, uint32_t size, uint32_t n,
+                                                                    uint32_t kp, float *__restrict__ feat) {
+    const uint32_t peer = blockIdx.y;
+    if (peer == skip) return;
+    const uint64_t lo64 = (uint64_t)peer * per + off;
+    const uint64_t hi64 = min(min(lo64 + size, (uint64_t)(peer + 1) * per), (uint64_t)n);
+    if (lo64 >= hi64) return;
+    const uint32_t *exc = reinterpret_cast<const uint32_t *>(buf + (size_t)peer * piece_words + (size_t)dense_rows * kp);
+    const uint32_t count = min(exc[0], cap), rows = (uint32_t)(hi64 - lo64);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const uint4 en = reinterpret_cast<const uint4 *>(exc)[1 + i];
+        if (en.x < rows && en.y < 16u) feat[(lo64 + en.x) * 16 + en.y] = __uint_as_float(en.z);
+    }
+}
+
 // the exception list of the same piece, applied after k_unpack_rows (stream order)
 __global__ __launch_bounds__(256) void k_unpack_exceptions(const uint32_t *__restrict__ exc, uint32_t cap, uint32_t row_lo,
                                                            uint32_t row_hi, float *__restrict__ feat) {
@@ -1495,6 +1538,20 @@ hipError_t unpack_rows(const float *dense, const uint32_t *exc, uint32_t cap, ui
         const unsigned blocks = std::min<unsigned>((cap + 255) / 256, 1024);
         hipLaunchKernelGGL(k_unpack_exceptions, dim3(blocks), dim3(256), 0, stream, exc, cap, row_lo, row_hi, feat);
     }
+    return hipGetLastError();
+}
+
+hipError_t unpack_gathered(const float *buf, uint32_t world, uint32_t skip, size_t piece_words, uint32_t dense_rows,
+                           uint32_t cap, uint32_t per, uint32_t off, uint32_t size, uint32_t n, uint32_t mask, uint32_t kp,
+                           float *feat, hipStream_t stream) {
+    if (!world || !size) return hipSuccess;
+    if (kp < 4 || kp > 16 || (uint32_t)__builtin_popcount(mask & 0xFFFFu) > kp || size > dense_rows) return hipErrorInvalidValue;
+    const unsigned bx = (unsigned)std::min<size_t>(((size_t)size * 4 + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_unpack_gathered, dim3(bx, world), dim3(256), 0, stream, buf, skip, piece_words, per, off, size, n,
+                       mask & 0xFFFFu, kp, feat);
+    if (cap)
+        hipLaunchKernelGGL(k_unpack_gathered_exceptions, dim3(std::min<unsigned>((cap + 255) / 256, 64), world), dim3(256), 0,
+                           stream, buf, skip, piece_words, dense_rows, cap, per, off, size, n, kp, feat);
     return hipGetLastError();
 }
 

@@ -267,6 +267,9 @@ def exchange_rows_packed(codec: RowCodec, bufs: ForwardBuffers, dst: torch.Tenso
                 ops.append(dist.P2POp(dist.irecv, region(peer), peer, group))
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+    if method == "allgather" and hasattr(codec, "unpack_gathered"):
+        codec.unpack_gathered(buf[: start[-1]], world, rank, per, per, 0, per, bufs.n, pk, dst)
+        return
     for peer, (plo, phi) in enumerate(bounds):
         if peer != rank and phi > plo:
             codec.unpack(region(peer), rows[peer], plo, phi, pk, dst)
@@ -287,6 +290,10 @@ def exchange_rows_pipelined_packed(codec: RowCodec, stage_fn, stage: int, src: t
 
     def finish(work, k, off, size):
         work.wait()
+        if hasattr(codec, "unpack_gathered"):     # all peers' regions of the piece in one launch
+            codec.unpack_gathered(buf[k * world * pw: (k + 1) * world * pw], world, rank, step, per, off, size, bufs.n,
+                                  pk, dst)
+            return
         for peer, (plo, phi) in enumerate(bounds):
             r0, r1 = min(plo + off, phi), min(plo + off + size, phi)
             if peer != rank and r1 > r0:

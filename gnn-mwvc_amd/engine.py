@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "gnnvc_in_width", "gnnvc_out_width", "gnnvc_upload_graph", "gnnvc_attach_graph_device",
     "gnnvc_graph_staging", "gnnvc_staged_columns_ready", "gnnvc_commit_staged_graph",
     "gnnvc_forward", "gnnvc_forward_device", "gnnvc_num_stages", "gnnvc_stage_widths",
-    "gnnvc_stage_forward_device", "gnnvc_live_columns", "gnnvc_column_counts", "gnnvc_pack_rows", "gnnvc_unpack_rows",
+    "gnnvc_stage_forward_device", "gnnvc_live_columns", "gnnvc_column_counts", "gnnvc_pack_rows", "gnnvc_unpack_rows", "gnnvc_unpack_gathered",
     "gnnvc_reduction_flags", "gnnvc_synchronize", "gnnvc_last_forward_ms",
     "gnnvc_graph_layer_forward", "gnnvc_linear_forward", "gnnvc_relu_forward",
     "gnnvc_sigmoid_forward", "gnnvc_sgemm",
@@ -100,6 +100,7 @@ def load_library():
     L.gnnvc_column_counts.argtypes = [vp, f32p, u32, u32, vp]
     L.gnnvc_pack_rows.argtypes = [vp, f32p, u32, u32, u32, u32, u32, f32p, vp, u32, vp]
     L.gnnvc_unpack_rows.argtypes = [vp, f32p, vp, u32, u32, u32, u32, u32, u32, f32p]
+    L.gnnvc_unpack_gathered.argtypes = [vp, f32p, u32, u32, u64, u32, u32, u32, u32, u32, u32, u32, u32, u32, f32p]
     L.gnnvc_last_forward_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
     L.gnnvc_graph_layer_forward.argtypes = [vp, u32, f32p, f32p]
     L.gnnvc_linear_forward.argtypes = [vp, u32, u32, u32, f32p, f32p, f32p, f32p]
@@ -354,3 +355,10 @@ class EngineRowCodec:
         base = region.data_ptr()
         self.e.unpack_rows(base, lo, hi, pk.mask, pk.kp, feat.data_ptr(), base + 4 * dense_rows * pk.kp, pk.cap,
                            feat.shape[1])
+
+    def unpack_gathered(self, buf, world: int, skip_rank: int, dense_rows: int, per: int, off: int, size: int, n: int,
+                        pk, feat) -> None:
+        """Every peer's region of one all-gathered piece ([rank][piece_words] in `buf`) in one launch."""
+        e = self.e
+        e._check(e._L.gnnvc_unpack_gathered(e._h, buf.data_ptr(), world, skip_rank, pk.piece_words(dense_rows), dense_rows,
+                                            pk.cap, feat.shape[1], per, off, size, n, pk.mask, pk.kp, feat.data_ptr()))

@@ -182,6 +182,14 @@ int gnnvc_pack_rows(gnnvc_engine *e, const float *d_feat, uint32_t width, uint32
 int gnnvc_unpack_rows(gnnvc_engine *e, const float *d_dense, const uint32_t *d_exc, uint32_t exc_cap, uint32_t width,
                       uint32_t row_lo, uint32_t row_hi, uint32_t mask, uint32_t kp, float *d_feat);
 
+/* One all-gathered piece, every peer's region in one launch: d_buf holds `world` regions of
+ * piece_words words (dense part of dense_rows rows, then the exception list), region r carrying rows
+ * [r * rows_per_rank + row_off, + rows) of rank r (cut at the end of its shard and at n);
+ * skip_rank's region (the caller's own rows, already in place) is left alone. */
+int gnnvc_unpack_gathered(gnnvc_engine *e, const float *d_buf, uint32_t world, uint32_t skip_rank, uint64_t piece_words,
+                          uint32_t dense_rows, uint32_t exc_cap, uint32_t width, uint32_t rows_per_rank, uint32_t row_off,
+                          uint32_t rows, uint32_t n, uint32_t mask, uint32_t kp, float *d_feat);
+
 /* ---- reduction-rule candidates ------------------------------------
  * One vertex-parallel pass over the uploaded graph that evaluates which local rules of the
  * reference's reduce_graph (include/mwvc_reductions.hpp:335-380) would fire on each vertex as

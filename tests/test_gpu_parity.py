@@ -634,6 +634,49 @@ def test_row_codec_round_trip(engine, mask, cap):
         assert int(flag.item()) == 0
 
 
+@pytest.mark.parametrize("world,n,off,size", [(4, 1000, 0, 256), (4, 1000, 64, 128), (3, 700, 192, 64), (2, 130, 0, 128)])
+def test_row_codec_unpack_gathered(engine, world, n, off, size):
+    """gnnvc_unpack_gathered (all peers of an all-gathered piece in one launch) == per-peer gnnvc_unpack_rows."""
+    import torch
+    import gnn_mwvc_amd as G
+    from gnn_mwvc_amd import distributed as D
+    dev = torch.device("cuda:0")
+    bounds = D.partition_bounds(n, world)
+    per = bounds[0][1] - bounds[0][0]
+    rng = np.random.default_rng(n + off)
+    a = np.zeros((n + 64, 16), dtype=np.float32)
+    a[:n, [0, 5, 11]] = rng.normal(size=(n, 3)).astype(np.float32)
+    a[:n:7, 9] = 2.5                                              # travels in the exception lists
+    feat = torch.from_numpy(a).to(dev)
+    pk = D.Packing(1 << 0 | 1 << 5 | 1 << 11, 4, 64, 0.0)
+    pw = pk.piece_words(size)
+    buf = torch.zeros(world * pw, dtype=torch.float32, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    codec = G.EngineRowCodec(engine)
+    for r, (lo, hi) in enumerate(bounds):
+        r0, r1 = min(lo + off, hi), min(lo + off + size, hi)
+        codec.pack(feat, r0, r1, pk, buf[r * pw:(r + 1) * pw], size, flag)
+    skip = 1
+    one = torch.full((n + 64, 16), 5.0, dtype=torch.float32, device=dev)
+    many = one.clone()
+    codec.unpack_gathered(buf, world, skip, size, per, off, size, n, pk, one)
+    for r, (lo, hi) in enumerate(bounds):
+        r0, r1 = min(lo + off, hi), min(lo + off + size, hi)
+        if r != skip and r1 > r0:
+            codec.unpack(buf[r * pw:(r + 1) * pw], size, r0, r1, pk, many)
+    engine.synchronize()
+    assert int(flag.item()) == 0
+    assert torch.equal(one.view(torch.int32), many.view(torch.int32))
+    got = one.cpu().numpy()
+    for r, (lo, hi) in enumerate(bounds):
+        r0, r1 = min(lo + off, hi), min(lo + off + size, hi)
+        if r == skip:
+            assert np.all(got[lo:hi] == 5.0)
+        else:
+            assert np.array_equal(got[r0:r1], a[r0:r1])
+    assert np.all(got[n:] == 5.0)
+
+
 def test_row_codec_errors(engine):
     import gnn_mwvc_amd as G
     with pytest.raises(G.GnnvcError):
