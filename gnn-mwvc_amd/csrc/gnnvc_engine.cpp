@@ -1041,6 +1041,27 @@ int gnnvc_unpack_gathered(gnnvc_engine *e, const float *d_buf, uint32_t world, u
     return GNNVC_OK;
 }
 
+int gnnvc_score_keys(gnnvc_engine *e, const float *d_scores, uint32_t n, float *keys, uint8_t *above_half) {
+    if (!e) return GNNVC_ERR_INVALID;
+    if (!d_scores) {   // the scores the last gnnvc_forward left on the device
+        if (!e->have_graph || e->out_width != 1) return fail(e, GNNVC_ERR_STATE, "no single-column scores on the device");
+        if (n != e->g.n) return fail(e, GNNVC_ERR_INVALID, "n = %u, the current graph has %u vertices", n, e->g.n);
+        d_scores = e->scores.p;
+    }
+    if (!n) return GNNVC_OK;
+    if (!keys || !above_half) return fail(e, GNNVC_ERR_INVALID, "null output buffers");
+    int rc = use_device(e);
+    if (rc) return rc;
+    HIP_TRY(e, e->scratch[0].reserve(n));
+    HIP_TRY(e, e->scratch[1].reserve((size_t)n / 4 + 2));
+    uint8_t *d_cls = reinterpret_cast<uint8_t *>(e->scratch[1].p);
+    HIP_TRY(e, gnnvc::score_keys(d_scores, n, e->scratch[0].p, d_cls, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(keys, e->scratch[0].p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(above_half, d_cls, n, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return GNNVC_OK;
+}
+
 int gnnvc_synchronize(gnnvc_engine *e) {
     if (!e) return GNNVC_ERR_INVALID;
     int rc = use_device(e);

@@ -90,6 +90,8 @@ hipError_t launch_sgemm(int ta, int tb, uint32_t m, uint32_t n, uint32_t k, cons
                         uint32_t lda, const float *B, uint32_t ldb, float beta, float *C,
                         uint32_t ldc, hipStream_t stream);
 
+hipError_t score_keys(const float *scores, size_t n, float *keys, uint8_t *above_half, hipStream_t stream);
+
 // feature-row codec of the inter-GPU exchange (16-column rows; a piece = dense rows + exception list)
 hipError_t live_columns(const float *feat, size_t rows, uint32_t *mask, hipStream_t stream);
 hipError_t column_counts(const float *feat, size_t rows, unsigned long long *counts, hipStream_t stream);

@@ -978,6 +978,17 @@ __device__ __forceinline__ bool dev_is_twin(const GraphDev &g, uint32_t u, uint3
     return true;
 }
 
+// What the driver's sort and selection loop read from the scores (reference src/GNN_VC.cpp:194-206,
+// 213, 220): key = std::min(s, 1.0f - s) (the second argument only if it is smaller), class = s > 0.5f.
+__global__ __launch_bounds__(256) void k_score_keys(const float *__restrict__ scores, size_t n, float *__restrict__ keys,
+                                                    uint8_t *__restrict__ above_half) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float s = scores[i], t = 1.0f - s;
+    keys[i] = t < s ? t : s;
+    above_half[i] = s > 0.5f ? 1 : 0;
+}
+
 // ---- feature-row codec of the inter-GPU exchange ----------------------------------------------
 // After the ReLU that ends a stage many of the 16 output columns are zero in every row (dead
 // units; which ones depends on the graph).  The ranks exchange only the live columns: rows are
@@ -1496,6 +1507,12 @@ hipError_t live_columns(const float *feat, size_t rows, uint32_t *mask, hipStrea
     const size_t quads = rows * 4;
     const unsigned blocks = (unsigned)std::min<size_t>((quads + 255) / 256, 4096);
     hipLaunchKernelGGL(k_live_columns, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const float4 *>(feat), quads, mask);
+    return hipGetLastError();
+}
+
+hipError_t score_keys(const float *scores, size_t n, float *keys, uint8_t *above_half, hipStream_t stream) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_score_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, scores, n, keys, above_half);
     return hipGetLastError();
 }
 

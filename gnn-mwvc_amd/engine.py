@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "gnnvc_graph_staging", "gnnvc_staged_columns_ready", "gnnvc_commit_staged_graph",
     "gnnvc_forward", "gnnvc_forward_device", "gnnvc_num_stages", "gnnvc_stage_widths",
     "gnnvc_stage_forward_device", "gnnvc_live_columns", "gnnvc_column_counts", "gnnvc_pack_rows", "gnnvc_unpack_rows", "gnnvc_unpack_gathered",
-    "gnnvc_reduction_flags", "gnnvc_synchronize", "gnnvc_last_forward_ms",
+    "gnnvc_reduction_flags", "gnnvc_score_keys", "gnnvc_synchronize", "gnnvc_last_forward_ms",
     "gnnvc_graph_layer_forward", "gnnvc_linear_forward", "gnnvc_relu_forward",
     "gnnvc_sigmoid_forward", "gnnvc_sgemm",
 ]
@@ -96,6 +96,7 @@ def load_library():
     L.gnnvc_forward_device.argtypes = [vp, f32p, f32p, f32p]
     L.gnnvc_stage_forward_device.argtypes = [vp, C.c_int, u32, u32, f32p, f32p, f32p]
     L.gnnvc_reduction_flags.argtypes = [vp, u32, vp]
+    L.gnnvc_score_keys.argtypes = [vp, f32p, u32, vp, vp]
     L.gnnvc_live_columns.argtypes = [vp, f32p, u32, u32, C.POINTER(u32)]
     L.gnnvc_column_counts.argtypes = [vp, f32p, u32, u32, vp]
     L.gnnvc_pack_rows.argtypes = [vp, f32p, u32, u32, u32, u32, u32, f32p, vp, u32, vp]
@@ -280,6 +281,14 @@ class Engine:
         flags = np.zeros(self.n, dtype=np.uint8)
         self._check(self._L.gnnvc_reduction_flags(self._h, max_degree, _np_ptr(flags)))
         return flags
+
+    def score_keys(self, scores_ptr: int = 0, n: "int | None" = None):
+        """(min(s, 1 - s), s > 0.5) per score, from device scores (default: the last host forward's)."""
+        n = self.n if n is None else n
+        keys = np.empty(n, dtype=np.float32)
+        above = np.zeros(n, dtype=np.uint8)
+        self._check(self._L.gnnvc_score_keys(self._h, scores_ptr or None, n, _np_ptr(keys), _np_ptr(above)))
+        return keys, above
 
     def synchronize(self):
         self._check(self._L.gnnvc_synchronize(self._h))

@@ -201,6 +201,14 @@ int gnnvc_unpack_gathered(gnnvc_engine *e, const float *d_buf, uint32_t world, u
  * stack order and merely skips clean vertices whose bit is 0. */
 int gnnvc_reduction_flags(gnnvc_engine *e, uint32_t max_degree, uint8_t *flags);
 
+/* ---- score consumer keys ------------------------------------------------
+ * What the driver's sort and selection loop read from the scores (reference src/GNN_VC.cpp:194-206,
+ * 213, 220): keys[u] = std::min(s, 1.0f - s), above_half[u] = s > 0.5f, computed on the device from
+ * d_scores (n floats; NULL = the scores the last gnnvc_forward left there) and copied to the host.
+ * The comparator itself (its 1e-4 tie band is not a strict weak order) must stay the host's
+ * std::sort for the order to stay the reference's. */
+int gnnvc_score_keys(gnnvc_engine *e, const float *d_scores, uint32_t n, float *keys, uint8_t *above_half);
+
 /* Wait for everything queued on the engine's stream. */
 int gnnvc_synchronize(gnnvc_engine *e);
 

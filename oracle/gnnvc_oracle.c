@@ -303,6 +303,16 @@ static int is_twin(const oracle_graph *g, uint32_t u, uint32_t v) {
     return memcmp(g->col + g->rowptr[u], g->col + g->rowptr[v], (size_t)d * sizeof(uint32_t)) == 0;
 }
 
+/* reference src/GNN_VC.cpp:196 (`min(out(a, 0), 1.0f - out(a, 0))`, std::min returns its first
+ * argument unless the second is smaller) and :213/:220 (`out(nodes[i], 0) > 0.5f`) */
+void oracle_score_keys(size_t n, const float *scores, float *keys, uint8_t *above_half) {
+    for (size_t i = 0; i < n; i++) {
+        const float s = scores[i], t = 1.0f - s;
+        keys[i] = t < s ? t : s;
+        above_half[i] = s > 0.5f;
+    }
+}
+
 void oracle_reduction_flags(const oracle_graph *g, uint32_t max_degree, uint8_t *flags) {
 #pragma omp parallel for schedule(dynamic, 4096)
     for (int64_t uu = 0; uu < (int64_t)g->n; uu++) {

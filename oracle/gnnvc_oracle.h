@@ -114,6 +114,11 @@ int oracle_predict(const oracle_model *m, const oracle_graph *g,
  * Adjacency lists must be ascending (they are in the reference's graphs). */
 void oracle_reduction_flags(const oracle_graph *g, uint32_t max_degree, uint8_t *flags);
 
+/* What the driver's sort reads from the scores (reference src/GNN_VC.cpp:194-206, 213, 220):
+ * keys[u] = min(s, 1.0f - s) — the confidence key of the comparator, std::min semantics —
+ * and above_half[u] = s > 0.5f, the class the selection loop acts on. */
+void oracle_score_keys(size_t n, const float *scores, float *keys, uint8_t *above_half);
+
 /* Number of worker threads the linear layers use (OpenMP), 1 if built without. */
 int oracle_num_threads(void);
 void oracle_set_num_threads(int n);

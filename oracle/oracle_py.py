@@ -65,6 +65,8 @@ def lib():
         L.oracle_sigmoid.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p]
         L.oracle_neighbourhood_weights.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p,
                                                    C.c_void_p, C.c_void_p]
+        L.oracle_score_keys.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_score_keys.restype = None
         L.oracle_reduction_flags.argtypes = [C.POINTER(_Graph), C.c_uint32, C.c_void_p]
         L.oracle_num_threads.restype = C.c_int
         L.oracle_set_num_threads.argtypes = [C.c_int]
@@ -185,6 +187,15 @@ def sigmoid(h: np.ndarray) -> np.ndarray:
     out = np.empty_like(h)
     lib().oracle_sigmoid(h.size, _ptr(h), _ptr(out))
     return out
+
+
+def score_keys(scores: np.ndarray):
+    """(min(s, 1 - s), s > 0.5) per score — what the driver's sort and selection loop read."""
+    s = np.ascontiguousarray(scores, dtype=np.float32).reshape(-1)
+    keys = np.empty_like(s)
+    above = np.zeros(s.size, dtype=np.uint8)
+    lib().oracle_score_keys(s.size, _ptr(s), _ptr(keys), _ptr(above))
+    return keys, above
 
 
 def reduction_flags(g, max_degree: int = 20) -> np.ndarray:

@@ -560,6 +560,29 @@ def test_sorted_tiles_auto_decision(model_text):
         e.close()
 
 
+# ---------------------------------------------------------------- score consumer keys (f-3)
+
+def test_score_keys_match_oracle(engine, oracle_model):
+    """min(s, 1 - s) and s > 0.5 from the device scores == the oracle's restatement of the driver's reads."""
+    import torch
+    g = gg.erdos_renyi(20000, 120000, 41)
+    engine.set_weight_scale(g.ws)
+    engine.upload_graph(g)
+    scores, _ = engine.forward(g.x())
+    keys, above = engine.score_keys()
+    want_k, want_a = oracle_py.score_keys(scores[:, 0])
+    assert np.array_equal(bits(keys), bits(want_k)) and np.array_equal(above, want_a)
+    assert 0 < above.sum() < g.n
+    # explicit device buffer, edge values: 0.5 exactly, the ends, values whose 1 - s rounds
+    s = np.array([0.5, 0.0, 1.0, np.nextafter(np.float32(0.5), np.float32(1)), np.nextafter(np.float32(0.5), np.float32(0)),
+                  1e-8, 1 - 1e-7, 0.25, 0.75, 3e-39], dtype=np.float32)
+    d = torch.from_numpy(s).to("cuda:0")
+    keys, above = engine.score_keys(d.data_ptr(), s.size)
+    want_k, want_a = oracle_py.score_keys(s)
+    assert np.array_equal(bits(keys), bits(want_k)) and np.array_equal(above, want_a)
+    assert above.tolist() == [0, 0, 1, 1, 0, 0, 1, 0, 1, 0]
+
+
 # ---------------------------------------------------------------- feature-row codec of the exchange
 
 @pytest.mark.parametrize("mask,cap", [(0x0000, 64), (0x080B, 64), (0x0001, 0), (0x8000, 4096), (0x0FF0, 64),
