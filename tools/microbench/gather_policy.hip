@@ -92,7 +92,15 @@ int main(int argc, char **argv) {
     const size_t per_quad = (gathers_req / quads) / 8 * 8;
     const size_t gathers = quads * per_quad;
     float4 *tab, *out; uint32_t *idx;
-    CK(hipMalloc(&tab, (rows + 1) * 64)); CK(hipMalloc(&idx, gathers * 4)); CK(hipMalloc(&out, quads * 64));
+    // argv[5]: how the table is allocated: 0 = hipMalloc (default), 1 = fine-grained, 3 = uncached (MTYPE UC)
+    const unsigned tab_flags = argc > 5 ? (unsigned)atoi(argv[5]) : 0;
+    if (tab_flags) {
+        CK(hipExtMallocWithFlags((void **)&tab, (rows + 1) * 64, tab_flags));
+        printf("table allocated with hipExtMallocWithFlags(%u)\n", tab_flags);
+    } else {
+        CK(hipMalloc(&tab, (rows + 1) * 64));
+    }
+    CK(hipMalloc(&idx, gathers * 4)); CK(hipMalloc(&out, quads * 64));
     hipLaunchKernelGGL(k_fill_tab, dim3(4096), dim3(256), 0, 0, (float *)tab, (rows + 1) * 16);
     hipLaunchKernelGGL(k_fill_idx, dim3(4096), dim3(256), 0, 0, idx, gathers, (uint32_t)rows);
     CK(hipDeviceSynchronize());
