@@ -576,29 +576,48 @@ constexpr uint32_t kLongRound = 64 * kLongR;
 // first-class vector type (HIP's float4 is a struct: arrays of it that live across loop
 // iterations are not promoted to registers)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void long_drain_round(const f32x4 (&rows)[kLongR], float (&slab)[2][kLongChunk * 16],
+// Slab layout: column-major, one padded run of kLongChunk neighbours per feature column, so that
+// the adder lane of a column reads four consecutive neighbours with one ds_read_b128 (a single wave
+// issues one instruction every ~4 cycles: with one LDS read per add the chain ran at ~11 cycles per
+// neighbour, with one per four adds it runs at ~5).  The pad of 4 floats spreads the 16 adder lanes
+// over all 64 banks (260 % 64 = 4) and the four column groups of the writers over 16-bank strides.
+constexpr int kLongStride = kLongChunk + 4;
+
+__device__ __forceinline__ void long_drain_round(const f32x4 (&rows)[kLongR], float (&slab)[2][kLongStride * 16],
                                                  uint32_t left_round, int tid, int q, int c, float &acc) {
 #pragma unroll
     for (int sub = 0; sub < kLongR / 4; ++sub) {
-        // slab row k of this quarter = neighbour sub*256 + k of the round  <->  (j = 4 sub + k / 64, q = k % 64)
+        // slab entry k of this quarter = neighbour sub*256 + k of the round  <->  (j = 4 sub + k / 64, q = k % 64)
         if ((uint32_t)(sub * kLongChunk) < left_round) {   // block-uniform
             float *buf = slab[sub & 1];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                *reinterpret_cast<f32x4 *>(&buf[(q + 64 * jj) * 16 + 4 * c]) = rows[4 * sub + jj];
+            for (int jj = 0; jj < 4; ++jj) {
+                const f32x4 r = rows[4 * sub + jj];
+                const int k = q + 64 * jj;
+                buf[(4 * c + 0) * kLongStride + k] = r[0];
+                buf[(4 * c + 1) * kLongStride + k] = r[1];
+                buf[(4 * c + 2) * kLongStride + k] = r[2];
+                buf[(4 * c + 3) * kLongStride + k] = r[3];
+            }
             __syncthreads();
             if (tid < 16) {
                 const uint32_t left = left_round - sub * kLongChunk;
                 const uint32_t cnt = left < (uint32_t)kLongChunk ? left : (uint32_t)kLongChunk;
+                const float *col = buf + tid * kLongStride;
                 uint32_t k = 0;
-                for (; k + 64 <= cnt; k += 64) {   // 64 LDS reads in flight, then 64 ordered adds:
-                    float t[64];                   // the add chain, not the LDS latency, paces the row
+                for (; k + 64 <= cnt; k += 64) {   // 16 LDS reads in flight, then 64 ordered adds:
+                    f32x4 t[16];                   // the add chain, not the LDS latency, paces the row
 #pragma unroll
-                    for (int j = 0; j < 64; ++j) t[j] = buf[(k + j) * 16 + tid];
+                    for (int j = 0; j < 16; ++j) t[j] = *reinterpret_cast<const f32x4 *>(&col[k + 4 * j]);
 #pragma unroll
-                    for (int j = 0; j < 64; ++j) acc += t[j];
+                    for (int j = 0; j < 16; ++j) {
+                        acc += t[j][0];
+                        acc += t[j][1];
+                        acc += t[j][2];
+                        acc += t[j][3];
+                    }
                 }
-                for (; k < cnt; ++k) acc += buf[k * 16 + tid];
+                for (; k < cnt; ++k) acc += col[k];
             }
             // slab[sub & 1] is rewritten two quarters later, after the barrier of the next
             // quarter, which the adders reach only when these reads are done
@@ -611,7 +630,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         GraphDev g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
         float *__restrict__ logits, const float *__restrict__ P, uint32_t row_lo, uint32_t row_hi,
         const uint32_t *__restrict__ list, uint32_t min_deg) {
-    __shared__ __attribute__((aligned(16))) float slab[2][kLongChunk * 16];
+    __shared__ __attribute__((aligned(16))) float slab[2][kLongStride * 16];
     const uint32_t u = list[blockIdx.x];
     if (u < row_lo || u >= row_hi) return;   // block-uniform
     const int tid = threadIdx.x, q = tid >> 2, c = tid & 3;
