@@ -117,6 +117,13 @@ struct gnnvc_engine {
     uint32_t blk_count = 0, blk_cols = 0;
     DevBuf<uint32_t> blk_ptr, blk_col, blk_scratch, blk_flag;
     DevBuf<float> blk_acc;
+    // LDS-table plan of the F = 1 stage (same timing as the blocked plan: built on the graph's second forward)
+    int opt_lds_table = 1;          // 0 = off, 1 = when it applies, 2 = also on skewed graphs
+    bool lt_ready = false, lt_tried = false;
+    uint32_t lt_rows = 0, lt_chunks = 0, lt_blocks = 0, lt_steps_total = 0;
+    DevBuf<uint8_t> lt_bytes;
+    DevBuf<uint32_t> lt_entries, lt_segcnt, lt_stepptr, lt_stepcnt, lt_bad;
+    DevBuf<uint4> lt_steps;
 
     // option "mfma_dense": dense layers on the matrix cores (bit-identical to the VALU path).
     // 0 = VALU everywhere, 1 = MFMA everywhere, 2 = MFMA in the F = 16 stages only (default:
@@ -459,6 +466,65 @@ int build_blocked(gnnvc_engine *e) {
 }
 
 // stage launcher shared by the whole-forward and the per-stage entry points
+// LDS-table plan of the current graph's F = 1 stage (kernels: k_lt_*).  Applies when every weight fits a
+// byte, adjacency lists ascend, no row is long enough for the long-row kernels and the graph is large and
+// not skewed; whether a given forward's input really is W / ws is checked on the device at every launch.
+int build_lds_table(gnnvc_engine *e) {
+    e->lt_ready = false;
+    e->lt_tried = true;
+    const GraphDev &g = e->g;
+    if (!e->opt_lds_table || e->stages.empty() || e->stages[0].f != 1 || e->stages[0].variant != 0) return GNNVC_OK;
+    if (g.n < e->opt_blocked_min_n || g.nnz == 0 || g.nnz >= (1ull << 31)) return GNNVC_OK;
+    if (e->opt_lds_table < 2 && (e->sorted_wanted || e->n_long > 0)) return GNNVC_OK;   // long runs would serialise in one thread
+    const uint32_t bc = gnnvc::lds_table_block(), max_rows = gnnvc::lds_table_max_rows();
+    const uint32_t nblocks = (g.n + bc - 1) / bc;
+    if (nblocks > 4096) return GNNVC_OK;
+    // chunks: a multiple of the 256 CUs, each within the LDS budget
+    uint32_t chunks = (g.n + max_rows - 1) / max_rows;
+    chunks = (chunks + 255u) / 256u * 256u;
+    const uint32_t rows = (g.n + chunks - 1) / chunks;
+    chunks = (g.n + rows - 1) / rows;
+    HIP_TRY(e, e->lt_bad.reserve(2));
+    HIP_TRY(e, e->lt_bytes.reserve((size_t)g.n + 64));
+    HIP_TRY(e, e->lt_segcnt.reserve((size_t)chunks * nblocks));
+    HIP_TRY(e, e->lt_stepcnt.reserve(chunks));
+    HIP_TRY(e, e->lt_stepptr.reserve((size_t)chunks + 1));
+    HIP_TRY(e, e->pin_small.reserve((size_t)chunks + 2));
+    uint32_t *flag = e->lt_bad.p + 1;   // word 0 is the per-forward flag
+    HIP_TRY(e, hipMemsetAsync(flag, 0, sizeof(uint32_t), e->stream));
+    HIP_TRY(e, hipMemsetAsync(e->lt_bytes.p + g.n, 0, 64, e->stream));
+    HIP_TRY(e, gnnvc::lds_table_bytes(g.w, g.n, e->lt_bytes.p, flag, e->stream));
+    HIP_TRY(e, gnnvc::lds_table_count(g, rows, chunks, nblocks, e->lt_segcnt.p, flag, e->stream));
+    HIP_TRY(e, gnnvc::lds_table_steps(g, rows, chunks, nblocks, e->lt_segcnt.p, nullptr, e->lt_stepcnt.p, nullptr, false, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, e->lt_stepcnt.p, chunks * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->pin_small.p + chunks, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (e->pin_small.p[chunks]) return GNNVC_OK;   // a weight above 255 or an unsorted row: the plan does not apply
+    std::vector<uint32_t> ptr((size_t)chunks + 1, 0);
+    uint64_t total = 0;
+    for (uint32_t c = 0; c < chunks; ++c) {
+        ptr[c] = (uint32_t)total;
+        total += e->pin_small.p[c];
+    }
+    if (total + 8 >= (1ull << 31)) return GNNVC_OK;
+    ptr[chunks] = (uint32_t)total;
+    HIP_TRY(e, e->lt_steps.reserve(total + 8));
+    HIP_TRY(e, e->lt_entries.reserve(g.nnz));
+    HIP_TRY(e, e->blk_acc.reserve(g.n));
+    std::memcpy(e->pin_small.p, ptr.data(), ptr.size() * sizeof(uint32_t));
+    HIP_TRY(e, hipMemcpyAsync(e->lt_stepptr.p, e->pin_small.p, ptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipMemsetAsync(e->lt_steps.p + total, 0, 8 * sizeof(uint4), e->stream));
+    HIP_TRY(e, gnnvc::lds_table_steps(g, rows, chunks, nblocks, e->lt_segcnt.p, e->lt_stepptr.p, nullptr, e->lt_steps.p, true, e->stream));
+    HIP_TRY(e, gnnvc::lds_table_scatter(g, rows, chunks, nblocks, e->lt_segcnt.p, e->lt_entries.p, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));   // pin_small is reused by others
+    e->lt_rows = rows;
+    e->lt_chunks = chunks;
+    e->lt_blocks = nblocks;
+    e->lt_steps_total = (uint32_t)total;
+    e->lt_ready = true;
+    return GNNVC_OK;
+}
+
 int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float *in, float *out, float *logits) {
     const bool longs = e->n_long > 0;
     const uint32_t thr = (e->stages[stage].f == 16) ? e->thresh_f16 : e->long_thresh;   // this stage's long-row threshold
@@ -470,13 +536,22 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
         HIP_TRY(e, hipEventRecord(e->ev_join, e->aux_stream));
     }
     if (stage == 0) {
-        if (e->graph_uses >= 1 && !e->blocked_tried) {
+        if (e->graph_uses >= 1 && !e->lt_tried) {
+            int rc = build_lds_table(e);
+            if (rc) return rc;
+        }
+        if (e->graph_uses >= 1 && !e->lt_ready && !e->blocked_tried) {
             int rc = build_blocked(e);
             if (rc) return rc;
         }
         ++e->graph_uses;
     }
-    if (stage == 0 && e->blocked_ready) {
+    if (stage == 0 && e->lt_ready) {
+        HIP_TRY(e, gnnvc::launch_stage0_lds_table(e->stages[0], e->g, e->ws, e->params.p, in, out, lo, hi, e->lt_rows,
+                                                  e->lt_stepptr.p, e->lt_steps.p, e->lt_entries.p, e->lt_bytes.p,
+                                                  e->blk_acc.p, e->lt_bad.p, e->long_thresh, e->opt_mfma == 1,
+                                                  e->interleave, e->stream));
+    } else if (stage == 0 && e->blocked_ready) {
         HIP_TRY(e, gnnvc::launch_stage0_blocked(e->stages[0], e->g, e->ws, e->params.p, in, out, lo, hi,
                                                 e->blk_count, e->blk_ptr.p, e->blk_col.p, e->blk_acc.p,
                                                 e->long_thresh, e->opt_mfma == 1, e->interleave, e->stream));
@@ -630,6 +705,8 @@ void gnnvc_destroy(gnnvc_engine *e) {
     e->scratch[0].release(); e->scratch[1].release();
     e->blk_ptr.release(); e->blk_col.release(); e->blk_scratch.release(); e->blk_flag.release();
     e->blk_acc.release();
+    e->lt_bytes.release(); e->lt_entries.release(); e->lt_segcnt.release(); e->lt_stepptr.release();
+    e->lt_stepcnt.release(); e->lt_bad.release(); e->lt_steps.release();
     e->long_list.release(); e->long_count.release();
     e->pin_rowptr.release(); e->pin_col.release(); e->pin_w.release(); e->pin_nw.release();
     e->pin_small.release();
@@ -661,6 +738,7 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "block_cols") e->opt_block_cols = value > 0 ? (uint32_t)value : 0;
     else if (k == "blocked_min_n") e->opt_blocked_min_n = value > 0 ? (uint32_t)value : 0;
     else if (k == "long_row_threshold") e->opt_long_thresh = value > 0 ? (uint32_t)value : 0;
+    else if (k == "lds_table") e->opt_lds_table = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else if (k == "sorted_min_nnz") e->opt_sorted_min_nnz = value > 0 ? (uint64_t)value : 0;
     else if (k == "sorted_long_row_threshold") e->opt_sorted_long_thresh = value > 0 ? (uint32_t)value : 1;
     else if (k == "mfma_dense") e->opt_mfma = (value >= 0 && value <= 2) ? (int)value : 2;
@@ -672,7 +750,10 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
 int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
     if (!e || !key || !value) return GNNVC_ERR_INVALID;
     const std::string k(key);
-    if (k == "blocked_stage0_active") *value = e->blocked_ready ? 1 : 0;
+    if (k == "lds_table_active") *value = e->lt_ready ? 1 : 0;
+    else if (k == "lds_table_chunks") *value = e->lt_ready ? (long)e->lt_chunks : 0;
+    else if (k == "lds_table_steps") *value = e->lt_ready ? (long)e->lt_steps_total : 0;
+    else if (k == "blocked_stage0_active") *value = e->blocked_ready ? 1 : 0;
     else if (k == "blocked_blocks") *value = e->blocked_ready ? (long)e->blk_count : 0;
     else if (k == "block_cols") *value = e->blocked_ready ? (long)e->blk_cols : 0;
     else if (k == "long_rows") *value = (long)e->n_long;
@@ -717,6 +798,7 @@ static int adopt_uploaded(gnnvc_engine *e, uint32_t n, uint64_t nnz) {
     e->have_graph = true;
     int rc = reserve_features(e, n);
     if (rc) return rc;
+    e->lt_ready = e->lt_tried = false;
     e->blocked_ready = false;   // the column-blocked index is built on the graph's SECOND forward:
     e->blocked_tried = false;   // it costs about as much as it saves on one, and the reference's
     e->graph_uses = 0;          // driver uses every graph exactly once (src/GNN_VC.cpp:171-192)
@@ -858,6 +940,7 @@ int gnnvc_attach_graph_device(gnnvc_engine *e, uint32_t n, uint64_t nnz, const u
     e->have_graph = true;
     rc = reserve_features(e, n);
     if (rc) return rc;
+    e->lt_ready = e->lt_tried = false;
     e->blocked_ready = false;   // the column-blocked index is built on the graph's SECOND forward:
     e->blocked_tried = false;   // it costs about as much as it saves on one, and the reference's
     e->graph_uses = 0;          // driver uses every graph exactly once (src/GNN_VC.cpp:171-192)

@@ -90,6 +90,22 @@ hipError_t launch_sgemm(int ta, int tb, uint32_t m, uint32_t n, uint32_t k, cons
                         uint32_t lda, const float *B, uint32_t ldb, float beta, float *C,
                         uint32_t ldc, hipStream_t stream);
 
+// LDS-table plan of the F = 1 stage (see the kernels): build steps, then the per-forward launch
+uint32_t lds_table_max_rows();
+uint32_t lds_table_block();
+hipError_t lds_table_bytes(const uint32_t *w, uint32_t n, uint8_t *wb, uint32_t *bad, hipStream_t stream);
+hipError_t lds_table_count(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t *seg_cnt,
+                           uint32_t *bad, hipStream_t stream);
+hipError_t lds_table_steps(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, const uint32_t *seg_cnt,
+                           const uint32_t *step_ptr, uint32_t *step_count, void *steps, bool write, hipStream_t stream);
+hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks,
+                             const uint32_t *seg_cnt, uint32_t *entries, hipStream_t stream);
+hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *x,
+                                   float *out, uint32_t row_lo, uint32_t row_hi, uint32_t rows_per_chunk,
+                                   const uint32_t *step_ptr, const void *steps, const uint32_t *entries, const uint8_t *wbyte,
+                                   float *acc, uint32_t *bad, uint32_t long_thresh, bool mfma, bool interleave,
+                                   hipStream_t stream);
+
 hipError_t score_keys(const float *scores, size_t n, float *keys, uint8_t *above_half, hipStream_t stream);
 
 // feature-row codec of the inter-GPU exchange (16-column rows; a piece = dense rows + exception list)

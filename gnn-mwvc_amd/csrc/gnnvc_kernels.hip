@@ -451,8 +451,13 @@ __global__ __launch_bounds__(kBlock) void k_stage_f1(
         GraphDev g, float ws, const float *__restrict__ xin, float *__restrict__ fout,
         const float *__restrict__ P, uint32_t row_lo, uint32_t row_hi,
         const uint32_t *__restrict__ ep, const uint32_t *__restrict__ ecol,
-        const float *__restrict__ acc_in, uint32_t long_thresh, int interleave) {
+        const float *__restrict__ acc_in, uint32_t long_thresh, int interleave,
+        const uint32_t *__restrict__ acc_bad) {
+    // acc_bad (LDS-table plan only): *acc_bad == 0 -> acc_in holds the rows' COMPLETE sums and no entry is left
+    // to add; != 0 -> the plan did not apply to this input, acc_in is ignored and every entry is gathered here.
     __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kRegionFloats];
+    const bool acc_full = acc_bad && *acc_bad == 0;
+    if (acc_bad && !acc_full) acc_in = nullptr;
     const int lane = threadIdx.x & 63;
     float *T = lds[threadIdx.x >> 6];
     uint32_t *stage = reinterpret_cast<uint32_t *>(T);
@@ -466,12 +471,12 @@ __global__ __launch_bounds__(kBlock) void k_stage_f1(
     const uint32_t deg = g.rowptr[uc + 1] - g.rowptr[uc];
     const bool mine = valid && deg < long_thresh;   // long rows belong to k_long_f1
     const uint32_t rs = ep[uc];
-    const uint32_t re = mine ? ep[uc + 1] : rs;
+    const uint32_t re = (mine && !acc_full) ? ep[uc + 1] : rs;
     const float f_deg = (float)deg;
 
     const uint32_t c0 = __builtin_amdgcn_readfirstlane(rs);
     const uint32_t vend = (v0 + kWave < row_hi) ? v0 + kWave : row_hi;
-    const uint32_t c1 = ep[vend];   // wave-uniform: end of the tile's last valid row
+    const uint32_t c1 = acc_full ? c0 : ep[vend];   // wave-uniform: end of the tile's last valid row
     const bool staged = (c1 - c0) <= kStageCap;
     uint32_t sbase = 0;
     if (staged) sbase = stage_cols(ecol, c0, c1, stage, lane);
@@ -777,6 +782,232 @@ __global__ __launch_bounds__(256) void k_long_f1(
     dense<N2, N2, N3, 0>(x2, x3, W3, b3);
 #pragma unroll
     for (int j = 0; j < N3; ++j) fout[(size_t)u * N3 + j] = x3[j];
+}
+
+// ---- LDS-table plan of the F = 1 stage ---------------------------------------------------------
+// The F = 1 gather reads 4 bytes per neighbour and is bound by line fills (one 128-byte line per
+// neighbour, from HBM or, column-blocked, from L2).  When the input really is x[v] = (float)W(v)/ws
+// with W(v) <= 255 — the reference's driver (src/GNN_VC.cpp:189-191) on the usual weight ranges — the
+// table of neighbour values is one BYTE per vertex, and a 32768-vertex slice of it fits in LDS beside
+// the partial sums of ~19.5 K rows.  Rows are cut into chunks (one 1024-thread workgroup each, sums in
+// LDS), columns into blocks of 32768; the CSR entries of a chunk are regrouped by block (a row's
+// entries of one block stay adjacent and in order) and cut into STEPS of <= 2048 entries.  A workgroup
+// walks its steps: the step's entries and the block's slice are staged in LDS (prefetched four steps
+// ahead through registers, every load unconditional so that the hardware counters can be waited on
+// exactly), each thread adds lut[w] for its entry to its row's sum, and the thread at the head of a
+// row's run of entries adds the whole run in order.  Blocks ascend and a row's entries of one block
+// belong to one thread, so every row is still summed in CSR order: same bits as the plain gather.
+constexpr uint32_t kLtBlock = 32768;      // vertices per column block (bytes per LDS slice)
+constexpr uint32_t kLtStep = 2048;        // entries per step (two per thread)
+constexpr uint32_t kLtMaxRows = 19532;    // rows per chunk: 4 B * rows + 2 * 32 KiB + 2 * 8 KiB + 1 KiB <= 160 KiB
+
+// bad |= 1 unless x[v] == (float)w[v] / ws (bit for bit) for every vertex
+__global__ __launch_bounds__(256) void k_lt_check_x(const float *__restrict__ x, const uint32_t *__restrict__ w, float ws,
+                                                    uint32_t n, uint32_t *bad) {
+    bool miss = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        miss |= __float_as_uint(x[i]) != __float_as_uint((float)w[i] / ws);
+    if (__any(miss) && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
+}
+
+// wb[v] = (uint8) w[v]; bad |= 1 if some weight does not fit a byte
+__global__ __launch_bounds__(256) void k_lt_bytes(const uint32_t *__restrict__ w, uint32_t n, uint8_t *__restrict__ wb,
+                                                  uint32_t *bad) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool big = false;
+    if (i < n) {
+        const uint32_t v = w[i];
+        big = v > 255u;
+        wb[i] = (uint8_t)v;
+    }
+    if (__any(big) && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
+}
+
+// entries of chunk `c` per column block -> seg_cnt[c * nblocks + b]; bad |= 2 if a row's blocks are
+// not ascending (unsorted adjacency: the plan would change the order of its sum)
+__global__ __launch_bounds__(1024) void k_lt_count(GraphDev g, uint32_t rows_per_chunk, uint32_t nblocks,
+                                                   uint32_t *__restrict__ seg_cnt, uint32_t *bad) {
+    __shared__ uint32_t hist[4096];
+    const uint32_t c = blockIdx.x, tid = threadIdx.x;
+    for (uint32_t i = tid; i < nblocks; i += 1024) hist[i] = 0;
+    __syncthreads();
+    const uint32_t r0 = c * rows_per_chunk, r1 = min(g.n, r0 + rows_per_chunk);
+    bool unsorted = false;
+    for (uint32_t u = r0 + tid; u < r1; u += 1024) {
+        uint32_t prev = 0, run = 0;
+        for (uint32_t e = g.rowptr[u]; e < g.rowptr[u + 1]; ++e) {
+            const uint32_t b = g.col[e] / kLtBlock;
+            if (run && b != prev) {
+                atomicAdd(&hist[prev], run);
+                unsorted |= b < prev;
+                run = 0;
+            }
+            prev = b;
+            ++run;
+        }
+        if (run) atomicAdd(&hist[prev], run);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < nblocks; i += 1024) seg_cnt[(size_t)c * nblocks + i] = hist[i];
+    if (__any(unsorted) && (tid & 63) == 0) atomicOr(bad, 2u);
+}
+
+// One thread per chunk.  write == 0: steps[c] = number of steps of chunk c (padded to a multiple of 4).
+// write != 0: the descriptors {block, first entry, count, 0} at step_ptr[c]...
+__global__ __launch_bounds__(256) void k_lt_steps(GraphDev g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks,
+                                                  const uint32_t *__restrict__ seg_cnt, const uint32_t *__restrict__ step_ptr,
+                                                  uint32_t *__restrict__ step_count, uint4 *__restrict__ steps, int write) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    const uint32_t *cnt = seg_cnt + (size_t)c * nblocks;
+    uint32_t first = g.rowptr[min((uint64_t)g.n, (uint64_t)c * rows_per_chunk)];   // a chunk's entries are a CSR range
+    uint32_t pos = write ? step_ptr[c] : 0, made = 0;
+    for (uint32_t b = 0; b < nblocks; ++b) {
+        uint32_t left = cnt[b];
+        while (left) {
+            const uint32_t take = left < kLtStep ? left : kLtStep;
+            if (write) steps[pos + made] = make_uint4(b, first, take, 0u);
+            ++made;
+            first += take;
+            left -= take;
+        }
+    }
+    const uint32_t padded = made ? (made + 3u) / 4u * 4u : 4u;
+    if (write)
+        for (; made < padded; ++made) steps[pos + made] = make_uint4(0u, 0u, 0u, 0u);
+    else
+        step_count[c] = padded;
+}
+
+// regroup the chunk's CSR entries by column block: entries[...] = row_local << 17 | col_local; a row's
+// entries of one block are written as one adjacent run, in order (the order among rows is free)
+__global__ __launch_bounds__(1024) void k_lt_scatter(GraphDev g, uint32_t rows_per_chunk, uint32_t nblocks,
+                                                     const uint32_t *__restrict__ seg_cnt, uint32_t *__restrict__ entries) {
+    __shared__ uint32_t cursor[4096];
+    const uint32_t c = blockIdx.x, tid = threadIdx.x;
+    const uint32_t r0 = c * rows_per_chunk, r1 = min(g.n, r0 + rows_per_chunk);
+    if (tid == 0) {   // exclusive scan of <= 4096 counts: a few microseconds, once per graph
+        uint32_t run = g.rowptr[r0 < g.n ? r0 : g.n];
+        for (uint32_t b = 0; b < nblocks; ++b) {
+            cursor[b] = run;
+            run += seg_cnt[(size_t)c * nblocks + b];
+        }
+    }
+    __syncthreads();
+    for (uint32_t u = r0 + tid; u < r1; u += 1024) {
+        const uint32_t rl = (u - r0) << 17;
+        uint32_t e = g.rowptr[u];
+        const uint32_t end = g.rowptr[u + 1];
+        while (e < end) {
+            const uint32_t b = g.col[e] / kLtBlock;
+            uint32_t f = e + 1;
+            while (f < end && g.col[f] / kLtBlock == b) ++f;
+            uint32_t pos = atomicAdd(&cursor[b], f - e);
+            for (; e < f; ++e) entries[pos++] = rl | (g.col[e] - b * kLtBlock);
+        }
+    }
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// sums of the rows of chunks [chunk0, chunk0 + gridDim.x) -> agg[row]; nothing if *bad != 0
+__global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ step_ptr, const uint4 *__restrict__ steps,
+                                                 const uint32_t *__restrict__ entries, const uint8_t *__restrict__ wbyte, float ws,
+                                                 float *__restrict__ agg, uint32_t n, uint32_t rows_per_chunk, uint32_t chunk0,
+                                                 uint32_t last_entry, const uint32_t *__restrict__ bad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lt_smem[];
+    if (*bad) return;                                                   // block-uniform
+    float *acc = reinterpret_cast<float *>(lt_smem);                    // rows_per_chunk (<= kLtMaxRows) floats
+    float *lut = acc + kLtMaxRows;                                      // 256 floats
+    uint32_t *ebuf0 = reinterpret_cast<uint32_t *>(lut + 256);          // 2 x kLtStep entries
+    uint8_t *slice0 = reinterpret_cast<uint8_t *>(ebuf0 + 2 * kLtStep); // 2 x kLtBlock bytes
+    const uint32_t chunk = chunk0 + blockIdx.x, tid = threadIdx.x;
+    const uint32_t row0 = chunk * rows_per_chunk;
+    for (uint32_t i = tid; i < rows_per_chunk; i += 1024) acc[i] = 0.0f;
+    if (tid < 256) lut[tid] = (float)tid / ws;                          // the very expression that makes x (checked per forward)
+    const uint32_t st0 = step_ptr[chunk], st1 = step_ptr[chunk + 1];   // a multiple of 4 steps; 8 more are readable
+    const uint32_t last_piece = (n + 15u) / 16u;                        // the byte table is padded beyond this
+    constexpr int SW = kLtBlock / 16 / 1024, J = kLtStep / 1024;
+    static_assert(SW == 2 && J == 2, "k_lt_agg is written for two pieces and two entries per thread");
+#define LT_LOAD(d_, sr_, en_)                                                             \
+    {                                                                                     \
+        _Pragma("unroll") for (int k = 0; k < SW; ++k) {                                  \
+            uint32_t piece_ = (d_).x * (kLtBlock / 16) + tid + 1024 * k;                  \
+            piece_ = piece_ < last_piece ? piece_ : last_piece;                           \
+            sr_[k] = reinterpret_cast<const u32x4 *>(wbyte)[piece_];                      \
+        }                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < J; ++j) {                                   \
+            const uint32_t e_ = (d_).y + tid + 1024 * j;                                  \
+            en_[j] = entries[e_ < last_entry ? e_ : last_entry];                          \
+        }                                                                                 \
+    }
+#define LT_STORE(s_, sr_, en_)                                                            \
+    {                                                                                     \
+        _Pragma("unroll") for (int k = 0; k < SW; ++k)                                    \
+            reinterpret_cast<u32x4 *>(slice0 + (size_t)((s_) & 1) * kLtBlock)[tid + 1024 * k] = sr_[k]; \
+        _Pragma("unroll") for (int j = 0; j < J; ++j) ebuf0[((s_) & 1) * kLtStep + tid + 1024 * j] = en_[j]; \
+    }
+    // both entries of a thread advance together: the LDS reads of the two chains are issued back to back
+#define LT_PROCESS(s_, len_)                                                              \
+    {                                                                                     \
+        const uint8_t *slice_ = slice0 + (size_t)((s_) & 1) * kLtBlock;                   \
+        const uint32_t *eb_ = ebuf0 + ((s_) & 1) * kLtStep;                               \
+        const uint32_t i0_ = tid, i1_ = tid + 1024;                                       \
+        const bool in0_ = i0_ < (len_), in1_ = i1_ < (len_);                              \
+        const uint32_t a0_ = eb_[in0_ ? i0_ : 0], a1_ = eb_[in1_ ? i1_ : 0];              \
+        const uint32_t b0_ = eb_[(in0_ && i0_) ? i0_ - 1 : 0], b1_ = eb_[in1_ ? i1_ - 1 : 0]; \
+        const uint32_t n0_ = eb_[(in0_ && i0_ + 1 < (len_)) ? i0_ + 1 : 0];               \
+        const uint32_t n1_ = eb_[(in1_ && i1_ + 1 < (len_)) ? i1_ + 1 : 0];               \
+        const uint32_t r0_ = a0_ >> 17, r1_ = a1_ >> 17;                                  \
+        const bool h0_ = in0_ && (i0_ == 0 || (b0_ >> 17) != r0_);                        \
+        const bool h1_ = in1_ && (b1_ >> 17) != r1_;                                      \
+        const float v0_ = lut[slice_[a0_ & 0x1FFFF]], v1_ = lut[slice_[a1_ & 0x1FFFF]];   \
+        const float c0_ = acc[r0_], c1_ = acc[r1_];                                       \
+        const bool more0_ = h0_ && i0_ + 1 < (len_) && (n0_ >> 17) == r0_;                \
+        const bool more1_ = h1_ && i1_ + 1 < (len_) && (n1_ >> 17) == r1_;                \
+        float s0_ = c0_ + v0_, s1_ = c1_ + v1_;                                           \
+        if (more0_)                                                                       \
+            for (uint32_t k_ = i0_ + 1; k_ < (len_) && (eb_[k_] >> 17) == r0_; ++k_) s0_ += lut[slice_[eb_[k_] & 0x1FFFF]]; \
+        if (more1_)                                                                       \
+            for (uint32_t k_ = i1_ + 1; k_ < (len_) && (eb_[k_] >> 17) == r1_; ++k_) s1_ += lut[slice_[eb_[k_] & 0x1FFFF]]; \
+        if (h0_) acc[r0_] = s0_;                                                          \
+        if (h1_) acc[r1_] = s1_;                                                          \
+    }
+    u32x4 sr0[SW], sr1[SW], sr2[SW], sr3[SW];
+    uint32_t en0[J], en1[J], en2[J], en3[J];
+    uint32_t l0, l1, l2, l3;                       // lengths of the steps whose data sit in ring slots 0..3
+    uint4 dn;
+    dn = steps[st0];     LT_LOAD(dn, sr0, en0) l0 = dn.z;
+    LT_STORE(0, sr0, en0)
+    dn = steps[st0 + 1]; LT_LOAD(dn, sr1, en1) l1 = dn.z;
+    dn = steps[st0 + 2]; LT_LOAD(dn, sr2, en2) l2 = dn.z;
+    dn = steps[st0 + 3]; LT_LOAD(dn, sr3, en3) l3 = dn.z;
+    uint32_t lcur = l0;                            // length of the step about to be processed
+    dn = steps[st0 + 4]; LT_LOAD(dn, sr0, en0) l0 = dn.z;
+    dn = steps[st0 + 5];                           // descriptor of the next load, fetched a whole step early
+#define LT_STEP(t_, sr_, en_, l_)                            \
+    {                                                        \
+        __syncthreads();                                     \
+        LT_PROCESS((t_), lcur)                               \
+        LT_STORE((t_) + 1, sr_, en_)                         \
+        lcur = l_;                                           \
+        const uint4 dl_ = dn;                                \
+        dn = steps[st0 + (t_) + 6];                          \
+        LT_LOAD(dl_, sr_, en_)                               \
+        l_ = dl_.z;                                          \
+    }
+    for (uint32_t t = 0; t < st1 - st0; t += 4) {
+        LT_STEP(t, sr1, en1, l1)
+        LT_STEP(t + 1, sr2, en2, l2)
+        LT_STEP(t + 2, sr3, en3, l3)
+        LT_STEP(t + 3, sr0, en0, l0)
+    }
+#undef LT_STEP
+#undef LT_PROCESS
+#undef LT_STORE
+#undef LT_LOAD
+    __syncthreads();
+    for (uint32_t i = tid; i < rows_per_chunk && row0 + i < n; i += 1024) agg[row0 + i] = acc[i];
 }
 
 // ------------------------------------------------------------------ degree-sorted tile order
@@ -1326,11 +1557,11 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
     switch (sp.variant * 2 + (mfma ? 1 : 0)) {
     case 0:
         hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, false>), grid, block, 0, stream, g, ws, in, out, P,
-                           row_lo, row_hi, g.rowptr, g.col, nofloat, long_thresh, il);
+                           row_lo, row_hi, g.rowptr, g.col, nofloat, long_thresh, il, (const uint32_t *)nullptr);
         break;
     case 1:
         hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, true>), grid, block, 0, stream, g, ws, in, out, P,
-                           row_lo, row_hi, g.rowptr, g.col, nofloat, long_thresh, il);
+                           row_lo, row_hi, g.rowptr, g.col, nofloat, long_thresh, il, (const uint32_t *)nullptr);
         break;
 #define GNNVC_LAUNCH_F16(N2_, N3_, SIG_, MF_, SRT_, LG_)                                              \
     hipLaunchKernelGGL((k_stage_f16<32, N2_, N3_, SIG_, 2, MF_, SRT_>), grid, block, 0, stream, g, ws, in4, out, \
@@ -1452,10 +1683,78 @@ hipError_t launch_stage0_blocked(const StagePlan &sp, const GraphDev &g, float w
     const dim3 grid(blocks_per_xcd * 8), block(kBlock);
     if (mfma)
         hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, true>), grid, block, 0, stream, g, ws, x, out,
-                           params + sp.param_offset, row_lo, row_hi, ep, colb, acc_in, long_thresh, interleave ? 1 : 0);
+                           params + sp.param_offset, row_lo, row_hi, ep, colb, acc_in, long_thresh, interleave ? 1 : 0,
+                           (const uint32_t *)nullptr);
     else
         hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, false>), grid, block, 0, stream, g, ws, x, out,
-                           params + sp.param_offset, row_lo, row_hi, ep, colb, acc_in, long_thresh, interleave ? 1 : 0);
+                           params + sp.param_offset, row_lo, row_hi, ep, colb, acc_in, long_thresh, interleave ? 1 : 0,
+                           (const uint32_t *)nullptr);
+    return hipGetLastError();
+}
+
+// ---- LDS-table plan of the F = 1 stage ----------------------------------------------------
+uint32_t lds_table_max_rows() { return kLtMaxRows; }
+uint32_t lds_table_block() { return kLtBlock; }
+
+hipError_t lds_table_bytes(const uint32_t *w, uint32_t n, uint8_t *wb, uint32_t *bad, hipStream_t stream) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_lt_bytes, dim3((n + 255) / 256), dim3(256), 0, stream, w, n, wb, bad);
+    return hipGetLastError();
+}
+
+hipError_t lds_table_count(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t *seg_cnt,
+                           uint32_t *bad, hipStream_t stream) {
+    if (nblocks > 4096) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_lt_count, dim3(nchunks), dim3(1024), 0, stream, g, rows_per_chunk, nblocks, seg_cnt, bad);
+    return hipGetLastError();
+}
+
+hipError_t lds_table_steps(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, const uint32_t *seg_cnt,
+                           const uint32_t *step_ptr, uint32_t *step_count, void *steps, bool write, hipStream_t stream) {
+    hipLaunchKernelGGL(k_lt_steps, dim3((nchunks + 255) / 256), dim3(256), 0, stream, g, rows_per_chunk, nchunks, nblocks,
+                       seg_cnt, step_ptr, step_count, reinterpret_cast<uint4 *>(steps), write ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks,
+                             const uint32_t *seg_cnt, uint32_t *entries, hipStream_t stream) {
+    hipLaunchKernelGGL(k_lt_scatter, dim3(nchunks), dim3(1024), 0, stream, g, rows_per_chunk, nblocks, seg_cnt, entries);
+    return hipGetLastError();
+}
+
+hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *x,
+                                   float *out, uint32_t row_lo, uint32_t row_hi, uint32_t rows_per_chunk,
+                                   const uint32_t *step_ptr, const void *steps, const uint32_t *entries, const uint8_t *wbyte,
+                                   float *acc, uint32_t *bad, uint32_t long_thresh, bool mfma, bool interleave,
+                                   hipStream_t stream) {
+    if (row_hi <= row_lo) return hipSuccess;
+    if (sp.variant != 0 || rows_per_chunk == 0 || rows_per_chunk > kLtMaxRows || g.nnz == 0) return hipErrorInvalidValue;
+    // does this forward's input match the table?  decided on the device: no host round trip
+    hipError_t rc = hipMemsetAsync(bad, 0, sizeof(uint32_t), stream);
+    if (rc != hipSuccess) return rc;
+    hipLaunchKernelGGL(k_lt_check_x, dim3(std::min<unsigned>((g.n + 255) / 256, 4096u)), dim3(256), 0, stream, x, g.w, ws, g.n,
+                       bad);
+    const uint32_t c0 = row_lo / rows_per_chunk, c1 = (row_hi - 1) / rows_per_chunk;
+    constexpr size_t lds = (size_t)kLtMaxRows * 4 + 1024 + 2 * kLtStep * 4 + 2 * kLtBlock;
+    static_assert(lds <= 160 * 1024, "LDS budget of k_lt_agg");
+    static bool attr_set = false;
+    if (!attr_set) {
+        rc = hipFuncSetAttribute(reinterpret_cast<const void *>(k_lt_agg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (rc != hipSuccess) return rc;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_lt_agg, dim3(c1 - c0 + 1), dim3(1024), lds, stream, step_ptr, reinterpret_cast<const uint4 *>(steps),
+                       entries, wbyte, ws, acc, g.n, rows_per_chunk, c0, (uint32_t)(g.nnz - 1), bad);
+    const uint32_t ntiles = (row_hi - row_lo + kWave - 1) / kWave;
+    const uint32_t per_xcd = (ntiles + 7) / 8;
+    const uint32_t blocks_per_xcd = (per_xcd + kWavesPerBlock - 1) / kWavesPerBlock;
+    const dim3 grid(blocks_per_xcd * 8), block(kBlock);
+    if (mfma)
+        hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, true>), grid, block, 0, stream, g, ws, x, out, params + sp.param_offset,
+                           row_lo, row_hi, g.rowptr, g.col, acc, long_thresh, interleave ? 1 : 0, (const uint32_t *)bad);
+    else
+        hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, false>), grid, block, 0, stream, g, ws, x, out, params + sp.param_offset,
+                           row_lo, row_hi, g.rowptr, g.col, acc, long_thresh, interleave ? 1 : 0, (const uint32_t *)bad);
     return hipGetLastError();
 }
 

@@ -70,6 +70,11 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
 /* Tuning options (take effect at the next graph upload / attach):
  *   "blocked_stage0" 0|1  column-blocked plan of the F = 1 stage (default 1; results are
  *                         bit-identical either way, it only changes memory traffic)
+ *   "lds_table"      0|1|2  LDS-table plan of the F = 1 stage: when every weight fits a byte and the
+ *                         input is x[v] = (float)W(v)/ws (checked on the device at every forward), the
+ *                         neighbour values are read from byte slices held in LDS instead of gathered from
+ *                         memory (default 1 = large, non-skewed graphs; 2 = any large graph; 0 = off).
+ *                         Takes precedence over "blocked_stage0"; bit-identical results
  *   "block_cols"     n    vertices per column block (default 524288 = 2 MiB of x)
  *   "blocked_min_n"  n    graphs with fewer vertices are not blocked (default 2^20)
  *   "long_row_threshold" d  rows of degree >= d get a workgroup of their own (default 512,
@@ -82,7 +87,7 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *                         would spend more than twice the useful gather rounds, the default)
  *   "sorted_min_nnz" n     in auto mode, graphs with fewer adjacency entries keep natural tiles
  *                         (default 4 Mi: the sort costs more than it saves on a graph used once)
- * gnnvc_get_info keys: "mfma_dense", "sorted_tiles_active", "tile_waste_x100", "blocked_stage0_active", "blocked_blocks", "block_cols", "long_rows",
+ * gnnvc_get_info keys: "lds_table_active", "lds_table_chunks", "lds_table_steps", "mfma_dense", "sorted_tiles_active", "tile_waste_x100", "blocked_stage0_active", "blocked_blocks", "block_cols", "long_rows",
  * "long_row_threshold". */
 int gnnvc_set_option(gnnvc_engine *e, const char *key, long value);
 int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value);

@@ -126,7 +126,9 @@ def test_deterministic_and_plan_invariant(big):
     eng.forward_device(big["x"].data_ptr(), sc.data_ptr(), lg.data_ptr())
     eng.synchronize()
     assert torch.equal(lg.view(torch.int32), ref_lg.view(torch.int32))
-    plans = [{"blocked_stage0": 0, "mfma_dense": 0}, {"block_cols": 1 << 21, "mfma_dense": 2, "blocked_stage0": 2}]
+    # (the stage-0 plans are built on a graph's second forward: every engine below runs two)
+    plans = [{"blocked_stage0": 0, "lds_table": 0, "mfma_dense": 0},
+             {"block_cols": 1 << 21, "mfma_dense": 2, "blocked_stage0": 2, "lds_table": 0}, {"lds_table": 2}]
     if big["name"] == "er10m":
         plans.append({"mfma_dense": 1, "long_row_threshold": 40})
     else:   # skewed graphs: other long-row thresholds, forced sorted tiles with a low threshold
@@ -139,11 +141,17 @@ def test_deterministic_and_plan_invariant(big):
             e2.set_weight_scale(g.ws)
             e2.attach_graph_device(g.n, g.nnz, g.rowptr.data_ptr(), g.col.data_ptr(), g.w.data_ptr(),
                                    g.nw.data_ptr(), keepalive=g)
-            lg.zero_()
-            torch.cuda.synchronize()
-            e2.forward_device(big["x"].data_ptr(), sc.data_ptr(), lg.data_ptr())
-            e2.synchronize()
-            assert torch.equal(lg.view(torch.int32), ref_lg.view(torch.int32)), opts
+            for _ in range(2):
+                lg.zero_()
+                torch.cuda.synchronize()
+                e2.forward_device(big["x"].data_ptr(), sc.data_ptr(), lg.data_ptr())
+                e2.synchronize()
+                assert torch.equal(lg.view(torch.int32), ref_lg.view(torch.int32)), opts
+            if big["name"] == "er10m":      # the plan the options ask for really ran (long rows rule the LDS table out)
+                want_lt = 1 if (opts.get("lds_table", 1) and "long_row_threshold" not in opts) else 0
+                assert e2.get_info("lds_table_active") == want_lt, opts
+                if opts.get("blocked_stage0") == 2:
+                    assert e2.get_info("blocked_stage0_active") == 1, opts
         finally:
             e2.close()
 

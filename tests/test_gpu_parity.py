@@ -376,6 +376,7 @@ def test_blocked_stage0_is_bit_identical(model_text, oracle_model, block_cols):
         e.set_option("blocked_min_n", 0)
         e.set_option("block_cols", block_cols)
         e.set_option("blocked_stage0", 2)      # also on the skewed sample graphs (off there by default)
+        e.set_option("lds_table", 0)           # (the LDS-table plan would take precedence; it has its own test)
         graphs = [gg.erdos_renyi(5000, 40000, 31), gg.hub_graph(20000, 60000, 3, 4096, seed=7),
                   gg.rmat(11, 8, 3), gg.from_edge_list(130, [(0, i) for i in range(1, 40)], list(range(20, 150)))]
         for g in graphs:
@@ -430,6 +431,101 @@ def test_unsorted_adjacency_falls_back_to_stored_order(model_text, oracle_model)
         # and the order does matter: the sorted graph gives (slightly) different logits
         oracle_model.set_weight_scale(g.ws)
         assert not np.array_equal(bits(want), bits(oracle_model.logits(g)))
+    finally:
+        e.close()
+
+
+# ---------------------------------------------------------------- LDS-table plan of the F = 1 stage
+
+def _dense_graph(n, deg, seed):
+    """Every row has ~deg neighbours inside one or two column blocks: long runs per (row, block)."""
+    return gg.erdos_renyi(n, n * deg // 2, seed)
+
+
+@pytest.mark.parametrize("maker,force", [
+    (lambda: gg.erdos_renyi(20000, 200000, 61), 1),
+    (lambda: gg.erdos_renyi(70000, 400000, 62), 1),                    # three column blocks of 32768
+    (lambda: _dense_graph(3000, 300, 63), 1),                          # runs of ~300 entries, cut by the 2048-entry steps
+    (lambda: gg.hub_graph(20000, 60000, 3, 4096, seed=7), 2),          # forced on a skewed graph: 4096-entry runs
+    (lambda: gg.from_edge_list(130, [(0, i) for i in range(1, 40)], list(range(20, 150))), 1),
+    (lambda: gg.from_edge_list(5, [], [20, 30, 40, 50, 60]), 1),       # no entries at all: the plan steps aside
+])
+def test_lds_table_plan_is_bit_identical(model_text, oracle_model, maker, force):
+    """k_lt_*: neighbour values come from byte slices of the weight table held in LDS, entries regrouped by
+    column block — every row is still summed in stored order, so the logits do not move by a bit."""
+    import torch
+    import gnn_mwvc_amd as G
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_option("blocked_min_n", 0)
+        e.set_option("lds_table", force)
+        e.set_option("blocked_stage0", 0)
+        if force == 2:
+            e.set_option("long_row_threshold", 0)      # the plan does not combine with the long-row kernels
+        g = maker()
+        e.set_weight_scale(g.ws)
+        oracle_model.set_weight_scale(g.ws)
+        e.upload_graph(g)
+        _, first = e.forward(g.x())
+        assert e.get_info("lds_table_active") == 0     # built lazily, on the second forward over the same graph
+        _, logits = e.forward(g.x())
+        assert e.get_info("lds_table_active") == (1 if g.nnz else 0)
+        assert np.array_equal(bits(first), bits(logits))
+        assert np.array_equal(bits(logits[:, 0]), bits(oracle_model.logits(g)))
+        if not g.nnz:
+            return
+        assert e.get_info("lds_table_steps") >= 4 * e.get_info("lds_table_chunks")
+        # row sub-ranges through the stage entry point (chunks that straddle the cut are computed twice)
+        dev = torch.device("cuda:0")
+        x = torch.from_numpy(g.x()).to(dev)
+        h1 = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        mid = (g.n // 3) // 64 * 64
+        for lo, hi in ((mid, g.n), (0, mid)):
+            e.stage_forward_device(0, lo, hi, x.data_ptr(), h1.data_ptr())
+        e.synchronize()
+        want_h1 = oracle_model.predict(g, g.x(), stop_after=6)
+        assert np.array_equal(bits(h1[:-1].cpu().numpy()), bits(want_h1))
+        # an input that is NOT W / ws: the device-side check sends every row down the plain gather
+        rng = np.random.default_rng(5)
+        x2 = rng.uniform(0.1, 1.0, size=(g.n, 1)).astype(np.float32)
+        _, lg2 = e.forward(x2)
+        assert e.get_info("lds_table_active") == 1
+        assert np.array_equal(bits(lg2[:, 0]), bits(oracle_model.predict(g, x2, stop_after=oracle_model.n_layers - 2)[:, 0]))
+        x3 = g.x().copy()
+        x3[g.n // 2] = np.nextafter(x3[g.n // 2], np.float32(2))           # one ulp off in one place is enough
+        _, lg3 = e.forward(x3)
+        assert np.array_equal(bits(lg3[:, 0]), bits(oracle_model.predict(g, x3, stop_after=oracle_model.n_layers - 2)[:, 0]))
+        _, back = e.forward(g.x())                                        # and the plan is used again afterwards
+        assert np.array_equal(bits(back), bits(logits))
+    finally:
+        e.close()
+
+
+def test_lds_table_plan_steps_aside(model_text, oracle_model):
+    """Weights above 255, descending adjacency lists, long rows: the plan must not be used."""
+    import gnn_mwvc_amd as G
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_option("blocked_min_n", 0)
+        e.set_option("blocked_stage0", 0)
+        g = gg.erdos_renyi(6000, 40000, 64)
+        big_w = gg.CsrGraph(g.n, g.rowptr, g.col, g.w * 3, gg.neighbourhood_weights(g.rowptr, g.col, g.w * 3))
+        g7 = gg.erdos_renyi(70000, 300000, 65)          # three column blocks: descending lists visit them backwards
+        rp = g7.rowptr.astype(np.int64)
+        col = g7.col.copy()
+        for u in range(g7.n):
+            col[rp[u]:rp[u + 1]] = col[rp[u]:rp[u + 1]][::-1]
+        unsorted = gg.CsrGraph(g7.n, g7.rowptr, col, g7.w, g7.nw)
+        hubs = gg.hub_graph(20000, 60000, 3, 4096, seed=7)
+        for gr in (big_w, unsorted, hubs):
+            e.set_weight_scale(gr.ws)
+            oracle_model.set_weight_scale(gr.ws)
+            e.upload_graph(gr)
+            e.forward(gr.x())
+            _, logits = e.forward(gr.x())
+            assert e.get_info("lds_table_active") == 0
+            assert np.array_equal(bits(logits[:, 0]), bits(oracle_model.logits(gr)))
     finally:
         e.close()
 
