@@ -954,15 +954,16 @@ __global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ st
         const uint32_t *eb_ = ebuf0 + ((s_) & 1) * kLtStep;                               \
         const uint32_t i0_ = tid, i1_ = tid + 1024;                                       \
         const bool in0_ = i0_ < (len_), in1_ = i1_ < (len_);                              \
-        const uint32_t a0_ = eb_[in0_ ? i0_ : 0], a1_ = eb_[in1_ ? i1_ : 0];              \
-        const uint32_t b0_ = eb_[(in0_ && i0_) ? i0_ - 1 : 0], b1_ = eb_[in1_ ? i1_ - 1 : 0]; \
-        const uint32_t n0_ = eb_[(in0_ && i0_ + 1 < (len_)) ? i0_ + 1 : 0];               \
-        const uint32_t n1_ = eb_[(in1_ && i1_ + 1 < (len_)) ? i1_ + 1 : 0];               \
+        /* unconditional reads: slots past the step's end (and eb_[-1], eb_[2048]) hold stale */ \
+        /* but readable LDS words; what they yield is masked by in0_/in1_/h0_/h1_ below      */ \
+        const uint32_t a0_ = eb_[i0_], a1_ = eb_[i1_];                                    \
+        const uint32_t b0_ = eb_[(int)i0_ - 1], b1_ = eb_[i1_ - 1];                       \
+        const uint32_t n0_ = eb_[i0_ + 1], n1_ = eb_[i1_ + 1];                            \
         const uint32_t r0_ = a0_ >> 17, r1_ = a1_ >> 17;                                  \
         const bool h0_ = in0_ && (i0_ == 0 || (b0_ >> 17) != r0_);                        \
         const bool h1_ = in1_ && (b1_ >> 17) != r1_;                                      \
-        const float v0_ = lut[slice_[a0_ & 0x1FFFF]], v1_ = lut[slice_[a1_ & 0x1FFFF]];   \
-        const float c0_ = acc[r0_], c1_ = acc[r1_];                                       \
+        const float v0_ = lut[slice_[a0_ & (kLtBlock - 1)]], v1_ = lut[slice_[a1_ & (kLtBlock - 1)]]; \
+        const float c0_ = acc[r0_ < kLtMaxRows ? r0_ : 0], c1_ = acc[r1_ < kLtMaxRows ? r1_ : 0]; \
         const bool more0_ = h0_ && i0_ + 1 < (len_) && (n0_ >> 17) == r0_;                \
         const bool more1_ = h1_ && i1_ + 1 < (len_) && (n1_ >> 17) == r1_;                \
         float s0_ = c0_ + v0_, s1_ = c1_ + v1_;                                           \
@@ -973,34 +974,38 @@ __global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ st
         if (h0_) acc[r0_] = s0_;                                                          \
         if (h1_) acc[r1_] = s1_;                                                          \
     }
+    // One loop does everything, warm-up included: at time u the workgroup processes step u (if u >= 0),
+    // moves step u + 1 from its ring slot to LDS and refills that slot with step u + 5.  The loads are
+    // unconditional and come in the same order on every trip (u starts at -8 with clamped, useless loads),
+    // so the compiler's load counters stay exact: a store waits for the loads of four steps ago and
+    // nothing younger.  (With a separate prologue the counters merged pessimistically at the loop head
+    // and every fourth step drained all loads in flight.)
     u32x4 sr0[SW], sr1[SW], sr2[SW], sr3[SW];
     uint32_t en0[J], en1[J], en2[J], en3[J];
-    uint32_t l0, l1, l2, l3;                       // lengths of the steps whose data sit in ring slots 0..3
-    uint4 dn;
-    dn = steps[st0];     LT_LOAD(dn, sr0, en0) l0 = dn.z;
-    LT_STORE(0, sr0, en0)
-    dn = steps[st0 + 1]; LT_LOAD(dn, sr1, en1) l1 = dn.z;
-    dn = steps[st0 + 2]; LT_LOAD(dn, sr2, en2) l2 = dn.z;
-    dn = steps[st0 + 3]; LT_LOAD(dn, sr3, en3) l3 = dn.z;
-    uint32_t lcur = l0;                            // length of the step about to be processed
-    dn = steps[st0 + 4]; LT_LOAD(dn, sr0, en0) l0 = dn.z;
-    dn = steps[st0 + 5];                           // descriptor of the next load, fetched a whole step early
-#define LT_STEP(t_, sr_, en_, l_)                            \
-    {                                                        \
-        __syncthreads();                                     \
-        LT_PROCESS((t_), lcur)                               \
-        LT_STORE((t_) + 1, sr_, en_)                         \
-        lcur = l_;                                           \
-        const uint4 dl_ = dn;                                \
-        dn = steps[st0 + (t_) + 6];                          \
-        LT_LOAD(dl_, sr_, en_)                               \
-        l_ = dl_.z;                                          \
+    uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0;       // lengths of the steps whose data sit in ring slots 0..3
+    const int nsteps = (int)(st1 - st0);
+    uint32_t lcur = 0;                             // length of the step about to be processed
+    uint4 dn = steps[st0];                         // descriptor of the next step to load (u + 5 clamped to 0)
+#define LT_STEP(u_, sr_, en_, l_)                                        \
+    {                                                                    \
+        if ((u_) >= 0) {                                                 \
+            __syncthreads();                                             \
+            LT_PROCESS((u_), lcur)                                       \
+        }                                                                \
+        LT_STORE((u_) + 1, sr_, en_)                                     \
+        lcur = l_;                                                       \
+        const uint4 dl_ = dn;                                            \
+        const int nx_ = (u_) + 6;                                        \
+        dn = steps[st0 + (uint32_t)(nx_ > 0 ? nx_ : 0)];                 \
+        LT_LOAD(dl_, sr_, en_)                                           \
+        l_ = ((u_) + 5 >= 0) ? dl_.z : 0u;                               \
     }
-    for (uint32_t t = 0; t < st1 - st0; t += 4) {
-        LT_STEP(t, sr1, en1, l1)
-        LT_STEP(t + 1, sr2, en2, l2)
-        LT_STEP(t + 2, sr3, en3, l3)
-        LT_STEP(t + 3, sr0, en0, l0)
+    // ring slot of step s is s & 3; at time u the slot of step u + 1 is stored and refilled
+    for (int u = -8; u < nsteps; u += 4) {
+        LT_STEP(u, sr1, en1, l1)
+        LT_STEP(u + 1, sr2, en2, l2)
+        LT_STEP(u + 2, sr3, en3, l3)
+        LT_STEP(u + 3, sr0, en0, l0)
     }
 #undef LT_STEP
 #undef LT_PROCESS
@@ -1015,18 +1020,31 @@ __global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ st
 // lockstep cost of natural tiles: sum over tiles of the tile's largest (non-long) degree
 __global__ __launch_bounds__(256) void k_tile_waste(GraphDev g, uint32_t row_lo, uint32_t row_hi,
                                                     uint32_t long_thresh, unsigned long long *__restrict__ sum_max) {
-    const uint32_t u = row_lo + blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t d = 0;
-    if (u < row_hi) {
-        d = g.rowptr[u + 1] - g.rowptr[u];
-        if (d >= long_thresh) d = 0;
-    }
+    // one wave = one 64-row tile per trip; per-wave sums, one atomic per block (every wave hitting the
+    // same 8 bytes with its own atomic cost 1.9 ms on the metric graph)
+    __shared__ unsigned long long part[4];
+    unsigned long long mine = 0;
+    const uint32_t ntiles = (row_hi - row_lo + 63) / 64;
+    for (uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6); t < ntiles; t += gridDim.x * 4) {
+        const uint32_t u = row_lo + t * 64 + (threadIdx.x & 63);
+        uint32_t d = 0;
+        if (u < row_hi) {
+            d = g.rowptr[u + 1] - g.rowptr[u];
+            if (d >= long_thresh) d = 0;
+        }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint32_t o = __shfl_xor(d, off);
-        d = o > d ? o : d;
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o = __shfl_xor(d, off);
+            d = o > d ? o : d;
+        }
+        mine += d;
     }
-    if ((threadIdx.x & 63) == 0 && d) atomicAdd(sum_max, (unsigned long long)d);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long s = part[0] + part[1] + part[2] + part[3];
+        if (s) atomicAdd(sum_max, s);
+    }
 }
 
 // histogram of min(degree, bins - 1) over the non-long rows of [row_lo, row_hi)
@@ -1763,8 +1781,8 @@ hipError_t measure_tile_waste(const GraphDev &g, uint32_t row_lo, uint32_t row_h
                               unsigned long long *sum_max, hipStream_t stream) {
     hipError_t rc = hipMemsetAsync(sum_max, 0, sizeof(unsigned long long), stream);
     if (rc != hipSuccess || row_hi <= row_lo) return rc;
-    hipLaunchKernelGGL(k_tile_waste, dim3((row_hi - row_lo + 255) / 256), dim3(256), 0, stream, g, row_lo, row_hi,
-                       long_thresh, sum_max);
+    hipLaunchKernelGGL(k_tile_waste, dim3(std::min<unsigned>((row_hi - row_lo + 255) / 256, 2048u)), dim3(256), 0, stream, g,
+                       row_lo, row_hi, long_thresh, sum_max);
     return hipGetLastError();
 }
 
