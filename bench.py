@@ -75,6 +75,7 @@ def main() -> int:
     ap.add_argument("--workload", default="er10m", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lds-table", action="store_true", help="F = 1 stage without the LDS-table plan")
+    ap.add_argument("--no-compact", action="store_true", help="16-wide stages without the compact-table plan")
     ap.add_argument("--cpu-sample", default="2000000x20000000",
                     help="n x m of the CPU-baseline sample graph")
     ap.add_argument("--no-blocked", action="store_true", help="disable the column-blocked F=1 stage (A/B)")
@@ -134,6 +135,8 @@ def main() -> int:
         eng.set_option("blocked_stage0", 0)
     if args.no_lds_table:
         eng.set_option("lds_table", 0)
+    if args.no_compact:
+        eng.set_option("compact_gather", 0)
     if args.block_cols:
         eng.set_option("block_cols", args.block_cols)
     if args.long_threshold >= 0:
@@ -249,7 +252,8 @@ def main() -> int:
                      "forward_bytes": fwd_bytes,
                      "forward_frac": fwd_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world},
         "stage_ms": stage_ms, "graph_build_s": t_gen, "graph_attach_s": t_attach,
-        "plan": {"lds_table_stage0": bool(eng.get_info("lds_table_active")),
+        "plan": {"compact_gather_f16": bool(eng.get_info("compact_gather_active")),
+                 "lds_table_stage0": bool(eng.get_info("lds_table_active")),
                  "blocked_stage0": bool(eng.get_info("blocked_stage0_active")),
                  "column_blocks": eng.get_info("blocked_blocks"), "block_cols": eng.get_info("block_cols"),
                  "mfma_dense": eng.get_info("mfma_dense"),

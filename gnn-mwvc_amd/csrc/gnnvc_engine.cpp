@@ -124,6 +124,16 @@ struct gnnvc_engine {
     DevBuf<uint8_t> lt_bytes;
     DevBuf<uint32_t> lt_entries, lt_segcnt, lt_stepptr, lt_stepcnt, lt_bad;
     DevBuf<uint4> lt_steps;
+    // compact-table plan of the 16-wide stages (built like the LDS-table plan, on the graph's second forward)
+    int opt_compact = 1;            // 0 = off, 1 = when it applies, 2 = also on skewed graphs
+    bool c4_ready = false, c4_tried = false;
+    uint32_t c4_rows = 0, c4_chunks = 0, c4_steps_total = 0;
+    DevBuf<uint32_t> c4_entries, c4_segcnt, c4_stepptr, c4_stepcnt, c4_desc;
+    DevBuf<uint4> c4_steps;
+    DevBuf<float> c4_table, c4_acc, c4_agg16;
+    DevBuf<uint32_t> c4_dirty;
+    uint32_t c4_dirty_cap = 0;
+    DevBuf<unsigned long long> c4_counts;
 
     // option "mfma_dense": dense layers on the matrix cores (bit-identical to the VALU path).
     // 0 = VALU everywhere, 1 = MFMA everywhere, 2 = MFMA in the F = 16 stages only (default:
@@ -494,7 +504,7 @@ int build_lds_table(gnnvc_engine *e) {
     HIP_TRY(e, hipMemsetAsync(flag, 0, sizeof(uint32_t), e->stream));
     HIP_TRY(e, hipMemsetAsync(e->lt_bytes.p + g.n, 0, 64, e->stream));
     HIP_TRY(e, gnnvc::lds_table_bytes(g.w, g.n, e->lt_bytes.p, flag, e->stream));
-    HIP_TRY(e, gnnvc::lds_table_count(g, rows, chunks, nblocks, e->lt_segcnt.p, flag, e->stream));
+    HIP_TRY(e, gnnvc::lds_table_count(g, rows, chunks, nblocks, bc, e->lt_segcnt.p, flag, e->stream));
     HIP_TRY(e, gnnvc::lds_table_steps(g, rows, chunks, nblocks, e->lt_segcnt.p, nullptr, e->lt_stepcnt.p, nullptr, false, e->stream));
     HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, e->lt_stepcnt.p, chunks * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipMemcpyAsync(e->pin_small.p + chunks, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
@@ -515,13 +525,75 @@ int build_lds_table(gnnvc_engine *e) {
     HIP_TRY(e, hipMemcpyAsync(e->lt_stepptr.p, e->pin_small.p, ptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipMemsetAsync(e->lt_steps.p + total, 0, 8 * sizeof(uint4), e->stream));
     HIP_TRY(e, gnnvc::lds_table_steps(g, rows, chunks, nblocks, e->lt_segcnt.p, e->lt_stepptr.p, nullptr, e->lt_steps.p, true, e->stream));
-    HIP_TRY(e, gnnvc::lds_table_scatter(g, rows, chunks, nblocks, e->lt_segcnt.p, e->lt_entries.p, e->stream));
+    HIP_TRY(e, gnnvc::lds_table_scatter(g, rows, chunks, nblocks, bc, e->lt_segcnt.p, e->lt_entries.p, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));   // pin_small is reused by others
     e->lt_rows = rows;
     e->lt_chunks = chunks;
     e->lt_blocks = nblocks;
     e->lt_steps_total = (uint32_t)total;
     e->lt_ready = true;
+    return GNNVC_OK;
+}
+
+// Compact-table plan of the 16-wide stages (kernels: k_c4_*): the same (chunk, column block, step) layout
+// as the LDS-table plan at 2 MiB column blocks.  Whether a forward's input really has at most four live
+// columns is decided on the device at every launch (k_c4_choose / k_c4_compact).
+int build_compact(gnnvc_engine *e) {
+    e->c4_ready = false;
+    e->c4_tried = true;
+    const GraphDev &g = e->g;
+    if (!e->opt_compact || e->stages.size() < 2) return GNNVC_OK;
+    for (size_t st = 1; st < e->stages.size(); ++st)
+        if (e->stages[st].f != 16) return GNNVC_OK;
+    if (g.n < e->opt_blocked_min_n || g.nnz == 0 || g.nnz >= (1ull << 31)) return GNNVC_OK;
+    if (e->opt_compact < 2 && (e->sorted_wanted || e->n_long > 0)) return GNNVC_OK;
+    if (e->n_long > 0) return GNNVC_OK;   // (the long-row kernels write their rows themselves)
+    const uint32_t bc = gnnvc::compact_block(), max_rows = gnnvc::compact_max_rows();
+    const uint32_t nblocks = (g.n + bc - 1) / bc;
+    if (nblocks > 4096) return GNNVC_OK;
+    uint32_t chunks = (g.n + max_rows - 1) / max_rows;
+    chunks = (chunks + 255u) / 256u * 256u;
+    const uint32_t rows = (g.n + chunks - 1) / chunks;
+    chunks = (g.n + rows - 1) / rows;
+    HIP_TRY(e, e->c4_desc.reserve(8));
+    HIP_TRY(e, e->c4_counts.reserve(16));
+    HIP_TRY(e, e->c4_segcnt.reserve((size_t)chunks * nblocks));
+    HIP_TRY(e, e->c4_stepcnt.reserve(chunks));
+    HIP_TRY(e, e->c4_stepptr.reserve((size_t)chunks + 1));
+    HIP_TRY(e, e->pin_small.reserve((size_t)chunks + 2));
+    uint32_t *flag = e->c4_desc.p + 7;
+    HIP_TRY(e, hipMemsetAsync(e->c4_desc.p, 0, 8 * sizeof(uint32_t), e->stream));
+    HIP_TRY(e, gnnvc::lds_table_count(g, rows, chunks, nblocks, bc, e->c4_segcnt.p, flag, e->stream));
+    HIP_TRY(e, gnnvc::lds_table_steps(g, rows, chunks, nblocks, e->c4_segcnt.p, nullptr, e->c4_stepcnt.p, nullptr, false, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, e->c4_stepcnt.p, chunks * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->pin_small.p + chunks, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (e->pin_small.p[chunks]) return GNNVC_OK;   // an unsorted row: regrouping by block would change the order of its sum
+    std::vector<uint32_t> ptr((size_t)chunks + 1, 0);
+    uint64_t total = 0;
+    for (uint32_t c = 0; c < chunks; ++c) {
+        ptr[c] = (uint32_t)total;
+        total += e->pin_small.p[c];
+    }
+    if (total + 8 >= (1ull << 31)) return GNNVC_OK;
+    ptr[chunks] = (uint32_t)total;
+    HIP_TRY(e, e->c4_steps.reserve(total + 8));
+    HIP_TRY(e, e->c4_entries.reserve(g.nnz));
+    HIP_TRY(e, e->c4_table.reserve(((size_t)g.n + 1) * 4));
+    HIP_TRY(e, e->c4_acc.reserve((size_t)g.n * 4));
+    e->c4_dirty_cap = std::max<uint32_t>(g.n / 4, 1024u);   // rows recomputed from full rows; beyond that the stage kernel gathers
+    HIP_TRY(e, e->c4_dirty.reserve(e->c4_dirty_cap));
+    HIP_TRY(e, e->c4_agg16.reserve((size_t)e->c4_dirty_cap * 16));
+    std::memcpy(e->pin_small.p, ptr.data(), ptr.size() * sizeof(uint32_t));
+    HIP_TRY(e, hipMemcpyAsync(e->c4_stepptr.p, e->pin_small.p, ptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipMemsetAsync(e->c4_steps.p + total, 0, 8 * sizeof(uint4), e->stream));
+    HIP_TRY(e, gnnvc::lds_table_steps(g, rows, chunks, nblocks, e->c4_segcnt.p, e->c4_stepptr.p, nullptr, e->c4_steps.p, true, e->stream));
+    HIP_TRY(e, gnnvc::lds_table_scatter(g, rows, chunks, nblocks, bc, e->c4_segcnt.p, e->c4_entries.p, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    e->c4_rows = rows;
+    e->c4_chunks = chunks;
+    e->c4_steps_total = (uint32_t)total;
+    e->c4_ready = true;
     return GNNVC_OK;
 }
 
@@ -559,7 +631,22 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
         const bool mfma = e->opt_mfma == 1 || (e->opt_mfma == 2 && e->stages[stage].f == 16);
         gnnvc::SortedOrder so;
         const gnnvc::SortedOrder *sop = nullptr;
+        const float *acc4 = nullptr;
+        const uint32_t *c4desc = nullptr;
         if (e->stages[stage].f == 16) {
+            if (e->graph_uses >= 2 && !e->c4_tried) {
+                int rc = build_compact(e);
+                if (rc) return rc;
+            }
+            // worth its fixed cost (count + compact the whole input) only when this call covers most of the rows
+            if (e->c4_ready && !longs && (uint64_t)(hi - lo) * 2 >= e->g.n) {
+                HIP_TRY(e, gnnvc::column_counts(in, e->g.n, e->c4_counts.p, e->stream));
+                HIP_TRY(e, gnnvc::launch_compact_gather(e->g, in, e->c4_counts.p, e->c4_desc.p, e->c4_table.p, e->c4_acc.p, lo, hi,
+                                                        e->c4_rows, e->c4_stepptr.p, e->c4_steps.p, e->c4_entries.p,
+                                                        e->c4_dirty.p, e->c4_dirty_cap, e->c4_agg16.p, e->stream));
+                acc4 = e->c4_acc.p;
+                c4desc = e->c4_desc.p;
+            }
             int rc = ensure_sorted(e, lo, hi);
             if (rc) return rc;
             if (e->sorted_use) {
@@ -570,7 +657,7 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
             }
         }
         HIP_TRY(e, gnnvc::launch_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi,
-                                       thr, mfma, sop, e->interleave, e->stream));
+                                       thr, mfma, sop, e->interleave, e->stream, acc4, c4desc, e->c4_agg16.p));
     }
     if (longs) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));   // join
     return GNNVC_OK;
@@ -707,6 +794,9 @@ void gnnvc_destroy(gnnvc_engine *e) {
     e->blk_acc.release();
     e->lt_bytes.release(); e->lt_entries.release(); e->lt_segcnt.release(); e->lt_stepptr.release();
     e->lt_stepcnt.release(); e->lt_bad.release(); e->lt_steps.release();
+    e->c4_entries.release(); e->c4_segcnt.release(); e->c4_stepptr.release(); e->c4_stepcnt.release();
+    e->c4_desc.release(); e->c4_steps.release(); e->c4_table.release(); e->c4_acc.release(); e->c4_counts.release();
+    e->c4_agg16.release(); e->c4_dirty.release();
     e->long_list.release(); e->long_count.release();
     e->pin_rowptr.release(); e->pin_col.release(); e->pin_w.release(); e->pin_nw.release();
     e->pin_small.release();
@@ -738,6 +828,7 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "block_cols") e->opt_block_cols = value > 0 ? (uint32_t)value : 0;
     else if (k == "blocked_min_n") e->opt_blocked_min_n = value > 0 ? (uint32_t)value : 0;
     else if (k == "long_row_threshold") e->opt_long_thresh = value > 0 ? (uint32_t)value : 0;
+    else if (k == "compact_gather") e->opt_compact = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else if (k == "lds_table") e->opt_lds_table = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else if (k == "sorted_min_nnz") e->opt_sorted_min_nnz = value > 0 ? (uint64_t)value : 0;
     else if (k == "sorted_long_row_threshold") e->opt_sorted_long_thresh = value > 0 ? (uint32_t)value : 1;
@@ -750,7 +841,20 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
 int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
     if (!e || !key || !value) return GNNVC_ERR_INVALID;
     const std::string k(key);
-    if (k == "lds_table_active") *value = e->lt_ready ? 1 : 0;
+    if (k == "compact_gather_active") *value = e->c4_ready ? 1 : 0;
+    else if (k == "compact_gather_chunks") *value = e->c4_ready ? (long)e->c4_chunks : 0;
+    else if (k == "compact_gather_last_ok" || k == "compact_gather_last_dirty") {
+        // what the device decided at the last launch of the plan (waits for the stream; for tests and tools)
+        *value = 0;
+        if (e->c4_ready && e->c4_desc.p) {
+            uint32_t d[8] = {0};
+            if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess ||
+                hipMemcpy(d, e->c4_desc.p, sizeof d, hipMemcpyDeviceToHost) != hipSuccess)
+                return GNNVC_ERR_DEVICE;
+            *value = k == "compact_gather_last_ok" ? (long)d[0] : (long)d[5];
+        }
+    }
+    else if (k == "lds_table_active") *value = e->lt_ready ? 1 : 0;
     else if (k == "lds_table_chunks") *value = e->lt_ready ? (long)e->lt_chunks : 0;
     else if (k == "lds_table_steps") *value = e->lt_ready ? (long)e->lt_steps_total : 0;
     else if (k == "blocked_stage0_active") *value = e->blocked_ready ? 1 : 0;
@@ -799,6 +903,7 @@ static int adopt_uploaded(gnnvc_engine *e, uint32_t n, uint64_t nnz) {
     int rc = reserve_features(e, n);
     if (rc) return rc;
     e->lt_ready = e->lt_tried = false;
+    e->c4_ready = e->c4_tried = false;
     e->blocked_ready = false;   // the column-blocked index is built on the graph's SECOND forward:
     e->blocked_tried = false;   // it costs about as much as it saves on one, and the reference's
     e->graph_uses = 0;          // driver uses every graph exactly once (src/GNN_VC.cpp:171-192)
@@ -941,6 +1046,7 @@ int gnnvc_attach_graph_device(gnnvc_engine *e, uint32_t n, uint64_t nnz, const u
     rc = reserve_features(e, n);
     if (rc) return rc;
     e->lt_ready = e->lt_tried = false;
+    e->c4_ready = e->c4_tried = false;
     e->blocked_ready = false;   // the column-blocked index is built on the graph's SECOND forward:
     e->blocked_tried = false;   // it costs about as much as it saves on one, and the reference's
     e->graph_uses = 0;          // driver uses every graph exactly once (src/GNN_VC.cpp:171-192)

@@ -46,7 +46,8 @@ int stage_variant(int f, int n1, int n2, int n3, int sigmoid_last);
 hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
                         const float *in, float *out, float *logits, uint32_t row_lo,
                         uint32_t row_hi, uint32_t long_thresh, bool mfma, const SortedOrder *so,
-                        bool interleave, hipStream_t stream);
+                        bool interleave, hipStream_t stream, const float *acc4 = nullptr,
+                        const uint32_t *c4desc = nullptr, const float *agg16 = nullptr);
 
 // Building blocks of the degree-sorted order (the prefix over the few thousand degree classes
 // is done on the host).
@@ -94,17 +95,26 @@ hipError_t launch_sgemm(int ta, int tb, uint32_t m, uint32_t n, uint32_t k, cons
 uint32_t lds_table_max_rows();
 uint32_t lds_table_block();
 hipError_t lds_table_bytes(const uint32_t *w, uint32_t n, uint8_t *wb, uint32_t *bad, hipStream_t stream);
-hipError_t lds_table_count(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t *seg_cnt,
-                           uint32_t *bad, hipStream_t stream);
+hipError_t lds_table_count(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t block_cols,
+                           uint32_t *seg_cnt, uint32_t *bad, hipStream_t stream);
 hipError_t lds_table_steps(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, const uint32_t *seg_cnt,
                            const uint32_t *step_ptr, uint32_t *step_count, void *steps, bool write, hipStream_t stream);
-hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks,
+hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t block_cols,
                              const uint32_t *seg_cnt, uint32_t *entries, hipStream_t stream);
 hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *x,
                                    float *out, uint32_t row_lo, uint32_t row_hi, uint32_t rows_per_chunk,
                                    const uint32_t *step_ptr, const void *steps, const uint32_t *entries, const uint8_t *wbyte,
                                    float *acc, uint32_t *bad, uint32_t long_thresh, bool mfma, bool interleave,
                                    hipStream_t stream);
+
+// compact-table plan of the 16-wide stages (see the k_c4_* kernels); the step layout is built with the
+// lds_table_* functions at compact_block() columns per block
+uint32_t compact_max_rows();
+uint32_t compact_block();
+hipError_t launch_compact_gather(const GraphDev &g, const float *in, const unsigned long long *counts, uint32_t *desc,
+                                 float *table, float *acc4, uint32_t row_lo, uint32_t row_hi, uint32_t rows_per_chunk,
+                                 const uint32_t *step_ptr, const void *steps, const uint32_t *entries, uint32_t *dirty_rows,
+                                 uint32_t dirty_cap, float *agg16, hipStream_t stream);
 
 hipError_t score_keys(const float *scores, size_t n, float *keys, uint8_t *above_half, hipStream_t stream);
 

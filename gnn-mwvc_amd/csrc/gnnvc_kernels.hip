@@ -246,11 +246,15 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
         GraphDev g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
         float *__restrict__ logits, const float *__restrict__ P, uint32_t row_lo,
         uint32_t row_hi, uint32_t long_thresh, const uint32_t *__restrict__ srt_vertex,
-        const uint4 *__restrict__ srt_meta, uint32_t n_sorted, int interleave) {
+        const uint4 *__restrict__ srt_meta, uint32_t n_sorted, int interleave,
+        const float4 *__restrict__ acc4, const uint32_t *__restrict__ c4desc, const float4 *__restrict__ agg16) {
     __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kRegionFloats];
     const int lane = threadIdx.x & 63;
     float *T = lds[threadIdx.x >> 6];
     uint32_t *stage = reinterpret_cast<uint32_t *>(T);
+    // compact-table plan (see k_c4_*): the aggregates of clean rows arrive as four sums in acc4
+    bool c4 = false;
+    if constexpr (!SORTED) c4 = acc4 != nullptr && c4desc[0] != 0;   // uniform
     const uint32_t ntiles = SORTED ? (n_sorted + kWave - 1) / kWave : (row_hi - row_lo + kWave - 1) / kWave;
     // natural order: XCD-contiguous ranges (locality).  Sorted order lists the heaviest tiles
     // first, so they are dealt round-robin instead — consecutive blocks sit on different XCDs
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
         const uint32_t c0 = __builtin_amdgcn_readfirstlane(rs);
         const uint32_t vend = (v0 + kWave < row_hi) ? v0 + kWave : row_hi;
         const uint32_t c1 = g.rowptr[vend];   // wave-uniform: end of the tile's last valid row
-        staged = (c1 - c0) <= kStageCap;
+        staged = !c4 && (c1 - c0) <= kStageCap;   // (with the compact table only the few dirty rows gather here)
         if (staged) sbase = stage_cols(g.col, c0, c1, stage, lane);
     }
 
@@ -318,6 +322,30 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
 #pragma unroll
     for (int p = 0; p < 4; ++p) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
     const uint32_t zrow = g.n;  // all-zero pad row: x + 0.0f == x exactly
+    if (c4) {
+        // this lane holds feature columns 4c .. 4c+3: which of them are table columns, and which slot
+        const uint32_t d0 = c4desc[1], d1 = c4desc[2], d2 = c4desc[3], d3 = c4desc[4];
+        int sel[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t col = 4 * c + t;
+            sel[t] = col == d0 ? 0 : col == d1 ? 1 : col == d2 ? 2 : col == d3 ? 3 : -1;
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float4 a = acc4[urow[p]];
+            const bool dirty = (__float_as_uint(a.x) >> 31) != 0;   // met a neighbour with stray non-zeros
+            if (!okrow[p]) continue;
+            if (!dirty) {
+                auto pick = [&](int j) { return j == 0 ? a.x : j == 1 ? a.y : j == 2 ? a.z : j == 3 ? a.w : 0.0f; };
+                acc[p] = make_float4(pick(sel[0]), pick(sel[1]), pick(sel[2]), pick(sel[3]));
+                e[p] = b[p];
+            } else if (__float_as_uint(a.y) != 0xFFFFFFFFu) {       // recomputed from full rows by k_c4_fix
+                acc[p] = agg16[(size_t)__float_as_uint(a.y) * 4 + c];
+                e[p] = b[p];
+            }                                                        // (no slot was left: gathered below, the plain way)
+        }
+    }
     wave_lds_sync();            // staged indices visible to the whole wave
 
     // ---- gather: neighbour rows summed in CSR order, S rows per vertex in flight
@@ -825,7 +853,7 @@ __global__ __launch_bounds__(256) void k_lt_bytes(const uint32_t *__restrict__ w
 
 // entries of chunk `c` per column block -> seg_cnt[c * nblocks + b]; bad |= 2 if a row's blocks are
 // not ascending (unsorted adjacency: the plan would change the order of its sum)
-__global__ __launch_bounds__(1024) void k_lt_count(GraphDev g, uint32_t rows_per_chunk, uint32_t nblocks,
+__global__ __launch_bounds__(1024) void k_lt_count(GraphDev g, uint32_t rows_per_chunk, uint32_t nblocks, uint32_t block_cols,
                                                    uint32_t *__restrict__ seg_cnt, uint32_t *bad) {
     __shared__ uint32_t hist[4096];
     const uint32_t c = blockIdx.x, tid = threadIdx.x;
@@ -836,7 +864,7 @@ __global__ __launch_bounds__(1024) void k_lt_count(GraphDev g, uint32_t rows_per
     for (uint32_t u = r0 + tid; u < r1; u += 1024) {
         uint32_t prev = 0, run = 0;
         for (uint32_t e = g.rowptr[u]; e < g.rowptr[u + 1]; ++e) {
-            const uint32_t b = g.col[e] / kLtBlock;
+            const uint32_t b = g.col[e] / block_cols;
             if (run && b != prev) {
                 atomicAdd(&hist[prev], run);
                 unsorted |= b < prev;
@@ -881,7 +909,7 @@ __global__ __launch_bounds__(256) void k_lt_steps(GraphDev g, uint32_t rows_per_
 
 // regroup the chunk's CSR entries by column block: entries[...] = row_local << 17 | col_local; a row's
 // entries of one block are written as one adjacent run, in order (the order among rows is free)
-__global__ __launch_bounds__(1024) void k_lt_scatter(GraphDev g, uint32_t rows_per_chunk, uint32_t nblocks,
+__global__ __launch_bounds__(1024) void k_lt_scatter(GraphDev g, uint32_t rows_per_chunk, uint32_t nblocks, uint32_t block_cols,
                                                      const uint32_t *__restrict__ seg_cnt, uint32_t *__restrict__ entries) {
     __shared__ uint32_t cursor[4096];
     const uint32_t c = blockIdx.x, tid = threadIdx.x;
@@ -899,11 +927,11 @@ __global__ __launch_bounds__(1024) void k_lt_scatter(GraphDev g, uint32_t rows_p
         uint32_t e = g.rowptr[u];
         const uint32_t end = g.rowptr[u + 1];
         while (e < end) {
-            const uint32_t b = g.col[e] / kLtBlock;
+            const uint32_t b = g.col[e] / block_cols;
             uint32_t f = e + 1;
-            while (f < end && g.col[f] / kLtBlock == b) ++f;
+            while (f < end && g.col[f] / block_cols == b) ++f;
             uint32_t pos = atomicAdd(&cursor[b], f - e);
-            for (; e < f; ++e) entries[pos++] = rl | (g.col[e] - b * kLtBlock);
+            for (; e < f; ++e) entries[pos++] = rl | (g.col[e] - b * block_cols);
         }
     }
 }
@@ -1013,6 +1041,206 @@ __global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ st
 #undef LT_LOAD
     __syncthreads();
     for (uint32_t i = tid; i < rows_per_chunk && row0 + i < n; i += 1024) agg[row0 + i] = acc[i];
+}
+
+// ---- compact-table plan of the 16-wide stages ---------------------------------------------------
+// The 64-byte-row gather is bound by line requests to the fabric (~55 G/s).  After the
+// ReLU that ends a stage most feature columns are zero on many graphs (metric graph: two columns dense,
+// two at ~10 %, a handful of stray non-zeros elsewhere).  When at most FOUR columns carry (nearly) all
+// non-zeros of this forward's input, the neighbours' rows are read from a COMPACT table — 4 floats per
+// vertex — with the blocked traversal of the LDS-table plan: rows in chunks (one 1024-thread workgroup,
+// 4 sums per row in LDS), columns in blocks of 131072 vertices = 2 MiB of the table, the workgroups of a
+// 256-wide persistent grid sweeping the blocks in the same order at the same pace, so that the block being
+// read stays in every XCD's L2 and a gather is an L2 hit (~105 G rows/s) instead of a fabric request.
+//   k_c4_choose   picks the four fullest columns from the per-column counts (device side, no host sync)
+//   k_c4_compact  writes the table; a vertex with a non-zero in any OTHER column gets the sign bit of
+//                 its first value set (inputs are >= 0 after ReLU — checked — so the bit is free)
+//   k_c4_agg      the sums; a row that met a flagged neighbour is marked DIRTY (sign bit of its first sum)
+//   k_stage_f16   takes a clean row's aggregate from the 4 sums (+0.0f elsewhere: a sum of zeros) and
+//                 gathers a dirty row the plain way, full rows in CSR order — so every aggregate is
+//                 exactly what the plain gather produces; then the dense layers as always.
+// desc words: [0] ok (1 = the plan applies to this input), [1..4] the chosen columns (ascending).
+constexpr uint32_t kC4Block = 131072;     // vertices per column block: 2 MiB of compact rows
+constexpr uint32_t kC4MaxRows = 7400;     // rows per chunk: 16 B * rows + 32 KiB values + 8 KiB entries + dirty bits <= 160 KiB
+
+__global__ void k_c4_choose(const unsigned long long *__restrict__ counts, uint32_t n, uint32_t *__restrict__ desc) {
+    if (threadIdx.x || blockIdx.x) return;
+    unsigned long long c[16];
+    bool taken[16];
+    for (int i = 0; i < 16; ++i) {
+        c[i] = counts[i];
+        taken[i] = false;
+    }
+    for (int j = 0; j < 4; ++j) {            // four fullest columns (ties: lowest index)
+        int best = -1;
+        for (int i = 0; i < 16; ++i)
+            if (!taken[i] && (best < 0 || c[i] > c[best])) best = i;
+        taken[best] = true;
+    }
+    unsigned long long rest = 0;
+    uint32_t k = 0;
+    for (int i = 0; i < 16; ++i) {
+        if (taken[i]) desc[1 + k++] = (uint32_t)i;
+        else rest += c[i];
+    }
+    // every stray non-zero flags a vertex and dirties that vertex's neighbours, which are then gathered the
+    // plain way: worth it only while they are few
+    desc[0] = rest <= (unsigned long long)n / 512 ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_c4_compact(const float4 *__restrict__ feat, uint32_t n, uint32_t *__restrict__ desc,
+                                                    f32x4 *__restrict__ table) {
+    if (!desc[0]) return;   // (a block that finds a negative value below clears it for the kernels that follow)
+    const uint32_t c0 = desc[1], c1 = desc[2], c2 = desc[3], c3 = desc[4];
+    const uint32_t mask = (1u << c0) | (1u << c1) | (1u << c2) | (1u << c3);
+    bool negative = false;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v <= n; v += (size_t)gridDim.x * blockDim.x) {
+        f32x4 out = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (v < n) {
+            const float4 q0 = feat[v * 4], q1 = feat[v * 4 + 1], q2 = feat[v * 4 + 2], q3 = feat[v * 4 + 3];
+            const float r[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+            uint32_t nz = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                nz |= (r[i] != 0.0f ? 1u : 0u) << i;
+                negative |= r[i] < 0.0f;
+            }
+            const float *row = reinterpret_cast<const float *>(feat) + v * 16;   // the four picks: L1 hits
+            const float a = row[c0], b = row[c1], c = row[c2], d = row[c3];
+            out = f32x4{a == 0.0f ? 0.0f : a, b == 0.0f ? 0.0f : b, c == 0.0f ? 0.0f : c, d == 0.0f ? 0.0f : d};   // -0.0f -> +0.0f
+            if (nz & ~mask) out[0] = __uint_as_float(__float_as_uint(out[0]) | 0x80000000u);   // stray non-zeros: flag the vertex
+        }
+        table[v] = out;   // row n: the zero row clamped reads land on
+    }
+    if (__any(negative) && (threadIdx.x & 63) == 0) atomicAnd(&desc[0], 0u);
+}
+
+__global__ __launch_bounds__(1024) void k_c4_agg(const uint32_t *__restrict__ step_ptr, const uint4 *__restrict__ steps,
+                                                 const uint32_t *__restrict__ entries, const f32x4 *__restrict__ table,
+                                                 f32x4 *__restrict__ agg, uint32_t n, uint32_t rows_per_chunk, uint32_t chunk0,
+                                                 uint32_t chunk1, uint32_t last_entry, uint32_t *__restrict__ desc,
+                                                 uint32_t *__restrict__ dirty_rows, uint32_t dirty_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char c4_smem[];
+    if (!desc[0]) return;                                               // block-uniform
+    f32x4 *acc = reinterpret_cast<f32x4 *>(c4_smem);                    // rows_per_chunk (<= kC4MaxRows) x 4 sums
+    f32x4 *vbuf = acc + kC4MaxRows;                                     // the step's gathered rows
+    uint32_t *ebuf = reinterpret_cast<uint32_t *>(vbuf + kLtStep);      // the step's entries
+    uint32_t *dirty = ebuf + kLtStep;                                   // one bit per row of the chunk
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t chunk = chunk0 + blockIdx.x; chunk < chunk1; chunk += gridDim.x) {
+        const uint32_t row0 = chunk * rows_per_chunk;
+        __syncthreads();                                                // the previous chunk's sums are written out
+        for (uint32_t i = tid; i < rows_per_chunk; i += 1024) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (uint32_t i = tid; i < (kC4MaxRows + 31) / 32; i += 1024) dirty[i] = 0;
+        const uint32_t st0 = step_ptr[chunk], st1 = step_ptr[chunk + 1];
+        const int nsteps = (int)(st1 - st0);
+        // Time u: process step u (entries and gathered rows parked in LDS), park step u + 1 (rows gathered
+        // during u - 1 ... u), gather step u + 2 (its entries have been in registers since u - 3), load the
+        // entries of step u + 5.  Everything unconditional and in the same order on every trip.
+        uint32_t ea0 = 0, ea1 = 0, eb0 = 0, eb1 = 0, ec0 = 0, ec1 = 0, ed0 = 0, ed1 = 0;   // entry ring: step s in slot s & 3
+        uint32_t la = 0, lb = 0, lc = 0, ld = 0, lcur = 0, cba = 0, cbb = 0, cbc = 0, cbd = 0;
+        f32x4 v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};                                        // rows gathered for the step parked next
+        uint4 dn = steps[st0];
+#define C4_STEP(u_, e0_, e1_, l_, cb_, ge0_, ge1_, gcb_)                                              \
+        {                                                                                             \
+            if ((u_) >= 0) {                                                                          \
+                __syncthreads();                                   /* step u is parked */             \
+                const uint32_t i0_ = tid, i1_ = tid + 1024;                                           \
+                const bool in0_ = i0_ < lcur, in1_ = i1_ < lcur;                                      \
+                const uint32_t a0_ = ebuf[i0_], a1_ = ebuf[i1_];                                      \
+                const uint32_t b0_ = ebuf[(int)i0_ - 1], b1_ = ebuf[i1_ - 1];                         \
+                const uint32_t r0_ = a0_ >> 17, r1_ = a1_ >> 17;                                      \
+                const bool h0_ = in0_ && (i0_ == 0 || (b0_ >> 17) != r0_);                            \
+                const bool h1_ = in1_ && (b1_ >> 17) != r1_;                                          \
+                if (h0_) {                                                                            \
+                    f32x4 s_ = acc[r0_] + vbuf[i0_];                                                  \
+                    for (uint32_t k_ = i0_ + 1; k_ < lcur && (ebuf[k_] >> 17) == r0_; ++k_) s_ += vbuf[k_]; \
+                    acc[r0_] = s_;                                                                    \
+                }                                                                                     \
+                if (h1_) {                                                                            \
+                    f32x4 s_ = acc[r1_] + vbuf[i1_];                                                  \
+                    for (uint32_t k_ = i1_ + 1; k_ < lcur && (ebuf[k_] >> 17) == r1_; ++k_) s_ += vbuf[k_]; \
+                    acc[r1_] = s_;                                                                    \
+                }                                                                                     \
+                __syncthreads();                                   /* everyone is done reading step u */ \
+            }                                                                                         \
+            /* park step u + 1: its entries (ring slot e_) and the rows gathered for it; a flagged row */ \
+            /* (sign bit of its first value) dirties the entry's row and is parked without the flag   */ \
+            {                                                                                         \
+                const uint32_t f0_ = __float_as_uint(v0[0]), f1_ = __float_as_uint(v1[0]);            \
+                if ((f0_ >> 31) && tid < (l_)) atomicOr(&dirty[(e0_ >> 17) >> 5], 1u << ((e0_ >> 17) & 31)); \
+                if ((f1_ >> 31) && tid + 1024 < (l_)) atomicOr(&dirty[(e1_ >> 17) >> 5], 1u << ((e1_ >> 17) & 31)); \
+                v0[0] = __uint_as_float(f0_ & 0x7FFFFFFFu);                                           \
+                v1[0] = __uint_as_float(f1_ & 0x7FFFFFFFu);                                           \
+            }                                                                                         \
+            ebuf[tid] = e0_;                                                                          \
+            ebuf[tid + 1024] = e1_;                                                                   \
+            vbuf[tid] = v0;                                                                           \
+            vbuf[tid + 1024] = v1;                                                                    \
+            lcur = l_;                                                                                \
+            {   /* gather step u + 2 (entries ge_, column base gcb_) */                               \
+                const uint32_t c0_ = gcb_ + (ge0_ & 0x1FFFF), c1_ = gcb_ + (ge1_ & 0x1FFFF);          \
+                v0 = table[c0_ < n ? c0_ : n];                                                        \
+                v1 = table[c1_ < n ? c1_ : n];                                                        \
+            }                                                                                         \
+            {   /* load the entries of step u + 5 into the slot just parked */                        \
+                const uint4 dl_ = dn;                                                                 \
+                const int nx_ = (u_) + 6;                                                             \
+                dn = steps[st0 + (uint32_t)(nx_ > 0 ? nx_ : 0)];                                      \
+                const uint32_t x0_ = dl_.y + tid, x1_ = dl_.y + tid + 1024;                           \
+                e0_ = entries[x0_ < last_entry ? x0_ : last_entry];                                   \
+                e1_ = entries[x1_ < last_entry ? x1_ : last_entry];                                   \
+                l_ = ((u_) + 5 >= 0) ? dl_.z : 0u;                                                    \
+                cb_ = dl_.x * kC4Block;                                                               \
+            }                                                                                         \
+        }
+        for (int u = -8; u < nsteps; u += 4) {
+            C4_STEP(u,     eb0, eb1, lb, cbb, ec0, ec1, cbc)
+            C4_STEP(u + 1, ec0, ec1, lc, cbc, ed0, ed1, cbd)
+            C4_STEP(u + 2, ed0, ed1, ld, cbd, ea0, ea1, cba)
+            C4_STEP(u + 3, ea0, ea1, la, cba, eb0, eb1, cbb)
+        }
+#undef C4_STEP
+        __syncthreads();
+        for (uint32_t i = tid; i < rows_per_chunk && row0 + i < n; i += 1024) {
+            f32x4 a = acc[i];
+            if (dirty[i >> 5] >> (i & 31) & 1u) {
+                // a dirty row: its aggregate is recomputed from full rows (k_c4_fix) into slot `slot` of the
+                // side buffer; the sums here are not used.  No slot left: the stage kernel gathers it itself.
+                const uint32_t slot = atomicAdd(&desc[5], 1u);
+                if (slot < dirty_cap) dirty_rows[slot] = row0 + i;
+                a[0] = __uint_as_float(0x80000000u);
+                a[1] = __uint_as_float(slot < dirty_cap ? slot : 0xFFFFFFFFu);
+            }
+            agg[row0 + i] = a;
+        }
+    }
+}
+
+// dirty rows (rows with a neighbour that has stray non-zeros): the plain aggregate, full 64-byte rows in CSR
+// order, one quad of lanes per row (lane c: columns 4c .. 4c+3) -> agg16[slot]
+__global__ __launch_bounds__(256) void k_c4_fix(GraphDev g, const float4 *__restrict__ fin, const uint32_t *__restrict__ desc,
+                                                const uint32_t *__restrict__ dirty_rows, uint32_t dirty_cap,
+                                                float4 *__restrict__ agg16) {
+    if (!desc[0]) return;
+    const uint32_t count = min(desc[5], dirty_cap);
+    const uint32_t c = threadIdx.x & 3;
+    for (uint32_t slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; slot < count; slot += (gridDim.x * blockDim.x) >> 2) {
+        const uint32_t u = dirty_rows[slot];
+        uint32_t e = g.rowptr[u];
+        const uint32_t end = g.rowptr[u + 1];
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (; e + 1 < end; e += 2) {   // two rows in flight, added in order
+            const float4 r0 = fin[(size_t)g.col[e] * 4 + c], r1 = fin[(size_t)g.col[e + 1] * 4 + c];
+            a.x += r0.x; a.y += r0.y; a.z += r0.z; a.w += r0.w;
+            a.x += r1.x; a.y += r1.y; a.z += r1.z; a.w += r1.w;
+        }
+        if (e < end) {
+            const float4 r0 = fin[(size_t)g.col[e] * 4 + c];
+            a.x += r0.x; a.y += r0.y; a.z += r0.z; a.w += r0.w;
+        }
+        agg16[(size_t)slot * 4 + c] = a;
+    }
 }
 
 // ------------------------------------------------------------------ degree-sorted tile order
@@ -1280,6 +1508,7 @@ __global__ __launch_bounds__(256) void k_live_columns(const float4 *__restrict__
 // counts[c] += rows of feat[rows x 16] that are non-zero in column c
 __global__ __launch_bounds__(256) void k_column_counts(const float4 *__restrict__ feat, size_t quads,
                                                        unsigned long long *counts) {
+    __shared__ uint32_t part[4][16];
     uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;   // this lane always sees the same column group (stride % 4 == 0)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (size_t)gridDim.x * blockDim.x) {
         const float4 v = feat[i];
@@ -1294,12 +1523,17 @@ __global__ __launch_bounds__(256) void k_column_counts(const float4 *__restrict_
         c2 += __shfl_xor(c2, off);
         c3 += __shfl_xor(c3, off);
     }
-    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane < 4) {
-        if (c0) atomicAdd(&counts[4 * lane + 0], (unsigned long long)c0);
-        if (c1) atomicAdd(&counts[4 * lane + 1], (unsigned long long)c1);
-        if (c2) atomicAdd(&counts[4 * lane + 2], (unsigned long long)c2);
-        if (c3) atomicAdd(&counts[4 * lane + 3], (unsigned long long)c3);
+        part[wave][4 * lane + 0] = c0;
+        part[wave][4 * lane + 1] = c1;
+        part[wave][4 * lane + 2] = c2;
+        part[wave][4 * lane + 3] = c3;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {   // one atomic per column and block (per wave they queued up behind each other)
+        const uint32_t t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        if (t) atomicAdd(&counts[threadIdx.x], (unsigned long long)t);
     }
 }
 
@@ -1560,7 +1794,7 @@ int stage_variant(int f, int n1, int n2, int n3, int sigmoid_last) {
 hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
                         const float *in, float *out, float *logits, uint32_t row_lo,
                         uint32_t row_hi, uint32_t long_thresh, bool mfma, const SortedOrder *so,
-                        bool interleave, hipStream_t stream) {
+                        bool interleave, hipStream_t stream, const float *acc4, const uint32_t *c4desc, const float *agg16) {
     if (row_hi <= row_lo) return hipSuccess;
     const bool sorted = so && so->n > 0 && sp.f == 16;
     if (so && so->n == 0 && sp.f == 16) return hipSuccess;   // every row of the range is a long row
@@ -1584,7 +1818,9 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
 #define GNNVC_LAUNCH_F16(N2_, N3_, SIG_, MF_, SRT_, LG_)                                              \
     hipLaunchKernelGGL((k_stage_f16<32, N2_, N3_, SIG_, 2, MF_, SRT_>), grid, block, 0, stream, g, ws, in4, out, \
                        LG_, P, row_lo, row_hi, long_thresh, sorted ? so->vertex : nullptr,                \
-                       sorted ? so->meta : nullptr, sorted ? so->n : 0u, il)
+                       sorted ? so->meta : nullptr, sorted ? so->n : 0u, il,                              \
+                       sorted ? nullptr : reinterpret_cast<const float4 *>(acc4), sorted ? nullptr : c4desc,         \
+                       reinterpret_cast<const float4 *>(agg16))
     case 2:
         if (sorted) GNNVC_LAUNCH_F16(32, 16, false, false, true, nullptr);
         else GNNVC_LAUNCH_F16(32, 16, false, false, false, nullptr);
@@ -1720,10 +1956,10 @@ hipError_t lds_table_bytes(const uint32_t *w, uint32_t n, uint8_t *wb, uint32_t 
     return hipGetLastError();
 }
 
-hipError_t lds_table_count(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t *seg_cnt,
-                           uint32_t *bad, hipStream_t stream) {
-    if (nblocks > 4096) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_lt_count, dim3(nchunks), dim3(1024), 0, stream, g, rows_per_chunk, nblocks, seg_cnt, bad);
+hipError_t lds_table_count(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t block_cols,
+                           uint32_t *seg_cnt, uint32_t *bad, hipStream_t stream) {
+    if (nblocks > 4096 || block_cols > (1u << 17) || rows_per_chunk > (1u << 15)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_lt_count, dim3(nchunks), dim3(1024), 0, stream, g, rows_per_chunk, nblocks, block_cols, seg_cnt, bad);
     return hipGetLastError();
 }
 
@@ -1734,9 +1970,10 @@ hipError_t lds_table_steps(const GraphDev &g, uint32_t rows_per_chunk, uint32_t 
     return hipGetLastError();
 }
 
-hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks,
+hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t block_cols,
                              const uint32_t *seg_cnt, uint32_t *entries, hipStream_t stream) {
-    hipLaunchKernelGGL(k_lt_scatter, dim3(nchunks), dim3(1024), 0, stream, g, rows_per_chunk, nblocks, seg_cnt, entries);
+    hipLaunchKernelGGL(k_lt_scatter, dim3(nchunks), dim3(1024), 0, stream, g, rows_per_chunk, nblocks, block_cols, seg_cnt,
+                       entries);
     return hipGetLastError();
 }
 
@@ -1773,6 +2010,43 @@ hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float
     else
         hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, false>), grid, block, 0, stream, g, ws, x, out, params + sp.param_offset,
                            row_lo, row_hi, g.rowptr, g.col, acc, long_thresh, interleave ? 1 : 0, (const uint32_t *)bad);
+    return hipGetLastError();
+}
+
+// ---- compact-table plan of the 16-wide stages -----------------------------------------------
+uint32_t compact_max_rows() { return kC4MaxRows; }
+uint32_t compact_block() { return kC4Block; }
+
+// counts -> desc -> table -> four sums per row of [row_lo, row_hi) (chunks that straddle the ends are done
+// whole).  `counts` holds the per-column non-zero counts of `in` (column_counts, same stream).
+hipError_t launch_compact_gather(const GraphDev &g, const float *in, const unsigned long long *counts, uint32_t *desc,
+                                 float *table, float *acc4, uint32_t row_lo, uint32_t row_hi, uint32_t rows_per_chunk,
+                                 const uint32_t *step_ptr, const void *steps, const uint32_t *entries, uint32_t *dirty_rows,
+                                 uint32_t dirty_cap, float *agg16, hipStream_t stream) {
+    if (row_hi <= row_lo || g.nnz == 0) return hipErrorInvalidValue;
+    if (rows_per_chunk == 0 || rows_per_chunk > kC4MaxRows) return hipErrorInvalidValue;
+    hipError_t rc0 = hipMemsetAsync(desc + 5, 0, sizeof(uint32_t), stream);   // dirty-row counter
+    if (rc0 != hipSuccess) return rc0;
+    hipLaunchKernelGGL(k_c4_choose, dim3(1), dim3(64), 0, stream, counts, g.n, desc);
+    hipLaunchKernelGGL(k_c4_compact, dim3(std::min<unsigned>((g.n + 256) / 256, 4096u)), dim3(256), 0, stream,
+                       reinterpret_cast<const float4 *>(in), g.n, desc, reinterpret_cast<f32x4 *>(table));
+    const uint32_t c0 = row_lo / rows_per_chunk, c1 = (row_hi - 1) / rows_per_chunk + 1;
+    constexpr size_t lds = (size_t)kC4MaxRows * 16 + (size_t)kLtStep * 16 + (size_t)kLtStep * 4 + ((kC4MaxRows + 31) / 32) * 4 + 64;
+    static_assert(lds <= 160 * 1024, "LDS budget of k_c4_agg");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(k_c4_agg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (rc != hipSuccess) return rc;
+        attr_set = true;
+    }
+    // a persistent grid of one workgroup per CU: they start together and sweep the column blocks together
+    hipLaunchKernelGGL(k_c4_agg, dim3(std::min<uint32_t>(256u, c1 - c0)), dim3(1024), lds, stream, step_ptr,
+                       reinterpret_cast<const uint4 *>(steps), entries, reinterpret_cast<const f32x4 *>(table),
+                       reinterpret_cast<f32x4 *>(acc4), g.n, rows_per_chunk, c0, c1, (uint32_t)(g.nnz - 1), desc, dirty_rows,
+                       dirty_cap);
+    // the grid is sized for a typical number of dirty rows and strides over more
+    hipLaunchKernelGGL(k_c4_fix, dim3(std::min<uint32_t>((dirty_cap + 63) / 64, 4096u)), dim3(256), 0, stream, g,
+                       reinterpret_cast<const float4 *>(in), desc, dirty_rows, dirty_cap, reinterpret_cast<float4 *>(agg16));
     return hipGetLastError();
 }
 
@@ -1856,7 +2130,7 @@ hipError_t column_counts(const float *feat, size_t rows, unsigned long long *cou
     hipError_t rc = hipMemsetAsync(counts, 0, 16 * sizeof(unsigned long long), stream);
     if (rc != hipSuccess || rows == 0) return rc;
     const size_t quads = rows * 4;
-    const unsigned blocks = (unsigned)std::min<size_t>((quads + 255) / 256, 4096);
+    const unsigned blocks = (unsigned)std::min<size_t>((quads + 255) / 256, 2048);
     hipLaunchKernelGGL(k_column_counts, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const float4 *>(feat), quads,
                        counts);
     return hipGetLastError();

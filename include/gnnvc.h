@@ -75,6 +75,10 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *                         neighbour values are read from byte slices held in LDS instead of gathered from
  *                         memory (default 1 = large, non-skewed graphs; 2 = any large graph; 0 = off).
  *                         Takes precedence over "blocked_stage0"; bit-identical results
+ *   "compact_gather" 0|1|2  compact-table plan of the 16-wide stages: when at most four feature columns carry
+ *                         (nearly) all non-zeros of a stage's input — decided on the device at every forward —
+ *                         neighbours are read from a 16-byte-per-vertex table swept block by block through L2
+ *                         instead of 64-byte rows from memory (default 1 = large, non-skewed graphs); bit-identical
  *   "block_cols"     n    vertices per column block (default 524288 = 2 MiB of x)
  *   "blocked_min_n"  n    graphs with fewer vertices are not blocked (default 2^20)
  *   "long_row_threshold" d  rows of degree >= d get a workgroup of their own (default 512,
@@ -87,7 +91,7 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *                         would spend more than twice the useful gather rounds, the default)
  *   "sorted_min_nnz" n     in auto mode, graphs with fewer adjacency entries keep natural tiles
  *                         (default 4 Mi: the sort costs more than it saves on a graph used once)
- * gnnvc_get_info keys: "lds_table_active", "lds_table_chunks", "lds_table_steps", "mfma_dense", "sorted_tiles_active", "tile_waste_x100", "blocked_stage0_active", "blocked_blocks", "block_cols", "long_rows",
+ * gnnvc_get_info keys: "compact_gather_active", "compact_gather_chunks", "lds_table_active", "lds_table_chunks", "lds_table_steps", "mfma_dense", "sorted_tiles_active", "tile_waste_x100", "blocked_stage0_active", "blocked_blocks", "block_cols", "long_rows",
  * "long_row_threshold". */
 int gnnvc_set_option(gnnvc_engine *e, const char *key, long value);
 int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value);

@@ -530,6 +530,88 @@ def test_lds_table_plan_steps_aside(model_text, oracle_model):
         e.close()
 
 
+# ---------------------------------------------------------------- compact-table plan of the 16-wide stages
+
+def _oracle_stage(oracle_model, g, stage, h_in):
+    """One fused stage from an arbitrary input, with the oracle's layer functions."""
+    a = oracle_py.graph_layer(g, g.ws, np.ascontiguousarray(h_in, dtype=np.float32))
+    for i, (W, b) in enumerate(oracle_model.linear_params()[3 * stage: 3 * stage + 3]):
+        a = oracle_py.linear_layer(a, W, b)
+        if not (stage == 2 and i == 2):
+            a = oracle_py.relu(a)
+    return a
+
+
+def _sparse_features(n, rng, live, density, strays=0, stray_cols=(5, 9)):
+    h = np.zeros((n, 16), dtype=np.float32)
+    for c, d in zip(live, density):
+        h[:, c] = rng.uniform(0.05, 2.0, n).astype(np.float32) * (rng.random(n) < d)
+    for i in rng.choice(n, strays, replace=False):
+        h[i, stray_cols[i % len(stray_cols)]] = 1.0 + (i % 7)
+    return h
+
+
+@pytest.mark.parametrize("case", ["clean", "strays", "two_live", "too_many_strays", "negative", "minus_zero", "slot_overflow"])
+def test_compact_gather_plan_is_bit_identical(model_text, oracle_model, case):
+    """k_c4_*: when at most four feature columns are live, neighbours are read from a 16-byte table swept through
+    L2; rows that meet a vertex with stray non-zeros are recomputed from full rows.  Whatever the input, the
+    stage output equals the oracle's bit for bit (inputs that do not fit the plan take the plain gather)."""
+    import torch
+    import gnn_mwvc_amd as G
+    rng = np.random.default_rng(len(case))
+    g = gg.erdos_renyi(3000, 3000 * 150, 71) if case == "slot_overflow" else gg.erdos_renyi(20000, 200000, 70)
+    live, dens = ([0, 3, 7, 11], [1.0, 0.1, 0.5, 1.0])
+    strays = {"clean": 0, "strays": 25, "too_many_strays": 400, "slot_overflow": 5}.get(case, 3)
+    if case == "two_live":
+        live, dens = [2, 13], [1.0, 0.3]
+    h = _sparse_features(g.n, rng, live, dens, strays)
+    if case == "negative":
+        h[17, 0] = -0.25
+    if case == "minus_zero":
+        h[::3, 3] = -0.0
+        h[5, 9] = -0.0                    # a negative zero in a dead column is no stray
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_option("blocked_min_n", 0)
+        e.set_weight_scale(g.ws)
+        oracle_model.set_weight_scale(g.ws)
+        e.upload_graph(g)
+        e.forward(g.x())
+        _, logits = e.forward(g.x())                       # second forward: the plans are built
+        assert e.get_info("compact_gather_active") == 1
+        assert np.array_equal(bits(logits[:, 0]), bits(oracle_model.logits(g)))
+        dev = torch.device("cuda:0")
+        hin = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+        hin[: g.n] = torch.from_numpy(h).to(dev)
+        for stage in (1, 2):
+            want = _oracle_stage(oracle_model, g, stage, h)
+            for lo, hi in ((0, g.n), (g.n // 4 // 64 * 64, g.n), (0, g.n // 8 // 64 * 64)):   # the last one is too short for the plan
+                if stage == 1:
+                    out = torch.full((g.n + 1, 16), 7.0, dtype=torch.float32, device=dev)
+                    torch.cuda.synchronize()
+                    e.stage_forward_device(1, lo, hi, hin.data_ptr(), out.data_ptr())
+                    e.synchronize()
+                    got = out[lo:hi].cpu().numpy()
+                else:
+                    out = torch.full((g.n + 1,), 7.0, dtype=torch.float32, device=dev)
+                    lg = torch.full((g.n + 1,), 7.0, dtype=torch.float32, device=dev)
+                    torch.cuda.synchronize()
+                    e.stage_forward_device(2, lo, hi, hin.data_ptr(), out.data_ptr(), lg.data_ptr())
+                    e.synchronize()
+                    got = lg[lo:hi].cpu().numpy().reshape(-1, 1)
+                assert np.array_equal(bits(got), bits(want[lo:hi])), (case, stage, lo, hi)
+                if (hi - lo) * 2 >= g.n:      # the plan ran: did the device take the route this case is about?
+                    ok, dirty = e.get_info("compact_gather_last_ok"), e.get_info("compact_gather_last_dirty")
+                    assert ok == (0 if case in ("too_many_strays", "negative") else 1), (case, ok)
+                    if ok:
+                        # (with two live columns the two stray columns simply become the other two table columns)
+                        assert (dirty > 0) == (strays > 0 and case != "two_live"), (case, dirty)
+                        if case == "slot_overflow":
+                            assert dirty > max(g.n // 4, 1024)
+    finally:
+        e.close()
+
+
 # ---------------------------------------------------------------- long-row path
 
 @pytest.mark.parametrize("thresh,block_cols", [(8, 0), (64, 0), (300, 0), (0, 0), (16, 512), (1000, 2048)])
