@@ -8,7 +8,7 @@ the highest-degree ones, which take the long-row path):
     from the device's own stage inputs (its neighbours' rows, in CSR order) — bit-identical;
   * determinism: two forwards give the same bits;
   * partition invariance: a stage run over two vertex ranges equals the whole-range run;
-  * plan invariance: column-blocked / MFMA / long-row options do not change a single bit;
+  * plan invariance: LDS-table / column-blocked / compact-table / MFMA / long-row options do not change a single bit;
   * scores are sigmoid(logits) and lie in [0, 1] (strictly inside on the metric graph).
 """
 import numpy as np
@@ -128,7 +128,8 @@ def test_deterministic_and_plan_invariant(big):
     assert torch.equal(lg.view(torch.int32), ref_lg.view(torch.int32))
     # (the stage-0 plans are built on a graph's second forward: every engine below runs two)
     plans = [{"blocked_stage0": 0, "lds_table": 0, "mfma_dense": 0},
-             {"block_cols": 1 << 21, "mfma_dense": 2, "blocked_stage0": 2, "lds_table": 0}, {"lds_table": 2}]
+             {"block_cols": 1 << 21, "mfma_dense": 2, "blocked_stage0": 2, "lds_table": 0}, {"lds_table": 2},
+             {"compact_gather": 0}]
     if big["name"] == "er10m":
         plans.append({"mfma_dense": 1, "long_row_threshold": 40})
     else:   # skewed graphs: other long-row thresholds, forced sorted tiles with a low threshold
@@ -152,6 +153,10 @@ def test_deterministic_and_plan_invariant(big):
                 assert e2.get_info("lds_table_active") == want_lt, opts
                 if opts.get("blocked_stage0") == 2:
                     assert e2.get_info("blocked_stage0_active") == 1, opts
+                want_c4 = 1 if (opts.get("compact_gather", 1) and "long_row_threshold" not in opts) else 0
+                assert e2.get_info("compact_gather_active") == want_c4, opts
+                if want_c4:     # and the device found this input fit for it (four live columns, a few strays)
+                    assert e2.get_info("compact_gather_last_ok") == 1 and e2.get_info("compact_gather_last_dirty") > 0
         finally:
             e2.close()
 

@@ -795,6 +795,7 @@ def test_row_codec_round_trip(engine, mask, cap):
     region = torch.full((pk.piece_words(dense_rows),), 9.0, dtype=torch.float32, device=dev)
     flag = torch.zeros(1, dtype=torch.int32, device=dev)
     codec = G.EngineRowCodec(engine)
+    torch.cuda.synchronize()   # (torch filled these on its own stream)
     codec.pack(feat, lo, hi, pk, region, dense_rows, flag)
     engine.synchronize()
     assert int(flag.item()) == 0
@@ -807,6 +808,7 @@ def test_row_codec_round_trip(engine, mask, cap):
     got = {(int(r) + lo, int(c)): v for r, c, v, _ in exc[4: 4 + 4 * len(stray)].reshape(-1, 4)}
     assert got == {(r, c): int(a[r, c:c + 1].view(np.uint32)[0]) for r, c in stray}
     out = torch.full((rows, 16), 5.0, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()   # the engine runs on its own stream: torch's fill must have landed first
     codec.unpack(region, dense_rows, lo, hi, pk, out)
     engine.synchronize()
     o = out.cpu().numpy()
@@ -819,10 +821,12 @@ def test_row_codec_round_trip(engine, mask, cap):
         extra = [(r, dead[0]) for r in range(lo, hi) if a[r, dead[0]] == 0][: max(cap - len(stray), 0) + 1]
         for r, c in extra:
             feat[r, c] = 1e-30
+        torch.cuda.synchronize()
         codec.pack(feat, lo, hi, pk, region, dense_rows, flag)
         engine.synchronize()
         assert int(flag.item()) == (2 if len(extra) + len(stray) > cap else 0)   # (a 4096-entry list cannot overflow here)
         flag.zero_()
+        torch.cuda.synchronize()
         engine.pack_rows(feat.data_ptr(), lo, hi, mask, kp, region.data_ptr(), flag.data_ptr())
         engine.synchronize()
         assert int(flag.item()) == 1
@@ -830,6 +834,7 @@ def test_row_codec_round_trip(engine, mask, cap):
         for r, c in extra + stray:
             feat[r, c] = 0.0
         feat[hi, dead[0]] = 3.0                                   # outside the shipped rows: not this call's business
+        torch.cuda.synchronize()
         engine.pack_rows(feat.data_ptr(), lo, hi, mask, kp, region.data_ptr(), flag.data_ptr())
         engine.synchronize()
         assert int(flag.item()) == 0
@@ -854,12 +859,14 @@ def test_row_codec_unpack_gathered(engine, world, n, off, size):
     buf = torch.zeros(world * pw, dtype=torch.float32, device=dev)
     flag = torch.zeros(1, dtype=torch.int32, device=dev)
     codec = G.EngineRowCodec(engine)
+    torch.cuda.synchronize()
     for r, (lo, hi) in enumerate(bounds):
         r0, r1 = min(lo + off, hi), min(lo + off + size, hi)
         codec.pack(feat, r0, r1, pk, buf[r * pw:(r + 1) * pw], size, flag)
     skip = 1
     one = torch.full((n + 64, 16), 5.0, dtype=torch.float32, device=dev)
     many = one.clone()
+    torch.cuda.synchronize()
     codec.unpack_gathered(buf, world, skip, size, per, off, size, n, pk, one)
     for r, (lo, hi) in enumerate(bounds):
         r0, r1 = min(lo + off, hi), min(lo + off + size, hi)
