@@ -581,7 +581,7 @@ int build_compact(gnnvc_engine *e) {
     HIP_TRY(e, e->c4_entries.reserve(g.nnz));
     HIP_TRY(e, e->c4_table.reserve(((size_t)g.n + 1) * 4));
     HIP_TRY(e, e->c4_acc.reserve((size_t)g.n * 4));
-    e->c4_dirty_cap = std::max<uint32_t>(g.n / 4, 1024u);   // rows recomputed from full rows; beyond that the stage kernel gathers
+    e->c4_dirty_cap = g.n;   // rows recomputed from full rows (every row could be one: the dense-only stage kernel never gathers)
     HIP_TRY(e, e->c4_dirty.reserve(e->c4_dirty_cap));
     HIP_TRY(e, e->c4_agg16.reserve((size_t)e->c4_dirty_cap * 16));
     std::memcpy(e->pin_small.p, ptr.data(), ptr.size() * sizeof(uint32_t));
@@ -657,7 +657,8 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
             }
         }
         HIP_TRY(e, gnnvc::launch_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi,
-                                       thr, mfma, sop, e->interleave, e->stream, acc4, c4desc, e->c4_agg16.p));
+                                       thr, mfma, sop, e->interleave, e->stream, acc4, c4desc, e->c4_agg16.p,
+                                       e->opt_mfma == 1));
     }
     if (longs) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));   // join
     return GNNVC_OK;

@@ -47,7 +47,7 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
                         const float *in, float *out, float *logits, uint32_t row_lo,
                         uint32_t row_hi, uint32_t long_thresh, bool mfma, const SortedOrder *so,
                         bool interleave, hipStream_t stream, const float *acc4 = nullptr,
-                        const uint32_t *c4desc = nullptr, const float *agg16 = nullptr);
+                        const uint32_t *c4desc = nullptr, const float *agg16 = nullptr, bool mfma_agg = false);
 
 // Building blocks of the degree-sorted order (the prefix over the few thousand degree classes
 // is done on the host).

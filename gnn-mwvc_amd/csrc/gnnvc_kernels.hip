@@ -241,7 +241,10 @@ __device__ __forceinline__ void mfma_tail(f32x16 (&d)[2], const float *__restric
 // srt_meta).  A tile costs max-degree gather rounds whatever the other lanes do, so on
 // skewed graphs tiles of similar degree waste far fewer rounds; rows are then no longer
 // contiguous, so the column indices are read straight from global memory.
-template <int N1, int N2, int N3, bool SIGMOID, int S, bool MFMA, bool SORTED>
+// AGGONLY (compact-table plan): every row's aggregate arrives ready-made — four sums in acc4 for clean rows, the
+// full 16 in agg16 for dirty ones — and the kernel is only the dense layers; it leaves at once when the device
+// found the input unfit for the plan (c4desc[0] == 0), and the gathering variant leaves at once when it was fit.
+template <int N1, int N2, int N3, bool SIGMOID, int S, bool MFMA, bool SORTED, bool AGGONLY = false>
 __global__ __launch_bounds__(kBlock) void k_stage_f16(
         GraphDev g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
         float *__restrict__ logits, const float *__restrict__ P, uint32_t row_lo,
@@ -252,9 +255,11 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
     const int lane = threadIdx.x & 63;
     float *T = lds[threadIdx.x >> 6];
     uint32_t *stage = reinterpret_cast<uint32_t *>(T);
-    // compact-table plan (see k_c4_*): the aggregates of clean rows arrive as four sums in acc4
-    bool c4 = false;
-    if constexpr (!SORTED) c4 = acc4 != nullptr && c4desc[0] != 0;   // uniform
+    if constexpr (AGGONLY) {
+        if (c4desc[0] == 0) return;           // uniform: the plan does not apply to this input
+    } else {
+        if (c4desc && c4desc[0] != 0) return; // uniform: the aggregate-only variant has this launch
+    }
     const uint32_t ntiles = SORTED ? (n_sorted + kWave - 1) / kWave : (row_hi - row_lo + kWave - 1) / kWave;
     // natural order: XCD-contiguous ranges (locality).  Sorted order lists the heaviest tiles
     // first, so they are dealt round-robin instead — consecutive blocks sit on different XCDs
@@ -296,11 +301,11 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
     // natural order: the tile's slice of col, [c0, c1), is contiguous in CSR -> stage it in LDS
     bool staged = false;
     uint32_t sbase = 0;
-    if constexpr (!SORTED) {
+    if constexpr (!SORTED && !AGGONLY) {
         const uint32_t c0 = __builtin_amdgcn_readfirstlane(rs);
         const uint32_t vend = (v0 + kWave < row_hi) ? v0 + kWave : row_hi;
         const uint32_t c1 = g.rowptr[vend];   // wave-uniform: end of the tile's last valid row
-        staged = !c4 && (c1 - c0) <= kStageCap;   // (with the compact table only the few dirty rows gather here)
+        staged = (c1 - c0) <= kStageCap;
         if (staged) sbase = stage_cols(g.col, c0, c1, stage, lane);
     }
 
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
 #pragma unroll
     for (int p = 0; p < 4; ++p) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
     const uint32_t zrow = g.n;  // all-zero pad row: x + 0.0f == x exactly
-    if (c4) {
+    if constexpr (AGGONLY) {
         // this lane holds feature columns 4c .. 4c+3: which of them are table columns, and which slot
         const uint32_t d0 = c4desc[1], d1 = c4desc[2], d2 = c4desc[3], d3 = c4desc[4];
         int sel[4];
@@ -334,21 +339,18 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const float4 a = acc4[urow[p]];
-            const bool dirty = (__float_as_uint(a.x) >> 31) != 0;   // met a neighbour with stray non-zeros
-            if (!okrow[p]) continue;
-            if (!dirty) {
+            if ((__float_as_uint(a.x) >> 31) != 0) {   // dirty: met a neighbour with stray non-zeros; recomputed from full rows by k_c4_fix
+                acc[p] = agg16[(size_t)__float_as_uint(a.y) * 4 + c];
+            } else {
                 auto pick = [&](int j) { return j == 0 ? a.x : j == 1 ? a.y : j == 2 ? a.z : j == 3 ? a.w : 0.0f; };
                 acc[p] = make_float4(pick(sel[0]), pick(sel[1]), pick(sel[2]), pick(sel[3]));
-                e[p] = b[p];
-            } else if (__float_as_uint(a.y) != 0xFFFFFFFFu) {       // recomputed from full rows by k_c4_fix
-                acc[p] = agg16[(size_t)__float_as_uint(a.y) * 4 + c];
-                e[p] = b[p];
-            }                                                        // (no slot was left: gathered below, the plain way)
+            }
         }
     }
     wave_lds_sync();            // staged indices visible to the whole wave
 
     // ---- gather: neighbour rows summed in CSR order, S rows per vertex in flight
+    if constexpr (!AGGONLY) {
     while ((b[0] < e[0]) | (b[1] < e[1]) | (b[2] < e[2]) | (b[3] < e[3])) {
         uint32_t idx[4][S];
 #pragma unroll
@@ -377,6 +379,7 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
             const uint32_t nb = b[p] + S;
             b[p] = nb < e[p] ? nb : e[p];
         }
+    }
     }
 
     // ---- hand over through the LDS tile: 64 rows x 32 inputs in k order
@@ -1794,7 +1797,8 @@ int stage_variant(int f, int n1, int n2, int n3, int sigmoid_last) {
 hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
                         const float *in, float *out, float *logits, uint32_t row_lo,
                         uint32_t row_hi, uint32_t long_thresh, bool mfma, const SortedOrder *so,
-                        bool interleave, hipStream_t stream, const float *acc4, const uint32_t *c4desc, const float *agg16) {
+                        bool interleave, hipStream_t stream, const float *acc4, const uint32_t *c4desc, const float *agg16,
+                        bool mfma_agg) {
     if (row_hi <= row_lo) return hipSuccess;
     const bool sorted = so && so->n > 0 && sp.f == 16;
     if (so && so->n == 0 && sp.f == 16) return hipSuccess;   // every row of the range is a long row
@@ -1819,8 +1823,7 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
     hipLaunchKernelGGL((k_stage_f16<32, N2_, N3_, SIG_, 2, MF_, SRT_>), grid, block, 0, stream, g, ws, in4, out, \
                        LG_, P, row_lo, row_hi, long_thresh, sorted ? so->vertex : nullptr,                \
                        sorted ? so->meta : nullptr, sorted ? so->n : 0u, il,                              \
-                       sorted ? nullptr : reinterpret_cast<const float4 *>(acc4), sorted ? nullptr : c4desc,         \
-                       reinterpret_cast<const float4 *>(agg16))
+                       (const float4 *)nullptr, (sorted || !acc4) ? nullptr : c4desc, (const float4 *)nullptr)
     case 2:
         if (sorted) GNNVC_LAUNCH_F16(32, 16, false, false, true, nullptr);
         else GNNVC_LAUNCH_F16(32, 16, false, false, false, nullptr);
@@ -1840,6 +1843,24 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
 #undef GNNVC_LAUNCH_F16
     default:
         return hipErrorInvalidValue;
+    }
+    if (!sorted && acc4 && sp.f == 16) {
+        // compact-table plan: the aggregate-only variant does the launch when the device found the input fit for
+        // it (the gathering variant above has then left at once, and the other way round).  Without gathers to
+        // overlap with, the dense layers run faster on the VALU (one lane per vertex, weights from SGPRs) than on
+        // the fp32 matrix cores: 6.65 vs 7.16 ms per forward on the metric graph.
+#define GNNVC_LAUNCH_AGG(N2_, N3_, SIG_, MF_, LG_)                                                        \
+        hipLaunchKernelGGL((k_stage_f16<32, N2_, N3_, SIG_, 2, MF_, false, true>), grid, block, 0, stream, g, ws, in4, \
+                           out, LG_, P, row_lo, row_hi, long_thresh, (const uint32_t *)nullptr, (const uint4 *)nullptr, \
+                           0u, il, reinterpret_cast<const float4 *>(acc4), c4desc, reinterpret_cast<const float4 *>(agg16))
+        if (sp.variant == 1) {
+            if (mfma_agg) GNNVC_LAUNCH_AGG(32, 16, false, true, nullptr);
+            else GNNVC_LAUNCH_AGG(32, 16, false, false, nullptr);
+        } else {
+            if (mfma_agg) GNNVC_LAUNCH_AGG(16, 1, true, true, logits);
+            else GNNVC_LAUNCH_AGG(16, 1, true, false, logits);
+        }
+#undef GNNVC_LAUNCH_AGG
     }
     return hipGetLastError();
 }
