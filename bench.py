@@ -232,9 +232,21 @@ def main() -> int:
     dom_bytes = stage_bytes(dom, rows, local_nnz)
     achieved = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9
     fwd_bytes = sum(stage_bytes(i, g.n, g.nnz) for i in range(3))
-    kernel_names = ["k_stage_f1<32,32,16", "k_stage_f16<32,32,16,false", "k_stage_f16<32,16,1,true"]
+    # the kernels a stage launches under the plans in force (names as in profiles/*/kernel_stats.csv); the first
+    # one is the stage's dominant kernel
+    lt, blk, c4 = (bool(eng.get_info(k)) for k in ("lds_table_active", "blocked_stage0_active", "compact_gather_active"))
+    c4 = c4 and world <= 2        # (calls that cover less than half of the rows keep the gathering kernels)
+    agg_only = "false,2,false,false,true>"
+    stage_kernels = [
+        (["k_lt_agg", "k_lt_check_x", "k_stage_f1<32,32,16"] if lt else
+         ["k_blk_accumulate", "k_stage_f1<32,32,16"] if blk else ["k_stage_f1<32,32,16"]),
+        (["k_c4_agg", "k_column_counts", "k_c4_choose", "k_c4_compact", "k_c4_fix", "k_stage_f16<32,32,16," + agg_only]
+         if c4 else ["k_stage_f16<32,32,16,false"]),
+        (["k_c4_agg", "k_column_counts", "k_c4_choose", "k_c4_compact", "k_c4_fix", "k_stage_f16<32,16,1,true,2,false,false,true>"]
+         if c4 else ["k_stage_f16<32,16,1,true"])]
+    kernel_names = [k[0] for k in stage_kernels]
 
-    traffic, traffic_src = measured_traffic(kernel_names[dom], args.workload)
+    traffic, traffic_src = measured_traffic(stage_kernels[dom], args.workload)
     out = {
         "metric": "GNN forward edges/sec", "value": edges_per_s, "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -244,7 +256,10 @@ def main() -> int:
                    "graph": args.workload, "partition": f"1d-vertex x{world} ({part_mode}-balanced)",
                    "exchange": "none" if world == 1 else "all-gather of the N feature rows (16 fp32, or only their live "
                                                           "columns) after each partitioned stage, N scores at the end"},
-        "roofline": {"bound": "hbm", "kernel": kernel_names[dom], "achieved": achieved,
+        "roofline": {"bound": "hbm", "kernel": kernel_names[dom], "stage": dom, "stage_kernels": stage_kernels[dom],
+                     "note": "achieved = algorithmic bytes of the dominant STAGE (SURVEY.md 8d, 64-byte rows, no cache "
+                             "credit) / its HIP-event time; the stage is the kernels listed, the first one dominates",
+                     "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": dom_bytes,
@@ -306,22 +321,25 @@ def main() -> int:
     return 0
 
 
-def measured_traffic(kernel: str, workload: str):
-    """HBM/fabric bytes per launch of the dominant kernel from the committed PMC summary of the
-    latest round (rocprofv3 --pmc passes of tools/pmc_probe.py on the metric graph; L2->fabric
-    read requests x 128 B, calibrated on a 1 GiB copy in the same run, + WRITE_SIZE).  null when
-    no summary covers this kernel / workload."""
+def measured_traffic(kernels, workload: str):
+    """HBM/fabric bytes per forward of the dominant stage's kernels from the committed PMC summary of the latest
+    round (rocprofv3 --pmc passes of tools/pmc_probe.py on the metric graph; L2->fabric read requests x 128 B,
+    calibrated on a 1 GiB copy in the same run, + WRITE_SIZE; steady-state launch of each kernel).  null when the
+    summary does not cover every kernel of the stage / the workload."""
     if workload != "er10m":
         return None, None
     prof = sorted((ROOT / "profiles").glob("r*/pmc_summary.json"))
     if not prof:
         return None, None
     data = json.loads(prof[-1].read_text())
-    want = kernel.replace(" ", "").rstrip(">")
-    for name, ctrs in data.items():
-        if name.replace(" ", "").startswith(want) and "traffic_bytes" in ctrs:
-            return ctrs["traffic_bytes"], str(prof[-1].relative_to(ROOT))
-    return None, None
+    total = 0.0
+    for kernel in kernels:
+        want = kernel.replace(" ", "")
+        hit = [c for name, c in data.items() if name.replace(" ", "").startswith(want) and "traffic_bytes" in c]
+        if not hit:
+            return None, None
+        total += hit[0]["traffic_bytes"]
+    return total, str(prof[-1].relative_to(ROOT))
 
 
 def cpu_baseline(args, dev, eng, ggt):

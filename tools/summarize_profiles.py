@@ -36,15 +36,20 @@ if log.exists():
     if lines:
         (DST / "bench_under_rocprof.json").write_text(lines[-1] + "\n")
 
-agg = collections.defaultdict(lambda: collections.defaultdict(list))
+# per kernel and counter: the value of the LAST launch of the run (steady state: the first forward runs
+# without the per-graph plans, the second builds them)
+agg = collections.defaultdict(dict)
 for p in glob.glob(str(SRC / "p_*" / "*" / "*_counter_collection.csv")):
     for r in csv.DictReader(open(p)):
         k = short(r["Kernel_Name"])
         if k:
-            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            did = int(r.get("Dispatch_Id", 0) or 0)
+            cur = agg[k].get(r["Counter_Name"])
+            if cur is None or did >= cur[0]:
+                agg[k][r["Counter_Name"]] = (did, float(r["Counter_Value"]))
 summary = {}
 for k, ctrs in sorted(agg.items()):
-    m = {c: sum(v) / len(v) for c, v in ctrs.items()}
+    m = {c: v for c, (_, v) in ctrs.items()}
     d = dict(m)
     if "TCC_EA0_RDREQ_sum" in m:
         # calibrated on the 1 GiB copy of the same run: every L2->fabric read request moves 128 B
