@@ -196,11 +196,31 @@ def main() -> int:
                               replicate_stage0=None if args.replicate_stage0 < 0 else bool(args.replicate_stage0),
                               pipeline_chunks=args.pipeline_chunks, codec=codec, verify=False)
 
+    trace = bool(os.environ.get("GNNVC_BENCH_TRACE"))
+
+    def mark(what):
+        if trace:
+            torch.cuda.synchronize()
+            print(f"[rank {rank} +{time.time() - t_start:.1f}s] {what}", file=sys.stderr, flush=True)
+
+    t_start = time.time()
     codec = G.EngineRowCodec(eng) if (world > 1 and args.compress_exchange) else None
+    mark("setup done")
+    def settle():
+        # outside the timed region the ranks are kept in step: the per-graph plans are built inside the second
+        # forward (host-synchronous pieces of work of different length on every rank)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
     if codec is not None:
         step(None)   # first forward on this graph: full rows, records each stage's live columns (not a timed or warm-up step)
-    for _ in range(args.warmup):
+        settle()
+        mark("learning forward done")
+    for i in range(args.warmup):
         step(None)
+        settle()
+        mark(f"warm-up {i} done")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
