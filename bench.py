@@ -183,6 +183,9 @@ def main() -> int:
 
     def step(k: int | None):
         hook = None
+        if k is None and os.environ.get("GNNVC_BENCH_TRACE") == "2":
+            def hook(st, phase):
+                print(f"[rank {rank} +{time.time() - t_start:.2f}s] stage {st} {phase}", file=sys.stderr, flush=True)
         if k is not None:
             ev = stage_evt[k]
 
@@ -197,16 +200,20 @@ def main() -> int:
                               pipeline_chunks=args.pipeline_chunks, codec=codec, verify=False)
 
     trace = bool(os.environ.get("GNNVC_BENCH_TRACE"))
+    t_start = time.time()
 
     def mark(what):
         if trace:
-            torch.cuda.synchronize()
+            if os.environ.get("GNNVC_BENCH_TRACE") != "2":   # "2": host-side progress only, no extra device syncs
+                torch.cuda.synchronize()
             print(f"[rank {rank} +{time.time() - t_start:.1f}s] {what}", file=sys.stderr, flush=True)
 
     t_start = time.time()
     codec = G.EngineRowCodec(eng) if (world > 1 and args.compress_exchange) else None
     mark("setup done")
     def settle():
+        if os.environ.get("GNNVC_BENCH_NO_SETTLE"):
+            return
         # outside the timed region the ranks are kept in step: the per-graph plans are built inside the second
         # forward (host-synchronous pieces of work of different length on every rank)
         torch.cuda.synchronize()
