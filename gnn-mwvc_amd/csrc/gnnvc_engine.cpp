@@ -133,7 +133,9 @@ struct gnnvc_engine {
     DevBuf<float> c4_table, c4_acc, c4_agg16;
     DevBuf<uint32_t> c4_dirty;
     uint32_t c4_dirty_cap = 0;
-    DevBuf<unsigned long long> c4_counts;
+    DevBuf<unsigned long long> c4_counts, c4_emit_counts;
+    int c4_fused_for = -1;          // stage whose input statistics (and table) the previous stage kernel of this forward produced
+    int c4_last_desc = 0;           // word offset in c4_desc of the plan's last launch (tests / tools)
 
     // option "mfma_dense": dense layers on the matrix cores (bit-identical to the VALU path).
     // 0 = VALU everywhere, 1 = MFMA everywhere, 2 = MFMA in the F = 16 stages only (default:
@@ -555,14 +557,15 @@ int build_compact(gnnvc_engine *e) {
     chunks = (chunks + 255u) / 256u * 256u;
     const uint32_t rows = (g.n + chunks - 1) / chunks;
     chunks = (g.n + rows - 1) / rows;
-    HIP_TRY(e, e->c4_desc.reserve(8));
+    HIP_TRY(e, e->c4_desc.reserve(24));   // 8 words per consumer stage (1, 2), word 16 = build flag
     HIP_TRY(e, e->c4_counts.reserve(16));
+    HIP_TRY(e, e->c4_emit_counts.reserve(gnnvc::kEmitCounters));
     HIP_TRY(e, e->c4_segcnt.reserve((size_t)chunks * nblocks));
     HIP_TRY(e, e->c4_stepcnt.reserve(chunks));
     HIP_TRY(e, e->c4_stepptr.reserve((size_t)chunks + 1));
     HIP_TRY(e, e->pin_small.reserve((size_t)chunks + 2));
-    uint32_t *flag = e->c4_desc.p + 7;
-    HIP_TRY(e, hipMemsetAsync(e->c4_desc.p, 0, 8 * sizeof(uint32_t), e->stream));
+    uint32_t *flag = e->c4_desc.p + 16;
+    HIP_TRY(e, hipMemsetAsync(e->c4_desc.p, 0, 24 * sizeof(uint32_t), e->stream));
     HIP_TRY(e, gnnvc::lds_table_count(g, rows, chunks, nblocks, bc, e->c4_segcnt.p, flag, e->stream));
     HIP_TRY(e, gnnvc::lds_table_steps(g, rows, chunks, nblocks, e->c4_segcnt.p, nullptr, e->c4_stepcnt.p, nullptr, false, e->stream));
     HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, e->c4_stepcnt.p, chunks * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
@@ -597,8 +600,18 @@ int build_compact(gnnvc_engine *e) {
     return GNNVC_OK;
 }
 
-int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float *in, float *out, float *logits) {
+int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float *in, float *out, float *logits,
+              bool in_forward = false) {
     const bool longs = e->n_long > 0;
+    // Producer side of the compact-table plan: inside a whole forward (engine-owned feature buffers nobody else
+    // writes) the stage kernel that produces the next 16-wide stage's input also counts its non-zeros and writes
+    // its compact rows, so that stage can skip its two passes over the input.  Only the VALU variants emit.
+    const int fused_in = in_forward ? e->c4_fused_for : -1;   // is THIS stage's input covered by the previous kernel?
+    e->c4_fused_for = -1;
+    gnnvc::EmitArgs emit;
+    const size_t ns_ = e->stages.size();
+    const bool may_emit = in_forward && e->c4_ready && !longs && (size_t)stage + 1 < ns_ && e->stages[stage + 1].f == 16 &&
+                          lo == 0 && hi == e->g.n && e->opt_mfma != 1;
     const uint32_t thr = (e->stages[stage].f == 16) ? e->thresh_f16 : e->long_thresh;   // this stage's long-row threshold
     if (longs) {   // fork: the long rows of this stage run beside the tile kernel
         HIP_TRY(e, hipEventRecord(e->ev_fork, e->stream));
@@ -618,15 +631,22 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
         }
         ++e->graph_uses;
     }
+    if (stage == 0 && may_emit) {
+        HIP_TRY(e, hipMemsetAsync(e->c4_emit_counts.p, 0, gnnvc::kEmitCounters * sizeof(unsigned long long), e->stream));
+        emit.spec = e->c4_desc.p;          // consumer stage 1: words 0..7
+        emit.table = e->c4_table.p;
+        emit.counts = e->c4_emit_counts.p;
+        e->c4_fused_for = 1;
+    }
     if (stage == 0 && e->lt_ready) {
         HIP_TRY(e, gnnvc::launch_stage0_lds_table(e->stages[0], e->g, e->ws, e->params.p, in, out, lo, hi, e->lt_rows,
                                                   e->lt_stepptr.p, e->lt_steps.p, e->lt_entries.p, e->lt_bytes.p,
                                                   e->blk_acc.p, e->lt_bad.p, e->long_thresh, e->opt_mfma == 1,
-                                                  e->interleave, e->stream));
+                                                  e->interleave, e->stream, emit));
     } else if (stage == 0 && e->blocked_ready) {
         HIP_TRY(e, gnnvc::launch_stage0_blocked(e->stages[0], e->g, e->ws, e->params.p, in, out, lo, hi,
                                                 e->blk_count, e->blk_ptr.p, e->blk_col.p, e->blk_acc.p,
-                                                e->long_thresh, e->opt_mfma == 1, e->interleave, e->stream));
+                                                e->long_thresh, e->opt_mfma == 1, e->interleave, e->stream, emit));
     } else {
         const bool mfma = e->opt_mfma == 1 || (e->opt_mfma == 2 && e->stages[stage].f == 16);
         gnnvc::SortedOrder so;
@@ -640,12 +660,23 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
             }
             // worth its fixed cost (count + compact the whole input) only when this call covers most of the rows
             if (e->c4_ready && !longs && (uint64_t)(hi - lo) * 2 >= e->g.n) {
-                HIP_TRY(e, gnnvc::column_counts(in, e->g.n, e->c4_counts.p, e->stream));
-                HIP_TRY(e, gnnvc::launch_compact_gather(e->g, in, e->c4_counts.p, e->c4_desc.p, e->c4_table.p, e->c4_acc.p, lo, hi,
+                uint32_t *desc = e->c4_desc.p + 8 * (stage - 1);
+                e->c4_last_desc = 8 * (stage - 1);
+                const bool fused = fused_in == stage;   // the producing kernel left counts (and perhaps the table)
+                if (!fused) HIP_TRY(e, gnnvc::column_counts(in, e->g.n, e->c4_counts.p, e->stream));
+                HIP_TRY(e, gnnvc::launch_compact_gather(e->g, in, fused ? e->c4_emit_counts.p : e->c4_counts.p, fused ? 64 : 1,
+                                                        desc, e->c4_table.p, e->c4_acc.p, lo, hi,
                                                         e->c4_rows, e->c4_stepptr.p, e->c4_steps.p, e->c4_entries.p,
                                                         e->c4_dirty.p, e->c4_dirty_cap, e->c4_agg16.p, e->stream));
                 acc4 = e->c4_acc.p;
-                c4desc = e->c4_desc.p;
+                c4desc = desc;
+                if (may_emit) {   // and this stage's own (aggregate-only, VALU) kernel produces for the next one
+                    HIP_TRY(e, hipMemsetAsync(e->c4_emit_counts.p, 0, gnnvc::kEmitCounters * sizeof(unsigned long long), e->stream));
+                    emit.spec = e->c4_desc.p + 8 * stage;
+                    emit.table = e->c4_table.p;
+                    emit.counts = e->c4_emit_counts.p;
+                    e->c4_fused_for = stage + 1;
+                }
             }
             int rc = ensure_sorted(e, lo, hi);
             if (rc) return rc;
@@ -658,7 +689,7 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
         }
         HIP_TRY(e, gnnvc::launch_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi,
                                        thr, mfma, sop, e->interleave, e->stream, acc4, c4desc, e->c4_agg16.p,
-                                       e->opt_mfma == 1));
+                                       e->opt_mfma == 1, emit));
     }
     if (longs) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));   // join
     return GNNVC_OK;
@@ -797,7 +828,7 @@ void gnnvc_destroy(gnnvc_engine *e) {
     e->lt_stepcnt.release(); e->lt_bad.release(); e->lt_steps.release();
     e->c4_entries.release(); e->c4_segcnt.release(); e->c4_stepptr.release(); e->c4_stepcnt.release();
     e->c4_desc.release(); e->c4_steps.release(); e->c4_table.release(); e->c4_acc.release(); e->c4_counts.release();
-    e->c4_agg16.release(); e->c4_dirty.release();
+    e->c4_agg16.release(); e->c4_dirty.release(); e->c4_emit_counts.release();
     e->long_list.release(); e->long_count.release();
     e->pin_rowptr.release(); e->pin_col.release(); e->pin_w.release(); e->pin_nw.release();
     e->pin_small.release();
@@ -850,7 +881,7 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
         if (e->c4_ready && e->c4_desc.p) {
             uint32_t d[8] = {0};
             if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess ||
-                hipMemcpy(d, e->c4_desc.p, sizeof d, hipMemcpyDeviceToHost) != hipSuccess)
+                hipMemcpy(d, e->c4_desc.p + e->c4_last_desc, sizeof d, hipMemcpyDeviceToHost) != hipSuccess)
                 return GNNVC_ERR_DEVICE;
             *value = k == "compact_gather_last_ok" ? (long)d[0] : (long)d[5];
         }
@@ -1093,11 +1124,12 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
     // pad rows (index n) of the 16-wide feature buffers must read as zero
     for (auto &b : e->h) HIP_TRY(e, gnnvc::launch_zero_pad_row(b.p, n, 16, e->stream));
     const float *cur = d_x;
+    e->c4_fused_for = -1;
     HIP_TRY(e, hipEventRecord(e->ev[0], e->stream));
     for (size_t s = 0; s < ns; ++s) {
         const bool last = s + 1 == ns;
         float *dst = last ? d_scores : e->h[s & 1].p;
-        rc = run_stage(e, (int)s, 0, n, cur, dst, last ? d_logits : nullptr);
+        rc = run_stage(e, (int)s, 0, n, cur, dst, last ? d_logits : nullptr, /*in_forward=*/true);
         if (rc) return rc;
         HIP_TRY(e, hipEventRecord(e->ev[s + 1], e->stream));
         cur = dst;

@@ -43,11 +43,22 @@ int stage_variant(int f, int n1, int n2, int n3, int sigmoid_last);
 // Fused stage over rows [row_lo, row_hi).  in: F=1 -> n floats; F=16 -> (n+1) x 16
 // with a zero last row.  out: (n+1) x n3 rows (n3 = 16) or, for the sigmoid
 // stage, out = scores[n], logits optional.
+// Producer side of the compact-table plan: a stage kernel whose dense layers run on the VALU can count the
+// non-zeros of the rows it writes (64 slots x 17 counters, zeroed by the caller) and write their compact form for
+// the columns chosen at the previous forward (spec = that forward's desc), see c4_emit.  All null = off.
+struct EmitArgs {
+    const uint32_t *spec = nullptr;
+    float *table = nullptr;
+    unsigned long long *counts = nullptr;
+};
+constexpr int kEmitCounters = 64 * 17;
+
 hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
                         const float *in, float *out, float *logits, uint32_t row_lo,
                         uint32_t row_hi, uint32_t long_thresh, bool mfma, const SortedOrder *so,
                         bool interleave, hipStream_t stream, const float *acc4 = nullptr,
-                        const uint32_t *c4desc = nullptr, const float *agg16 = nullptr, bool mfma_agg = false);
+                        const uint32_t *c4desc = nullptr, const float *agg16 = nullptr, bool mfma_agg = false,
+                        const EmitArgs &emit = EmitArgs());
 
 // Building blocks of the degree-sorted order (the prefix over the few thousand degree classes
 // is done on the host).
@@ -78,7 +89,8 @@ hipError_t build_blocked_index(const GraphDev &g, uint32_t wb, uint32_t nblocks,
 hipError_t launch_stage0_blocked(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
                                  const float *x, float *out, uint32_t row_lo, uint32_t row_hi,
                                  uint32_t nblocks, const uint32_t *bp, const uint32_t *colb, float *acc,
-                                 uint32_t long_thresh, bool mfma, bool interleave, hipStream_t stream);
+                                 uint32_t long_thresh, bool mfma, bool interleave, hipStream_t stream,
+                                 const EmitArgs &emit = EmitArgs());
 
 // Layer-by-layer kernels (any model; also the layer-level ABI entry points).
 hipError_t launch_graph_layer(const GraphDev &g, float ws, uint32_t f, const float *in,
@@ -105,13 +117,16 @@ hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float
                                    float *out, uint32_t row_lo, uint32_t row_hi, uint32_t rows_per_chunk,
                                    const uint32_t *step_ptr, const void *steps, const uint32_t *entries, const uint8_t *wbyte,
                                    float *acc, uint32_t *bad, uint32_t long_thresh, bool mfma, bool interleave,
-                                   hipStream_t stream);
+                                   hipStream_t stream, const EmitArgs &emit = EmitArgs());
 
 // compact-table plan of the 16-wide stages (see the k_c4_* kernels); the step layout is built with the
 // lds_table_* functions at compact_block() columns per block
 uint32_t compact_max_rows();
 uint32_t compact_block();
-hipError_t launch_compact_gather(const GraphDev &g, const float *in, const unsigned long long *counts, uint32_t *desc,
+// counts: per-column non-zero counts of `in` — 16 counters from column_counts() (count_slots = 1) or the
+// producer's kEmitCounters (count_slots = 64: 17 counters per slot, the 17th = rows seen; the table may then
+// already hold the rows' compact form for the columns in desc, see EmitArgs)
+hipError_t launch_compact_gather(const GraphDev &g, const float *in, const unsigned long long *counts, int count_slots, uint32_t *desc,
                                  float *table, float *acc4, uint32_t row_lo, uint32_t row_hi, uint32_t rows_per_chunk,
                                  const uint32_t *step_ptr, const void *steps, const uint32_t *entries, uint32_t *dirty_rows,
                                  uint32_t dirty_cap, float *agg16, hipStream_t stream);

@@ -241,6 +241,37 @@ __device__ __forceinline__ void mfma_tail(f32x16 (&d)[2], const float *__restric
 // srt_meta).  A tile costs max-degree gather rounds whatever the other lanes do, so on
 // skewed graphs tiles of similar degree waste far fewer rounds; rows are then no longer
 // contiguous, so the column indices are read straight from global memory.
+// Producer side of the compact-table plan (k_c4_*, further down): a stage kernel's VALU epilogue hands over
+// this lane's finished output row (already written to its LDS tile row `trow`, non-zero mask `nz`).  The row
+// is added to the per-column non-zero counts of the NEXT stage's input — 64 slots of 17 counters (16 columns +
+// rows seen) so that the atomics of different blocks rarely meet — and, when the previous forward's choice of
+// table columns is at hand (spec[0] != 0), its compact form is written: the consumer then needs neither its
+// counting pass nor its compaction pass over the 640 MB it is about to read.
+typedef float c4row __attribute__((ext_vector_type(4)));
+constexpr int kEmitSlots = 64, kEmitStride = 17;
+
+__device__ __forceinline__ void c4_emit(const float *trow, uint32_t nz, uint32_t u, bool mine, int lane,
+                                        const uint32_t *__restrict__ spec, c4row *__restrict__ table,
+                                        unsigned long long *__restrict__ counts) {
+    uint32_t my = 0;
+#pragma unroll
+    for (int cidx = 0; cidx < 16; ++cidx) {
+        const uint32_t cnt = (uint32_t)__popcll(__ballot(mine && (nz >> cidx & 1u)));
+        if (lane == cidx) my = cnt;
+    }
+    const uint32_t rows = (uint32_t)__popcll(__ballot(mine));
+    if (lane == 16) my = rows;
+    if (lane <= 16 && my) atomicAdd(&counts[(blockIdx.x & (kEmitSlots - 1)) * kEmitStride + lane], (unsigned long long)my);
+    if (spec[0] && mine) {
+        const uint32_t s0 = spec[1], s1 = spec[2], s2 = spec[3], s3 = spec[4];
+        const float a = trow[s0], b = trow[s1], c = trow[s2], d = trow[s3];
+        c4row out = {a == 0.0f ? 0.0f : a, b == 0.0f ? 0.0f : b, c == 0.0f ? 0.0f : c, d == 0.0f ? 0.0f : d};
+        if (nz & ~((1u << s0) | (1u << s1) | (1u << s2) | (1u << s3)))
+            out[0] = __uint_as_float(__float_as_uint(out[0]) | 0x80000000u);   // stray non-zeros: flag the vertex
+        table[u] = out;
+    }
+}
+
 // AGGONLY (compact-table plan): every row's aggregate arrives ready-made — four sums in acc4 for clean rows, the
 // full 16 in agg16 for dirty ones — and the kernel is only the dense layers; it leaves at once when the device
 // found the input unfit for the plan (c4desc[0] == 0), and the gathering variant leaves at once when it was fit.
@@ -250,7 +281,8 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
         float *__restrict__ logits, const float *__restrict__ P, uint32_t row_lo,
         uint32_t row_hi, uint32_t long_thresh, const uint32_t *__restrict__ srt_vertex,
         const uint4 *__restrict__ srt_meta, uint32_t n_sorted, int interleave,
-        const float4 *__restrict__ acc4, const uint32_t *__restrict__ c4desc, const float4 *__restrict__ agg16) {
+        const float4 *__restrict__ acc4, const uint32_t *__restrict__ c4desc, const float4 *__restrict__ agg16,
+        const uint32_t *__restrict__ emit_spec, c4row *__restrict__ emit_table, unsigned long long *__restrict__ emit_counts) {
     __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kRegionFloats];
     const int lane = threadIdx.x & 63;
     float *T = lds[threadIdx.x >> 6];
@@ -453,8 +485,13 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
             }
         } else {
             wave_lds_sync();
+            uint32_t nz = 0;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) T[lane * kOutPitch + j] = x3[j];
+            for (int j = 0; j < 16; ++j) {
+                T[lane * kOutPitch + j] = x3[j];
+                nz |= (x3[j] != 0.0f ? 1u : 0u) << j;
+            }
+            if (emit_counts) c4_emit(&T[lane * kOutPitch], nz, u, mine, lane, emit_spec, emit_table, emit_counts);
         }
     }
 
@@ -483,7 +520,8 @@ __global__ __launch_bounds__(kBlock) void k_stage_f1(
         const float *__restrict__ P, uint32_t row_lo, uint32_t row_hi,
         const uint32_t *__restrict__ ep, const uint32_t *__restrict__ ecol,
         const float *__restrict__ acc_in, uint32_t long_thresh, int interleave,
-        const uint32_t *__restrict__ acc_bad) {
+        const uint32_t *__restrict__ acc_bad,
+        const uint32_t *__restrict__ emit_spec, c4row *__restrict__ emit_table, unsigned long long *__restrict__ emit_counts) {
     // acc_bad (LDS-table plan only): *acc_bad == 0 -> acc_in holds the rows' COMPLETE sums and no entry is left
     // to add; != 0 -> the plan did not apply to this input, acc_in is ignored and every entry is gathered here.
     __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kRegionFloats];
@@ -572,8 +610,13 @@ __global__ __launch_bounds__(kBlock) void k_stage_f1(
         float x2[N2], x3[N3];
         dense<N1, N1, N2, 0>(x1, x2, W2, b2);
         dense<N2, N2, N3, 0>(x2, x3, W3, b3);
+        uint32_t nz = 0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) T[lane * kOutPitch + j] = x3[j];
+        for (int j = 0; j < 16; ++j) {
+            T[lane * kOutPitch + j] = x3[j];
+            nz |= (x3[j] != 0.0f ? 1u : 0u) << j;
+        }
+        if (emit_counts) c4_emit(&T[lane * kOutPitch], nz, u, mine, lane, emit_spec, emit_table, emit_counts);
     }
     wave_lds_sync();
 #pragma unroll
@@ -1066,13 +1109,35 @@ __global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ st
 constexpr uint32_t kC4Block = 131072;     // vertices per column block: 2 MiB of compact rows
 constexpr uint32_t kC4MaxRows = 7400;     // rows per chunk: 16 B * rows + 32 KiB values + 8 KiB entries + dirty bits <= 160 KiB
 
-__global__ void k_c4_choose(const unsigned long long *__restrict__ counts, uint32_t n, uint32_t *__restrict__ desc) {
+// desc words: [0] ok, [1..4] the chosen columns (ascending), [5] dirty-row counter, [6] the table still has to be
+// written (k_c4_compact) — 0 when the producing stage kernel already wrote it for exactly these columns.
+// slots == 1: counts[16] from k_column_counts.  slots == 64: the producer's counters (17 per slot; the 17th
+// counts the rows it saw — if that is not n, the producer that ran was not the emitting one and nothing here can
+// be trusted for this forward).  desc on entry = the previous forward's choice (the producer's spec).
+__global__ void k_c4_choose(const unsigned long long *__restrict__ counts, int slots, uint32_t n, uint32_t *__restrict__ desc) {
     if (threadIdx.x || blockIdx.x) return;
     unsigned long long c[16];
     bool taken[16];
     for (int i = 0; i < 16; ++i) {
-        c[i] = counts[i];
+        c[i] = 0;
         taken[i] = false;
+    }
+    unsigned long long rows = 0;
+    if (slots == 1) {
+        for (int i = 0; i < 16; ++i) c[i] = counts[i];
+        rows = n;
+    } else {
+        for (int sl = 0; sl < slots; ++sl) {
+            for (int i = 0; i < 16; ++i) c[i] += counts[sl * kEmitStride + i];
+            rows += counts[sl * kEmitStride + 16];
+        }
+    }
+    const bool prev_ok = desc[0] != 0;
+    const uint32_t p1 = desc[1], p2 = desc[2], p3 = desc[3], p4 = desc[4];
+    if (rows != n) {   // no (complete) statistics for this input
+        desc[0] = 0;
+        desc[6] = 0;
+        return;
     }
     for (int j = 0; j < 4; ++j) {            // four fullest columns (ties: lowest index)
         int best = -1;
@@ -1081,19 +1146,27 @@ __global__ void k_c4_choose(const unsigned long long *__restrict__ counts, uint3
         taken[best] = true;
     }
     unsigned long long rest = 0;
-    uint32_t k = 0;
+    uint32_t k = 0, col[4];
     for (int i = 0; i < 16; ++i) {
-        if (taken[i]) desc[1 + k++] = (uint32_t)i;
+        if (taken[i]) col[k++] = (uint32_t)i;
         else rest += c[i];
     }
-    // every stray non-zero flags a vertex and dirties that vertex's neighbours, which are then gathered the
-    // plain way: worth it only while they are few
-    desc[0] = rest <= (unsigned long long)n / 512 ? 1u : 0u;
+    // every stray non-zero flags a vertex and dirties that vertex's neighbours, which are then recomputed from
+    // full rows: worth it only while they are few
+    const uint32_t ok = rest <= (unsigned long long)n / 512 ? 1u : 0u;
+    const bool table_written = slots > 1 && prev_ok && p1 == col[0] && p2 == col[1] && p3 == col[2] && p4 == col[3];
+    desc[0] = ok;
+    desc[1] = col[0];
+    desc[2] = col[1];
+    desc[3] = col[2];
+    desc[4] = col[3];
+    desc[6] = (ok && !table_written) ? 1u : 0u;
 }
 
 __global__ __launch_bounds__(256) void k_c4_compact(const float4 *__restrict__ feat, uint32_t n, uint32_t *__restrict__ desc,
                                                     f32x4 *__restrict__ table) {
-    if (!desc[0]) return;   // (a block that finds a negative value below clears it for the kernels that follow)
+    if (!desc[0] || !desc[6]) return;   // not fit, or the producing kernel wrote the table already
+    // (a block that finds a negative value below clears desc[0] for the kernels that follow)
     const uint32_t c0 = desc[1], c1 = desc[2], c2 = desc[3], c3 = desc[4];
     const uint32_t mask = (1u << c0) | (1u << c1) | (1u << c2) | (1u << c3);
     bool negative = false;
@@ -1798,7 +1871,7 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
                         const float *in, float *out, float *logits, uint32_t row_lo,
                         uint32_t row_hi, uint32_t long_thresh, bool mfma, const SortedOrder *so,
                         bool interleave, hipStream_t stream, const float *acc4, const uint32_t *c4desc, const float *agg16,
-                        bool mfma_agg) {
+                        bool mfma_agg, const EmitArgs &emit) {
     if (row_hi <= row_lo) return hipSuccess;
     const bool sorted = so && so->n > 0 && sp.f == 16;
     if (so && so->n == 0 && sp.f == 16) return hipSuccess;   // every row of the range is a long row
@@ -1813,17 +1886,20 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
     switch (sp.variant * 2 + (mfma ? 1 : 0)) {
     case 0:
         hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, false>), grid, block, 0, stream, g, ws, in, out, P,
-                           row_lo, row_hi, g.rowptr, g.col, nofloat, long_thresh, il, (const uint32_t *)nullptr);
+                           row_lo, row_hi, g.rowptr, g.col, nofloat, long_thresh, il, (const uint32_t *)nullptr,
+                           emit.spec, reinterpret_cast<c4row *>(emit.table), emit.counts);
         break;
     case 1:
         hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, true>), grid, block, 0, stream, g, ws, in, out, P,
-                           row_lo, row_hi, g.rowptr, g.col, nofloat, long_thresh, il, (const uint32_t *)nullptr);
+                           row_lo, row_hi, g.rowptr, g.col, nofloat, long_thresh, il, (const uint32_t *)nullptr,
+                           (const uint32_t *)nullptr, (c4row *)nullptr, (unsigned long long *)nullptr);
         break;
 #define GNNVC_LAUNCH_F16(N2_, N3_, SIG_, MF_, SRT_, LG_)                                              \
     hipLaunchKernelGGL((k_stage_f16<32, N2_, N3_, SIG_, 2, MF_, SRT_>), grid, block, 0, stream, g, ws, in4, out, \
                        LG_, P, row_lo, row_hi, long_thresh, sorted ? so->vertex : nullptr,                \
                        sorted ? so->meta : nullptr, sorted ? so->n : 0u, il,                              \
-                       (const float4 *)nullptr, (sorted || !acc4) ? nullptr : c4desc, (const float4 *)nullptr)
+                       (const float4 *)nullptr, (sorted || !acc4) ? nullptr : c4desc, (const float4 *)nullptr,           \
+                       (const uint32_t *)nullptr, (c4row *)nullptr, (unsigned long long *)nullptr)
     case 2:
         if (sorted) GNNVC_LAUNCH_F16(32, 16, false, false, true, nullptr);
         else GNNVC_LAUNCH_F16(32, 16, false, false, false, nullptr);
@@ -1852,7 +1928,9 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
 #define GNNVC_LAUNCH_AGG(N2_, N3_, SIG_, MF_, LG_)                                                        \
         hipLaunchKernelGGL((k_stage_f16<32, N2_, N3_, SIG_, 2, MF_, false, true>), grid, block, 0, stream, g, ws, in4, \
                            out, LG_, P, row_lo, row_hi, long_thresh, (const uint32_t *)nullptr, (const uint4 *)nullptr, \
-                           0u, il, reinterpret_cast<const float4 *>(acc4), c4desc, reinterpret_cast<const float4 *>(agg16))
+                           0u, il, reinterpret_cast<const float4 *>(acc4), c4desc, reinterpret_cast<const float4 *>(agg16), \
+                           (MF_ || SIG_) ? nullptr : emit.spec, reinterpret_cast<c4row *>((MF_ || SIG_) ? nullptr : emit.table), \
+                           (MF_ || SIG_) ? nullptr : emit.counts)
         if (sp.variant == 1) {
             if (mfma_agg) GNNVC_LAUNCH_AGG(32, 16, false, true, nullptr);
             else GNNVC_LAUNCH_AGG(32, 16, false, false, nullptr);
@@ -1943,7 +2021,7 @@ hipError_t build_blocked_index(const GraphDev &g, uint32_t wb, uint32_t nblocks,
 hipError_t launch_stage0_blocked(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
                                  const float *x, float *out, uint32_t row_lo, uint32_t row_hi,
                                  uint32_t nblocks, const uint32_t *bp, const uint32_t *colb, float *acc,
-                                 uint32_t long_thresh, bool mfma, bool interleave, hipStream_t stream) {
+                                 uint32_t long_thresh, bool mfma, bool interleave, hipStream_t stream, const EmitArgs &emit) {
     if (row_hi <= row_lo) return hipSuccess;
     if (sp.variant != 0) return hipErrorInvalidValue;
     const unsigned nb = (row_hi - row_lo + 255) / 256;
@@ -1959,11 +2037,11 @@ hipError_t launch_stage0_blocked(const StagePlan &sp, const GraphDev &g, float w
     if (mfma)
         hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, true>), grid, block, 0, stream, g, ws, x, out,
                            params + sp.param_offset, row_lo, row_hi, ep, colb, acc_in, long_thresh, interleave ? 1 : 0,
-                           (const uint32_t *)nullptr);
+                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, (c4row *)nullptr, (unsigned long long *)nullptr);
     else
         hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, false>), grid, block, 0, stream, g, ws, x, out,
                            params + sp.param_offset, row_lo, row_hi, ep, colb, acc_in, long_thresh, interleave ? 1 : 0,
-                           (const uint32_t *)nullptr);
+                           (const uint32_t *)nullptr, emit.spec, reinterpret_cast<c4row *>(emit.table), emit.counts);
     return hipGetLastError();
 }
 
@@ -2002,7 +2080,7 @@ hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float
                                    float *out, uint32_t row_lo, uint32_t row_hi, uint32_t rows_per_chunk,
                                    const uint32_t *step_ptr, const void *steps, const uint32_t *entries, const uint8_t *wbyte,
                                    float *acc, uint32_t *bad, uint32_t long_thresh, bool mfma, bool interleave,
-                                   hipStream_t stream) {
+                                   hipStream_t stream, const EmitArgs &emit) {
     if (row_hi <= row_lo) return hipSuccess;
     if (sp.variant != 0 || rows_per_chunk == 0 || rows_per_chunk > kLtMaxRows || g.nnz == 0) return hipErrorInvalidValue;
     // does this forward's input match the table?  decided on the device: no host round trip
@@ -2027,10 +2105,12 @@ hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float
     const dim3 grid(blocks_per_xcd * 8), block(kBlock);
     if (mfma)
         hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, true>), grid, block, 0, stream, g, ws, x, out, params + sp.param_offset,
-                           row_lo, row_hi, g.rowptr, g.col, acc, long_thresh, interleave ? 1 : 0, (const uint32_t *)bad);
+                           row_lo, row_hi, g.rowptr, g.col, acc, long_thresh, interleave ? 1 : 0, (const uint32_t *)bad,
+                           (const uint32_t *)nullptr, (c4row *)nullptr, (unsigned long long *)nullptr);
     else
         hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, false>), grid, block, 0, stream, g, ws, x, out, params + sp.param_offset,
-                           row_lo, row_hi, g.rowptr, g.col, acc, long_thresh, interleave ? 1 : 0, (const uint32_t *)bad);
+                           row_lo, row_hi, g.rowptr, g.col, acc, long_thresh, interleave ? 1 : 0, (const uint32_t *)bad,
+                           emit.spec, reinterpret_cast<c4row *>(emit.table), emit.counts);
     return hipGetLastError();
 }
 
@@ -2040,7 +2120,7 @@ uint32_t compact_block() { return kC4Block; }
 
 // counts -> desc -> table -> four sums per row of [row_lo, row_hi) (chunks that straddle the ends are done
 // whole).  `counts` holds the per-column non-zero counts of `in` (column_counts, same stream).
-hipError_t launch_compact_gather(const GraphDev &g, const float *in, const unsigned long long *counts, uint32_t *desc,
+hipError_t launch_compact_gather(const GraphDev &g, const float *in, const unsigned long long *counts, int count_slots, uint32_t *desc,
                                  float *table, float *acc4, uint32_t row_lo, uint32_t row_hi, uint32_t rows_per_chunk,
                                  const uint32_t *step_ptr, const void *steps, const uint32_t *entries, uint32_t *dirty_rows,
                                  uint32_t dirty_cap, float *agg16, hipStream_t stream) {
@@ -2048,7 +2128,7 @@ hipError_t launch_compact_gather(const GraphDev &g, const float *in, const unsig
     if (rows_per_chunk == 0 || rows_per_chunk > kC4MaxRows) return hipErrorInvalidValue;
     hipError_t rc0 = hipMemsetAsync(desc + 5, 0, sizeof(uint32_t), stream);   // dirty-row counter
     if (rc0 != hipSuccess) return rc0;
-    hipLaunchKernelGGL(k_c4_choose, dim3(1), dim3(64), 0, stream, counts, g.n, desc);
+    hipLaunchKernelGGL(k_c4_choose, dim3(1), dim3(64), 0, stream, counts, count_slots, g.n, desc);
     hipLaunchKernelGGL(k_c4_compact, dim3(std::min<unsigned>((g.n + 256) / 256, 4096u)), dim3(256), 0, stream,
                        reinterpret_cast<const float4 *>(in), g.n, desc, reinterpret_cast<f32x4 *>(table));
     const uint32_t c0 = row_lo / rows_per_chunk, c1 = (row_hi - 1) / rows_per_chunk + 1;

@@ -612,6 +612,34 @@ def test_compact_gather_plan_is_bit_identical(model_text, oracle_model, case):
         e.close()
 
 
+def test_compact_gather_producer_side_statistics(model_text, oracle_model):
+    """From the third forward on a graph, the stage kernels themselves count the non-zeros of the rows they write and
+    write their compact form (c4_emit), and the next stage skips its two passes over its input.  Same bits, forward
+    after forward, also when the input — and with it the set of live columns — changes in between."""
+    import gnn_mwvc_amd as G
+    g = gg.erdos_renyi(30000, 300000, 72)
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_option("blocked_min_n", 0)
+        e.set_weight_scale(g.ws)
+        oracle_model.set_weight_scale(g.ws)
+        e.upload_graph(g)
+        want = oracle_model.logits(g)
+        rng = np.random.default_rng(9)
+        x2 = (g.x() * rng.uniform(0.2, 3.0, g.n).astype(np.float32)).astype(np.float32)   # other features, other live columns
+        want2 = oracle_model.predict(g, x2, stop_after=oracle_model.n_layers - 2)[:, 0]
+        seen_ok = 0
+        for i, (x, w) in enumerate([(g.x(), want)] * 4 + [(x2, want2)] * 3 + [(g.x(), want)] * 2):
+            _, logits = e.forward(x)
+            assert np.array_equal(bits(logits[:, 0]), bits(w)), i
+            if i >= 1:
+                assert e.get_info("compact_gather_active") == 1
+                seen_ok += e.get_info("compact_gather_last_ok")
+        assert seen_ok > 0       # the plan really ran on some of these forwards
+    finally:
+        e.close()
+
+
 # ---------------------------------------------------------------- long-row path
 
 @pytest.mark.parametrize("thresh,block_cols", [(8, 0), (64, 0), (300, 0), (0, 0), (16, 512), (1000, 2048)])
