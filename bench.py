@@ -283,10 +283,12 @@ def main() -> int:
     stage_kernels = [
         (["k_lt_agg", "k_lt_check_x", "k_stage_f1<32,32,16"] if lt else
          ["k_blk_accumulate", "k_stage_f1<32,32,16"] if blk else ["k_stage_f1<32,32,16"]),
-        (["k_c4_agg", "k_column_counts", "k_c4_choose", "k_c4_compact", "k_c4_fix", "k_stage_f16<32,32,16," + agg_only]
-         if c4 else ["k_stage_f16<32,32,16,false"]),
-        (["k_c4_agg", "k_column_counts", "k_c4_choose", "k_c4_compact", "k_c4_fix", "k_stage_f16<32,16,1,true,2,false,false,true>"]
-         if c4 else ["k_stage_f16<32,16,1,true"])]
+        # (inside a whole forward the producing stage kernel counts and compacts: no k_column_counts, and
+        # k_c4_compact leaves at once)
+        (["k_c4_agg", "k_c4_choose", "k_c4_compact", "k_c4_fix", "k_stage_f16<32,32,16," + agg_only] +
+         (["k_column_counts"] if world > 1 else []) if c4 else ["k_stage_f16<32,32,16,false"]),
+        (["k_c4_agg", "k_c4_choose", "k_c4_compact", "k_c4_fix", "k_stage_f16<32,16,1,true,2,false,false,true>"] +
+         (["k_column_counts"] if world > 1 else []) if c4 else ["k_stage_f16<32,16,1,true"])]
     kernel_names = [k[0] for k in stage_kernels]
 
     traffic, traffic_src = measured_traffic(stage_kernels[dom], args.workload)

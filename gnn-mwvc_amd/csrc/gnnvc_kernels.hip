@@ -1114,24 +1114,33 @@ constexpr uint32_t kC4MaxRows = 7400;     // rows per chunk: 16 B * rows + 32 Ki
 // slots == 1: counts[16] from k_column_counts.  slots == 64: the producer's counters (17 per slot; the 17th
 // counts the rows it saw — if that is not n, the producer that ran was not the emitting one and nothing here can
 // be trusted for this forward).  desc on entry = the previous forward's choice (the producer's spec).
-__global__ void k_c4_choose(const unsigned long long *__restrict__ counts, int slots, uint32_t n, uint32_t *__restrict__ desc) {
-    if (threadIdx.x || blockIdx.x) return;
-    unsigned long long c[16];
-    bool taken[16];
-    for (int i = 0; i < 16; ++i) {
-        c[i] = 0;
-        taken[i] = false;
-    }
-    unsigned long long rows = 0;
+__global__ __launch_bounds__(64) void k_c4_choose(const unsigned long long *__restrict__ counts, int slots, uint32_t n,
+                                                  uint32_t *__restrict__ desc) {
+    // one wave: lane sl sums nothing but reads slot sl's 17 counters; a butterfly adds the slots up
+    const int lane = threadIdx.x;
+    unsigned long long c[17];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) c[i] = 0;
     if (slots == 1) {
-        for (int i = 0; i < 16; ++i) c[i] = counts[i];
-        rows = n;
-    } else {
-        for (int sl = 0; sl < slots; ++sl) {
-            for (int i = 0; i < 16; ++i) c[i] += counts[sl * kEmitStride + i];
-            rows += counts[sl * kEmitStride + 16];
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) c[i] = counts[i];
+            c[16] = n;
         }
+    } else if (lane < slots) {
+#pragma unroll
+        for (int i = 0; i < 17; ++i) c[i] = counts[lane * kEmitStride + i];
     }
+#pragma unroll
+    for (int i = 0; i < 17; ++i)
+        for (int off = 32; off; off >>= 1) {
+            const unsigned lo = __shfl_xor((unsigned)c[i], off), hi = __shfl_xor((unsigned)(c[i] >> 32), off);
+            c[i] += ((unsigned long long)hi << 32) | lo;
+        }
+    if (lane) return;
+    bool taken[16];
+    for (int i = 0; i < 16; ++i) taken[i] = false;
+    const unsigned long long rows = c[16];
     const bool prev_ok = desc[0] != 0;
     const uint32_t p1 = desc[1], p2 = desc[2], p3 = desc[3], p4 = desc[4];
     if (rows != n) {   // no (complete) statistics for this input
