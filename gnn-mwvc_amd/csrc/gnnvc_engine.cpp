@@ -127,7 +127,7 @@ struct gnnvc_engine {
     // compact-table plan of the 16-wide stages (built like the LDS-table plan, on the graph's second forward)
     int opt_compact = 1;            // 0 = off, 1 = when it applies, 2 = also on skewed graphs
     bool c4_ready = false, c4_tried = false;
-    uint32_t c4_rows = 0, c4_chunks = 0, c4_steps_total = 0;
+    uint32_t c4_rows = 0, c4_chunks = 0, c4_steps_total = 0, c4_block = 0;
     DevBuf<uint32_t> c4_entries, c4_segcnt, c4_stepptr, c4_stepcnt, c4_desc;
     DevBuf<uint4> c4_steps;
     DevBuf<float> c4_table, c4_acc, c4_agg16;
@@ -550,13 +550,22 @@ int build_compact(gnnvc_engine *e) {
     if (g.n < e->opt_blocked_min_n || g.nnz == 0 || g.nnz >= (1ull << 31)) return GNNVC_OK;
     if (e->opt_compact < 2 && (e->sorted_wanted || e->n_long > 0)) return GNNVC_OK;
     if (e->n_long > 0) return GNNVC_OK;   // (the long-row kernels write their rows themselves)
-    const uint32_t bc = gnnvc::compact_block(), max_rows = gnnvc::compact_max_rows();
-    const uint32_t nblocks = (g.n + bc - 1) / bc;
-    if (nblocks > 4096) return GNNVC_OK;
+    const uint32_t max_rows = gnnvc::compact_max_rows();
     uint32_t chunks = (g.n + max_rows - 1) / max_rows;
     chunks = (chunks + 255u) / 256u * 256u;
     const uint32_t rows = (g.n + chunks - 1) / chunks;
     chunks = (g.n + rows - 1) / rows;
+    // column blocks: wide enough that a chunk brings just under one 2048-entry step per block (1950 on average:
+    // a segment of 2049 costs a second, nearly empty step), but at most 160 K vertices = 2.5 MiB of table, which
+    // still sits in an XCD's 4 MiB L2 while its 32 CUs sweep it
+    uint32_t bc = gnnvc::compact_block();
+    {
+        const double per_chunk = (double)g.nnz / chunks;
+        const double want = 1950.0 * g.n / std::max(per_chunk, 1.0);
+        bc = (uint32_t)std::min(160.0 * 1024, std::max(32.0 * 1024, want)) / 1024u * 1024u;
+    }
+    const uint32_t nblocks = (g.n + bc - 1) / bc;
+    if (nblocks > 4096) return GNNVC_OK;
     HIP_TRY(e, e->c4_desc.reserve(24));   // 8 words per consumer stage (1, 2), word 16 = build flag
     HIP_TRY(e, e->c4_counts.reserve(16));
     HIP_TRY(e, e->c4_emit_counts.reserve(gnnvc::kEmitCounters));
@@ -591,8 +600,10 @@ int build_compact(gnnvc_engine *e) {
     HIP_TRY(e, hipMemcpyAsync(e->c4_stepptr.p, e->pin_small.p, ptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipMemsetAsync(e->c4_steps.p + total, 0, 8 * sizeof(uint4), e->stream));
     HIP_TRY(e, gnnvc::lds_table_steps(g, rows, chunks, nblocks, e->c4_segcnt.p, e->c4_stepptr.p, nullptr, e->c4_steps.p, true, e->stream));
-    HIP_TRY(e, gnnvc::lds_table_scatter(g, rows, chunks, nblocks, bc, e->c4_segcnt.p, e->c4_entries.p, e->stream));
+    HIP_TRY(e, gnnvc::lds_table_scatter(g, rows, chunks, nblocks, bc, e->c4_segcnt.p, e->c4_entries.p, e->stream,
+                                        gnnvc::compact_shift()));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
+    e->c4_block = bc;
     e->c4_rows = rows;
     e->c4_chunks = chunks;
     e->c4_steps_total = (uint32_t)total;
@@ -667,7 +678,7 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
                 HIP_TRY(e, gnnvc::launch_compact_gather(e->g, in, fused ? e->c4_emit_counts.p : e->c4_counts.p, fused ? 64 : 1,
                                                         desc, e->c4_table.p, e->c4_acc.p, lo, hi,
                                                         e->c4_rows, e->c4_stepptr.p, e->c4_steps.p, e->c4_entries.p,
-                                                        e->c4_dirty.p, e->c4_dirty_cap, e->c4_agg16.p, e->stream));
+                                                        e->c4_dirty.p, e->c4_dirty_cap, e->c4_agg16.p, e->stream, e->c4_block));
                 acc4 = e->c4_acc.p;
                 c4desc = desc;
                 if (may_emit) {   // and this stage's own (aggregate-only, VALU) kernel produces for the next one
@@ -875,6 +886,8 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
     const std::string k(key);
     if (k == "compact_gather_active") *value = e->c4_ready ? 1 : 0;
     else if (k == "compact_gather_chunks") *value = e->c4_ready ? (long)e->c4_chunks : 0;
+    else if (k == "compact_gather_block_cols") *value = e->c4_ready ? (long)e->c4_block : 0;
+    else if (k == "compact_gather_steps") *value = e->c4_ready ? (long)e->c4_steps_total : 0;
     else if (k == "compact_gather_last_ok" || k == "compact_gather_last_dirty") {
         // what the device decided at the last launch of the plan (waits for the stream; for tests and tools)
         *value = 0;

@@ -956,7 +956,8 @@ __global__ __launch_bounds__(256) void k_lt_steps(GraphDev g, uint32_t rows_per_
 // regroup the chunk's CSR entries by column block: entries[...] = row_local << 17 | col_local; a row's
 // entries of one block are written as one adjacent run, in order (the order among rows is free)
 __global__ __launch_bounds__(1024) void k_lt_scatter(GraphDev g, uint32_t rows_per_chunk, uint32_t nblocks, uint32_t block_cols,
-                                                     const uint32_t *__restrict__ seg_cnt, uint32_t *__restrict__ entries) {
+                                                     uint32_t shift, const uint32_t *__restrict__ seg_cnt,
+                                                     uint32_t *__restrict__ entries) {
     __shared__ uint32_t cursor[4096];
     const uint32_t c = blockIdx.x, tid = threadIdx.x;
     const uint32_t r0 = c * rows_per_chunk, r1 = min(g.n, r0 + rows_per_chunk);
@@ -969,7 +970,7 @@ __global__ __launch_bounds__(1024) void k_lt_scatter(GraphDev g, uint32_t rows_p
     }
     __syncthreads();
     for (uint32_t u = r0 + tid; u < r1; u += 1024) {
-        const uint32_t rl = (u - r0) << 17;
+        const uint32_t rl = (u - r0) << shift;
         uint32_t e = g.rowptr[u];
         const uint32_t end = g.rowptr[u + 1];
         while (e < end) {
@@ -1106,7 +1107,9 @@ __global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ st
 //                 gathers a dirty row the plain way, full rows in CSR order — so every aggregate is
 //                 exactly what the plain gather produces; then the dense layers as always.
 // desc words: [0] ok (1 = the plan applies to this input), [1..4] the chosen columns (ascending).
-constexpr uint32_t kC4Block = 131072;     // vertices per column block: 2 MiB of compact rows
+constexpr uint32_t kC4Block = 131072;     // default vertices per column block: 2 MiB of compact rows (the engine sizes the
+                                          // blocks so that a chunk has just under one step of entries per block)
+constexpr uint32_t kC4Shift = 18;         // entries: row_local << 18 | col_local (blocks of up to 262144 vertices)
 constexpr uint32_t kC4MaxRows = 7400;     // rows per chunk: 16 B * rows + 32 KiB values + 8 KiB entries + dirty bits <= 160 KiB
 
 // desc words: [0] ok, [1..4] the chosen columns (ascending), [5] dirty-row counter, [6] the table still has to be
@@ -1204,7 +1207,7 @@ __global__ __launch_bounds__(1024) void k_c4_agg(const uint32_t *__restrict__ st
                                                  const uint32_t *__restrict__ entries, const f32x4 *__restrict__ table,
                                                  f32x4 *__restrict__ agg, uint32_t n, uint32_t rows_per_chunk, uint32_t chunk0,
                                                  uint32_t chunk1, uint32_t last_entry, uint32_t *__restrict__ desc,
-                                                 uint32_t *__restrict__ dirty_rows, uint32_t dirty_cap) {
+                                                 uint32_t *__restrict__ dirty_rows, uint32_t dirty_cap, uint32_t block_cols) {
     extern __shared__ __attribute__((aligned(16))) unsigned char c4_smem[];
     if (!desc[0]) return;                                               // block-uniform
     f32x4 *acc = reinterpret_cast<f32x4 *>(c4_smem);                    // rows_per_chunk (<= kC4MaxRows) x 4 sums
@@ -1234,17 +1237,17 @@ __global__ __launch_bounds__(1024) void k_c4_agg(const uint32_t *__restrict__ st
                 const bool in0_ = i0_ < lcur, in1_ = i1_ < lcur;                                      \
                 const uint32_t a0_ = ebuf[i0_], a1_ = ebuf[i1_];                                      \
                 const uint32_t b0_ = ebuf[(int)i0_ - 1], b1_ = ebuf[i1_ - 1];                         \
-                const uint32_t r0_ = a0_ >> 17, r1_ = a1_ >> 17;                                      \
-                const bool h0_ = in0_ && (i0_ == 0 || (b0_ >> 17) != r0_);                            \
-                const bool h1_ = in1_ && (b1_ >> 17) != r1_;                                          \
+                const uint32_t r0_ = a0_ >> kC4Shift, r1_ = a1_ >> kC4Shift;                                      \
+                const bool h0_ = in0_ && (i0_ == 0 || (b0_ >> kC4Shift) != r0_);                            \
+                const bool h1_ = in1_ && (b1_ >> kC4Shift) != r1_;                                          \
                 if (h0_) {                                                                            \
                     f32x4 s_ = acc[r0_] + vbuf[i0_];                                                  \
-                    for (uint32_t k_ = i0_ + 1; k_ < lcur && (ebuf[k_] >> 17) == r0_; ++k_) s_ += vbuf[k_]; \
+                    for (uint32_t k_ = i0_ + 1; k_ < lcur && (ebuf[k_] >> kC4Shift) == r0_; ++k_) s_ += vbuf[k_]; \
                     acc[r0_] = s_;                                                                    \
                 }                                                                                     \
                 if (h1_) {                                                                            \
                     f32x4 s_ = acc[r1_] + vbuf[i1_];                                                  \
-                    for (uint32_t k_ = i1_ + 1; k_ < lcur && (ebuf[k_] >> 17) == r1_; ++k_) s_ += vbuf[k_]; \
+                    for (uint32_t k_ = i1_ + 1; k_ < lcur && (ebuf[k_] >> kC4Shift) == r1_; ++k_) s_ += vbuf[k_]; \
                     acc[r1_] = s_;                                                                    \
                 }                                                                                     \
                 __syncthreads();                                   /* everyone is done reading step u */ \
@@ -1253,8 +1256,8 @@ __global__ __launch_bounds__(1024) void k_c4_agg(const uint32_t *__restrict__ st
             /* (sign bit of its first value) dirties the entry's row and is parked without the flag   */ \
             {                                                                                         \
                 const uint32_t f0_ = __float_as_uint(v0[0]), f1_ = __float_as_uint(v1[0]);            \
-                if ((f0_ >> 31) && tid < (l_)) atomicOr(&dirty[(e0_ >> 17) >> 5], 1u << ((e0_ >> 17) & 31)); \
-                if ((f1_ >> 31) && tid + 1024 < (l_)) atomicOr(&dirty[(e1_ >> 17) >> 5], 1u << ((e1_ >> 17) & 31)); \
+                if ((f0_ >> 31) && tid < (l_)) atomicOr(&dirty[(e0_ >> kC4Shift) >> 5], 1u << ((e0_ >> kC4Shift) & 31)); \
+                if ((f1_ >> 31) && tid + 1024 < (l_)) atomicOr(&dirty[(e1_ >> kC4Shift) >> 5], 1u << ((e1_ >> kC4Shift) & 31)); \
                 v0[0] = __uint_as_float(f0_ & 0x7FFFFFFFu);                                           \
                 v1[0] = __uint_as_float(f1_ & 0x7FFFFFFFu);                                           \
             }                                                                                         \
@@ -1264,7 +1267,7 @@ __global__ __launch_bounds__(1024) void k_c4_agg(const uint32_t *__restrict__ st
             vbuf[tid + 1024] = v1;                                                                    \
             lcur = l_;                                                                                \
             {   /* gather step u + 2 (entries ge_, column base gcb_) */                               \
-                const uint32_t c0_ = gcb_ + (ge0_ & 0x1FFFF), c1_ = gcb_ + (ge1_ & 0x1FFFF);          \
+                const uint32_t c0_ = gcb_ + (ge0_ & ((1u << kC4Shift) - 1u)), c1_ = gcb_ + (ge1_ & ((1u << kC4Shift) - 1u));          \
                 v0 = table[c0_ < n ? c0_ : n];                                                        \
                 v1 = table[c1_ < n ? c1_ : n];                                                        \
             }                                                                                         \
@@ -1276,7 +1279,7 @@ __global__ __launch_bounds__(1024) void k_c4_agg(const uint32_t *__restrict__ st
                 e0_ = entries[x0_ < last_entry ? x0_ : last_entry];                                   \
                 e1_ = entries[x1_ < last_entry ? x1_ : last_entry];                                   \
                 l_ = ((u_) + 5 >= 0) ? dl_.z : 0u;                                                    \
-                cb_ = dl_.x * kC4Block;                                                               \
+                cb_ = dl_.x * block_cols;                                                               \
             }                                                                                         \
         }
         for (int u = -8; u < nsteps; u += 4) {
@@ -2066,7 +2069,7 @@ hipError_t lds_table_bytes(const uint32_t *w, uint32_t n, uint8_t *wb, uint32_t 
 
 hipError_t lds_table_count(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t block_cols,
                            uint32_t *seg_cnt, uint32_t *bad, hipStream_t stream) {
-    if (nblocks > 4096 || block_cols > (1u << 17) || rows_per_chunk > (1u << 15)) return hipErrorInvalidValue;
+    if (nblocks > 4096 || block_cols > (1u << 18) || rows_per_chunk > (1u << 15)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_lt_count, dim3(nchunks), dim3(1024), 0, stream, g, rows_per_chunk, nblocks, block_cols, seg_cnt, bad);
     return hipGetLastError();
 }
@@ -2079,8 +2082,9 @@ hipError_t lds_table_steps(const GraphDev &g, uint32_t rows_per_chunk, uint32_t 
 }
 
 hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t block_cols,
-                             const uint32_t *seg_cnt, uint32_t *entries, hipStream_t stream) {
-    hipLaunchKernelGGL(k_lt_scatter, dim3(nchunks), dim3(1024), 0, stream, g, rows_per_chunk, nblocks, block_cols, seg_cnt,
+                             const uint32_t *seg_cnt, uint32_t *entries, hipStream_t stream, uint32_t shift) {
+    if (block_cols > (1u << shift) || ((uint64_t)rows_per_chunk << shift) > (1ull << 32)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_lt_scatter, dim3(nchunks), dim3(1024), 0, stream, g, rows_per_chunk, nblocks, block_cols, shift, seg_cnt,
                        entries);
     return hipGetLastError();
 }
@@ -2126,13 +2130,14 @@ hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float
 // ---- compact-table plan of the 16-wide stages -----------------------------------------------
 uint32_t compact_max_rows() { return kC4MaxRows; }
 uint32_t compact_block() { return kC4Block; }
+uint32_t compact_shift() { return kC4Shift; }
 
 // counts -> desc -> table -> four sums per row of [row_lo, row_hi) (chunks that straddle the ends are done
 // whole).  `counts` holds the per-column non-zero counts of `in` (column_counts, same stream).
 hipError_t launch_compact_gather(const GraphDev &g, const float *in, const unsigned long long *counts, int count_slots, uint32_t *desc,
                                  float *table, float *acc4, uint32_t row_lo, uint32_t row_hi, uint32_t rows_per_chunk,
                                  const uint32_t *step_ptr, const void *steps, const uint32_t *entries, uint32_t *dirty_rows,
-                                 uint32_t dirty_cap, float *agg16, hipStream_t stream) {
+                                 uint32_t dirty_cap, float *agg16, hipStream_t stream, uint32_t block_cols) {
     if (row_hi <= row_lo || g.nnz == 0) return hipErrorInvalidValue;
     if (rows_per_chunk == 0 || rows_per_chunk > kC4MaxRows) return hipErrorInvalidValue;
     hipError_t rc0 = hipMemsetAsync(desc + 5, 0, sizeof(uint32_t), stream);   // dirty-row counter
@@ -2153,7 +2158,7 @@ hipError_t launch_compact_gather(const GraphDev &g, const float *in, const unsig
     hipLaunchKernelGGL(k_c4_agg, dim3(std::min<uint32_t>(256u, c1 - c0)), dim3(1024), lds, stream, step_ptr,
                        reinterpret_cast<const uint4 *>(steps), entries, reinterpret_cast<const f32x4 *>(table),
                        reinterpret_cast<f32x4 *>(acc4), g.n, rows_per_chunk, c0, c1, (uint32_t)(g.nnz - 1), desc, dirty_rows,
-                       dirty_cap);
+                       dirty_cap, block_cols);
     // the grid is sized for a typical number of dirty rows and strides over more
     hipLaunchKernelGGL(k_c4_fix, dim3(std::min<uint32_t>((dirty_cap + 63) / 64, 4096u)), dim3(256), 0, stream, g,
                        reinterpret_cast<const float4 *>(in), desc, dirty_rows, dirty_cap, reinterpret_cast<float4 *>(agg16));
