@@ -1233,23 +1233,27 @@ __global__ __launch_bounds__(1024) void k_c4_agg(const uint32_t *__restrict__ st
         {                                                                                             \
             if ((u_) >= 0) {                                                                          \
                 __syncthreads();                                   /* step u is parked */             \
+                /* both entries of a thread advance together: the LDS reads of the two chains are issued */ \
+                /* back to back (slots past the step's end hold stale but readable words, masked below)  */ \
                 const uint32_t i0_ = tid, i1_ = tid + 1024;                                           \
                 const bool in0_ = i0_ < lcur, in1_ = i1_ < lcur;                                      \
                 const uint32_t a0_ = ebuf[i0_], a1_ = ebuf[i1_];                                      \
                 const uint32_t b0_ = ebuf[(int)i0_ - 1], b1_ = ebuf[i1_ - 1];                         \
-                const uint32_t r0_ = a0_ >> kC4Shift, r1_ = a1_ >> kC4Shift;                                      \
-                const bool h0_ = in0_ && (i0_ == 0 || (b0_ >> kC4Shift) != r0_);                            \
-                const bool h1_ = in1_ && (b1_ >> kC4Shift) != r1_;                                          \
-                if (h0_) {                                                                            \
-                    f32x4 s_ = acc[r0_] + vbuf[i0_];                                                  \
-                    for (uint32_t k_ = i0_ + 1; k_ < lcur && (ebuf[k_] >> kC4Shift) == r0_; ++k_) s_ += vbuf[k_]; \
-                    acc[r0_] = s_;                                                                    \
-                }                                                                                     \
-                if (h1_) {                                                                            \
-                    f32x4 s_ = acc[r1_] + vbuf[i1_];                                                  \
-                    for (uint32_t k_ = i1_ + 1; k_ < lcur && (ebuf[k_] >> kC4Shift) == r1_; ++k_) s_ += vbuf[k_]; \
-                    acc[r1_] = s_;                                                                    \
-                }                                                                                     \
+                const uint32_t n0_ = ebuf[i0_ + 1], n1_ = ebuf[i1_ + 1];                              \
+                const f32x4 w0_ = vbuf[i0_], w1_ = vbuf[i1_];                                         \
+                const uint32_t r0_ = a0_ >> kC4Shift, r1_ = a1_ >> kC4Shift;                          \
+                const bool h0_ = in0_ && (i0_ == 0 || (b0_ >> kC4Shift) != r0_);                      \
+                const bool h1_ = in1_ && (b1_ >> kC4Shift) != r1_;                                    \
+                const f32x4 c0_ = acc[r0_ < kC4MaxRows ? r0_ : 0], c1_ = acc[r1_ < kC4MaxRows ? r1_ : 0]; \
+                const bool more0_ = h0_ && i0_ + 1 < lcur && (n0_ >> kC4Shift) == r0_;                \
+                const bool more1_ = h1_ && i1_ + 1 < lcur && (n1_ >> kC4Shift) == r1_;                \
+                f32x4 s0_ = c0_ + w0_, s1_ = c1_ + w1_;                                               \
+                if (more0_)                                                                           \
+                    for (uint32_t k_ = i0_ + 1; k_ < lcur && (ebuf[k_] >> kC4Shift) == r0_; ++k_) s0_ += vbuf[k_]; \
+                if (more1_)                                                                           \
+                    for (uint32_t k_ = i1_ + 1; k_ < lcur && (ebuf[k_] >> kC4Shift) == r1_; ++k_) s1_ += vbuf[k_]; \
+                if (h0_) acc[r0_] = s0_;                                                              \
+                if (h1_) acc[r1_] = s1_;                                                              \
                 __syncthreads();                                   /* everyone is done reading step u */ \
             }                                                                                         \
             /* park step u + 1: its entries (ring slot e_) and the rows gathered for it; a flagged row */ \
