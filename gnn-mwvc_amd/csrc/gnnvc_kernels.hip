@@ -1220,6 +1220,7 @@ __global__ __launch_bounds__(1024) void k_c4_agg(const uint32_t *__restrict__ st
         __syncthreads();                                                // the previous chunk's sums are written out
         for (uint32_t i = tid; i < rows_per_chunk; i += 1024) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         for (uint32_t i = tid; i < (kC4MaxRows + 31) / 32; i += 1024) dirty[i] = 0;
+        __syncthreads();                                                // (the first dirty mark may come before the first step's barrier)
         const uint32_t st0 = step_ptr[chunk], st1 = step_ptr[chunk + 1];
         const int nsteps = (int)(st1 - st0);
         // Time u: process step u (entries and gathered rows parked in LDS), park step u + 1 (rows gathered
