@@ -631,12 +631,17 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
                                             e->long_list.p, e->n_long, thr, e->aux_stream));
         HIP_TRY(e, hipEventRecord(e->ev_join, e->aux_stream));
     }
+    // The LDS-table plan works in chunks of ~19.5 K rows, one workgroup each: a call that covers fewer than
+    // three quarters of a GPU's worth of chunks (the pieces of a pipelined multi-GPU run) would leave most CUs
+    // idle for the time one chunk takes — such calls use the column-blocked plan instead.
+    bool lt_fits = false;
     if (stage == 0) {
         if (e->graph_uses >= 1 && !e->lt_tried) {
             int rc = build_lds_table(e);
             if (rc) return rc;
         }
-        if (e->graph_uses >= 1 && !e->lt_ready && !e->blocked_tried) {
+        lt_fits = e->lt_ready && hi > lo && ((hi - 1) / e->lt_rows - lo / e->lt_rows + 1) >= 192u;
+        if (e->graph_uses >= 1 && !lt_fits && !e->blocked_tried) {
             int rc = build_blocked(e);
             if (rc) return rc;
         }
@@ -649,7 +654,7 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
         emit.counts = e->c4_emit_counts.p;
         e->c4_fused_for = 1;
     }
-    if (stage == 0 && e->lt_ready) {
+    if (stage == 0 && lt_fits) {
         HIP_TRY(e, gnnvc::launch_stage0_lds_table(e->stages[0], e->g, e->ws, e->params.p, in, out, lo, hi, e->lt_rows,
                                                   e->lt_stepptr.p, e->lt_steps.p, e->lt_entries.p, e->lt_bytes.p,
                                                   e->blk_acc.p, e->lt_bad.p, e->long_thresh, e->opt_mfma == 1,

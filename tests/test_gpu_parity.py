@@ -475,12 +475,13 @@ def test_lds_table_plan_is_bit_identical(model_text, oracle_model, maker, force)
         if not g.nnz:
             return
         assert e.get_info("lds_table_steps") >= 4 * e.get_info("lds_table_chunks")
-        # row sub-ranges through the stage entry point (chunks that straddle the cut are computed twice)
+        # row sub-ranges through the stage entry point: a long one keeps the plan (the chunk that straddles the cut
+        # is computed whole), a short one would leave most CUs idle and takes the blocked / plain kernel instead
         dev = torch.device("cuda:0")
         x = torch.from_numpy(g.x()).to(dev)
         h1 = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
-        mid = (g.n // 3) // 64 * 64
+        mid = max(64, (g.n // 8) // 64 * 64) if g.n > 128 else 64
         for lo, hi in ((mid, g.n), (0, mid)):
             e.stage_forward_device(0, lo, hi, x.data_ptr(), h1.data_ptr())
         e.synchronize()
