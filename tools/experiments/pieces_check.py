@@ -48,3 +48,22 @@ for st in range(3):
     same = torch.equal(out[st][:n].view(torch.int32), full[st][:n].view(torch.int32))
     print(f"stage {st}: {P} x {chunks} pieces, identical to the whole-range run: {same}  ({time.time() - t0:.2f} s)")
     src = full[st]
+
+# per-rank compute of a P-rank run (rank 0's pieces only, no exchange), steady state
+lo, hi = bounds[0]
+for rep in range(3):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    times = []
+    src = x
+    for st in range(3):
+        ts = time.perf_counter()
+        for off in range(0, per, step):
+            r0, r1 = min(lo + off, hi), min(lo + off + min(step, per - off), hi)
+            if r1 > r0:
+                e.stage_forward_device(st, r0, r1, src.data_ptr(), out[st].data_ptr(), lg.data_ptr() if st == 2 else 0)
+        e.synchronize()
+        times.append((time.perf_counter() - ts) * 1e3)
+        src = full[st]
+print(f"rank 0 of {P}: per-stage compute {[round(t, 3) for t in times]} ms, sum {sum(times):.3f} ms "
+      f"(whole graph on one GPU / P = {5.96 / P:.3f} ms)")
