@@ -278,7 +278,9 @@ def main() -> int:
     # the kernels a stage launches under the plans in force (names as in profiles/*/kernel_stats.csv); the first
     # one is the stage's dominant kernel
     lt, blk, c4 = (bool(eng.get_info(k)) for k in ("lds_table_active", "blocked_stage0_active", "compact_gather_active"))
-    c4 = c4 and world <= 2        # (calls that cover less than half of the rows keep the gathering kernels)
+    c4 = c4 and world == 1        # (calls that cover less than half of the rows keep the gathering kernels)
+    lt = lt and world <= 4        # (stage 0 is replicated — one whole-range call — up to 4 ranks; pieces take the blocked plan)
+    blk = blk or (world > 4 and bool(eng.get_info("blocked_stage0_active")))
     agg_only = "false,2,false,false,true>"
     stage_kernels = [
         (["k_lt_agg", "k_lt_check_x", "k_stage_f1<32,32,16"] if lt else
@@ -291,7 +293,8 @@ def main() -> int:
          (["k_column_counts"] if world > 1 else []) if c4 else ["k_stage_f16<32,16,1,true"])]
     kernel_names = [k[0] for k in stage_kernels]
 
-    traffic, traffic_src = measured_traffic(stage_kernels[dom], args.workload)
+    # (the PMC summary is a single-GPU run of whole-range launches: not comparable with a rank's pieces)
+    traffic, traffic_src = measured_traffic(stage_kernels[dom], args.workload) if world == 1 else (None, None)
     out = {
         "metric": "GNN forward edges/sec", "value": edges_per_s, "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
