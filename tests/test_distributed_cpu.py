@@ -250,6 +250,17 @@ def test_replication_rule():
     assert D.replicated_stages(2, num_stages=1) == set()
 
 
+def test_plan_replication_with_packings():
+    good = {0: D.Packing(0x80B, 4, 1024, 16.0), 1: D.Packing(0x603, 4, 1024, 16.0)}
+    wide = {0: D.Packing(0xFFF, 12, 1024, 48.0), 1: D.Packing(0x603, 4, 1024, 16.0)}
+    for world in (2, 3, 4):
+        assert D.plan_replication(world, 3, good) == {0}        # 16-wide stages partitioned, stage 0 in full
+        assert D.plan_replication(world, 3, wide) == D.replicated_stages(world)
+        assert D.plan_replication(world, 3, {0: good[0]}) == D.replicated_stages(world)   # a stage not measured yet
+    assert D.plan_replication(8, 3, good) == set() and D.plan_replication(8, 3, None) == set()
+    assert D.plan_replication(1, 3, good) == set()
+
+
 def test_partition_bounds_properties():
     g = gg.hub_graph(20000, 60000, 3, 4096, seed=7)
     for world in (1, 2, 4, 8):
