@@ -84,7 +84,10 @@ def main() -> int:
     ap.add_argument("--sorted-tiles", type=int, default=-1, help="degree-sorted tiles: -1 auto, 0 off, 1 on")
     ap.add_argument("--sorted-long-threshold", type=int, default=0)
     ap.add_argument("--mfma", type=int, default=-1, help="dense layers: 0 VALU, 1 MFMA everywhere, 2 MFMA in the 16-wide stages (default)")
-    ap.add_argument("--pipeline-chunks", type=int, default=4,
+    ap.add_argument("--prepare-input", type=int, default=1,
+                    help="N = 2..3: 1 = announce each 16-wide stage's complete input to the engine (compact-table plan "
+                         "over the rank's rows), 0 = plain gathering kernels")
+    ap.add_argument("--pipeline-chunks", type=int, default=-1,
                     help="N>1: pieces per stage whose all-gather overlaps the next piece's compute (0/1 = off)")
     ap.add_argument("--replicate-stage0", type=int, default=-1,
                     help="N>1: 1/0 forces stage 0 replicated / partitioned; -1 = auto (P=2: stages 0,1; P<=4: stage 0)")
@@ -181,6 +184,12 @@ def main() -> int:
     stage_evt = [[torch.cuda.Event(enable_timing=True) for _ in range(6)]
                  for _ in range(args.steps)]
 
+    # pieces per stage: with the compact-table plan over a rank's rows a piece should be a whole number of
+    # 256-chunk rounds (3 at 2 ranks, 2 at 3-4 ranks on the metric graph); otherwise 4
+    use_prepare = bool(args.prepare_input) and 2 <= world <= 3   # (from 4 ranks on a rank's pieces are too small to gain)
+    chunks = args.pipeline_chunks if args.pipeline_chunks >= 0 else ((3 if world == 2 else 2) if use_prepare else 4)
+    prepare_fn = (lambda st, src, r0, r1: eng.stage_input_ready(st, src.data_ptr(), r0, r1)) if use_prepare else None
+    piece_rows = [0]   # set after the first forward: pieces of 256 of the engine's chunks, so that no piece ends inside one
     fwd_scores = torch.zeros(g.n, dtype=torch.float32, device=dev)
     engine_stage_ms = []
 
@@ -208,7 +217,8 @@ def main() -> int:
         # verify=False: the dead-column check of the compressed exchange is read once, after the loop
         D.partitioned_forward(stage_fn, 3, x, bufs, bounds, rank, on_stage=hook, gather_logits=False,
                               replicate_stage0=None if args.replicate_stage0 < 0 else bool(args.replicate_stage0),
-                              pipeline_chunks=args.pipeline_chunks, codec=codec, verify=False)
+                              pipeline_chunks=chunks, codec=codec, verify=False, prepare_fn=prepare_fn,
+                              piece_rows=piece_rows[0])
 
     trace = bool(os.environ.get("GNNVC_BENCH_TRACE"))
     t_start = time.time()
@@ -234,6 +244,8 @@ def main() -> int:
     if codec is not None:
         step(None)   # first forward on this graph: full rows, records each stage's live columns (not a timed or warm-up step)
         settle()
+        if use_prepare and args.pipeline_chunks < 0 and eng.get_info("compact_gather_active"):
+            piece_rows[0] = 256 * eng.get_info("compact_gather_rows_per_chunk")
         mark("learning forward done")
     for i in range(args.warmup):
         step(None)
@@ -339,7 +351,9 @@ def main() -> int:
         out["config"]["replicated_stages"] = \
             sorted(D.plan_replication(world, 3, bufs.live if codec is not None else None)) \
             if args.replicate_stage0 < 0 else ([0] if args.replicate_stage0 else [])
-        out["config"]["pipeline_chunks"] = args.pipeline_chunks
+        out["config"]["pipeline_chunks"] = chunks
+        out["config"]["piece_rows"] = piece_rows[0]
+        out["config"]["compact_table_over_rank_rows"] = bool(use_prepare and eng.get_info("compact_gather_active"))
         out["config"]["compressed_exchange"] = None if codec is None else {
             "verified_lossless": bool(exchange_ok),
             "bytes_per_row_shipped_of_64": {str(st): (round(pk.bytes_per_row, 2) if pk is not None else 64)

@@ -134,6 +134,10 @@ struct gnnvc_engine {
     DevBuf<uint32_t> c4_dirty;
     uint32_t c4_dirty_cap = 0;
     DevBuf<unsigned long long> c4_counts, c4_emit_counts;
+    uint32_t c4_base = 0, c4_end = 0;   // the plan's row range: the whole graph, or the rows a multi-GPU rank computes
+    bool c4_range_mode = false;         // a driver asked for a range plan (gnnvc_stage_input_ready): no whole-graph plan any more
+    int c4_prepared_stage = -1;         // gnnvc_stage_input_ready: the table holds this stage's input ...
+    const float *c4_prepared_in = nullptr;   // ... as found at this address
     int c4_fused_for = -1;          // stage whose input statistics (and table) the previous stage kernel of this forward produced
     int c4_last_desc = 0;           // word offset in c4_desc of the plan's last launch (tests / tools)
 
@@ -540,10 +544,14 @@ int build_lds_table(gnnvc_engine *e) {
 // Compact-table plan of the 16-wide stages (kernels: k_c4_*): the same (chunk, column block, step) layout
 // as the LDS-table plan at 2 MiB column blocks.  Whether a forward's input really has at most four live
 // columns is decided on the device at every launch (k_c4_choose / k_c4_compact).
-int build_compact(gnnvc_engine *e) {
+int build_compact(gnnvc_engine *e, uint32_t base = 0, uint32_t end = 0xFFFFFFFFu) {
     e->c4_ready = false;
     e->c4_tried = true;
+    e->c4_prepared_stage = -1;
     const GraphDev &g = e->g;
+    if (end > g.n) end = g.n;
+    if (base >= end) return GNNVC_OK;
+    const uint32_t span = end - base;
     if (!e->opt_compact || e->stages.size() < 2) return GNNVC_OK;
     for (size_t st = 1; st < e->stages.size(); ++st)
         if (e->stages[st].f != 16) return GNNVC_OK;
@@ -551,16 +559,25 @@ int build_compact(gnnvc_engine *e) {
     if (e->opt_compact < 2 && (e->sorted_wanted || e->n_long > 0)) return GNNVC_OK;
     if (e->n_long > 0) return GNNVC_OK;   // (the long-row kernels write their rows themselves)
     const uint32_t max_rows = gnnvc::compact_max_rows();
-    uint32_t chunks = (g.n + max_rows - 1) / max_rows;
+    uint32_t chunks = (span + max_rows - 1) / max_rows;
     chunks = (chunks + 255u) / 256u * 256u;
-    const uint32_t rows = (g.n + chunks - 1) / chunks;
-    chunks = (g.n + rows - 1) / rows;
+    const uint32_t rows = (span + chunks - 1) / chunks;
+    chunks = (span + rows - 1) / rows;
+    uint64_t range_nnz = g.nnz;
+    if (span != g.n) {   // the range's share of the entries
+        uint32_t rp[2] = {0, 0};
+        HIP_TRY(e, hipMemcpyAsync(&rp[0], g.rowptr + base, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(&rp[1], g.rowptr + end, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        range_nnz = rp[1] - rp[0];
+        if (range_nnz == 0) return GNNVC_OK;
+    }
     // column blocks: wide enough that a chunk brings just under one 2048-entry step per block (1950 on average:
     // a segment of 2049 costs a second, nearly empty step), but at most 160 K vertices = 2.5 MiB of table, which
     // still sits in an XCD's 4 MiB L2 while its 32 CUs sweep it
     uint32_t bc = gnnvc::compact_block();
     {
-        const double per_chunk = (double)g.nnz / chunks;
+        const double per_chunk = (double)range_nnz / chunks;
         const double want = 1950.0 * g.n / std::max(per_chunk, 1.0);
         bc = (uint32_t)std::min(160.0 * 1024, std::max(32.0 * 1024, want)) / 1024u * 1024u;
     }
@@ -575,8 +592,9 @@ int build_compact(gnnvc_engine *e) {
     HIP_TRY(e, e->pin_small.reserve((size_t)chunks + 2));
     uint32_t *flag = e->c4_desc.p + 16;
     HIP_TRY(e, hipMemsetAsync(e->c4_desc.p, 0, 24 * sizeof(uint32_t), e->stream));
-    HIP_TRY(e, gnnvc::lds_table_count(g, rows, chunks, nblocks, bc, e->c4_segcnt.p, flag, e->stream));
-    HIP_TRY(e, gnnvc::lds_table_steps(g, rows, chunks, nblocks, e->c4_segcnt.p, nullptr, e->c4_stepcnt.p, nullptr, false, e->stream));
+    HIP_TRY(e, gnnvc::lds_table_count(g, rows, chunks, nblocks, bc, e->c4_segcnt.p, flag, e->stream, base, end));
+    HIP_TRY(e, gnnvc::lds_table_steps(g, rows, chunks, nblocks, e->c4_segcnt.p, nullptr, e->c4_stepcnt.p, nullptr, false, e->stream,
+                                      base, end));
     HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, e->c4_stepcnt.p, chunks * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipMemcpyAsync(e->pin_small.p + chunks, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -599,11 +617,14 @@ int build_compact(gnnvc_engine *e) {
     std::memcpy(e->pin_small.p, ptr.data(), ptr.size() * sizeof(uint32_t));
     HIP_TRY(e, hipMemcpyAsync(e->c4_stepptr.p, e->pin_small.p, ptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipMemsetAsync(e->c4_steps.p + total, 0, 8 * sizeof(uint4), e->stream));
-    HIP_TRY(e, gnnvc::lds_table_steps(g, rows, chunks, nblocks, e->c4_segcnt.p, e->c4_stepptr.p, nullptr, e->c4_steps.p, true, e->stream));
+    HIP_TRY(e, gnnvc::lds_table_steps(g, rows, chunks, nblocks, e->c4_segcnt.p, e->c4_stepptr.p, nullptr, e->c4_steps.p, true, e->stream,
+                                      base, end));
     HIP_TRY(e, gnnvc::lds_table_scatter(g, rows, chunks, nblocks, bc, e->c4_segcnt.p, e->c4_entries.p, e->stream,
-                                        gnnvc::compact_shift()));
+                                        gnnvc::compact_shift(), base, end));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     e->c4_block = bc;
+    e->c4_base = base;
+    e->c4_end = end;
     e->c4_rows = rows;
     e->c4_chunks = chunks;
     e->c4_steps_total = (uint32_t)total;
@@ -621,8 +642,8 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
     e->c4_fused_for = -1;
     gnnvc::EmitArgs emit;
     const size_t ns_ = e->stages.size();
-    const bool may_emit = in_forward && e->c4_ready && !longs && (size_t)stage + 1 < ns_ && e->stages[stage + 1].f == 16 &&
-                          lo == 0 && hi == e->g.n && e->opt_mfma != 1;
+    const bool may_emit = in_forward && e->c4_ready && !e->c4_range_mode && e->c4_base == 0 && e->c4_end == e->g.n && !longs &&
+                          (size_t)stage + 1 < ns_ && e->stages[stage + 1].f == 16 && lo == 0 && hi == e->g.n && e->opt_mfma != 1;
     const uint32_t thr = (e->stages[stage].f == 16) ? e->thresh_f16 : e->long_thresh;   // this stage's long-row threshold
     if (longs) {   // fork: the long rows of this stage run beside the tile kernel
         HIP_TRY(e, hipEventRecord(e->ev_fork, e->stream));
@@ -670,12 +691,29 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
         const float *acc4 = nullptr;
         const uint32_t *c4desc = nullptr;
         if (e->stages[stage].f == 16) {
-            if (e->graph_uses >= 2 && !e->c4_tried) {
+            if (!e->c4_range_mode && e->graph_uses >= 2 && !e->c4_tried) {
                 int rc = build_compact(e);
                 if (rc) return rc;
             }
-            // worth its fixed cost (count + compact the whole input) only when this call covers most of the rows
-            if (e->c4_ready && !longs && (uint64_t)(hi - lo) * 2 >= e->g.n) {
+            const bool whole_plan = e->c4_ready && e->c4_base == 0 && e->c4_end == e->g.n;
+            const bool prepared = e->c4_ready && e->c4_prepared_stage == stage && e->c4_prepared_in == in &&
+                                  lo >= e->c4_base && hi <= e->c4_end && hi > lo;
+            if (prepared && !longs) {
+                // gnnvc_stage_input_ready wrote the table for this input: any call that fills at least half the
+                // GPU with chunks takes the sums from it (smaller ones would leave most CUs idle for a chunk's time)
+                const uint32_t nchunks = (hi - 1 - e->c4_base) / e->c4_rows - (lo - e->c4_base) / e->c4_rows + 1;
+                if (nchunks >= 128u) {
+                    uint32_t *desc = e->c4_desc.p + 8 * (stage - 1);
+                    e->c4_last_desc = 8 * (stage - 1);
+                    HIP_TRY(e, gnnvc::launch_compact_gather(e->g, in, e->c4_counts.p, 1, desc, e->c4_table.p, e->c4_acc.p, lo, hi,
+                                                            e->c4_rows, e->c4_stepptr.p, e->c4_steps.p, e->c4_entries.p,
+                                                            e->c4_dirty.p, e->c4_dirty_cap, e->c4_agg16.p, e->stream, e->c4_block,
+                                                            e->c4_base, e->c4_end, /*what=*/2));
+                    acc4 = e->c4_acc.p;
+                    c4desc = desc;
+                }
+            } else if (!e->c4_range_mode && whole_plan && !longs && (uint64_t)(hi - lo) * 2 >= e->g.n) {
+                // worth its fixed cost (count + compact the whole input) only when this call covers most of the rows
                 uint32_t *desc = e->c4_desc.p + 8 * (stage - 1);
                 e->c4_last_desc = 8 * (stage - 1);
                 const bool fused = fused_in == stage;   // the producing kernel left counts (and perhaps the table)
@@ -683,7 +721,8 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
                 HIP_TRY(e, gnnvc::launch_compact_gather(e->g, in, fused ? e->c4_emit_counts.p : e->c4_counts.p, fused ? 64 : 1,
                                                         desc, e->c4_table.p, e->c4_acc.p, lo, hi,
                                                         e->c4_rows, e->c4_stepptr.p, e->c4_steps.p, e->c4_entries.p,
-                                                        e->c4_dirty.p, e->c4_dirty_cap, e->c4_agg16.p, e->stream, e->c4_block));
+                                                        e->c4_dirty.p, e->c4_dirty_cap, e->c4_agg16.p, e->stream, e->c4_block,
+                                                        e->c4_base, e->c4_end));
                 acc4 = e->c4_acc.p;
                 c4desc = desc;
                 if (may_emit) {   // and this stage's own (aggregate-only, VALU) kernel produces for the next one
@@ -892,6 +931,7 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
     if (k == "compact_gather_active") *value = e->c4_ready ? 1 : 0;
     else if (k == "compact_gather_chunks") *value = e->c4_ready ? (long)e->c4_chunks : 0;
     else if (k == "compact_gather_block_cols") *value = e->c4_ready ? (long)e->c4_block : 0;
+    else if (k == "compact_gather_rows_per_chunk") *value = e->c4_ready ? (long)e->c4_rows : 0;
     else if (k == "compact_gather_steps") *value = e->c4_ready ? (long)e->c4_steps_total : 0;
     else if (k == "compact_gather_last_ok" || k == "compact_gather_last_dirty") {
         // what the device decided at the last launch of the plan (waits for the stream; for tests and tools)
@@ -954,6 +994,8 @@ static int adopt_uploaded(gnnvc_engine *e, uint32_t n, uint64_t nnz) {
     if (rc) return rc;
     e->lt_ready = e->lt_tried = false;
     e->c4_ready = e->c4_tried = false;
+    e->c4_range_mode = false;
+    e->c4_prepared_stage = -1;
     e->blocked_ready = false;   // the column-blocked index is built on the graph's SECOND forward:
     e->blocked_tried = false;   // it costs about as much as it saves on one, and the reference's
     e->graph_uses = 0;          // driver uses every graph exactly once (src/GNN_VC.cpp:171-192)
@@ -1097,6 +1139,8 @@ int gnnvc_attach_graph_device(gnnvc_engine *e, uint32_t n, uint64_t nnz, const u
     if (rc) return rc;
     e->lt_ready = e->lt_tried = false;
     e->c4_ready = e->c4_tried = false;
+    e->c4_range_mode = false;
+    e->c4_prepared_stage = -1;
     e->blocked_ready = false;   // the column-blocked index is built on the graph's SECOND forward:
     e->blocked_tried = false;   // it costs about as much as it saves on one, and the reference's
     e->graph_uses = 0;          // driver uses every graph exactly once (src/GNN_VC.cpp:171-192)
@@ -1143,6 +1187,7 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
     for (auto &b : e->h) HIP_TRY(e, gnnvc::launch_zero_pad_row(b.p, n, 16, e->stream));
     const float *cur = d_x;
     e->c4_fused_for = -1;
+    e->c4_prepared_stage = -1;
     HIP_TRY(e, hipEventRecord(e->ev[0], e->stream));
     for (size_t s = 0; s < ns; ++s) {
         const bool last = s + 1 == ns;
@@ -1153,6 +1198,40 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
         cur = dst;
     }
     e->ev_count = (int)ns + 1;
+    return GNNVC_OK;
+}
+
+int gnnvc_stage_input_ready(gnnvc_engine *e, int stage, const float *d_in, uint32_t row_lo, uint32_t row_hi) {
+    if (!e) return GNNVC_ERR_INVALID;
+    if (!e->have_graph) return fail(e, GNNVC_ERR_STATE, "no graph attached");
+    if (e->stages.empty()) return fail(e, GNNVC_ERR_UNSUPPORTED, "model is not fused into stages");
+    if (stage < 1 || stage >= (int)e->stages.size()) return fail(e, GNNVC_ERR_INVALID, "stage %d has no 16-wide input", stage);
+    if (row_lo > row_hi || row_hi > e->g.n) return fail(e, GNNVC_ERR_INVALID, "row range [%u, %u) outside the graph", row_lo, row_hi);
+    e->c4_prepared_stage = -1;
+    if (e->g.n == 0 || row_lo == row_hi) return GNNVC_OK;
+    if (!d_in) return fail(e, GNNVC_ERR_INVALID, "null feature buffer");
+    int rc = use_device(e);
+    if (rc) return rc;
+    const bool same_range = e->c4_range_mode && e->c4_tried && e->c4_base == row_lo && e->c4_end == row_hi;
+    e->c4_range_mode = true;
+    if (!same_range) {
+        rc = build_compact(e, row_lo, row_hi);
+        if (rc) return rc;
+        if (!e->c4_ready) {   // remember what was tried, so that the next forward does not try again
+            e->c4_base = row_lo;
+            e->c4_end = row_hi;
+        }
+    }
+    if (!e->c4_ready || e->n_long > 0) return GNNVC_OK;   // the plan does not apply to this graph: nothing to prepare
+    uint32_t *desc = e->c4_desc.p + 8 * (stage - 1);
+    e->c4_last_desc = 8 * (stage - 1);
+    HIP_TRY(e, gnnvc::column_counts(d_in, e->g.n, e->c4_counts.p, e->stream));
+    HIP_TRY(e, gnnvc::launch_compact_gather(e->g, d_in, e->c4_counts.p, 1, desc, e->c4_table.p, e->c4_acc.p, e->c4_base, e->c4_end,
+                                            e->c4_rows, e->c4_stepptr.p, e->c4_steps.p, e->c4_entries.p, e->c4_dirty.p,
+                                            e->c4_dirty_cap, e->c4_agg16.p, e->stream, e->c4_block, e->c4_base, e->c4_end,
+                                            /*what=*/1));
+    e->c4_prepared_stage = stage;
+    e->c4_prepared_in = d_in;
     return GNNVC_OK;
 }
 

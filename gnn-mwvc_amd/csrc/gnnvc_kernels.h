@@ -108,11 +108,14 @@ uint32_t lds_table_max_rows();
 uint32_t lds_table_block();
 hipError_t lds_table_bytes(const uint32_t *w, uint32_t n, uint8_t *wb, uint32_t *bad, hipStream_t stream);
 hipError_t lds_table_count(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t block_cols,
-                           uint32_t *seg_cnt, uint32_t *bad, hipStream_t stream);
+                           uint32_t *seg_cnt, uint32_t *bad, hipStream_t stream, uint32_t row_base = 0,
+                           uint32_t row_end = 0xFFFFFFFFu);
 hipError_t lds_table_steps(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, const uint32_t *seg_cnt,
-                           const uint32_t *step_ptr, uint32_t *step_count, void *steps, bool write, hipStream_t stream);
+                           const uint32_t *step_ptr, uint32_t *step_count, void *steps, bool write, hipStream_t stream,
+                           uint32_t row_base = 0, uint32_t row_end = 0xFFFFFFFFu);
 hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t block_cols,
-                             const uint32_t *seg_cnt, uint32_t *entries, hipStream_t stream, uint32_t shift = 17);
+                             const uint32_t *seg_cnt, uint32_t *entries, hipStream_t stream, uint32_t shift = 17,
+                             uint32_t row_base = 0, uint32_t row_end = 0xFFFFFFFFu);
 hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *x,
                                    float *out, uint32_t row_lo, uint32_t row_hi, uint32_t rows_per_chunk,
                                    const uint32_t *step_ptr, const void *steps, const uint32_t *entries, const uint8_t *wbyte,
@@ -130,7 +133,8 @@ uint32_t compact_shift();
 hipError_t launch_compact_gather(const GraphDev &g, const float *in, const unsigned long long *counts, int count_slots, uint32_t *desc,
                                  float *table, float *acc4, uint32_t row_lo, uint32_t row_hi, uint32_t rows_per_chunk,
                                  const uint32_t *step_ptr, const void *steps, const uint32_t *entries, uint32_t *dirty_rows,
-                                 uint32_t dirty_cap, float *agg16, hipStream_t stream, uint32_t block_cols);
+                                 uint32_t dirty_cap, float *agg16, hipStream_t stream, uint32_t block_cols,
+                                 uint32_t plan_base, uint32_t plan_end, int what = 3 /* 1 = prepare, 2 = sums, 3 = both */);
 
 hipError_t score_keys(const float *scores, size_t n, float *keys, uint8_t *above_half, hipStream_t stream);
 

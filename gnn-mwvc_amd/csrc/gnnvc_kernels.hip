@@ -900,12 +900,13 @@ __global__ __launch_bounds__(256) void k_lt_bytes(const uint32_t *__restrict__ w
 // entries of chunk `c` per column block -> seg_cnt[c * nblocks + b]; bad |= 2 if a row's blocks are
 // not ascending (unsorted adjacency: the plan would change the order of its sum)
 __global__ __launch_bounds__(1024) void k_lt_count(GraphDev g, uint32_t rows_per_chunk, uint32_t nblocks, uint32_t block_cols,
-                                                   uint32_t *__restrict__ seg_cnt, uint32_t *bad) {
+                                                   uint32_t *__restrict__ seg_cnt, uint32_t *bad, uint32_t row_base,
+                                                   uint32_t row_end) {
     __shared__ uint32_t hist[4096];
     const uint32_t c = blockIdx.x, tid = threadIdx.x;
     for (uint32_t i = tid; i < nblocks; i += 1024) hist[i] = 0;
     __syncthreads();
-    const uint32_t r0 = c * rows_per_chunk, r1 = min(g.n, r0 + rows_per_chunk);
+    const uint32_t r0 = min(row_end, row_base + c * rows_per_chunk), r1 = min(row_end, r0 + rows_per_chunk);
     bool unsorted = false;
     for (uint32_t u = r0 + tid; u < r1; u += 1024) {
         uint32_t prev = 0, run = 0;
@@ -930,11 +931,12 @@ __global__ __launch_bounds__(1024) void k_lt_count(GraphDev g, uint32_t rows_per
 // write != 0: the descriptors {block, first entry, count, 0} at step_ptr[c]...
 __global__ __launch_bounds__(256) void k_lt_steps(GraphDev g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks,
                                                   const uint32_t *__restrict__ seg_cnt, const uint32_t *__restrict__ step_ptr,
-                                                  uint32_t *__restrict__ step_count, uint4 *__restrict__ steps, int write) {
+                                                  uint32_t *__restrict__ step_count, uint4 *__restrict__ steps, int write,
+                                                  uint32_t row_base, uint32_t row_end) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
     const uint32_t *cnt = seg_cnt + (size_t)c * nblocks;
-    uint32_t first = g.rowptr[min((uint64_t)g.n, (uint64_t)c * rows_per_chunk)];   // a chunk's entries are a CSR range
+    uint32_t first = g.rowptr[min((uint64_t)row_end, (uint64_t)row_base + (uint64_t)c * rows_per_chunk)];   // a chunk's entries are a CSR range
     uint32_t pos = write ? step_ptr[c] : 0, made = 0;
     for (uint32_t b = 0; b < nblocks; ++b) {
         uint32_t left = cnt[b];
@@ -957,12 +959,12 @@ __global__ __launch_bounds__(256) void k_lt_steps(GraphDev g, uint32_t rows_per_
 // entries of one block are written as one adjacent run, in order (the order among rows is free)
 __global__ __launch_bounds__(1024) void k_lt_scatter(GraphDev g, uint32_t rows_per_chunk, uint32_t nblocks, uint32_t block_cols,
                                                      uint32_t shift, const uint32_t *__restrict__ seg_cnt,
-                                                     uint32_t *__restrict__ entries) {
+                                                     uint32_t *__restrict__ entries, uint32_t row_base, uint32_t row_end) {
     __shared__ uint32_t cursor[4096];
     const uint32_t c = blockIdx.x, tid = threadIdx.x;
-    const uint32_t r0 = c * rows_per_chunk, r1 = min(g.n, r0 + rows_per_chunk);
+    const uint32_t r0 = min(row_end, row_base + c * rows_per_chunk), r1 = min(row_end, r0 + rows_per_chunk);
     if (tid == 0) {   // exclusive scan of <= 4096 counts: a few microseconds, once per graph
-        uint32_t run = g.rowptr[r0 < g.n ? r0 : g.n];
+        uint32_t run = g.rowptr[r0];
         for (uint32_t b = 0; b < nblocks; ++b) {
             cursor[b] = run;
             run += seg_cnt[(size_t)c * nblocks + b];
@@ -1207,7 +1209,8 @@ __global__ __launch_bounds__(1024) void k_c4_agg(const uint32_t *__restrict__ st
                                                  const uint32_t *__restrict__ entries, const f32x4 *__restrict__ table,
                                                  f32x4 *__restrict__ agg, uint32_t n, uint32_t rows_per_chunk, uint32_t chunk0,
                                                  uint32_t chunk1, uint32_t last_entry, uint32_t *__restrict__ desc,
-                                                 uint32_t *__restrict__ dirty_rows, uint32_t dirty_cap, uint32_t block_cols) {
+                                                 uint32_t *__restrict__ dirty_rows, uint32_t dirty_cap, uint32_t block_cols,
+                                                 uint32_t row_base, uint32_t row_end) {
     extern __shared__ __attribute__((aligned(16))) unsigned char c4_smem[];
     if (!desc[0]) return;                                               // block-uniform
     f32x4 *acc = reinterpret_cast<f32x4 *>(c4_smem);                    // rows_per_chunk (<= kC4MaxRows) x 4 sums
@@ -1216,7 +1219,7 @@ __global__ __launch_bounds__(1024) void k_c4_agg(const uint32_t *__restrict__ st
     uint32_t *dirty = ebuf + kLtStep;                                   // one bit per row of the chunk
     const uint32_t tid = threadIdx.x;
     for (uint32_t chunk = chunk0 + blockIdx.x; chunk < chunk1; chunk += gridDim.x) {
-        const uint32_t row0 = chunk * rows_per_chunk;
+        const uint32_t row0 = row_base + chunk * rows_per_chunk;   // chunks are numbered within the plan's row range
         __syncthreads();                                                // the previous chunk's sums are written out
         for (uint32_t i = tid; i < rows_per_chunk; i += 1024) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         for (uint32_t i = tid; i < (kC4MaxRows + 31) / 32; i += 1024) dirty[i] = 0;
@@ -1295,7 +1298,7 @@ __global__ __launch_bounds__(1024) void k_c4_agg(const uint32_t *__restrict__ st
         }
 #undef C4_STEP
         __syncthreads();
-        for (uint32_t i = tid; i < rows_per_chunk && row0 + i < n; i += 1024) {
+        for (uint32_t i = tid; i < rows_per_chunk && row0 + i < row_end; i += 1024) {
             f32x4 a = acc[i];
             if (dirty[i >> 5] >> (i & 31) & 1u) {
                 // a dirty row: its aggregate is recomputed from full rows (k_c4_fix) into slot `slot` of the
@@ -2073,24 +2076,30 @@ hipError_t lds_table_bytes(const uint32_t *w, uint32_t n, uint8_t *wb, uint32_t 
 }
 
 hipError_t lds_table_count(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t block_cols,
-                           uint32_t *seg_cnt, uint32_t *bad, hipStream_t stream) {
+                           uint32_t *seg_cnt, uint32_t *bad, hipStream_t stream, uint32_t row_base, uint32_t row_end) {
+    if (row_end > g.n) row_end = g.n;
     if (nblocks > 4096 || block_cols > (1u << 18) || rows_per_chunk > (1u << 15)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_lt_count, dim3(nchunks), dim3(1024), 0, stream, g, rows_per_chunk, nblocks, block_cols, seg_cnt, bad);
+    hipLaunchKernelGGL(k_lt_count, dim3(nchunks), dim3(1024), 0, stream, g, rows_per_chunk, nblocks, block_cols, seg_cnt, bad,
+                       row_base, row_end);
     return hipGetLastError();
 }
 
 hipError_t lds_table_steps(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, const uint32_t *seg_cnt,
-                           const uint32_t *step_ptr, uint32_t *step_count, void *steps, bool write, hipStream_t stream) {
+                           const uint32_t *step_ptr, uint32_t *step_count, void *steps, bool write, hipStream_t stream,
+                           uint32_t row_base, uint32_t row_end) {
+    if (row_end > g.n) row_end = g.n;
     hipLaunchKernelGGL(k_lt_steps, dim3((nchunks + 255) / 256), dim3(256), 0, stream, g, rows_per_chunk, nchunks, nblocks,
-                       seg_cnt, step_ptr, step_count, reinterpret_cast<uint4 *>(steps), write ? 1 : 0);
+                       seg_cnt, step_ptr, step_count, reinterpret_cast<uint4 *>(steps), write ? 1 : 0, row_base, row_end);
     return hipGetLastError();
 }
 
 hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t block_cols,
-                             const uint32_t *seg_cnt, uint32_t *entries, hipStream_t stream, uint32_t shift) {
+                             const uint32_t *seg_cnt, uint32_t *entries, hipStream_t stream, uint32_t shift,
+                             uint32_t row_base, uint32_t row_end) {
     if (block_cols > (1u << shift) || ((uint64_t)rows_per_chunk << shift) > (1ull << 32)) return hipErrorInvalidValue;
+    if (row_end > g.n) row_end = g.n;
     hipLaunchKernelGGL(k_lt_scatter, dim3(nchunks), dim3(1024), 0, stream, g, rows_per_chunk, nblocks, block_cols, shift, seg_cnt,
-                       entries);
+                       entries, row_base, row_end);
     return hipGetLastError();
 }
 
@@ -2142,15 +2151,19 @@ uint32_t compact_shift() { return kC4Shift; }
 hipError_t launch_compact_gather(const GraphDev &g, const float *in, const unsigned long long *counts, int count_slots, uint32_t *desc,
                                  float *table, float *acc4, uint32_t row_lo, uint32_t row_hi, uint32_t rows_per_chunk,
                                  const uint32_t *step_ptr, const void *steps, const uint32_t *entries, uint32_t *dirty_rows,
-                                 uint32_t dirty_cap, float *agg16, hipStream_t stream, uint32_t block_cols) {
-    if (row_hi <= row_lo || g.nnz == 0) return hipErrorInvalidValue;
+                                 uint32_t dirty_cap, float *agg16, hipStream_t stream, uint32_t block_cols,
+                                 uint32_t plan_base, uint32_t plan_end, int what) {
+    if (row_hi <= row_lo || g.nnz == 0 || row_lo < plan_base || row_hi > plan_end) return hipErrorInvalidValue;
     if (rows_per_chunk == 0 || rows_per_chunk > kC4MaxRows) return hipErrorInvalidValue;
+    if (what & 1) {   // prepare: choose the columns and (unless the producing kernel did) write the table
+        hipLaunchKernelGGL(k_c4_choose, dim3(1), dim3(64), 0, stream, counts, count_slots, g.n, desc);
+        hipLaunchKernelGGL(k_c4_compact, dim3(std::min<unsigned>((g.n + 256) / 256, 4096u)), dim3(256), 0, stream,
+                           reinterpret_cast<const float4 *>(in), g.n, desc, reinterpret_cast<f32x4 *>(table));
+    }
+    if (!(what & 2)) return hipGetLastError();
     hipError_t rc0 = hipMemsetAsync(desc + 5, 0, sizeof(uint32_t), stream);   // dirty-row counter
     if (rc0 != hipSuccess) return rc0;
-    hipLaunchKernelGGL(k_c4_choose, dim3(1), dim3(64), 0, stream, counts, count_slots, g.n, desc);
-    hipLaunchKernelGGL(k_c4_compact, dim3(std::min<unsigned>((g.n + 256) / 256, 4096u)), dim3(256), 0, stream,
-                       reinterpret_cast<const float4 *>(in), g.n, desc, reinterpret_cast<f32x4 *>(table));
-    const uint32_t c0 = row_lo / rows_per_chunk, c1 = (row_hi - 1) / rows_per_chunk + 1;
+    const uint32_t c0 = (row_lo - plan_base) / rows_per_chunk, c1 = (row_hi - 1 - plan_base) / rows_per_chunk + 1;
     constexpr size_t lds = (size_t)kC4MaxRows * 16 + (size_t)kLtStep * 16 + (size_t)kLtStep * 4 + ((kC4MaxRows + 31) / 32) * 4 + 64;
     static_assert(lds <= 160 * 1024, "LDS budget of k_c4_agg");
     static bool attr_set = false;
@@ -2163,7 +2176,7 @@ hipError_t launch_compact_gather(const GraphDev &g, const float *in, const unsig
     hipLaunchKernelGGL(k_c4_agg, dim3(std::min<uint32_t>(256u, c1 - c0)), dim3(1024), lds, stream, step_ptr,
                        reinterpret_cast<const uint4 *>(steps), entries, reinterpret_cast<const f32x4 *>(table),
                        reinterpret_cast<f32x4 *>(acc4), g.n, rows_per_chunk, c0, c1, (uint32_t)(g.nnz - 1), desc, dirty_rows,
-                       dirty_cap, block_cols);
+                       dirty_cap, block_cols, plan_base, plan_end);
     // the grid is sized for a typical number of dirty rows and strides over more
     hipLaunchKernelGGL(k_c4_fix, dim3(std::min<uint32_t>((dirty_cap + 63) / 64, 4096u)), dim3(256), 0, stream, g,
                        reinterpret_cast<const float4 *>(in), desc, dirty_rows, dirty_cap, reinterpret_cast<float4 *>(agg16));

@@ -207,9 +207,19 @@ def exchange_rows(buf: torch.Tensor, bounds: Sequence[Tuple[int, int]], rank: in
             w.wait()
 
 
+def _piece_step(per: int, chunks: int, piece_rows: int) -> int:
+    """Rows per piece: `piece_rows` when the caller knows a natural size (a multiple of ALIGN — e.g. 256 chunks of
+    the engine's compact-table plan, so that no piece ends inside a chunk), else the shard cut into `chunks`."""
+    if piece_rows > 0:
+        if piece_rows % ALIGN:
+            raise ValueError("piece_rows must be a multiple of ALIGN")
+        return piece_rows
+    return max(ALIGN, (per // max(chunks, 1) + ALIGN - 1) // ALIGN * ALIGN)
+
+
 def exchange_rows_pipelined(stage_fn, stage: int, src: torch.Tensor, dst: torch.Tensor, logits,
                             bounds: Sequence[Tuple[int, int]], rank: int, n: int, chunks: int,
-                            group=None) -> None:
+                            group=None, piece_rows: int = 0) -> None:
     """Compute this rank's rows of `stage` in `chunks` pieces and all-gather each piece
     asynchronously while the next piece is being computed (equal-rows partition only).
 
@@ -221,7 +231,7 @@ def exchange_rows_pipelined(stage_fn, stage: int, src: torch.Tensor, dst: torch.
     world = len(bounds)
     per = _equal_shard_rows(n, bounds)
     lo, hi = bounds[rank]
-    step = max(ALIGN, (per // max(chunks, 1) + ALIGN - 1) // ALIGN * ALIGN)
+    step = _piece_step(per, chunks, piece_rows)
     works = []
     for off in range(0, per, step):
         size = min(step, per - off)
@@ -277,13 +287,13 @@ def exchange_rows_packed(codec: RowCodec, bufs: ForwardBuffers, dst: torch.Tenso
 
 def exchange_rows_pipelined_packed(codec: RowCodec, stage_fn, stage: int, src: torch.Tensor, dst: torch.Tensor,
                                    bufs: ForwardBuffers, pk: Packing, bounds: Sequence[Tuple[int, int]], rank: int,
-                                   chunks: int, group=None) -> None:
+                                   chunks: int, group=None, piece_rows: int = 0) -> None:
     """exchange_rows_pipelined with packed rows: piece k is computed, packed and its all-gather
     started; while it travels, piece k - 1 is waited for and expanded and piece k + 1 computed."""
     world = len(bounds)
     per = _equal_shard_rows(bufs.n, bounds)
     lo, hi = bounds[rank]
-    step = max(ALIGN, (per // max(chunks, 1) + ALIGN - 1) // ALIGN * ALIGN)
+    step = _piece_step(per, chunks, piece_rows)
     pw = pk.piece_words(step)
     n_pieces = (per + step - 1) // step
     buf = bufs.staging(n_pieces * world * pw)      # [piece][rank][pw]: one contiguous gather per piece
@@ -362,7 +372,9 @@ def partitioned_forward(stage_fn: StageFn, num_stages: int, x: torch.Tensor, buf
                         pipeline_chunks: int = 0,
                         replicate: "set[int] | None" = None,
                         codec: "RowCodec | None" = None,
-                        verify: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+                        verify: bool = True,
+                        prepare_fn=None,
+                        piece_rows: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
     """Run every fused stage on this rank's rows and exchange between stages.
 
     stage_fn(stage, lo, hi, src, dst, logits_or_None) computes rows [lo, hi) of `dst`
@@ -377,7 +389,10 @@ def partitioned_forward(stage_fn: StageFn, num_stages: int, x: torch.Tensor, buf
     codec: enables the compressed exchange.  The first forward on a graph exchanges full rows and
     settles each stage's Packing in bufs.live from its per-column non-zero counts; later forwards
     ship packed rows.  With verify=True (default) the forward ends with exchange_verified(): if any
-    rank's exception list overflowed, every rank goes back to full rows and the forward is repeated.  Callers that pass verify=False (a timed loop) must call
+    rank's exception list overflowed, every rank goes back to full rows and the forward is repeated.
+    prepare_fn(stage, src, lo, hi): optional hint called once before a partitioned stage >= 1 — "src is this
+    stage's complete input and stays as it is while rows [lo, hi) are computed from it, possibly in pieces"
+    (Engine.stage_input_ready: the engine writes its compact table once instead of gathering full rows per piece).  Callers that pass verify=False (a timed loop) must call
     exchange_verified() themselves before trusting the results.
     """
     world = len(bounds)
@@ -394,6 +409,8 @@ def partitioned_forward(stage_fn: StageFn, num_stages: int, x: torch.Tensor, buf
     can_pipeline = pipeline_chunks > 1 and world > 1 and _equal_shard_rows(bufs.n, bounds) > 0
     used_codec = False
     pieces = world * (max(pipeline_chunks, 1) if can_pipeline else 1)
+    if can_pipeline and piece_rows > 0:
+        pieces = world * max(1, -(-_equal_shard_rows(bufs.n, bounds) // piece_rows))
     src = x
     for st in range(num_stages):
         last = st == num_stages - 1
@@ -407,16 +424,18 @@ def partitioned_forward(stage_fn: StageFn, num_stages: int, x: torch.Tensor, buf
             if codec is not None and world > 1 and st not in bufs.live:
                 bufs.live[st] = choose_packing(codec.column_counts(dst, bufs.n), bufs.n, pieces)
         elif not last:
+            if prepare_fn is not None and st >= 1:
+                prepare_fn(st, src, lo, hi)
             pk = bufs.live.get(st) if (codec is not None and world > 1) else None
             pack = pk is not None
             used_codec = used_codec or pack
             if can_pipeline:
                 if pack:
                     exchange_rows_pipelined_packed(codec, stage_fn, st, src, dst, bufs, pk, bounds, rank,
-                                                   pipeline_chunks, group)
+                                                   pipeline_chunks, group, piece_rows)
                 else:
                     exchange_rows_pipelined(stage_fn, st, src, dst, None, bounds, rank, bufs.n,
-                                            pipeline_chunks, group)
+                                            pipeline_chunks, group, piece_rows)
                 if on_stage:
                     on_stage(st, "computed")
             else:
@@ -432,6 +451,8 @@ def partitioned_forward(stage_fn: StageFn, num_stages: int, x: torch.Tensor, buf
                 # (synchronises; first forward on a graph only) and settle how it travels from now on
                 bufs.live[st] = choose_packing(codec.column_counts(dst, bufs.n), bufs.n, pieces)
         else:
+            if prepare_fn is not None and st >= 1:
+                prepare_fn(st, src, lo, hi)
             stage_fn(st, lo, hi, src, dst, bufs.logits)
             if on_stage:
                 on_stage(st, "computed")
@@ -443,7 +464,8 @@ def partitioned_forward(stage_fn: StageFn, num_stages: int, x: torch.Tensor, buf
         src = dst
     if used_codec and verify and not exchange_verified(bufs, group):
         return partitioned_forward(stage_fn, num_stages, x, bufs, bounds, rank, group, exchange, on_stage,
-                                   gather_logits, replicate_stage0, pipeline_chunks, replicate, codec, verify)
+                                   gather_logits, replicate_stage0, pipeline_chunks, replicate, codec, verify, prepare_fn,
+                                   piece_rows)
     return bufs.scores[: bufs.n], bufs.logits[: bufs.n]
 
 

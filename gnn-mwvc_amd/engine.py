@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "gnnvc_in_width", "gnnvc_out_width", "gnnvc_upload_graph", "gnnvc_attach_graph_device",
     "gnnvc_graph_staging", "gnnvc_staged_columns_ready", "gnnvc_commit_staged_graph",
     "gnnvc_forward", "gnnvc_forward_device", "gnnvc_num_stages", "gnnvc_stage_widths",
-    "gnnvc_stage_forward_device", "gnnvc_live_columns", "gnnvc_column_counts", "gnnvc_pack_rows", "gnnvc_unpack_rows", "gnnvc_unpack_gathered",
+    "gnnvc_stage_forward_device", "gnnvc_stage_input_ready", "gnnvc_live_columns", "gnnvc_column_counts", "gnnvc_pack_rows", "gnnvc_unpack_rows", "gnnvc_unpack_gathered",
     "gnnvc_reduction_flags", "gnnvc_score_keys", "gnnvc_synchronize", "gnnvc_last_forward_ms",
     "gnnvc_graph_layer_forward", "gnnvc_linear_forward", "gnnvc_relu_forward",
     "gnnvc_sigmoid_forward", "gnnvc_sgemm",
@@ -96,6 +96,7 @@ def load_library():
     L.gnnvc_forward_device.argtypes = [vp, f32p, f32p, f32p]
     L.gnnvc_stage_forward_device.argtypes = [vp, C.c_int, u32, u32, f32p, f32p, f32p]
     L.gnnvc_reduction_flags.argtypes = [vp, u32, vp]
+    L.gnnvc_stage_input_ready.argtypes = [vp, C.c_int, f32p, u32, u32]
     L.gnnvc_score_keys.argtypes = [vp, f32p, u32, vp, vp]
     L.gnnvc_live_columns.argtypes = [vp, f32p, u32, u32, C.POINTER(u32)]
     L.gnnvc_column_counts.argtypes = [vp, f32p, u32, u32, vp]
@@ -255,6 +256,10 @@ class Engine:
                              logits_ptr: int = 0):
         self._check(self._L.gnnvc_stage_forward_device(self._h, stage, row_lo, row_hi, in_ptr,
                                                        out_ptr, logits_ptr or None))
+
+    def stage_input_ready(self, stage: int, in_ptr: int, row_lo: int, row_hi: int):
+        """Announce the complete, final input of `stage` before computing rows [row_lo, row_hi) of it in pieces."""
+        self._check(self._L.gnnvc_stage_input_ready(self._h, stage, in_ptr, row_lo, row_hi))
 
     # -- feature-row codec of the inter-GPU exchange (device pointers)
     def live_columns(self, feat_ptr: int, rows: int, width: int = 16) -> int:

@@ -199,6 +199,15 @@ int gnnvc_unpack_gathered(gnnvc_engine *e, const float *d_buf, uint32_t world, u
                           uint32_t dense_rows, uint32_t exc_cap, uint32_t width, uint32_t rows_per_rank, uint32_t row_off,
                           uint32_t rows, uint32_t n, uint32_t mask, uint32_t kp, float *d_feat);
 
+/* A multi-GPU rank that computes rows [row_lo, row_hi) of `stage` (1 or 2) in several gnnvc_stage_forward_device
+ * calls announces the stage's complete input once: "d_in is final and will not change until those calls are done".
+ * The engine then builds the compact-table plan over that row range — once per graph and range —
+ * and writes the table for this input, so that each of the calls (if it covers enough rows to fill the GPU) reads
+ * its neighbours from the table instead of gathering 64-byte rows.  Purely an optimisation hint: results are
+ * bit-identical with or without it, and it does nothing on graphs or inputs the plan does not fit.  The
+ * announcement is forgotten at the next gnnvc_stage_input_ready / gnnvc_forward(_device) / graph change. */
+int gnnvc_stage_input_ready(gnnvc_engine *e, int stage, const float *d_in, uint32_t row_lo, uint32_t row_hi);
+
 /* ---- reduction-rule candidates ------------------------------------
  * One vertex-parallel pass over the uploaded graph that evaluates which local rules of the
  * reference's reduce_graph (include/mwvc_reductions.hpp:335-380) would fire on each vertex as

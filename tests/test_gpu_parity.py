@@ -613,6 +613,49 @@ def test_compact_gather_plan_is_bit_identical(model_text, oracle_model, case):
         e.close()
 
 
+@pytest.mark.parametrize("world,pieces", [(2, 3), (2, 1), (3, 2), (4, 2)])
+def test_compact_gather_over_a_ranks_rows(model_text, oracle_model, world, pieces):
+    """gnnvc_stage_input_ready: the plan chunked over the rows ONE rank of a P-rank run computes, the table written
+    once per stage, the rank's rows computed in pieces — same bits as the oracle for every rank's range."""
+    import torch
+    import gnn_mwvc_amd as G
+    from gnn_mwvc_amd import distributed as D
+    g = gg.erdos_renyi(120000, 1200000, 73)   # (enough chunks per piece for the pieces to take the plan)
+    rng = np.random.default_rng(world * 10 + pieces)
+    h = _sparse_features(g.n, rng, [0, 3, 7, 11], [1.0, 0.1, 0.5, 1.0], strays=12)
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_option("blocked_min_n", 0)
+        e.set_weight_scale(g.ws)
+        oracle_model.set_weight_scale(g.ws)
+        e.upload_graph(g)
+        dev = torch.device("cuda:0")
+        hin = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+        hin[: g.n] = torch.from_numpy(h).to(dev)
+        bounds = D.partition_bounds(g.n, world)
+        for stage in (1, 2):
+            want = _oracle_stage(oracle_model, g, stage, h)
+            for lo, hi in bounds:
+                out = torch.full((g.n + 1, 16) if stage == 1 else (g.n + 1,), 7.0, dtype=torch.float32, device=dev)
+                lg = torch.full((g.n + 1,), 7.0, dtype=torch.float32, device=dev)
+                torch.cuda.synchronize()
+                e.stage_input_ready(stage, hin.data_ptr(), lo, hi)
+                assert e.get_info("compact_gather_active") == 1
+                step = ((hi - lo + pieces - 1) // pieces + 63) // 64 * 64
+                for r0 in range(lo, hi, step):
+                    e.stage_forward_device(stage, r0, min(r0 + step, hi), hin.data_ptr(), out.data_ptr(),
+                                           lg.data_ptr() if stage == 2 else 0)
+                e.synchronize()
+                got = out[lo:hi].cpu().numpy() if stage == 1 else lg[lo:hi].cpu().numpy().reshape(-1, 1)
+                assert np.array_equal(bits(got), bits(want[lo:hi])), (stage, lo, hi)
+                assert e.get_info("compact_gather_last_ok") == 1
+        # a whole forward afterwards still gives the reference's logits (the range plan is simply not used for it)
+        _, logits = e.forward(g.x())
+        assert np.array_equal(bits(logits[:, 0]), bits(oracle_model.logits(g)))
+    finally:
+        e.close()
+
+
 def test_compact_gather_producer_side_statistics(model_text, oracle_model):
     """From the third forward on a graph, the stage kernels themselves count the non-zeros of the rows they write and
     write their compact form (c4_emit), and the next stage skips its two passes over its input.  Same bits, forward

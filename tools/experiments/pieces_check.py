@@ -51,6 +51,11 @@ for st in range(3):
 
 # per-rank compute of a P-rank run (rank 0's pieces only, no exchange), steady state
 lo, hi = bounds[0]
+prepare = len(sys.argv) > 4 and sys.argv[4] == "prepare"
+if prepare:   # pieces of 256 of the plan's chunks
+    e.stage_input_ready(1, full[0].data_ptr(), lo, hi)
+    if e.get_info("compact_gather_active"):
+        step = 256 * e.get_info("compact_gather_rows_per_chunk")
 for rep in range(3):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -58,6 +63,8 @@ for rep in range(3):
     src = x
     for st in range(3):
         ts = time.perf_counter()
+        if prepare and st >= 1:
+            e.stage_input_ready(st, src.data_ptr(), lo, hi)
         for off in range(0, per, step):
             r0, r1 = min(lo + off, hi), min(lo + off + min(step, per - off), hi)
             if r1 > r0:
@@ -65,5 +72,7 @@ for rep in range(3):
         e.synchronize()
         times.append((time.perf_counter() - ts) * 1e3)
         src = full[st]
+same = all(torch.equal(out[st][lo:hi].view(torch.int32), full[st][lo:hi].view(torch.int32)) for st in range(3))
+print(f"prepare={prepare} identical={same} plan rows [{lo},{hi}) chunks={e.get_info('compact_gather_chunks')}")
 print(f"rank 0 of {P}: per-stage compute {[round(t, 3) for t in times]} ms, sum {sum(times):.3f} ms "
       f"(whole graph on one GPU / P = {5.96 / P:.3f} ms)")
