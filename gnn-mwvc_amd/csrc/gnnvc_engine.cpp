@@ -733,6 +733,8 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
                     e->c4_fused_for = stage + 1;
                 }
             }
+        }
+        {   // degree-sorted tiles on skewed graphs (every stage; the list is cached per row range)
             int rc = ensure_sorted(e, lo, hi);
             if (rc) return rc;
             if (e->sorted_use) {

@@ -521,37 +521,56 @@ __global__ __launch_bounds__(kBlock) void k_stage_f1(
         const uint32_t *__restrict__ ep, const uint32_t *__restrict__ ecol,
         const float *__restrict__ acc_in, uint32_t long_thresh, int interleave,
         const uint32_t *__restrict__ acc_bad,
-        const uint32_t *__restrict__ emit_spec, c4row *__restrict__ emit_table, unsigned long long *__restrict__ emit_counts) {
+        const uint32_t *__restrict__ emit_spec, c4row *__restrict__ emit_table, unsigned long long *__restrict__ emit_counts,
+        const uint32_t *__restrict__ srt_vertex, const uint4 *__restrict__ srt_meta, uint32_t n_sorted) {
     // acc_bad (LDS-table plan only): *acc_bad == 0 -> acc_in holds the rows' COMPLETE sums and no entry is left
     // to add; != 0 -> the plan did not apply to this input, acc_in is ignored and every entry is gathered here.
+    // srt_vertex (skewed graphs): tiles of 64 vertices of similar degree from the degree-sorted list (see
+    // k_stage_f16) instead of 64 consecutive rows, so a tile's gather rounds are not set by one heavy row.
     __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kRegionFloats];
     const bool acc_full = acc_bad && *acc_bad == 0;
     if (acc_bad && !acc_full) acc_in = nullptr;
+    const bool sorted = srt_vertex != nullptr;   // uniform
     const int lane = threadIdx.x & 63;
     float *T = lds[threadIdx.x >> 6];
     uint32_t *stage = reinterpret_cast<uint32_t *>(T);
-    const uint32_t ntiles = (row_hi - row_lo + kWave - 1) / kWave;
-    const uint32_t tile = tile_for_wave(ntiles, interleave != 0);
+    const uint32_t ntiles = sorted ? (n_sorted + kWave - 1) / kWave : (row_hi - row_lo + kWave - 1) / kWave;
+    const uint32_t tile = tile_for_wave(ntiles, sorted || interleave != 0);
     if (tile >= ntiles) return;
-    const uint32_t v0 = row_lo + tile * kWave;
-    const uint32_t u = v0 + lane;
-    const bool valid = u < row_hi;
-    const uint32_t uc = valid ? u : row_hi - 1;
-    const uint32_t deg = g.rowptr[uc + 1] - g.rowptr[uc];
-    const bool mine = valid && deg < long_thresh;   // long rows belong to k_long_f1
-    const uint32_t rs = ep[uc];
-    const uint32_t re = (mine && !acc_full) ? ep[uc + 1] : rs;
-    const float f_deg = (float)deg;
-
-    const uint32_t c0 = __builtin_amdgcn_readfirstlane(rs);
-    const uint32_t vend = (v0 + kWave < row_hi) ? v0 + kWave : row_hi;
-    const uint32_t c1 = acc_full ? c0 : ep[vend];   // wave-uniform: end of the tile's last valid row
-    const bool staged = (c1 - c0) <= kStageCap;
+    const uint32_t v0 = row_lo + tile * kWave;   // natural order only
+    uint32_t u, uc, deg, rs, re;
+    bool mine, staged = false;
     uint32_t sbase = 0;
-    if (staged) sbase = stage_cols(ecol, c0, c1, stage, lane);
+    float f_w, f_nw;
+    if (sorted) {
+        const uint32_t slot = tile * kWave + lane;
+        const bool in = slot < n_sorted;
+        const uint4 meta = srt_meta[in ? slot : n_sorted - 1];
+        u = uc = srt_vertex[in ? slot : n_sorted - 1];
+        deg = meta.y - meta.x;
+        mine = in && deg < long_thresh;           // the list also holds rows this stage leaves to k_long_f1
+        rs = meta.x;
+        re = mine ? meta.y : rs;
+        f_w = (float)meta.z / ws;
+        f_nw = (float)meta.w / ws;
+    } else {
+        u = v0 + lane;
+        const bool valid = u < row_hi;
+        uc = valid ? u : row_hi - 1;
+        deg = g.rowptr[uc + 1] - g.rowptr[uc];
+        mine = valid && deg < long_thresh;        // long rows belong to k_long_f1
+        rs = ep[uc];
+        re = (mine && !acc_full) ? ep[uc + 1] : rs;
+        const uint32_t c0 = __builtin_amdgcn_readfirstlane(rs);
+        const uint32_t vend = (v0 + kWave < row_hi) ? v0 + kWave : row_hi;
+        const uint32_t c1 = acc_full ? c0 : ep[vend];   // wave-uniform: end of the tile's last valid row
+        staged = (c1 - c0) <= kStageCap;
+        if (staged) sbase = stage_cols(ecol, c0, c1, stage, lane);
+        f_w = (float)g.w[uc] / ws;
+        f_nw = (float)g.nw[uc] / ws;
+    }
+    const float f_deg = (float)deg;
     const float xself = xin[uc];
-    const float f_w = (float)g.w[uc] / ws;
-    const float f_nw = (float)g.nw[uc] / ws;
     float agg = acc_in ? acc_in[uc] : 0.0f;
     wave_lds_sync();
 
@@ -621,7 +640,7 @@ __global__ __launch_bounds__(kBlock) void k_stage_f1(
     wave_lds_sync();
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const uint32_t row = v0 + 16 * p + q;
+        const uint32_t row = __shfl(u, 16 * p + q);   // (= v0 + 16 p + q in natural order)
         const float *src = &T[(16 * p + q) * kOutPitch + 4 * c];
         const float4 o = make_float4(src[0], src[1], src[2], src[3]);
         if (__shfl((int)mine, 16 * p + q)) reinterpret_cast<float4 *>(fout)[(size_t)row * 4 + c] = o;
@@ -1893,8 +1912,8 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
                         bool interleave, hipStream_t stream, const float *acc4, const uint32_t *c4desc, const float *agg16,
                         bool mfma_agg, const EmitArgs &emit) {
     if (row_hi <= row_lo) return hipSuccess;
-    const bool sorted = so && so->n > 0 && sp.f == 16;
-    if (so && so->n == 0 && sp.f == 16) return hipSuccess;   // every row of the range is a long row
+    const bool sorted = so && so->n > 0;
+    if (so && so->n == 0) return hipSuccess;   // every row of the range is a long row
     const uint32_t ntiles = sorted ? (so->n + kWave - 1) / kWave : (row_hi - row_lo + kWave - 1) / kWave;
     const uint32_t per_xcd = (ntiles + 7) / 8;
     const uint32_t blocks_per_xcd = (per_xcd + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -1907,12 +1926,15 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
     case 0:
         hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, false>), grid, block, 0, stream, g, ws, in, out, P,
                            row_lo, row_hi, g.rowptr, g.col, nofloat, long_thresh, il, (const uint32_t *)nullptr,
-                           emit.spec, reinterpret_cast<c4row *>(emit.table), emit.counts);
+                           emit.spec, reinterpret_cast<c4row *>(emit.table), emit.counts, sorted ? so->vertex : nullptr,
+                           sorted ? reinterpret_cast<const uint4 *>(so->meta) : nullptr, sorted ? so->n : 0u);
         break;
     case 1:
         hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, true>), grid, block, 0, stream, g, ws, in, out, P,
                            row_lo, row_hi, g.rowptr, g.col, nofloat, long_thresh, il, (const uint32_t *)nullptr,
-                           (const uint32_t *)nullptr, (c4row *)nullptr, (unsigned long long *)nullptr);
+                           (const uint32_t *)nullptr, (c4row *)nullptr, (unsigned long long *)nullptr,
+                           sorted ? so->vertex : nullptr, sorted ? reinterpret_cast<const uint4 *>(so->meta) : nullptr,
+                           sorted ? so->n : 0u);
         break;
 #define GNNVC_LAUNCH_F16(N2_, N3_, SIG_, MF_, SRT_, LG_)                                              \
     hipLaunchKernelGGL((k_stage_f16<32, N2_, N3_, SIG_, 2, MF_, SRT_>), grid, block, 0, stream, g, ws, in4, out, \
@@ -2057,11 +2079,13 @@ hipError_t launch_stage0_blocked(const StagePlan &sp, const GraphDev &g, float w
     if (mfma)
         hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, true>), grid, block, 0, stream, g, ws, x, out,
                            params + sp.param_offset, row_lo, row_hi, ep, colb, acc_in, long_thresh, interleave ? 1 : 0,
-                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, (c4row *)nullptr, (unsigned long long *)nullptr);
+                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, (c4row *)nullptr, (unsigned long long *)nullptr,
+                           (const uint32_t *)nullptr, (const uint4 *)nullptr, 0u);
     else
         hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, false>), grid, block, 0, stream, g, ws, x, out,
                            params + sp.param_offset, row_lo, row_hi, ep, colb, acc_in, long_thresh, interleave ? 1 : 0,
-                           (const uint32_t *)nullptr, emit.spec, reinterpret_cast<c4row *>(emit.table), emit.counts);
+                           (const uint32_t *)nullptr, emit.spec, reinterpret_cast<c4row *>(emit.table), emit.counts,
+                           (const uint32_t *)nullptr, (const uint4 *)nullptr, 0u);
     return hipGetLastError();
 }
 
@@ -2133,11 +2157,13 @@ hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float
     if (mfma)
         hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, true>), grid, block, 0, stream, g, ws, x, out, params + sp.param_offset,
                            row_lo, row_hi, g.rowptr, g.col, acc, long_thresh, interleave ? 1 : 0, (const uint32_t *)bad,
-                           (const uint32_t *)nullptr, (c4row *)nullptr, (unsigned long long *)nullptr);
+                           (const uint32_t *)nullptr, (c4row *)nullptr, (unsigned long long *)nullptr,
+                           (const uint32_t *)nullptr, (const uint4 *)nullptr, 0u);
     else
         hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, false>), grid, block, 0, stream, g, ws, x, out, params + sp.param_offset,
                            row_lo, row_hi, g.rowptr, g.col, acc, long_thresh, interleave ? 1 : 0, (const uint32_t *)bad,
-                           emit.spec, reinterpret_cast<c4row *>(emit.table), emit.counts);
+                           emit.spec, reinterpret_cast<c4row *>(emit.table), emit.counts,
+                           (const uint32_t *)nullptr, (const uint4 *)nullptr, 0u);
     return hipGetLastError();
 }
 
