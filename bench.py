@@ -4,14 +4,16 @@
 One step = one full forward (3 fused stages: graph layer + dense layers) over
 the synthetic Erdős–Rényi graph with 10 M vertices / 100 M undirected edges
 (weights U[20,120]), device-resident in HBM when the timed region
-starts.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL),
-the graph 1-D vertex-partitioned, the N x 16 fp32 feature rows all-gathered over
-xGMI between stages; total work is fixed, so scaling is "strong".
+starts.  N = 1: the engine's whole forward (gnnvc_forward_device).  N > 1: one
+process per GPU (torch.distributed, backend nccl = RCCL), the graph 1-D
+vertex-partitioned (gnn-mwvc_amd/distributed.py), the feature rows all-gathered
+over xGMI between stages — only their live columns once a forward has shown which
+those are; total work is fixed, so scaling is "strong".
 
 Prints ONE JSON line on rank 0 (contract in the project brief):
   value      = undirected edges / second, whole job
-  roofline   = the dominant kernel's algorithmic HBM bytes / its mean launch
-               duration (HIP events on the launch stream, live) vs 8 TB/s
+  roofline   = the dominant stage's algorithmic HBM bytes / its duration (HIP
+               events on the launch stream, live) vs 8 TB/s, its kernels by name
   cpu_baseline = the oracle (bit-equal CPU port of the reference path) timed on
                this host on a bounded sample graph of the same distribution
 """
