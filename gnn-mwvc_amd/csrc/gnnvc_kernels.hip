@@ -1769,6 +1769,130 @@ __global__ __launch_bounds__(256) void k_unpack_exceptions(const uint32_t *__res
 }
 
 
+// ---- the two reduction rules that run the reference's small exact solver (include/mwvc_reductions.hpp:204-252,
+// include/small_solve.hpp:44-74), as exact per-vertex predicates.
+// minimum-weight vertex cover of k <= 8 nodes by enumeration: a subset is a cover when every node is in it or has
+// all of its neighbours in it; int32 sums like the reference's
+__device__ inline int32_t dev_small_mwvc(int k, const int32_t (&wt)[9], const uint32_t (&adj)[9]) {
+    int32_t best = 0x7FFFFFFF;
+    for (uint32_t sset = 0; sset < (1u << k); ++sset) {
+        bool ok = true;
+        int32_t cost = 0;
+        for (int j = 0; j < k; ++j) {
+            if (sset >> j & 1u) cost += wt[j];
+            else ok &= (sset & adj[j]) == adj[j];
+        }
+        if (ok && cost < best) best = cost;
+    }
+    return best;
+}
+
+__device__ inline bool dev_has_edge(const GraphDev &g, uint32_t a, uint32_t b) {   // b in adj(a)?  (ascending lists)
+    uint32_t lo = g.rowptr[a], hi = g.rowptr[a + 1];
+    const uint32_t end = hi;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (g.col[mid] < b) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo < end && g.col[lo] == b;
+}
+
+// cover weight of the subgraph induced by nodes[0..k) (edges to vertices outside the list do not exist for the solver)
+__device__ inline int32_t dev_induced_mwvc(const GraphDev &g, int k, const uint32_t (&nodes)[9]) {
+    int32_t wt[9];
+    uint32_t adj[9];
+    for (int i = 0; i < k; ++i) {
+        wt[i] = (int32_t)g.w[nodes[i]];
+        adj[i] = 0;
+    }
+    for (int i = 0; i < k; ++i)
+        for (int j = i + 1; j < k; ++j)
+            if (dev_has_edge(g, nodes[i], nodes[j])) {
+                adj[i] |= 1u << j;
+                adj[j] |= 1u << i;
+            }
+    return dev_small_mwvc(k, wt, adj);
+}
+
+// neighborhood_meta_reduction: D(u) <= 8 and W(u) >= NW(u) - MWVC(G[N(u)])
+__device__ inline bool dev_rule_neighborhood_meta(const GraphDev &g, uint32_t u) {
+    const uint32_t rs = g.rowptr[u], d = g.rowptr[u + 1] - rs;
+    if (d > 8u) return false;
+    uint32_t nodes[9];
+    uint32_t wmax = 0;
+    unsigned long long sum = 0;
+    for (uint32_t i = 0; i < d; ++i) {
+        nodes[i] = g.col[rs + i];
+        const uint32_t wv = g.w[nodes[i]];
+        wmax = wv > wmax ? wv : wmax;
+        sum += wv;
+    }
+    // NW(u) - MWVC = weight of the heaviest independent set of N(u): between the heaviest neighbour and NW(u).
+    // Only when W(u) falls in between does the cover have to be enumerated (weights below 2^31, like the solver's int32).
+    const uint32_t wu = g.w[u], nwu = g.nw[u];
+    if (sum == nwu && sum < (1ull << 31)) {   // (no wrap-around anywhere: the bounds below are the reference's arithmetic)
+        if (wu < wmax) return false;
+        if (wu >= nwu) return true;
+    }
+    const unsigned long long vc = (unsigned long long)(long long)dev_induced_mwvc(g, (int)d, nodes);
+    return (unsigned long long)wu >= (unsigned long long)nwu - vc;
+}
+
+// neighbor_meta_reduction, with neighborhood_difference's two peculiarities (gives up once 9 elements are written;
+// once adj(u) is exhausted the rest of adj(v) is copied without the "not u itself" test)
+__device__ inline bool dev_rule_neighbor_meta(const GraphDev &g, uint32_t u) {
+    const uint32_t us = g.rowptr[u], ue = g.rowptr[u + 1], du = ue - us, wu = g.w[u];
+    for (uint32_t e = us; e < ue; ++e) {
+        const uint32_t v = g.col[e];
+        const uint32_t vs = g.rowptr[v], ve = g.rowptr[v + 1], dv = ve - vs, wv = g.w[v];
+        if (wv <= wu || (dv > du && dv - du > 8u)) continue;
+        uint32_t tmp[9];
+        uint32_t t = 0, f1 = vs, f2 = us;
+        bool gave_up = false;
+        while (f1 != ve && f2 != ue) {
+            const uint32_t a = g.col[f1], b = g.col[f2];
+            if (a < b) {
+                if (a != u) {
+                    if (t < 9u) tmp[t] = a;
+                    ++t;
+                    if (t > 8u) {
+                        gave_up = true;
+                        break;
+                    }
+                }
+                ++f1;
+            } else if (b < a) {
+                ++f2;
+            } else {
+                ++f1;
+                ++f2;
+            }
+        }
+        if (!gave_up)
+            for (; f1 != ve; ++f1) {
+                if (t < 9u) tmp[t] = g.col[f1];
+                ++t;
+            }
+        if (t > 8u) continue;
+        uint32_t c = 0, wmax = 0;   // Tw arithmetic
+        for (uint32_t i = 0; i < t; ++i) {
+            const uint32_t wt = g.w[tmp[i]];
+            c += wt;
+            wmax = wt > wmax ? wt : wmax;
+        }
+        // c - MWVC = weight of the heaviest independent set of tmp, between its heaviest member and c: the
+        // enumeration is needed only when those bounds leave the comparison open (no wrap-around: sums below 2^31)
+        if (c < (1u << 30) && wu < (1u << 30)) {
+            if (wmax + wu > wv) continue;
+            if (c + wu <= wv) return true;
+        }
+        const uint32_t vc = (uint32_t)dev_induced_mwvc(g, (int)t, tmp);
+        if ((uint32_t)(c - vc + wu) <= wv) return true;
+    }
+    return false;
+}
+
 __global__ __launch_bounds__(256) void k_reduction_flags(GraphDev g, uint32_t max_degree,
                                                          uint8_t *__restrict__ flags) {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1777,7 +1901,8 @@ __global__ __launch_bounds__(256) void k_reduction_flags(GraphDev g, uint32_t ma
     uint32_t f = 0;
     if (d <= max_degree) {
         const uint32_t wu = g.w[u], nwu = g.nw[u];
-        f = 0x60u;
+        if (dev_rule_neighbor_meta(g, u)) f |= 32u;
+        if (dev_rule_neighborhood_meta(g, u)) f |= 64u;
         if (nwu <= wu) f |= 1u;
         if (d > 0) {
             const uint32_t last = g.col[rs + d - 1];

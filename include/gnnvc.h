@@ -212,9 +212,10 @@ int gnnvc_stage_input_ready(gnnvc_engine *e, int stage, const float *d_in, uint3
  * One vertex-parallel pass over the uploaded graph that evaluates which local rules of the
  * reference's reduce_graph (include/mwvc_reductions.hpp:335-380) would fire on each vertex as
  * the graph stands: flags[u] bit r for rule r of its switch — 0 neighborhood_reduction,
- * 1 twin_fold, 2 domination_reduction, 3 isolated_fold, 4 independent_fold (exact predicates);
- * bits 5, 6 (the two small-solver rules) are set for every vertex the loop looks at ("host
- * decides").  Vertices with D(u) > max_degree get 0 (reduce_graph skips them, :344; pass 20).
+ * 1 twin_fold, 2 domination_reduction, 3 isolated_fold, 4 independent_fold, 5 neighbor_meta_reduction,
+ * 6 neighborhood_meta_reduction — exact predicates, the last two with the covers of their <= 8-vertex
+ * subgraphs enumerated the way include/small_solve.hpp does.  Vertices with D(u) > max_degree get 0
+ * (reduce_graph skips them, :344; pass 20).
  * Needs ascending neighbour lists.  The host keeps applying reductions in the reference's own
  * stack order and merely skips clean vertices whose bit is 0. */
 int gnnvc_reduction_flags(gnnvc_engine *e, uint32_t max_degree, uint8_t *flags);

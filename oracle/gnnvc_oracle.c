@@ -303,6 +303,108 @@ static int is_twin(const oracle_graph *g, uint32_t u, uint32_t v) {
     return memcmp(g->col + g->rowptr[u], g->col + g->rowptr[v], (size_t)d * sizeof(uint32_t)) == 0;
 }
 
+/* small_mwvc_solver::solve (include/small_solve.hpp:44-74): minimum-weight vertex cover of a graph of k <= 16
+ * nodes by enumeration of all 2^k subsets — a subset is a cover when every node is in it or has all its
+ * neighbours in it; weights are summed as int32. */
+static int64_t small_mwvc(int k, const int32_t *wt, const uint16_t *adj) {
+    int32_t best = INT32_MAX;
+    for (uint32_t s = 0; s < (1u << k); s++) {
+        int ok = 1;
+        int32_t cost = 0;
+        for (int j = 0; j < k && ok; j++) {
+            if (s >> j & 1u) cost += wt[j];
+            else if ((s & adj[j]) != adj[j]) ok = 0;
+        }
+        if (ok && cost < best) best = cost;
+    }
+    return best;
+}
+
+static int has_edge(const oracle_graph *g, uint32_t a, uint32_t b) { /* b in adj(a)?  (ascending lists) */
+    uint64_t lo = g->rowptr[a], hi = g->rowptr[a + 1];
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) / 2;
+        if (g->col[mid] < b) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo < g->rowptr[a + 1] && g->col[lo] == b;
+}
+
+/* cover weight of the subgraph induced by `nodes` (the way the rules feed the solver, mwvc_reductions.hpp:212-218,
+ * 239-244: add_node in list order, add_edge for every stored neighbour — edges to nodes outside the list are
+ * dropped by add_edge, small_solve.hpp:33-42) */
+static int64_t induced_mwvc(const oracle_graph *g, int k, const uint32_t *nodes) {
+    int32_t wt[16];
+    uint16_t adj[16];
+    for (int i = 0; i < k; i++) {
+        wt[i] = (int32_t)g->w[nodes[i]];
+        adj[i] = 0;
+    }
+    for (int i = 0; i < k; i++)
+        for (int j = 0; j < k; j++)
+            if (i != j && nodes[i] != nodes[j] && has_edge(g, nodes[i], nodes[j])) adj[i] |= (uint16_t)(1u << j);
+    return small_mwvc(k, wt, adj);
+}
+
+#define ORACLE_MAX_SMALL 8 /* max_small_solve, mwvc_reductions.hpp:20 */
+
+/* neighborhood_meta_reduction (mwvc_reductions.hpp:234-252): D(u) <= 8 and W(u) >= NW(u) - MWVC(G[N(u)]) */
+static int rule_neighborhood_meta(const oracle_graph *g, uint32_t u) {
+    const uint32_t d = deg_of(g, u);
+    if (d > ORACLE_MAX_SMALL) return 0;
+    const uint64_t vc = (uint64_t)induced_mwvc(g, (int)d, g->col + g->rowptr[u]);
+    return (uint64_t)g->w[u] >= (uint64_t)g->nw[u] - vc;
+}
+
+/* neighborhood_difference(g, a, b, res, cutoff) (mwvc_reductions.hpp:179-202): the elements of adj(a) that are
+ * not in adj(b) and are not b itself — with the reference's two peculiarities: it gives up (returns) as soon as
+ * cutoff + 1 elements have been written, and once adj(b) is exhausted the rest of adj(a) is copied WITHOUT the
+ * "not b itself" test.  Returns the number of elements written (at most cap are stored). */
+static uint32_t neighborhood_difference(const oracle_graph *g, uint32_t a, uint32_t b, uint32_t *res, uint32_t cap,
+                                        uint32_t cutoff) {
+    const uint32_t *f1 = g->col + g->rowptr[a], *l1 = g->col + g->rowptr[a + 1];
+    const uint32_t *f2 = g->col + g->rowptr[b], *l2 = g->col + g->rowptr[b + 1];
+    uint32_t t = 0;
+    while (f1 != l1 && f2 != l2) {
+        if (*f1 < *f2) {
+            if (*f1 != b) {
+                if (t < cap) res[t] = *f1;
+                ++t;
+                if (t > cutoff) return t;
+            }
+            ++f1;
+        } else if (*f2 < *f1) {
+            ++f2;
+        } else {
+            ++f1;
+            ++f2;
+        }
+    }
+    for (; f1 != l1; ++f1) {
+        if (t < cap) res[t] = *f1;
+        ++t;
+    }
+    return t;
+}
+
+/* neighbor_meta_reduction (mwvc_reductions.hpp:204-232) */
+static int rule_neighbor_meta(const oracle_graph *g, uint32_t u) {
+    const uint32_t du = deg_of(g, u);
+    for (uint64_t e = g->rowptr[u]; e < g->rowptr[u + 1]; e++) {
+        const uint32_t v = g->col[e];
+        const uint32_t dv = deg_of(g, v);
+        if (g->w[v] <= g->w[u] || (dv > du && dv - du > ORACLE_MAX_SMALL)) continue;
+        uint32_t tmp[ORACLE_MAX_SMALL + 1];
+        const uint32_t k = neighborhood_difference(g, v, u, tmp, ORACLE_MAX_SMALL + 1, ORACLE_MAX_SMALL);
+        if (k > ORACLE_MAX_SMALL) continue;
+        uint32_t c = 0; /* Tw arithmetic */
+        for (uint32_t i = 0; i < k; i++) c += g->w[tmp[i]];
+        const uint32_t vc = (uint32_t)induced_mwvc(g, (int)k, tmp);
+        if ((uint32_t)(c - vc + g->w[u]) <= g->w[v]) return 1;
+    }
+    return 0;
+}
+
 /* reference src/GNN_VC.cpp:196 (`min(out(a, 0), 1.0f - out(a, 0))`, std::min returns its first
  * argument unless the second is smaller) and :213/:220 (`out(nodes[i], 0) > 0.5f`) */
 void oracle_score_keys(size_t n, const float *scores, float *keys, uint8_t *above_half) {
@@ -321,7 +423,8 @@ void oracle_reduction_flags(const oracle_graph *g, uint32_t max_degree, uint8_t 
         uint8_t f = 0;
         if (d <= max_degree) {
             const uint32_t *adj = g->col + g->rowptr[u];
-            f |= 0x60; /* the two small-solver rules: the host decides */
+            if (rule_neighbor_meta(g, u)) f |= 1u << 5;
+            if (rule_neighborhood_meta(g, u)) f |= 1u << 6;
             if (g->nw[u] <= g->w[u]) f |= 1u << 0;
             if (d > 0) {
                 const uint32_t last = adj[d - 1]; /* "first_neighbor = *(end(g[u]) - 1)" (mwvc_reductions.hpp:144) */

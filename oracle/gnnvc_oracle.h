@@ -101,16 +101,17 @@ int oracle_predict(const oracle_model *m, const oracle_graph *g,
                    uint32_t *out_width, int stop_after, int flags);
 
 /* Reduction-rule predicates on the unmutated graph, one byte per vertex:
- * bit r = "rule r of reduce_graph's switch would fire on u right now" for the five rules
- * that are pure graph predicates; the two rules that run the small exact solver are reported
- * as "maybe" (bit set) for every vertex the loop would look at.  Vertices with
+ * bit r = "rule r of reduce_graph's switch would fire on u right now", for all seven local rules —
+ * the two that run the small exact solver (include/small_solve.hpp) included: their covers are
+ * enumerated the way the solver does.  Vertices with
  * D(u) > max_degree get 0, like reduce_graph skips them (include/mwvc_reductions.hpp:344).
  *   bit 0 neighborhood_reduction   NW(u) <= W(u)                          (:131-139)
  *   bit 1 twin_fold                a twin among the neighbours of u's LAST neighbour (:141-160)
  *   bit 2 domination_reduction     some neighbour dominates u / is dominated (:162-177)
  *   bit 3 isolated_fold            every neighbour dominates u            (:270-284, reduction_graph.hpp:189-199)
  *   bit 4 independent_fold         W(u) >= NW(u) - min neighbour weight   (:246-268)
- *   bit 5 neighbor_meta_reduction, bit 6 neighborhood_meta_reduction: maybe (small solver)
+ *   bit 5 neighbor_meta_reduction      some heavier neighbour v: MWIS(G[N(v) \\ N[u]]) + W(u) <= W(v)  (:204-232, :179-202)
+ *   bit 6 neighborhood_meta_reduction  D(u) <= 8 and W(u) >= NW(u) - MWVC(G[N(u)])                  (:234-252)
  * Adjacency lists must be ascending (they are in the reference's graphs). */
 void oracle_reduction_flags(const oracle_graph *g, uint32_t max_degree, uint8_t *flags);
 

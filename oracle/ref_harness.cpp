@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "gnn_inference.hpp"
+#include "mwvc_reductions.hpp"
 
 namespace {
 reduction_graph<uint32_t, uint32_t> make_graph(uint32_t n, const uint64_t *rowptr, const uint32_t *col,
@@ -98,6 +99,34 @@ int ref_reduction_flags(uint32_t n, const uint64_t *rowptr, const uint32_t *col,
                 if (g.W(u) >= g.NW(u) - wmin) f |= 1u << 4;
             }
             if (g.is_isolated(u)) f |= 1u << 3;
+        }
+        flags[u] = f;
+    }
+    return 0;
+}
+
+// The two rules that run the small exact solver (include/mwvc_reductions.hpp:204-252), evaluated by calling the
+// REFERENCE's own rule functions — each on a fresh copy of the graph, because they apply the reduction when they
+// fire.  flags[u] bit 5 = neighbor_meta_reduction fires on u, bit 6 = neighborhood_meta_reduction fires on u, for the
+// vertices reduce_graph would look at (D(u) <= max_degree, :344).  O(n (n + m)): small graphs only.
+int ref_meta_flags(uint32_t n, const uint64_t *rowptr, const uint32_t *col, const uint32_t *w, uint32_t max_degree,
+                   uint8_t *flags) {
+    const auto g0 = make_graph(n, rowptr, col, w);
+    for (uint32_t u = 0; u < n; ++u) {
+        uint8_t f = 0;
+        if (g0.D(u) <= max_degree) {
+            {
+                auto g = g0;
+                vertex_cover<uint32_t, uint32_t> vc(n);
+                graph_search<uint32_t> gs(n);
+                if (neighbor_meta_reduction(g, vc, gs, u)) f |= 1u << 5;
+            }
+            {
+                auto g = g0;
+                vertex_cover<uint32_t, uint32_t> vc(n);
+                graph_search<uint32_t> gs(n);
+                if (neighborhood_meta_reduction(g, vc, gs, u)) f |= 1u << 6;
+            }
         }
         flags[u] = f;
     }

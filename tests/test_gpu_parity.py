@@ -976,9 +976,13 @@ def test_reduction_flags_match_oracle(engine):
     rule predicates (itself checked against the reference's own graph methods on CPU)."""
     for g in (gg.erdos_renyi(100000, 300000, 1), gg.erdos_renyi(50000, 60000, 2), gg.rmat(14, 4, 3),
               gg.hub_graph(20000, 30000, 2, 3000, seed=4),
+              gg.erdos_renyi(30000, 45000, 8, lo=1, hi=9),          # small weights: the small-solver rules fire often
+              gg.from_edge_list(8, [(0, 7), (1, 7), (7, 6), (6, 2), (6, 3), (2, 3), (4, 5)], [3, 4, 9, 2, 6, 6, 12, 5]),
               gg.from_edge_list(6, [(0, 2), (0, 3), (1, 2), (1, 3), (4, 5)], [10, 10, 20, 20, 7, 7])):
         engine.upload_graph(g)
         got = engine.reduction_flags(20)
         want = oracle_py.reduction_flags(g, 20)
-        assert np.array_equal(got, want)
+        assert np.array_equal(got, want), [int(((got ^ want) >> b & 1).sum()) for b in range(7)]
+        if g.n > 1000:
+            assert (got & 0x20).any() and (got & 0x40).any()      # all seven rules are exercised
     assert engine.reduction_flags(3).max() <= 0x7F
