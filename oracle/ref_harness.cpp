@@ -13,6 +13,8 @@
 
 #include "gnn_inference.hpp"
 #include "mwvc_reductions.hpp"
+#include "flagged_reduce.hpp"
+#include <chrono>
 
 namespace {
 reduction_graph<uint32_t, uint32_t> make_graph(uint32_t n, const uint64_t *rowptr, const uint32_t *col,
@@ -129,6 +131,89 @@ int ref_meta_flags(uint32_t n, const uint64_t *rowptr, const uint32_t *col, cons
             }
         }
         flags[u] = f;
+    }
+    return 0;
+}
+
+// reduce_graph (reference) against gnnvc_host::reduce_graph_flagged (host/flagged_reduce.hpp) on the same graph:
+// returns 0 when graph and cover come out identical; stats = {ms reference, ms flagged, tests skipped, tests run}.
+int ref_flagged_reduce_check(uint32_t n, const uint64_t *rowptr, const uint32_t *col, const uint32_t *w,
+                             const uint8_t *flags, double *stats) {
+    using clk = std::chrono::steady_clock;
+    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    auto ga = make_graph(n, rowptr, col, w);
+    auto gb = ga;
+    vertex_cover<uint32_t, uint32_t> va(n), vb(n);
+    graph_search<uint32_t> gsa(n);
+    const auto t0 = clk::now();
+    reduce_graph(ga, va, gsa);
+    const auto t1 = clk::now();
+    graph_search<uint32_t> gsb(n, 8);
+    gnnvc_host::flag_state<uint32_t> fs(std::vector<uint8_t>(flags, flags + n), gsb);
+    const auto t2 = clk::now();
+    gnnvc_host::reduce_graph_flagged(gb, vb, gsb, fs);
+    const auto t3 = clk::now();
+    stats[0] = ms(t0, t1);
+    stats[1] = ms(t2, t3);
+    stats[2] = (double)fs.skipped;
+    stats[3] = (double)fs.tested;
+    if (va.cost != vb.cost || va.S.size() != vb.S.size() || ga.size() != gb.size()) return 1;
+    if (va.r1 != vb.r1 || va.r2 != vb.r2 || va.r3 != vb.r3 || va.r4 != vb.r4 || va.r5 != vb.r5 || va.r6 != vb.r6 ||
+        va.r7 != vb.r7)
+        return 2;
+    for (size_t i = 0; i < va.S.size(); ++i)
+        if (va.S[i] != vb.S[i]) return 3;
+    for (uint32_t u = 0; u < ga.size(); ++u) {
+        if (ga.is_active(u) != gb.is_active(u)) return 4;
+        if (!ga.is_active(u)) continue;
+        if (ga.W(u) != gb.W(u) || ga.NW(u) != gb.NW(u)) return 5;
+        if (!std::equal(ga.begin(u), ga.end(u), gb.begin(u), gb.end(u))) return 6;
+    }
+    return 0;
+}
+
+// debugging aid: the flagged loop, but every skipped test is also run on a copy — reports the first skip that
+// would have fired: out = {vertex, rule, tests so far}
+int ref_flagged_debug(uint32_t n, const uint64_t *rowptr, const uint32_t *col, const uint32_t *w, const uint8_t *flags,
+                      uint32_t *out) {
+    auto g = make_graph(n, rowptr, col, w);
+    vertex_cover<uint32_t, uint32_t> vc(n);
+    graph_search<uint32_t> gs(n, 8);
+    gnnvc_host::flag_state<uint32_t> fs(std::vector<uint8_t>(flags, flags + n), gs);
+    size_t rule = 0, steps = 0;
+    while (rule < 7) {
+        if (gs.search[rule].empty()) { ++rule; continue; }
+        const uint32_t u = gs.pop_search(rule);
+        if (u >= g.size() || !g.is_active(u) || g.D(u) > 20) continue;
+        ++steps;
+        auto run = [&](reduction_graph<uint32_t, uint32_t> &gg, vertex_cover<uint32_t, uint32_t> &vv, graph_search<uint32_t> &ss) {
+            switch ((reduction_rules)rule) {
+            case reduction_rules::neighborhood_reduction: return neighborhood_reduction(gg, vv, ss, u);
+            case reduction_rules::twin_fold: return twin_fold(gg, vv, ss, u);
+            case reduction_rules::domination_reduction: return domination_reduction(gg, vv, ss, u);
+            case reduction_rules::isolated_fold: return isolated_fold(gg, vv, ss, u);
+            case reduction_rules::independent_fold: return independent_fold(gg, vv, ss, u);
+            case reduction_rules::neighbor_meta_reduction: return neighbor_meta_reduction(gg, vv, ss, u);
+            case reduction_rules::neighborhood_meta_reduction: return neighborhood_meta_reduction(gg, vv, ss, u);
+            default: return false;
+            }
+        };
+        if (fs.can_skip(u, rule)) {
+            auto g2 = g;
+            auto v2 = vc;
+            auto s2 = gs;
+            if (run(g2, v2, s2)) {
+                out[0] = u;
+                out[1] = (uint32_t)rule;
+                out[2] = (uint32_t)steps;
+                return 1;
+            }
+            continue;
+        }
+        if (run(g, vc, gs)) {
+            fs.drain(g, gs);
+            rule = 0;
+        }
     }
     return 0;
 }

@@ -127,6 +127,30 @@ def test_reduction_predicates_match_reference_methods(ref_layers, maker):
     assert np.array_equal(got & 0x60, meta), np.flatnonzero((got & 0x60) != meta)[:10]
 
 
+@pytest.mark.parametrize("maker", [
+    lambda: gg.erdos_renyi(3000, 6000, 5),
+    lambda: gg.erdos_renyi(20000, 30000, 6),
+    lambda: gg.erdos_renyi(30000, 90000, 7),
+    lambda: gg.rmat(13, 4, 3),                             # hubs: the marks budget drops the flags
+    lambda: gg.erdos_renyi(1500, 2200, 8, lo=1, hi=9),
+    lambda: gg.from_edge_list(6, [(0, 2), (0, 3), (1, 2), (1, 3), (4, 5)], [10, 10, 20, 20, 7, 7]),
+])
+def test_flagged_reduce_is_the_reference_reduce(ref_layers, maker):
+    """host/flagged_reduce.hpp (the consumer of the device flags: skips a first test of a vertex whose flags
+    say no rule applies and whose 2-hop neighbourhood is untouched) against the reference's own reduce_graph on
+    copies of the same graph: identical reduced graph, cover marks and offset (rc 0)."""
+    g = maker()
+    L = ref_layers
+    L.ref_flagged_reduce_check.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    flags = oracle_py.reduction_flags(g, 20)
+    rowptr = np.ascontiguousarray(g.rowptr, dtype=np.uint64)
+    stats = np.zeros(4)
+    rc = L.ref_flagged_reduce_check(g.n, rowptr.ctypes.data, g.col.ctypes.data, g.w.ctypes.data,
+                                    flags.ctypes.data, stats.ctypes.data)
+    assert rc == 0, (rc, stats)
+    assert stats[3] > 0
+
+
 def _run_cli(binary, graph_path, out_path):
     r = subprocess.run([str(binary), str(graph_path), str(out_path), "0", "-1", "0"],
                        capture_output=True, text=True, timeout=600)
