@@ -127,7 +127,7 @@ struct gnnvc_engine {
     // compact-table plan of the 16-wide stages (built like the LDS-table plan, on the graph's second forward)
     int opt_compact = 1;            // 0 = off, 1 = when it applies, 2 = also on skewed graphs
     bool c4_ready = false, c4_tried = false;
-    uint32_t c4_rows = 0, c4_chunks = 0, c4_steps_total = 0, c4_block = 0;
+    uint32_t c4_rows = 0, c4_chunks = 0, c4_steps_total = 0, c4_block = 0, c4_last_entry = 0;
     DevBuf<uint32_t> c4_entries, c4_segcnt, c4_stepptr, c4_stepcnt, c4_desc;
     DevBuf<uint4> c4_steps;
     DevBuf<float> c4_table, c4_acc, c4_agg16;
@@ -558,11 +558,14 @@ int build_compact(gnnvc_engine *e, uint32_t base = 0, uint32_t end = 0xFFFFFFFFu
     if (g.n < e->opt_blocked_min_n || g.nnz == 0 || g.nnz >= (1ull << 31)) return GNNVC_OK;
     if (e->opt_compact < 2 && (e->sorted_wanted || e->n_long > 0)) return GNNVC_OK;
     if (e->n_long > 0) return GNNVC_OK;   // (the long-row kernels write their rows themselves)
-    const uint32_t max_rows = gnnvc::compact_max_rows();
+    // a chunk = 16 slices (one per wave of the workgroup that sums it); the plan is laid out per slice
+    const uint32_t max_rows = gnnvc::compact_max_rows(), nsl = gnnvc::compact_slices();
     uint32_t chunks = (span + max_rows - 1) / max_rows;
     chunks = (chunks + 255u) / 256u * 256u;
-    const uint32_t rows = (span + chunks - 1) / chunks;
+    uint32_t rows = (span + chunks - 1) / chunks;
+    rows = (rows + nsl - 1) / nsl * nsl;
     chunks = (span + rows - 1) / rows;
+    const uint32_t slice_rows = rows / nsl, slices = chunks * nsl;
     uint64_t range_nnz = g.nnz;
     if (span != g.n) {   // the range's share of the entries
         uint32_t rp[2] = {0, 0};
@@ -572,43 +575,48 @@ int build_compact(gnnvc_engine *e, uint32_t base = 0, uint32_t end = 0xFFFFFFFFu
         range_nnz = rp[1] - rp[0];
         if (range_nnz == 0) return GNNVC_OK;
     }
-    // column blocks: wide enough that a chunk brings just under one 2048-entry step per block (1950 on average:
-    // a segment of 2049 costs a second, nearly empty step), but at most 160 K vertices = 2.5 MiB of table, which
-    // still sits in an XCD's 4 MiB L2 while its 32 CUs sweep it
+    // column blocks: wide enough that a slice brings about 160 entries per block (one 256-entry step with room for
+    // the spread: a segment of 257 costs a second step that the other waves of the workgroup wait for), but at
+    // most 160 K vertices = 2.5 MiB of table, which still sits in an XCD's 4 MiB L2 while its 32 CUs sweep it
     uint32_t bc = gnnvc::compact_block();
     {
-        const double per_chunk = (double)range_nnz / chunks;
-        const double want = 1950.0 * g.n / std::max(per_chunk, 1.0);
+        const double per_slice = (double)range_nnz / slices;
+        const double want = 160.0 * g.n / std::max(per_slice, 1.0);
         bc = (uint32_t)std::min(160.0 * 1024, std::max(32.0 * 1024, want)) / 1024u * 1024u;
     }
     const uint32_t nblocks = (g.n + bc - 1) / bc;
     if (nblocks > 4096) return GNNVC_OK;
+    // every (slice, block) segment starts at a multiple of 4 entries: up to 3 pad entries per segment
+    const uint32_t slack = 3u * nblocks + 4u;
+    const uint64_t entry_cap = g.nnz + (uint64_t)slack * slices + 8;
+    if (entry_cap >= (1ull << 31)) return GNNVC_OK;
     HIP_TRY(e, e->c4_desc.reserve(24));   // 8 words per consumer stage (1, 2), word 16 = build flag
     HIP_TRY(e, e->c4_counts.reserve(16));
     HIP_TRY(e, e->c4_emit_counts.reserve(gnnvc::kEmitCounters));
-    HIP_TRY(e, e->c4_segcnt.reserve((size_t)chunks * nblocks));
-    HIP_TRY(e, e->c4_stepcnt.reserve(chunks));
-    HIP_TRY(e, e->c4_stepptr.reserve((size_t)chunks + 1));
-    HIP_TRY(e, e->pin_small.reserve((size_t)chunks + 2));
+    HIP_TRY(e, e->c4_segcnt.reserve((size_t)slices * nblocks));
+    HIP_TRY(e, e->c4_stepcnt.reserve(slices));
+    HIP_TRY(e, e->c4_stepptr.reserve((size_t)slices + 2));
+    HIP_TRY(e, e->pin_small.reserve((size_t)slices + 3));
     uint32_t *flag = e->c4_desc.p + 16;
     HIP_TRY(e, hipMemsetAsync(e->c4_desc.p, 0, 24 * sizeof(uint32_t), e->stream));
-    HIP_TRY(e, gnnvc::lds_table_count(g, rows, chunks, nblocks, bc, e->c4_segcnt.p, flag, e->stream, base, end));
-    HIP_TRY(e, gnnvc::lds_table_steps(g, rows, chunks, nblocks, e->c4_segcnt.p, nullptr, e->c4_stepcnt.p, nullptr, false, e->stream,
-                                      base, end));
-    HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, e->c4_stepcnt.p, chunks * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(e, hipMemcpyAsync(e->pin_small.p + chunks, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, gnnvc::lds_table_count(g, slice_rows, slices, nblocks, bc, e->c4_segcnt.p, flag, e->stream, base, end));
+    HIP_TRY(e, gnnvc::lds_table_steps(g, slice_rows, slices, nblocks, e->c4_segcnt.p, nullptr, e->c4_stepcnt.p, nullptr, false, e->stream,
+                                      base, end, gnnvc::compact_step(), slack));
+    HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, e->c4_stepcnt.p, slices * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->pin_small.p + slices, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
-    if (e->pin_small.p[chunks]) return GNNVC_OK;   // an unsorted row: regrouping by block would change the order of its sum
-    std::vector<uint32_t> ptr((size_t)chunks + 1, 0);
+    if (e->pin_small.p[slices]) return GNNVC_OK;   // an unsorted row: regrouping by block would change the order of its sum
+    std::vector<uint32_t> ptr((size_t)slices + 2, 0);
     uint64_t total = 0;
-    for (uint32_t c = 0; c < chunks; ++c) {
+    for (uint32_t c = 0; c < slices; ++c) {
         ptr[c] = (uint32_t)total;
         total += e->pin_small.p[c];
     }
     if (total + 8 >= (1ull << 31)) return GNNVC_OK;
-    ptr[chunks] = (uint32_t)total;
+    ptr[slices] = (uint32_t)total;
+    ptr[slices + 1] = (uint32_t)total;   // slice `slices`: the empty one idle waves walk
     HIP_TRY(e, e->c4_steps.reserve(total + 8));
-    HIP_TRY(e, e->c4_entries.reserve(g.nnz));
+    HIP_TRY(e, e->c4_entries.reserve(entry_cap));
     HIP_TRY(e, e->c4_table.reserve(((size_t)g.n + 1) * 4));
     HIP_TRY(e, e->c4_acc.reserve((size_t)g.n * 4));
     e->c4_dirty_cap = g.n;   // rows recomputed from full rows (every row could be one: the dense-only stage kernel never gathers)
@@ -617,11 +625,13 @@ int build_compact(gnnvc_engine *e, uint32_t base = 0, uint32_t end = 0xFFFFFFFFu
     std::memcpy(e->pin_small.p, ptr.data(), ptr.size() * sizeof(uint32_t));
     HIP_TRY(e, hipMemcpyAsync(e->c4_stepptr.p, e->pin_small.p, ptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipMemsetAsync(e->c4_steps.p + total, 0, 8 * sizeof(uint4), e->stream));
-    HIP_TRY(e, gnnvc::lds_table_steps(g, rows, chunks, nblocks, e->c4_segcnt.p, e->c4_stepptr.p, nullptr, e->c4_steps.p, true, e->stream,
-                                      base, end));
-    HIP_TRY(e, gnnvc::lds_table_scatter(g, rows, chunks, nblocks, bc, e->c4_segcnt.p, e->c4_entries.p, e->stream,
-                                        gnnvc::compact_shift(), base, end));
+    HIP_TRY(e, hipMemsetAsync(e->c4_entries.p, 0, entry_cap * sizeof(uint32_t), e->stream));   // (pad slots are read, never used)
+    HIP_TRY(e, gnnvc::lds_table_steps(g, slice_rows, slices, nblocks, e->c4_segcnt.p, e->c4_stepptr.p, nullptr, e->c4_steps.p, true, e->stream,
+                                      base, end, gnnvc::compact_step(), slack));
+    HIP_TRY(e, gnnvc::lds_table_scatter(g, slice_rows, slices, nblocks, bc, e->c4_segcnt.p, e->c4_entries.p, e->stream,
+                                        gnnvc::compact_shift(), base, end, slack));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
+    e->c4_last_entry = (uint32_t)((entry_cap - 4) & ~3ull);
     e->c4_block = bc;
     e->c4_base = base;
     e->c4_end = end;
@@ -708,7 +718,7 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
                     HIP_TRY(e, gnnvc::launch_compact_gather(e->g, in, e->c4_counts.p, 1, desc, e->c4_table.p, e->c4_acc.p, lo, hi,
                                                             e->c4_rows, e->c4_stepptr.p, e->c4_steps.p, e->c4_entries.p,
                                                             e->c4_dirty.p, e->c4_dirty_cap, e->c4_agg16.p, e->stream, e->c4_block,
-                                                            e->c4_base, e->c4_end, /*what=*/2));
+                                                            e->c4_base, e->c4_end, e->c4_last_entry, /*what=*/2));
                     acc4 = e->c4_acc.p;
                     c4desc = desc;
                 }
@@ -722,7 +732,7 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
                                                         desc, e->c4_table.p, e->c4_acc.p, lo, hi,
                                                         e->c4_rows, e->c4_stepptr.p, e->c4_steps.p, e->c4_entries.p,
                                                         e->c4_dirty.p, e->c4_dirty_cap, e->c4_agg16.p, e->stream, e->c4_block,
-                                                        e->c4_base, e->c4_end));
+                                                        e->c4_base, e->c4_end, e->c4_last_entry));
                 acc4 = e->c4_acc.p;
                 c4desc = desc;
                 if (may_emit) {   // and this stage's own (aggregate-only, VALU) kernel produces for the next one
@@ -1231,7 +1241,7 @@ int gnnvc_stage_input_ready(gnnvc_engine *e, int stage, const float *d_in, uint3
     HIP_TRY(e, gnnvc::launch_compact_gather(e->g, d_in, e->c4_counts.p, 1, desc, e->c4_table.p, e->c4_acc.p, e->c4_base, e->c4_end,
                                             e->c4_rows, e->c4_stepptr.p, e->c4_steps.p, e->c4_entries.p, e->c4_dirty.p,
                                             e->c4_dirty_cap, e->c4_agg16.p, e->stream, e->c4_block, e->c4_base, e->c4_end,
-                                            /*what=*/1));
+                                            e->c4_last_entry, /*what=*/1));
     e->c4_prepared_stage = stage;
     e->c4_prepared_in = d_in;
     return GNNVC_OK;

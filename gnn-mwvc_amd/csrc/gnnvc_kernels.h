@@ -112,10 +112,11 @@ hipError_t lds_table_count(const GraphDev &g, uint32_t rows_per_chunk, uint32_t 
                            uint32_t row_end = 0xFFFFFFFFu);
 hipError_t lds_table_steps(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, const uint32_t *seg_cnt,
                            const uint32_t *step_ptr, uint32_t *step_count, void *steps, bool write, hipStream_t stream,
-                           uint32_t row_base = 0, uint32_t row_end = 0xFFFFFFFFu);
+                           uint32_t row_base = 0, uint32_t row_end = 0xFFFFFFFFu, uint32_t cap = 0 /* entries per step, 0 = 2048 */,
+                           uint32_t slack = 0 /* != 0: segments start at multiples of 4, chunk c shifted by c * slack */);
 hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t block_cols,
                              const uint32_t *seg_cnt, uint32_t *entries, hipStream_t stream, uint32_t shift = 17,
-                             uint32_t row_base = 0, uint32_t row_end = 0xFFFFFFFFu);
+                             uint32_t row_base = 0, uint32_t row_end = 0xFFFFFFFFu, uint32_t slack = 0);
 hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *x,
                                    float *out, uint32_t row_lo, uint32_t row_hi, uint32_t rows_per_chunk,
                                    const uint32_t *step_ptr, const void *steps, const uint32_t *entries, const uint8_t *wbyte,
@@ -123,10 +124,13 @@ hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float
                                    hipStream_t stream, const EmitArgs &emit = EmitArgs());
 
 // compact-table plan of the 16-wide stages (see the k_c4_* kernels); the step layout is built with the
-// lds_table_* functions at compact_block() columns per block
+// lds_table_* functions per SLICE (rows_per_chunk / compact_slices() rows), compact_step() entries per step,
+// segments aligned to 4 entries (slack != 0)
 uint32_t compact_max_rows();
 uint32_t compact_block();
 uint32_t compact_shift();
+uint32_t compact_slices();   // a chunk = this many row slices (one per wave); the plan is built per slice
+uint32_t compact_step();     // entries per step
 // counts: per-column non-zero counts of `in` — 16 counters from column_counts() (count_slots = 1) or the
 // producer's kEmitCounters (count_slots = 64: 17 counters per slot, the 17th = rows seen; the table may then
 // already hold the rows' compact form for the columns in desc, see EmitArgs)
@@ -134,7 +138,8 @@ hipError_t launch_compact_gather(const GraphDev &g, const float *in, const unsig
                                  float *table, float *acc4, uint32_t row_lo, uint32_t row_hi, uint32_t rows_per_chunk,
                                  const uint32_t *step_ptr, const void *steps, const uint32_t *entries, uint32_t *dirty_rows,
                                  uint32_t dirty_cap, float *agg16, hipStream_t stream, uint32_t block_cols,
-                                 uint32_t plan_base, uint32_t plan_end, int what = 3 /* 1 = prepare, 2 = sums, 3 = both */);
+                                 uint32_t plan_base, uint32_t plan_end, uint32_t last_entry /* last index of entries[] a 16-byte read may start at */,
+                                 int what = 3 /* 1 = prepare, 2 = sums, 3 = both */);
 
 hipError_t score_keys(const float *scores, size_t n, float *keys, uint8_t *above_half, hipStream_t stream);
 

@@ -946,26 +946,38 @@ __global__ __launch_bounds__(1024) void k_lt_count(GraphDev g, uint32_t rows_per
     if (__any(unsorted) && (tid & 63) == 0) atomicOr(bad, 2u);
 }
 
+// Where the regrouped entries of chunk c start.  slack == 0: at the chunk's CSR offset (the regrouped array is a
+// permutation of col[]).  slack != 0 (compact-table plan: a lane reads 16 bytes = 4 entries at once): every
+// (chunk, block) segment starts at a multiple of 4, and chunk c is shifted by c * slack, slack >= 3 * nblocks + 4
+// covering the padding of all chunks before it.
+__device__ __forceinline__ uint32_t lt_chunk_first(const GraphDev &g, uint32_t c, uint32_t rows_per_chunk, uint32_t row_base,
+                                                   uint32_t row_end, uint32_t slack) {
+    const uint32_t r0 = (uint32_t)min((uint64_t)row_end, (uint64_t)row_base + (uint64_t)c * rows_per_chunk);
+    const uint32_t first = g.rowptr[r0];
+    return slack ? (first + c * slack + 3u) & ~3u : first;
+}
+
 // One thread per chunk.  write == 0: steps[c] = number of steps of chunk c (padded to a multiple of 4).
 // write != 0: the descriptors {block, first entry, count, 0} at step_ptr[c]...
 __global__ __launch_bounds__(256) void k_lt_steps(GraphDev g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks,
                                                   const uint32_t *__restrict__ seg_cnt, const uint32_t *__restrict__ step_ptr,
                                                   uint32_t *__restrict__ step_count, uint4 *__restrict__ steps, int write,
-                                                  uint32_t row_base, uint32_t row_end) {
+                                                  uint32_t row_base, uint32_t row_end, uint32_t cap, uint32_t slack) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
     const uint32_t *cnt = seg_cnt + (size_t)c * nblocks;
-    uint32_t first = g.rowptr[min((uint64_t)row_end, (uint64_t)row_base + (uint64_t)c * rows_per_chunk)];   // a chunk's entries are a CSR range
+    uint32_t first = lt_chunk_first(g, c, rows_per_chunk, row_base, row_end, slack);   // a chunk's entries are a CSR range
     uint32_t pos = write ? step_ptr[c] : 0, made = 0;
     for (uint32_t b = 0; b < nblocks; ++b) {
         uint32_t left = cnt[b];
         while (left) {
-            const uint32_t take = left < kLtStep ? left : kLtStep;
+            const uint32_t take = left < cap ? left : cap;
             if (write) steps[pos + made] = make_uint4(b, first, take, 0u);
             ++made;
             first += take;
             left -= take;
         }
+        if (slack) first = (first + 3u) & ~3u;
     }
     const uint32_t padded = made ? (made + 3u) / 4u * 4u : 4u;
     if (write)
@@ -978,15 +990,17 @@ __global__ __launch_bounds__(256) void k_lt_steps(GraphDev g, uint32_t rows_per_
 // entries of one block are written as one adjacent run, in order (the order among rows is free)
 __global__ __launch_bounds__(1024) void k_lt_scatter(GraphDev g, uint32_t rows_per_chunk, uint32_t nblocks, uint32_t block_cols,
                                                      uint32_t shift, const uint32_t *__restrict__ seg_cnt,
-                                                     uint32_t *__restrict__ entries, uint32_t row_base, uint32_t row_end) {
+                                                     uint32_t *__restrict__ entries, uint32_t row_base, uint32_t row_end,
+                                                     uint32_t slack) {
     __shared__ uint32_t cursor[4096];
     const uint32_t c = blockIdx.x, tid = threadIdx.x;
     const uint32_t r0 = min(row_end, row_base + c * rows_per_chunk), r1 = min(row_end, r0 + rows_per_chunk);
     if (tid == 0) {   // exclusive scan of <= 4096 counts: a few microseconds, once per graph
-        uint32_t run = g.rowptr[r0];
+        uint32_t run = lt_chunk_first(g, c, rows_per_chunk, row_base, row_end, slack);
         for (uint32_t b = 0; b < nblocks; ++b) {
             cursor[b] = run;
             run += seg_cnt[(size_t)c * nblocks + b];
+            if (slack) run = (run + 3u) & ~3u;
         }
     }
     __syncthreads();
@@ -1116,10 +1130,10 @@ __global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ st
 // ReLU that ends a stage most feature columns are zero on many graphs (metric graph: two columns dense,
 // two at ~10 %, a handful of stray non-zeros elsewhere).  When at most FOUR columns carry (nearly) all
 // non-zeros of this forward's input, the neighbours' rows are read from a COMPACT table — 4 floats per
-// vertex — with the blocked traversal of the LDS-table plan: rows in chunks (one 1024-thread workgroup,
-// 4 sums per row in LDS), columns in blocks of 131072 vertices = 2 MiB of the table, the workgroups of a
-// 256-wide persistent grid sweeping the blocks in the same order at the same pace, so that the block being
-// read stays in every XCD's L2 and a gather is an L2 hit (~105 G rows/s) instead of a fabric request.
+// vertex — with a blocked traversal: rows in chunks of 16 SLICES (one 1024-thread workgroup, one slice per
+// wave, 4 sums per row in the wave's part of LDS), columns in blocks of ~128 K vertices = 2 MiB of the
+// table, the workgroups of a 256-wide persistent grid sweeping the blocks in the same order at the same pace,
+// so that the block being read stays in every XCD's L2 and a gather is an L2 hit instead of a fabric request.
 //   k_c4_choose   picks the four fullest columns from the per-column counts (device side, no host sync)
 //   k_c4_compact  writes the table; a vertex with a non-zero in any OTHER column gets the sign bit of
 //                 its first value set (inputs are >= 0 after ReLU — checked — so the bit is free)
@@ -1129,9 +1143,15 @@ __global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ st
 //                 exactly what the plain gather produces; then the dense layers as always.
 // desc words: [0] ok (1 = the plan applies to this input), [1..4] the chosen columns (ascending).
 constexpr uint32_t kC4Block = 131072;     // default vertices per column block: 2 MiB of compact rows (the engine sizes the
-                                          // blocks so that a chunk has just under one step of entries per block)
+                                          // blocks so that a slice has about 160 entries per block: one step, 40 lanes busy)
 constexpr uint32_t kC4Shift = 18;         // entries: row_local << 18 | col_local (blocks of up to 262144 vertices)
-constexpr uint32_t kC4MaxRows = 7400;     // rows per chunk: 16 B * rows + 32 KiB values + 8 KiB entries + dirty bits <= 160 KiB
+constexpr uint32_t kC4Slices = 16;        // slices per chunk = waves per workgroup
+constexpr uint32_t kC4SliceRows = 632;    // rows per slice: 16 x (16 B x rows + dirty bits) <= 160 KiB
+constexpr uint32_t kC4MaxRows = kC4Slices * kC4SliceRows;
+constexpr uint32_t kC4Step = 256;         // entries per step: four consecutive ones per lane
+constexpr uint32_t kC4DirtyWords = (kC4SliceRows + 31) / 32;
+constexpr uint32_t kC4NoRow = (1u << (32 - kC4Shift)) - 1u;   // row field of a slot past the step's end
+static_assert(kC4SliceRows < kC4NoRow - 1u, "row field too narrow");
 
 // desc words: [0] ok, [1..4] the chosen columns (ascending), [5] dirty-row counter, [6] the table still has to be
 // written (k_c4_compact) — 0 when the producing stage kernel already wrote it for exactly these columns.
@@ -1224,111 +1244,198 @@ __global__ __launch_bounds__(256) void k_c4_compact(const float4 *__restrict__ f
     if (__any(negative) && (threadIdx.x & 63) == 0) atomicAnd(&desc[0], 0u);
 }
 
+// whole-wave shifts by one lane (DPP wave_shl / wave_shr, zero shifted in)
+__device__ __forceinline__ uint32_t lane_next(uint32_t x) {   // lane i <- lane i + 1
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t lane_prev(uint32_t x) {   // lane i <- lane i - 1
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xF, 0xF, true);
+}
+__device__ __forceinline__ f32x4 lane_next(f32x4 v) {
+    f32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = __uint_as_float(lane_next(__float_as_uint(v[i])));
+    return r;
+}
+// c ? v : +0.0f — every value and sum here is >= +0 (checked inputs, sums from +0), so x + 0 == x bit for bit
+__device__ __forceinline__ f32x4 c4_sel(bool c, f32x4 v) {
+    return f32x4{c ? v[0] : 0.0f, c ? v[1] : 0.0f, c ? v[2] : 0.0f, c ? v[3] : 0.0f};
+}
+
+// The sums.  A WAVE owns a slice of rows: its sums live in its own part of LDS and it walks its own entry
+// stream, regrouped per (slice, column block) into steps of <= 256 entries (a row's entries of one block are
+// adjacent and in order; a segment starts at a multiple of 4).  A lane takes FOUR CONSECUTIVE entries of the
+// step with one 16-byte load, gathers their four table rows, and the lane that gathers a row is the lane that
+// adds it: runs of the same row are folded lane-locally, a run that reaches the lane's last entry goes on
+// with the next lane's entries (one whole-wave DPP shift of its 4 rows and 4 values; more shifts only for
+// runs longer than a lane), and every row written in a step is written by exactly one lane — so the four LDS
+// reads of a lane are issued together.  LDS operations of one wave execute in order, hence no barrier is needed
+// for the sums; the one barrier per column block only keeps the 16 waves of a workgroup (and, since all
+// workgroups do the same work, the chip) in the same block, which is what keeps the block in L2.
+// Loads are unconditional and in the same order on every trip so that the hardware counters are waited on
+// exactly: entries two steps ahead, gathers one step ahead.
 __global__ __launch_bounds__(1024) void k_c4_agg(const uint32_t *__restrict__ step_ptr, const uint4 *__restrict__ steps,
                                                  const uint32_t *__restrict__ entries, const f32x4 *__restrict__ table,
-                                                 f32x4 *__restrict__ agg, uint32_t n, uint32_t rows_per_chunk, uint32_t chunk0,
-                                                 uint32_t chunk1, uint32_t last_entry, uint32_t *__restrict__ desc,
+                                                 f32x4 *__restrict__ agg, uint32_t n, uint32_t slice_rows, uint32_t slice0,
+                                                 uint32_t slice1, uint32_t nslices, uint32_t last_entry, uint32_t *__restrict__ desc,
                                                  uint32_t *__restrict__ dirty_rows, uint32_t dirty_cap, uint32_t block_cols,
-                                                 uint32_t row_base, uint32_t row_end) {
+                                                 uint32_t nblocks, uint32_t row_base, uint32_t row_end) {
     extern __shared__ __attribute__((aligned(16))) unsigned char c4_smem[];
     if (!desc[0]) return;                                               // block-uniform
-    f32x4 *acc = reinterpret_cast<f32x4 *>(c4_smem);                    // rows_per_chunk (<= kC4MaxRows) x 4 sums
-    f32x4 *vbuf = acc + kC4MaxRows;                                     // the step's gathered rows
-    uint32_t *ebuf = reinterpret_cast<uint32_t *>(vbuf + kLtStep);      // the step's entries
-    uint32_t *dirty = ebuf + kLtStep;                                   // one bit per row of the chunk
-    const uint32_t tid = threadIdx.x;
-    for (uint32_t chunk = chunk0 + blockIdx.x; chunk < chunk1; chunk += gridDim.x) {
-        const uint32_t row0 = row_base + chunk * rows_per_chunk;   // chunks are numbered within the plan's row range
-        __syncthreads();                                                // the previous chunk's sums are written out
-        for (uint32_t i = tid; i < rows_per_chunk; i += 1024) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        for (uint32_t i = tid; i < (kC4MaxRows + 31) / 32; i += 1024) dirty[i] = 0;
-        __syncthreads();                                                // (the first dirty mark may come before the first step's barrier)
-        const uint32_t st0 = step_ptr[chunk], st1 = step_ptr[chunk + 1];
-        const int nsteps = (int)(st1 - st0);
-        // Time u: process step u (entries and gathered rows parked in LDS), park step u + 1 (rows gathered
-        // during u - 1 ... u), gather step u + 2 (its entries have been in registers since u - 3), load the
-        // entries of step u + 5.  Everything unconditional and in the same order on every trip.
-        uint32_t ea0 = 0, ea1 = 0, eb0 = 0, eb1 = 0, ec0 = 0, ec1 = 0, ed0 = 0, ed1 = 0;   // entry ring: step s in slot s & 3
-        uint32_t la = 0, lb = 0, lc = 0, ld = 0, lcur = 0, cba = 0, cbb = 0, cbc = 0, cbd = 0;
-        f32x4 v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};                                        // rows gathered for the step parked next
-        uint4 dn = steps[st0];
-#define C4_STEP(u_, e0_, e1_, l_, cb_, ge0_, ge1_, gcb_)                                              \
-        {                                                                                             \
-            if ((u_) >= 0) {                                                                          \
-                __syncthreads();                                   /* step u is parked */             \
-                /* both entries of a thread advance together: the LDS reads of the two chains are issued */ \
-                /* back to back (slots past the step's end hold stale but readable words, masked below)  */ \
-                const uint32_t i0_ = tid, i1_ = tid + 1024;                                           \
-                const bool in0_ = i0_ < lcur, in1_ = i1_ < lcur;                                      \
-                const uint32_t a0_ = ebuf[i0_], a1_ = ebuf[i1_];                                      \
-                const uint32_t b0_ = ebuf[(int)i0_ - 1], b1_ = ebuf[i1_ - 1];                         \
-                const uint32_t n0_ = ebuf[i0_ + 1], n1_ = ebuf[i1_ + 1];                              \
-                const f32x4 w0_ = vbuf[i0_], w1_ = vbuf[i1_];                                         \
-                const uint32_t r0_ = a0_ >> kC4Shift, r1_ = a1_ >> kC4Shift;                          \
-                const bool h0_ = in0_ && (i0_ == 0 || (b0_ >> kC4Shift) != r0_);                      \
-                const bool h1_ = in1_ && (b1_ >> kC4Shift) != r1_;                                    \
-                const f32x4 c0_ = acc[r0_ < kC4MaxRows ? r0_ : 0], c1_ = acc[r1_ < kC4MaxRows ? r1_ : 0]; \
-                const bool more0_ = h0_ && i0_ + 1 < lcur && (n0_ >> kC4Shift) == r0_;                \
-                const bool more1_ = h1_ && i1_ + 1 < lcur && (n1_ >> kC4Shift) == r1_;                \
-                f32x4 s0_ = c0_ + w0_, s1_ = c1_ + w1_;                                               \
-                if (more0_)                                                                           \
-                    for (uint32_t k_ = i0_ + 1; k_ < lcur && (ebuf[k_] >> kC4Shift) == r0_; ++k_) s0_ += vbuf[k_]; \
-                if (more1_)                                                                           \
-                    for (uint32_t k_ = i1_ + 1; k_ < lcur && (ebuf[k_] >> kC4Shift) == r1_; ++k_) s1_ += vbuf[k_]; \
-                if (h0_) acc[r0_] = s0_;                                                              \
-                if (h1_) acc[r1_] = s1_;                                                              \
-                __syncthreads();                                   /* everyone is done reading step u */ \
-            }                                                                                         \
-            /* park step u + 1: its entries (ring slot e_) and the rows gathered for it; a flagged row */ \
-            /* (sign bit of its first value) dirties the entry's row and is parked without the flag   */ \
-            {                                                                                         \
-                const uint32_t f0_ = __float_as_uint(v0[0]), f1_ = __float_as_uint(v1[0]);            \
-                if ((f0_ >> 31) && tid < (l_)) atomicOr(&dirty[(e0_ >> kC4Shift) >> 5], 1u << ((e0_ >> kC4Shift) & 31)); \
-                if ((f1_ >> 31) && tid + 1024 < (l_)) atomicOr(&dirty[(e1_ >> kC4Shift) >> 5], 1u << ((e1_ >> kC4Shift) & 31)); \
-                v0[0] = __uint_as_float(f0_ & 0x7FFFFFFFu);                                           \
-                v1[0] = __uint_as_float(f1_ & 0x7FFFFFFFu);                                           \
-            }                                                                                         \
-            ebuf[tid] = e0_;                                                                          \
-            ebuf[tid + 1024] = e1_;                                                                   \
-            vbuf[tid] = v0;                                                                           \
-            vbuf[tid + 1024] = v1;                                                                    \
-            lcur = l_;                                                                                \
-            {   /* gather step u + 2 (entries ge_, column base gcb_) */                               \
-                const uint32_t c0_ = gcb_ + (ge0_ & ((1u << kC4Shift) - 1u)), c1_ = gcb_ + (ge1_ & ((1u << kC4Shift) - 1u));          \
-                v0 = table[c0_ < n ? c0_ : n];                                                        \
-                v1 = table[c1_ < n ? c1_ : n];                                                        \
-            }                                                                                         \
-            {   /* load the entries of step u + 5 into the slot just parked */                        \
-                const uint4 dl_ = dn;                                                                 \
-                const int nx_ = (u_) + 6;                                                             \
-                dn = steps[st0 + (uint32_t)(nx_ > 0 ? nx_ : 0)];                                      \
-                const uint32_t x0_ = dl_.y + tid, x1_ = dl_.y + tid + 1024;                           \
-                e0_ = entries[x0_ < last_entry ? x0_ : last_entry];                                   \
-                e1_ = entries[x1_ < last_entry ? x1_ : last_entry];                                   \
-                l_ = ((u_) + 5 >= 0) ? dl_.z : 0u;                                                    \
-                cb_ = dl_.x * block_cols;                                                               \
-            }                                                                                         \
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 *A = reinterpret_cast<f32x4 *>(c4_smem) + wave * slice_rows;  // this wave's sums
+    uint32_t *dirty = reinterpret_cast<uint32_t *>(c4_smem + (size_t)kC4Slices * slice_rows * 16) + wave * kC4DirtyWords;
+    for (uint32_t base = slice0 + blockIdx.x * kC4Slices; base < slice1; base += gridDim.x * kC4Slices) {
+        const bool live = base + wave < slice1;
+        const uint32_t wc = live ? base + wave : nslices;               // slice `nslices` is empty (step_ptr has one more entry)
+        const uint32_t row0 = row_base + (live ? wc * slice_rows : 0u);
+        uint32_t cur_blk = 0;
+        for (uint32_t i = lane; i < slice_rows; i += 64) A[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (lane < kC4DirtyWords) dirty[lane] = 0;
+        const uint32_t st0 = __builtin_amdgcn_readfirstlane(step_ptr[wc]);
+        const int nsteps = (int)(__builtin_amdgcn_readfirstlane(step_ptr[wc + 1]) - st0);   // a multiple of 4 (0 for the empty slice)
+        uint4 e[4];                          // entries of step s in slot s & 3
+        f32x4 v[2][4];                       // gathered rows of step s in slot s & 1
+        uint32_t cb[4], cnt[4], bk[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            cb[a] = 0;
+            bk[a] = 0;
+            cnt[a] = 0;
+            e[a] = uint4{0, 0, 0, 0};
         }
-        for (int u = -8; u < nsteps; u += 4) {
-            C4_STEP(u,     eb0, eb1, lb, cbb, ec0, ec1, cbc)
-            C4_STEP(u + 1, ec0, ec1, lc, cbc, ed0, ed1, cbd)
-            C4_STEP(u + 2, ed0, ed1, ld, cbd, ea0, ea1, cba)
-            C4_STEP(u + 3, ea0, ea1, la, cba, eb0, eb1, cbb)
-        }
-#undef C4_STEP
-        __syncthreads();
-        for (uint32_t i = tid; i < rows_per_chunk && row0 + i < row_end; i += 1024) {
-            f32x4 a = acc[i];
-            if (dirty[i >> 5] >> (i & 31) & 1u) {
-                // a dirty row: its aggregate is recomputed from full rows (k_c4_fix) into slot `slot` of the
-                // side buffer; the sums here are not used.  No slot left: the stage kernel gathers it itself.
-                const uint32_t slot = atomicAdd(&desc[5], 1u);
-                if (slot < dirty_cap) dirty_rows[slot] = row0 + i;
-                a[0] = __uint_as_float(0x80000000u);
-                a[1] = __uint_as_float(slot < dirty_cap ? slot : 0xFFFFFFFFu);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[a][k] = f32x4{0, 0, 0, 0};
+        uint4 dsc = steps[st0];              // descriptor of the step whose entries are loaded next
+        int dsc_step = 0;
+        for (int u = -4; u < nsteps; u += 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int s = u + j;         // the step whose sums are done now
+                {   // entries of step s + 2, descriptor of step s + 3
+                    const int se = s + 2;
+                    const int slot = (j + 2) & 3;
+                    const bool on = se >= 0 && se < nsteps && dsc_step == se;
+                    const uint32_t first = dsc.y, count = on ? dsc.z : 0u;
+                    cb[slot] = dsc.x * block_cols;
+                    bk[slot] = dsc.x;
+                    cnt[slot] = count;
+                    const uint32_t x = first + 4u * lane;                    // first is a multiple of 4
+                    const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(entries + (x < last_entry ? x : last_entry)));
+                    e[slot] = uint4{q[0], q[1], q[2], q[3]};
+                    const int nx = se + 1;
+                    const int nxc = nx < 0 ? 0 : (nx < nsteps ? nx : (nsteps > 0 ? nsteps - 1 : 0));
+                    dsc = steps[st0 + (uint32_t)nxc];
+                    dsc_step = nx;
+                }
+                {   // gather step s + 1
+                    const int slot = (j + 1) & 3;
+                    const int vs = (j + 1) & 1;
+                    const uint32_t w[4] = {e[slot].x, e[slot].y, e[slot].z, e[slot].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t c = cb[slot] + (w[k] & ((1u << kC4Shift) - 1u));
+                        const bool in = 4u * lane + k < cnt[slot];
+                        v[vs][k] = table[(in && c < n) ? c : n];             // row n: the zero row
+                    }
+                }
+                if (s >= 0) {   // sums of step s
+                    const int slot = j & 3;
+                    const int vs = j & 1;
+                    if (cnt[slot])
+                        while (cur_blk < bk[slot]) {   // pacing: the workgroup enters a column block together
+                            __syncthreads();
+                            ++cur_blk;
+                        }
+                    if (cnt[slot]) {
+                        const uint32_t w[4] = {e[slot].x, e[slot].y, e[slot].z, e[slot].w};
+                        uint32_t r[4];
+                        f32x4 a[4], val[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            r[k] = (4u * lane + k < cnt[slot]) ? (w[k] >> kC4Shift) : kC4NoRow;
+                            a[k] = A[r[k] < slice_rows ? r[k] : 0];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {   // a flagged table row (stray non-zeros) dirties the entry's row
+                            val[k] = v[vs][k];
+                            const uint32_t f = __float_as_uint(val[k][0]);
+                            if ((f >> 31) && r[k] != kC4NoRow) atomicOr(&dirty[r[k] >> 5], 1u << (r[k] & 31));
+                            val[k][0] = __uint_as_float(f & 0x7FFFFFFFu);
+                        }
+                        uint32_t prev3 = lane_prev(r[3]);
+                        if (lane == 0) prev3 = kC4NoRow - 1u;
+                        const bool h0 = r[0] != kC4NoRow && r[0] != prev3;
+                        const bool h1 = r[1] != kC4NoRow && r[1] != r[0];
+                        const bool h2 = r[2] != kC4NoRow && r[2] != r[1];
+                        const bool h3 = r[3] != kC4NoRow && r[3] != r[2];
+                        uint32_t nr[4];      // the next lane's rows and values
+                        f32x4 nv[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            nr[k] = lane_next(r[k]);
+                            nv[k] = lane_next(val[k]);
+                            if (lane == 63) nr[k] = kC4NoRow;
+                        }
+                        // lane-local folds (a row's entries are adjacent: r[2] == r[0] implies r[1] == r[0])
+                        f32x4 s0 = a[0] + val[0];
+                        s0 += c4_sel(r[1] == r[0], val[1]);
+                        s0 += c4_sel(r[2] == r[0], val[2]);
+                        s0 += c4_sel(r[3] == r[0], val[3]);
+                        f32x4 s1 = a[1] + val[1];
+                        s1 += c4_sel(r[2] == r[1], val[2]);
+                        s1 += c4_sel(r[3] == r[1], val[3]);
+                        f32x4 s2 = a[2] + val[2];
+                        s2 += c4_sel(r[3] == r[2], val[3]);
+                        f32x4 s3 = a[3] + val[3];
+                        // the run that holds this lane's last entry goes on in the next lane(s); it is this lane's to
+                        // finish iff it starts here
+                        const bool o0 = h0 && r[0] == r[3], o1 = h1 && r[1] == r[3], o2 = h2 && r[2] == r[3], o3 = h3;
+                        f32x4 x = o0 ? s0 : o1 ? s1 : o2 ? s2 : s3;
+                        bool more = (o0 || o1 || o2 || o3) && r[3] != kC4NoRow;
+                        for (;;) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) x += c4_sel(more && nr[k] == r[3], nv[k]);
+                            more = more && nr[3] == r[3];
+                            if (!__any(more)) break;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {   // one lane further
+                                nr[k] = lane_next(nr[k]);
+                                nv[k] = lane_next(nv[k]);
+                                if (lane == 63) nr[k] = kC4NoRow;
+                            }
+                        }
+                        if (o0) s0 = x;
+                        if (o1) s1 = x;
+                        if (o2) s2 = x;
+                        if (o3) s3 = x;
+                        if (h0) A[r[0]] = s0;
+                        if (h1) A[r[1]] = s1;
+                        if (h2) A[r[2]] = s2;
+                        if (h3) A[r[3]] = s3;
+                    }
+                }
             }
-            agg[row0 + i] = a;
         }
+        while (cur_blk < nblocks) {          // every wave passes one barrier per block and chunk
+            __syncthreads();
+            ++cur_blk;
+        }
+        if (live)
+            for (uint32_t i = lane; i < slice_rows && row0 + i < row_end; i += 64) {
+                f32x4 a = A[i];
+                if (dirty[i >> 5] >> (i & 31) & 1u) {
+                    // a dirty row: its aggregate is recomputed from full rows (k_c4_fix) into slot `slot` of the
+                    // side buffer; the sums here are not used.  No slot left: the stage kernel gathers it itself.
+                    const uint32_t slot = atomicAdd(&desc[5], 1u);
+                    if (slot < dirty_cap) dirty_rows[slot] = row0 + i;
+                    a[0] = __uint_as_float(0x80000000u);
+                    a[1] = __uint_as_float(slot < dirty_cap ? slot : 0xFFFFFFFFu);
+                }
+                agg[row0 + i] = a;
+            }
     }
 }
 
@@ -2235,20 +2342,23 @@ hipError_t lds_table_count(const GraphDev &g, uint32_t rows_per_chunk, uint32_t 
 
 hipError_t lds_table_steps(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, const uint32_t *seg_cnt,
                            const uint32_t *step_ptr, uint32_t *step_count, void *steps, bool write, hipStream_t stream,
-                           uint32_t row_base, uint32_t row_end) {
+                           uint32_t row_base, uint32_t row_end, uint32_t cap, uint32_t slack) {
     if (row_end > g.n) row_end = g.n;
+    if (cap == 0) cap = kLtStep;
+    if (slack && slack < 3u * nblocks + 4u) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_lt_steps, dim3((nchunks + 255) / 256), dim3(256), 0, stream, g, rows_per_chunk, nchunks, nblocks,
-                       seg_cnt, step_ptr, step_count, reinterpret_cast<uint4 *>(steps), write ? 1 : 0, row_base, row_end);
+                       seg_cnt, step_ptr, step_count, reinterpret_cast<uint4 *>(steps), write ? 1 : 0, row_base, row_end, cap, slack);
     return hipGetLastError();
 }
 
 hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t block_cols,
                              const uint32_t *seg_cnt, uint32_t *entries, hipStream_t stream, uint32_t shift,
-                             uint32_t row_base, uint32_t row_end) {
+                             uint32_t row_base, uint32_t row_end, uint32_t slack) {
     if (block_cols > (1u << shift) || ((uint64_t)rows_per_chunk << shift) > (1ull << 32)) return hipErrorInvalidValue;
+    if (slack && slack < 3u * nblocks + 4u) return hipErrorInvalidValue;
     if (row_end > g.n) row_end = g.n;
     hipLaunchKernelGGL(k_lt_scatter, dim3(nchunks), dim3(1024), 0, stream, g, rows_per_chunk, nblocks, block_cols, shift, seg_cnt,
-                       entries, row_base, row_end);
+                       entries, row_base, row_end, slack);
     return hipGetLastError();
 }
 
@@ -2296,6 +2406,8 @@ hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float
 uint32_t compact_max_rows() { return kC4MaxRows; }
 uint32_t compact_block() { return kC4Block; }
 uint32_t compact_shift() { return kC4Shift; }
+uint32_t compact_slices() { return kC4Slices; }
+uint32_t compact_step() { return kC4Step; }
 
 // counts -> desc -> table -> four sums per row of [row_lo, row_hi) (chunks that straddle the ends are done
 // whole).  `counts` holds the per-column non-zero counts of `in` (column_counts, same stream).
@@ -2303,9 +2415,9 @@ hipError_t launch_compact_gather(const GraphDev &g, const float *in, const unsig
                                  float *table, float *acc4, uint32_t row_lo, uint32_t row_hi, uint32_t rows_per_chunk,
                                  const uint32_t *step_ptr, const void *steps, const uint32_t *entries, uint32_t *dirty_rows,
                                  uint32_t dirty_cap, float *agg16, hipStream_t stream, uint32_t block_cols,
-                                 uint32_t plan_base, uint32_t plan_end, int what) {
+                                 uint32_t plan_base, uint32_t plan_end, uint32_t last_entry, int what) {
     if (row_hi <= row_lo || g.nnz == 0 || row_lo < plan_base || row_hi > plan_end) return hipErrorInvalidValue;
-    if (rows_per_chunk == 0 || rows_per_chunk > kC4MaxRows) return hipErrorInvalidValue;
+    if (rows_per_chunk == 0 || rows_per_chunk > kC4MaxRows || rows_per_chunk % kC4Slices) return hipErrorInvalidValue;
     if (what & 1) {   // prepare: choose the columns and (unless the producing kernel did) write the table
         hipLaunchKernelGGL(k_c4_choose, dim3(1), dim3(64), 0, stream, counts, count_slots, g.n, desc);
         hipLaunchKernelGGL(k_c4_compact, dim3(std::min<unsigned>((g.n + 256) / 256, 4096u)), dim3(256), 0, stream,
@@ -2315,19 +2427,23 @@ hipError_t launch_compact_gather(const GraphDev &g, const float *in, const unsig
     hipError_t rc0 = hipMemsetAsync(desc + 5, 0, sizeof(uint32_t), stream);   // dirty-row counter
     if (rc0 != hipSuccess) return rc0;
     const uint32_t c0 = (row_lo - plan_base) / rows_per_chunk, c1 = (row_hi - 1 - plan_base) / rows_per_chunk + 1;
-    constexpr size_t lds = (size_t)kC4MaxRows * 16 + (size_t)kLtStep * 16 + (size_t)kLtStep * 4 + ((kC4MaxRows + 31) / 32) * 4 + 64;
-    static_assert(lds <= 160 * 1024, "LDS budget of k_c4_agg");
+    const uint32_t slice_rows = rows_per_chunk / kC4Slices;
+    const uint32_t nslices = ((plan_end - plan_base + rows_per_chunk - 1) / rows_per_chunk) * kC4Slices;
+    const uint32_t nblocks = (g.n + block_cols - 1) / block_cols;
+    constexpr size_t lds_max = (size_t)kC4Slices * (kC4SliceRows * 16 + kC4DirtyWords * 4);
+    static_assert(lds_max <= 160 * 1024, "LDS budget of k_c4_agg");
+    const size_t lds = (size_t)kC4Slices * ((size_t)slice_rows * 16 + kC4DirtyWords * 4);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(k_c4_agg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(k_c4_agg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         if (rc != hipSuccess) return rc;
         attr_set = true;
     }
     // a persistent grid of one workgroup per CU: they start together and sweep the column blocks together
     hipLaunchKernelGGL(k_c4_agg, dim3(std::min<uint32_t>(256u, c1 - c0)), dim3(1024), lds, stream, step_ptr,
                        reinterpret_cast<const uint4 *>(steps), entries, reinterpret_cast<const f32x4 *>(table),
-                       reinterpret_cast<f32x4 *>(acc4), g.n, rows_per_chunk, c0, c1, (uint32_t)(g.nnz - 1), desc, dirty_rows,
-                       dirty_cap, block_cols, plan_base, plan_end);
+                       reinterpret_cast<f32x4 *>(acc4), g.n, slice_rows, c0 * kC4Slices, std::min(c1 * kC4Slices, nslices), nslices,
+                       last_entry, desc, dirty_rows, dirty_cap, block_cols, nblocks, plan_base, plan_end);
     // the grid is sized for a typical number of dirty rows and strides over more
     hipLaunchKernelGGL(k_c4_fix, dim3(std::min<uint32_t>((dirty_cap + 63) / 64, 4096u)), dim3(256), 0, stream, g,
                        reinterpret_cast<const float4 *>(in), desc, dirty_rows, dirty_cap, reinterpret_cast<float4 *>(agg16));

@@ -584,6 +584,10 @@ def test_compact_gather_plan_is_bit_identical(model_text, oracle_model, case):
         dev = torch.device("cuda:0")
         hin = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
         hin[: g.n] = torch.from_numpy(h).to(dev)
+        stray_vertex = (h[:, [c for c in range(16) if c not in live]] != 0).any(axis=1)
+        rp = g.rowptr.astype(np.int64)
+        hits = np.concatenate(([0], np.cumsum(stray_vertex[g.col[: rp[-1]]])))
+        dirty_row = hits[rp[1:]] > hits[rp[:-1]]
         for stage in (1, 2):
             want = _oracle_stage(oracle_model, g, stage, h)
             for lo, hi in ((0, g.n), (g.n // 4 // 64 * 64, g.n), (0, g.n // 8 // 64 * 64)):   # the last one is too short for the plan
@@ -607,8 +611,14 @@ def test_compact_gather_plan_is_bit_identical(model_text, oracle_model, case):
                     if ok:
                         # (with two live columns the two stray columns simply become the other two table columns)
                         assert (dirty > 0) == (strays > 0 and case != "two_live"), (case, dirty)
+                        if case != "two_live":
+                            # dirty rows = rows with a neighbour that has a non-zero outside the table's columns
+                            # (chunks that straddle the ends of [lo, hi) are done whole)
+                            assert int(dirty_row[lo:hi].sum()) <= dirty <= int(dirty_row.sum()), (case, lo, hi, dirty)
+                            if lo == 0 and hi == g.n:
+                                assert dirty == int(dirty_row.sum()), (case, dirty)
                         if case == "slot_overflow":
-                            assert dirty > max(g.n // 4, 1024)
+                            assert dirty > g.n // 4
     finally:
         e.close()
 
