@@ -120,7 +120,7 @@ struct gnnvc_engine {
     // LDS-table plan of the F = 1 stage (same timing as the blocked plan: built on the graph's second forward)
     int opt_lds_table = 1;          // 0 = off, 1 = when it applies, 2 = also on skewed graphs
     bool lt_ready = false, lt_tried = false;
-    uint32_t lt_rows = 0, lt_chunks = 0, lt_blocks = 0, lt_steps_total = 0;
+    uint32_t lt_rows = 0, lt_chunks = 0, lt_blocks = 0, lt_steps_total = 0, lt_last_entry = 0;
     DevBuf<uint8_t> lt_bytes;
     DevBuf<uint32_t> lt_entries, lt_segcnt, lt_stepptr, lt_stepcnt, lt_bad;
     DevBuf<uint4> lt_steps;
@@ -495,14 +495,19 @@ int build_lds_table(gnnvc_engine *e) {
     const uint32_t bc = gnnvc::lds_table_block(), max_rows = gnnvc::lds_table_max_rows();
     const uint32_t nblocks = (g.n + bc - 1) / bc;
     if (nblocks > 4096) return GNNVC_OK;
-    // chunks: a multiple of the 256 CUs, each within the LDS budget
+    // chunks: a multiple of the 256 CUs, each within the LDS budget; a chunk = 16 slices of rows (one per wave)
     uint32_t chunks = (g.n + max_rows - 1) / max_rows;
     chunks = (chunks + 255u) / 256u * 256u;
-    const uint32_t rows = (g.n + chunks - 1) / chunks;
+    uint32_t rows = (g.n + chunks - 1) / chunks;
+    rows = (rows + 15u) / 16u * 16u;
     chunks = (g.n + rows - 1) / rows;
+    const uint32_t slice_rows = rows / 16u, slices = chunks * 16u;
+    const uint32_t slack = 3u * nblocks + 4u;   // every (slice, block) segment starts at a multiple of 4 entries
+    const uint64_t entry_cap = g.nnz + (uint64_t)slack * slices + 8;
+    if (entry_cap >= (1ull << 31)) return GNNVC_OK;
     HIP_TRY(e, e->lt_bad.reserve(2));
     HIP_TRY(e, e->lt_bytes.reserve((size_t)g.n + 64));
-    HIP_TRY(e, e->lt_segcnt.reserve((size_t)chunks * nblocks));
+    HIP_TRY(e, e->lt_segcnt.reserve((size_t)slices * nblocks));
     HIP_TRY(e, e->lt_stepcnt.reserve(chunks));
     HIP_TRY(e, e->lt_stepptr.reserve((size_t)chunks + 1));
     HIP_TRY(e, e->pin_small.reserve((size_t)chunks + 2));
@@ -510,8 +515,9 @@ int build_lds_table(gnnvc_engine *e) {
     HIP_TRY(e, hipMemsetAsync(flag, 0, sizeof(uint32_t), e->stream));
     HIP_TRY(e, hipMemsetAsync(e->lt_bytes.p + g.n, 0, 64, e->stream));
     HIP_TRY(e, gnnvc::lds_table_bytes(g.w, g.n, e->lt_bytes.p, flag, e->stream));
-    HIP_TRY(e, gnnvc::lds_table_count(g, rows, chunks, nblocks, bc, e->lt_segcnt.p, flag, e->stream));
-    HIP_TRY(e, gnnvc::lds_table_steps(g, rows, chunks, nblocks, e->lt_segcnt.p, nullptr, e->lt_stepcnt.p, nullptr, false, e->stream));
+    HIP_TRY(e, gnnvc::lds_table_count(g, slice_rows, slices, nblocks, bc, e->lt_segcnt.p, flag, e->stream));
+    HIP_TRY(e, gnnvc::lds_table_wsteps(g, slice_rows, chunks, nblocks, e->lt_segcnt.p, nullptr, e->lt_stepcnt.p, nullptr, false, slack,
+                                       e->stream));
     HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, e->lt_stepcnt.p, chunks * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipMemcpyAsync(e->pin_small.p + chunks, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -522,17 +528,22 @@ int build_lds_table(gnnvc_engine *e) {
         ptr[c] = (uint32_t)total;
         total += e->pin_small.p[c];
     }
-    if (total + 8 >= (1ull << 31)) return GNNVC_OK;
+    if (total + 8 >= (1ull << 26)) return GNNVC_OK;
     ptr[chunks] = (uint32_t)total;
-    HIP_TRY(e, e->lt_steps.reserve(total + 8));
-    HIP_TRY(e, e->lt_entries.reserve(g.nnz));
+    const size_t rec_quads = ((total + 8) * gnnvc::lds_table_record_words() + 3) / 4;   // lt_steps counts in 16-byte units
+    HIP_TRY(e, e->lt_steps.reserve(rec_quads));
+    HIP_TRY(e, e->lt_entries.reserve(entry_cap));
     HIP_TRY(e, e->blk_acc.reserve(g.n));
     std::memcpy(e->pin_small.p, ptr.data(), ptr.size() * sizeof(uint32_t));
     HIP_TRY(e, hipMemcpyAsync(e->lt_stepptr.p, e->pin_small.p, ptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(e, hipMemsetAsync(e->lt_steps.p + total, 0, 8 * sizeof(uint4), e->stream));
-    HIP_TRY(e, gnnvc::lds_table_steps(g, rows, chunks, nblocks, e->lt_segcnt.p, e->lt_stepptr.p, nullptr, e->lt_steps.p, true, e->stream));
-    HIP_TRY(e, gnnvc::lds_table_scatter(g, rows, chunks, nblocks, bc, e->lt_segcnt.p, e->lt_entries.p, e->stream));
+    HIP_TRY(e, hipMemsetAsync(e->lt_steps.p, 0, rec_quads * sizeof(uint4), e->stream));
+    HIP_TRY(e, hipMemsetAsync(e->lt_entries.p, 0, entry_cap * sizeof(uint32_t), e->stream));   // (pad slots are read, never used)
+    HIP_TRY(e, gnnvc::lds_table_wsteps(g, slice_rows, chunks, nblocks, e->lt_segcnt.p, e->lt_stepptr.p, nullptr,
+                                       reinterpret_cast<uint32_t *>(e->lt_steps.p), true, slack, e->stream));
+    HIP_TRY(e, gnnvc::lds_table_scatter(g, slice_rows, slices, nblocks, bc, e->lt_segcnt.p, e->lt_entries.p, e->stream, 17, 0,
+                                        0xFFFFFFFFu, slack));
     HIP_TRY(e, hipStreamSynchronize(e->stream));   // pin_small is reused by others
+    e->lt_last_entry = (uint32_t)((entry_cap - 4) & ~3ull);
     e->lt_rows = rows;
     e->lt_chunks = chunks;
     e->lt_blocks = nblocks;
@@ -689,7 +700,7 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
         HIP_TRY(e, gnnvc::launch_stage0_lds_table(e->stages[0], e->g, e->ws, e->params.p, in, out, lo, hi, e->lt_rows,
                                                   e->lt_stepptr.p, e->lt_steps.p, e->lt_entries.p, e->lt_bytes.p,
                                                   e->blk_acc.p, e->lt_bad.p, e->long_thresh, e->opt_mfma == 1,
-                                                  e->interleave, e->stream, emit));
+                                                  e->interleave, e->stream, emit, e->lt_last_entry));
     } else if (stage == 0 && e->blocked_ready) {
         HIP_TRY(e, gnnvc::launch_stage0_blocked(e->stages[0], e->g, e->ws, e->params.p, in, out, lo, hi,
                                                 e->blk_count, e->blk_ptr.p, e->blk_col.p, e->blk_acc.p,

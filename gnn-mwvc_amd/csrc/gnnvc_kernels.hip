@@ -881,18 +881,16 @@ __global__ __launch_bounds__(256) void k_long_f1(
 // The F = 1 gather reads 4 bytes per neighbour and is bound by line fills (one 128-byte line per
 // neighbour, from HBM or, column-blocked, from L2).  When the input really is x[v] = (float)W(v)/ws
 // with W(v) <= 255 — the reference's driver (src/GNN_VC.cpp:189-191) on the usual weight ranges — the
-// table of neighbour values is one BYTE per vertex, and a 32768-vertex slice of it fits in LDS beside
-// the partial sums of ~19.5 K rows.  Rows are cut into chunks (one 1024-thread workgroup each, sums in
-// LDS), columns into blocks of 32768; the CSR entries of a chunk are regrouped by block (a row's
-// entries of one block stay adjacent and in order) and cut into STEPS of <= 2048 entries.  A workgroup
-// walks its steps: the step's entries and the block's slice are staged in LDS (prefetched four steps
-// ahead through registers, every load unconditional so that the hardware counters can be waited on
-// exactly), each thread adds lut[w] for its entry to its row's sum, and the thread at the head of a
-// row's run of entries adds the whole run in order.  Blocks ascend and a row's entries of one block
-// belong to one thread, so every row is still summed in CSR order: same bits as the plain gather.
-constexpr uint32_t kLtBlock = 32768;      // vertices per column block (bytes per LDS slice)
-constexpr uint32_t kLtStep = 2048;        // entries per step (two per thread)
-constexpr uint32_t kLtMaxRows = 19532;    // rows per chunk: 4 B * rows + 2 * 32 KiB + 2 * 8 KiB + 1 KiB <= 160 KiB
+// table of neighbour values is one BYTE per vertex, and an 81920-vertex slice of it fits in LDS beside
+// the partial sums of ~19.5 K rows.  Rows are cut into chunks (one 1024-thread workgroup each) of 16
+// SLICES (one per wave, sums in the wave's part of LDS), columns into blocks of 81920; the CSR entries of a
+// slice are regrouped by block (a row's entries of one block stay adjacent and in order, every (slice, block)
+// segment starts at a multiple of 4) and a workgroup STEP is one block with up to 256 entries per slice.
+// Per step the workgroup stages the block's byte slice in LDS and every wave folds its own entries into its
+// own rows (k_lt_agg).  Blocks ascend and a row's entries of one block are folded in order by one wave, so
+// every row is still summed in CSR order: same bits as the plain gather.  What bounds it: every workgroup
+// streams the whole byte table once per chunk (512 chunks x 10 MB on the metric graph) from L2 into LDS.
+constexpr uint32_t kLtStep = 2048;        // default entries per step of the plan builder
 
 // bad |= 1 unless x[v] == (float)w[v] / ws (bit for bit) for every vertex
 __global__ __launch_bounds__(256) void k_lt_check_x(const float *__restrict__ x, const uint32_t *__restrict__ w, float ws,
@@ -1020,109 +1018,214 @@ __global__ __launch_bounds__(1024) void k_lt_scatter(GraphDev g, uint32_t rows_p
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// sums of the rows of chunks [chunk0, chunk0 + gridDim.x) -> agg[row]; nothing if *bad != 0
-__global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ step_ptr, const uint4 *__restrict__ steps,
+// whole-wave shifts by one lane (DPP wave_shl / wave_shr, zero shifted in)
+__device__ __forceinline__ uint32_t lane_next(uint32_t x) {   // lane i <- lane i + 1
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t lane_prev(uint32_t x) {   // lane i <- lane i - 1
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xF, 0xF, true);
+}
+__device__ __forceinline__ float lane_next(float v) { return __uint_as_float(lane_next(__float_as_uint(v))); }
+
+// Workgroup steps of the LDS-table plan.  A chunk = 16 slices of rows, one per wave; a step = one column block
+// (whose byte slice the workgroup stages in LDS) with up to 256 entries per slice.  Record (kLtwRec words):
+// [0] block, [2 + w] first entry of slice w, [18 + w] its count.  One thread per chunk.
+// write == 0: step_count[c] = number of records of chunk c (padded to a multiple of 4).
+constexpr uint32_t kLtwRec = 36;
+__global__ __launch_bounds__(64) void k_ltw_steps(GraphDev g, uint32_t slice_rows, uint32_t nchunks, uint32_t nblocks,
+                                                  const uint32_t *__restrict__ seg_cnt, const uint32_t *__restrict__ step_ptr,
+                                                  uint32_t *__restrict__ step_count, uint32_t *__restrict__ recs, int write,
+                                                  uint32_t cap, uint32_t slack) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    uint32_t first[16];
+#pragma unroll
+    for (uint32_t w = 0; w < 16; ++w) first[w] = lt_chunk_first(g, c * 16 + w, slice_rows, 0, g.n, slack);
+    const uint32_t pos = write ? step_ptr[c] : 0;
+    uint32_t made = 0, last_block = 0;
+    for (uint32_t b = 0; b < nblocks; ++b) {
+        uint32_t cnt[16], mx = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 16; ++w) {
+            cnt[w] = seg_cnt[(size_t)(c * 16 + w) * nblocks + b];
+            mx = max(mx, cnt[w]);
+        }
+        for (uint32_t t = 0; t * cap < mx; ++t) {
+            if (write) {
+                uint32_t *rec = recs + (size_t)(pos + made) * kLtwRec;
+                rec[0] = b;
+                rec[1] = 0;
+#pragma unroll
+                for (uint32_t w = 0; w < 16; ++w) {
+                    rec[2 + w] = first[w] + t * cap;
+                    rec[18 + w] = cnt[w] > t * cap ? min(cap, cnt[w] - t * cap) : 0u;
+                }
+                rec[34] = rec[35] = 0;
+            }
+            ++made;
+            last_block = b;
+        }
+#pragma unroll
+        for (uint32_t w = 0; w < 16; ++w) {
+            first[w] += cnt[w];
+            if (slack) first[w] = (first[w] + 3u) & ~3u;
+        }
+    }
+    const uint32_t padded = made ? (made + 3u) / 4u * 4u : 4u;
+    if (write)
+        for (; made < padded; ++made) {
+            uint32_t *rec = recs + (size_t)(pos + made) * kLtwRec;
+            for (uint32_t i = 0; i < kLtwRec; ++i) rec[i] = 0;
+            rec[0] = last_block;
+        }
+    else
+        step_count[c] = padded;
+}
+
+// sums of the rows of chunks [chunk0, chunk0 + gridDim.x) -> agg[row]; nothing if *bad != 0.
+// A WAVE owns a slice of the chunk's rows (sums in its own part of LDS) and walks its own entries; the workgroup
+// shares the column block's byte slice.  Per step: the lane takes four consecutive entries (one 16-byte load,
+// two steps ahead), looks their bytes up, and folds runs of the same row lane-locally, a run that reaches the
+// lane's last entry continuing with the next lane's entries (whole-wave DPP shift) — see k_c4_agg, which does
+// the same with four floats per row.  Two barriers per step: everyone is done with the slice / the next one
+// is in place (it was loaded into registers before the step's sums).
+constexpr uint32_t kLtwBlock = 81920;       // vertices per column block = bytes of the LDS slice
+constexpr uint32_t kLtwSliceRows = 1221;    // rows per slice: 16 x 4 B x rows + 1 KiB + 80 KiB <= 160 KiB
+constexpr uint32_t kLtwStep = 256;          // entries per slice and step
+constexpr uint32_t kLtwShift = 17;
+constexpr uint32_t kLtwNoRow = (1u << (32 - kLtwShift)) - 1u;
+static_assert(kLtwBlock <= (1u << kLtwShift) && kLtwSliceRows < kLtwNoRow - 1u, "entry fields");
+static_assert(kLtwBlock % (16 * 1024) == 0, "slice pieces per thread");
+
+__device__ __forceinline__ float ltw_sel(bool c, float v) { return c ? v : 0.0f; }   // values >= +0: x + 0 == x
+
+__global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ step_ptr, const uint32_t *__restrict__ recs,
                                                  const uint32_t *__restrict__ entries, const uint8_t *__restrict__ wbyte, float ws,
-                                                 float *__restrict__ agg, uint32_t n, uint32_t rows_per_chunk, uint32_t chunk0,
+                                                 float *__restrict__ agg, uint32_t n, uint32_t slice_rows, uint32_t chunk0,
                                                  uint32_t last_entry, const uint32_t *__restrict__ bad) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lt_smem[];
     if (*bad) return;                                                   // block-uniform
-    float *acc = reinterpret_cast<float *>(lt_smem);                    // rows_per_chunk (<= kLtMaxRows) floats
-    float *lut = acc + kLtMaxRows;                                      // 256 floats
-    uint32_t *ebuf0 = reinterpret_cast<uint32_t *>(lut + 256);          // 2 x kLtStep entries
-    uint8_t *slice0 = reinterpret_cast<uint8_t *>(ebuf0 + 2 * kLtStep); // 2 x kLtBlock bytes
-    const uint32_t chunk = chunk0 + blockIdx.x, tid = threadIdx.x;
-    const uint32_t row0 = chunk * rows_per_chunk;
-    for (uint32_t i = tid; i < rows_per_chunk; i += 1024) acc[i] = 0.0f;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *A = reinterpret_cast<float *>(lt_smem) + wave * slice_rows;  // this wave's sums
+    float *lut = reinterpret_cast<float *>(lt_smem) + 16 * slice_rows;  // 256 floats
+    uint8_t *slice = reinterpret_cast<uint8_t *>(lut + 256);            // kLtwBlock bytes (16-byte aligned: slice_rows * 64 is)
+    const uint32_t chunk = chunk0 + blockIdx.x;
+    const uint32_t row0 = (chunk * 16 + wave) * slice_rows;
+    for (uint32_t i = lane; i < slice_rows; i += 64) A[i] = 0.0f;
     if (tid < 256) lut[tid] = (float)tid / ws;                          // the very expression that makes x (checked per forward)
-    const uint32_t st0 = step_ptr[chunk], st1 = step_ptr[chunk + 1];   // a multiple of 4 steps; 8 more are readable
+    const uint32_t st0 = __builtin_amdgcn_readfirstlane(step_ptr[chunk]);
+    const int nsteps = (int)(__builtin_amdgcn_readfirstlane(step_ptr[chunk + 1]) - st0);   // a multiple of 4; 8 more records are readable
     const uint32_t last_piece = (n + 15u) / 16u;                        // the byte table is padded beyond this
-    constexpr int SW = kLtBlock / 16 / 1024, J = kLtStep / 1024;
-    static_assert(SW == 2 && J == 2, "k_lt_agg is written for two pieces and two entries per thread");
-#define LT_LOAD(d_, sr_, en_)                                                             \
-    {                                                                                     \
-        _Pragma("unroll") for (int k = 0; k < SW; ++k) {                                  \
-            uint32_t piece_ = (d_).x * (kLtBlock / 16) + tid + 1024 * k;                  \
-            piece_ = piece_ < last_piece ? piece_ : last_piece;                           \
-            sr_[k] = reinterpret_cast<const u32x4 *>(wbyte)[piece_];                      \
-        }                                                                                 \
-        _Pragma("unroll") for (int j = 0; j < J; ++j) {                                   \
-            const uint32_t e_ = (d_).y + tid + 1024 * j;                                  \
-            en_[j] = entries[e_ < last_entry ? e_ : last_entry];                          \
-        }                                                                                 \
+    constexpr int SW = kLtwBlock / 16 / 1024;
+    uint4 e[4];                              // entries of step s in slot s & 3
+    uint32_t cnt[4], bk[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        e[a] = uint4{0, 0, 0, 0};
+        cnt[a] = 0;
+        bk[a] = 0;
     }
-#define LT_STORE(s_, sr_, en_)                                                            \
-    {                                                                                     \
-        _Pragma("unroll") for (int k = 0; k < SW; ++k)                                    \
-            reinterpret_cast<u32x4 *>(slice0 + (size_t)((s_) & 1) * kLtBlock)[tid + 1024 * k] = sr_[k]; \
-        _Pragma("unroll") for (int j = 0; j < J; ++j) ebuf0[((s_) & 1) * kLtStep + tid + 1024 * j] = en_[j]; \
+    u32x4 sr[SW];
+    // descriptor of the step whose entries are loaded next: block, this wave's first entry and count
+    uint32_t d_blk = recs[(size_t)st0 * kLtwRec], d_first = recs[(size_t)st0 * kLtwRec + 2 + wave], d_cnt = recs[(size_t)st0 * kLtwRec + 18 + wave];
+    int d_step = 0;
+    for (int u = -4; u < nsteps; u += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int s = u + j;             // the step whose sums are done now
+            {   // entries of step s + 2, descriptor of step s + 3
+                const int se = s + 2;
+                const int slot = (j + 2) & 3;
+                const bool on = se >= 0 && se < nsteps && d_step == se;
+                bk[slot] = d_blk;
+                cnt[slot] = on ? d_cnt : 0u;
+                const uint32_t x = d_first + 4u * lane;                  // first is a multiple of 4
+                const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(entries + (x < last_entry ? x : last_entry)));
+                e[slot] = uint4{q[0], q[1], q[2], q[3]};
+                const int nx = se + 1;
+                const uint32_t nxc = (uint32_t)(nx < 0 ? 0 : (nx < nsteps ? nx : nsteps - 1));
+                const uint32_t *rec = recs + (size_t)(st0 + nxc) * kLtwRec;
+                d_blk = rec[0];              // (wave-uniform values, left in vector registers: nothing waits for
+                d_first = rec[2 + wave];     //  them before the next trip)
+                d_cnt = rec[18 + wave];
+                d_step = nx;
+            }
+            {   // the byte slice of step s + 1's block, into registers
+                const uint32_t b = bk[(j + 1) & 3];
+#pragma unroll
+                for (int k = 0; k < SW; ++k) {
+                    uint32_t piece = b * (kLtwBlock / 16) + tid + 1024u * k;
+                    piece = piece < last_piece ? piece : last_piece;
+                    sr[k] = reinterpret_cast<const u32x4 *>(wbyte)[piece];
+                }
+            }
+            if (s >= 0 && __builtin_amdgcn_readfirstlane(cnt[j & 3])) {   // sums of step s (the slice of its block is in LDS)
+                const int slot = j & 3;
+                const uint32_t w[4] = {e[slot].x, e[slot].y, e[slot].z, e[slot].w};
+                uint32_t r[4];
+                float a[4], val[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool in = 4u * lane + k < cnt[slot];
+                    r[k] = in ? (w[k] >> kLtwShift) : kLtwNoRow;
+                    val[k] = lut[slice[in ? (w[k] & ((1u << kLtwShift) - 1u)) : 0u]];
+                    a[k] = A[r[k] < slice_rows ? r[k] : 0];
+                }
+                uint32_t prev3 = lane_prev(r[3]);
+                if (lane == 0) prev3 = kLtwNoRow - 1u;
+                const bool h0 = r[0] != kLtwNoRow && r[0] != prev3;
+                const bool h1 = r[1] != kLtwNoRow && r[1] != r[0];
+                const bool h2 = r[2] != kLtwNoRow && r[2] != r[1];
+                const bool h3 = r[3] != kLtwNoRow && r[3] != r[2];
+                uint32_t nr[4];
+                float nv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    nr[k] = lane_next(r[k]);
+                    nv[k] = lane_next(val[k]);
+                    if (lane == 63) nr[k] = kLtwNoRow;
+                }
+                float s0 = a[0] + val[0];
+                s0 += ltw_sel(r[1] == r[0], val[1]);
+                s0 += ltw_sel(r[2] == r[0], val[2]);
+                s0 += ltw_sel(r[3] == r[0], val[3]);
+                float s1 = a[1] + val[1];
+                s1 += ltw_sel(r[2] == r[1], val[2]);
+                s1 += ltw_sel(r[3] == r[1], val[3]);
+                float s2 = a[2] + val[2];
+                s2 += ltw_sel(r[3] == r[2], val[3]);
+                float s3 = a[3] + val[3];
+                const bool o0 = h0 && r[0] == r[3], o1 = h1 && r[1] == r[3], o2 = h2 && r[2] == r[3], o3 = h3;
+                float x = o0 ? s0 : o1 ? s1 : o2 ? s2 : s3;
+                bool more = (o0 || o1 || o2 || o3) && r[3] != kLtwNoRow;
+                for (;;) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) x += ltw_sel(more && nr[k] == r[3], nv[k]);
+                    more = more && nr[3] == r[3];
+                    if (!__any(more)) break;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {   // one lane further
+                        nr[k] = lane_next(nr[k]);
+                        nv[k] = lane_next(nv[k]);
+                        if (lane == 63) nr[k] = kLtwNoRow;
+                    }
+                }
+                if (o0) s0 = x;
+                if (o1) s1 = x;
+                if (o2) s2 = x;
+                if (o3) s3 = x;
+                if (h0) A[r[0]] = s0;
+                if (h1) A[r[1]] = s1;
+                if (h2) A[r[2]] = s2;
+                if (h3) A[r[3]] = s3;
+            }
+            __syncthreads();                 // everyone is done with the slice in LDS
+#pragma unroll
+            for (int k = 0; k < SW; ++k) reinterpret_cast<u32x4 *>(slice)[tid + 1024 * k] = sr[k];
+            __syncthreads();                 // the slice of step s + 1 is in place
+        }
     }
-    // both entries of a thread advance together: the LDS reads of the two chains are issued back to back
-#define LT_PROCESS(s_, len_)                                                              \
-    {                                                                                     \
-        const uint8_t *slice_ = slice0 + (size_t)((s_) & 1) * kLtBlock;                   \
-        const uint32_t *eb_ = ebuf0 + ((s_) & 1) * kLtStep;                               \
-        const uint32_t i0_ = tid, i1_ = tid + 1024;                                       \
-        const bool in0_ = i0_ < (len_), in1_ = i1_ < (len_);                              \
-        /* unconditional reads: slots past the step's end (and eb_[-1], eb_[2048]) hold stale */ \
-        /* but readable LDS words; what they yield is masked by in0_/in1_/h0_/h1_ below      */ \
-        const uint32_t a0_ = eb_[i0_], a1_ = eb_[i1_];                                    \
-        const uint32_t b0_ = eb_[(int)i0_ - 1], b1_ = eb_[i1_ - 1];                       \
-        const uint32_t n0_ = eb_[i0_ + 1], n1_ = eb_[i1_ + 1];                            \
-        const uint32_t r0_ = a0_ >> 17, r1_ = a1_ >> 17;                                  \
-        const bool h0_ = in0_ && (i0_ == 0 || (b0_ >> 17) != r0_);                        \
-        const bool h1_ = in1_ && (b1_ >> 17) != r1_;                                      \
-        const float v0_ = lut[slice_[a0_ & (kLtBlock - 1)]], v1_ = lut[slice_[a1_ & (kLtBlock - 1)]]; \
-        const float c0_ = acc[r0_ < kLtMaxRows ? r0_ : 0], c1_ = acc[r1_ < kLtMaxRows ? r1_ : 0]; \
-        const bool more0_ = h0_ && i0_ + 1 < (len_) && (n0_ >> 17) == r0_;                \
-        const bool more1_ = h1_ && i1_ + 1 < (len_) && (n1_ >> 17) == r1_;                \
-        float s0_ = c0_ + v0_, s1_ = c1_ + v1_;                                           \
-        if (more0_)                                                                       \
-            for (uint32_t k_ = i0_ + 1; k_ < (len_) && (eb_[k_] >> 17) == r0_; ++k_) s0_ += lut[slice_[eb_[k_] & 0x1FFFF]]; \
-        if (more1_)                                                                       \
-            for (uint32_t k_ = i1_ + 1; k_ < (len_) && (eb_[k_] >> 17) == r1_; ++k_) s1_ += lut[slice_[eb_[k_] & 0x1FFFF]]; \
-        if (h0_) acc[r0_] = s0_;                                                          \
-        if (h1_) acc[r1_] = s1_;                                                          \
-    }
-    // One loop does everything, warm-up included: at time u the workgroup processes step u (if u >= 0),
-    // moves step u + 1 from its ring slot to LDS and refills that slot with step u + 5.  The loads are
-    // unconditional and come in the same order on every trip (u starts at -8 with clamped, useless loads),
-    // so the compiler's load counters stay exact: a store waits for the loads of four steps ago and
-    // nothing younger.  (With a separate prologue the counters merged pessimistically at the loop head
-    // and every fourth step drained all loads in flight.)
-    u32x4 sr0[SW], sr1[SW], sr2[SW], sr3[SW];
-    uint32_t en0[J], en1[J], en2[J], en3[J];
-    uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0;       // lengths of the steps whose data sit in ring slots 0..3
-    const int nsteps = (int)(st1 - st0);
-    uint32_t lcur = 0;                             // length of the step about to be processed
-    uint4 dn = steps[st0];                         // descriptor of the next step to load (u + 5 clamped to 0)
-#define LT_STEP(u_, sr_, en_, l_)                                        \
-    {                                                                    \
-        if ((u_) >= 0) {                                                 \
-            __syncthreads();                                             \
-            LT_PROCESS((u_), lcur)                                       \
-        }                                                                \
-        LT_STORE((u_) + 1, sr_, en_)                                     \
-        lcur = l_;                                                       \
-        const uint4 dl_ = dn;                                            \
-        const int nx_ = (u_) + 6;                                        \
-        dn = steps[st0 + (uint32_t)(nx_ > 0 ? nx_ : 0)];                 \
-        LT_LOAD(dl_, sr_, en_)                                           \
-        l_ = ((u_) + 5 >= 0) ? dl_.z : 0u;                               \
-    }
-    // ring slot of step s is s & 3; at time u the slot of step u + 1 is stored and refilled
-    for (int u = -8; u < nsteps; u += 4) {
-        LT_STEP(u, sr1, en1, l1)
-        LT_STEP(u + 1, sr2, en2, l2)
-        LT_STEP(u + 2, sr3, en3, l3)
-        LT_STEP(u + 3, sr0, en0, l0)
-    }
-#undef LT_STEP
-#undef LT_PROCESS
-#undef LT_STORE
-#undef LT_LOAD
-    __syncthreads();
-    for (uint32_t i = tid; i < rows_per_chunk && row0 + i < n; i += 1024) agg[row0 + i] = acc[i];
+    for (uint32_t i = lane; i < slice_rows && row0 + i < n; i += 64) agg[row0 + i] = A[i];
 }
 
 // ---- compact-table plan of the 16-wide stages ---------------------------------------------------
@@ -1244,13 +1347,6 @@ __global__ __launch_bounds__(256) void k_c4_compact(const float4 *__restrict__ f
     if (__any(negative) && (threadIdx.x & 63) == 0) atomicAnd(&desc[0], 0u);
 }
 
-// whole-wave shifts by one lane (DPP wave_shl / wave_shr, zero shifted in)
-__device__ __forceinline__ uint32_t lane_next(uint32_t x) {   // lane i <- lane i + 1
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xF, 0xF, true);
-}
-__device__ __forceinline__ uint32_t lane_prev(uint32_t x) {   // lane i <- lane i - 1
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xF, 0xF, true);
-}
 __device__ __forceinline__ f32x4 lane_next(f32x4 v) {
     f32x4 r;
 #pragma unroll
@@ -2322,8 +2418,19 @@ hipError_t launch_stage0_blocked(const StagePlan &sp, const GraphDev &g, float w
 }
 
 // ---- LDS-table plan of the F = 1 stage ----------------------------------------------------
-uint32_t lds_table_max_rows() { return kLtMaxRows; }
-uint32_t lds_table_block() { return kLtBlock; }
+uint32_t lds_table_max_rows() { return 16u * kLtwSliceRows; }
+uint32_t lds_table_block() { return kLtwBlock; }
+uint32_t lds_table_step() { return kLtwStep; }
+uint32_t lds_table_record_words() { return kLtwRec; }
+
+hipError_t lds_table_wsteps(const GraphDev &g, uint32_t slice_rows, uint32_t nchunks, uint32_t nblocks, const uint32_t *seg_cnt,
+                            const uint32_t *step_ptr, uint32_t *step_count, uint32_t *recs, bool write, uint32_t slack,
+                            hipStream_t stream) {
+    if (slack < 3u * nblocks + 4u) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_ltw_steps, dim3((nchunks + 63) / 64), dim3(64), 0, stream, g, slice_rows, nchunks, nblocks, seg_cnt,
+                       step_ptr, step_count, recs, write ? 1 : 0, kLtwStep, slack);
+    return hipGetLastError();
+}
 
 hipError_t lds_table_bytes(const uint32_t *w, uint32_t n, uint8_t *wb, uint32_t *bad, hipStream_t stream) {
     if (!n) return hipSuccess;
@@ -2366,25 +2473,28 @@ hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float
                                    float *out, uint32_t row_lo, uint32_t row_hi, uint32_t rows_per_chunk,
                                    const uint32_t *step_ptr, const void *steps, const uint32_t *entries, const uint8_t *wbyte,
                                    float *acc, uint32_t *bad, uint32_t long_thresh, bool mfma, bool interleave,
-                                   hipStream_t stream, const EmitArgs &emit) {
+                                   hipStream_t stream, const EmitArgs &emit, uint32_t last_entry) {
     if (row_hi <= row_lo) return hipSuccess;
-    if (sp.variant != 0 || rows_per_chunk == 0 || rows_per_chunk > kLtMaxRows || g.nnz == 0) return hipErrorInvalidValue;
+    if (sp.variant != 0 || rows_per_chunk == 0 || rows_per_chunk > 16u * kLtwSliceRows || rows_per_chunk % 16u || g.nnz == 0)
+        return hipErrorInvalidValue;
     // does this forward's input match the table?  decided on the device: no host round trip
     hipError_t rc = hipMemsetAsync(bad, 0, sizeof(uint32_t), stream);
     if (rc != hipSuccess) return rc;
     hipLaunchKernelGGL(k_lt_check_x, dim3(std::min<unsigned>((g.n + 255) / 256, 4096u)), dim3(256), 0, stream, x, g.w, ws, g.n,
                        bad);
     const uint32_t c0 = row_lo / rows_per_chunk, c1 = (row_hi - 1) / rows_per_chunk;
-    constexpr size_t lds = (size_t)kLtMaxRows * 4 + 1024 + 2 * kLtStep * 4 + 2 * kLtBlock;
-    static_assert(lds <= 160 * 1024, "LDS budget of k_lt_agg");
+    const uint32_t slice_rows = rows_per_chunk / 16u;
+    constexpr size_t lds_max = (size_t)16 * kLtwSliceRows * 4 + 1024 + kLtwBlock;
+    static_assert(lds_max <= 160 * 1024, "LDS budget of k_lt_agg");
+    const size_t lds = (size_t)16 * slice_rows * 4 + 1024 + kLtwBlock;
     static bool attr_set = false;
     if (!attr_set) {
-        rc = hipFuncSetAttribute(reinterpret_cast<const void *>(k_lt_agg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        rc = hipFuncSetAttribute(reinterpret_cast<const void *>(k_lt_agg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         if (rc != hipSuccess) return rc;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_lt_agg, dim3(c1 - c0 + 1), dim3(1024), lds, stream, step_ptr, reinterpret_cast<const uint4 *>(steps),
-                       entries, wbyte, ws, acc, g.n, rows_per_chunk, c0, (uint32_t)(g.nnz - 1), bad);
+    hipLaunchKernelGGL(k_lt_agg, dim3(c1 - c0 + 1), dim3(1024), lds, stream, step_ptr, reinterpret_cast<const uint32_t *>(steps),
+                       entries, wbyte, ws, acc, g.n, slice_rows, c0, last_entry, bad);
     const uint32_t ntiles = (row_hi - row_lo + kWave - 1) / kWave;
     const uint32_t per_xcd = (ntiles + 7) / 8;
     const uint32_t blocks_per_xcd = (per_xcd + kWavesPerBlock - 1) / kWavesPerBlock;

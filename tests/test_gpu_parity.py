@@ -444,8 +444,8 @@ def _dense_graph(n, deg, seed):
 
 @pytest.mark.parametrize("maker,force", [
     (lambda: gg.erdos_renyi(20000, 200000, 61), 1),
-    (lambda: gg.erdos_renyi(70000, 400000, 62), 1),                    # three column blocks of 32768
-    (lambda: _dense_graph(3000, 300, 63), 1),                          # runs of ~300 entries, cut by the 2048-entry steps
+    (lambda: gg.erdos_renyi(200000, 900000, 62), 1),                   # three column blocks of 81920
+    (lambda: _dense_graph(3000, 300, 63), 1),                          # runs of ~300 entries: longer than a lane, a wave, a 256-entry step
     (lambda: gg.hub_graph(20000, 60000, 3, 4096, seed=7), 2),          # forced on a skewed graph: 4096-entry runs
     (lambda: gg.from_edge_list(130, [(0, i) for i in range(1, 40)], list(range(20, 150))), 1),
     (lambda: gg.from_edge_list(5, [], [20, 30, 40, 50, 60]), 1),       # no entries at all: the plan steps aside
@@ -512,11 +512,12 @@ def test_lds_table_plan_steps_aside(model_text, oracle_model):
         e.set_option("blocked_stage0", 0)
         g = gg.erdos_renyi(6000, 40000, 64)
         big_w = gg.CsrGraph(g.n, g.rowptr, g.col, g.w * 3, gg.neighbourhood_weights(g.rowptr, g.col, g.w * 3))
-        g7 = gg.erdos_renyi(70000, 300000, 65)          # three column blocks: descending lists visit them backwards
+        g7 = gg.erdos_renyi(200000, 800000, 65)         # three column blocks: descending lists visit them backwards
         rp = g7.rowptr.astype(np.int64)
         col = g7.col.copy()
-        for u in range(g7.n):
-            col[rp[u]:rp[u + 1]] = col[rp[u]:rp[u + 1]][::-1]
+        row = np.repeat(np.arange(g7.n), np.diff(rp))
+        k = np.arange(rp[-1]) - rp[row]
+        col[: rp[-1]] = g7.col[rp[row + 1] - 1 - k]     # every adjacency list reversed
         unsorted = gg.CsrGraph(g7.n, g7.rowptr, col, g7.w, g7.nw)
         hubs = gg.hub_graph(20000, 60000, 3, 4096, seed=7)
         for gr in (big_w, unsorted, hubs):

@@ -75,4 +75,4 @@ for rep in range(3):
 same = all(torch.equal(out[st][lo:hi].view(torch.int32), full[st][lo:hi].view(torch.int32)) for st in range(3))
 print(f"prepare={prepare} identical={same} plan rows [{lo},{hi}) chunks={e.get_info('compact_gather_chunks')}")
 print(f"rank 0 of {P}: per-stage compute {[round(t, 3) for t in times]} ms, sum {sum(times):.3f} ms "
-      f"(whole graph on one GPU / P = {5.96 / P:.3f} ms)")
+      f"(whole graph on one GPU / P = {4.79 / P:.3f} ms)")
