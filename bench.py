@@ -118,8 +118,12 @@ def main() -> int:
     dev_index = local_rank % torch.cuda.device_count()   # == local_rank on a real multi-GPU node
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # rehearsal on one GPU: GNNVC_BENCH_ONE_RANK_GROUP=1 runs the partitioned path (pieces, packed exchange, RCCL
+    # calls on a one-rank group) instead of the single-GPU forward
+    multi = world > 1 or bool(os.environ.get("GNNVC_BENCH_ONE_RANK_GROUP"))
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -196,7 +200,7 @@ def main() -> int:
     engine_stage_ms = []
 
     def step(k: int | None):
-        if world == 1:
+        if not multi:
             # one GPU: the whole forward inside the engine (its own feature buffers; per-stage HIP events on this
             # stream are read back after the timed region)
             eng.forward_device(x.data_ptr(), fwd_scores.data_ptr(), 0)
@@ -232,7 +236,7 @@ def main() -> int:
             print(f"[rank {rank} +{time.time() - t_start:.1f}s] {what}", file=sys.stderr, flush=True)
 
     t_start = time.time()
-    codec = G.EngineRowCodec(eng) if (world > 1 and args.compress_exchange) else None
+    codec = G.EngineRowCodec(eng) if (multi and args.compress_exchange) else None
     mark("setup done")
     def settle():
         if os.environ.get("GNNVC_BENCH_NO_SETTLE"):
@@ -240,7 +244,7 @@ def main() -> int:
         # outside the timed region the ranks are kept in step: the per-graph plans are built inside the second
         # forward (host-synchronous pieces of work of different length on every rank)
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
 
     if codec is not None:
@@ -254,25 +258,25 @@ def main() -> int:
         settle()
         mark(f"warm-up {i} done")
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     exchange_ok = D.exchange_verified(bufs) if codec is not None else True   # no shipped row hid a non-zero
 
-    if world == 1:
+    if not multi:
         # the engine's own HIP events (same stream) around each stage of the last timed forward; the mean step time
         # of the K timed forwards is ms_per_step
         stage_ms = list(engine_stage_ms[0])
@@ -302,13 +306,13 @@ def main() -> int:
         # (inside a whole forward the producing stage kernel counts and compacts: no k_column_counts, and
         # k_c4_compact leaves at once)
         (["k_c4_agg", "k_c4_choose", "k_c4_compact", "k_c4_fix", "k_stage_f16<32,32,16," + agg_only] +
-         (["k_column_counts"] if world > 1 else []) if c4 else ["k_stage_f16<32,32,16,false"]),
+         (["k_column_counts"] if multi else []) if c4 else ["k_stage_f16<32,32,16,false"]),
         (["k_c4_agg", "k_c4_choose", "k_c4_compact", "k_c4_fix", "k_stage_f16<32,16,1,true,2,false,false,true>"] +
-         (["k_column_counts"] if world > 1 else []) if c4 else ["k_stage_f16<32,16,1,true"])]
+         (["k_column_counts"] if multi else []) if c4 else ["k_stage_f16<32,16,1,true"])]
     kernel_names = [k[0] for k in stage_kernels]
 
     # (the PMC summary is a single-GPU run of whole-range launches: not comparable with a rank's pieces)
-    traffic, traffic_src = measured_traffic(stage_kernels[dom], args.workload) if world == 1 else (None, None)
+    traffic, traffic_src = measured_traffic(stage_kernels[dom], args.workload) if not multi else (None, None)
     out = {
         "metric": "GNN forward edges/sec", "value": edges_per_s, "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -316,7 +320,7 @@ def main() -> int:
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload_desc, "vertices": g.n, "edges": g.n_edges,
                    "graph": args.workload, "partition": f"1d-vertex x{world} ({part_mode}-balanced)",
-                   "exchange": "none" if world == 1 else "all-gather of the N feature rows (16 fp32, or only their live "
+                   "exchange": "none" if not multi else "all-gather of the N feature rows (16 fp32, or only their live "
                                                           "columns) after each partitioned stage, N scores at the end"},
         "roofline": {"bound": "hbm", "kernel": kernel_names[dom], "stage": dom, "stage_kernels": stage_kernels[dom],
                      "note": "achieved = algorithmic bytes of the dominant STAGE (SURVEY.md 8d, 64-byte rows, no cache "
@@ -339,7 +343,7 @@ def main() -> int:
                  "interleaved_tiles": bool(eng.get_info("interleaved_tiles")), "long_rows": eng.get_info("long_rows"), "long_row_threshold": eng.get_info("long_row_threshold")},
     }
 
-    if world > 1:
+    if multi:
         # self-check: the partitioned result on THIS rank against a plain single-GPU forward of
         # the same graph on this GPU (outside the timed region)
         ref_sc = torch.zeros(g.n, dtype=torch.float32, device=dev)
@@ -364,7 +368,7 @@ def main() -> int:
                               for st, pk in sorted(bufs.live.items())}}
         if not exchange_ok:
             out["invalid"] = "an exception list of the compressed exchange overflowed in the timed region"
-    if rank == 0 and world == 1:
+    if rank == 0 and not multi:
         if args.host_path:
             # PCIe-inclusive path (host x in, host scores + logits out); never `value`
             import numpy as np
@@ -380,7 +384,7 @@ def main() -> int:
     if rank == 0:
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
     return 0
 
