@@ -586,13 +586,14 @@ int build_compact(gnnvc_engine *e, uint32_t base = 0, uint32_t end = 0xFFFFFFFFu
         range_nnz = rp[1] - rp[0];
         if (range_nnz == 0) return GNNVC_OK;
     }
-    // column blocks: wide enough that a slice brings about 160 entries per block (one 256-entry step with room for
-    // the spread: a segment of 257 costs a second step that the other waves of the workgroup wait for), but at
+    // column blocks: wide enough that a slice brings about 160 entries per block (5/6 of a 192-entry step: room for
+    // the spread — a segment of 193 costs a second step that the other waves of the workgroup wait for; measured
+    // on the metric graph: 0.70 / 0.78 / 0.83 / 0.88 / 0.93 of a step -> 4.71 / 4.66 / 4.65 / 4.82 / 5.26 ms), but at
     // most 160 K vertices = 2.5 MiB of table, which still sits in an XCD's 4 MiB L2 while its 32 CUs sweep it
     uint32_t bc = gnnvc::compact_block();
     {
         const double per_slice = (double)range_nnz / slices;
-        const double want = 160.0 * g.n / std::max(per_slice, 1.0);
+        const double want = (gnnvc::compact_step() * 5.0 / 6.0) * g.n / std::max(per_slice, 1.0);
         bc = (uint32_t)std::min(160.0 * 1024, std::max(32.0 * 1024, want)) / 1024u * 1024u;
     }
     const uint32_t nblocks = (g.n + bc - 1) / bc;

@@ -1251,7 +1251,8 @@ constexpr uint32_t kC4Shift = 18;         // entries: row_local << 18 | col_loca
 constexpr uint32_t kC4Slices = 16;        // slices per chunk = waves per workgroup
 constexpr uint32_t kC4SliceRows = 632;    // rows per slice: 16 x (16 B x rows + dirty bits) <= 160 KiB
 constexpr uint32_t kC4MaxRows = kC4Slices * kC4SliceRows;
-constexpr uint32_t kC4Step = 256;         // entries per step: four consecutive ones per lane
+constexpr int kC4LaneEntries = 3;         // consecutive entries a lane takes per step
+constexpr uint32_t kC4Step = 64u * kC4LaneEntries;   // entries per step
 constexpr uint32_t kC4DirtyWords = (kC4SliceRows + 31) / 32;
 constexpr uint32_t kC4NoRow = (1u << (32 - kC4Shift)) - 1u;   // row field of a slot past the step's end
 static_assert(kC4SliceRows < kC4NoRow - 1u, "row field too narrow");
@@ -1390,20 +1391,22 @@ __global__ __launch_bounds__(1024) void k_c4_agg(const uint32_t *__restrict__ st
         if (lane < kC4DirtyWords) dirty[lane] = 0;
         const uint32_t st0 = __builtin_amdgcn_readfirstlane(step_ptr[wc]);
         const int nsteps = (int)(__builtin_amdgcn_readfirstlane(step_ptr[wc + 1]) - st0);   // a multiple of 4 (0 for the empty slice)
-        uint4 e[4];                          // entries of step s in slot s & 3
-        f32x4 v[2][4];                       // gathered rows of step s in slot s & 1
+        constexpr int E = kC4LaneEntries;
+        uint32_t e[4][E];                    // entries of step s in slot s & 3
+        f32x4 v[2][E];                       // gathered rows of step s in slot s & 1
         uint32_t cb[4], cnt[4], bk[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             cb[a] = 0;
             bk[a] = 0;
             cnt[a] = 0;
-            e[a] = uint4{0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < E; ++k) e[a][k] = 0;
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[a][k] = f32x4{0, 0, 0, 0};
+            for (int k = 0; k < E; ++k) v[a][k] = f32x4{0, 0, 0, 0};
         uint4 dsc = steps[st0];              // descriptor of the step whose entries are loaded next
         int dsc_step = 0;
         for (int u = -4; u < nsteps; u += 4) {
@@ -1418,9 +1421,16 @@ __global__ __launch_bounds__(1024) void k_c4_agg(const uint32_t *__restrict__ st
                     cb[slot] = dsc.x * block_cols;
                     bk[slot] = dsc.x;
                     cnt[slot] = count;
-                    const uint32_t x = first + 4u * lane;                    // first is a multiple of 4
-                    const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(entries + (x < last_entry ? x : last_entry)));
-                    e[slot] = uint4{q[0], q[1], q[2], q[3]};
+                    const uint32_t x0 = first + (uint32_t)E * lane;          // first is a multiple of 4
+                    const uint32_t x = x0 < last_entry ? x0 : last_entry;
+                    if constexpr (E == 4) {
+                        const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(entries + x));
+#pragma unroll
+                        for (int k = 0; k < E; ++k) e[slot][k] = q[k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < E; ++k) e[slot][k] = __builtin_nontemporal_load(entries + x + k);
+                    }
                     const int nx = se + 1;
                     const int nxc = nx < 0 ? 0 : (nx < nsteps ? nx : (nsteps > 0 ? nsteps - 1 : 0));
                     dsc = steps[st0 + (uint32_t)nxc];
@@ -1429,11 +1439,10 @@ __global__ __launch_bounds__(1024) void k_c4_agg(const uint32_t *__restrict__ st
                 {   // gather step s + 1
                     const int slot = (j + 1) & 3;
                     const int vs = (j + 1) & 1;
-                    const uint32_t w[4] = {e[slot].x, e[slot].y, e[slot].z, e[slot].w};
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const uint32_t c = cb[slot] + (w[k] & ((1u << kC4Shift) - 1u));
-                        const bool in = 4u * lane + k < cnt[slot];
+                    for (int k = 0; k < E; ++k) {
+                        const uint32_t c = cb[slot] + (e[slot][k] & ((1u << kC4Shift) - 1u));
+                        const bool in = (uint32_t)E * lane + k < cnt[slot];
                         v[vs][k] = table[(in && c < n) ? c : n];             // row n: the zero row
                     }
                 }
@@ -1446,71 +1455,69 @@ __global__ __launch_bounds__(1024) void k_c4_agg(const uint32_t *__restrict__ st
                             ++cur_blk;
                         }
                     if (cnt[slot]) {
-                        const uint32_t w[4] = {e[slot].x, e[slot].y, e[slot].z, e[slot].w};
-                        uint32_t r[4];
-                        f32x4 a[4], val[4];
+                        uint32_t r[E];
+                        f32x4 a[E], val[E];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            r[k] = (4u * lane + k < cnt[slot]) ? (w[k] >> kC4Shift) : kC4NoRow;
+                        for (int k = 0; k < E; ++k) {
+                            r[k] = ((uint32_t)E * lane + k < cnt[slot]) ? (e[slot][k] >> kC4Shift) : kC4NoRow;
                             a[k] = A[r[k] < slice_rows ? r[k] : 0];
                         }
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {   // a flagged table row (stray non-zeros) dirties the entry's row
+                        for (int k = 0; k < E; ++k) {   // a flagged table row (stray non-zeros) dirties the entry's row
                             val[k] = v[vs][k];
                             const uint32_t f = __float_as_uint(val[k][0]);
                             if ((f >> 31) && r[k] != kC4NoRow) atomicOr(&dirty[r[k] >> 5], 1u << (r[k] & 31));
                             val[k][0] = __uint_as_float(f & 0x7FFFFFFFu);
                         }
-                        uint32_t prev3 = lane_prev(r[3]);
-                        if (lane == 0) prev3 = kC4NoRow - 1u;
-                        const bool h0 = r[0] != kC4NoRow && r[0] != prev3;
-                        const bool h1 = r[1] != kC4NoRow && r[1] != r[0];
-                        const bool h2 = r[2] != kC4NoRow && r[2] != r[1];
-                        const bool h3 = r[3] != kC4NoRow && r[3] != r[2];
-                        uint32_t nr[4];      // the next lane's rows and values
-                        f32x4 nv[4];
+                        uint32_t prevr = lane_prev(r[E - 1]);
+                        if (lane == 0) prevr = kC4NoRow - 1u;
+                        bool h[E];           // the entry starts a run
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
+                        for (int k = 0; k < E; ++k) h[k] = r[k] != kC4NoRow && r[k] != (k ? r[k - 1] : prevr);
+                        uint32_t nr[E];      // the next lane's rows and values
+                        f32x4 nv[E];
+#pragma unroll
+                        for (int k = 0; k < E; ++k) {
                             nr[k] = lane_next(r[k]);
                             nv[k] = lane_next(val[k]);
                             if (lane == 63) nr[k] = kC4NoRow;
                         }
                         // lane-local folds (a row's entries are adjacent: r[2] == r[0] implies r[1] == r[0])
-                        f32x4 s0 = a[0] + val[0];
-                        s0 += c4_sel(r[1] == r[0], val[1]);
-                        s0 += c4_sel(r[2] == r[0], val[2]);
-                        s0 += c4_sel(r[3] == r[0], val[3]);
-                        f32x4 s1 = a[1] + val[1];
-                        s1 += c4_sel(r[2] == r[1], val[2]);
-                        s1 += c4_sel(r[3] == r[1], val[3]);
-                        f32x4 s2 = a[2] + val[2];
-                        s2 += c4_sel(r[3] == r[2], val[3]);
-                        f32x4 s3 = a[3] + val[3];
+                        f32x4 sum[E];
+#pragma unroll
+                        for (int i = 0; i < E; ++i) {
+                            sum[i] = a[i] + val[i];
+#pragma unroll
+                            for (int j = i + 1; j < E; ++j) sum[i] += c4_sel(r[j] == r[i], val[j]);
+                        }
                         // the run that holds this lane's last entry goes on in the next lane(s); it is this lane's to
                         // finish iff it starts here
-                        const bool o0 = h0 && r[0] == r[3], o1 = h1 && r[1] == r[3], o2 = h2 && r[2] == r[3], o3 = h3;
-                        f32x4 x = o0 ? s0 : o1 ? s1 : o2 ? s2 : s3;
-                        bool more = (o0 || o1 || o2 || o3) && r[3] != kC4NoRow;
+                        bool o[E], any_o = false;
+                        f32x4 x = sum[E - 1];
+#pragma unroll
+                        for (int i = E - 1; i >= 0; --i) {
+                            o[i] = h[i] && r[i] == r[E - 1];
+                            any_o = any_o || o[i];
+                            if (o[i]) x = sum[i];
+                        }
+                        bool more = any_o && r[E - 1] != kC4NoRow;
                         for (;;) {
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) x += c4_sel(more && nr[k] == r[3], nv[k]);
-                            more = more && nr[3] == r[3];
+                            for (int k = 0; k < E; ++k) x += c4_sel(more && nr[k] == r[E - 1], nv[k]);
+                            more = more && nr[E - 1] == r[E - 1];
                             if (!__any(more)) break;
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) {   // one lane further
+                            for (int k = 0; k < E; ++k) {   // one lane further
                                 nr[k] = lane_next(nr[k]);
                                 nv[k] = lane_next(nv[k]);
                                 if (lane == 63) nr[k] = kC4NoRow;
                             }
                         }
-                        if (o0) s0 = x;
-                        if (o1) s1 = x;
-                        if (o2) s2 = x;
-                        if (o3) s3 = x;
-                        if (h0) A[r[0]] = s0;
-                        if (h1) A[r[1]] = s1;
-                        if (h2) A[r[2]] = s2;
-                        if (h3) A[r[3]] = s3;
+#pragma unroll
+                        for (int i = 0; i < E; ++i) {
+                            if (o[i]) sum[i] = x;
+                            if (h[i]) A[r[i]] = sum[i];
+                        }
                     }
                 }
             }

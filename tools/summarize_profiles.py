@@ -24,7 +24,9 @@ def short(name: str) -> str:
     return n
 
 
-stats = glob.glob(str(SRC / "trace" / "*" / "*_kernel_stats.csv"))
+import os
+# (gpurun merges a run's files into gpurun_out/ without removing an earlier run's: take the newest of each kind)
+stats = sorted(glob.glob(str(SRC / "trace" / "*" / "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)
 if stats:
     rows = list(csv.reader(open(stats[0])))
     keep = [rows[0]] + [[short(r[0])] + r[1:] for r in rows[1:] if "gnnvc" in r[0]]
@@ -39,7 +41,12 @@ if log.exists():
 # per kernel and counter: the value of the LAST launch of the run (steady state: the first forward runs
 # without the per-graph plans, the second builds them)
 agg = collections.defaultdict(dict)
+newest = {}
 for p in glob.glob(str(SRC / "p_*" / "*" / "*_counter_collection.csv")):
+    grp = pathlib.Path(p).parts[-3]
+    if grp not in newest or os.path.getmtime(p) > os.path.getmtime(newest[grp]):
+        newest[grp] = p
+for p in newest.values():
     for r in csv.DictReader(open(p)):
         k = short(r["Kernel_Name"])
         if k:
