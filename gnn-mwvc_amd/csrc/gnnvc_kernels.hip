@@ -1246,7 +1246,7 @@ __global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ st
 //                 exactly what the plain gather produces; then the dense layers as always.
 // desc words: [0] ok (1 = the plan applies to this input), [1..4] the chosen columns (ascending).
 constexpr uint32_t kC4Block = 131072;     // default vertices per column block: 2 MiB of compact rows (the engine sizes the
-                                          // blocks so that a slice has about 160 entries per block: one step, 40 lanes busy)
+                                          // blocks so that a slice has about 160 entries per block: one step, 54 lanes busy)
 constexpr uint32_t kC4Shift = 18;         // entries: row_local << 18 | col_local (blocks of up to 262144 vertices)
 constexpr uint32_t kC4Slices = 16;        // slices per chunk = waves per workgroup
 constexpr uint32_t kC4SliceRows = 632;    // rows per slice: 16 x (16 B x rows + dirty bits) <= 160 KiB
@@ -1361,12 +1361,13 @@ __device__ __forceinline__ f32x4 c4_sel(bool c, f32x4 v) {
 
 // The sums.  A WAVE owns a slice of rows: its sums live in its own part of LDS and it walks its own entry
 // stream, regrouped per (slice, column block) into steps of <= 256 entries (a row's entries of one block are
-// adjacent and in order; a segment starts at a multiple of 4).  A lane takes FOUR CONSECUTIVE entries of the
-// step with one 16-byte load, gathers their four table rows, and the lane that gathers a row is the lane that
+// adjacent and in order; a segment starts at a multiple of 4).  A lane takes kC4LaneEntries = 3 CONSECUTIVE entries
+// of the step with one 12-byte load, gathers their table rows, and the lane that gathers a row is the lane that
 // adds it: runs of the same row are folded lane-locally, a run that reaches the lane's last entry goes on
-// with the next lane's entries (one whole-wave DPP shift of its 4 rows and 4 values; more shifts only for
-// runs longer than a lane), and every row written in a step is written by exactly one lane — so the four LDS
-// reads of a lane are issued together.  LDS operations of one wave execute in order, hence no barrier is needed
+// with the next lane's entries (one whole-wave DPP shift of its rows and values; more shifts only for
+// runs longer than a lane), and every row written in a step is written by exactly one lane — so the LDS
+// reads of a lane are issued together.  (Three entries per lane: lanes past a step's end still cost their slot
+// in the texture-address path, and 192-entry steps are 83 % full where 256-entry ones are 62 %.)  LDS operations of one wave execute in order, hence no barrier is needed
 // for the sums; the one barrier per column block only keeps the 16 waves of a workgroup (and, since all
 // workgroups do the same work, the chip) in the same block, which is what keeps the block in L2.
 // Loads are unconditional and in the same order on every trip so that the hardware counters are waited on
