@@ -111,6 +111,7 @@ struct gnnvc_engine {
     int opt_blocked = 1;            // option "blocked_stage0"
     uint32_t opt_block_cols = 0;    // option "block_cols" (0 = default)
     uint32_t opt_blocked_min_n = 1u << 20;  // below this x fits the L2s anyway
+    uint32_t opt_plan_chunk_rows = 0;       // != 0: cap on the rows per chunk of the LDS-table / compact-table plans
     bool blocked_ready = false;
     bool blocked_tried = false;     // build attempted for the current graph
     uint32_t graph_uses = 0;        // stage-0 executions on the current graph
@@ -492,7 +493,9 @@ int build_lds_table(gnnvc_engine *e) {
     if (!e->opt_lds_table || e->stages.empty() || e->stages[0].f != 1 || e->stages[0].variant != 0) return GNNVC_OK;
     if (g.n < e->opt_blocked_min_n || g.nnz == 0 || g.nnz >= (1ull << 31)) return GNNVC_OK;
     if (e->opt_lds_table < 2 && (e->sorted_wanted || e->n_long > 0)) return GNNVC_OK;   // long runs would serialise in one thread
-    const uint32_t bc = gnnvc::lds_table_block(), max_rows = gnnvc::lds_table_max_rows();
+    const uint32_t bc = gnnvc::lds_table_block();
+    uint32_t max_rows = gnnvc::lds_table_max_rows();
+    if (e->opt_plan_chunk_rows) max_rows = std::min(max_rows, std::max(16u, e->opt_plan_chunk_rows / 16u * 16u));
     const uint32_t nblocks = (g.n + bc - 1) / bc;
     if (nblocks > 4096) return GNNVC_OK;
     // chunks: a multiple of the 256 CUs, each within the LDS budget; a chunk = 16 slices of rows (one per wave)
@@ -570,7 +573,9 @@ int build_compact(gnnvc_engine *e, uint32_t base = 0, uint32_t end = 0xFFFFFFFFu
     if (e->opt_compact < 2 && (e->sorted_wanted || e->n_long > 0)) return GNNVC_OK;
     if (e->n_long > 0) return GNNVC_OK;   // (the long-row kernels write their rows themselves)
     // a chunk = 16 slices (one per wave of the workgroup that sums it); the plan is laid out per slice
-    const uint32_t max_rows = gnnvc::compact_max_rows(), nsl = gnnvc::compact_slices();
+    const uint32_t nsl = gnnvc::compact_slices();
+    uint32_t max_rows = gnnvc::compact_max_rows();
+    if (e->opt_plan_chunk_rows) max_rows = std::min(max_rows, std::max(nsl, e->opt_plan_chunk_rows / nsl * nsl));
     uint32_t chunks = (span + max_rows - 1) / max_rows;
     chunks = (chunks + 255u) / 256u * 256u;
     uint32_t rows = (span + chunks - 1) / chunks;
@@ -938,6 +943,7 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     if (k == "blocked_stage0") e->opt_blocked = value < 0 ? 0 : (value > 2 ? 2 : (int)value);   // 2 = also on skewed graphs
     else if (k == "block_cols") e->opt_block_cols = value > 0 ? (uint32_t)value : 0;
     else if (k == "blocked_min_n") e->opt_blocked_min_n = value > 0 ? (uint32_t)value : 0;
+    else if (k == "plan_chunk_rows") e->opt_plan_chunk_rows = value > 0 ? (uint32_t)value : 0;
     else if (k == "long_row_threshold") e->opt_long_thresh = value > 0 ? (uint32_t)value : 0;
     else if (k == "compact_gather") e->opt_compact = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else if (k == "lds_table") e->opt_lds_table = value < 0 ? 0 : (value > 2 ? 2 : (int)value);

@@ -624,6 +624,48 @@ def test_compact_gather_plan_is_bit_identical(model_text, oracle_model, case):
         e.close()
 
 
+@pytest.mark.parametrize("chunk_rows,maker", [
+    (16, lambda: gg.erdos_renyi(20000, 200000, 72)),        # one row per wave slice: 1250 chunks, five rounds of the grid
+    (48, lambda: gg.erdos_renyi(20011, 150000, 73)),        # three rows per slice, a ragged last chunk
+    (32, lambda: _dense_graph(3000, 300, 74)),              # 300-entry rows: runs longer than a step in a 2-row slice
+])
+def test_plans_with_many_small_chunks(model_text, oracle_model, chunk_rows, maker):
+    """Both per-graph plans with the chunk size capped ("plan_chunk_rows"): several rounds of the persistent grids,
+    a partial last round, slices of one to three rows — what only the 10 M-vertex graph exercises otherwise."""
+    import torch
+    import gnn_mwvc_amd as G
+    g = maker()
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_option("blocked_min_n", 0)
+        e.set_option("plan_chunk_rows", chunk_rows)
+        e.set_weight_scale(g.ws)
+        oracle_model.set_weight_scale(g.ws)
+        e.upload_graph(g)
+        e.forward(g.x())
+        _, logits = e.forward(g.x())
+        _, again = e.forward(g.x())
+        assert e.get_info("lds_table_active") == 1 and e.get_info("compact_gather_active") == 1
+        rows = e.get_info("compact_gather_rows_per_chunk")          # (at least 256 chunks: small graphs get smaller ones still)
+        assert 16 <= rows <= chunk_rows and e.get_info("compact_gather_chunks") == (g.n + rows - 1) // rows
+        want = oracle_model.logits(g)
+        assert np.array_equal(bits(logits[:, 0]), bits(want)) and np.array_equal(bits(again[:, 0]), bits(want))
+        # the 16-wide stages on an input the compact table certainly takes (the model's own activations may not)
+        rng = np.random.default_rng(chunk_rows)
+        h = _sparse_features(g.n, rng, [1, 6, 10, 15], [1.0, 0.4, 0.2, 1.0], strays=min(7, g.n // 1024))   # (more than n / 512 stray values and the plan steps aside)
+        dev = torch.device("cuda:0")
+        hin = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+        hin[: g.n] = torch.from_numpy(h).to(dev)
+        out = torch.full((g.n + 1, 16), 7.0, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        e.stage_forward_device(1, 0, g.n, hin.data_ptr(), out.data_ptr())
+        e.synchronize()
+        assert e.get_info("compact_gather_last_ok") == 1 and e.get_info("compact_gather_last_dirty") > 0
+        assert np.array_equal(bits(out[: g.n].cpu().numpy()), bits(_oracle_stage(oracle_model, g, 1, h)))
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("world,pieces", [(2, 3), (2, 1), (3, 2), (4, 2)])
 def test_compact_gather_over_a_ranks_rows(model_text, oracle_model, world, pieces):
     """gnnvc_stage_input_ready: the plan chunked over the rows ONE rank of a P-rank run computes, the table written
