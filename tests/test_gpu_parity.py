@@ -624,6 +624,47 @@ def test_compact_gather_plan_is_bit_identical(model_text, oracle_model, case):
         e.close()
 
 
+def test_compact_gather_long_runs(model_text, oracle_model):
+    """k_c4_agg forced onto a skewed graph (three hubs of degree 4096, no long-row kernels): runs of thousands of
+    entries of one row cross lanes, waves' steps and — with small chunks — sit alone in a one-row slice."""
+    import torch
+    import gnn_mwvc_amd as G
+    g = gg.hub_graph(20000, 60000, 3, 4096, seed=7)
+    for chunk_rows in (0, 16):
+        e = G.Engine(model_text, device=0)
+        try:
+            e.set_option("blocked_min_n", 0)
+            e.set_option("compact_gather", 2)
+            e.set_option("lds_table", 2)
+            e.set_option("long_row_threshold", 0)
+            e.set_option("sorted_tiles", 0)
+            e.set_option("plan_chunk_rows", chunk_rows)
+            e.set_weight_scale(g.ws)
+            oracle_model.set_weight_scale(g.ws)
+            e.upload_graph(g)
+            e.forward(g.x())
+            _, logits = e.forward(g.x())
+            assert e.get_info("compact_gather_active") == 1
+            assert np.array_equal(bits(logits[:, 0]), bits(oracle_model.logits(g)))
+            rng = np.random.default_rng(11)
+            h = _sparse_features(g.n, rng, [0, 5, 9, 12], [1.0, 0.3, 0.6, 1.0], strays=5)
+            dev = torch.device("cuda:0")
+            hin = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+            hin[: g.n] = torch.from_numpy(h).to(dev)
+            for stage in (1, 2):
+                out = torch.full((g.n + 1, 16 if stage == 1 else 1), 7.0, dtype=torch.float32, device=dev)
+                lg = torch.full((g.n + 1,), 7.0, dtype=torch.float32, device=dev)
+                torch.cuda.synchronize()
+                e.stage_forward_device(stage, 0, g.n, hin.data_ptr(), out.data_ptr(), lg.data_ptr() if stage == 2 else 0)
+                e.synchronize()
+                assert e.get_info("compact_gather_last_ok") == 1
+                want = _oracle_stage(oracle_model, g, stage, h)
+                got = out[: g.n].cpu().numpy() if stage == 1 else lg[: g.n].cpu().numpy().reshape(-1, 1)
+                assert np.array_equal(bits(got), bits(want)), (chunk_rows, stage)
+        finally:
+            e.close()
+
+
 @pytest.mark.parametrize("chunk_rows,maker", [
     (16, lambda: gg.erdos_renyi(20000, 200000, 72)),        # one row per wave slice: 1250 chunks, five rounds of the grid
     (48, lambda: gg.erdos_renyi(20011, 150000, 73)),        # three rows per slice, a ragged last chunk
