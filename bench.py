@@ -373,10 +373,10 @@ def main() -> int:
             # PCIe-inclusive path (host x in, host scores + logits out); never `value`
             import numpy as np
             xh = x.cpu().numpy()
-            eng.forward(xh)
+            keep = eng.forward(xh)          # the caller's output buffers, reused like the reference's `out` matrix
             t1 = time.perf_counter()
             for _ in range(3):
-                eng.forward(xh)
+                eng.forward(xh, out=keep)
             out["host_path_ms"] = (time.perf_counter() - t1) * 1e3 / 3
         if not args.no_cpu_baseline:
             out["cpu_baseline"], out["parity"] = cpu_baseline(args, dev, eng, ggt)

@@ -240,11 +240,18 @@ class Engine:
         self._keep = keepalive
 
     # -- forward
-    def forward(self, x: np.ndarray, want_logits: bool = True):
-        """Host forward: returns (scores[n, out_width], logits or None)."""
+    def forward(self, x: np.ndarray, want_logits: bool = True, out=None):
+        """Host forward: returns (scores[n, out_width], logits or None).  `out` = (scores, logits) arrays to fill
+        instead of new ones (a caller that times the call keeps first-touch page faults out of it that way)."""
         x = np.ascontiguousarray(x, dtype=np.float32).reshape(self.n, self.in_width)
-        scores = np.empty((self.n, self.out_width), dtype=np.float32)
-        logits = np.empty((self.n, self.out_width), dtype=np.float32) if want_logits else None
+        if out is not None:
+            scores, logits = out
+            for a in (scores, logits) if want_logits else (scores,):
+                if a.dtype != np.float32 or a.shape != (self.n, self.out_width) or not a.flags.c_contiguous:
+                    raise ValueError("out arrays must be C-contiguous float32 of shape (n, out_width)")
+        else:
+            scores = np.empty((self.n, self.out_width), dtype=np.float32)
+            logits = np.empty((self.n, self.out_width), dtype=np.float32) if want_logits else None
         self._check(self._L.gnnvc_forward(self._h, _np_ptr(x), _np_ptr(scores),
                                           _np_ptr(logits) if want_logits else None))
         return scores, logits
