@@ -78,6 +78,7 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lds-table", action="store_true", help="F = 1 stage without the LDS-table plan")
     ap.add_argument("--no-compact", action="store_true", help="16-wide stages without the compact-table plan")
+    ap.add_argument("--no-overlap", action="store_true", help="dense layers after the sums instead of under the next round's")
     ap.add_argument("--cpu-sample", default="2000000x20000000",
                     help="n x m of the CPU-baseline sample graph")
     ap.add_argument("--no-blocked", action="store_true", help="disable the column-blocked F=1 stage (A/B)")
@@ -146,6 +147,8 @@ def main() -> int:
         eng.set_option("lds_table", 0)
     if args.no_compact:
         eng.set_option("compact_gather", 0)
+    if args.no_overlap:
+        eng.set_option("overlap_dense", 0)
     if args.block_cols:
         eng.set_option("block_cols", args.block_cols)
     if args.long_threshold >= 0:
@@ -305,9 +308,10 @@ def main() -> int:
          ["k_blk_accumulate", "k_stage_f1<32,32,16"] if blk else ["k_stage_f1<32,32,16"]),
         # (inside a whole forward the producing stage kernel counts and compacts: no k_column_counts, and
         # k_c4_compact leaves at once)
-        (["k_c4_agg", "k_c4_choose", "k_c4_compact", "k_c4_fix", "k_stage_f16<32,32,16," + agg_only] +
+        (["k_c4_agg<0>", "k_c4_choose", "k_c4_compact", "k_c4_fix", "k_stage_f16<32,32,16," + agg_only] +
          (["k_column_counts"] if multi else []) if c4 else ["k_stage_f16<32,32,16,false"]),
-        (["k_c4_agg", "k_c4_choose", "k_c4_compact", "k_c4_fix", "k_stage_f16<32,16,1,true,2,false,false,true>"] +
+        # (last stage: the sums one round at a time, k_dense_sigmoid of round k under the sums of round k + 1)
+        ([("k_c4_agg<0>" if args.no_overlap else "k_c4_agg<1>"), "k_c4_choose", "k_c4_compact", "k_c4_fix", "k_dense_sigmoid<32,16>"] +
          (["k_column_counts"] if multi else []) if c4 else ["k_stage_f16<32,16,1,true"])]
     kernel_names = [k[0] for k in stage_kernels]
 

@@ -132,6 +132,9 @@ struct gnnvc_engine {
     DevBuf<uint32_t> c4_entries, c4_segcnt, c4_stepptr, c4_stepcnt, c4_desc;
     DevBuf<uint4> c4_steps;
     DevBuf<float> c4_table, c4_acc, c4_agg16;
+    DevBuf<uint32_t> c4_marks;            // dirty-row slots handed out after each round of the aggregation grid
+    std::vector<hipEvent_t> round_ev;     // "round k's sums are done" (main stream -> aux stream)
+    int opt_overlap = 1;                  // last stage: dense layers of round k under the sums of round k + 1
     DevBuf<uint32_t> c4_dirty;
     uint32_t c4_dirty_cap = 0;
     DevBuf<unsigned long long> c4_counts, c4_emit_counts;
@@ -635,6 +638,7 @@ int build_compact(gnnvc_engine *e, uint32_t base = 0, uint32_t end = 0xFFFFFFFFu
     HIP_TRY(e, e->c4_steps.reserve(total + 8));
     HIP_TRY(e, e->c4_entries.reserve(entry_cap));
     HIP_TRY(e, e->c4_table.reserve(((size_t)g.n + 1) * 4));
+    HIP_TRY(e, e->c4_marks.reserve(64));
     HIP_TRY(e, e->c4_acc.reserve((size_t)g.n * 4));
     e->c4_dirty_cap = g.n;   // rows recomputed from full rows (every row could be one: the dense-only stage kernel never gathers)
     HIP_TRY(e, e->c4_dirty.reserve(e->c4_dirty_cap));
@@ -656,6 +660,20 @@ int build_compact(gnnvc_engine *e, uint32_t base = 0, uint32_t end = 0xFFFFFFFFu
     e->c4_chunks = chunks;
     e->c4_steps_total = (uint32_t)total;
     e->c4_ready = true;
+    return GNNVC_OK;
+}
+
+int ensure_round_events(gnnvc_engine *e, size_t count) {
+    if (!e->aux_stream) {
+        HIP_TRY(e, hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking));
+        HIP_TRY(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+        HIP_TRY(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    }
+    while (e->round_ev.size() < count) {
+        hipEvent_t v;
+        HIP_TRY(e, hipEventCreateWithFlags(&v, hipEventDisableTiming));
+        e->round_ev.push_back(v);
+    }
     return GNNVC_OK;
 }
 
@@ -717,6 +735,13 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
         const gnnvc::SortedOrder *sop = nullptr;
         const float *acc4 = nullptr;
         const uint32_t *c4desc = nullptr;
+        // Last stage under the whole-graph compact-table plan: k_c4_agg is a persistent grid that holds nearly all LDS of
+        // its CUs but leaves most VALU cycles idle, and the dense-only sigmoid kernel that follows is VALU-bound and
+        // needs no LDS.  So the sums are launched one round (256 chunks) at a time and the dense kernel of round k
+        // goes to the aux stream, where it runs under the sums of round k + 1 (the last round's stays on the main
+        // stream, which then waits for the aux stream).  Metric graph: 1.71 -> 1.58 ms.  (Not for the feature
+        // stages: their dense kernels store 64-byte rows and slow the co-running sums by more than is gained.)
+        bool c4_rounds = false;
         if (e->stages[stage].f == 16) {
             if (!e->c4_range_mode && e->graph_uses >= 2 && !e->c4_tried) {
                 int rc = build_compact(e);
@@ -749,9 +774,11 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
                                                         desc, e->c4_table.p, e->c4_acc.p, lo, hi,
                                                         e->c4_rows, e->c4_stepptr.p, e->c4_steps.p, e->c4_entries.p,
                                                         e->c4_dirty.p, e->c4_dirty_cap, e->c4_agg16.p, e->stream, e->c4_block,
-                                                        e->c4_base, e->c4_end, e->c4_last_entry));
+                                                        e->c4_base, e->c4_end, e->c4_last_entry,
+                                                        /*what=*/(e->opt_overlap && e->stages[stage].variant == 2 && e->opt_mfma != 1) ? 1 : 3));
                 acc4 = e->c4_acc.p;
                 c4desc = desc;
+                c4_rounds = e->opt_overlap && e->stages[stage].variant == 2 && e->opt_mfma != 1;
                 if (may_emit) {   // and this stage's own (aggregate-only, VALU) kernel produces for the next one
                     HIP_TRY(e, hipMemsetAsync(e->c4_emit_counts.p, 0, gnnvc::kEmitCounters * sizeof(unsigned long long), e->stream));
                     emit.spec = e->c4_desc.p + 8 * stage;
@@ -771,9 +798,43 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
                 sop = &so;
             }
         }
+        if (sop) c4_rounds = false;   // (the plan forced onto a graph with sorted tiles: the gathering kernel does the stage)
         HIP_TRY(e, gnnvc::launch_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi,
                                        thr, mfma, sop, e->interleave, e->stream, acc4, c4desc, e->c4_agg16.p,
-                                       e->opt_mfma == 1, emit));
+                                       e->opt_mfma == 1, emit, /*dense_part=*/!c4_rounds));
+        if (c4_rounds) {
+            uint32_t *desc = e->c4_desc.p + 8 * (stage - 1);
+            HIP_TRY(e, hipMemsetAsync(desc + 5, 0, sizeof(uint32_t), e->stream));        // dirty-row counter
+            HIP_TRY(e, hipMemsetAsync(e->c4_marks.p, 0, sizeof(uint32_t), e->stream));   // marks[0]
+            const uint32_t rows = e->c4_rows, c0 = (lo - e->c4_base) / rows, c1 = (hi - 1 - e->c4_base) / rows;
+            const uint32_t nrounds = (c1 - c0) / 256u + 1u;
+            if (nrounds + 1 > 64) return fail(e, GNNVC_ERR_UNSUPPORTED, "too many rounds of the compact-table plan");
+            int rc = ensure_round_events(e, nrounds);
+            if (rc) return rc;
+            for (uint32_t k = 0; k < nrounds; ++k) {
+                const uint32_t ca = c0 + 256u * k, cb = std::min(c1 + 1u, ca + 256u);
+                const uint32_t ra = std::max(lo, e->c4_base + ca * rows);
+                const uint32_t rb = (uint32_t)std::min<uint64_t>(hi, (uint64_t)e->c4_base + (uint64_t)cb * rows);
+                HIP_TRY(e, gnnvc::compact_sums(e->g, desc, e->c4_table.p, e->c4_acc.p, ra, rb, rows, e->c4_stepptr.p, e->c4_steps.p,
+                                               e->c4_entries.p, e->c4_dirty.p, e->c4_dirty_cap, e->stream, e->c4_block, e->c4_base,
+                                               e->c4_end, e->c4_last_entry, /*one_round=*/true));
+                HIP_TRY(e, gnnvc::compact_mark(desc, e->c4_marks.p, k + 1, e->stream));
+                const bool last = k + 1 == nrounds;
+                hipStream_t ds = last ? e->stream : e->aux_stream;
+                if (!last) {
+                    HIP_TRY(e, hipEventRecord(e->round_ev[k], e->stream));
+                    HIP_TRY(e, hipStreamWaitEvent(e->aux_stream, e->round_ev[k], 0));
+                }
+                HIP_TRY(e, gnnvc::compact_fix(e->g, in, desc, e->c4_dirty.p, e->c4_dirty_cap, e->c4_agg16.p, e->c4_marks.p + k, ds,
+                                              /*blocks=*/64));
+                HIP_TRY(e, gnnvc::launch_dense_sigmoid(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, ra, rb,
+                                                       e->c4_acc.p, desc, e->c4_agg16.p, ds));
+            }
+            if (nrounds > 1) {
+                HIP_TRY(e, hipEventRecord(e->ev_join, e->aux_stream));
+                HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
+            }
+        }
     }
     if (longs) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));   // join
     return GNNVC_OK;
@@ -911,7 +972,7 @@ void gnnvc_destroy(gnnvc_engine *e) {
     e->lt_bytes.release(); e->lt_entries.release(); e->lt_segcnt.release(); e->lt_stepptr.release();
     e->lt_stepcnt.release(); e->lt_bad.release(); e->lt_steps.release();
     e->c4_entries.release(); e->c4_segcnt.release(); e->c4_stepptr.release(); e->c4_stepcnt.release();
-    e->c4_desc.release(); e->c4_steps.release(); e->c4_table.release(); e->c4_acc.release(); e->c4_counts.release();
+    e->c4_desc.release(); e->c4_steps.release(); e->c4_table.release(); e->c4_marks.release(); e->c4_acc.release(); e->c4_counts.release();
     e->c4_agg16.release(); e->c4_dirty.release(); e->c4_emit_counts.release();
     e->long_list.release(); e->long_count.release();
     e->pin_rowptr.release(); e->pin_col.release(); e->pin_w.release(); e->pin_nw.release();
@@ -921,6 +982,7 @@ void gnnvc_destroy(gnnvc_engine *e) {
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->aux_stream) { (void)hipStreamSynchronize(e->aux_stream); (void)hipStreamDestroy(e->aux_stream); }
     for (auto v : e->ev) (void)hipEventDestroy(v);
+    for (auto v : e->round_ev) (void)hipEventDestroy(v);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
 }
@@ -944,6 +1006,7 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "block_cols") e->opt_block_cols = value > 0 ? (uint32_t)value : 0;
     else if (k == "blocked_min_n") e->opt_blocked_min_n = value > 0 ? (uint32_t)value : 0;
     else if (k == "plan_chunk_rows") e->opt_plan_chunk_rows = value > 0 ? (uint32_t)value : 0;
+    else if (k == "overlap_dense") e->opt_overlap = value != 0 ? 1 : 0;
     else if (k == "long_row_threshold") e->opt_long_thresh = value > 0 ? (uint32_t)value : 0;
     else if (k == "compact_gather") e->opt_compact = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else if (k == "lds_table") e->opt_lds_table = value < 0 ? 0 : (value > 2 ? 2 : (int)value);

@@ -58,7 +58,13 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
                         uint32_t row_hi, uint32_t long_thresh, bool mfma, const SortedOrder *so,
                         bool interleave, hipStream_t stream, const float *acc4 = nullptr,
                         const uint32_t *c4desc = nullptr, const float *agg16 = nullptr, bool mfma_agg = false,
-                        const EmitArgs &emit = EmitArgs());
+                        const EmitArgs &emit = EmitArgs(),
+                        bool dense_part = true /* false: only the gathering kernel (which leaves at once when the compact-table
+                                                  plan applies); the caller launches the sums and the dense kernel itself */);
+// the dense layers + sigmoid of the last stage when its aggregates are ready (compact-table plan)
+hipError_t launch_dense_sigmoid(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *in, float *out,
+                                float *logits, uint32_t row_lo, uint32_t row_hi, const float *acc4, const uint32_t *c4desc,
+                                const float *agg16, hipStream_t stream);
 
 // Building blocks of the degree-sorted order (the prefix over the few thousand degree classes
 // is done on the host).
@@ -146,6 +152,15 @@ hipError_t launch_compact_gather(const GraphDev &g, const float *in, const unsig
                                  uint32_t dirty_cap, float *agg16, hipStream_t stream, uint32_t block_cols,
                                  uint32_t plan_base, uint32_t plan_end, uint32_t last_entry /* last index of entries[] a 16-byte read may start at */,
                                  int what = 3 /* 1 = prepare, 2 = sums, 3 = both */);
+
+// the parts of launch_compact_gather's second half, for callers that run them round by round
+hipError_t compact_sums(const GraphDev &g, uint32_t *desc, const float *table, float *acc4, uint32_t row_lo, uint32_t row_hi,
+                        uint32_t rows_per_chunk, const uint32_t *step_ptr, const void *steps, const uint32_t *entries,
+                        uint32_t *dirty_rows, uint32_t dirty_cap, hipStream_t stream, uint32_t block_cols, uint32_t plan_base,
+                        uint32_t plan_end, uint32_t last_entry, bool one_round = false);
+hipError_t compact_mark(const uint32_t *desc, uint32_t *marks, uint32_t k, hipStream_t stream);
+hipError_t compact_fix(const GraphDev &g, const float *in, const uint32_t *desc, const uint32_t *dirty_rows, uint32_t dirty_cap,
+                       float *agg16, const uint32_t *marks, hipStream_t stream, uint32_t blocks = 4096);
 
 hipError_t score_keys(const float *scores, size_t n, float *keys, uint8_t *above_half, hipStream_t stream);
 

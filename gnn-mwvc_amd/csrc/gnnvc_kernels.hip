@@ -508,6 +508,62 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
     }
 }
 
+// ------------------------------------------------------------------ dense-only sigmoid stage (no LDS)
+// When the last stage's aggregates arrive ready-made (compact-table plan: four sums per clean row, sixteen per
+// dirty one) what is left of it is the dense layers and the sigmoid.  This kernel does them one lane per vertex on
+// the VALU with NO LDS, so that its workgroups fit on a CU beside k_c4_agg's (which hold nearly all of its LDS
+// but half of its wave slots and registers and leave most VALU cycles idle): the engine launches the sums one
+// round of the persistent grid at a time and runs this kernel for round k on a second stream, under the sums
+// of round k + 1.  Same fma chains, same bits.  (The feature stages keep the LDS-staged kernel: their 64-byte
+// row stores would be one lane per row here, and that many partial-line requests slow the co-running sums by
+// more than the overlap gains — measured.)
+// acc4[u] = four sums (columns c4desc[1..4]) of a clean row, or {sign bit, slot} of a dirty one whose sixteen sums
+// sit in agg16[slot]; leaves at once when c4desc[0] == 0 (the gathering k_stage_f16 has the launch then).
+template <int N1, int N2>
+__global__ __launch_bounds__(kBlock) void k_dense_sigmoid(GraphDev g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
+                                                          float *__restrict__ logits, const float *__restrict__ P, uint32_t row_lo,
+                                                          uint32_t row_hi, const float4 *__restrict__ acc4,
+                                                          const uint32_t *__restrict__ c4desc, const float4 *__restrict__ agg16) {
+    if (c4desc[0] == 0) return;
+    const uint32_t uu = row_lo + blockIdx.x * kBlock + threadIdx.x;
+    const bool mine = uu < row_hi;
+    const uint32_t u = mine ? uu : row_hi - 1;
+    const uint32_t d0 = c4desc[1], d1 = c4desc[2], d2 = c4desc[3], d3 = c4desc[4];
+    const float4 a = acc4[u];
+    const float4 h0 = fin[(size_t)u * 4], h1 = fin[(size_t)u * 4 + 1], h2 = fin[(size_t)u * 4 + 2], h3 = fin[(size_t)u * 4 + 3];
+    // first-layer inputs in k order: 0..15 aggregate, 16 = h[0], 17 = degree, 18 = W/ws, 19 = NW/ws, 20..31 = h[4..15]
+    float x0[32];
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        x0[k] = ((uint32_t)k == d0) ? a.x : ((uint32_t)k == d1) ? a.y : ((uint32_t)k == d2) ? a.z : ((uint32_t)k == d3) ? a.w : 0.0f;
+    const bool dirty = (__float_as_uint(a.x) >> 31) != 0;   // met a neighbour with stray non-zeros: recomputed from full rows by k_c4_fix
+    if (__any(dirty)) {
+        const size_t slot = dirty ? (size_t)__float_as_uint(a.y) : 0;
+        const float4 g0 = agg16[slot * 4], g1 = agg16[slot * 4 + 1], g2 = agg16[slot * 4 + 2], g3 = agg16[slot * 4 + 3];
+        const float gg[16] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w, g3.x, g3.y, g3.z, g3.w};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x0[k] = dirty ? gg[k] : x0[k];
+    }
+    x0[16] = h0.x;
+    x0[17] = (float)(g.rowptr[u + 1] - g.rowptr[u]);
+    x0[18] = (float)g.w[u] / ws;
+    x0[19] = (float)g.nw[u] / ws;
+    x0[20] = h1.x; x0[21] = h1.y; x0[22] = h1.z; x0[23] = h1.w;
+    x0[24] = h2.x; x0[25] = h2.y; x0[26] = h2.z; x0[27] = h2.w;
+    x0[28] = h3.x; x0[29] = h3.y; x0[30] = h3.z; x0[31] = h3.w;
+    const float *W1 = P, *b1 = W1 + 35 * N1;
+    const float *W2 = b1 + N1, *b2 = W2 + N1 * N2;
+    const float *W3 = b2 + N2, *b3 = W3 + N2;
+    float x1[N1], x2[N2], x3[1];
+    dense<32, 32, N1, 0>(x0, x1, W1, b1);   // rows 32..34 of W1 meet exact zeros
+    dense<N1, N1, N2, 0>(x1, x2, W2, b2);
+    dense<N2, N2, 1, 1>(x2, x3, W3, b3);
+    if (mine) {
+        if (logits) logits[u] = x3[0];
+        fout[u] = sigmoid_ref(x3[0]);
+    }
+}
+
 // ------------------------------------------------------------------ stage, F = 1
 // First dense layer input (f = 1): [aggregate, x, degree, W/ws, NW/ws].
 // `ep` / `ecol` say which CSR entries this launch sums: the whole rows
@@ -1372,6 +1428,8 @@ __device__ __forceinline__ f32x4 c4_sel(bool c, f32x4 v) {
 // workgroups do the same work, the chip) in the same block, which is what keeps the block in L2.
 // Loads are unconditional and in the same order on every trip so that the hardware counters are waited on
 // exactly: entries two steps ahead, gathers one step ahead.
+// (TAG only names the launch in profiles: 0 = all chunks of a call, 1 = one round of a call done round by round)
+template <int TAG>
 __global__ __launch_bounds__(1024) void k_c4_agg(const uint32_t *__restrict__ step_ptr, const uint4 *__restrict__ steps,
                                                  const uint32_t *__restrict__ entries, const f32x4 *__restrict__ table,
                                                  f32x4 *__restrict__ agg, uint32_t n, uint32_t slice_rows, uint32_t slice0,
@@ -1547,11 +1605,13 @@ __global__ __launch_bounds__(1024) void k_c4_agg(const uint32_t *__restrict__ st
 // order, one quad of lanes per row (lane c: columns 4c .. 4c+3) -> agg16[slot]
 __global__ __launch_bounds__(256) void k_c4_fix(GraphDev g, const float4 *__restrict__ fin, const uint32_t *__restrict__ desc,
                                                 const uint32_t *__restrict__ dirty_rows, uint32_t dirty_cap,
-                                                float4 *__restrict__ agg16) {
+                                                float4 *__restrict__ agg16, const uint32_t *__restrict__ marks) {
     if (!desc[0]) return;
-    const uint32_t count = min(desc[5], dirty_cap);
+    // marks != nullptr: only the slots handed out between two marks (one round of the aggregation grid)
+    const uint32_t first = marks ? min(marks[0], dirty_cap) : 0u;
+    const uint32_t count = min(marks ? marks[1] : desc[5], dirty_cap);
     const uint32_t c = threadIdx.x & 3;
-    for (uint32_t slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; slot < count; slot += (gridDim.x * blockDim.x) >> 2) {
+    for (uint32_t slot = first + ((blockIdx.x * blockDim.x + threadIdx.x) >> 2); slot < count; slot += (gridDim.x * blockDim.x) >> 2) {
         const uint32_t u = dirty_rows[slot];
         uint32_t e = g.rowptr[u];
         const uint32_t end = g.rowptr[u + 1];
@@ -1568,6 +1628,9 @@ __global__ __launch_bounds__(256) void k_c4_fix(GraphDev g, const float4 *__rest
         agg16[(size_t)slot * 4 + c] = a;
     }
 }
+
+// marks[k] = the number of dirty-row slots handed out so far (after round k - 1 of the aggregation grid)
+__global__ void k_c4_mark(const uint32_t *__restrict__ desc, uint32_t *__restrict__ marks, uint32_t k) { marks[k] = desc[5]; }
 
 // ------------------------------------------------------------------ degree-sorted tile order
 // (built once per graph and row range when natural tiles would waste most of their rounds)
@@ -2242,11 +2305,24 @@ int stage_variant(int f, int n1, int n2, int n3, int sigmoid_last) {
     return -1;
 }
 
+// the dense layers + sigmoid of the last stage when its aggregates are ready (compact-table plan): rows [row_lo, row_hi)
+hipError_t launch_dense_sigmoid(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *in, float *out,
+                                float *logits, uint32_t row_lo, uint32_t row_hi, const float *acc4, const uint32_t *c4desc,
+                                const float *agg16, hipStream_t stream) {
+    if (row_hi <= row_lo) return hipSuccess;
+    if (sp.f != 16 || sp.variant != 2 || !acc4 || !c4desc) return hipErrorInvalidValue;
+    const dim3 grid((row_hi - row_lo + kBlock - 1) / kBlock), block(kBlock);
+    hipLaunchKernelGGL((k_dense_sigmoid<32, 16>), grid, block, 0, stream, g, ws, reinterpret_cast<const float4 *>(in), out, logits,
+                       params + sp.param_offset, row_lo, row_hi, reinterpret_cast<const float4 *>(acc4), c4desc,
+                       reinterpret_cast<const float4 *>(agg16));
+    return hipGetLastError();
+}
+
 hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
                         const float *in, float *out, float *logits, uint32_t row_lo,
                         uint32_t row_hi, uint32_t long_thresh, bool mfma, const SortedOrder *so,
                         bool interleave, hipStream_t stream, const float *acc4, const uint32_t *c4desc, const float *agg16,
-                        bool mfma_agg, const EmitArgs &emit) {
+                        bool mfma_agg, const EmitArgs &emit, bool dense_part) {
     if (row_hi <= row_lo) return hipSuccess;
     const bool sorted = so && so->n > 0;
     if (so && so->n == 0) return hipSuccess;   // every row of the range is a long row
@@ -2298,7 +2374,7 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
     default:
         return hipErrorInvalidValue;
     }
-    if (!sorted && acc4 && sp.f == 16) {
+    if (!sorted && acc4 && sp.f == 16 && dense_part) {
         // compact-table plan: the aggregate-only variant does the launch when the device found the input fit for
         // it (the gathering variant above has then left at once, and the other way round).  Without gathers to
         // overlap with, the dense layers run faster on the VALU (one lane per vertex, weights from SGPRs) than on
@@ -2314,7 +2390,7 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
             else GNNVC_LAUNCH_AGG(32, 16, false, false, nullptr);
         } else {
             if (mfma_agg) GNNVC_LAUNCH_AGG(16, 1, true, true, logits);
-            else GNNVC_LAUNCH_AGG(16, 1, true, false, logits);
+            else return launch_dense_sigmoid(sp, g, ws, params, in, out, logits, row_lo, row_hi, acc4, c4desc, agg16, stream);
         }
 #undef GNNVC_LAUNCH_AGG
     }
@@ -2544,6 +2620,19 @@ hipError_t launch_compact_gather(const GraphDev &g, const float *in, const unsig
     if (!(what & 2)) return hipGetLastError();
     hipError_t rc0 = hipMemsetAsync(desc + 5, 0, sizeof(uint32_t), stream);   // dirty-row counter
     if (rc0 != hipSuccess) return rc0;
+    rc0 = compact_sums(g, desc, table, acc4, row_lo, row_hi, rows_per_chunk, step_ptr, steps, entries, dirty_rows, dirty_cap, stream,
+                       block_cols, plan_base, plan_end, last_entry);
+    if (rc0 != hipSuccess) return rc0;
+    return compact_fix(g, in, desc, dirty_rows, dirty_cap, agg16, nullptr, stream);
+}
+
+// the sums of the chunks that hold rows [row_lo, row_hi) (the dirty-row counter desc[5] is the caller's to reset)
+hipError_t compact_sums(const GraphDev &g, uint32_t *desc, const float *table, float *acc4, uint32_t row_lo, uint32_t row_hi,
+                        uint32_t rows_per_chunk, const uint32_t *step_ptr, const void *steps, const uint32_t *entries,
+                        uint32_t *dirty_rows, uint32_t dirty_cap, hipStream_t stream, uint32_t block_cols, uint32_t plan_base,
+                        uint32_t plan_end, uint32_t last_entry, bool one_round) {
+    if (row_hi <= row_lo || g.nnz == 0 || row_lo < plan_base || row_hi > plan_end) return hipErrorInvalidValue;
+    if (rows_per_chunk == 0 || rows_per_chunk > kC4MaxRows || rows_per_chunk % kC4Slices) return hipErrorInvalidValue;
     const uint32_t c0 = (row_lo - plan_base) / rows_per_chunk, c1 = (row_hi - 1 - plan_base) / rows_per_chunk + 1;
     const uint32_t slice_rows = rows_per_chunk / kC4Slices;
     const uint32_t nslices = ((plan_end - plan_base + rows_per_chunk - 1) / rows_per_chunk) * kC4Slices;
@@ -2553,18 +2642,39 @@ hipError_t launch_compact_gather(const GraphDev &g, const float *in, const unsig
     const size_t lds = (size_t)kC4Slices * ((size_t)slice_rows * 16 + kC4DirtyWords * 4);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(k_c4_agg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(k_c4_agg<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        if (rc == hipSuccess)
+            rc = hipFuncSetAttribute(reinterpret_cast<const void *>(k_c4_agg<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         if (rc != hipSuccess) return rc;
         attr_set = true;
     }
     // a persistent grid of one workgroup per CU: they start together and sweep the column blocks together
-    hipLaunchKernelGGL(k_c4_agg, dim3(std::min<uint32_t>(256u, c1 - c0)), dim3(1024), lds, stream, step_ptr,
-                       reinterpret_cast<const uint4 *>(steps), entries, reinterpret_cast<const f32x4 *>(table),
-                       reinterpret_cast<f32x4 *>(acc4), g.n, slice_rows, c0 * kC4Slices, std::min(c1 * kC4Slices, nslices), nslices,
-                       last_entry, desc, dirty_rows, dirty_cap, block_cols, nblocks, plan_base, plan_end);
-    // the grid is sized for a typical number of dirty rows and strides over more
-    hipLaunchKernelGGL(k_c4_fix, dim3(std::min<uint32_t>((dirty_cap + 63) / 64, 4096u)), dim3(256), 0, stream, g,
-                       reinterpret_cast<const float4 *>(in), desc, dirty_rows, dirty_cap, reinterpret_cast<float4 *>(agg16));
+    const dim3 grid(std::min<uint32_t>(256u, c1 - c0)), block(1024);
+    if (one_round)
+        hipLaunchKernelGGL(k_c4_agg<1>, grid, block, lds, stream, step_ptr,
+                           reinterpret_cast<const uint4 *>(steps), entries, reinterpret_cast<const f32x4 *>(table),
+                           reinterpret_cast<f32x4 *>(acc4), g.n, slice_rows, c0 * kC4Slices, std::min(c1 * kC4Slices, nslices), nslices,
+                           last_entry, desc, dirty_rows, dirty_cap, block_cols, nblocks, plan_base, plan_end);
+    else
+        hipLaunchKernelGGL(k_c4_agg<0>, grid, block, lds, stream, step_ptr,
+                           reinterpret_cast<const uint4 *>(steps), entries, reinterpret_cast<const f32x4 *>(table),
+                           reinterpret_cast<f32x4 *>(acc4), g.n, slice_rows, c0 * kC4Slices, std::min(c1 * kC4Slices, nslices), nslices,
+                           last_entry, desc, dirty_rows, dirty_cap, block_cols, nblocks, plan_base, plan_end);
+    return hipGetLastError();
+}
+
+// marks[k] = dirty-row slots handed out so far
+hipError_t compact_mark(const uint32_t *desc, uint32_t *marks, uint32_t k, hipStream_t stream) {
+    hipLaunchKernelGGL(k_c4_mark, dim3(1), dim3(1), 0, stream, desc, marks, k);
+    return hipGetLastError();
+}
+
+// full-row aggregates of the dirty rows: all of them (marks == nullptr) or those of slots [marks[0], marks[1]); `blocks`:
+// a small grid when the kernel runs beside the aggregation grid (it strides over what it has to do)
+hipError_t compact_fix(const GraphDev &g, const float *in, const uint32_t *desc, const uint32_t *dirty_rows, uint32_t dirty_cap,
+                       float *agg16, const uint32_t *marks, hipStream_t stream, uint32_t blocks) {
+    hipLaunchKernelGGL(k_c4_fix, dim3(std::min<uint32_t>((dirty_cap + 63) / 64, blocks)), dim3(256), 0, stream, g,
+                       reinterpret_cast<const float4 *>(in), desc, dirty_rows, dirty_cap, reinterpret_cast<float4 *>(agg16), marks);
     return hipGetLastError();
 }
 

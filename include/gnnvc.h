@@ -81,6 +81,8 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *                         instead of 64-byte rows from memory (default 1 = large, non-skewed graphs); bit-identical
  *   "block_cols"     n    vertices per column block (default 524288 = 2 MiB of x)
  *   "blocked_min_n"  n    graphs with fewer vertices are not blocked (default 2^20)
+ *   "overlap_dense"  0|1  last stage under the compact-table plan: dense layers of one round of the sums on a second
+ *                         stream, under the next round's sums (default 1; bit-identical either way)
  *   "plan_chunk_rows" n   cap on the rows per chunk of the LDS-table and compact-table plans (default 0 = what
  *                         fits LDS); smaller chunks mean more rounds of the persistent grids — a test hook
  *   "long_row_threshold" d  rows of degree >= d get a workgroup of their own (default 512,

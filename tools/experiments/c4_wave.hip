@@ -18,6 +18,9 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef BURN_PAD
+#define BURN_PAD 896
+#endif
 constexpr int kShift = 18;
 #ifndef KSUB
 #define KSUB 4
@@ -349,6 +352,31 @@ extern "C" int c4w_agg(const uint32_t *step_ptr, const void *steps, const uint32
         hipLaunchKernelGGL(k_c4w_agg<1>, dim3(grid), dim3(1024), lds, (hipStream_t)stream, step_ptr, reinterpret_cast<const uint4 *>(steps),
                            entries, reinterpret_cast<const f32x4 *>(table), reinterpret_cast<f32x4 *>(agg), n, Rw, Bc, nnz - 1, nwc, nblocks);
     }
+    CK(hipGetLastError());
+    return 0;
+}
+
+// ---- co-residency experiment: a VALU-bound kernel without (much) LDS beside the aggregation kernel, which
+// holds nearly all of a CU's LDS but only half of its wave slots and registers
+__global__ __launch_bounds__(256) void k_valu_burn(float *__restrict__ out, int iters, float seed) {
+    __shared__ float pad[BURN_PAD];                    // 3.5 KiB: at most one such workgroup fits beside k_c4v_agg's 156.4 KiB
+    float a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = seed + (float)(threadIdx.x + i);
+    const float b = seed * 0.5f, c = 0.25f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] = __builtin_fmaf(a[i], b, c);
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += a[i];
+    if (threadIdx.x == 0) pad[0] = s;
+    if (s == 1.2345f) out[blockIdx.x * 256 + threadIdx.x] = s + pad[threadIdx.x & 7];
+}
+
+extern "C" int valu_burn(float *out, int blocks, int iters, void *stream) {
+    hipLaunchKernelGGL(k_valu_burn, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters, 1.0f);
     CK(hipGetLastError());
     return 0;
 }

@@ -116,3 +116,48 @@ ev[1].record()
 torch.cuda.synchronize()
 t = ev[0].elapsed_time(ev[1]) / 10
 print(f"c4w_agg: {t:.3f} ms per pass = {g.nnz / t / 1e6:.1f} G gathers/s")
+
+
+# ---- co-residency experiment (depth 4 form only): the aggregation kernel and a VALU-bound kernel on two streams
+if depth == 4 and os.environ.get("CORES"):
+    L.valu_burn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    sink = torch.zeros(1 << 22, dtype=torch.float32, device=dev)
+    s2 = torch.cuda.Stream(device=dev)
+    blocks, iters = 256 * 40, int(os.environ["CORES"])
+
+    def burn(st):
+        assert L.valu_burn(sink.data_ptr(), blocks, iters, st.cuda_stream) == 0
+
+    def timed(fn, reps=5):
+        torch.cuda.synchronize()
+        t0 = __import__("time").perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (__import__("time").perf_counter() - t0) / reps * 1e3
+
+    cur = torch.cuda.current_stream()
+    t_agg = timed(run)
+    t_burn = timed(lambda: burn(cur))
+
+    def both():
+        run()          # current stream
+        burn(s2)       # second stream, no dependency
+
+    both()
+    # each kernel's own span when both are in flight
+    ea = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    eb = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    torch.cuda.synchronize()
+    ea[0].record(cur)
+    run()
+    ea[1].record(cur)
+    eb[0].record(s2)
+    burn(s2)
+    eb[1].record(s2)
+    torch.cuda.synchronize()
+    print(f"in flight together: agg span {ea[0].elapsed_time(ea[1]):.3f} ms, VALU kernel span {eb[0].elapsed_time(eb[1]):.3f} ms, "
+          f"VALU kernel ends {ea[0].elapsed_time(eb[1]):.3f} ms after the agg's start")
+    t_both = timed(both)
+    print(f"agg alone {t_agg:.3f} ms, VALU kernel alone {t_burn:.3f} ms, both on two streams {t_both:.3f} ms "
+          f"(sum {t_agg + t_burn:.3f})")
