@@ -665,12 +665,13 @@ def test_compact_gather_long_runs(model_text, oracle_model):
             e.close()
 
 
-@pytest.mark.parametrize("chunk_rows,maker", [
-    (16, lambda: gg.erdos_renyi(20000, 200000, 72)),        # one row per wave slice: 1250 chunks, five rounds of the grid
-    (48, lambda: gg.erdos_renyi(20011, 150000, 73)),        # three rows per slice, a ragged last chunk
-    (32, lambda: _dense_graph(3000, 300, 74)),              # 300-entry rows: runs longer than a step in a 2-row slice
+@pytest.mark.parametrize("chunk_rows,overlap,maker", [
+    (16, 1, lambda: gg.erdos_renyi(20000, 200000, 72)),     # one row per wave slice: 1250 chunks, five rounds of the grid
+    (16, 0, lambda: gg.erdos_renyi(20000, 200000, 72)),     # the same with the last stage's dense layers after, not under, the sums
+    (48, 1, lambda: gg.erdos_renyi(20011, 150000, 73)),     # three rows per slice, a ragged last chunk
+    (32, 1, lambda: _dense_graph(3000, 300, 74)),           # 300-entry rows: runs longer than a step in a 2-row slice
 ])
-def test_plans_with_many_small_chunks(model_text, oracle_model, chunk_rows, maker):
+def test_plans_with_many_small_chunks(model_text, oracle_model, chunk_rows, overlap, maker):
     """Both per-graph plans with the chunk size capped ("plan_chunk_rows"): several rounds of the persistent grids,
     a partial last round, slices of one to three rows — what only the 10 M-vertex graph exercises otherwise."""
     import torch
@@ -680,6 +681,7 @@ def test_plans_with_many_small_chunks(model_text, oracle_model, chunk_rows, make
     try:
         e.set_option("blocked_min_n", 0)
         e.set_option("plan_chunk_rows", chunk_rows)
+        e.set_option("overlap_dense", overlap)
         e.set_weight_scale(g.ws)
         oracle_model.set_weight_scale(g.ws)
         e.upload_graph(g)
