@@ -1,6 +1,6 @@
 """Parity at BASELINE.json's full sizes, built on the GPU: the metric graph (Erdős–Rényi 10 M
-vertices / 100 M edges), R-MAT scale 22 (config 2) and the 1 M-vertex power-law graph with
-65536-degree hubs (config 4).  The oracle cannot run these whole graphs in seconds, so the checks
+vertices / 100 M edges), R-MAT scale 22 (config 2), R-MAT scale 24 (config 3: 16.8 M vertices / 260 M
+edges, here on one GPU) and the 1 M-vertex power-law graph with 65536-degree hubs (config 4).  The oracle cannot run these whole graphs in seconds, so the checks
 are size-independent properties plus EXACT per-row checks on a sample of vertices (random ones and
 the highest-degree ones, which take the long-row path):
 
@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 SAMPLE = 256
 
 
-@pytest.fixture(scope="module", params=["er10m", "rmat22", "powerlaw1m"])
+@pytest.fixture(scope="module", params=["er10m", "rmat22", "rmat24", "powerlaw1m"])
 def big(request):
     import torch
     import bench
