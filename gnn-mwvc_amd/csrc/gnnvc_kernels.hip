@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 
 #include "expf_glibc.h"
 #include "gnnvc_kernels.h"
@@ -2502,6 +2503,18 @@ hipError_t launch_stage0_blocked(const StagePlan &sp, const GraphDev &g, float w
 }
 
 // ---- LDS-table plan of the F = 1 stage ----------------------------------------------------
+// kernels that need more than 64 KiB of dynamic LDS must be told so once per device (engines on several devices may
+// live in one process; `done` has one bit per device ordinal)
+static hipError_t allow_dynamic_lds(const void *func, int bytes, std::atomic<uint64_t> &done) {
+    int dev = 0;
+    hipError_t rc = hipGetDevice(&dev);
+    if (rc != hipSuccess) return rc;
+    if (dev >= 0 && dev < 64 && (done.load(std::memory_order_acquire) >> dev & 1u)) return hipSuccess;
+    rc = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (rc == hipSuccess && dev >= 0 && dev < 64) done.fetch_or(1ull << dev, std::memory_order_release);
+    return rc;
+}
+
 uint32_t lds_table_max_rows() { return 16u * kLtwSliceRows; }
 uint32_t lds_table_block() { return kLtwBlock; }
 uint32_t lds_table_step() { return kLtwStep; }
@@ -2571,12 +2584,9 @@ hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float
     constexpr size_t lds_max = (size_t)16 * kLtwSliceRows * 4 + 1024 + kLtwBlock;
     static_assert(lds_max <= 160 * 1024, "LDS budget of k_lt_agg");
     const size_t lds = (size_t)16 * slice_rows * 4 + 1024 + kLtwBlock;
-    static bool attr_set = false;
-    if (!attr_set) {
-        rc = hipFuncSetAttribute(reinterpret_cast<const void *>(k_lt_agg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-        if (rc != hipSuccess) return rc;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    rc = allow_dynamic_lds(reinterpret_cast<const void *>(k_lt_agg), (int)lds_max, lds_ok);
+    if (rc != hipSuccess) return rc;
     hipLaunchKernelGGL(k_lt_agg, dim3(c1 - c0 + 1), dim3(1024), lds, stream, step_ptr, reinterpret_cast<const uint32_t *>(steps),
                        entries, wbyte, ws, acc, g.n, slice_rows, c0, last_entry, bad);
     const uint32_t ntiles = (row_hi - row_lo + kWave - 1) / kWave;
@@ -2640,13 +2650,11 @@ hipError_t compact_sums(const GraphDev &g, uint32_t *desc, const float *table, f
     constexpr size_t lds_max = (size_t)kC4Slices * (kC4SliceRows * 16 + kC4DirtyWords * 4);
     static_assert(lds_max <= 160 * 1024, "LDS budget of k_c4_agg");
     const size_t lds = (size_t)kC4Slices * ((size_t)slice_rows * 16 + kC4DirtyWords * 4);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(k_c4_agg<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-        if (rc == hipSuccess)
-            rc = hipFuncSetAttribute(reinterpret_cast<const void *>(k_c4_agg<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    static std::atomic<uint64_t> lds_ok0{0}, lds_ok1{0};
+    {
+        hipError_t rc = allow_dynamic_lds(reinterpret_cast<const void *>(k_c4_agg<0>), (int)lds_max, lds_ok0);
+        if (rc == hipSuccess) rc = allow_dynamic_lds(reinterpret_cast<const void *>(k_c4_agg<1>), (int)lds_max, lds_ok1);
         if (rc != hipSuccess) return rc;
-        attr_set = true;
     }
     // a persistent grid of one workgroup per CU: they start together and sweep the column blocks together
     const dim3 grid(std::min<uint32_t>(256u, c1 - c0)), block(1024);
