@@ -1,0 +1,4 @@
+cd "$GRAFT_REPO_ROOT"
+for w in er3m er1m er100k rmat22 rmat20 powerlaw1m rmat24; do
+  timeout -k 10 240 python bench.py --no-cpu-baseline --workload $w 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$w', round(d['ms_per_step'],3), 'ms', round(d['value']/1e9,2), 'G edges/s', [round(x,3) for x in d['stage_ms']])" || exit 1
+done
