@@ -83,16 +83,16 @@ XS_HD Map elem_map(uint32_t vbits, uint32_t E, bool &bad) {
 // — whenever it matters (t >= 2^-126; anything smaller is far below u/2), floor(t) = k and
 // t - floor(t) = r / u are exact for t < 2^24, and a t beyond that saturates: its add carries.
 XS_HD Map elem_map_f(uint32_t vbits, uint32_t E, bool &bad) {
-    Map r = {0u, 0u};
-    const uint32_t e = (vbits >> 23) & 0xFFu;
-    if ((vbits >> 31) ? (vbits != 0x80000000u) : (e == 255u)) { bad = true; return r; }
+    // branch-free: a negative or non-finite value only raises `bad` (its map is then never used)
+    bad |= (vbits > 0x80000000u) | ((vbits & 0x7F800000u) == 0x7F800000u);
     float v;
     __builtin_memcpy(&v, &vbits, 4);
     const float t = __builtin_ldexpf(v, 150 - (int)E);
     const float fl = __builtin_floorf(t);
-    const uint32_t k = (fl < 67108864.0f) ? (uint32_t)fl : kSat;
+    const uint32_t k = (uint32_t)__builtin_fminf(__builtin_fmaxf(fl, 0.0f), 67108864.0f);   // (NaN -> 0, huge -> kSat)
     const float fr = t - fl;
     const uint32_t up = fr > 0.5f ? 1u : 0u, tie = fr == 0.5f ? 1u : 0u;
+    Map r;
     r.d0 = sat_(k + up + (tie & k));
     r.d1 = sat_(k + up + (tie & (k + 1u)));
     return r;

@@ -172,6 +172,14 @@ struct gnnvc_engine {
     DevBuf<uint32_t> long_list, long_count;
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // giant rows (degree >= giant_thresh, a subset of the long rows): CSR-order sums evaluated in parallel (exact_sum.h)
+    uint32_t opt_giant_thresh = 16384;   // option "giant_row_threshold" (0 = off: k_long_* take every long row)
+    int opt_hub_mode = 0;                // option "hub_mode": 0 = exact (the chain's bits), 1 = fast (tree sums, tolerance mode)
+    uint32_t giant_thresh = 0xFFFFFFFFu, n_giant = 0, giant_blocks = 0;
+    uint64_t giant_entries = 0;
+    DevBuf<uint4> gi_meta;
+    DevBuf<unsigned long long> gi_off;
+    DevBuf<float> gi_slab, gi_agg;
 
     std::string err;
 };
@@ -352,9 +360,54 @@ int use_device(gnnvc_engine *e) {
     return GNNVC_OK;
 }
 
+// Giant rows of the current graph: those of the long-row list whose degree reaches the giant threshold (in fast
+// hub mode: every long row).  Their neighbour values go through a column-major slab, one stream per (row, feature
+// column), laid out here on the host — heaviest row first, so the longest streams start first.
+int find_giant(gnnvc_engine *e) {
+    uint32_t gt = e->opt_giant_thresh ? std::max(e->opt_giant_thresh, e->long_thresh) : 0xFFFFFFFFu;
+    if (e->opt_hub_mode == 1) gt = e->long_thresh;
+    if (gt == 0xFFFFFFFFu || e->n_long == 0) return GNNVC_OK;
+    HIP_TRY(e, e->gi_meta.reserve((size_t)e->n_long + 1));
+    HIP_TRY(e, gnnvc::find_giant_rows(e->g, e->long_list.p, e->n_long, gt, e->gi_meta.p, e->long_count.p, e->stream));
+    uint32_t cnt = 0;
+    HIP_TRY(e, hipMemcpyAsync(&cnt, e->long_count.p, sizeof cnt, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (cnt == 0) return GNNVC_OK;
+    std::vector<uint4> meta((size_t)cnt + 1);
+    HIP_TRY(e, hipMemcpy(meta.data(), e->gi_meta.p, (size_t)cnt * sizeof(uint4), hipMemcpyDeviceToHost));
+    std::sort(meta.begin(), meta.begin() + cnt, [](const uint4 &a, const uint4 &b) { return a.z != b.z ? a.z > b.z : a.x < b.x; });
+    std::vector<unsigned long long> off(cnt);
+    const uint32_t win = gnnvc::giant_window(), blk = gnnvc::giant_block();
+    uint64_t floats = 0, blocks = 0, entries = 0;
+    for (uint32_t i = 0; i < cnt; ++i) {
+        const uint64_t lpad = ((uint64_t)meta[i].z + win - 1) / win * win;
+        off[i] = floats;
+        meta[i].w = (uint32_t)blocks;
+        floats += 16 * lpad;
+        blocks += (meta[i].z + blk - 1) / blk;
+        entries += meta[i].z;
+    }
+    if (blocks >= 0x7FFFFFFFull) return GNNVC_OK;   // (cannot happen with 32-bit row pointers and a threshold >= 2)
+    meta[cnt] = make_uint4(0xFFFFFFFFu, 0u, 0u, (uint32_t)blocks);
+    HIP_TRY(e, e->gi_off.reserve(cnt));
+    HIP_TRY(e, e->gi_slab.reserve(floats));
+    HIP_TRY(e, e->gi_agg.reserve((size_t)cnt * 16));
+    HIP_TRY(e, hipMemcpy(e->gi_meta.p, meta.data(), ((size_t)cnt + 1) * sizeof(uint4), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(e->gi_off.p, off.data(), (size_t)cnt * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    e->n_giant = cnt;
+    e->giant_blocks = (uint32_t)blocks;
+    e->giant_entries = entries;
+    e->giant_thresh = gt;
+    return GNNVC_OK;
+}
+
 // Rows the tile kernels hand to the long-row kernels (per graph).
 int find_long(gnnvc_engine *e) {
     e->n_long = 0;
+    e->n_giant = 0;
+    e->giant_blocks = 0;
+    e->giant_entries = 0;
+    e->giant_thresh = 0xFFFFFFFFu;
     e->long_thresh = 0xFFFFFFFFu;
     e->thresh_f16 = 0xFFFFFFFFu;
     e->sorted_valid = false;   // new graph: any cached tile order is stale
@@ -410,7 +463,7 @@ int find_long(gnnvc_engine *e) {
     e->n_long = cnt;
     e->long_thresh = thresh;
     e->thresh_f16 = e->sorted_wanted ? std::max(thresh, e->opt_sorted_long_thresh) : thresh;
-    return GNNVC_OK;
+    return find_giant(e);
 }
 
 // Degree-sorted tile order for rows [lo, hi) of the current graph.  A natural tile of 64
@@ -693,8 +746,20 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
     if (longs) {   // fork: the long rows of this stage run beside the tile kernel
         HIP_TRY(e, hipEventRecord(e->ev_fork, e->stream));
         HIP_TRY(e, hipStreamWaitEvent(e->aux_stream, e->ev_fork, 0));
-        HIP_TRY(e, gnnvc::launch_long_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi,
-                                            e->long_list.p, e->n_long, thr, e->aux_stream));
+        if (e->n_giant) {   // the heaviest rows first: they are the long pole of the side stream
+            gnnvc::GiantRows gr;
+            gr.n = e->n_giant;
+            gr.blocks = e->giant_blocks;
+            gr.meta = e->gi_meta.p;
+            gr.off = e->gi_off.p;
+            gr.slab = e->gi_slab.p;
+            gr.agg = e->gi_agg.p;
+            HIP_TRY(e, gnnvc::launch_giant_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi, gr,
+                                                 e->opt_hub_mode == 1, e->aux_stream));
+        }
+        if (e->n_giant < e->n_long)
+            HIP_TRY(e, gnnvc::launch_long_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi,
+                                                e->long_list.p, e->n_long, thr, e->giant_thresh, e->aux_stream));
         HIP_TRY(e, hipEventRecord(e->ev_join, e->aux_stream));
     }
     // The LDS-table plan works in chunks of ~19.5 K rows, one workgroup each: a call that covers fewer than
@@ -975,6 +1040,7 @@ void gnnvc_destroy(gnnvc_engine *e) {
     e->c4_desc.release(); e->c4_steps.release(); e->c4_table.release(); e->c4_marks.release(); e->c4_acc.release(); e->c4_counts.release();
     e->c4_agg16.release(); e->c4_dirty.release(); e->c4_emit_counts.release();
     e->long_list.release(); e->long_count.release();
+    e->gi_meta.release(); e->gi_off.release(); e->gi_slab.release(); e->gi_agg.release();
     e->pin_rowptr.release(); e->pin_col.release(); e->pin_w.release(); e->pin_nw.release();
     e->pin_small.release();
     e->srt_vertex.release(); e->srt_hist.release(); e->srt_meta.release(); e->srt_sum.release();
@@ -1008,6 +1074,8 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "plan_chunk_rows") e->opt_plan_chunk_rows = value > 0 ? (uint32_t)value : 0;
     else if (k == "overlap_dense") e->opt_overlap = value != 0 ? 1 : 0;
     else if (k == "long_row_threshold") e->opt_long_thresh = value > 0 ? (uint32_t)value : 0;
+    else if (k == "giant_row_threshold") e->opt_giant_thresh = value > 0 ? (uint32_t)std::max<long>(value, 64) : 0;
+    else if (k == "hub_mode") e->opt_hub_mode = value == 1 ? 1 : 0;
     else if (k == "compact_gather") e->opt_compact = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else if (k == "lds_table") e->opt_lds_table = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else if (k == "sorted_min_nnz") e->opt_sorted_min_nnz = value > 0 ? (uint64_t)value : 0;
@@ -1044,6 +1112,10 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
     else if (k == "blocked_blocks") *value = e->blocked_ready ? (long)e->blk_count : 0;
     else if (k == "block_cols") *value = e->blocked_ready ? (long)e->blk_cols : 0;
     else if (k == "long_rows") *value = (long)e->n_long;
+    else if (k == "giant_rows") *value = (long)e->n_giant;
+    else if (k == "giant_entries") *value = (long)e->giant_entries;
+    else if (k == "giant_row_threshold") *value = e->n_giant ? (long)e->giant_thresh : 0;
+    else if (k == "hub_mode") *value = e->opt_hub_mode;
     else if (k == "mfma_dense") *value = e->opt_mfma;
     else if (k == "sorted_tiles_active") *value = e->sorted_wanted ? 1 : 0;
     else if (k == "tile_waste_x100") *value = (long)(e->srt_waste * 100.0);
@@ -1574,6 +1646,40 @@ int gnnvc_sigmoid_forward(gnnvc_engine *e, size_t count, const float *in, float 
                        [](gnnvc_engine *en, const float *di, float *dout, void *c) {
                            return gnnvc::launch_sigmoid(((Ctx *)c)->n, di, dout, en->stream);
                        }, &ctx);
+}
+
+int gnnvc_stream_sum(gnnvc_engine *e, const float *values, uint32_t streams, uint32_t len, int mode, float *sums) {
+    if (!e) return GNNVC_ERR_INVALID;
+    if (!streams) return GNNVC_OK;
+    if (!sums || (len && !values)) return fail(e, GNNVC_ERR_INVALID, "null host buffers");
+    if (mode != 0 && mode != 1) return fail(e, GNNVC_ERR_INVALID, "mode %d (0 = exact, 1 = fast)", mode);
+    if (len == 0) {
+        for (uint32_t i = 0; i < streams; ++i) sums[i] = 0.0f;
+        return GNNVC_OK;
+    }
+    int rc = use_device(e);
+    if (rc) return rc;
+    const uint32_t win = gnnvc::giant_window();
+    const size_t lpad = ((size_t)len + win - 1) / win * win;
+    DevBuf<float> slab, agg;
+    DevBuf<uint4> meta;
+    DevBuf<unsigned long long> off;
+    hipError_t h = slab.reserve(lpad * streams);
+    if (h == hipSuccess) h = agg.reserve((size_t)streams * 16);
+    if (h == hipSuccess) h = meta.reserve((size_t)streams + 1);
+    if (h == hipSuccess) h = off.reserve(streams);
+    if (h == hipSuccess) h = hipMemsetAsync(slab.p, 0, lpad * streams * sizeof(float), e->stream);
+    if (h == hipSuccess)
+        h = hipMemcpy2DAsync(slab.p, lpad * sizeof(float), values, (size_t)len * sizeof(float), (size_t)len * sizeof(float), streams,
+                             hipMemcpyHostToDevice, e->stream);
+    if (h == hipSuccess) h = gnnvc::stream_sums(slab.p, streams, len, meta.p, off.p, agg.p, mode == 1, e->stream);
+    std::vector<float> host((size_t)streams * 16);
+    if (h == hipSuccess) h = hipMemcpyAsync(host.data(), agg.p, host.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream);
+    if (h == hipSuccess) h = hipStreamSynchronize(e->stream);
+    slab.release(); agg.release(); meta.release(); off.release();
+    if (h != hipSuccess) return fail(e, h == hipErrorOutOfMemory ? GNNVC_ERR_NOMEM : GNNVC_ERR_DEVICE, "stream sum: %s", hipGetErrorString(h));
+    for (uint32_t i = 0; i < streams; ++i) sums[i] = host[(size_t)i * 16];
+    return GNNVC_OK;
 }
 
 int gnnvc_sgemm(gnnvc_engine *e, int trans_a, int trans_b, uint32_t m, uint32_t n, uint32_t k,

@@ -82,7 +82,26 @@ hipError_t find_long_rows(const GraphDev &g, uint32_t thresh, uint32_t *list, ui
                           hipStream_t stream);
 hipError_t launch_long_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
                              const float *in, float *out, float *logits, uint32_t row_lo, uint32_t row_hi,
-                             const uint32_t *list, uint32_t n_long, uint32_t min_deg, hipStream_t stream);
+                             const uint32_t *list, uint32_t n_long, uint32_t min_deg, uint32_t max_deg, hipStream_t stream);
+
+// Giant rows (degree >= the giant threshold, a subset of the long rows): the same CSR-order fp32 sums evaluated in
+// parallel (exact_sum.h).  meta: uint4[n + 1] {row, first CSR entry, degree, first gather block}, the last entry's
+// .w = blocks; off[i]: float offset in `slab` of row i's first stream (16 streams of the degree rounded up to
+// giant_window()); agg: float[n x 16].  find_giant_rows fills {row, first entry, degree, 0} in no particular order.
+struct GiantRows {
+    uint32_t n = 0, blocks = 0;
+    const void *meta = nullptr;
+    const unsigned long long *off = nullptr;
+    float *slab = nullptr, *agg = nullptr;
+};
+uint32_t giant_window();
+uint32_t giant_block();
+hipError_t find_giant_rows(const GraphDev &g, const uint32_t *list, uint32_t n_long, uint32_t thresh, void *meta, uint32_t *count,
+                           hipStream_t stream);
+hipError_t launch_giant_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *in, float *out,
+                              float *logits, uint32_t row_lo, uint32_t row_hi, const GiantRows &gr, bool fast, hipStream_t stream);
+hipError_t stream_sums(const float *streams_dev, uint32_t streams, uint32_t len, void *meta, unsigned long long *off, float *agg,
+                       bool fast, hipStream_t stream);
 
 // Column-blocked F = 1 stage (bit-identical to launch_stage on stage 0; see the kernels).
 // bp: uint32[nblocks * n + 1] block-major entry pointers, colb: uint32[nnz + pad] re-bucketed

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <atomic>
 
+#include "exact_sum.h"
 #include "expf_glibc.h"
 #include "gnnvc_kernels.h"
 
@@ -721,6 +722,59 @@ __global__ void k_find_long(GraphDev g, uint32_t thresh, uint32_t *__restrict__ 
     if (g.rowptr[u + 1] - g.rowptr[u] >= thresh) list[atomicAdd(count, 1u)] = u;
 }
 
+// The dense layers of one long row on one lane, given its aggregate (the tail of k_long_* and k_giant_dense).
+template <int N1, int N2, int N3, bool SIGMOID>
+__device__ __forceinline__ void long_tail_f16(const GraphDev &g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
+                                              float *__restrict__ logits, const float *__restrict__ P, uint32_t u, uint32_t deg,
+                                              const float (&agg)[16]) {
+    float x0[32];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x0[j] = agg[j];
+    const float4 h0 = fin[(size_t)u * 4 + 0], h1 = fin[(size_t)u * 4 + 1];
+    const float4 h2 = fin[(size_t)u * 4 + 2], h3 = fin[(size_t)u * 4 + 3];
+    x0[16] = h0.x;
+    x0[17] = (float)deg;
+    x0[18] = (float)g.w[u] / ws;
+    x0[19] = (float)g.nw[u] / ws;
+    x0[20] = h1.x; x0[21] = h1.y; x0[22] = h1.z; x0[23] = h1.w;
+    x0[24] = h2.x; x0[25] = h2.y; x0[26] = h2.z; x0[27] = h2.w;
+    x0[28] = h3.x; x0[29] = h3.y; x0[30] = h3.z; x0[31] = h3.w;
+    const float *W1 = P, *b1 = W1 + 35 * N1;
+    const float *W2 = b1 + N1, *b2 = W2 + N1 * N2;
+    const float *W3 = b2 + N2, *b3 = W3 + N2 * N3;
+    float x1[N1], x2[N2], x3[N3];
+    dense<32, 32, N1, 0>(x0, x1, W1, b1);
+    dense<N1, N1, N2, 0>(x1, x2, W2, b2);
+    dense<N2, N2, N3, SIGMOID ? 1 : 0>(x2, x3, W3, b3);
+    if constexpr (SIGMOID) {
+        if (logits) logits[u] = x3[0];
+        fout[u] = sigmoid_ref(x3[0]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < N3; ++j) fout[(size_t)u * N3 + j] = x3[j];
+    }
+}
+
+template <int N1, int N2, int N3>
+__device__ __forceinline__ void long_tail_f1(const GraphDev &g, float ws, const float *__restrict__ xin, float *__restrict__ fout,
+                                             const float *__restrict__ P, uint32_t u, uint32_t deg, float agg) {
+    float x0[5];
+    x0[0] = agg;
+    x0[1] = xin[u];
+    x0[2] = (float)deg;
+    x0[3] = (float)g.w[u] / ws;
+    x0[4] = (float)g.nw[u] / ws;
+    const float *W1 = P, *b1 = W1 + 5 * N1;
+    const float *W2 = b1 + N1, *b2 = W2 + N1 * N2;
+    const float *W3 = b2 + N2, *b3 = W3 + N2 * N3;
+    float x1[N1], x2[N2], x3[N3];
+    dense<5, 5, N1, 0>(x0, x1, W1, b1);
+    dense<N1, N1, N2, 0>(x1, x2, W2, b2);
+    dense<N2, N2, N3, 0>(x2, x3, W3, b3);
+#pragma unroll
+    for (int j = 0; j < N3; ++j) fout[(size_t)u * N3 + j] = x3[j];
+}
+
 constexpr int kLongChunk = 256;
 
 // One round of the long-row kernel: the 1024 rows a workgroup holds in registers (16 per
@@ -784,7 +838,7 @@ template <int N1, int N2, int N3, bool SIGMOID>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_long_f16(
         GraphDev g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
         float *__restrict__ logits, const float *__restrict__ P, uint32_t row_lo, uint32_t row_hi,
-        const uint32_t *__restrict__ list, uint32_t min_deg) {
+        const uint32_t *__restrict__ list, uint32_t min_deg, uint32_t max_deg) {
     __shared__ __attribute__((aligned(16))) float slab[2][kLongStride * 16];
     const uint32_t u = list[blockIdx.x];
     if (u < row_lo || u >= row_hi) return;   // block-uniform
@@ -792,6 +846,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const uint32_t rs = g.rowptr[u], re = g.rowptr[u + 1];
     const uint32_t deg = re - rs;
     if (deg < min_deg) return;               // listed for another stage's threshold; a tile kernel has it here
+    if (deg >= max_deg) return;              // a giant row: the k_giant_* kernels have it
     const uint32_t zrow = g.n;
     // Two register sets (A, B) alternate: while one round drains through the slab, the
     // 1024 row fetches of the next round and the column indices of the round after it are
@@ -834,39 +889,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     if (tid < 16) slab[0][tid] = acc;
     __syncthreads();
     if (tid != 0) return;
-    float x0[32];
+    float agg[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) x0[j] = slab[0][j];
-    const float4 h0 = fin[(size_t)u * 4 + 0], h1 = fin[(size_t)u * 4 + 1];
-    const float4 h2 = fin[(size_t)u * 4 + 2], h3 = fin[(size_t)u * 4 + 3];
-    x0[16] = h0.x;
-    x0[17] = (float)deg;
-    x0[18] = (float)g.w[u] / ws;
-    x0[19] = (float)g.nw[u] / ws;
-    x0[20] = h1.x; x0[21] = h1.y; x0[22] = h1.z; x0[23] = h1.w;
-    x0[24] = h2.x; x0[25] = h2.y; x0[26] = h2.z; x0[27] = h2.w;
-    x0[28] = h3.x; x0[29] = h3.y; x0[30] = h3.z; x0[31] = h3.w;
-    const float *W1 = P, *b1 = W1 + 35 * N1;
-    const float *W2 = b1 + N1, *b2 = W2 + N1 * N2;
-    const float *W3 = b2 + N2, *b3 = W3 + N2 * N3;
-    float x1[N1], x2[N2], x3[N3];
-    dense<32, 32, N1, 0>(x0, x1, W1, b1);
-    dense<N1, N1, N2, 0>(x1, x2, W2, b2);
-    dense<N2, N2, N3, SIGMOID ? 1 : 0>(x2, x3, W3, b3);
-    if constexpr (SIGMOID) {
-        if (logits) logits[u] = x3[0];
-        fout[u] = sigmoid_ref(x3[0]);
-    } else {
-#pragma unroll
-        for (int j = 0; j < N3; ++j) fout[(size_t)u * N3 + j] = x3[j];
-    }
+    for (int j = 0; j < 16; ++j) agg[j] = slab[0][j];
+    long_tail_f16<N1, N2, N3, SIGMOID>(g, ws, fin, fout, logits, P, u, deg, agg);
 }
 
 template <int N1, int N2, int N3>
 __global__ __launch_bounds__(256) void k_long_f1(
         GraphDev g, float ws, const float *__restrict__ xin, float *__restrict__ fout,
         const float *__restrict__ P, uint32_t row_lo, uint32_t row_hi,
-        const uint32_t *__restrict__ list, uint32_t min_deg) {
+        const uint32_t *__restrict__ list, uint32_t min_deg, uint32_t max_deg) {
     // a round = 2048 neighbours (8 per thread); values of round r + 1 and column indices of
     // round r + 2 are in flight while thread 0 adds round r from the LDS slab in CSR order
     constexpr int R = 8;
@@ -877,7 +910,7 @@ __global__ __launch_bounds__(256) void k_long_f1(
     const int tid = threadIdx.x;
     const uint32_t rs = g.rowptr[u], re = g.rowptr[u + 1];
     const uint32_t deg = re - rs;
-    if (deg < min_deg) return;
+    if (deg < min_deg || deg >= max_deg) return;   // (giant rows: k_giant_*)
     const uint32_t nrounds = (deg + kRound - 1) / kRound;
     uint32_t idx[R];
     float v[R];
@@ -917,21 +950,246 @@ __global__ __launch_bounds__(256) void k_long_f1(
 #undef GNNVC_FETCH_IDX1
 #undef GNNVC_FETCH_VAL1
     if (tid != 0) return;
-    float x0[5];
-    x0[0] = agg;
-    x0[1] = xin[u];
-    x0[2] = (float)deg;
-    x0[3] = (float)g.w[u] / ws;
-    x0[4] = (float)g.nw[u] / ws;
-    const float *W1 = P, *b1 = W1 + 5 * N1;
-    const float *W2 = b1 + N1, *b2 = W2 + N1 * N2;
-    const float *W3 = b2 + N2, *b3 = W3 + N2 * N3;
-    float x1[N1], x2[N2], x3[N3];
-    dense<5, 5, N1, 0>(x0, x1, W1, b1);
-    dense<N1, N1, N2, 0>(x1, x2, W2, b2);
-    dense<N2, N2, N3, 0>(x2, x3, W3, b3);
+    long_tail_f1<N1, N2, N3>(g, ws, xin, fout, P, u, deg, agg);
+}
+
+// ------------------------------------------------------------------ giant rows
+// k_long_* still walk a row with ONE add chain: ~4 ns per neighbour, so a hub of 650 K neighbours (R-MAT
+// scale 22) holds its stage for 2.6 ms whatever the other 255 CUs do.  Rows of degree >= the giant threshold
+// take another route that keeps the chain's bits (exact_sum.h: within a binade an fp32 add depends on the
+// accumulator only through the parity of its significand, and such maps compose):
+//   k_giant_gather*  every CU: the row's neighbour values are gathered once, 256 neighbours per workgroup,
+//                    and written COLUMN-major into a slab — one contiguous stream of floats per (row, feature
+//                    column), in stored order (stream c of giant row i at slab + off[i] + c * lpad);
+//   k_giant_sum      one wave per stream: windows of 1024 addends, 16 consecutive ones per lane.  A lane folds
+//                    its addends into a parity map, a 6-step wave scan composes the 64 maps, and if the window
+//                    ends inside the accumulator's binade the new accumulator is m + D[m & 1].  Where it would
+//                    carry (or a lane met a negative / non-finite value) the lanes in front are applied, that
+//                    lane's 16 addends are added the plain way in fp32, and the window resumes behind it with
+//                    the new binade.  A row crosses a binade about log2(degree) times, so nearly every window
+//                    is one step: ~1 ns per neighbour and column, columns in parallel;
+//   k_giant_dense    the rows' dense layers, one lane per row (as the tail of k_long_*).
+// All three skip rows outside [row_lo, row_hi) (vertex-partitioned runs).  FAST (option "hub_mode" 1, never
+// the default): k_giant_sum adds lane-strided partial sums and combines them with a wave tree — the
+// tolerance mode of SURVEY.md §7; results then differ from the chain's in the last bits.
+constexpr int kGiantB = 16;                          // addends per lane and window
+constexpr uint32_t kGiantWin = 64u * kGiantB;        // 1024: streams are padded to a multiple of this
+constexpr uint32_t kGiantBlk = 256;                  // neighbours per gather workgroup
+constexpr int kGiantRing = 4;                        // windows held in registers (three loads in flight)
+
+// meta[i] = {row, first CSR entry, degree, first gather block}, meta[n_giant].w = number of gather blocks
+__device__ __forceinline__ uint32_t giant_of_block(const uint4 *__restrict__ meta, uint32_t n_giant, uint32_t b) {
+    uint32_t lo = 0, hi = n_giant;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (meta[mid].w <= b) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void k_find_giant(GraphDev g, const uint32_t *__restrict__ list, uint32_t n_long, uint32_t thresh,
+                             uint4 *__restrict__ meta, uint32_t *__restrict__ count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_long) return;
+    const uint32_t u = list[i], rs = g.rowptr[u], deg = g.rowptr[u + 1] - rs;
+    if (deg >= thresh) meta[atomicAdd(count, 1u)] = make_uint4(u, rs, deg, 0u);
+}
+
+__global__ __launch_bounds__(256) void k_giant_gather16(GraphDev g, const float4 *__restrict__ fin, float *__restrict__ slab,
+                                                        const uint4 *__restrict__ meta, const unsigned long long *__restrict__ off,
+                                                        uint32_t n_giant, uint32_t row_lo, uint32_t row_hi) {
+    __shared__ __attribute__((aligned(16))) float tile[16][kGiantBlk + 4];
+    const uint32_t i = giant_of_block(meta, n_giant, blockIdx.x);
+    const uint4 mt = meta[i];
+    if (mt.x < row_lo || mt.x >= row_hi) return;      // block-uniform
+    const uint32_t j0 = (blockIdx.x - mt.w) * kGiantBlk, deg = mt.z;
+    const uint32_t lpad = (deg + kGiantWin - 1) / kGiantWin * kGiantWin;
+    const int tid = threadIdx.x, q = tid >> 2, c = tid & 3;
+    const f32x4 *__restrict__ fv = reinterpret_cast<const f32x4 *>(fin);
+    uint32_t idx[4];
 #pragma unroll
-    for (int j = 0; j < N3; ++j) fout[(size_t)u * N3 + j] = x3[j];
+    for (int jj = 0; jj < 4; ++jj) {
+        const uint32_t j = j0 + q + 64 * jj;
+        idx[jj] = j < deg ? g.col[mt.y + j] : g.n;    // past the row's end: the all-zero pad row
+    }
+    f32x4 r[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) r[jj] = fv[(size_t)idx[jj] * 4 + c];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int k = q + 64 * jj;
+        tile[4 * c + 0][k] = r[jj][0];
+        tile[4 * c + 1][k] = r[jj][1];
+        tile[4 * c + 2][k] = r[jj][2];
+        tile[4 * c + 3][k] = r[jj][3];
+    }
+    __syncthreads();
+    float *dst = slab + off[i] + j0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int cc = 4 * p + (tid >> 6), k4 = (tid & 63) * 4;
+        *reinterpret_cast<f32x4 *>(dst + (size_t)cc * lpad + k4) = *reinterpret_cast<const f32x4 *>(&tile[cc][k4]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_giant_gather1(GraphDev g, const float *__restrict__ x, float *__restrict__ slab,
+                                                       const uint4 *__restrict__ meta, const unsigned long long *__restrict__ off,
+                                                       uint32_t n_giant, uint32_t row_lo, uint32_t row_hi) {
+    const uint32_t i = giant_of_block(meta, n_giant, blockIdx.x);
+    const uint4 mt = meta[i];
+    if (mt.x < row_lo || mt.x >= row_hi) return;
+    const uint32_t j = (blockIdx.x - mt.w) * kGiantBlk + threadIdx.x;
+    slab[off[i] + j] = j < mt.z ? x[g.col[mt.y + j]] : 0.0f;
+}
+
+// one window of a stream: this lane's 16 addends are d[0..3]; valid are those with local index in [lo, hi)
+template <bool FAST>
+__device__ __forceinline__ void giant_window(const f32x4 (&d)[kGiantB / 4], int lane, int hi, float &acc, float &part) {
+    if constexpr (FAST) {
+#pragma unroll
+        for (int i = 0; i < kGiantB; ++i) part += (i < hi) ? d[i >> 2][i & 3] : 0.0f;
+        return;
+    }
+    int lo = 0;   // per lane: local indices below lo are consumed
+    for (int guard = 0; guard < 66; ++guard) {   // every pass consumes at least one lane
+        uint32_t E = 0, m = 0;
+        const bool ok = xsum::decode_acc(__float_as_uint(acc), E, m);
+        xsum::Map run = {0u, 0u};
+        bool bad = false;
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < kGiantB; ++i) {
+                const uint32_t vb = (i >= lo && i < hi) ? __float_as_uint(d[i >> 2][i & 3]) : 0u;
+                xsum::append<true>(run, vb, E, bad);
+            }
+        }
+        const unsigned long long badmask = __ballot(bad);
+        if (!ok || __popcll(badmask) > 4) {
+            // the integer route does not apply (negative or non-finite accumulator, or many such addends):
+            // what is left of this window the plain way, in stored order
+            for (int l = 0; l < 64; ++l) {
+                const int llo = __builtin_amdgcn_readlane(lo, l), lhi = __builtin_amdgcn_readlane(hi, l);
+#pragma unroll
+                for (int i = 0; i < kGiantB; ++i) {
+                    const float v = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d[i >> 2][i & 3]), l));
+                    if (i >= llo && i < lhi) acc = acc + v;
+                }
+            }
+            return;
+        }
+        // inclusive scan of the lanes' maps (earlier lanes first)
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            xsum::Map a;
+            a.d0 = __shfl_up(run.d0, s);
+            a.d1 = __shfl_up(run.d1, s);
+            const xsum::Map cmb = xsum::compose(a, run);
+            if (lane >= s) run = cmb;
+        }
+        const uint32_t D = (m & 1u) ? run.d1 : run.d0;
+        const unsigned long long stop = __ballot(bad || m + D >= xsum::kCarry);
+        if (stop == 0ull) {
+            acc = __uint_as_float(xsum::encode_acc(E, m + __builtin_amdgcn_readlane(D, 63)));
+            return;
+        }
+        const int L = __ffsll((long long)stop) - 1;   // uniform: first lane whose end is beyond the binade
+        const uint32_t before = L ? __builtin_amdgcn_readlane(D, L - 1) : 0u;
+        acc = __uint_as_float(xsum::encode_acc(E, m + before));
+        const int llo = __builtin_amdgcn_readlane(lo, L), lhi = __builtin_amdgcn_readlane(hi, L);
+#pragma unroll
+        for (int i = 0; i < kGiantB; ++i) {
+            const float v = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d[i >> 2][i & 3]), L));
+            if (i >= llo && i < lhi) acc = acc + v;
+        }
+        if (L == 63) return;
+        if (lane <= L) lo = kGiantB;
+    }
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(64) void k_giant_sum(const float *__restrict__ slab, const uint4 *__restrict__ meta,
+                                                  const unsigned long long *__restrict__ off, uint32_t F, float *__restrict__ agg,
+                                                  uint32_t row_lo, uint32_t row_hi) {
+    const uint32_t i = blockIdx.x / F, c = blockIdx.x % F;
+    const uint4 mt = meta[i];
+    if (mt.x < row_lo || mt.x >= row_hi) return;
+    const int lane = threadIdx.x;
+    const uint32_t len = mt.z;
+    const uint32_t lpad = (len + kGiantWin - 1) / kGiantWin * kGiantWin;
+    const uint32_t nwin = lpad / kGiantWin;
+    const f32x4 *__restrict__ src = reinterpret_cast<const f32x4 *>(slab + off[i] + (size_t)c * lpad) + lane * (kGiantB / 4);
+    f32x4 buf[kGiantRing][kGiantB / 4];
+    // loads are unconditional (clamped to the last window) so that the in-order vmcnt waits cover exactly the window
+    // being consumed while the next three stay in flight
+#define GNNVC_GIANT_LOAD(slot_, w_)                                                        \
+    {                                                                                      \
+        const uint32_t ww_ = (w_) < nwin ? (w_) : nwin - 1;                                \
+        const f32x4 *p_ = src + (size_t)ww_ * (kGiantWin / 4);                             \
+        _Pragma("unroll") for (int k_ = 0; k_ < kGiantB / 4; ++k_) buf[slot_][k_] = p_[k_]; \
+    }
+#define GNNVC_GIANT_USE(slot_, w_)                                                         \
+    {                                                                                      \
+        const long long left_ = (long long)len - (long long)(w_) * kGiantWin - (long long)lane * kGiantB; \
+        const int hi_ = left_ <= 0 ? 0 : (left_ >= kGiantB ? kGiantB : (int)left_);         \
+        giant_window<FAST>(buf[slot_], lane, hi_, acc, part);                              \
+    }
+    float acc = 0.0f, part = 0.0f;
+    GNNVC_GIANT_LOAD(0, 0u)
+    GNNVC_GIANT_LOAD(1, 1u)
+    GNNVC_GIANT_LOAD(2, 2u)
+    for (uint32_t w = 0; w < nwin; w += 4) {
+        GNNVC_GIANT_LOAD(3, w + 3)
+        GNNVC_GIANT_USE(0, w)
+        if (w + 1 >= nwin) break;
+        GNNVC_GIANT_LOAD(0, w + 4)
+        GNNVC_GIANT_USE(1, w + 1)
+        if (w + 2 >= nwin) break;
+        GNNVC_GIANT_LOAD(1, w + 5)
+        GNNVC_GIANT_USE(2, w + 2)
+        if (w + 3 >= nwin) break;
+        GNNVC_GIANT_LOAD(2, w + 6)
+        GNNVC_GIANT_USE(3, w + 3)
+    }
+#undef GNNVC_GIANT_LOAD
+#undef GNNVC_GIANT_USE
+    if constexpr (FAST) {
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) part += __shfl_xor(part, s);
+        acc = part;
+    }
+    if (lane == 0) agg[(size_t)i * 16 + c] = acc;
+}
+
+// VARIANT as stage_variant(): 0 = F 1 -> 16 features, 1 = F 16 -> 16 features, 2 = F 16 -> sigmoid
+template <int VARIANT>
+__global__ __launch_bounds__(64) void k_giant_dense(GraphDev g, float ws, const float *__restrict__ in, float *__restrict__ out,
+                                                    float *__restrict__ logits, const float *__restrict__ P,
+                                                    const uint4 *__restrict__ meta, uint32_t n_giant,
+                                                    const float *__restrict__ agg, uint32_t row_lo, uint32_t row_hi) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_giant) return;
+    const uint4 mt = meta[i];
+    if (mt.x < row_lo || mt.x >= row_hi) return;
+    if constexpr (VARIANT == 0) {
+        long_tail_f1<32, 32, 16>(g, ws, in, out, P, mt.x, mt.z, agg[(size_t)i * 16]);
+    } else {
+        float a[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j] = agg[(size_t)i * 16 + j];
+        if constexpr (VARIANT == 1)
+            long_tail_f16<32, 32, 16, false>(g, ws, reinterpret_cast<const float4 *>(in), out, nullptr, P, mt.x, mt.z, a);
+        else
+            long_tail_f16<32, 16, 1, true>(g, ws, reinterpret_cast<const float4 *>(in), out, logits, P, mt.x, mt.z, a);
+    }
+}
+
+// the chain's sums of explicit streams (gnnvc_stream_sum: the k_giant_sum path on caller data)
+__global__ void k_stream_meta(uint4 *meta, unsigned long long *off, uint32_t streams, uint32_t len) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > streams) return;
+    const uint32_t lpad = (len + kGiantWin - 1) / kGiantWin * kGiantWin;
+    meta[i] = make_uint4(0u, 0u, len, 0u);
+    if (i < streams) off[i] = (unsigned long long)i * lpad;
 }
 
 // ---- LDS-table plan of the F = 1 stage ---------------------------------------------------------
@@ -2722,24 +2980,78 @@ hipError_t find_long_rows(const GraphDev &g, uint32_t thresh, uint32_t *list, ui
     return hipGetLastError();
 }
 
+hipError_t find_giant_rows(const GraphDev &g, const uint32_t *list, uint32_t n_long, uint32_t thresh, void *meta, uint32_t *count,
+                           hipStream_t stream) {
+    hipError_t rc = hipMemsetAsync(count, 0, sizeof(uint32_t), stream);
+    if (rc != hipSuccess || n_long == 0) return rc;
+    hipLaunchKernelGGL(k_find_giant, dim3((n_long + 255) / 256), dim3(256), 0, stream, g, list, n_long, thresh,
+                       reinterpret_cast<uint4 *>(meta), count);
+    return hipGetLastError();
+}
+
+uint32_t giant_window() { return kGiantWin; }
+uint32_t giant_block() { return kGiantBlk; }
+
+hipError_t launch_giant_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *in, float *out,
+                              float *logits, uint32_t row_lo, uint32_t row_hi, const GiantRows &gr, bool fast, hipStream_t stream) {
+    if (gr.n == 0 || row_hi <= row_lo) return hipSuccess;
+    const uint4 *meta = reinterpret_cast<const uint4 *>(gr.meta);
+    const uint32_t F = sp.f == 16 ? 16u : 1u;
+    if (sp.f == 16)
+        hipLaunchKernelGGL(k_giant_gather16, dim3(gr.blocks), dim3(256), 0, stream, g, reinterpret_cast<const float4 *>(in), gr.slab,
+                           meta, gr.off, gr.n, row_lo, row_hi);
+    else if (sp.f == 1)
+        hipLaunchKernelGGL(k_giant_gather1, dim3(gr.blocks), dim3(256), 0, stream, g, in, gr.slab, meta, gr.off, gr.n, row_lo, row_hi);
+    else
+        return hipErrorInvalidValue;
+    if (fast)
+        hipLaunchKernelGGL(k_giant_sum<true>, dim3(gr.n * F), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.agg, row_lo, row_hi);
+    else
+        hipLaunchKernelGGL(k_giant_sum<false>, dim3(gr.n * F), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.agg, row_lo, row_hi);
+    const float *P = params + sp.param_offset;
+    const dim3 grid((gr.n + 63) / 64), block(64);
+    switch (sp.variant) {
+    case 0: hipLaunchKernelGGL(k_giant_dense<0>, grid, block, 0, stream, g, ws, in, out, logits, P, meta, gr.n, gr.agg, row_lo, row_hi); break;
+    case 1: hipLaunchKernelGGL(k_giant_dense<1>, grid, block, 0, stream, g, ws, in, out, logits, P, meta, gr.n, gr.agg, row_lo, row_hi); break;
+    case 2: hipLaunchKernelGGL(k_giant_dense<2>, grid, block, 0, stream, g, ws, in, out, logits, P, meta, gr.n, gr.agg, row_lo, row_hi); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// sums[i] = the sequential fp32 sum of streams[i * lpad .. + len) (lpad = len rounded up to giant_window()); meta needs
+// streams + 1 entries, off streams entries
+hipError_t stream_sums(const float *streams_dev, uint32_t streams, uint32_t len, void *meta, unsigned long long *off, float *agg,
+                       bool fast, hipStream_t stream) {
+    if (!streams) return hipSuccess;
+    hipLaunchKernelGGL(k_stream_meta, dim3((streams + 256) / 256), dim3(256), 0, stream, reinterpret_cast<uint4 *>(meta), off, streams, len);
+    if (fast)
+        hipLaunchKernelGGL(k_giant_sum<true>, dim3(streams), dim3(64), 0, stream, streams_dev, reinterpret_cast<const uint4 *>(meta), off,
+                           1u, agg, 0u, 1u);
+    else
+        hipLaunchKernelGGL(k_giant_sum<false>, dim3(streams), dim3(64), 0, stream, streams_dev, reinterpret_cast<const uint4 *>(meta), off,
+                           1u, agg, 0u, 1u);
+    return hipGetLastError();
+}
+
 hipError_t launch_long_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params,
                              const float *in, float *out, float *logits, uint32_t row_lo, uint32_t row_hi,
-                             const uint32_t *list, uint32_t n_long, uint32_t min_deg, hipStream_t stream) {
+                             const uint32_t *list, uint32_t n_long, uint32_t min_deg, uint32_t max_deg, hipStream_t stream) {
     if (n_long == 0 || row_hi <= row_lo) return hipSuccess;
     const float *P = params + sp.param_offset;
     const dim3 grid(n_long), block(256);
     switch (sp.variant) {
     case 0:
         hipLaunchKernelGGL((k_long_f1<32, 32, 16>), grid, block, 0, stream, g, ws, in, out, P, row_lo, row_hi, list,
-                           min_deg);
+                           min_deg, max_deg);
         break;
     case 1:
         hipLaunchKernelGGL((k_long_f16<32, 32, 16, false>), grid, block, 0, stream, g, ws,
-                           reinterpret_cast<const float4 *>(in), out, nullptr, P, row_lo, row_hi, list, min_deg);
+                           reinterpret_cast<const float4 *>(in), out, nullptr, P, row_lo, row_hi, list, min_deg, max_deg);
         break;
     case 2:
         hipLaunchKernelGGL((k_long_f16<32, 16, 1, true>), grid, block, 0, stream, g, ws,
-                           reinterpret_cast<const float4 *>(in), out, logits, P, row_lo, row_hi, list, min_deg);
+                           reinterpret_cast<const float4 *>(in), out, logits, P, row_lo, row_hi, list, min_deg, max_deg);
         break;
     default:
         return hipErrorInvalidValue;

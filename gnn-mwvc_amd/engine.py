@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "gnnvc_stage_forward_device", "gnnvc_stage_input_ready", "gnnvc_live_columns", "gnnvc_column_counts", "gnnvc_pack_rows", "gnnvc_unpack_rows", "gnnvc_unpack_gathered",
     "gnnvc_reduction_flags", "gnnvc_score_keys", "gnnvc_synchronize", "gnnvc_last_forward_ms",
     "gnnvc_graph_layer_forward", "gnnvc_linear_forward", "gnnvc_relu_forward",
-    "gnnvc_sigmoid_forward", "gnnvc_sgemm",
+    "gnnvc_sigmoid_forward", "gnnvc_sgemm", "gnnvc_stream_sum",
 ]
 COL_PAD = 64
 
@@ -110,6 +110,7 @@ def load_library():
     L.gnnvc_sigmoid_forward.argtypes = [vp, C.c_size_t, f32p, f32p]
     L.gnnvc_sgemm.argtypes = [vp, C.c_int, C.c_int, u32, u32, u32, f32p, u32, f32p, u32, C.c_float,
                               f32p, u32]
+    L.gnnvc_stream_sum.argtypes = [vp, f32p, u32, u32, C.c_int, f32p]
     for name in ABI_SYMBOLS:
         if name not in ("gnnvc_strerror", "gnnvc_last_error", "gnnvc_destroy"):
             getattr(L, name).restype = C.c_int
@@ -339,6 +340,14 @@ class Engine:
         h = np.ascontiguousarray(h, dtype=np.float32)
         out = np.empty_like(h)
         self._check(self._L.gnnvc_sigmoid_forward(self._h, h.size, _np_ptr(h), _np_ptr(out)))
+        return out
+
+    def stream_sum(self, values: np.ndarray, mode: int = 0) -> np.ndarray:
+        """Sequential fp32 sums of the rows of `values` (streams x len) through the giant-row kernels."""
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        v = v.reshape(1, -1) if v.ndim == 1 else v
+        out = np.empty(v.shape[0], dtype=np.float32)
+        self._check(self._L.gnnvc_stream_sum(self._h, _np_ptr(v), v.shape[0], v.shape[1], mode, _np_ptr(out)))
         return out
 
     def sgemm(self, A: np.ndarray, B: np.ndarray, C_in: np.ndarray | None = None, beta: float = 0.0,

@@ -87,6 +87,14 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *                         fits LDS); smaller chunks mean more rounds of the persistent grids — a test hook
  *   "long_row_threshold" d  rows of degree >= d get a workgroup of their own (default 512,
  *                         0 = off); same CSR-order sums, bit-identical results
+ *   "giant_row_threshold" d  long rows of degree >= d (default 16384, 0 = off) are summed by many waves at once:
+ *                         their neighbour values are gathered by every CU into per-column streams and each stream's
+ *                         sequential fp32 sum is evaluated with a parallel scan that reproduces the chain's
+ *                         roundings (csrc/exact_sum.h); bit-identical results
+ *   "hub_mode"       0|1  0 (default) = exact; 1 = FAST, the tolerance mode of SURVEY.md §7: every long row goes the
+ *                         giant-row way and its streams are added as lane-strided partial sums + a wave tree.
+ *                         Scores then differ from the reference's in the last bits (and with them, possibly, the
+ *                         cover the greedy builds); never the default, never what the parity tests run
  *   "mfma_dense"     0|1|2  dense layers on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, a
  *                         k-ordered fma chain: same bits as the VALU path): 0 = VALU, 1 = MFMA in
  *                         every stage, 2 = MFMA in the 16-wide stages only (default); immediate
@@ -96,7 +104,7 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *   "sorted_min_nnz" n     in auto mode, graphs with fewer adjacency entries keep natural tiles
  *                         (default 4 Mi: the sort costs more than it saves on a graph used once)
  * gnnvc_get_info keys: "compact_gather_active", "compact_gather_chunks", "lds_table_active", "lds_table_chunks", "lds_table_steps", "mfma_dense", "sorted_tiles_active", "tile_waste_x100", "blocked_stage0_active", "blocked_blocks", "block_cols", "long_rows",
- * "long_row_threshold". */
+ * "long_row_threshold", "giant_rows", "giant_entries", "giant_row_threshold", "hub_mode". */
 int gnnvc_set_option(gnnvc_engine *e, const char *key, long value);
 int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value);
 
@@ -255,6 +263,13 @@ int gnnvc_linear_forward(gnnvc_engine *e, uint32_t n, uint32_t k, uint32_t m,
 /* ReLU::forward / sigmoid::forward (reference src/gnn_inference.cpp:44-52). */
 int gnnvc_relu_forward(gnnvc_engine *e, size_t count, const float *in, float *out);
 int gnnvc_sigmoid_forward(gnnvc_engine *e, size_t count, const float *in, float *out);
+
+/* The neighbour sum of graph_layer::forward (reference src/gnn_inference.cpp:33-36) on explicit data:
+ * sums[i] = (((0 + v[i][0]) + v[i][1]) + ...) + v[i][len-1], one rounded fp32 add per element, for `streams`
+ * rows of `len` floats (host pointers, row-major).  mode 0 evaluates that chain with the engine's parallel
+ * giant-row kernels and returns its exact bits whatever the data holds; mode 1 is the tolerance mode (tree
+ * sums: a few ulp off).  The layer-level handle on the path rows of degree >= "giant_row_threshold" take. */
+int gnnvc_stream_sum(gnnvc_engine *e, const float *values, uint32_t streams, uint32_t len, int mode, float *sums);
 
 /* dot() (reference src/matrix.cpp:106-122, the cblas_sgemm seam):
  * C = op(A) * op(B) + beta * C, row-major, op = transpose when the flag is set;

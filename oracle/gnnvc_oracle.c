@@ -195,6 +195,62 @@ void oracle_linear_layer(uint32_t n, uint32_t k, uint32_t m, const float *in,
     }
 }
 
+/* The reference's own call pattern for timing (bench.py's cpu_baseline): dot() hands the product to
+ * cblas_sgemm (src/matrix.cpp:112-121: RowMajor, no transposes, alpha 1, beta 0, lda = k, ldb = ldc = m) —
+ * here through a function pointer the caller found by dlopen'ing an OpenBLAS, since the image has no
+ * header to link against — and linear_layer::forward then adds the bias row by row, serially
+ * (src/gnn_inference.cpp:22-24).  Same bits as oracle_linear_layer (tests/test_openblas_seam.py). */
+typedef void (*oracle_cblas_sgemm_fn)(int order, int ta, int tb, int M, int N, int K, float alpha, const float *A, int lda,
+                                      const float *B, int ldb, float beta, float *C, int ldc);
+static oracle_cblas_sgemm_fn g_cblas_sgemm = NULL;
+
+void oracle_set_cblas_sgemm(void *fn) { g_cblas_sgemm = (oracle_cblas_sgemm_fn)fn; }
+int oracle_has_cblas_sgemm(void) { return g_cblas_sgemm != NULL; }
+
+static void linear_layer_as_shipped(uint32_t n, uint32_t k, uint32_t m, const float *in, const float *W, const float *bias,
+                                    float *out) {
+    if (!g_cblas_sgemm) {
+        oracle_linear_layer(n, k, m, in, W, bias, out);
+        return;
+    }
+    g_cblas_sgemm(101 /* CblasRowMajor */, 111 /* CblasNoTrans */, 111, (int)n, (int)m, (int)k, 1.0f, in, (int)k, W, (int)m, 0.0f,
+                  out, (int)m);
+    for (uint32_t i = 0; i < n; i++) {
+        float *o = out + (size_t)i * m;
+        for (uint32_t j = 0; j < m; j++) o[j] = o[j] + bias[j];
+    }
+}
+
+/* dot() in full (src/matrix.cpp:106-122): C = op(A) * op(B) + beta * C, row-major; m, n, k after op.
+ * The restatement the engine's gnnvc_sgemm documents (include/gnnvc.h): one sequential-k fmaf chain per output
+ * from +0.0f, then — only when beta != 0 — fmaf(beta, C_old, chain).  The inference path always passes
+ * beta = 0 (src/gnn_inference.cpp:21).  With beta != 0 OpenBLAS itself rounds in two different ways
+ * depending on the problem size (its small-matrix kernels fuse beta * C into the final add, its blocked
+ * path scales C first: tests/test_openblas_seam.py records both), so there is no single third-party
+ * behaviour to restate there; the fused form is the documented contract. */
+void oracle_sgemm(int ta, int tb, uint32_t m, uint32_t n, uint32_t k, const float *A, uint32_t lda, const float *B,
+                  uint32_t ldb, float beta, float *C, uint32_t ldc) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)m; i++)
+        for (uint32_t j = 0; j < n; j++) {
+            float acc = 0.0f;
+            for (uint32_t kk = 0; kk < k; kk++) {
+                const float a = ta ? A[(size_t)kk * lda + i] : A[(size_t)i * lda + kk];
+                const float b = tb ? B[(size_t)j * ldb + kk] : B[(size_t)kk * ldb + j];
+                acc = fmaf(a, b, acc);
+            }
+            float *c = &C[(size_t)i * ldc + j];
+            *c = (beta == 0.0f) ? acc : fmaf(beta, *c, acc);
+        }
+}
+
+static void relu_serial(size_t count, const float *in, float *out) {
+    for (size_t i = 0; i < count; i++) {
+        float x = in[i];
+        out[i] = (x < 0.0f) ? 0.0f : x;
+    }
+}
+
 /* ReLU::forward (src/gnn_inference.cpp:44-47): std::max(x, 0.0f) — returns x
  * unless x < 0 (so -0.0f and NaN pass through like std::max does). */
 void oracle_relu(size_t count, const float *in, float *out) {
@@ -248,7 +304,8 @@ int oracle_predict(const oracle_model *m, const oracle_graph *g, uint32_t in_wid
         const oracle_layer *l = &m->layers[i];
         switch (l->kind) {
         case ORACLE_LAYER_LINEAR:
-            oracle_linear_layer(n, l->k, l->m, a, l->W, l->bias, b);
+            if (flags & 2) linear_layer_as_shipped(n, l->k, l->m, a, l->W, l->bias, b);
+            else oracle_linear_layer(n, l->k, l->m, a, l->W, l->bias, b);
             wd = l->m;
             break;
         case ORACLE_LAYER_GRAPH:
@@ -256,7 +313,8 @@ int oracle_predict(const oracle_model *m, const oracle_graph *g, uint32_t in_wid
             wd = 2 * wd + 3;
             break;
         case ORACLE_LAYER_RELU:
-            oracle_relu((size_t)n * wd, a, b);
+            if (flags & 2) relu_serial((size_t)n * wd, a, b);   /* the reference's std::transform is serial */
+            else oracle_relu((size_t)n * wd, a, b);
             break;
         case ORACLE_LAYER_SIGMOID:
             oracle_sigmoid((size_t)n * wd, a, b);

@@ -95,10 +95,21 @@ void oracle_neighbourhood_weights(uint32_t n, const uint64_t *rowptr,
  * n * 35 floats in the worst case (or n * max layer width).
  * flags bit0: parallelise the aggregation over rows (the variant the
  * reference's inert pragma intended); 0 = serial as shipped.
+ * flags bit1: the reference's threading for timing — the products through the cblas_sgemm given to
+ * oracle_set_cblas_sgemm (its own thread pool), bias adds and ReLU serial; same bits.
  * Returns 0 on success. */
 int oracle_predict(const oracle_model *m, const oracle_graph *g,
                    uint32_t in_width, const float *in, float *out,
                    uint32_t *out_width, int stop_after, int flags);
+
+/* bench.py's cpu_baseline: a cblas_sgemm found at run time (dlopen of an OpenBLAS), used by
+ * oracle_predict(flags bit1) the way src/matrix.cpp:112-121 calls it.  NULL = the internal fmaf loops. */
+void oracle_set_cblas_sgemm(void *fn);
+int oracle_has_cblas_sgemm(void);
+
+/* dot() with transposes and beta (src/matrix.cpp:106-122) as include/gnnvc.h documents gnnvc_sgemm. */
+void oracle_sgemm(int ta, int tb, uint32_t m, uint32_t n, uint32_t k, const float *A, uint32_t lda, const float *B,
+                  uint32_t ldb, float beta, float *C, uint32_t ldc);
 
 /* Reduction-rule predicates on the unmutated graph, one byte per vertex:
  * bit r = "rule r of reduce_graph's switch would fire on u right now", for all seven local rules —

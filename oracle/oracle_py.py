@@ -68,6 +68,11 @@ def lib():
         L.oracle_score_keys.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_score_keys.restype = None
         L.oracle_reduction_flags.argtypes = [C.POINTER(_Graph), C.c_uint32, C.c_void_p]
+        L.oracle_set_cblas_sgemm.argtypes = [C.c_void_p]
+        L.oracle_has_cblas_sgemm.restype = C.c_int
+        L.oracle_sgemm.restype = None
+        L.oracle_sgemm.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
+                                   C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_uint32]
         L.oracle_num_threads.restype = C.c_int
         L.oracle_set_num_threads.argtypes = [C.c_int]
         # Size the OpenMP team to the CPUs this process may really use: a GPU box hands out a
@@ -132,8 +137,9 @@ class OracleModel:
     def set_weight_scale(self, ws: float):
         lib().oracle_model_set_weight_scale(self._m, C.c_float(ws))
 
-    def predict(self, g, x: np.ndarray, stop_after: int = -1, parallel_agg: bool = False):
-        """Returns the [n, width] output after layer `stop_after` (-1 = all)."""
+    def predict(self, g, x: np.ndarray, stop_after: int = -1, parallel_agg: bool = False, as_shipped: bool = False):
+        """Returns the [n, width] output after layer `stop_after` (-1 = all).  as_shipped: the reference's
+        threading (products through the cblas_sgemm set with use_openblas(), everything else serial)."""
         x = np.ascontiguousarray(x, dtype=np.float32)
         x = x.reshape(g.n, x.size // g.n if g.n else 1)
         gs, keep = _graph_struct(g)
@@ -141,7 +147,7 @@ class OracleModel:
                        dtype=np.float32)
         wd = C.c_uint32(0)
         rc = lib().oracle_predict(self._m, C.byref(gs), x.shape[1], _ptr(x), _ptr(out),
-                                  C.byref(wd), stop_after, 1 if parallel_agg else 0)
+                                  C.byref(wd), stop_after, (1 if parallel_agg else 0) | (2 if as_shipped else 0))
         if rc != 0:
             raise RuntimeError(f"oracle_predict failed: {rc}")
         del keep
@@ -205,6 +211,75 @@ def reduction_flags(g, max_degree: int = 20) -> np.ndarray:
     lib().oracle_reduction_flags(C.byref(gs), max_degree, _ptr(flags))
     del keep
     return flags
+
+
+def sgemm(A, B, C_in=None, beta: float = 0.0, trans_a: bool = False, trans_b: bool = False) -> np.ndarray:
+    """dot() with transposes and beta as include/gnnvc.h documents gnnvc_sgemm (oracle_sgemm)."""
+    A = np.ascontiguousarray(A, dtype=np.float32)
+    B = np.ascontiguousarray(B, dtype=np.float32)
+    m = A.shape[1] if trans_a else A.shape[0]
+    k = A.shape[0] if trans_a else A.shape[1]
+    n = B.shape[0] if trans_b else B.shape[1]
+    out = np.zeros((m, n), dtype=np.float32) if C_in is None else np.ascontiguousarray(C_in, dtype=np.float32).copy()
+    lib().oracle_sgemm(int(trans_a), int(trans_b), m, n, k, _ptr(A), A.shape[1], _ptr(B), B.shape[1], C.c_float(beta),
+                       _ptr(out), n)
+    return out
+
+
+_openblas = None
+
+
+def find_openblas():
+    """(path, symbol) of an LP64 OpenBLAS cblas_sgemm on this machine: a system libopenblas, or the one SciPy
+    bundles (`scipy_cblas_sgemm`); None if neither is present."""
+    import ctypes.util
+    import glob
+    cands = []
+    sysname = ctypes.util.find_library("openblas")
+    if sysname:
+        cands.append((sysname, "cblas_sgemm"))
+    try:
+        import scipy
+        base = os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)), "scipy.libs")
+        cands += [(p, "scipy_cblas_sgemm") for p in sorted(glob.glob(os.path.join(base, "libscipy_openblas-*.so")))]
+    except Exception:
+        pass
+    for path, sym in cands:
+        try:
+            L = C.CDLL(path)
+            if hasattr(L, sym):
+                return path, sym
+        except OSError:
+            continue
+    return None
+
+
+def use_openblas(threads: int = 0):
+    """Route predict(as_shipped=True)'s products through a discovered OpenBLAS (what the reference links,
+    src/matrix.cpp:5,112-121).  Returns a description string, or None when no OpenBLAS was found (the internal
+    fmaf loops stay in place)."""
+    global _openblas
+    hit = find_openblas()
+    if hit is None:
+        lib().oracle_set_cblas_sgemm(None)
+        return None
+    path, sym = hit
+    L = C.CDLL(path)
+    fn = getattr(L, sym)
+    for name in ("scipy_openblas_set_num_threads", "openblas_set_num_threads"):
+        if threads and hasattr(L, name):
+            getattr(L, name)(threads)
+            break
+    ver = ""
+    for name in ("scipy_openblas_get_config", "openblas_get_config"):
+        if hasattr(L, name):
+            f = getattr(L, name)
+            f.restype = C.c_char_p
+            ver = (f() or b"").decode(errors="replace")
+            break
+    _openblas = (L, fn)   # keep the library alive
+    lib().oracle_set_cblas_sgemm(C.cast(fn, C.c_void_p))
+    return f"{os.path.basename(path)}:{sym} [{ver.strip()}]"
 
 
 def num_threads() -> int:

@@ -828,6 +828,151 @@ def test_long_row_path_is_bit_identical(model_text, oracle_model, thresh, block_
         e.close()
 
 
+# ---------------------------------------------------------------- giant rows: the chain's bits from a parallel scan
+
+def _seq_sum(v):
+    return np.cumsum(np.ascontiguousarray(v, dtype=np.float32), dtype=np.float32)[-1] if len(v) else np.float32(0)
+
+
+def test_stream_sum_entry_point_is_the_sequential_chain(engine):
+    """gnnvc_stream_sum (k_giant_sum on caller data) against acc = acc + v[i] (reference src/gnn_inference.cpp:33-36)
+    on streams chosen to hit every branch of csrc/exact_sum.h: ties, parity flips, carries through many binades,
+    denormals, huge jumps, overflow, -0.0, negative and non-finite values."""
+    rng = np.random.default_rng(7)
+    n = 70_000
+    streams = []
+    v = rng.gamma(2.0, 0.7, n).astype(np.float32); v[rng.random(n) < 0.4] = 0.0; streams.append(v)
+    streams.append((rng.integers(20, 121, n) / np.float32(120.0)).astype(np.float32))
+    t = (rng.integers(0, 64, n) * np.float32(1 / 16)).astype(np.float32); t[0] = 4096.0; streams.append(t)
+    streams.append(np.full(n, 1.0, dtype=np.float32))
+    streams.append(np.full(n, 0.1, dtype=np.float32))
+    a = np.tile(np.array([1.5, 0.5, 2.5, 1.0], dtype=np.float32) * np.float32(2.0 ** -10), n // 4); a[0] = 8191.0; streams.append(a)
+    streams.append((rng.random(n).astype(np.float32) * np.exp2(rng.integers(-149, 20, n)).astype(np.float32)).astype(np.float32))
+    streams.append(rng.integers(0, 1 << 20, n).astype(np.uint32).view(np.float32))          # denormals only
+    streams.append(rng.integers(0, 1 << 24, n).astype(np.uint32).view(np.float32))          # across the denormal boundary
+    j = rng.uniform(0, 1, n).astype(np.float32); j[n // 2] = 3.0e30; streams.append(j)
+    b = rng.uniform(0, 1, n).astype(np.float32); b[1000:11000] = 3.0e38; streams.append(b)  # overflows to +inf
+    z = rng.uniform(0, 2, n).astype(np.float32); z[::997] = -0.0; streams.append(z)
+    g1 = z.copy(); g1[1234] = -5.0; g1[55_555] = -1e-3; streams.append(g1)                  # two negative values
+    streams.append(rng.normal(0, 1, n).astype(np.float32))                                  # half negative
+    q = z.copy(); q[40_000] = np.nan; streams.append(q)
+    i2 = z.copy(); i2[10] = np.inf; i2[20_000] = -np.inf; streams.append(i2)
+    streams.append(np.zeros(n, dtype=np.float32))
+    bitsr = rng.integers(0, 1 << 31, n).astype(np.uint32); bitsr[(bitsr >> 23) == 255] &= 0x7F000000
+    streams.append(bitsr.view(np.float32))
+    V = np.stack(streams)
+    got = engine.stream_sum(V)
+    with np.errstate(all="ignore"):
+        want = np.array([_seq_sum(r) for r in V], dtype=np.float32)
+    same = (bits(got) == bits(want)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), f"streams {np.nonzero(~same)[0].tolist()} differ: {got[~same]} vs {want[~same]}"
+    # ragged lengths around the window size (1024 addends) and the lane size (16)
+    for ln in (1, 15, 16, 17, 1023, 1024, 1025, 2048, 5000):
+        r = rng.gamma(2.0, 0.7, (3, ln)).astype(np.float32)
+        assert np.array_equal(bits(engine.stream_sum(r)), bits(np.array([_seq_sum(x) for x in r], dtype=np.float32))), ln
+    assert engine.stream_sum(np.zeros((2, 0), dtype=np.float32)).tolist() == [0.0, 0.0]
+    # the tolerance mode is close, not equal
+    fast = engine.stream_sum(V[:2], mode=1)
+    assert np.all(np.abs(fast - want[:2]) <= 2e-4 * np.abs(want[:2]))
+
+
+@pytest.mark.parametrize("giant,long_t", [(64, 8), (300, 64), (1000, 512), (5000, 512)])
+def test_giant_row_path_is_bit_identical(model_text, oracle_model, giant, long_t):
+    """Rows of degree >= "giant_row_threshold" are gathered into per-column streams and summed by k_giant_sum; the
+    rest of the long rows stay with k_long_*.  Same bits as the chain, whole forwards and vertex sub-ranges."""
+    import gnn_mwvc_amd as G
+    import torch
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_option("long_row_threshold", long_t)
+        e.set_option("giant_row_threshold", giant)
+        e.set_option("sorted_tiles", 0)
+        graphs = [gg.hub_graph(20000, 60000, 3, 4096, seed=7), gg.rmat(11, 16, 5),
+                  gg.hub_graph(30000, 40000, 2, 20000, seed=8),
+                  gg.from_edge_list(700, [(0, i) for i in range(1, 700)] + [(1, i) for i in range(2, 300)],
+                                    [20 + (i % 101) for i in range(700)])]
+        for g in graphs:
+            e.set_weight_scale(g.ws)
+            oracle_model.set_weight_scale(g.ws)
+            e.upload_graph(g)
+            deg = np.diff(g.rowptr.astype(np.int64))
+            assert e.get_info("giant_rows") == int((deg >= max(giant, long_t)).sum())
+            assert e.get_info("giant_entries") == int(deg[deg >= max(giant, long_t)].sum())
+            scores, logits = e.forward(g.x())
+            assert np.array_equal(bits(logits[:, 0]), bits(oracle_model.logits(g)))
+            assert ulp(scores[:, 0], oracle_model.scores(g)).max() <= 1
+            dev = torch.device("cuda:0")
+            x = torch.from_numpy(g.x()).to(dev)
+            h1 = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+            h2 = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+            mid = (g.n // 3) // 64 * 64
+            for lo, hi in ((0, mid), (mid, g.n)):
+                e.stage_forward_device(0, lo, hi, x.data_ptr(), h1.data_ptr())
+            for lo, hi in ((0, mid), (mid, g.n)):
+                e.stage_forward_device(1, lo, hi, h1.data_ptr(), h2.data_ptr())
+            e.synchronize()
+            assert np.array_equal(bits(h2[:-1].cpu().numpy()), bits(oracle_model.predict(g, g.x(), stop_after=13)))
+    finally:
+        e.close()
+
+
+def test_giant_rows_with_arbitrary_features(model_text, oracle_model):
+    """Stage entry point with inputs the model itself never produces (negative values, -0.0): the giant-row sums
+    still are the chain's."""
+    import gnn_mwvc_amd as G
+    import torch
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_option("long_row_threshold", 64)
+        e.set_option("giant_row_threshold", 1000)
+        g = gg.hub_graph(20000, 60000, 3, 4096, seed=7)
+        e.set_weight_scale(g.ws)
+        oracle_model.set_weight_scale(g.ws)
+        e.upload_graph(g)
+        rng = np.random.default_rng(3)
+        for kind in ("mixed_sign", "few_negative"):
+            h = rng.gamma(2.0, 0.5, (g.n, 16)).astype(np.float32)
+            h[rng.random((g.n, 16)) < 0.5] = 0.0
+            if kind == "mixed_sign":
+                h *= rng.choice(np.array([-1.0, 1.0], dtype=np.float32), size=h.shape)
+            else:
+                h[rng.integers(0, g.n, 40), rng.integers(0, 16, 40)] = -3.0
+                h[rng.integers(0, g.n, 40), rng.integers(0, 16, 40)] = -0.0
+            dev = torch.device("cuda:0")
+            hin = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+            hin[:-1] = torch.from_numpy(h).to(dev)
+            hout = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+            e.stage_forward_device(1, 0, g.n, hin.data_ptr(), hout.data_ptr())
+            e.synchronize()
+            want = _oracle_stage(oracle_model, g, 1, h)
+            assert np.array_equal(bits(hout[:-1].cpu().numpy()), bits(want)), kind
+    finally:
+        e.close()
+
+
+def test_fast_hub_mode_is_within_its_tolerance(model_text, oracle_model):
+    """Option "hub_mode" 1 (SURVEY.md §7's tolerance mode: tree sums for every long row).  Not bit-identical by
+    design; the bound stated in DESIGN.md is |delta score| <= 5e-6 and no score crossing 0.5."""
+    import gnn_mwvc_amd as G
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_option("hub_mode", 1)
+        for g in (gg.hub_graph(20000, 60000, 3, 4096, seed=7), gg.hub_graph(200000, 400000, 3, 65536, seed=5)):
+            e.set_weight_scale(g.ws)
+            oracle_model.set_weight_scale(g.ws)
+            e.upload_graph(g)
+            assert e.get_info("giant_rows") == e.get_info("long_rows") > 0
+            scores, logits = e.forward(g.x())
+            want = oracle_model.scores(g)
+            d = np.abs(scores[:, 0].astype(np.float64) - want.astype(np.float64))
+            assert d.max() <= 5e-6, d.max()
+            assert int(((scores[:, 0] > 0.5) != (want > 0.5)).sum()) == 0
+    finally:
+        e.close()
+
+
 # ---------------------------------------------------------------- dense layers: MFMA vs VALU
 
 @pytest.mark.parametrize("mfma", [0, 1, 2])
