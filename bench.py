@@ -87,6 +87,9 @@ def main() -> int:
     ap.add_argument("--no-blocked", action="store_true", help="disable the column-blocked F=1 stage (A/B)")
     ap.add_argument("--block-cols", type=int, default=0)
     ap.add_argument("--long-threshold", type=int, default=-1, help="degree at which a row gets its own workgroup")
+    ap.add_argument("--giant-threshold", type=int, default=-1, help="degree from which a long row is summed by the parallel scan kernels")
+    ap.add_argument("--hub-mode", type=int, default=0, help="1 = tolerance mode for long rows (tree sums); never the default")
+    ap.add_argument("--side-streams", type=int, default=1, help="0 = long / giant rows on the main stream (profiling: standalone kernel times)")
     ap.add_argument("--sorted-tiles", type=int, default=-1, help="degree-sorted tiles: -1 auto, 0 off, 1 on")
     ap.add_argument("--sorted-long-threshold", type=int, default=0)
     ap.add_argument("--mfma", type=int, default=-1, help="dense layers: 0 VALU, 1 MFMA everywhere, 2 MFMA in the 16-wide stages (default)")
@@ -158,6 +161,11 @@ def main() -> int:
         eng.set_option("long_row_threshold", args.long_threshold)
     if args.mfma >= 0:
         eng.set_option("mfma_dense", args.mfma)
+    if args.giant_threshold >= 0:
+        eng.set_option("giant_row_threshold", args.giant_threshold)
+    if args.hub_mode:
+        eng.set_option("hub_mode", 1)
+    eng.set_option("side_streams", args.side_streams)
     eng.set_option("sorted_tiles", args.sorted_tiles)
     if args.sorted_long_threshold > 0:
         eng.set_option("sorted_long_row_threshold", args.sorted_long_threshold)

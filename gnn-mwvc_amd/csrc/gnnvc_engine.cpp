@@ -172,8 +172,11 @@ struct gnnvc_engine {
     DevBuf<uint32_t> long_list, long_count;
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t giant_stream = nullptr;  // giant rows: three dependent launches, the side work's long pole -> a high-priority stream of its own
+    hipEvent_t ev_giant = nullptr;
     // giant rows (degree >= giant_thresh, a subset of the long rows): CSR-order sums evaluated in parallel (exact_sum.h)
     uint32_t opt_giant_thresh = 16384;   // option "giant_row_threshold" (0 = off: k_long_* take every long row)
+    int opt_side_streams = 1;            // option "side_streams": 0 = long / giant rows on the main stream, one after the other (profiling)
     int opt_hub_mode = 0;                // option "hub_mode": 0 = exact (the chain's bits), 1 = fast (tree sums, tolerance mode)
     uint32_t giant_thresh = 0xFFFFFFFFu, n_giant = 0, giant_blocks = 0;
     uint64_t giant_entries = 0;
@@ -394,6 +397,12 @@ int find_giant(gnnvc_engine *e) {
     HIP_TRY(e, e->gi_agg.reserve((size_t)cnt * 16));
     HIP_TRY(e, hipMemcpy(e->gi_meta.p, meta.data(), ((size_t)cnt + 1) * sizeof(uint4), hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(e->gi_off.p, off.data(), (size_t)cnt * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    if (!e->giant_stream) {
+        int lo_p = 0, hi_p = 0;   // (numerically lower = higher priority)
+        HIP_TRY(e, hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+        HIP_TRY(e, hipStreamCreateWithPriority(&e->giant_stream, hipStreamNonBlocking, hi_p));
+        HIP_TRY(e, hipEventCreateWithFlags(&e->ev_giant, hipEventDisableTiming));
+    }
     e->n_giant = cnt;
     e->giant_blocks = (uint32_t)blocks;
     e->giant_entries = entries;
@@ -744,9 +753,14 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
                           (size_t)stage + 1 < ns_ && e->stages[stage + 1].f == 16 && lo == 0 && hi == e->g.n && e->opt_mfma != 1;
     const uint32_t thr = (e->stages[stage].f == 16) ? e->thresh_f16 : e->long_thresh;   // this stage's long-row threshold
     if (longs) {   // fork: the long rows of this stage run beside the tile kernel
-        HIP_TRY(e, hipEventRecord(e->ev_fork, e->stream));
-        HIP_TRY(e, hipStreamWaitEvent(e->aux_stream, e->ev_fork, 0));
-        if (e->n_giant) {   // the heaviest rows first: they are the long pole of the side stream
+        const bool side = e->opt_side_streams != 0;
+        hipStream_t s_long = side ? e->aux_stream : e->stream, s_giant = side ? e->giant_stream : e->stream;
+        if (side) {
+            HIP_TRY(e, hipEventRecord(e->ev_fork, e->stream));
+            HIP_TRY(e, hipStreamWaitEvent(e->aux_stream, e->ev_fork, 0));
+        }
+        if (e->n_giant) {   // the heaviest rows: beside the tile kernel AND beside the other long rows
+            if (side) HIP_TRY(e, hipStreamWaitEvent(e->giant_stream, e->ev_fork, 0));
             gnnvc::GiantRows gr;
             gr.n = e->n_giant;
             gr.blocks = e->giant_blocks;
@@ -755,12 +769,13 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
             gr.slab = e->gi_slab.p;
             gr.agg = e->gi_agg.p;
             HIP_TRY(e, gnnvc::launch_giant_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi, gr,
-                                                 e->opt_hub_mode == 1, e->aux_stream));
+                                                 e->opt_hub_mode == 1, s_giant));
+            if (side) HIP_TRY(e, hipEventRecord(e->ev_giant, e->giant_stream));
         }
         if (e->n_giant < e->n_long)
             HIP_TRY(e, gnnvc::launch_long_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi,
-                                                e->long_list.p, e->n_long, thr, e->giant_thresh, e->aux_stream));
-        HIP_TRY(e, hipEventRecord(e->ev_join, e->aux_stream));
+                                                e->long_list.p, e->n_long, thr, e->giant_thresh, s_long));
+        if (side) HIP_TRY(e, hipEventRecord(e->ev_join, e->aux_stream));
     }
     // The LDS-table plan works in chunks of ~19.5 K rows, one workgroup each: a call that covers fewer than
     // three quarters of a GPU's worth of chunks (the pieces of a pipelined multi-GPU run) would leave most CUs
@@ -901,7 +916,10 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
             }
         }
     }
-    if (longs) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));   // join
+    if (longs && e->opt_side_streams) {   // join
+        HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
+        if (e->n_giant) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_giant, 0));
+    }
     return GNNVC_OK;
 }
 
@@ -1047,6 +1065,8 @@ void gnnvc_destroy(gnnvc_engine *e) {
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->aux_stream) { (void)hipStreamSynchronize(e->aux_stream); (void)hipStreamDestroy(e->aux_stream); }
+    if (e->giant_stream) { (void)hipStreamSynchronize(e->giant_stream); (void)hipStreamDestroy(e->giant_stream); }
+    if (e->ev_giant) (void)hipEventDestroy(e->ev_giant);
     for (auto v : e->ev) (void)hipEventDestroy(v);
     for (auto v : e->round_ev) (void)hipEventDestroy(v);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -1076,6 +1096,7 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "long_row_threshold") e->opt_long_thresh = value > 0 ? (uint32_t)value : 0;
     else if (k == "giant_row_threshold") e->opt_giant_thresh = value > 0 ? (uint32_t)std::max<long>(value, 64) : 0;
     else if (k == "hub_mode") e->opt_hub_mode = value == 1 ? 1 : 0;
+    else if (k == "side_streams") e->opt_side_streams = value != 0 ? 1 : 0;
     else if (k == "compact_gather") e->opt_compact = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else if (k == "lds_table") e->opt_lds_table = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else if (k == "sorted_min_nnz") e->opt_sorted_min_nnz = value > 0 ? (uint64_t)value : 0;
