@@ -175,6 +175,7 @@ struct gnnvc_engine {
     hipStream_t giant_stream = nullptr;  // giant rows: three dependent launches, the side work's long pole -> a high-priority stream of its own
     hipEvent_t ev_giant = nullptr;
     // giant rows (degree >= giant_thresh, a subset of the long rows): CSR-order sums evaluated in parallel (exact_sum.h)
+    bool empty_slice = false;            // gnnvc_attach_graph_slice with no rows: every stage call is a no-op
     uint32_t opt_giant_thresh = 16384;   // option "giant_row_threshold" (0 = off: k_long_* take every long row)
     int opt_side_streams = 1;            // option "side_streams": 0 = long / giant rows on the main stream, one after the other (profiling)
     int opt_hub_mode = 0;                // option "hub_mode": 0 = exact (the chain's bits), 1 = fast (tree sums, tolerance mode)
@@ -425,13 +426,14 @@ int find_long(gnnvc_engine *e) {
     e->sorted_wanted = false;
     e->srt_waste = 0.0;
     e->interleave = false;
-    if (e->stages.empty() || g.n == 0) return GNNVC_OK;
-    if (g.nnz && g.n >= 4096) {
+    if (e->stages.empty() || g.n == 0 || g.hi() <= g.lo()) return GNNVC_OK;
+    const uint32_t glo = g.lo(), ghi = g.hi();   // the rows this engine holds (a slice of a partitioned graph, or all)
+    if (g.nnz && ghi - glo >= 4096) {
         // The natural tile map hands each XCD a contiguous eighth of the rows.  If the eighths hold
         // very different numbers of entries (R-MAT: low ids are the hubs) deal tiles round-robin.
         uint32_t cut[9];
         for (int k = 0; k <= 8; ++k)
-            HIP_TRY(e, hipMemcpyAsync(&cut[k], g.rowptr + (size_t)((uint64_t)g.n * k / 8), sizeof(uint32_t),
+            HIP_TRY(e, hipMemcpyAsync(&cut[k], g.rowptr + glo + (size_t)((uint64_t)(ghi - glo) * k / 8), sizeof(uint32_t),
                                       hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(e, hipStreamSynchronize(e->stream));
         uint32_t mx = 0;
@@ -442,7 +444,7 @@ int find_long(gnnvc_engine *e) {
     if (e->opt_sorted != 0 && g.nnz) {
         // lockstep cost of natural 64-row tiles (64 x sum of per-tile maxima) against the useful work
         HIP_TRY(e, e->srt_sum.reserve(1));
-        HIP_TRY(e, gnnvc::measure_tile_waste(g, 0, g.n, base_thresh, e->srt_sum.p, e->stream));
+        HIP_TRY(e, gnnvc::measure_tile_waste(g, glo, ghi, base_thresh, e->srt_sum.p, e->stream));
         unsigned long long sum_max = 0;
         HIP_TRY(e, hipMemcpyAsync(&sum_max, e->srt_sum.p, sizeof sum_max, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -457,7 +459,7 @@ int find_long(gnnvc_engine *e) {
     // (the others return at once from the long kernel and sit in the sorted tile list instead).
     const uint32_t thresh = e->opt_long_thresh;
     e->thresh_f16 = 0xFFFFFFFFu;
-    HIP_TRY(e, e->long_list.reserve(g.n));
+    HIP_TRY(e, e->long_list.reserve(ghi - glo));
     HIP_TRY(e, e->long_count.reserve(1));
     HIP_TRY(e, gnnvc::find_long_rows(g, thresh, e->long_list.p, e->long_count.p, e->stream));
     uint32_t cnt = 0;
@@ -521,6 +523,7 @@ int build_blocked(gnnvc_engine *e) {
     e->blocked_tried = true;
     const GraphDev &g = e->g;
     if (!e->opt_blocked || e->stages.empty() || e->stages[0].f != 1 || e->stages[0].variant != 0) return GNNVC_OK;
+    if (g.sliced()) return GNNVC_OK;   // (the per-graph plans index whole graphs)
     if (g.n < e->opt_blocked_min_n || g.nnz == 0) return GNNVC_OK;
     // skewed graphs gather mostly from a few hot (hub) entries of x that stay cached anyway, and
     // the per-row accumulate passes run in lockstep to each wave's largest count: measured slower
@@ -556,6 +559,7 @@ int build_lds_table(gnnvc_engine *e) {
     e->lt_tried = true;
     const GraphDev &g = e->g;
     if (!e->opt_lds_table || e->stages.empty() || e->stages[0].f != 1 || e->stages[0].variant != 0) return GNNVC_OK;
+    if (g.sliced()) return GNNVC_OK;
     if (g.n < e->opt_blocked_min_n || g.nnz == 0 || g.nnz >= (1ull << 31)) return GNNVC_OK;
     if (e->opt_lds_table < 2 && (e->sorted_wanted || e->n_long > 0)) return GNNVC_OK;   // long runs would serialise in one thread
     const uint32_t bc = gnnvc::lds_table_block();
@@ -630,6 +634,7 @@ int build_compact(gnnvc_engine *e, uint32_t base = 0, uint32_t end = 0xFFFFFFFFu
     const GraphDev &g = e->g;
     if (end > g.n) end = g.n;
     if (base >= end) return GNNVC_OK;
+    if (base < g.lo() || end > g.hi()) return GNNVC_OK;   // rows this engine does not hold (a slice): no plan
     const uint32_t span = end - base;
     if (!e->opt_compact || e->stages.size() < 2) return GNNVC_OK;
     for (size_t st = 1; st < e->stages.size(); ++st)
@@ -648,7 +653,7 @@ int build_compact(gnnvc_engine *e, uint32_t base = 0, uint32_t end = 0xFFFFFFFFu
     chunks = (span + rows - 1) / rows;
     const uint32_t slice_rows = rows / nsl, slices = chunks * nsl;
     uint64_t range_nnz = g.nnz;
-    if (span != g.n) {   // the range's share of the entries
+    if (span != g.n) {   // the range's share of the entries (on a slice g.nnz counts the slice's entries only)
         uint32_t rp[2] = {0, 0};
         HIP_TRY(e, hipMemcpyAsync(&rp[0], g.rowptr + base, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(e, hipMemcpyAsync(&rp[1], g.rowptr + end, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
@@ -924,6 +929,7 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
 }
 
 int reserve_features(gnnvc_engine *e, uint32_t n) {
+    if (e->g.sliced()) return GNNVC_OK;   // a slice is driven stage by stage on the caller's replicated buffers
     const size_t rows = (size_t)n + 1;
     HIP_TRY(e, e->x.reserve(rows * (size_t)e->in_width));
     HIP_TRY(e, e->scores.reserve(rows * (size_t)e->out_width));
@@ -1133,6 +1139,8 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
     else if (k == "blocked_blocks") *value = e->blocked_ready ? (long)e->blk_count : 0;
     else if (k == "block_cols") *value = e->blocked_ready ? (long)e->blk_cols : 0;
     else if (k == "long_rows") *value = (long)e->n_long;
+    else if (k == "slice_rows") *value = e->empty_slice ? 0 : (long)(e->g.hi() - e->g.lo());
+    else if (k == "slice_entries") *value = (long)e->g.nnz;
     else if (k == "giant_rows") *value = (long)e->n_giant;
     else if (k == "giant_entries") *value = (long)e->giant_entries;
     else if (k == "giant_row_threshold") *value = e->n_giant ? (long)e->giant_thresh : 0;
@@ -1176,6 +1184,7 @@ static int adopt_uploaded(gnnvc_engine *e, uint32_t n, uint64_t nnz) {
     }
     e->g = GraphDev{n, nnz, e->rowptr.p, e->col.p, e->w.p, e->nw.p};
     e->have_graph = true;
+    e->empty_slice = false;
     int rc = reserve_features(e, n);
     if (rc) return rc;
     e->lt_ready = e->lt_tried = false;
@@ -1299,15 +1308,8 @@ int gnnvc_commit_staged_graph(gnnvc_engine *e) {
     return adopt_uploaded(e, n, nnz);
 }
 
-int gnnvc_attach_graph_device(gnnvc_engine *e, uint32_t n, uint64_t nnz, const uint32_t *d_rowptr,
-                              const uint32_t *d_col, const uint32_t *d_w, const uint32_t *d_nw) {
-    if (!e) return GNNVC_ERR_INVALID;
-    if (n && (!d_rowptr || !d_col || !d_w || !d_nw)) return fail(e, GNNVC_ERR_INVALID, "null device graph arrays");
-    if (nnz >= 0xFFFFFFFFull - GNNVC_COL_PAD) return fail(e, GNNVC_ERR_UNSUPPORTED, "nnz too large");
-    int rc = use_device(e);
-    if (rc) return rc;
+static int attach_common(gnnvc_engine *e, const GraphDev &cand) {
     {   // a column id >= n would send the gather to a wild address: check before accepting the graph
-        const GraphDev cand{n, nnz, d_rowptr, d_col, d_w, d_nw};
         HIP_TRY(e, e->blk_flag.reserve(1));
         HIP_TRY(e, gnnvc::validate_graph(cand, e->blk_flag.p, e->stream));
         uint32_t bad = 0;
@@ -1319,9 +1321,10 @@ int gnnvc_attach_graph_device(gnnvc_engine *e, uint32_t n, uint64_t nnz, const u
                                                                  : "row pointers are not monotone from 0 to nnz");
         }
     }
-    e->g = GraphDev{n, nnz, d_rowptr, d_col, d_w, d_nw};
+    e->g = cand;
     e->have_graph = true;
-    rc = reserve_features(e, n);
+    e->empty_slice = false;
+    int rc = reserve_features(e, cand.n);
     if (rc) return rc;
     e->lt_ready = e->lt_tried = false;
     e->c4_ready = e->c4_tried = false;
@@ -1333,6 +1336,52 @@ int gnnvc_attach_graph_device(gnnvc_engine *e, uint32_t n, uint64_t nnz, const u
     return find_long(e);
 }
 
+int gnnvc_attach_graph_device(gnnvc_engine *e, uint32_t n, uint64_t nnz, const uint32_t *d_rowptr,
+                              const uint32_t *d_col, const uint32_t *d_w, const uint32_t *d_nw) {
+    if (!e) return GNNVC_ERR_INVALID;
+    if (n && (!d_rowptr || !d_col || !d_w || !d_nw)) return fail(e, GNNVC_ERR_INVALID, "null device graph arrays");
+    if (nnz >= 0xFFFFFFFFull - GNNVC_COL_PAD) return fail(e, GNNVC_ERR_UNSUPPORTED, "nnz too large");
+    int rc = use_device(e);
+    if (rc) return rc;
+    return attach_common(e, GraphDev{n, nnz, d_rowptr, d_col, d_w, d_nw});
+}
+
+int gnnvc_attach_graph_slice(gnnvc_engine *e, uint32_t n_global, uint32_t row_lo, uint32_t row_hi, uint64_t nnz_local,
+                             const uint32_t *d_rowptr_local, const uint32_t *d_col_local, const uint32_t *d_w_local,
+                             const uint32_t *d_nw_local) {
+    if (!e) return GNNVC_ERR_INVALID;
+    if (row_lo > row_hi || row_hi > n_global) return fail(e, GNNVC_ERR_INVALID, "slice [%u, %u) outside a graph of %u vertices", row_lo, row_hi, n_global);
+    if (!d_rowptr_local || !d_col_local || (row_hi > row_lo && (!d_w_local || !d_nw_local)))
+        return fail(e, GNNVC_ERR_INVALID, "null device graph arrays");
+    if (nnz_local >= 0xFFFFFFFFull - GNNVC_COL_PAD) return fail(e, GNNVC_ERR_UNSUPPORTED, "nnz too large");
+    int rc = use_device(e);
+    if (rc) return rc;
+    // the kernels index rowptr / w / nw by GLOBAL row id: bias the slice's arrays so that they can (only rows of the
+    // slice are ever touched — every whole-graph pass of the engine walks [row_base, row_end))
+    GraphDev cand{n_global, nnz_local, d_rowptr_local - row_lo, d_col_local, d_w_local - row_lo, d_nw_local - row_lo};
+    cand.row_base = row_lo;
+    cand.row_end = row_hi ? row_hi : 0;
+    if (row_lo == 0 && row_hi == n_global) cand.row_end = 0;   // the whole graph after all
+    if (row_hi == 0) {   // an empty slice at the front: nothing to compute, nothing to index
+        e->g = GraphDev{n_global, 0, d_rowptr_local, d_col_local, d_w_local, d_nw_local};
+        e->g.row_base = 0;
+        e->g.row_end = 0;
+        e->have_graph = true;
+        e->n_long = e->n_giant = 0;
+        e->empty_slice = true;
+        return GNNVC_OK;
+    }
+    e->empty_slice = row_hi == row_lo;
+    if (e->empty_slice) {
+        e->g = cand;
+        e->g.row_end = row_hi;
+        e->have_graph = true;
+        e->n_long = e->n_giant = 0;
+        return GNNVC_OK;
+    }
+    return attach_common(e, cand);
+}
+
 int gnnvc_stage_forward_device(gnnvc_engine *e, int stage, uint32_t row_lo, uint32_t row_hi,
                                const float *d_in, float *d_out, float *d_logits) {
     if (!e) return GNNVC_ERR_INVALID;
@@ -1340,6 +1389,9 @@ int gnnvc_stage_forward_device(gnnvc_engine *e, int stage, uint32_t row_lo, uint
     if (stage < 0 || stage >= (int)e->stages.size()) return fail(e, GNNVC_ERR_INVALID, "stage %d out of range", stage);
     if (row_lo > row_hi || row_hi > e->g.n) return fail(e, GNNVC_ERR_INVALID, "row range [%u,%u) outside graph of %u", row_lo, row_hi, e->g.n);
     if (row_lo == row_hi) return GNNVC_OK;
+    if (e->empty_slice || row_lo < e->g.lo() || row_hi > e->g.hi())
+        return fail(e, GNNVC_ERR_INVALID, "rows [%u,%u) are not in the slice [%u,%u) this engine holds", row_lo, row_hi, e->g.lo(),
+                    e->empty_slice ? e->g.lo() : e->g.hi());
     if (!d_in || !d_out) return fail(e, GNNVC_ERR_INVALID, "null feature buffers");
     int rc = use_device(e);
     if (rc) return rc;
@@ -1353,6 +1405,8 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
     e->ev_count = 0;
     if (e->layers.empty()) return fail(e, GNNVC_ERR_STATE, "engine was created without a model");
     if (n == 0) return GNNVC_OK;
+    if (e->g.sliced() || e->empty_slice)
+        return fail(e, GNNVC_ERR_STATE, "this engine holds a slice of the graph: run it stage by stage (gnnvc_stage_forward_device)");
     if (!d_x || !d_scores) return fail(e, GNNVC_ERR_INVALID, "null feature buffers");
     int rc = use_device(e);
     if (rc) return rc;
@@ -1394,7 +1448,7 @@ int gnnvc_stage_input_ready(gnnvc_engine *e, int stage, const float *d_in, uint3
     if (stage < 1 || stage >= (int)e->stages.size()) return fail(e, GNNVC_ERR_INVALID, "stage %d has no 16-wide input", stage);
     if (row_lo > row_hi || row_hi > e->g.n) return fail(e, GNNVC_ERR_INVALID, "row range [%u, %u) outside the graph", row_lo, row_hi);
     e->c4_prepared_stage = -1;
-    if (e->g.n == 0 || row_lo == row_hi) return GNNVC_OK;
+    if (e->g.n == 0 || row_lo == row_hi || e->empty_slice) return GNNVC_OK;
     if (!d_in) return fail(e, GNNVC_ERR_INVALID, "null feature buffer");
     int rc = use_device(e);
     if (rc) return rc;
@@ -1447,6 +1501,7 @@ int gnnvc_reduction_flags(gnnvc_engine *e, uint32_t max_degree, uint8_t *flags) 
     if (!e->have_graph) return fail(e, GNNVC_ERR_STATE, "no graph attached");
     const uint32_t n = e->g.n;
     if (n == 0) return GNNVC_OK;
+    if (e->g.sliced() || e->empty_slice) return fail(e, GNNVC_ERR_STATE, "this engine holds a slice of the graph");
     if (!flags) return fail(e, GNNVC_ERR_INVALID, "null flags buffer");
     int rc = use_device(e);
     if (rc) return rc;
@@ -1613,6 +1668,7 @@ int gnnvc_graph_layer_forward(gnnvc_engine *e, uint32_t f, const float *in, floa
     if (f == 0) return fail(e, GNNVC_ERR_INVALID, "zero feature width");
     const uint32_t n = e->g.n;
     if (n == 0) return GNNVC_OK;
+    if (e->g.sliced() || e->empty_slice) return fail(e, GNNVC_ERR_STATE, "this engine holds a slice of the graph");
     if (!in || !out) return fail(e, GNNVC_ERR_INVALID, "null host buffers");
     struct Ctx { uint32_t f; } ctx{f};
     return run_host_op(e, (size_t)n * f, in, (size_t)n * (2 * f + 3), out, false,

@@ -17,6 +17,20 @@ struct GraphDev {
     const uint32_t *col = nullptr;     // nnz + GNNVC_COL_PAD (pad content irrelevant)
     const uint32_t *w = nullptr;       // n
     const uint32_t *nw = nullptr;      // n
+    // A SLICE of a graph (one rank of a vertex-partitioned run, gnnvc_attach_graph_slice) holds rows
+    // [row_base, row_end) only: rowptr / w / nw are then the slice's arrays biased by -row_base so that they are
+    // still indexed by global row id (valid for those rows only, row pointers relative to the slice's first
+    // entry), col holds the slice's nnz entries with GLOBAL column ids.  row_end == 0: the whole graph.
+    uint32_t row_base = 0, row_end = 0;
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    uint32_t lo() const { return row_base; }
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    uint32_t hi() const { return row_end ? row_end : n; }
+    bool sliced() const { return row_end != 0 && (row_base != 0 || row_end != n); }
 };
 
 // One fused stage = graph layer (input width F) followed by up to three dense

@@ -717,8 +717,8 @@ __global__ __launch_bounds__(kBlock) void k_stage_f1(
 // kernel of the same stage (disjoint output rows).
 __global__ void k_find_long(GraphDev g, uint32_t thresh, uint32_t *__restrict__ list,
                             uint32_t *__restrict__ count) {
-    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= g.n) return;
+    const uint32_t u = g.lo() + blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= g.hi()) return;
     if (g.rowptr[u + 1] - g.rowptr[u] >= thresh) list[atomicAdd(count, 1u)] = u;
 }
 
@@ -2533,9 +2533,10 @@ __global__ __launch_bounds__(256) void k_validate_graph(GraphDev g, uint32_t *__
     uint32_t bad = 0;
     for (size_t i = gid; i < g.nnz; i += step)
         if (g.col[i] >= g.n) bad |= 1u;
-    for (size_t u = gid; u < g.n; u += step)
+    const size_t r0 = g.lo(), r1 = g.hi();   // (a slice holds rows [r0, r1) only; its row pointers start at 0)
+    for (size_t u = r0 + gid; u < r1; u += step)
         if (g.rowptr[u] > g.rowptr[u + 1]) bad |= 2u;
-    if (gid == 0 && (g.rowptr[0] != 0 || (uint64_t)g.rowptr[g.n] != g.nnz)) bad |= 2u;
+    if (gid == 0 && (g.rowptr[r0] != 0 || (uint64_t)g.rowptr[r1] != g.nnz)) bad |= 2u;
     if (bad) atomicOr(flags, bad);
 }
 
@@ -2975,8 +2976,8 @@ hipError_t degree_scatter(const GraphDev &g, uint32_t row_lo, uint32_t row_hi, u
 hipError_t find_long_rows(const GraphDev &g, uint32_t thresh, uint32_t *list, uint32_t *count,
                           hipStream_t stream) {
     hipError_t rc = hipMemsetAsync(count, 0, sizeof(uint32_t), stream);
-    if (rc != hipSuccess || g.n == 0) return rc;
-    hipLaunchKernelGGL(k_find_long, dim3((g.n + 255) / 256), dim3(256), 0, stream, g, thresh, list, count);
+    if (rc != hipSuccess || g.hi() <= g.lo()) return rc;
+    hipLaunchKernelGGL(k_find_long, dim3((g.hi() - g.lo() + 255) / 256), dim3(256), 0, stream, g, thresh, list, count);
     return hipGetLastError();
 }
 

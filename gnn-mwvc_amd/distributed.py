@@ -1,13 +1,17 @@
 """1-D vertex-partitioned forward across the GPUs of one node.
 
 One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI on the
-GPU box, "gloo" in the CPU tests).  Every rank holds the whole CSR (global column
-ids) and full-size feature buffers; rank r computes the rows [lo_r, hi_r) of each
-fused stage, then the ranks exchange their freshly written rows so that every
-rank holds the complete input of the next stage — an all-gather of the N x 16
-fp32 feature matrix after stages 0 and 1 and of the N scores after the last
-stage.  Each row is still summed on one GPU in CSR order, so results are
-bit-identical to the single-GPU forward.
+GPU box, "gloo" in the CPU tests).  Rank r holds the CSR SLICE of its rows
+[lo_r, hi_r) — row pointers relative to the slice, global column ids, its slice of
+W / NW (`slice_csr`, `Engine.attach_graph_slice`): 1 / P of the graph's memory —
+and full-size, replicated feature buffers.  It computes those rows of each fused
+stage, then the ranks exchange their freshly written rows so that every rank holds
+the complete input of the next stage — an all-gather of the N x 16 fp32 feature
+matrix after stages 0 and 1 and of the N scores after the last stage.  Each row is
+still summed on one GPU in CSR order, so results are bit-identical to the
+single-GPU forward.  (A caller that keeps the WHOLE graph on every rank may also
+have early stages computed in full everywhere instead of exchanged — `replicate`;
+with slices every stage is partitioned.)
 
 There is no reference counterpart (the reference is single-process); the
 arithmetic is `gnn::model::predict` (reference src/gnn_inference.cpp:67-81)
@@ -64,6 +68,36 @@ def partition_bounds(n: int, world: int, rowptr=None, mode: str = "rows") -> Lis
         raise ValueError(f"unknown partition mode {mode!r}")
     cuts[-1] = n
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+@dataclasses.dataclass
+class CsrSlice:
+    """Rows [lo, hi) of a CSR graph of n vertices: what one rank of a vertex-partitioned run keeps."""
+    n: int                 # vertices of the whole graph (column ids are global)
+    lo: int
+    hi: int
+    rowptr: torch.Tensor   # (hi - lo + 1,) relative to the slice: rowptr[0] = 0, rowptr[-1] = nnz
+    col: torch.Tensor      # (nnz + pad,) global column ids, stored order
+    w: torch.Tensor        # (hi - lo,)
+    nw: torch.Tensor       # (hi - lo,)
+    nnz: int
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in (self.rowptr, self.col, self.w, self.nw))
+
+
+def slice_csr(n: int, rowptr: torch.Tensor, col: torch.Tensor, w: torch.Tensor, nw: torch.Tensor, lo: int, hi: int,
+              pad: int = 64) -> CsrSlice:
+    """Cut rows [lo, hi) out of a whole CSR (tensors on any device; the slice owns fresh storage, so the whole
+    graph can be released afterwards).  `pad` extra column entries follow the slice's last one (the engine's
+    kernels read a few entries past a tile's end, GNNVC_COL_PAD)."""
+    if not 0 <= lo <= hi <= n:
+        raise ValueError(f"rows [{lo}, {hi}) outside a graph of {n} vertices")
+    e0, e1 = int(rowptr[lo]), int(rowptr[hi])
+    rp = (rowptr[lo: hi + 1].to(torch.int64) - e0).to(rowptr.dtype).contiguous()
+    c = torch.zeros(e1 - e0 + pad, dtype=col.dtype, device=col.device)
+    c[: e1 - e0] = col[e0:e1]
+    return CsrSlice(n, lo, hi, rp, c, w[lo:hi].clone().contiguous(), nw[lo:hi].clone().contiguous(), e1 - e0)
 
 
 @dataclasses.dataclass(frozen=True)

@@ -19,7 +19,7 @@ _LIB = _PKG / "libgnnvc_hip.so"
 ABI_SYMBOLS = [
     "gnnvc_abi_version", "gnnvc_strerror", "gnnvc_last_error", "gnnvc_create", "gnnvc_destroy",
     "gnnvc_set_weight_scale", "gnnvc_set_stream", "gnnvc_set_option", "gnnvc_get_info", "gnnvc_num_layers", "gnnvc_is_fused",
-    "gnnvc_in_width", "gnnvc_out_width", "gnnvc_upload_graph", "gnnvc_attach_graph_device",
+    "gnnvc_in_width", "gnnvc_out_width", "gnnvc_upload_graph", "gnnvc_attach_graph_device", "gnnvc_attach_graph_slice",
     "gnnvc_graph_staging", "gnnvc_staged_columns_ready", "gnnvc_commit_staged_graph",
     "gnnvc_forward", "gnnvc_forward_device", "gnnvc_num_stages", "gnnvc_stage_widths",
     "gnnvc_stage_forward_device", "gnnvc_stage_input_ready", "gnnvc_live_columns", "gnnvc_column_counts", "gnnvc_pack_rows", "gnnvc_unpack_rows", "gnnvc_unpack_gathered",
@@ -89,6 +89,7 @@ def load_library():
     L.gnnvc_stage_widths.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.gnnvc_upload_graph.argtypes = [vp, u32, vp, vp, vp, vp]
     L.gnnvc_attach_graph_device.argtypes = [vp, u32, u64, vp, vp, vp, vp]
+    L.gnnvc_attach_graph_slice.argtypes = [vp, u32, u32, u32, u64, vp, vp, vp, vp]
     L.gnnvc_graph_staging.argtypes = [vp, u32, u64] + [C.POINTER(vp)] * 4
     L.gnnvc_staged_columns_ready.argtypes = [vp, u64, u64]
     L.gnnvc_commit_staged_graph.argtypes = [vp]
@@ -238,6 +239,14 @@ class Engine:
         self._check(self._L.gnnvc_attach_graph_device(self._h, n, nnz, rowptr_ptr, col_ptr, w_ptr,
                                                       nw_ptr))
         self.n = n
+        self._keep = keepalive
+
+    def attach_graph_slice(self, n_global: int, row_lo: int, row_hi: int, nnz_local: int, rowptr_ptr: int, col_ptr: int,
+                           w_ptr: int, nw_ptr: int, keepalive=None):
+        """This rank's rows [row_lo, row_hi) of a vertex-partitioned graph (device arrays, see gnnvc.h)."""
+        self._check(self._L.gnnvc_attach_graph_slice(self._h, n_global, row_lo, row_hi, nnz_local, rowptr_ptr, col_ptr,
+                                                     w_ptr, nw_ptr))
+        self.n = n_global
         self._keep = keepalive
 
     # -- forward

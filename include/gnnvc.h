@@ -135,6 +135,21 @@ int gnnvc_attach_graph_device(gnnvc_engine *e, uint32_t n, uint64_t nnz,
                               const uint32_t *d_rowptr, const uint32_t *d_col,
                               const uint32_t *d_w, const uint32_t *d_nw);
 
+/* One rank's SLICE of a vertex-partitioned graph ("each GPU holds its rows' CSR slice with global
+ * column ids, its slice of W / NW").  The engine then holds rows [row_lo, row_hi) of a graph of n_global vertices:
+ *   d_rowptr_local  uint32[row_hi - row_lo + 1], relative to the slice (first = 0, last = nnz_local)
+ *   d_col_local     uint32[nnz_local + GNNVC_COL_PAD], GLOBAL column ids, stored order
+ *   d_w_local, d_nw_local  uint32[row_hi - row_lo]
+ * — 1 / P of the graph's memory at P ranks; the feature matrices stay full-size and replicated (the caller's).  A
+ * sliced engine is driven stage by stage with gnnvc_stage_forward_device on sub-ranges of its slice; the whole-graph
+ * entry points (gnnvc_forward*, gnnvc_reduction_flags, gnnvc_graph_layer_forward) return GNNVC_ERR_STATE, and the
+ * per-graph plans that index whole graphs stay off.  Results are those of the whole graph: a row is summed on one
+ * GPU in stored order.  No reference counterpart (the reference is one process reading one graph,
+ * src/gnn_inference.cpp:32-41).  The caller keeps the arrays alive until the next attach / upload / destroy. */
+int gnnvc_attach_graph_slice(gnnvc_engine *e, uint32_t n_global, uint32_t row_lo, uint32_t row_hi, uint64_t nnz_local,
+                             const uint32_t *d_rowptr_local, const uint32_t *d_col_local, const uint32_t *d_w_local,
+                             const uint32_t *d_nw_local);
+
 /* Staged hand-off (the caller is the pack loop over reduction_graph's
  * begin(u)/end(u) ranges, include/reduction_graph.hpp:693-704): instead of building a temporary
  * CSR and passing it to gnnvc_upload_graph, the caller writes the arrays straight into page-locked

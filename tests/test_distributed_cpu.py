@@ -49,6 +49,42 @@ def _oracle_stage_fn(g, text):
     return stage_fn
 
 
+def _sliced_oracle_stage_fn(sl, ws, text):
+    """stage_fn of a rank that holds only its CSR slice (D.slice_csr): rows outside [lo, hi) have no adjacency
+    here, and asking for them is an error — like Engine.stage_forward_device on a sliced engine."""
+    from oracle import oracle_py
+    om = oracle_py.OracleModel(text)
+    params = om.linear_params()
+    n, lo, hi = sl.n, sl.lo, sl.hi
+    rowptr = np.zeros(n + 1, dtype=np.uint64)
+    rowptr[lo: hi + 1] = sl.rowptr.numpy().astype(np.uint64)
+    rowptr[hi + 1:] = sl.nnz
+    w = np.zeros(n, dtype=np.uint32)
+    nw = np.zeros(n, dtype=np.uint32)
+    w[lo:hi] = sl.w.numpy()
+    nw[lo:hi] = sl.nw.numpy()
+    local = gg.CsrGraph(n, rowptr, sl.col.numpy()[: sl.nnz].astype(np.uint32), w, nw)
+
+    def stage_fn(stage, r0, r1, src, dst, logits):
+        assert lo <= r0 <= r1 <= hi, f"rows [{r0}, {r1}) are not in this rank's slice [{lo}, {hi})"
+        h = src[:n].numpy().reshape(n, -1)
+        a = oracle_py.graph_layer(local, ws, h)[r0:r1]
+        for i, (W, b) in enumerate(params[3 * stage: 3 * stage + 3]):
+            a = oracle_py.linear_layer(a, W, b)
+            if stage == 2 and i == 2:
+                if logits is not None:
+                    logits[r0:r1] = torch.from_numpy(a[:, 0].copy())
+                a = oracle_py.sigmoid(a)
+            else:
+                a = oracle_py.relu(a)
+        out = torch.from_numpy(np.ascontiguousarray(a))
+        if dst.dim() == 1:
+            dst[r0:r1] = out[:, 0]
+        else:
+            dst[r0:r1] = out
+    return stage_fn
+
+
 class TorchRowCodec(D.RowCodec):
     """CPU stand-in (tests only) for gnn_mwvc_amd.EngineRowCodec: same contract, torch indexing."""
 
@@ -187,7 +223,7 @@ def test_choose_packing():
     assert D.choose_packing([5] * 16, 0, 2) is None
 
 
-def _worker(rank, world, port, mode, exchange, graph_args, q, replicate=None, chunks=0):
+def _worker(rank, world, port, mode, exchange, graph_args, q, replicate=None, chunks=0, sliced=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -199,9 +235,23 @@ def _worker(rank, world, port, mode, exchange, graph_args, q, replicate=None, ch
         bounds = D.partition_bounds(g.n, world, g.rowptr, mode)
         bufs = D.ForwardBuffers.allocate(g.n, bounds, "cpu")
         x = torch.from_numpy(g.x())
-        scores, logits = D.partitioned_forward(_oracle_stage_fn(g, text), 3, x, bufs, bounds, rank,
-                                               exchange=exchange, replicate_stage0=replicate,
-                                               pipeline_chunks=chunks)
+        if sliced:
+            # this rank keeps its rows' slice of the CSR and nothing else of the graph
+            lo, hi = bounds[rank]
+            sl = D.slice_csr(g.n, torch.from_numpy(g.rowptr.astype(np.int64)), torch.from_numpy(g.col.astype(np.int64)),
+                             torch.from_numpy(g.w.astype(np.int64)), torch.from_numpy(g.nw.astype(np.int64)), lo, hi)
+            nnz_all = int(g.rowptr[-1])
+            assert sl.nnz == int(g.rowptr[hi]) - int(g.rowptr[lo]) and sl.rowptr[0] == 0 and sl.rowptr[-1] == sl.nnz
+            assert world == 1 or sl.nnz < nnz_all
+            fn, n_ = _sliced_oracle_stage_fn(sl, g.ws, text), g.n
+            del g
+            g = type("N", (), {"n": n_})()
+            scores, logits = D.partitioned_forward(fn, 3, x, bufs, bounds, rank, exchange=exchange, replicate=set(),
+                                                   pipeline_chunks=chunks)
+        else:
+            scores, logits = D.partitioned_forward(_oracle_stage_fn(g, text), 3, x, bufs, bounds, rank,
+                                                   exchange=exchange, replicate_stage0=replicate,
+                                                   pipeline_chunks=chunks)
         # pad rows of the feature buffers must still be zero (the gather reads row n)
         pad_ok = all(float(f[g.n:].abs().sum()) == 0.0 for f in bufs.feat)
         q.put((rank, scores.numpy().copy(), logits.numpy().copy(), bounds, pad_ok))
@@ -209,20 +259,25 @@ def _worker(rank, world, port, mode, exchange, graph_args, q, replicate=None, ch
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode,exchange,graph_args,replicate,chunks", [
-    (2, "rows", "allgather", (3000, 15000, 4), False, 0),
-    (2, "rows", "p2p", (3000, 15000, 4), None, 0),        # default: stage 0 replicated at P <= 4
-    (3, "nnz", "auto", (5000, 20000, 2, 1500, 9), False, 0),  # hub graph: uneven nnz-balanced shards
-    (2, "rows", "auto", (100, 300, 5), False, 0),         # second rank's shard is short
-    (2, "rows", "auto", (3000, 15000, 4), False, 4),      # exchanges overlapped with compute, 4 pieces
-    (3, "rows", "auto", (1000, 6000, 8), None, 3),        # replicated stage 0 + pipelined stage 1
+@pytest.mark.parametrize("world,mode,exchange,graph_args,replicate,chunks,sliced", [
+    (2, "rows", "allgather", (3000, 15000, 4), False, 0, False),
+    (2, "rows", "p2p", (3000, 15000, 4), None, 0, False),        # whole CSR on every rank: stage 0 replicated at P <= 4
+    (3, "nnz", "auto", (5000, 20000, 2, 1500, 9), False, 0, False),  # hub graph: uneven nnz-balanced shards
+    (2, "rows", "auto", (100, 300, 5), False, 0, False),         # second rank's shard is short
+    (2, "rows", "auto", (3000, 15000, 4), False, 4, False),      # exchanges overlapped with compute, 4 pieces
+    (3, "rows", "auto", (1000, 6000, 8), None, 3, False),        # replicated stage 0 + pipelined stage 1
+    # every rank holds ONLY its CSR slice: the same bits
+    (2, "rows", "auto", (3000, 15000, 4), False, 0, True),
+    (3, "nnz", "auto", (5000, 20000, 2, 1500, 9), False, 0, True),   # uneven slices, direct sends
+    (2, "rows", "auto", (3000, 15000, 4), False, 3, True),       # sliced + pipelined pieces
+    (3, "rows", "auto", (100, 300, 5), False, 0, True),          # a short second slice, an empty third one
 ])
-def test_partitioned_forward_matches_single_process(world, mode, exchange, graph_args, replicate, chunks,
+def test_partitioned_forward_matches_single_process(world, mode, exchange, graph_args, replicate, chunks, sliced,
                                                     oracle_model):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, exchange, graph_args, q, replicate, chunks))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, exchange, graph_args, q, replicate, chunks, sliced))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -239,7 +294,7 @@ def test_partitioned_forward_matches_single_process(world, mode, exchange, graph
         assert np.array_equal(l.view(np.uint32), want_l.view(np.uint32)), f"rank {rank}"
         assert bounds[0][0] == 0 and bounds[-1][1] == g.n
         assert all(a[1] == b[0] for a, b in zip(bounds[:-1], bounds[1:]))
-        assert all(lo % D.ALIGN == 0 for lo, _ in bounds)
+        assert all(lo % D.ALIGN == 0 or lo == g.n for lo, _ in bounds)   # (an empty last shard starts at n)
 
 
 def test_replication_rule():

@@ -973,6 +973,73 @@ def test_fast_hub_mode_is_within_its_tolerance(model_text, oracle_model):
         e.close()
 
 
+# ---------------------------------------------------------------- one rank's CSR slice
+
+@pytest.mark.parametrize("maker,world,mode", [
+    (lambda: gg.erdos_renyi(5000, 40000, 31), 2, "rows"),
+    (lambda: gg.hub_graph(20000, 60000, 3, 4096, seed=7), 3, "nnz"),       # long rows inside slices
+    (lambda: gg.hub_graph(30000, 40000, 2, 20000, seed=8), 4, "nnz"),      # giant rows inside slices
+    (lambda: gg.rmat(11, 16, 5), 3, "rows"),
+    (lambda: gg.erdos_renyi(100, 300, 5), 3, "rows"),                      # a short slice and an empty one
+])
+def test_sliced_engines_equal_the_whole_graph(model_text, oracle_model, maker, world, mode):
+    """gnnvc_attach_graph_slice: `world` engines, each holding only its rows' CSR slice (row pointers relative to
+    the slice, global column ids), driven stage by stage on shared full-size feature buffers — what the ranks of
+    a vertex-partitioned run do between exchanges.  Same bits as the whole graph."""
+    import gnn_mwvc_amd as G
+    import torch
+    from gnn_mwvc_amd import distributed as D
+    g = maker()
+    dev = torch.device("cuda:0")
+    oracle_model.set_weight_scale(g.ws)
+    bounds = D.partition_bounds(g.n, world, g.rowptr, mode)
+    rp = torch.from_numpy(g.rowptr.astype(np.int64)).to(torch.int32).to(dev)   # (uint32 values fit: small graphs)
+    col = torch.from_numpy(g.col.astype(np.int64)).to(torch.int32).to(dev)
+    w = torch.from_numpy(g.w.astype(np.int64)).to(torch.int32).to(dev)
+    nw = torch.from_numpy(g.nw.astype(np.int64)).to(torch.int32).to(dev)
+    engines = []
+    try:
+        total = 0
+        for lo, hi in bounds:
+            e = G.Engine(model_text, device=0)
+            engines.append(e)
+            e.set_option("long_row_threshold", 64)
+            e.set_option("giant_row_threshold", 3000)
+            e.set_weight_scale(g.ws)
+            sl = D.slice_csr(g.n, rp, col, w, nw, lo, hi)
+            torch.cuda.synchronize()
+            e.attach_graph_slice(g.n, lo, hi, sl.nnz, sl.rowptr.data_ptr(), sl.col.data_ptr(), sl.w.data_ptr(),
+                                 sl.nw.data_ptr(), keepalive=sl)
+            assert e.get_info("slice_rows") == hi - lo and e.get_info("slice_entries") == sl.nnz
+            total += sl.nbytes()
+        assert total <= (rp.numel() + col.numel() + w.numel() + nw.numel()) * 4 + world * (64 + 1) * 4   # slices partition the CSR
+        x = torch.from_numpy(g.x()).to(dev)
+        h1 = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+        h2 = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+        sc = torch.zeros(g.n, dtype=torch.float32, device=dev)
+        lg = torch.zeros(g.n, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        for st, (src, dst, lgt) in enumerate(((x, h1, None), (h1, h2, None), (h2, sc, lg))):
+            for e, (lo, hi) in zip(engines, bounds):
+                mid = lo + ((hi - lo) // 2) // 64 * 64
+                for r0, r1 in ((lo, mid), (mid, hi)):       # in two pieces, like a pipelined rank
+                    e.stage_forward_device(st, r0, r1, src.data_ptr(), dst.data_ptr(), lgt.data_ptr() if lgt is not None else 0)
+            for e in engines:
+                e.synchronize()                              # ("exchange": the buffers are shared here)
+        assert np.array_equal(bits(lg.cpu().numpy()), bits(oracle_model.logits(g)))
+        assert ulp(sc.cpu().numpy(), oracle_model.scores(g)).max() <= 1
+        # outside its slice an engine has no adjacency, and says so
+        e0, (lo0, hi0) = engines[0], bounds[0]
+        if hi0 < g.n:
+            with pytest.raises(G.GnnvcError):
+                e0.stage_forward_device(1, hi0, g.n, h1.data_ptr(), h2.data_ptr())
+        with pytest.raises(G.GnnvcError):
+            e0.forward_device(x.data_ptr(), sc.data_ptr(), lg.data_ptr())
+    finally:
+        for e in engines:
+            e.close()
+
+
 # ---------------------------------------------------------------- dense layers: MFMA vs VALU
 
 @pytest.mark.parametrize("mfma", [0, 1, 2])
