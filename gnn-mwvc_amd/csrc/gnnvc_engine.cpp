@@ -8,6 +8,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cctype>
 #include <cstdarg>
 #include <cstdio>
@@ -175,6 +176,9 @@ struct gnnvc_engine {
     hipStream_t giant_stream = nullptr;  // giant rows: three dependent launches, the side work's long pole -> a high-priority stream of its own
     hipEvent_t ev_giant = nullptr;
     // giant rows (degree >= giant_thresh, a subset of the long rows): CSR-order sums evaluated in parallel (exact_sum.h)
+    double plan_build_ms = 0.0;          // host wall time spent building per-graph plans for the current graph (they end in stream syncs)
+    int opt_ktrace = 0;                  // option "kernel_trace": HIP events around every main-stream kernel of a forward
+    gnnvc::KernelTraceSink ktrace;
     bool empty_slice = false;            // gnnvc_attach_graph_slice with no rows: every stage call is a no-op
     uint32_t opt_giant_thresh = 16384;   // option "giant_row_threshold" (0 = off: k_long_* take every long row)
     int opt_side_streams = 1;            // option "side_streams": 0 = long / giant rows on the main stream, one after the other (profiling)
@@ -518,7 +522,7 @@ int ensure_sorted(gnnvc_engine *e, uint32_t lo, uint32_t hi) {
 
 // Column-blocked index of the current graph (stage 0 only).  Not used when the
 // model is not fused, the graph is small, or a row's block ids are not monotone.
-int build_blocked(gnnvc_engine *e) {
+int build_blocked_impl(gnnvc_engine *e) {
     e->blocked_ready = false;
     e->blocked_tried = true;
     const GraphDev &g = e->g;
@@ -554,7 +558,7 @@ int build_blocked(gnnvc_engine *e) {
 // LDS-table plan of the current graph's F = 1 stage (kernels: k_lt_*).  Applies when every weight fits a
 // byte, adjacency lists ascend, no row is long enough for the long-row kernels and the graph is large and
 // not skewed; whether a given forward's input really is W / ws is checked on the device at every launch.
-int build_lds_table(gnnvc_engine *e) {
+int build_lds_table_impl(gnnvc_engine *e) {
     e->lt_ready = false;
     e->lt_tried = true;
     const GraphDev &g = e->g;
@@ -627,7 +631,7 @@ int build_lds_table(gnnvc_engine *e) {
 // Compact-table plan of the 16-wide stages (kernels: k_c4_*): the same (chunk, column block, step) layout
 // as the LDS-table plan at 2 MiB column blocks.  Whether a forward's input really has at most four live
 // columns is decided on the device at every launch (k_c4_choose / k_c4_compact).
-int build_compact(gnnvc_engine *e, uint32_t base = 0, uint32_t end = 0xFFFFFFFFu) {
+int build_compact_impl(gnnvc_engine *e, uint32_t base, uint32_t end) {
     e->c4_ready = false;
     e->c4_tried = true;
     e->c4_prepared_stage = -1;
@@ -728,6 +732,20 @@ int build_compact(gnnvc_engine *e, uint32_t base = 0, uint32_t end = 0xFFFFFFFFu
     e->c4_steps_total = (uint32_t)total;
     e->c4_ready = true;
     return GNNVC_OK;
+}
+
+template <class F>
+int timed_build(gnnvc_engine *e, F &&f) {
+    (void)hipStreamSynchronize(e->stream);   // what was queued before is not the plan's cost
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = f();
+    e->plan_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+int build_blocked(gnnvc_engine *e) { return timed_build(e, [&] { return build_blocked_impl(e); }); }
+int build_lds_table(gnnvc_engine *e) { return timed_build(e, [&] { return build_lds_table_impl(e); }); }
+int build_compact(gnnvc_engine *e, uint32_t base = 0, uint32_t end = 0xFFFFFFFFu) {
+    return timed_build(e, [&] { return build_compact_impl(e, base, end); });
 }
 
 int ensure_round_events(gnnvc_engine *e, size_t count) {
@@ -1075,6 +1093,7 @@ void gnnvc_destroy(gnnvc_engine *e) {
     if (e->ev_giant) (void)hipEventDestroy(e->ev_giant);
     for (auto v : e->ev) (void)hipEventDestroy(v);
     for (auto v : e->round_ev) (void)hipEventDestroy(v);
+    for (auto &r : e->ktrace.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
 }
@@ -1103,6 +1122,7 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "giant_row_threshold") e->opt_giant_thresh = value > 0 ? (uint32_t)std::max<long>(value, 64) : 0;
     else if (k == "hub_mode") e->opt_hub_mode = value == 1 ? 1 : 0;
     else if (k == "side_streams") e->opt_side_streams = value != 0 ? 1 : 0;
+    else if (k == "kernel_trace") e->opt_ktrace = value != 0 ? 1 : 0;
     else if (k == "compact_gather") e->opt_compact = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else if (k == "lds_table") e->opt_lds_table = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else if (k == "sorted_min_nnz") e->opt_sorted_min_nnz = value > 0 ? (uint64_t)value : 0;
@@ -1139,6 +1159,7 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
     else if (k == "blocked_blocks") *value = e->blocked_ready ? (long)e->blk_count : 0;
     else if (k == "block_cols") *value = e->blocked_ready ? (long)e->blk_cols : 0;
     else if (k == "long_rows") *value = (long)e->n_long;
+    else if (k == "plan_build_us") *value = (long)(e->plan_build_ms * 1000.0);
     else if (k == "slice_rows") *value = e->empty_slice ? 0 : (long)(e->g.hi() - e->g.lo());
     else if (k == "slice_entries") *value = (long)e->g.nnz;
     else if (k == "giant_rows") *value = (long)e->n_giant;
@@ -1194,6 +1215,7 @@ static int adopt_uploaded(gnnvc_engine *e, uint32_t n, uint64_t nnz) {
     e->blocked_ready = false;   // the column-blocked index is built on the graph's SECOND forward:
     e->blocked_tried = false;   // it costs about as much as it saves on one, and the reference's
     e->graph_uses = 0;          // driver uses every graph exactly once (src/GNN_VC.cpp:171-192)
+    e->plan_build_ms = 0.0;
     return find_long(e);
 }
 
@@ -1333,6 +1355,7 @@ static int attach_common(gnnvc_engine *e, const GraphDev &cand) {
     e->blocked_ready = false;   // the column-blocked index is built on the graph's SECOND forward:
     e->blocked_tried = false;   // it costs about as much as it saves on one, and the reference's
     e->graph_uses = 0;          // driver uses every graph exactly once (src/GNN_VC.cpp:171-192)
+    e->plan_build_ms = 0.0;
     return find_long(e);
 }
 
@@ -1428,15 +1451,21 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
     const float *cur = d_x;
     e->c4_fused_for = -1;
     e->c4_prepared_stage = -1;
+    if (e->opt_ktrace && e->ktrace.used < 16384) {   // records pile up over forwards until gnnvc_kernel_trace reads them
+        e->ktrace.stream = e->stream;
+        gnnvc::set_kernel_trace(&e->ktrace);
+    }
     HIP_TRY(e, hipEventRecord(e->ev[0], e->stream));
     for (size_t s = 0; s < ns; ++s) {
         const bool last = s + 1 == ns;
         float *dst = last ? d_scores : e->h[s & 1].p;
         rc = run_stage(e, (int)s, 0, n, cur, dst, last ? d_logits : nullptr, /*in_forward=*/true);
-        if (rc) return rc;
-        HIP_TRY(e, hipEventRecord(e->ev[s + 1], e->stream));
+        if (rc) break;
+        if (hipEventRecord(e->ev[s + 1], e->stream) != hipSuccess) { rc = fail(e, GNNVC_ERR_DEVICE, "hipEventRecord failed"); break; }
         cur = dst;
     }
+    gnnvc::set_kernel_trace(nullptr);
+    if (rc) return rc;
     e->ev_count = (int)ns + 1;
     return GNNVC_OK;
 }
@@ -1639,6 +1668,28 @@ int gnnvc_last_forward_ms(gnnvc_engine *e, float *total_ms, float *stage_ms, int
     if (total_ms) HIP_TRY(e, hipEventElapsedTime(total_ms, e->ev[0], e->ev[e->ev_count - 1]));
     for (int s = 0; stage_ms && s < max_stages && s + 1 < e->ev_count; ++s)
         HIP_TRY(e, hipEventElapsedTime(&stage_ms[s], e->ev[s], e->ev[s + 1]));
+    return GNNVC_OK;
+}
+
+int gnnvc_kernel_trace(gnnvc_engine *e, int max, const char **names, float *ms, int *count) {
+    if (!e || !count) return GNNVC_ERR_INVALID;
+    *count = 0;
+    if (!e->opt_ktrace) return fail(e, GNNVC_ERR_STATE, "option kernel_trace is off");
+    int rc = use_device(e);
+    if (rc) return rc;
+    const size_t used = e->ktrace.used;
+    for (size_t i = 0; i < used; ++i) {
+        const auto &r = e->ktrace.recs[i];
+        HIP_TRY(e, hipEventSynchronize(r.b));
+        if ((int)i < max) {
+            float t = 0.0f;
+            HIP_TRY(e, hipEventElapsedTime(&t, r.a, r.b));
+            if (names) names[i] = r.name;
+            if (ms) ms[i] = t;
+        }
+    }
+    *count = (int)used;
+    e->ktrace.used = 0;
     return GNNVC_OK;
 }
 

@@ -6,6 +6,8 @@
 #include <stdint.h>
 #include <hip/hip_vector_types.h>
 
+#include <vector>
+
 namespace gnnvc {
 
 // Device view of what the forward reads from reduction_graph
@@ -50,6 +52,19 @@ struct SortedOrder {
     const uint32_t *vertex = nullptr; // vertex id per entry, degrees descending
     const uint4 *meta = nullptr;      // {row begin, row end, W, NW} per entry
 };
+
+// Per-kernel timing: while a sink is installed on the calling thread, every kernel the launchers below put on
+// sink->stream is bracketed by two HIP events (recs[0 .. used): name = the kernel as written at the launch site).
+struct KernelTraceSink {
+    struct Rec {
+        const char *name;
+        hipEvent_t a, b;
+    };
+    hipStream_t stream = nullptr;
+    std::vector<Rec> recs;
+    size_t used = 0;
+};
+void set_kernel_trace(KernelTraceSink *sink);   // nullptr = off
 
 // Returns the instantiation index for a stage shape, or -1.
 int stage_variant(int f, int n1, int n2, int n3, int sigmoid_last);

@@ -30,6 +30,35 @@ constexpr int kWave = 64;
 constexpr int kBlock = 256;              // 4 waves, each wave owns one 64-vertex tile
 constexpr int kWavesPerBlock = kBlock / kWave;
 
+// ---- per-kernel timing (bench.py's roofline block): while a sink is installed on this thread, every launch
+// on the sink's stream is bracketed by two HIP events of the sink's pool (launches on the side streams are not).
+thread_local KernelTraceSink *t_sink = nullptr;
+
+struct KernelTimer {
+    KernelTraceSink::Rec *rec = nullptr;
+    hipStream_t stream;
+    KernelTimer(hipStream_t s, const char *name) : stream(s) {
+        KernelTraceSink *k = t_sink;
+        if (!k || k->stream != s) return;
+        if (k->used == k->recs.size()) {
+            KernelTraceSink::Rec fresh{name, nullptr, nullptr};
+            if (hipEventCreate(&fresh.a) != hipSuccess || hipEventCreate(&fresh.b) != hipSuccess) return;
+            k->recs.push_back(fresh);
+        }
+        rec = &k->recs[k->used++];
+        rec->name = name;
+        (void)hipEventRecord(rec->a, s);
+    }
+    ~KernelTimer() {
+        if (rec) (void)hipEventRecord(rec->b, stream);
+    }
+};
+#define GNNVC_LAUNCH(kernel_, grid_, block_, lds_, stream_, ...)              \
+    do {                                                                      \
+        KernelTimer kt_((stream_), #kernel_);                                 \
+        hipLaunchKernelGGL(kernel_, grid_, block_, lds_, stream_, __VA_ARGS__); \
+    } while (0)
+
 __device__ __forceinline__ void wave_lds_sync() {
     // LDS operations of one wave execute in program order; this only stops the
     // compiler from moving LDS accesses across the hand-off point.
@@ -2558,6 +2587,8 @@ inline unsigned blocks_for(size_t work, unsigned block) {
 
 // ---------------------------------------------------------------------- launchers
 
+void set_kernel_trace(KernelTraceSink *sink) { t_sink = sink; }
+
 int stage_variant(int f, int n1, int n2, int n3, int sigmoid_last) {
     if (f == 1 && n1 == 32 && n2 == 32 && n3 == 16 && !sigmoid_last) return 0;
     if (f == 16 && n1 == 32 && n2 == 32 && n3 == 16 && !sigmoid_last) return 1;
@@ -2572,7 +2603,7 @@ hipError_t launch_dense_sigmoid(const StagePlan &sp, const GraphDev &g, float ws
     if (row_hi <= row_lo) return hipSuccess;
     if (sp.f != 16 || sp.variant != 2 || !acc4 || !c4desc) return hipErrorInvalidValue;
     const dim3 grid((row_hi - row_lo + kBlock - 1) / kBlock), block(kBlock);
-    hipLaunchKernelGGL((k_dense_sigmoid<32, 16>), grid, block, 0, stream, g, ws, reinterpret_cast<const float4 *>(in), out, logits,
+    GNNVC_LAUNCH((k_dense_sigmoid<32, 16>), grid, block, 0, stream, g, ws, reinterpret_cast<const float4 *>(in), out, logits,
                        params + sp.param_offset, row_lo, row_hi, reinterpret_cast<const float4 *>(acc4), c4desc,
                        reinterpret_cast<const float4 *>(agg16));
     return hipGetLastError();
@@ -2596,20 +2627,20 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
     const int il = interleave ? 1 : 0;
     switch (sp.variant * 2 + (mfma ? 1 : 0)) {
     case 0:
-        hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, false>), grid, block, 0, stream, g, ws, in, out, P,
+        GNNVC_LAUNCH((k_stage_f1<32, 32, 16, 4, false>), grid, block, 0, stream, g, ws, in, out, P,
                            row_lo, row_hi, g.rowptr, g.col, nofloat, long_thresh, il, (const uint32_t *)nullptr,
                            emit.spec, reinterpret_cast<c4row *>(emit.table), emit.counts, sorted ? so->vertex : nullptr,
                            sorted ? reinterpret_cast<const uint4 *>(so->meta) : nullptr, sorted ? so->n : 0u);
         break;
     case 1:
-        hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, true>), grid, block, 0, stream, g, ws, in, out, P,
+        GNNVC_LAUNCH((k_stage_f1<32, 32, 16, 4, true>), grid, block, 0, stream, g, ws, in, out, P,
                            row_lo, row_hi, g.rowptr, g.col, nofloat, long_thresh, il, (const uint32_t *)nullptr,
                            (const uint32_t *)nullptr, (c4row *)nullptr, (unsigned long long *)nullptr,
                            sorted ? so->vertex : nullptr, sorted ? reinterpret_cast<const uint4 *>(so->meta) : nullptr,
                            sorted ? so->n : 0u);
         break;
 #define GNNVC_LAUNCH_F16(N2_, N3_, SIG_, MF_, SRT_, LG_)                                              \
-    hipLaunchKernelGGL((k_stage_f16<32, N2_, N3_, SIG_, 2, MF_, SRT_>), grid, block, 0, stream, g, ws, in4, out, \
+    GNNVC_LAUNCH((k_stage_f16<32, N2_, N3_, SIG_, 2, MF_, SRT_>), grid, block, 0, stream, g, ws, in4, out, \
                        LG_, P, row_lo, row_hi, long_thresh, sorted ? so->vertex : nullptr,                \
                        sorted ? so->meta : nullptr, sorted ? so->n : 0u, il,                              \
                        (const float4 *)nullptr, (sorted || !acc4) ? nullptr : c4desc, (const float4 *)nullptr,           \
@@ -2640,7 +2671,7 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
         // overlap with, the dense layers run faster on the VALU (one lane per vertex, weights from SGPRs) than on
         // the fp32 matrix cores: 6.65 vs 7.16 ms per forward on the metric graph.
 #define GNNVC_LAUNCH_AGG(N2_, N3_, SIG_, MF_, LG_)                                                        \
-        hipLaunchKernelGGL((k_stage_f16<32, N2_, N3_, SIG_, 2, MF_, false, true>), grid, block, 0, stream, g, ws, in4, \
+        GNNVC_LAUNCH((k_stage_f16<32, N2_, N3_, SIG_, 2, MF_, false, true>), grid, block, 0, stream, g, ws, in4, \
                            out, LG_, P, row_lo, row_hi, long_thresh, (const uint32_t *)nullptr, (const uint4 *)nullptr, \
                            0u, il, reinterpret_cast<const float4 *>(acc4), c4desc, reinterpret_cast<const float4 *>(agg16), \
                            (MF_ || SIG_) ? nullptr : emit.spec, reinterpret_cast<c4row *>((MF_ || SIG_) ? nullptr : emit.table), \
@@ -2661,7 +2692,7 @@ hipError_t launch_graph_layer(const GraphDev &g, float ws, uint32_t f, const flo
                               float *out, hipStream_t stream) {
     const size_t work = (size_t)g.n * (2 * f + 3);
     if (!work) return hipSuccess;
-    hipLaunchKernelGGL(k_graph_layer, dim3(blocks_for(work, 256)), dim3(256), 0, stream, g, ws, f,
+    GNNVC_LAUNCH(k_graph_layer, dim3(blocks_for(work, 256)), dim3(256), 0, stream, g, ws, f,
                        in, out);
     return hipGetLastError();
 }
@@ -2670,7 +2701,7 @@ hipError_t launch_linear(uint32_t n, uint32_t k, uint32_t m, const float *in, co
                          const float *bias, float *out, hipStream_t stream) {
     const size_t work = (size_t)n * m;
     if (!work) return hipSuccess;
-    hipLaunchKernelGGL(k_linear, dim3(blocks_for(work, 256)), dim3(256), 0, stream, n, k, m, in,
+    GNNVC_LAUNCH(k_linear, dim3(blocks_for(work, 256)), dim3(256), 0, stream, n, k, m, in,
                        W, bias, out);
     return hipGetLastError();
 }
@@ -2678,14 +2709,14 @@ hipError_t launch_linear(uint32_t n, uint32_t k, uint32_t m, const float *in, co
 hipError_t launch_relu(size_t count, const float *in, float *out, hipStream_t stream) {
     if (!count) return hipSuccess;
     const unsigned nb = (unsigned)((count + 255) / 256 < 8192 ? (count + 255) / 256 : 8192);
-    hipLaunchKernelGGL(k_relu, dim3(nb), dim3(256), 0, stream, count, in, out);
+    GNNVC_LAUNCH(k_relu, dim3(nb), dim3(256), 0, stream, count, in, out);
     return hipGetLastError();
 }
 
 hipError_t launch_sigmoid(size_t count, const float *in, float *out, hipStream_t stream) {
     if (!count) return hipSuccess;
     const unsigned nb = (unsigned)((count + 255) / 256 < 8192 ? (count + 255) / 256 : 8192);
-    hipLaunchKernelGGL(k_sigmoid, dim3(nb), dim3(256), 0, stream, count, in, out);
+    GNNVC_LAUNCH(k_sigmoid, dim3(nb), dim3(256), 0, stream, count, in, out);
     return hipGetLastError();
 }
 
@@ -2694,7 +2725,7 @@ hipError_t launch_sgemm(int ta, int tb, uint32_t m, uint32_t n, uint32_t k, cons
                         uint32_t ldc, hipStream_t stream) {
     const size_t work = (size_t)m * n;
     if (!work) return hipSuccess;
-    hipLaunchKernelGGL(k_sgemm, dim3(blocks_for(work, 256)), dim3(256), 0, stream, ta, tb, m, n, k,
+    GNNVC_LAUNCH(k_sgemm, dim3(blocks_for(work, 256)), dim3(256), 0, stream, ta, tb, m, n, k,
                        A, lda, B, ldb, beta, C, ldc);
     return hipGetLastError();
 }
@@ -2704,11 +2735,11 @@ static hipError_t scan_u32(uint32_t *data, size_t n, uint32_t *scratch, hipStrea
     // scratch needs ceil(n/chunk) + ceil(that/chunk) + ... entries (callers reserve n/2048 + 8192)
     if (n == 0) return hipSuccess;
     const size_t chunks = (n + kScanChunk - 1) / kScanChunk;
-    hipLaunchKernelGGL(k_scan_chunks, dim3((unsigned)chunks), dim3(256), 0, stream, data, n, scratch);
+    GNNVC_LAUNCH(k_scan_chunks, dim3((unsigned)chunks), dim3(256), 0, stream, data, n, scratch);
     if (chunks > 1) {
         hipError_t rc = scan_u32(scratch, chunks, scratch + chunks, stream);
         if (rc != hipSuccess) return rc;
-        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, data, n,
+        GNNVC_LAUNCH(k_scan_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, data, n,
                            scratch);
     }
     return hipGetLastError();
@@ -2725,10 +2756,10 @@ hipError_t build_blocked_index(const GraphDev &g, uint32_t wb, uint32_t nblocks,
     rc = hipMemsetAsync(bad_flag, 0, sizeof(uint32_t), stream);
     if (rc != hipSuccess) return rc;
     const unsigned nb = (g.n + 255) / 256;
-    hipLaunchKernelGGL(k_blk_count, dim3(nb), dim3(256), 0, stream, g, wb, long_thresh, bp, bad_flag);
+    GNNVC_LAUNCH(k_blk_count, dim3(nb), dim3(256), 0, stream, g, wb, long_thresh, bp, bad_flag);
     rc = scan_u32(bp, elems, scratch, stream);
     if (rc != hipSuccess) return rc;
-    hipLaunchKernelGGL(k_blk_scatter, dim3(nb), dim3(256), 0, stream, g, wb, long_thresh, bp, colb);
+    GNNVC_LAUNCH(k_blk_scatter, dim3(nb), dim3(256), 0, stream, g, wb, long_thresh, bp, colb);
     return hipGetLastError();
 }
 
@@ -2740,7 +2771,7 @@ hipError_t launch_stage0_blocked(const StagePlan &sp, const GraphDev &g, float w
     if (sp.variant != 0) return hipErrorInvalidValue;
     const unsigned nb = (row_hi - row_lo + 255) / 256;
     for (uint32_t k = 0; k + 1 < nblocks; ++k)
-        hipLaunchKernelGGL(k_blk_accumulate, dim3(nb), dim3(256), 0, stream, bp + (size_t)k * g.n, colb, x,
+        GNNVC_LAUNCH(k_blk_accumulate, dim3(nb), dim3(256), 0, stream, bp + (size_t)k * g.n, colb, x,
                            acc, row_lo, row_hi, k == 0 ? 1 : 0);
     const uint32_t ntiles = (row_hi - row_lo + kWave - 1) / kWave;
     const uint32_t per_xcd = (ntiles + 7) / 8;
@@ -2749,12 +2780,12 @@ hipError_t launch_stage0_blocked(const StagePlan &sp, const GraphDev &g, float w
     const float *acc_in = nblocks > 1 ? acc : nullptr;
     const dim3 grid(blocks_per_xcd * 8), block(kBlock);
     if (mfma)
-        hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, true>), grid, block, 0, stream, g, ws, x, out,
+        GNNVC_LAUNCH((k_stage_f1<32, 32, 16, 4, true>), grid, block, 0, stream, g, ws, x, out,
                            params + sp.param_offset, row_lo, row_hi, ep, colb, acc_in, long_thresh, interleave ? 1 : 0,
                            (const uint32_t *)nullptr, (const uint32_t *)nullptr, (c4row *)nullptr, (unsigned long long *)nullptr,
                            (const uint32_t *)nullptr, (const uint4 *)nullptr, 0u);
     else
-        hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, false>), grid, block, 0, stream, g, ws, x, out,
+        GNNVC_LAUNCH((k_stage_f1<32, 32, 16, 4, false>), grid, block, 0, stream, g, ws, x, out,
                            params + sp.param_offset, row_lo, row_hi, ep, colb, acc_in, long_thresh, interleave ? 1 : 0,
                            (const uint32_t *)nullptr, emit.spec, reinterpret_cast<c4row *>(emit.table), emit.counts,
                            (const uint32_t *)nullptr, (const uint4 *)nullptr, 0u);
@@ -2783,14 +2814,14 @@ hipError_t lds_table_wsteps(const GraphDev &g, uint32_t slice_rows, uint32_t nch
                             const uint32_t *step_ptr, uint32_t *step_count, uint32_t *recs, bool write, uint32_t slack,
                             hipStream_t stream) {
     if (slack < 3u * nblocks + 4u) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_ltw_steps, dim3((nchunks + 63) / 64), dim3(64), 0, stream, g, slice_rows, nchunks, nblocks, seg_cnt,
+    GNNVC_LAUNCH(k_ltw_steps, dim3((nchunks + 63) / 64), dim3(64), 0, stream, g, slice_rows, nchunks, nblocks, seg_cnt,
                        step_ptr, step_count, recs, write ? 1 : 0, kLtwStep, slack);
     return hipGetLastError();
 }
 
 hipError_t lds_table_bytes(const uint32_t *w, uint32_t n, uint8_t *wb, uint32_t *bad, hipStream_t stream) {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(k_lt_bytes, dim3((n + 255) / 256), dim3(256), 0, stream, w, n, wb, bad);
+    GNNVC_LAUNCH(k_lt_bytes, dim3((n + 255) / 256), dim3(256), 0, stream, w, n, wb, bad);
     return hipGetLastError();
 }
 
@@ -2798,7 +2829,7 @@ hipError_t lds_table_count(const GraphDev &g, uint32_t rows_per_chunk, uint32_t 
                            uint32_t *seg_cnt, uint32_t *bad, hipStream_t stream, uint32_t row_base, uint32_t row_end) {
     if (row_end > g.n) row_end = g.n;
     if (nblocks > 4096 || block_cols > (1u << 18) || rows_per_chunk > (1u << 15)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_lt_count, dim3(nchunks), dim3(1024), 0, stream, g, rows_per_chunk, nblocks, block_cols, seg_cnt, bad,
+    GNNVC_LAUNCH(k_lt_count, dim3(nchunks), dim3(1024), 0, stream, g, rows_per_chunk, nblocks, block_cols, seg_cnt, bad,
                        row_base, row_end);
     return hipGetLastError();
 }
@@ -2809,7 +2840,7 @@ hipError_t lds_table_steps(const GraphDev &g, uint32_t rows_per_chunk, uint32_t 
     if (row_end > g.n) row_end = g.n;
     if (cap == 0) cap = kLtStep;
     if (slack && slack < 3u * nblocks + 4u) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_lt_steps, dim3((nchunks + 255) / 256), dim3(256), 0, stream, g, rows_per_chunk, nchunks, nblocks,
+    GNNVC_LAUNCH(k_lt_steps, dim3((nchunks + 255) / 256), dim3(256), 0, stream, g, rows_per_chunk, nchunks, nblocks,
                        seg_cnt, step_ptr, step_count, reinterpret_cast<uint4 *>(steps), write ? 1 : 0, row_base, row_end, cap, slack);
     return hipGetLastError();
 }
@@ -2820,7 +2851,7 @@ hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_
     if (block_cols > (1u << shift) || ((uint64_t)rows_per_chunk << shift) > (1ull << 32)) return hipErrorInvalidValue;
     if (slack && slack < 3u * nblocks + 4u) return hipErrorInvalidValue;
     if (row_end > g.n) row_end = g.n;
-    hipLaunchKernelGGL(k_lt_scatter, dim3(nchunks), dim3(1024), 0, stream, g, rows_per_chunk, nblocks, block_cols, shift, seg_cnt,
+    GNNVC_LAUNCH(k_lt_scatter, dim3(nchunks), dim3(1024), 0, stream, g, rows_per_chunk, nblocks, block_cols, shift, seg_cnt,
                        entries, row_base, row_end, slack);
     return hipGetLastError();
 }
@@ -2836,7 +2867,7 @@ hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float
     // does this forward's input match the table?  decided on the device: no host round trip
     hipError_t rc = hipMemsetAsync(bad, 0, sizeof(uint32_t), stream);
     if (rc != hipSuccess) return rc;
-    hipLaunchKernelGGL(k_lt_check_x, dim3(std::min<unsigned>((g.n + 255) / 256, 4096u)), dim3(256), 0, stream, x, g.w, ws, g.n,
+    GNNVC_LAUNCH(k_lt_check_x, dim3(std::min<unsigned>((g.n + 255) / 256, 4096u)), dim3(256), 0, stream, x, g.w, ws, g.n,
                        bad);
     const uint32_t c0 = row_lo / rows_per_chunk, c1 = (row_hi - 1) / rows_per_chunk;
     const uint32_t slice_rows = rows_per_chunk / 16u;
@@ -2846,19 +2877,19 @@ hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float
     static std::atomic<uint64_t> lds_ok{0};
     rc = allow_dynamic_lds(reinterpret_cast<const void *>(k_lt_agg), (int)lds_max, lds_ok);
     if (rc != hipSuccess) return rc;
-    hipLaunchKernelGGL(k_lt_agg, dim3(c1 - c0 + 1), dim3(1024), lds, stream, step_ptr, reinterpret_cast<const uint32_t *>(steps),
+    GNNVC_LAUNCH(k_lt_agg, dim3(c1 - c0 + 1), dim3(1024), lds, stream, step_ptr, reinterpret_cast<const uint32_t *>(steps),
                        entries, wbyte, ws, acc, g.n, slice_rows, c0, last_entry, bad);
     const uint32_t ntiles = (row_hi - row_lo + kWave - 1) / kWave;
     const uint32_t per_xcd = (ntiles + 7) / 8;
     const uint32_t blocks_per_xcd = (per_xcd + kWavesPerBlock - 1) / kWavesPerBlock;
     const dim3 grid(blocks_per_xcd * 8), block(kBlock);
     if (mfma)
-        hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, true>), grid, block, 0, stream, g, ws, x, out, params + sp.param_offset,
+        GNNVC_LAUNCH((k_stage_f1<32, 32, 16, 4, true>), grid, block, 0, stream, g, ws, x, out, params + sp.param_offset,
                            row_lo, row_hi, g.rowptr, g.col, acc, long_thresh, interleave ? 1 : 0, (const uint32_t *)bad,
                            (const uint32_t *)nullptr, (c4row *)nullptr, (unsigned long long *)nullptr,
                            (const uint32_t *)nullptr, (const uint4 *)nullptr, 0u);
     else
-        hipLaunchKernelGGL((k_stage_f1<32, 32, 16, 4, false>), grid, block, 0, stream, g, ws, x, out, params + sp.param_offset,
+        GNNVC_LAUNCH((k_stage_f1<32, 32, 16, 4, false>), grid, block, 0, stream, g, ws, x, out, params + sp.param_offset,
                            row_lo, row_hi, g.rowptr, g.col, acc, long_thresh, interleave ? 1 : 0, (const uint32_t *)bad,
                            emit.spec, reinterpret_cast<c4row *>(emit.table), emit.counts,
                            (const uint32_t *)nullptr, (const uint4 *)nullptr, 0u);
@@ -2882,8 +2913,8 @@ hipError_t launch_compact_gather(const GraphDev &g, const float *in, const unsig
     if (row_hi <= row_lo || g.nnz == 0 || row_lo < plan_base || row_hi > plan_end) return hipErrorInvalidValue;
     if (rows_per_chunk == 0 || rows_per_chunk > kC4MaxRows || rows_per_chunk % kC4Slices) return hipErrorInvalidValue;
     if (what & 1) {   // prepare: choose the columns and (unless the producing kernel did) write the table
-        hipLaunchKernelGGL(k_c4_choose, dim3(1), dim3(64), 0, stream, counts, count_slots, g.n, desc);
-        hipLaunchKernelGGL(k_c4_compact, dim3(std::min<unsigned>((g.n + 256) / 256, 4096u)), dim3(256), 0, stream,
+        GNNVC_LAUNCH(k_c4_choose, dim3(1), dim3(64), 0, stream, counts, count_slots, g.n, desc);
+        GNNVC_LAUNCH(k_c4_compact, dim3(std::min<unsigned>((g.n + 256) / 256, 4096u)), dim3(256), 0, stream,
                            reinterpret_cast<const float4 *>(in), g.n, desc, reinterpret_cast<f32x4 *>(table));
     }
     if (!(what & 2)) return hipGetLastError();
@@ -2918,12 +2949,12 @@ hipError_t compact_sums(const GraphDev &g, uint32_t *desc, const float *table, f
     // a persistent grid of one workgroup per CU: they start together and sweep the column blocks together
     const dim3 grid(std::min<uint32_t>(256u, c1 - c0)), block(1024);
     if (one_round)
-        hipLaunchKernelGGL(k_c4_agg<1>, grid, block, lds, stream, step_ptr,
+        GNNVC_LAUNCH(k_c4_agg<1>, grid, block, lds, stream, step_ptr,
                            reinterpret_cast<const uint4 *>(steps), entries, reinterpret_cast<const f32x4 *>(table),
                            reinterpret_cast<f32x4 *>(acc4), g.n, slice_rows, c0 * kC4Slices, std::min(c1 * kC4Slices, nslices), nslices,
                            last_entry, desc, dirty_rows, dirty_cap, block_cols, nblocks, plan_base, plan_end);
     else
-        hipLaunchKernelGGL(k_c4_agg<0>, grid, block, lds, stream, step_ptr,
+        GNNVC_LAUNCH(k_c4_agg<0>, grid, block, lds, stream, step_ptr,
                            reinterpret_cast<const uint4 *>(steps), entries, reinterpret_cast<const f32x4 *>(table),
                            reinterpret_cast<f32x4 *>(acc4), g.n, slice_rows, c0 * kC4Slices, std::min(c1 * kC4Slices, nslices), nslices,
                            last_entry, desc, dirty_rows, dirty_cap, block_cols, nblocks, plan_base, plan_end);
@@ -2932,7 +2963,7 @@ hipError_t compact_sums(const GraphDev &g, uint32_t *desc, const float *table, f
 
 // marks[k] = dirty-row slots handed out so far
 hipError_t compact_mark(const uint32_t *desc, uint32_t *marks, uint32_t k, hipStream_t stream) {
-    hipLaunchKernelGGL(k_c4_mark, dim3(1), dim3(1), 0, stream, desc, marks, k);
+    GNNVC_LAUNCH(k_c4_mark, dim3(1), dim3(1), 0, stream, desc, marks, k);
     return hipGetLastError();
 }
 
@@ -2940,7 +2971,7 @@ hipError_t compact_mark(const uint32_t *desc, uint32_t *marks, uint32_t k, hipSt
 // a small grid when the kernel runs beside the aggregation grid (it strides over what it has to do)
 hipError_t compact_fix(const GraphDev &g, const float *in, const uint32_t *desc, const uint32_t *dirty_rows, uint32_t dirty_cap,
                        float *agg16, const uint32_t *marks, hipStream_t stream, uint32_t blocks) {
-    hipLaunchKernelGGL(k_c4_fix, dim3(std::min<uint32_t>((dirty_cap + 63) / 64, blocks)), dim3(256), 0, stream, g,
+    GNNVC_LAUNCH(k_c4_fix, dim3(std::min<uint32_t>((dirty_cap + 63) / 64, blocks)), dim3(256), 0, stream, g,
                        reinterpret_cast<const float4 *>(in), desc, dirty_rows, dirty_cap, reinterpret_cast<float4 *>(agg16), marks);
     return hipGetLastError();
 }
@@ -2950,7 +2981,7 @@ hipError_t measure_tile_waste(const GraphDev &g, uint32_t row_lo, uint32_t row_h
                               unsigned long long *sum_max, hipStream_t stream) {
     hipError_t rc = hipMemsetAsync(sum_max, 0, sizeof(unsigned long long), stream);
     if (rc != hipSuccess || row_hi <= row_lo) return rc;
-    hipLaunchKernelGGL(k_tile_waste, dim3(std::min<unsigned>((row_hi - row_lo + 255) / 256, 2048u)), dim3(256), 0, stream, g,
+    GNNVC_LAUNCH(k_tile_waste, dim3(std::min<unsigned>((row_hi - row_lo + 255) / 256, 2048u)), dim3(256), 0, stream, g,
                        row_lo, row_hi, long_thresh, sum_max);
     return hipGetLastError();
 }
@@ -2960,14 +2991,14 @@ hipError_t degree_histogram(const GraphDev &g, uint32_t row_lo, uint32_t row_hi,
     hipError_t rc = hipMemsetAsync(hist, 0, bins * sizeof(uint32_t), stream);
     if (rc != hipSuccess || row_hi <= row_lo) return rc;
     const unsigned nb = std::min<unsigned>((row_hi - row_lo + 255) / 256, 2048u);
-    hipLaunchKernelGGL(k_deg_hist, dim3(nb), dim3(256), 0, stream, g, row_lo, row_hi, long_thresh, bins, hist);
+    GNNVC_LAUNCH(k_deg_hist, dim3(nb), dim3(256), 0, stream, g, row_lo, row_hi, long_thresh, bins, hist);
     return hipGetLastError();
 }
 
 hipError_t degree_scatter(const GraphDev &g, uint32_t row_lo, uint32_t row_hi, uint32_t long_thresh,
                           uint32_t bins, uint32_t *cursor, uint32_t *vertex, void *meta, hipStream_t stream) {
     if (row_hi <= row_lo) return hipSuccess;
-    hipLaunchKernelGGL(k_deg_scatter, dim3((row_hi - row_lo + 255) / 256), dim3(256), 0, stream, g, row_lo, row_hi,
+    GNNVC_LAUNCH(k_deg_scatter, dim3((row_hi - row_lo + 255) / 256), dim3(256), 0, stream, g, row_lo, row_hi,
                        long_thresh, bins, cursor, vertex, reinterpret_cast<uint4 *>(meta));
     return hipGetLastError();
 }
@@ -2977,7 +3008,7 @@ hipError_t find_long_rows(const GraphDev &g, uint32_t thresh, uint32_t *list, ui
                           hipStream_t stream) {
     hipError_t rc = hipMemsetAsync(count, 0, sizeof(uint32_t), stream);
     if (rc != hipSuccess || g.hi() <= g.lo()) return rc;
-    hipLaunchKernelGGL(k_find_long, dim3((g.hi() - g.lo() + 255) / 256), dim3(256), 0, stream, g, thresh, list, count);
+    GNNVC_LAUNCH(k_find_long, dim3((g.hi() - g.lo() + 255) / 256), dim3(256), 0, stream, g, thresh, list, count);
     return hipGetLastError();
 }
 
@@ -2985,7 +3016,7 @@ hipError_t find_giant_rows(const GraphDev &g, const uint32_t *list, uint32_t n_l
                            hipStream_t stream) {
     hipError_t rc = hipMemsetAsync(count, 0, sizeof(uint32_t), stream);
     if (rc != hipSuccess || n_long == 0) return rc;
-    hipLaunchKernelGGL(k_find_giant, dim3((n_long + 255) / 256), dim3(256), 0, stream, g, list, n_long, thresh,
+    GNNVC_LAUNCH(k_find_giant, dim3((n_long + 255) / 256), dim3(256), 0, stream, g, list, n_long, thresh,
                        reinterpret_cast<uint4 *>(meta), count);
     return hipGetLastError();
 }
@@ -2999,22 +3030,22 @@ hipError_t launch_giant_stage(const StagePlan &sp, const GraphDev &g, float ws, 
     const uint4 *meta = reinterpret_cast<const uint4 *>(gr.meta);
     const uint32_t F = sp.f == 16 ? 16u : 1u;
     if (sp.f == 16)
-        hipLaunchKernelGGL(k_giant_gather16, dim3(gr.blocks), dim3(256), 0, stream, g, reinterpret_cast<const float4 *>(in), gr.slab,
+        GNNVC_LAUNCH(k_giant_gather16, dim3(gr.blocks), dim3(256), 0, stream, g, reinterpret_cast<const float4 *>(in), gr.slab,
                            meta, gr.off, gr.n, row_lo, row_hi);
     else if (sp.f == 1)
-        hipLaunchKernelGGL(k_giant_gather1, dim3(gr.blocks), dim3(256), 0, stream, g, in, gr.slab, meta, gr.off, gr.n, row_lo, row_hi);
+        GNNVC_LAUNCH(k_giant_gather1, dim3(gr.blocks), dim3(256), 0, stream, g, in, gr.slab, meta, gr.off, gr.n, row_lo, row_hi);
     else
         return hipErrorInvalidValue;
     if (fast)
-        hipLaunchKernelGGL(k_giant_sum<true>, dim3(gr.n * F), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.agg, row_lo, row_hi);
+        GNNVC_LAUNCH(k_giant_sum<true>, dim3(gr.n * F), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.agg, row_lo, row_hi);
     else
-        hipLaunchKernelGGL(k_giant_sum<false>, dim3(gr.n * F), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.agg, row_lo, row_hi);
+        GNNVC_LAUNCH(k_giant_sum<false>, dim3(gr.n * F), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.agg, row_lo, row_hi);
     const float *P = params + sp.param_offset;
     const dim3 grid((gr.n + 63) / 64), block(64);
     switch (sp.variant) {
-    case 0: hipLaunchKernelGGL(k_giant_dense<0>, grid, block, 0, stream, g, ws, in, out, logits, P, meta, gr.n, gr.agg, row_lo, row_hi); break;
-    case 1: hipLaunchKernelGGL(k_giant_dense<1>, grid, block, 0, stream, g, ws, in, out, logits, P, meta, gr.n, gr.agg, row_lo, row_hi); break;
-    case 2: hipLaunchKernelGGL(k_giant_dense<2>, grid, block, 0, stream, g, ws, in, out, logits, P, meta, gr.n, gr.agg, row_lo, row_hi); break;
+    case 0: GNNVC_LAUNCH(k_giant_dense<0>, grid, block, 0, stream, g, ws, in, out, logits, P, meta, gr.n, gr.agg, row_lo, row_hi); break;
+    case 1: GNNVC_LAUNCH(k_giant_dense<1>, grid, block, 0, stream, g, ws, in, out, logits, P, meta, gr.n, gr.agg, row_lo, row_hi); break;
+    case 2: GNNVC_LAUNCH(k_giant_dense<2>, grid, block, 0, stream, g, ws, in, out, logits, P, meta, gr.n, gr.agg, row_lo, row_hi); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -3025,12 +3056,12 @@ hipError_t launch_giant_stage(const StagePlan &sp, const GraphDev &g, float ws, 
 hipError_t stream_sums(const float *streams_dev, uint32_t streams, uint32_t len, void *meta, unsigned long long *off, float *agg,
                        bool fast, hipStream_t stream) {
     if (!streams) return hipSuccess;
-    hipLaunchKernelGGL(k_stream_meta, dim3((streams + 256) / 256), dim3(256), 0, stream, reinterpret_cast<uint4 *>(meta), off, streams, len);
+    GNNVC_LAUNCH(k_stream_meta, dim3((streams + 256) / 256), dim3(256), 0, stream, reinterpret_cast<uint4 *>(meta), off, streams, len);
     if (fast)
-        hipLaunchKernelGGL(k_giant_sum<true>, dim3(streams), dim3(64), 0, stream, streams_dev, reinterpret_cast<const uint4 *>(meta), off,
+        GNNVC_LAUNCH(k_giant_sum<true>, dim3(streams), dim3(64), 0, stream, streams_dev, reinterpret_cast<const uint4 *>(meta), off,
                            1u, agg, 0u, 1u);
     else
-        hipLaunchKernelGGL(k_giant_sum<false>, dim3(streams), dim3(64), 0, stream, streams_dev, reinterpret_cast<const uint4 *>(meta), off,
+        GNNVC_LAUNCH(k_giant_sum<false>, dim3(streams), dim3(64), 0, stream, streams_dev, reinterpret_cast<const uint4 *>(meta), off,
                            1u, agg, 0u, 1u);
     return hipGetLastError();
 }
@@ -3043,15 +3074,15 @@ hipError_t launch_long_stage(const StagePlan &sp, const GraphDev &g, float ws, c
     const dim3 grid(n_long), block(256);
     switch (sp.variant) {
     case 0:
-        hipLaunchKernelGGL((k_long_f1<32, 32, 16>), grid, block, 0, stream, g, ws, in, out, P, row_lo, row_hi, list,
+        GNNVC_LAUNCH((k_long_f1<32, 32, 16>), grid, block, 0, stream, g, ws, in, out, P, row_lo, row_hi, list,
                            min_deg, max_deg);
         break;
     case 1:
-        hipLaunchKernelGGL((k_long_f16<32, 32, 16, false>), grid, block, 0, stream, g, ws,
+        GNNVC_LAUNCH((k_long_f16<32, 32, 16, false>), grid, block, 0, stream, g, ws,
                            reinterpret_cast<const float4 *>(in), out, nullptr, P, row_lo, row_hi, list, min_deg, max_deg);
         break;
     case 2:
-        hipLaunchKernelGGL((k_long_f16<32, 16, 1, true>), grid, block, 0, stream, g, ws,
+        GNNVC_LAUNCH((k_long_f16<32, 16, 1, true>), grid, block, 0, stream, g, ws,
                            reinterpret_cast<const float4 *>(in), out, logits, P, row_lo, row_hi, list, min_deg, max_deg);
         break;
     default:
@@ -3065,13 +3096,13 @@ hipError_t live_columns(const float *feat, size_t rows, uint32_t *mask, hipStrea
     if (rc != hipSuccess || rows == 0) return rc;
     const size_t quads = rows * 4;
     const unsigned blocks = (unsigned)std::min<size_t>((quads + 255) / 256, 4096);
-    hipLaunchKernelGGL(k_live_columns, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const float4 *>(feat), quads, mask);
+    GNNVC_LAUNCH(k_live_columns, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const float4 *>(feat), quads, mask);
     return hipGetLastError();
 }
 
 hipError_t score_keys(const float *scores, size_t n, float *keys, uint8_t *above_half, hipStream_t stream) {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(k_score_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, scores, n, keys, above_half);
+    GNNVC_LAUNCH(k_score_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, scores, n, keys, above_half);
     return hipGetLastError();
 }
 
@@ -3080,7 +3111,7 @@ hipError_t column_counts(const float *feat, size_t rows, unsigned long long *cou
     if (rc != hipSuccess || rows == 0) return rc;
     const size_t quads = rows * 4;
     const unsigned blocks = (unsigned)std::min<size_t>((quads + 255) / 256, 2048);
-    hipLaunchKernelGGL(k_column_counts, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const float4 *>(feat), quads,
+    GNNVC_LAUNCH(k_column_counts, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const float4 *>(feat), quads,
                        counts);
     return hipGetLastError();
 }
@@ -3098,7 +3129,7 @@ hipError_t pack_rows(const float *feat, uint32_t row_lo, uint32_t row_hi, uint32
         if (mask >> c & 1u) map.col[k++] = (uint8_t)c;
     if (k > kp || kp < 4 || kp > 16) return hipErrorInvalidValue;
     const size_t total = (size_t)(row_hi - row_lo) * kp;
-    hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, feat, row_lo, row_hi,
+    GNNVC_LAUNCH(k_pack_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, feat, row_lo, row_hi,
                        mask, k, kp, map, dense, exc, cap, flag);
     return hipGetLastError();
 }
@@ -3108,11 +3139,11 @@ hipError_t unpack_rows(const float *dense, const uint32_t *exc, uint32_t cap, ui
     if (row_hi <= row_lo) return hipSuccess;
     if (kp < 4 || kp > 16 || (uint32_t)__builtin_popcount(mask & 0xFFFFu) > kp) return hipErrorInvalidValue;
     const size_t total = (size_t)(row_hi - row_lo) * 4;
-    hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dense, row_lo, row_hi,
+    GNNVC_LAUNCH(k_unpack_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dense, row_lo, row_hi,
                        mask & 0xFFFFu, kp, feat);
     if (exc && cap) {
         const unsigned blocks = std::min<unsigned>((cap + 255) / 256, 1024);
-        hipLaunchKernelGGL(k_unpack_exceptions, dim3(blocks), dim3(256), 0, stream, exc, cap, row_lo, row_hi, feat);
+        GNNVC_LAUNCH(k_unpack_exceptions, dim3(blocks), dim3(256), 0, stream, exc, cap, row_lo, row_hi, feat);
     }
     return hipGetLastError();
 }
@@ -3123,36 +3154,36 @@ hipError_t unpack_gathered(const float *buf, uint32_t world, uint32_t skip, size
     if (!world || !size) return hipSuccess;
     if (kp < 4 || kp > 16 || (uint32_t)__builtin_popcount(mask & 0xFFFFu) > kp || size > dense_rows) return hipErrorInvalidValue;
     const unsigned bx = (unsigned)std::min<size_t>(((size_t)size * 4 + 255) / 256, 2048);
-    hipLaunchKernelGGL(k_unpack_gathered, dim3(bx, world), dim3(256), 0, stream, buf, skip, piece_words, per, off, size, n,
+    GNNVC_LAUNCH(k_unpack_gathered, dim3(bx, world), dim3(256), 0, stream, buf, skip, piece_words, per, off, size, n,
                        mask & 0xFFFFu, kp, feat);
     if (cap)
-        hipLaunchKernelGGL(k_unpack_gathered_exceptions, dim3(std::min<unsigned>((cap + 255) / 256, 64), world), dim3(256), 0,
+        GNNVC_LAUNCH(k_unpack_gathered_exceptions, dim3(std::min<unsigned>((cap + 255) / 256, 64), world), dim3(256), 0,
                            stream, buf, skip, piece_words, dense_rows, cap, per, off, size, n, kp, feat);
     return hipGetLastError();
 }
 
 hipError_t launch_reduction_flags(const GraphDev &g, uint32_t max_degree, uint8_t *flags, hipStream_t stream) {
     if (g.n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_reduction_flags, dim3((g.n + 255) / 256), dim3(256), 0, stream, g, max_degree, flags);
+    GNNVC_LAUNCH(k_reduction_flags, dim3((g.n + 255) / 256), dim3(256), 0, stream, g, max_degree, flags);
     return hipGetLastError();
 }
 
 hipError_t validate_graph(const GraphDev &g, uint32_t *flags, hipStream_t stream) {
     hipError_t rc = hipMemsetAsync(flags, 0, sizeof(uint32_t), stream);
     if (rc != hipSuccess || g.n == 0) return rc;
-    hipLaunchKernelGGL(k_validate_graph, dim3(2048), dim3(256), 0, stream, g, flags);
+    GNNVC_LAUNCH(k_validate_graph, dim3(2048), dim3(256), 0, stream, g, flags);
     return hipGetLastError();
 }
 
 hipError_t narrow_rowptr(const void *in_u64, uint32_t *out, size_t count, hipStream_t stream) {
     if (!count) return hipSuccess;
-    hipLaunchKernelGGL(k_narrow_rowptr, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream,
+    GNNVC_LAUNCH(k_narrow_rowptr, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream,
                        reinterpret_cast<const unsigned long long *>(in_u64), out, count);
     return hipGetLastError();
 }
 
 hipError_t launch_zero_pad_row(float *buf, uint32_t n, uint32_t width, hipStream_t stream) {
-    hipLaunchKernelGGL(k_zero_row, dim3(1), dim3(64), 0, stream, buf, n, width);
+    GNNVC_LAUNCH(k_zero_row, dim3(1), dim3(64), 0, stream, buf, n, width);
     return hipGetLastError();
 }
 

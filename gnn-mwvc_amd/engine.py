@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "gnnvc_stage_forward_device", "gnnvc_stage_input_ready", "gnnvc_live_columns", "gnnvc_column_counts", "gnnvc_pack_rows", "gnnvc_unpack_rows", "gnnvc_unpack_gathered",
     "gnnvc_reduction_flags", "gnnvc_score_keys", "gnnvc_synchronize", "gnnvc_last_forward_ms",
     "gnnvc_graph_layer_forward", "gnnvc_linear_forward", "gnnvc_relu_forward",
-    "gnnvc_sigmoid_forward", "gnnvc_sgemm", "gnnvc_stream_sum",
+    "gnnvc_sigmoid_forward", "gnnvc_sgemm", "gnnvc_stream_sum", "gnnvc_kernel_trace",
 ]
 COL_PAD = 64
 
@@ -111,6 +111,7 @@ def load_library():
     L.gnnvc_sigmoid_forward.argtypes = [vp, C.c_size_t, f32p, f32p]
     L.gnnvc_sgemm.argtypes = [vp, C.c_int, C.c_int, u32, u32, u32, f32p, u32, f32p, u32, C.c_float,
                               f32p, u32]
+    L.gnnvc_kernel_trace.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.gnnvc_stream_sum.argtypes = [vp, f32p, u32, u32, C.c_int, f32p]
     for name in ABI_SYMBOLS:
         if name not in ("gnnvc_strerror", "gnnvc_last_error", "gnnvc_destroy"):
@@ -321,6 +322,14 @@ class Engine:
         self._check(self._L.gnnvc_last_forward_ms(self._h, C.byref(total), stages, 8))
         ns = max(self.num_stages, 1)
         return total.value, [stages[i] for i in range(ns)]
+
+    def kernel_trace(self, max_records: int = 256):
+        """[(kernel name, ms)] of the last forward_device under option "kernel_trace" (main-stream kernels)."""
+        names = (C.c_char_p * max_records)()
+        ms = (C.c_float * max_records)()
+        cnt = C.c_int(0)
+        self._check(self._L.gnnvc_kernel_trace(self._h, max_records, names, ms, C.byref(cnt)))
+        return [(names[i].decode(), float(ms[i])) for i in range(min(cnt.value, max_records))]
 
     # -- layer-level entry points
     def graph_layer(self, h: np.ndarray) -> np.ndarray:

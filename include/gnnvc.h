@@ -91,6 +91,9 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *                         their neighbour values are gathered by every CU into per-column streams and each stream's
  *                         sequential fp32 sum is evaluated with a parallel scan that reproduces the chain's
  *                         roundings (csrc/exact_sum.h); bit-identical results
+ *   "side_streams"   0|1  1 (default) = long / giant rows on side streams beside the tile kernel; 0 = on the main
+ *                         stream, one after the other (profiling: standalone kernel times)
+ *   "kernel_trace"   0|1  HIP events around every main-stream kernel of a forward (gnnvc_kernel_trace)
  *   "hub_mode"       0|1  0 (default) = exact; 1 = FAST, the tolerance mode of SURVEY.md §7: every long row goes the
  *                         giant-row way and its streams are added as lane-strided partial sums + a wave tree.
  *                         Scores then differ from the reference's in the last bits (and with them, possibly, the
@@ -261,6 +264,12 @@ int gnnvc_synchronize(gnnvc_engine *e);
 /* hipEvent timings of the last gnnvc_forward / gnnvc_forward_device on the
  * engine's stream: total and per stage, in milliseconds (waits for them). */
 int gnnvc_last_forward_ms(gnnvc_engine *e, float *total_ms, float *stage_ms, int max_stages);
+
+/* Per-kernel HIP-event timings of the last gnnvc_forward_device, when option "kernel_trace" is 1 (bench.py's
+ * roofline block): every kernel the forward launched on the engine's stream, in launch order — names[i] (static
+ * strings: the kernel as written at its launch site) and ms[i]; *count = how many there were (may exceed max).
+ * Kernels on the engine's side streams (long / giant rows, overlapped dense rounds) are not listed.  Waits. */
+int gnnvc_kernel_trace(gnnvc_engine *e, int max, const char **names, float *ms, int *count);
 
 /* ---- layer-level entry points (host pointers) ------------------------------
  * One call per reference layer forward(); used by the C++ mirror of the
