@@ -153,6 +153,12 @@ def main() -> int:
                     help="also time the host-pointer path (PCIe inclusive), reported separately")
     args = ap.parse_args()
 
+    # stdout carries ONE line, the result: whatever libraries print there while the job runs (RCCL's version banner,
+    # gloo's connection notes) is sent to stderr instead, and the JSON goes out through the saved descriptor
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -509,7 +515,8 @@ def main() -> int:
                 cpu_baseline(args, dev, eng, ggt, g, x, fwd_logits)
 
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     eng.close()
     if multi:
         dist.destroy_process_group()

@@ -200,6 +200,14 @@ def _equal_shard_rows(n: int, bounds: Sequence[Tuple[int, int]]) -> int:
     return per
 
 
+def _before_comm(t: torch.Tensor, group=None) -> None:
+    """RCCL collectives are ordered on the stream behind the kernels that produced `t`.  gloo is not: handed a device
+    tensor (the one-GPU rehearsal, `bench.py --backend gloo`) it reads the memory from the host right away, so the
+    stream has to be drained first — otherwise it ships rows a pack or stage kernel is still writing."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        torch.cuda.current_stream(t.device).synchronize()
+
+
 def exchange_rows(buf: torch.Tensor, bounds: Sequence[Tuple[int, int]], rank: int, n: int,
                   group=None, method: str = "auto") -> None:
     """Make rows [lo_r, hi_r) written by each rank r visible on every rank, in place.
@@ -218,6 +226,7 @@ def exchange_rows(buf: torch.Tensor, bounds: Sequence[Tuple[int, int]], rank: in
     per = _equal_shard_rows(n, bounds)
     if method == "auto":
         method = "allgather" if per else "p2p"
+    _before_comm(buf, group)
     if method == "allgather":
         if not per:
             raise ValueError("all_gather_into_tensor needs the equal-rows partition")
@@ -274,6 +283,7 @@ def exchange_rows_pipelined(stage_fn, stage: int, src: torch.Tensor, dst: torch.
             stage_fn(stage, r0, r1, src, dst, logits)
         # piece `off` of every rank's (padded) shard: equal sizes, rows past n stay zero
         outs = [dst[r * per + off: r * per + off + size] for r in range(world)]
+        _before_comm(dst, group)
         works.append(dist.all_gather(outs, outs[rank], group=group, async_op=True))
     for w in works:
         w.wait()
@@ -301,6 +311,7 @@ def exchange_rows_packed(codec: RowCodec, bufs: ForwardBuffers, dst: torch.Tenso
     buf = bufs.staging(start[-1])
     region = lambda r: buf[start[r]: start[r + 1]]
     codec.pack(dst, lo, hi, pk, region(rank), rows[rank], bufs.flag)
+    _before_comm(buf, group)
     if method == "allgather":
         dist.all_gather_into_tensor(buf[: start[-1]], region(rank), group=group)
     else:
@@ -351,6 +362,7 @@ def exchange_rows_pipelined_packed(codec: RowCodec, stage_fn, stage: int, src: t
             stage_fn(stage, r0, r1, src, dst, None)
         mine = buf[(k * world + rank) * pw: (k * world + rank + 1) * pw]
         codec.pack(dst, r0, r1, pk, mine, step, bufs.flag)       # an empty range still clears the list header
+        _before_comm(buf, group)
         work = dist.all_gather_into_tensor(buf[k * world * pw: (k + 1) * world * pw], mine, group=group, async_op=True)
         if pending is not None:
             finish(*pending)
