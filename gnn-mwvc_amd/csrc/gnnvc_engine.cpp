@@ -159,12 +159,21 @@ struct gnnvc_engine {
     uint32_t thresh_f16 = 0xFFFFFFFFu;        // rows >= this go to k_long_f16 (>= long_thresh, the list's threshold)
     bool interleave = false;           // deal natural tiles round-robin (work is unevenly spread over the row range)
     bool sorted_wanted = false;        // decided per graph from the measured tile waste
-    bool sorted_valid = false;         // the cached order below matches (srt_lo, srt_hi) of the current graph
-    bool sorted_use = false;
-    uint32_t srt_lo = 0, srt_hi = 0, srt_n = 0;
+    // A few row ranges are cached: a vertex-partitioned caller alternates between its own rows and (for a replicated
+    // stage) the whole graph, or between the pieces of a pipelined stage — each range is sorted once per graph.
+    struct SortedRange {
+        bool valid = false, use = false;
+        uint32_t lo = 0, hi = 0, n = 0;
+        uint64_t stamp = 0;
+        DevBuf<uint32_t> vertex;
+        DevBuf<uint4> meta;
+    };
+    static constexpr int kSortedRanges = 6;
+    SortedRange srt[kSortedRanges];
+    int srt_cur = -1;                  // the entry ensure_sorted selected for the call in progress
+    uint64_t srt_clock = 0;
     double srt_waste = 0.0;
-    DevBuf<uint32_t> srt_vertex, srt_hist;
-    DevBuf<uint4> srt_meta;
+    DevBuf<uint32_t> srt_hist;
     DevBuf<unsigned long long> srt_sum;
 
     // long rows (degree >= long_thresh): one workgroup each, on aux_stream beside the tile kernel
@@ -424,8 +433,8 @@ int find_long(gnnvc_engine *e) {
     e->giant_thresh = 0xFFFFFFFFu;
     e->long_thresh = 0xFFFFFFFFu;
     e->thresh_f16 = 0xFFFFFFFFu;
-    e->sorted_valid = false;   // new graph: any cached tile order is stale
-    e->sorted_use = false;
+    for (auto &r : e->srt) r.valid = false;   // new graph: any cached tile order is stale
+    e->srt_cur = -1;
     const GraphDev &g = e->g;
     e->sorted_wanted = false;
     e->srt_waste = 0.0;
@@ -486,19 +495,34 @@ int find_long(gnnvc_engine *e) {
 // per-tile maxima) exceeds twice the useful work, tiles are formed from a degree-sorted list
 // instead.  Cached per row range; the scan over the degree classes runs on the host.
 int ensure_sorted(gnnvc_engine *e, uint32_t lo, uint32_t hi) {
-    if (e->sorted_valid && e->srt_lo == lo && e->srt_hi == hi) return GNNVC_OK;
-    e->sorted_valid = true;
-    e->sorted_use = false;
-    e->srt_lo = lo;
-    e->srt_hi = hi;
-    e->srt_n = 0;
+    int slot = -1, empty = -1, lru = 0;
+    for (int i = 0; i < gnnvc_engine::kSortedRanges; ++i) {
+        const auto &r = e->srt[i];
+        if (r.valid && r.lo == lo && r.hi == hi) slot = i;
+        if (!r.valid && empty < 0) empty = i;
+        if (r.valid && r.stamp < e->srt[lru].stamp) lru = i;
+    }
+    if (slot >= 0) {
+        e->srt[slot].stamp = ++e->srt_clock;
+        e->srt_cur = slot;
+        return GNNVC_OK;
+    }
+    const int victim = empty >= 0 ? empty : lru;   // an empty entry, else the least recently used one
+    gnnvc_engine::SortedRange &sr = e->srt[victim];
+    sr.valid = true;
+    sr.use = false;
+    sr.lo = lo;
+    sr.hi = hi;
+    sr.n = 0;
+    sr.stamp = ++e->srt_clock;
+    e->srt_cur = victim;
     const GraphDev &g = e->g;
     if (!e->sorted_wanted || hi <= lo || g.nnz == 0) return GNNVC_OK;
     const uint32_t lt = e->thresh_f16;
     const uint32_t bins = lt < 4096u ? lt + 1 : 4096u;
     HIP_TRY(e, e->srt_hist.reserve(bins));
-    HIP_TRY(e, e->srt_vertex.reserve(hi - lo));
-    HIP_TRY(e, e->srt_meta.reserve(hi - lo));
+    HIP_TRY(e, sr.vertex.reserve(hi - lo));
+    HIP_TRY(e, sr.meta.reserve(hi - lo));
     // the scan's host round trip goes through page-locked memory: an async copy to or from
     // pageable memory above a few KB pins it on the fly, which costs milliseconds the first time
     HIP_TRY(e, e->pin_small.reserve(2 * (size_t)bins));
@@ -512,11 +536,10 @@ int ensure_sorted(gnnvc_engine *e, uint32_t lo, uint32_t hi) {
         run += hist[d];
     }
     HIP_TRY(e, hipMemcpyAsync(e->srt_hist.p, start, bins * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(e, gnnvc::degree_scatter(g, lo, hi, lt, bins, e->srt_hist.p, e->srt_vertex.p,
-                                     e->srt_meta.p, e->stream));
+    HIP_TRY(e, gnnvc::degree_scatter(g, lo, hi, lt, bins, e->srt_hist.p, sr.vertex.p, sr.meta.p, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));   // `start` is read by the async copy above
-    e->srt_n = run;
-    e->sorted_use = true;
+    sr.n = run;
+    sr.use = true;
     return GNNVC_OK;
 }
 
@@ -765,6 +788,10 @@ int ensure_round_events(gnnvc_engine *e, size_t count) {
 int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float *in, float *out, float *logits,
               bool in_forward = false) {
     const bool longs = e->n_long > 0;
+    // An announcement (gnnvc_stage_input_ready) covers the calls for ITS stage that follow it.  A call for any other
+    // stage means the caller has moved on — the next forward has begun, or the announced buffer is about to be
+    // rewritten — and a call that writes into the announced buffer ends it too: the table must never outlive its input.
+    if (e->c4_prepared_stage != -1 && (stage != e->c4_prepared_stage || out == e->c4_prepared_in)) e->c4_prepared_stage = -1;
     // Producer side of the compact-table plan: inside a whole forward (engine-owned feature buffers nobody else
     // writes) the stage kernel that produces the next 16-wide stage's input also counts its non-zeros and writes
     // its compact rows, so that stage can skip its two passes over the input.  Only the VALU variants emit.
@@ -894,10 +921,10 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
         {   // degree-sorted tiles on skewed graphs (every stage; the list is cached per row range)
             int rc = ensure_sorted(e, lo, hi);
             if (rc) return rc;
-            if (e->sorted_use) {
-                so.n = e->srt_n;
-                so.vertex = e->srt_vertex.p;
-                so.meta = e->srt_meta.p;
+            if (e->srt_cur >= 0 && e->srt[e->srt_cur].use) {
+                so.n = e->srt[e->srt_cur].n;
+                so.vertex = e->srt[e->srt_cur].vertex.p;
+                so.meta = e->srt[e->srt_cur].meta.p;
                 sop = &so;
             }
         }
@@ -1085,7 +1112,8 @@ void gnnvc_destroy(gnnvc_engine *e) {
     e->gi_meta.release(); e->gi_off.release(); e->gi_slab.release(); e->gi_agg.release();
     e->pin_rowptr.release(); e->pin_col.release(); e->pin_w.release(); e->pin_nw.release();
     e->pin_small.release();
-    e->srt_vertex.release(); e->srt_hist.release(); e->srt_meta.release(); e->srt_sum.release();
+    for (auto &r : e->srt) { r.vertex.release(); r.meta.release(); }
+    e->srt_hist.release(); e->srt_sum.release();
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->aux_stream) { (void)hipStreamSynchronize(e->aux_stream); (void)hipStreamDestroy(e->aux_stream); }
@@ -1128,7 +1156,7 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "sorted_min_nnz") e->opt_sorted_min_nnz = value > 0 ? (uint64_t)value : 0;
     else if (k == "sorted_long_row_threshold") e->opt_sorted_long_thresh = value > 0 ? (uint32_t)value : 1;
     else if (k == "mfma_dense") e->opt_mfma = (value >= 0 && value <= 2) ? (int)value : 2;
-    else if (k == "sorted_tiles") { e->opt_sorted = value < 0 ? -1 : (value ? 1 : 0); e->sorted_valid = false; }
+    else if (k == "sorted_tiles") { e->opt_sorted = value < 0 ? -1 : (value ? 1 : 0); for (auto &r : e->srt) r.valid = false; }
     else return fail(e, GNNVC_ERR_INVALID, "unknown option '%s'", key);
     return GNNVC_OK;
 }
@@ -1821,15 +1849,20 @@ int gnnvc_sgemm(gnnvc_engine *e, int trans_a, int trans_b, uint32_t m, uint32_t 
     if (lda < a_cols || ldb < b_cols || ldc < n) return fail(e, GNNVC_ERR_INVALID, "leading dimension too small");
     int rc = use_device(e);
     if (rc) return rc;
+    // BLAS guarantees only (rows - 1) * ld + cols elements of a matrix with a padded leading dimension: copy exactly
+    // that much in either direction (the last row's padding is not the caller's memory)
+    const size_t a_elems = a_rows ? (a_rows - 1) * lda + a_cols : 0;
+    const size_t b_elems = b_rows ? (b_rows - 1) * ldb + b_cols : 0;
+    const size_t c_elems = (size_t)(m - 1) * ldc + n;
     DevBuf<float> dB;
-    HIP_TRY(e, dB.reserve(b_rows * ldb + 1));
-    if (b_rows && hipMemcpy(dB.p, B, b_rows * ldb * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    HIP_TRY(e, dB.reserve(b_elems + 1));
+    if (b_elems && hipMemcpy(dB.p, B, b_elems * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
         dB.release();
         return fail(e, GNNVC_ERR_DEVICE, "B upload failed");
     }
     struct Ctx { int ta, tb; uint32_t m, n, k, lda, ldb, ldc; float beta; const float *B; } ctx{
         trans_a, trans_b, m, n, k, lda, ldb, ldc, beta, dB.p};
-    rc = run_host_op(e, a_rows * lda, A, (size_t)m * ldc, C, true,
+    rc = run_host_op(e, a_elems, A, c_elems, C, true,
                      [](gnnvc_engine *en, const float *dA, float *dC, void *c) {
                          auto *x = (Ctx *)c;
                          return gnnvc::launch_sgemm(x->ta, x->tb, x->m, x->n, x->k, dA, x->lda, x->B, x->ldb,

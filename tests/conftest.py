@@ -13,6 +13,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: takes more than a few seconds on CPU")
 
 
+def pytest_report_header(config):
+    """Which prebuilt binaries (built in the container that has the reference sources, carried along git-ignored)
+    this run will find — the GPU CLI test fails without oracle/_ref/GNN_VC_hip, the link-level drop-in tests are
+    skipped without the reference sources."""
+    names = ["oracle/_ref/GNN_VC_hip", "oracle/_ref/ref_layers.so", "oracle/_ref/GNN_VC_dropin", "oracle/_ref/ref_parse.so",
+             "oracle/liboracle.so", "gnn-mwvc_amd/libgnnvc_hip.so", "gnn-mwvc_amd/libgnnvc_host.so"]
+    found = [n for n in names if (ROOT / n).exists()]
+    missing = [n for n in names if n not in found]
+    return [f"prebuilt binaries found: {', '.join(found) or 'none'}", f"prebuilt binaries missing: {', '.join(missing) or 'none'}"]
+
+
 @pytest.fixture(scope="session")
 def model_text():
     return (ROOT / "gnn-mwvc_amd" / "data" / "mwvc_model.txt").read_text()

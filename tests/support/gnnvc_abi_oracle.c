@@ -188,9 +188,25 @@ int gnnvc_sigmoid_forward(gnnvc_engine *e, size_t count, const float *in, float 
     return GNNVC_OK;
 }
 
+/* tools/make_golden_layers.py only: with a genuine cblas_sgemm installed here (dlopen'ed OpenBLAS), the products the
+ * reference's layer code asks dot() for go to THAT library exactly as src/matrix.cpp:112-121 would send them
+ * (row-major, no transposes, alpha 1, beta 0) — so the fixtures it writes do not depend on this repo's restatement
+ * of the product. */
+typedef void (*test_cblas_sgemm_fn)(int order, int ta, int tb, int M, int N, int K, float alpha, const float *A, int lda,
+                                    const float *B, int ldb, float beta, float *C, int ldc);
+static test_cblas_sgemm_fn g_test_cblas = 0;
+static unsigned long g_test_cblas_calls = 0;
+void gnnvc_test_set_cblas_sgemm(void *fn) { g_test_cblas = (test_cblas_sgemm_fn)fn; g_test_cblas_calls = 0; }
+unsigned long gnnvc_test_cblas_calls(void) { return g_test_cblas_calls; }
+
 int gnnvc_sgemm(gnnvc_engine *e, int ta, int tb, uint32_t m, uint32_t n, uint32_t k, const float *A,
                 uint32_t lda, const float *B, uint32_t ldb, float beta, float *C, uint32_t ldc) {
     (void)e;
+    if (g_test_cblas) {
+        g_test_cblas(101, ta ? 112 : 111, tb ? 112 : 111, (int)m, (int)n, (int)k, 1.0f, A, (int)lda, B, (int)ldb, beta, C, (int)ldc);
+        ++g_test_cblas_calls;
+        return GNNVC_OK;
+    }
     for (uint32_t i = 0; i < m; i++)
         for (uint32_t j = 0; j < n; j++) {
             float acc = 0.0f;

@@ -209,9 +209,47 @@ def test_sgemm_seam(engine):
     assert np.array_equal(bits(engine.sgemm(A, B)), bits(want))
     assert np.array_equal(bits(engine.sgemm(np.ascontiguousarray(A.T), B, trans_a=True)), bits(want))
     assert np.array_equal(bits(engine.sgemm(A, np.ascontiguousarray(B.T), trans_b=True)), bits(want))
+    # beta != 0 (training only in the reference; the inference path passes 0): the documented contract is
+    # fma(beta, C_old, chain) — oracle_sgemm restates it; bitwise, with and without transposes, odd betas
     C0 = rng.normal(size=(37, 23)).astype(np.float32)
-    got = engine.sgemm(A, B, C_in=C0, beta=0.5)
-    np.testing.assert_allclose(got, want + 0.5 * C0, rtol=1e-6, atol=1e-6)
+    for beta in (0.5, 1.0, -1.7, 0.3):
+        assert np.array_equal(bits(engine.sgemm(A, B, C_in=C0, beta=beta)), bits(oracle_py.sgemm(A, B, C0, beta)))
+        assert np.array_equal(bits(engine.sgemm(np.ascontiguousarray(A.T), np.ascontiguousarray(B.T), C_in=C0, beta=beta,
+                                                trans_a=True, trans_b=True)),
+                              bits(oracle_py.sgemm(np.ascontiguousarray(A.T), np.ascontiguousarray(B.T), C0, beta, True, True)))
+    assert np.array_equal(bits(oracle_py.sgemm(A, B)), bits(want))
+
+
+@pytest.mark.parametrize("name", ["ex3", "er4k", "hub2k"])
+def test_layer_boundary_fixtures_on_the_gpu(engine, golden_dir, name):
+    """The stage boundaries of the fused forward (h1, h2, logits) against tests/golden/manifest_layers.json:
+    outputs of the reference's own layer code with its products in genuine OpenBLAS."""
+    import torch
+    man = json.loads((golden_dir / "manifest_layers.json").read_text())
+    spec = man["graphs"][name]
+    p = spec["graph"]
+    g = (gg.from_edge_list(p["n"], p["edges"], p["weights"]) if p["kind"] == "edge_list" else
+         gg.erdos_renyi(p["n"], p["m"], p["seed"]) if p["kind"] == "erdos_renyi" else
+         gg.hub_graph(p["n"], p["m"], p["hubs"], p["hub_degree"], seed=p["seed"]))
+    assert gg.metis_md5(g) == spec["metis_md5"]
+    engine.set_weight_scale(g.ws)
+    engine.upload_graph(g)
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(g.x()).to(dev)
+    h1 = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+    h2 = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+    sc = torch.zeros(g.n, dtype=torch.float32, device=dev)
+    lg = torch.zeros(g.n, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    engine.stage_forward_device(0, 0, g.n, x.data_ptr(), h1.data_ptr())
+    engine.stage_forward_device(1, 0, g.n, h1.data_ptr(), h2.data_ptr())
+    engine.stage_forward_device(2, 0, g.n, h2.data_ptr(), sc.data_ptr(), lg.data_ptr())
+    engine.synchronize()
+    gold = {k: np.fromfile(golden_dir / f["file"], dtype=np.float32).reshape(f["shape"]) for k, f in spec["files"].items()}
+    assert np.array_equal(bits(h1[:-1].cpu().numpy()), bits(gold["h1"]))
+    assert np.array_equal(bits(h2[:-1].cpu().numpy()), bits(gold["h2"]))
+    assert np.array_equal(bits(lg.cpu().numpy()), bits(gold["logits"][:, 0]))
+    assert ulp(sc.cpu().numpy(), gold["scores2"][:, 0]).max() <= 1
 
 
 def test_unfused_model_path(model_text, oracle_model):
@@ -1038,6 +1076,43 @@ def test_sliced_engines_equal_the_whole_graph(model_text, oracle_model, maker, w
     finally:
         for e in engines:
             e.close()
+
+
+def test_stage_input_announcement_does_not_outlive_its_input(model_text, oracle_model):
+    """gnnvc_stage_input_ready is matched on (stage, buffer address, row range); the contents of that buffer change
+    from one forward to the next.  A caller that announces in one forward and not in the next (same buffers) must
+    not be served the old table: any call for another stage ends the announcement."""
+    import gnn_mwvc_amd as G
+    import torch
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_option("blocked_min_n", 0)      # let the compact-table plan apply to a small graph
+        e.set_option("compact_gather", 2)
+        g = _dense_graph(6000, 24, 71)
+        e.set_weight_scale(g.ws)
+        oracle_model.set_weight_scale(g.ws)
+        e.upload_graph(g)
+        dev = torch.device("cuda:0")
+        h1 = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+        h2 = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+        rng = np.random.default_rng(5)
+        outs = []
+        for rnd in range(2):
+            x = rng.integers(20, 121, g.n).astype(np.float32) / np.float32(g.ws)     # a different input every forward
+            xt = torch.from_numpy(x).to(dev)
+            torch.cuda.synchronize()
+            e.stage_forward_device(0, 0, g.n, xt.data_ptr(), h1.data_ptr())
+            if rnd == 0:
+                e.stage_input_ready(1, h1.data_ptr(), 0, g.n)     # announced in the first forward only
+                assert e.get_info("compact_gather_active") == 1   # (the plan really is in force: the test is not vacuous)
+            e.stage_forward_device(1, 0, g.n, h1.data_ptr(), h2.data_ptr())
+            e.synchronize()
+            want = oracle_model.predict(g, x.reshape(-1, 1), stop_after=13)
+            assert np.array_equal(bits(h2[:-1].cpu().numpy()), bits(want)), rnd
+            outs.append(h2[:-1].cpu().numpy().copy())
+        assert not np.array_equal(outs[0], outs[1])
+    finally:
+        e.close()
 
 
 # ---------------------------------------------------------------- dense layers: MFMA vs VALU

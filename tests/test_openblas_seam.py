@@ -69,3 +69,35 @@ def test_sgemm_is_sequential_fma_chain(sgemm, oracle_model, threads):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (k, n)
         total += got.size
     assert total > 1_000_000
+
+
+def test_beta_nonzero_has_no_single_openblas_behaviour(sgemm):
+    """dot()'s `beta` (reference src/matrix.cpp:106-122) is never non-zero on the inference path
+    (src/gnn_inference.cpp:21 passes 0).  Recorded here because include/gnnvc.h documents gnnvc_sgemm's
+    beta != 0 result as fma(beta, C_old, chain): OpenBLAS 0.3.28 itself rounds beta * C in TWO ways depending on the
+    problem size — its small-matrix kernels fuse it into the final add (the form the engine and oracle_sgemm use),
+    its blocked path scales C first and then adds — so neither form is "the" third-party behaviour."""
+    fn, set_threads = sgemm
+    if set_threads is not None:
+        set_threads(1)
+    rng = np.random.default_rng(11)
+    seen = set()
+    for (m, n, k) in [(1000, 32, 35), (37, 16, 32), (2000, 16, 32), (24, 24, 24)]:
+        A = rng.uniform(-2, 2, (m, k)).astype(np.float32)
+        B = rng.uniform(-2, 2, (k, n)).astype(np.float32)
+        C0 = rng.uniform(-2, 2, (m, n)).astype(np.float32)
+        for beta in (-1.7, 0.3):
+            c = C0.copy()
+            fn(101, 111, 111, m, n, k, 1.0, A.ctypes.data, k, B.ctypes.data, n, beta, c.ctypes.data, n)
+            chain = oracle_py.sgemm(A, B)                                   # beta = 0: the sequential-k chain
+            fused = oracle_py.sgemm(A, B, C0, beta)                         # fma(beta, C, chain)
+            scaled = ((np.float32(beta) * C0).astype(np.float32) + chain).astype(np.float32)   # RN(RN(beta C) + chain)
+            is_fused = np.array_equal(c.view(np.uint32), fused.view(np.uint32))
+            is_scaled = np.array_equal(c.view(np.uint32), scaled.view(np.uint32))
+            assert is_fused or is_scaled, (m, n, k, beta)
+            seen.add("fused" if is_fused else "scaled")
+        # beta = 1 and 0.5 (exact products) agree in both forms and with OpenBLAS
+        c = C0.copy()
+        fn(101, 111, 111, m, n, k, 1.0, A.ctypes.data, k, B.ctypes.data, n, 0.5, c.ctypes.data, n)
+        assert np.array_equal(c.view(np.uint32), oracle_py.sgemm(A, B, C0, 0.5).view(np.uint32))
+    assert seen == {"fused", "scaled"}, seen

@@ -85,6 +85,38 @@ def test_hub_graph_bitwise(oracle_model, golden_dir, manifest):
     assert mism <= 16
 
 
+def _layer_graph(spec):
+    p = spec["graph"]
+    if p["kind"] == "edge_list":
+        return gg.from_edge_list(p["n"], p["edges"], p["weights"])
+    if p["kind"] == "erdos_renyi":
+        return gg.erdos_renyi(p["n"], p["m"], p["seed"])
+    return gg.hub_graph(p["n"], p["m"], p["hubs"], p["hub_degree"], seed=p["seed"])
+
+
+@pytest.mark.parametrize("name", ["ex3", "er4k", "hub2k"])
+def test_layer_boundary_fixtures(oracle_model, golden_dir, name):
+    """Activations after the first and second fused block (N x 16), logits and scores, written by
+    tools/make_golden_layers.py from the reference's own layer code with its products in genuine OpenBLAS
+    (tests/golden/manifest_layers.json): the oracle reproduces every one bit for bit."""
+    man = json.loads((golden_dir / "manifest_layers.json").read_text())
+    spec = man["graphs"][name]
+    g = _layer_graph(spec)
+    assert gg.metis_md5(g) == spec["metis_md5"] and g.ws == spec["ws"]
+    oracle_model.set_weight_scale(g.ws)
+    for what, f in spec["files"].items():
+        raw = (golden_dir / f["file"]).read_bytes()
+        assert hashlib.md5(raw).hexdigest() == f["md5"]
+        gold = np.frombuffer(raw, dtype=np.float32).reshape(f["shape"])
+        got = oracle_model.predict(g, g.x(), stop_after=f["after_layer_index"])
+        if what == "scores2":     # (host expf: see _check_scores)
+            assert _ulp_diff(np.ascontiguousarray(got), gold).max() <= 1
+        else:
+            assert np.array_equal(got.view(np.uint32), gold.view(np.uint32)), what
+    # and the committed recipe reproduced the survey-time score files when it ran
+    assert all(v["equals_recorded_md5"] for v in man["reproduced_survey_scores"].values())
+
+
 def test_graph_layer_column_layout():
     """The F+1..F+3 quirk (reference src/gnn_inference.cpp:37-40), on the survey's
     probe input: in(u, j) = (u+1)*10 + j on the README graph, ws = 20."""
