@@ -2639,8 +2639,11 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
                            sorted ? so->vertex : nullptr, sorted ? reinterpret_cast<const uint4 *>(so->meta) : nullptr,
                            sorted ? so->n : 0u);
         break;
+#ifndef GNNVC_GATHER_S
+#define GNNVC_GATHER_S 2   // neighbour rows in flight per vertex in the 16-wide tile kernel (x 4 vertices per quad)
+#endif
 #define GNNVC_LAUNCH_F16(N2_, N3_, SIG_, MF_, SRT_, LG_)                                              \
-    GNNVC_LAUNCH((k_stage_f16<32, N2_, N3_, SIG_, 2, MF_, SRT_>), grid, block, 0, stream, g, ws, in4, out, \
+    GNNVC_LAUNCH((k_stage_f16<32, N2_, N3_, SIG_, GNNVC_GATHER_S, MF_, SRT_>), grid, block, 0, stream, g, ws, in4, out, \
                        LG_, P, row_lo, row_hi, long_thresh, sorted ? so->vertex : nullptr,                \
                        sorted ? so->meta : nullptr, sorted ? so->n : 0u, il,                              \
                        (const float4 *)nullptr, (sorted || !acc4) ? nullptr : c4desc, (const float4 *)nullptr,           \

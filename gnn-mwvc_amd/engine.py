@@ -7,13 +7,15 @@ is present, construction raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import pathlib
 import subprocess
 
 import numpy as np
 
 _PKG = pathlib.Path(__file__).resolve().parent
-_LIB = _PKG / "libgnnvc_hip.so"
+# GNNVC_LIBRARY: another build of the same library (A/B experiments with compile-time variants); default: the in-tree one
+_LIB = pathlib.Path(os.environ["GNNVC_LIBRARY"]).resolve() if os.environ.get("GNNVC_LIBRARY") else _PKG / "libgnnvc_hip.so"
 
 # every symbol include/gnnvc.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [

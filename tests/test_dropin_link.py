@@ -187,3 +187,23 @@ def test_cli_er100k_identical_cover(built, manifest, golden_dir, tmp_path, binar
     assert np.array_equal(cover, gold)
     # identical final vertex-cover weight on this integer-weighted graph
     assert int(g.w[cover == 1].astype(np.int64).sum()) == spec["cli"]["final_cost"]
+
+
+def test_fast_io_driver_is_the_same_program(built, tmp_path):
+    """oracle/ref_driver_fastio.cpp: the reference's driver with this repo's METIS reader behind parse_graph and
+    unflushed result writes, against the plain drop-in: same stdout cost fields, byte-identical
+    result files."""
+    (tmp_path / "ex3.graph").write_text("3 2 10\n15 3\n15 3\n20 1 2\n")
+    g = gg.erdos_renyi(30000, 150000, 13)
+    (tmp_path / "g.graph").write_text(gg.metis_text(g))
+    for name in ("ex3", "g"):
+        res = []
+        for binary in ("GNN_VC_dropin", "GNN_VC_dropin_fastio"):
+            out = tmp_path / f"{name}.{binary}.out"
+            r = subprocess.run([str(built / binary), str(tmp_path / f"{name}.graph"), str(out), "0", "-1", "0"],
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-1000:]
+            f = r.stdout.strip().split(",")
+            res.append((f[0], f[1], f[2], out.read_bytes()))     # name, cost, best seen; (the last field is a time)
+        assert res[0] == res[1], name
+    assert len(res[0][3]) == 2 * g.n

@@ -112,3 +112,20 @@ def test_cli_er1m_identical_result_file(manifest, tmp_path):
     assert fields[0] == "er1m" and int(fields[1]) == spec["cli"]["final_cost"]
     raw = (tmp_path / "er1m.out").read_bytes()
     assert hashlib.md5(raw).hexdigest() == spec["cli"]["result_md5"]
+
+
+def test_cli_fast_io_driver_identical_result(manifest, tmp_path):
+    """The same run through oracle/_ref/GNN_VC_hip_fastio (this repo's METIS reader behind parse_graph, result file
+    written without a flush per line — SURVEY.md 8 f-4): byte-identical result file."""
+    fast = CLI.with_name("GNN_VC_hip_fastio")
+    if not fast.exists():
+        pytest.fail(f"{fast} is missing (built by `make -C oracle ref` next to GNN_VC_hip)")
+    spec = manifest["er100k"]
+    g = _graph(spec)
+    (tmp_path / "er100k.graph").write_text(gg.metis_text(g))
+    r = subprocess.run([str(fast), str(tmp_path / "er100k.graph"), str(tmp_path / "er100k.out"), "0", "-1", "0"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    fields = r.stdout.strip().split(",")
+    assert fields[0] == "er100k" and int(fields[1]) == spec["cli"]["final_cost"]
+    assert hashlib.md5((tmp_path / "er100k.out").read_bytes()).hexdigest() == spec["cli"]["result_md5"]

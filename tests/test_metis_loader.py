@@ -77,6 +77,28 @@ def test_errors(ours, tmp_path):
     assert _load(ours, "gnnvc_host_load_metis", tmp_path / "missing.graph", C.c_uint(1)) is None
 
 
+def test_result_writer_and_metis_writer(ours, tmp_path):
+    """host/result_writer.cpp: the reference CLI's result file (N lines of 0 / 1, src/GNN_VC.cpp:388-391) and its input
+    format (README.md:49-62) written in one go; byte-identical to the line-by-line forms."""
+    ours.gnnvc_host_write_cover.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
+    ours.gnnvc_host_write_metis.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(4)
+    for n in (0, 1, 5, 100_003):
+        cover = (rng.random(n) < 0.4).astype(np.uint8)
+        path = tmp_path / "res.out"
+        assert ours.gnnvc_host_write_cover(str(path).encode(), cover.ctypes.data if n else None, n) == 0
+        assert path.read_bytes() == "".join(f"{int(v)}\n" for v in cover).encode()    # what `os << (in ? 1 : 0) << endl` writes
+    assert ours.gnnvc_host_write_cover(str(tmp_path / "no" / "dir.out").encode(), None, 0) != 0
+    for g in (gg.erdos_renyi(3000, 15000, 1), gg.hub_graph(5000, 8000, 2, 3000, seed=3),
+              gg.from_edge_list(7, [(0, 1), (5, 6)], [20, 30, 40, 50, 60, 70, 80])):
+        rp = np.ascontiguousarray(g.rowptr, dtype=np.uint64)
+        path = tmp_path / "w.graph"
+        assert ours.gnnvc_host_write_metis(str(path).encode(), g.n, rp.ctypes.data, g.col.ctypes.data, g.w.ctypes.data) == 0
+        assert path.read_text() == gg.metis_text(g)
+        n, w, pairs = _load(ours, "gnnvc_host_load_metis", path, C.c_uint(4))           # and the reader takes it back
+        assert n == g.n and np.array_equal(w, g.w) and np.array_equal(pairs, _expected(g))
+
+
 @pytest.mark.skipif(not REF.exists(), reason="reference sources not mounted here")
 def test_same_result_as_reference_loader(ours, tmp_path):
     r = subprocess.run(["make", "-C", str(ROOT / "oracle"), "_ref/ref_parse.so"], capture_output=True, text=True)
