@@ -2639,11 +2639,18 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
                            sorted ? so->vertex : nullptr, sorted ? reinterpret_cast<const uint4 *>(so->meta) : nullptr,
                            sorted ? so->n : 0u);
         break;
+// neighbour rows in flight per vertex in the 16-wide tile kernel (x 4 vertices per quad).  Natural tiles: 2.  Degree-sorted
+// tiles (skewed graphs: rows of a tile have similar, mostly larger degrees): 3 — measured R-MAT-22 6.71 -> 6.53 ms, power-law
+// 2.00 -> 1.82 ms per forward; 4 costs a wave per SIMD (power-law stage 1: 0.75 -> 1.6 ms) and natural tiles gain nothing
+// from 3 (metric graph, plain kernels: 9.73 vs 9.75 ms).
 #ifndef GNNVC_GATHER_S
-#define GNNVC_GATHER_S 2   // neighbour rows in flight per vertex in the 16-wide tile kernel (x 4 vertices per quad)
+#define GNNVC_GATHER_S 2
+#endif
+#ifndef GNNVC_GATHER_S_SORTED
+#define GNNVC_GATHER_S_SORTED 3
 #endif
 #define GNNVC_LAUNCH_F16(N2_, N3_, SIG_, MF_, SRT_, LG_)                                              \
-    GNNVC_LAUNCH((k_stage_f16<32, N2_, N3_, SIG_, GNNVC_GATHER_S, MF_, SRT_>), grid, block, 0, stream, g, ws, in4, out, \
+    GNNVC_LAUNCH((k_stage_f16<32, N2_, N3_, SIG_, (SRT_) ? GNNVC_GATHER_S_SORTED : GNNVC_GATHER_S, MF_, SRT_>), grid, block, 0, stream, g, ws, in4, out, \
                        LG_, P, row_lo, row_hi, long_thresh, sorted ? so->vertex : nullptr,                \
                        sorted ? so->meta : nullptr, sorted ? so->n : 0u, il,                              \
                        (const float4 *)nullptr, (sorted || !acc4) ? nullptr : c4desc, (const float4 *)nullptr,           \

@@ -400,7 +400,7 @@ def plan_replication(world: int, num_stages: int, live: "dict | None" = None) ->
     those stages are partitioned.  Stage 0 stays replicated up to 4 ranks: computed in full it takes ~1.1 ms on
     the metric graph (its input x is replicated anyway, and a whole-range call runs the LDS-table plan), which is
     less than a rank's share in pipelined pieces plus the first exchange (measured per-rank compute of the pieces
-    alone: 1.43 ms at P = 2, 0.91 ms at P = 4, 0.61 ms at P = 8 — tools/experiments/pieces_check.py)."""
+    alone: 1.43 ms at P = 2, 0.91 ms at P = 4, 0.61 ms at P = 8 — scratch/experiments/pieces_check.py)."""
     if live is not None and all(live.get(st) is not None and live[st].bytes_per_row <= 34.0
                                 for st in range(num_stages - 1)):
         return {0} if (1 < world <= 4 and num_stages > 1) else set()

@@ -2,7 +2,7 @@
 
 Runs oracle/_ref/GNN_VC_hip (reference driver + this repo's host mirror +
 libgnnvc_hip.so) with GNNVC_TRACE=1 on a generated graph and prints the trace.
-usage: python tools/experiments/cli_trace.py [n] [m] [seed]
+usage: python scratch/experiments/cli_trace.py [n] [m] [seed]
 """
 import pathlib
 import subprocess

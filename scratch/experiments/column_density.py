@@ -1,5 +1,5 @@
 """Non-zero density of every feature column after stages 0 and 1 (GPU box): the premise of the
-compressed inter-GPU exchange.  usage: python tools/experiments/column_density.py [workload ...]"""
+compressed inter-GPU exchange.  usage: python scratch/experiments/column_density.py [workload ...]"""
 import sys
 
 import torch

@@ -1,7 +1,7 @@
 """f-4 at the size it exists for: the metric graph (Erdős–Rényi 10 M vertices / 100 M edges) as a ~1.5 GB METIS text file —
 this repo's reader (host/metis_loader.cpp) against the reference's parse_graph (src/GNN_VC.cpp:34-91, through
 oracle/_ref/ref_parse.so), and the two result-file writers at 10 M lines.  Build container, CPU only; needs ~25 GB of RAM.
-python tools/experiments/metis_timing.py [n] [m]"""
+python scratch/experiments/metis_timing.py [n] [m]"""
 import ctypes as C
 import pathlib
 import subprocess

@@ -1,5 +1,5 @@
 """One process, no collectives: run every fused stage in the row pieces a P-rank pipelined run would use (plans
-active) and compare with the whole-range result.  usage: python tools/experiments/pieces_check.py [workload] [P] [chunks]"""
+active) and compare with the whole-range result.  usage: python scratch/experiments/pieces_check.py [workload] [P] [chunks]"""
 import sys
 import time
 

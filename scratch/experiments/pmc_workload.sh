@@ -1,4 +1,4 @@
-# PMC pass over bench.py on a workload (GPU box): bash tools/experiments/pmc_workload.sh rmat22 "<counters>" [bench args]
+# PMC pass over bench.py on a workload (GPU box): bash scratch/experiments/pmc_workload.sh rmat22 "<counters>" [bench args]
 set -u
 w=$1; ctr=$2; shift 2
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"

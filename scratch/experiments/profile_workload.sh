@@ -1,4 +1,4 @@
-# rocprofv3 kernel stats of bench.py on another workload (GPU box): bash tools/experiments/profile_workload.sh rmat22 [extra bench args]
+# rocprofv3 kernel stats of bench.py on another workload (GPU box): bash scratch/experiments/profile_workload.sh rmat22 [extra bench args]
 set -u
 w=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"

@@ -1,5 +1,5 @@
 """Two engines, each on its slice (or on the whole graph with row ranges) of a bench workload, against one whole-graph forward.
-python tools/experiments/slice_check.py rmat20 2 nnz"""
+python scratch/experiments/slice_check.py rmat20 2 nnz"""
 import sys, pathlib
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 import torch

@@ -1,4 +1,4 @@
-"""Write an Erdős–Rényi METIS file: python tools/experiments/write_er_metis.py n m seed path"""
+"""Write an Erdős–Rényi METIS file: python scratch/experiments/write_er_metis.py n m seed path"""
 import sys
 sys.path.insert(0, ".")
 from tools import graphgen as gg  # noqa: E402
