@@ -223,6 +223,11 @@ int fail(gnnvc_engine *e, int code, const char *fmt, ...) {
                         "%s: %s", #call, hipGetErrorString(rc_));                          \
     } while (0)
 
+int hip_rc(gnnvc_engine *e, hipError_t rc) {
+    if (rc == hipSuccess) return GNNVC_OK;
+    return fail(e, rc == hipErrorOutOfMemory ? GNNVC_ERR_NOMEM : GNNVC_ERR_DEVICE, "%s", hipGetErrorString(rc));
+}
+
 // ---- model text ------------------------------------------------------------
 struct Cursor {
     const char *p, *end;
@@ -785,9 +790,34 @@ int ensure_round_events(gnnvc_engine *e, size_t count) {
     return GNNVC_OK;
 }
 
-int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float *in, float *out, float *logits,
-              bool in_forward = false) {
+// ---------------------------------------------------------------- one stage call = plan selection, then launches
+//
+// choose_stage  decides WHAT a call runs: which of the per-graph plans serves the neighbour sums (building a plan the
+//               first time it is due), whether the previous stage kernel of this forward already left the column
+//               statistics, whether this stage's kernel produces them for the next one, sorted or natural tiles.
+//               It launches nothing.
+// launch_side_rows / launch_main  put the chosen kernels on the streams.  A new plan variant adds an enumerator, its
+//               eligibility rule in choose_stage and its launches in launch_main.
+struct StageChoice {
+    enum Sums {
+        kGather,            // the tile kernel gathers full rows itself (always correct; the fallback of every plan)
+        kLdsTable,          // F = 1: byte table in LDS (k_lt_agg), the tile kernel only runs the dense layers
+        kBlocked,           // F = 1: column-blocked partial sums (k_blk_accumulate)
+        kCompactPrepared,   // F = 16: compact table written by gnnvc_stage_input_ready for exactly this input
+        kCompactWhole       // F = 16: compact table over the whole graph, decided per forward on the device
+    } sums = kGather;
+    bool mfma = false;          // dense layers of the gathering kernel on the matrix cores
+    bool fused_counts = false;  // kCompactWhole: the producing stage kernel of this forward left counts (and perhaps the table)
+    bool rounds = false;        // kCompactWhole, last stage: sums one round at a time, dense kernel of round k under round k + 1
+    bool emit = false;          // this stage's VALU epilogue counts / compacts its output rows for stage `stage + 1`
+    uint32_t long_thresh = 0xFFFFFFFFu;   // rows of at least this degree belong to the side streams
+    gnnvc::SortedOrder sorted;  // n != 0: tiles from the degree-sorted list of this row range
+};
+
+int choose_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float *in, const float *out, bool in_forward,
+                 StageChoice &c) {
     const bool longs = e->n_long > 0;
+    const gnnvc::StagePlan &sp = e->stages[stage];
     // An announcement (gnnvc_stage_input_ready) covers the calls for ITS stage that follow it.  A call for any other
     // stage means the caller has moved on — the next forward has begun, or the announced buffer is about to be
     // rewritten — and a call that writes into the announced buffer ends it too: the table must never outlive its input.
@@ -797,175 +827,195 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
     // its compact rows, so that stage can skip its two passes over the input.  Only the VALU variants emit.
     const int fused_in = in_forward ? e->c4_fused_for : -1;   // is THIS stage's input covered by the previous kernel?
     e->c4_fused_for = -1;
-    gnnvc::EmitArgs emit;
-    const size_t ns_ = e->stages.size();
     const bool may_emit = in_forward && e->c4_ready && !e->c4_range_mode && e->c4_base == 0 && e->c4_end == e->g.n && !longs &&
-                          (size_t)stage + 1 < ns_ && e->stages[stage + 1].f == 16 && lo == 0 && hi == e->g.n && e->opt_mfma != 1;
-    const uint32_t thr = (e->stages[stage].f == 16) ? e->thresh_f16 : e->long_thresh;   // this stage's long-row threshold
-    if (longs) {   // fork: the long rows of this stage run beside the tile kernel
-        const bool side = e->opt_side_streams != 0;
-        hipStream_t s_long = side ? e->aux_stream : e->stream, s_giant = side ? e->giant_stream : e->stream;
-        if (side) {
-            HIP_TRY(e, hipEventRecord(e->ev_fork, e->stream));
-            HIP_TRY(e, hipStreamWaitEvent(e->aux_stream, e->ev_fork, 0));
-        }
-        if (e->n_giant) {   // the heaviest rows: beside the tile kernel AND beside the other long rows
-            if (side) HIP_TRY(e, hipStreamWaitEvent(e->giant_stream, e->ev_fork, 0));
-            gnnvc::GiantRows gr;
-            gr.n = e->n_giant;
-            gr.blocks = e->giant_blocks;
-            gr.meta = e->gi_meta.p;
-            gr.off = e->gi_off.p;
-            gr.slab = e->gi_slab.p;
-            gr.agg = e->gi_agg.p;
-            HIP_TRY(e, gnnvc::launch_giant_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi, gr,
-                                                 e->opt_hub_mode == 1, s_giant));
-            if (side) HIP_TRY(e, hipEventRecord(e->ev_giant, e->giant_stream));
-        }
-        if (e->n_giant < e->n_long)
-            HIP_TRY(e, gnnvc::launch_long_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi,
-                                                e->long_list.p, e->n_long, thr, e->giant_thresh, s_long));
-        if (side) HIP_TRY(e, hipEventRecord(e->ev_join, e->aux_stream));
-    }
-    // The LDS-table plan works in chunks of ~19.5 K rows, one workgroup each: a call that covers fewer than
-    // three quarters of a GPU's worth of chunks (the pieces of a pipelined multi-GPU run) would leave most CUs
-    // idle for the time one chunk takes — such calls use the column-blocked plan instead.
-    bool lt_fits = false;
+                          (size_t)stage + 1 < e->stages.size() && e->stages[stage + 1].f == 16 && lo == 0 && hi == e->g.n &&
+                          e->opt_mfma != 1;
+    c.long_thresh = (sp.f == 16) ? e->thresh_f16 : e->long_thresh;
+    c.mfma = e->opt_mfma == 1 || (e->opt_mfma == 2 && sp.f == 16);
     if (stage == 0) {
+        // The LDS-table plan works in chunks of ~19.5 K rows, one workgroup each: a call that covers fewer than
+        // three quarters of a GPU's worth of chunks (the pieces of a pipelined multi-GPU run) would leave most CUs
+        // idle for the time one chunk takes — such calls use the column-blocked plan instead.
         if (e->graph_uses >= 1 && !e->lt_tried) {
             int rc = build_lds_table(e);
             if (rc) return rc;
         }
-        lt_fits = e->lt_ready && hi > lo && ((hi - 1) / e->lt_rows - lo / e->lt_rows + 1) >= 192u;
+        const bool lt_fits = e->lt_ready && hi > lo && ((hi - 1) / e->lt_rows - lo / e->lt_rows + 1) >= 192u;
         if (e->graph_uses >= 1 && !lt_fits && !e->blocked_tried) {
             int rc = build_blocked(e);
             if (rc) return rc;
         }
         ++e->graph_uses;
+        c.sums = lt_fits ? StageChoice::kLdsTable : (e->blocked_ready ? StageChoice::kBlocked : StageChoice::kGather);
+        c.emit = may_emit;
+        if (c.sums != StageChoice::kGather) return GNNVC_OK;   // (those two bring their own tile order)
+    } else if (sp.f == 16) {
+        if (!e->c4_range_mode && e->graph_uses >= 2 && !e->c4_tried) {
+            int rc = build_compact(e);
+            if (rc) return rc;
+        }
+        const bool whole_plan = e->c4_ready && e->c4_base == 0 && e->c4_end == e->g.n;
+        const bool prepared = e->c4_ready && e->c4_prepared_stage == stage && e->c4_prepared_in == in &&
+                              lo >= e->c4_base && hi <= e->c4_end && hi > lo;
+        if (prepared && !longs) {
+            // gnnvc_stage_input_ready wrote the table for this input: any call that fills at least half the
+            // GPU with chunks takes the sums from it (smaller ones would leave most CUs idle for a chunk's time)
+            const uint32_t nchunks = (hi - 1 - e->c4_base) / e->c4_rows - (lo - e->c4_base) / e->c4_rows + 1;
+            if (nchunks >= 128u) c.sums = StageChoice::kCompactPrepared;
+        } else if (!e->c4_range_mode && whole_plan && !longs && (uint64_t)(hi - lo) * 2 >= e->g.n) {
+            // worth its fixed cost (count + compact the whole input) only when this call covers most of the rows
+            c.sums = StageChoice::kCompactWhole;
+            c.fused_counts = fused_in == stage;
+            // Last stage: k_c4_agg is a persistent grid that holds nearly all LDS of its CUs but leaves most VALU
+            // cycles idle, and the dense-only sigmoid kernel that follows is VALU-bound and needs no LDS.  So the sums
+            // are launched one round (256 chunks) at a time and the dense kernel of round k goes to the aux stream,
+            // under the sums of round k + 1.  Metric graph: 1.71 -> 1.58 ms.  (Not for the feature stages: their dense
+            // kernels store 64-byte rows and slow the co-running sums by more than is gained.)
+            c.rounds = e->opt_overlap && sp.variant == 2 && e->opt_mfma != 1;
+            c.emit = may_emit;   // this stage's own (aggregate-only, VALU) kernel produces for the next one
+        }
     }
-    if (stage == 0 && may_emit) {
+    // degree-sorted tiles on skewed graphs (every stage; the list is cached per row range)
+    int rc = ensure_sorted(e, lo, hi);
+    if (rc) return rc;
+    if (e->srt_cur >= 0 && e->srt[e->srt_cur].use) {
+        c.sorted.n = e->srt[e->srt_cur].n;
+        c.sorted.vertex = e->srt[e->srt_cur].vertex.p;
+        c.sorted.meta = e->srt[e->srt_cur].meta.p;
+        c.rounds = false;   // (the plan forced onto a graph with sorted tiles: the gathering kernel does the stage)
+    }
+    return GNNVC_OK;
+}
+
+// fork: the long (and giant) rows of this stage beside the tile kernel
+int launch_side_rows(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float *in, float *out, float *logits,
+                     uint32_t thr) {
+    const bool side = e->opt_side_streams != 0;
+    hipStream_t s_long = side ? e->aux_stream : e->stream, s_giant = side ? e->giant_stream : e->stream;
+    if (side) {
+        HIP_TRY(e, hipEventRecord(e->ev_fork, e->stream));
+        HIP_TRY(e, hipStreamWaitEvent(e->aux_stream, e->ev_fork, 0));
+    }
+    if (e->n_giant) {   // the heaviest rows: beside the tile kernel AND beside the other long rows
+        if (side) HIP_TRY(e, hipStreamWaitEvent(e->giant_stream, e->ev_fork, 0));
+        gnnvc::GiantRows gr;
+        gr.n = e->n_giant;
+        gr.blocks = e->giant_blocks;
+        gr.meta = e->gi_meta.p;
+        gr.off = e->gi_off.p;
+        gr.slab = e->gi_slab.p;
+        gr.agg = e->gi_agg.p;
+        HIP_TRY(e, gnnvc::launch_giant_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi, gr,
+                                             e->opt_hub_mode == 1, s_giant));
+        if (side) HIP_TRY(e, hipEventRecord(e->ev_giant, e->giant_stream));
+    }
+    if (e->n_giant < e->n_long)
+        HIP_TRY(e, gnnvc::launch_long_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi,
+                                            e->long_list.p, e->n_long, thr, e->giant_thresh, s_long));
+    if (side) HIP_TRY(e, hipEventRecord(e->ev_join, e->aux_stream));
+    return GNNVC_OK;
+}
+
+int launch_main(gnnvc_engine *e, const StageChoice &c, int stage, uint32_t lo, uint32_t hi, const float *in, float *out,
+                float *logits) {
+    const gnnvc::StagePlan &sp = e->stages[stage];
+    gnnvc::EmitArgs emit;
+    // (the counters are zeroed only AFTER this stage's own k_c4_choose has read what the previous stage kernel left in them)
+    auto arm_emit = [&]() -> int {
+        if (!c.emit) return GNNVC_OK;
         HIP_TRY(e, hipMemsetAsync(e->c4_emit_counts.p, 0, gnnvc::kEmitCounters * sizeof(unsigned long long), e->stream));
-        emit.spec = e->c4_desc.p;          // consumer stage 1: words 0..7
+        emit.spec = e->c4_desc.p + 8 * stage;          // consumer stage `stage + 1`: its 8 descriptor words
         emit.table = e->c4_table.p;
         emit.counts = e->c4_emit_counts.p;
-        e->c4_fused_for = 1;
+        e->c4_fused_for = stage + 1;
+        return GNNVC_OK;
+    };
+    if (c.sums == StageChoice::kLdsTable || c.sums == StageChoice::kBlocked) {
+        int rc = arm_emit();
+        if (rc) return rc;
     }
-    if (stage == 0 && lt_fits) {
-        HIP_TRY(e, gnnvc::launch_stage0_lds_table(e->stages[0], e->g, e->ws, e->params.p, in, out, lo, hi, e->lt_rows,
-                                                  e->lt_stepptr.p, e->lt_steps.p, e->lt_entries.p, e->lt_bytes.p,
-                                                  e->blk_acc.p, e->lt_bad.p, e->long_thresh, e->opt_mfma == 1,
-                                                  e->interleave, e->stream, emit, e->lt_last_entry));
-    } else if (stage == 0 && e->blocked_ready) {
-        HIP_TRY(e, gnnvc::launch_stage0_blocked(e->stages[0], e->g, e->ws, e->params.p, in, out, lo, hi,
-                                                e->blk_count, e->blk_ptr.p, e->blk_col.p, e->blk_acc.p,
-                                                e->long_thresh, e->opt_mfma == 1, e->interleave, e->stream, emit));
-    } else {
-        const bool mfma = e->opt_mfma == 1 || (e->opt_mfma == 2 && e->stages[stage].f == 16);
-        gnnvc::SortedOrder so;
-        const gnnvc::SortedOrder *sop = nullptr;
-        const float *acc4 = nullptr;
-        const uint32_t *c4desc = nullptr;
-        // Last stage under the whole-graph compact-table plan: k_c4_agg is a persistent grid that holds nearly all LDS of
-        // its CUs but leaves most VALU cycles idle, and the dense-only sigmoid kernel that follows is VALU-bound and
-        // needs no LDS.  So the sums are launched one round (256 chunks) at a time and the dense kernel of round k
-        // goes to the aux stream, where it runs under the sums of round k + 1 (the last round's stays on the main
-        // stream, which then waits for the aux stream).  Metric graph: 1.71 -> 1.58 ms.  (Not for the feature
-        // stages: their dense kernels store 64-byte rows and slow the co-running sums by more than is gained.)
-        bool c4_rounds = false;
-        if (e->stages[stage].f == 16) {
-            if (!e->c4_range_mode && e->graph_uses >= 2 && !e->c4_tried) {
-                int rc = build_compact(e);
-                if (rc) return rc;
-            }
-            const bool whole_plan = e->c4_ready && e->c4_base == 0 && e->c4_end == e->g.n;
-            const bool prepared = e->c4_ready && e->c4_prepared_stage == stage && e->c4_prepared_in == in &&
-                                  lo >= e->c4_base && hi <= e->c4_end && hi > lo;
-            if (prepared && !longs) {
-                // gnnvc_stage_input_ready wrote the table for this input: any call that fills at least half the
-                // GPU with chunks takes the sums from it (smaller ones would leave most CUs idle for a chunk's time)
-                const uint32_t nchunks = (hi - 1 - e->c4_base) / e->c4_rows - (lo - e->c4_base) / e->c4_rows + 1;
-                if (nchunks >= 128u) {
-                    uint32_t *desc = e->c4_desc.p + 8 * (stage - 1);
-                    e->c4_last_desc = 8 * (stage - 1);
-                    HIP_TRY(e, gnnvc::launch_compact_gather(e->g, in, e->c4_counts.p, 1, desc, e->c4_table.p, e->c4_acc.p, lo, hi,
-                                                            e->c4_rows, e->c4_stepptr.p, e->c4_steps.p, e->c4_entries.p,
-                                                            e->c4_dirty.p, e->c4_dirty_cap, e->c4_agg16.p, e->stream, e->c4_block,
-                                                            e->c4_base, e->c4_end, e->c4_last_entry, /*what=*/2));
-                    acc4 = e->c4_acc.p;
-                    c4desc = desc;
-                }
-            } else if (!e->c4_range_mode && whole_plan && !longs && (uint64_t)(hi - lo) * 2 >= e->g.n) {
-                // worth its fixed cost (count + compact the whole input) only when this call covers most of the rows
-                uint32_t *desc = e->c4_desc.p + 8 * (stage - 1);
-                e->c4_last_desc = 8 * (stage - 1);
-                const bool fused = fused_in == stage;   // the producing kernel left counts (and perhaps the table)
-                if (!fused) HIP_TRY(e, gnnvc::column_counts(in, e->g.n, e->c4_counts.p, e->stream));
-                HIP_TRY(e, gnnvc::launch_compact_gather(e->g, in, fused ? e->c4_emit_counts.p : e->c4_counts.p, fused ? 64 : 1,
-                                                        desc, e->c4_table.p, e->c4_acc.p, lo, hi,
-                                                        e->c4_rows, e->c4_stepptr.p, e->c4_steps.p, e->c4_entries.p,
-                                                        e->c4_dirty.p, e->c4_dirty_cap, e->c4_agg16.p, e->stream, e->c4_block,
-                                                        e->c4_base, e->c4_end, e->c4_last_entry,
-                                                        /*what=*/(e->opt_overlap && e->stages[stage].variant == 2 && e->opt_mfma != 1) ? 1 : 3));
-                acc4 = e->c4_acc.p;
-                c4desc = desc;
-                c4_rounds = e->opt_overlap && e->stages[stage].variant == 2 && e->opt_mfma != 1;
-                if (may_emit) {   // and this stage's own (aggregate-only, VALU) kernel produces for the next one
-                    HIP_TRY(e, hipMemsetAsync(e->c4_emit_counts.p, 0, gnnvc::kEmitCounters * sizeof(unsigned long long), e->stream));
-                    emit.spec = e->c4_desc.p + 8 * stage;
-                    emit.table = e->c4_table.p;
-                    emit.counts = e->c4_emit_counts.p;
-                    e->c4_fused_for = stage + 1;
-                }
-            }
-        }
-        {   // degree-sorted tiles on skewed graphs (every stage; the list is cached per row range)
-            int rc = ensure_sorted(e, lo, hi);
-            if (rc) return rc;
-            if (e->srt_cur >= 0 && e->srt[e->srt_cur].use) {
-                so.n = e->srt[e->srt_cur].n;
-                so.vertex = e->srt[e->srt_cur].vertex.p;
-                so.meta = e->srt[e->srt_cur].meta.p;
-                sop = &so;
-            }
-        }
-        if (sop) c4_rounds = false;   // (the plan forced onto a graph with sorted tiles: the gathering kernel does the stage)
-        HIP_TRY(e, gnnvc::launch_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi,
-                                       thr, mfma, sop, e->interleave, e->stream, acc4, c4desc, e->c4_agg16.p,
-                                       e->opt_mfma == 1, emit, /*dense_part=*/!c4_rounds));
-        if (c4_rounds) {
-            uint32_t *desc = e->c4_desc.p + 8 * (stage - 1);
-            HIP_TRY(e, hipMemsetAsync(desc + 5, 0, sizeof(uint32_t), e->stream));        // dirty-row counter
-            HIP_TRY(e, hipMemsetAsync(e->c4_marks.p, 0, sizeof(uint32_t), e->stream));   // marks[0]
-            const uint32_t rows = e->c4_rows, c0 = (lo - e->c4_base) / rows, c1 = (hi - 1 - e->c4_base) / rows;
-            const uint32_t nrounds = (c1 - c0) / 256u + 1u;
-            if (nrounds + 1 > 64) return fail(e, GNNVC_ERR_UNSUPPORTED, "too many rounds of the compact-table plan");
-            int rc = ensure_round_events(e, nrounds);
-            if (rc) return rc;
-            for (uint32_t k = 0; k < nrounds; ++k) {
-                const uint32_t ca = c0 + 256u * k, cb = std::min(c1 + 1u, ca + 256u);
-                const uint32_t ra = std::max(lo, e->c4_base + ca * rows);
-                const uint32_t rb = (uint32_t)std::min<uint64_t>(hi, (uint64_t)e->c4_base + (uint64_t)cb * rows);
-                HIP_TRY(e, gnnvc::compact_sums(e->g, desc, e->c4_table.p, e->c4_acc.p, ra, rb, rows, e->c4_stepptr.p, e->c4_steps.p,
-                                               e->c4_entries.p, e->c4_dirty.p, e->c4_dirty_cap, e->stream, e->c4_block, e->c4_base,
-                                               e->c4_end, e->c4_last_entry, /*one_round=*/true));
-                HIP_TRY(e, gnnvc::compact_mark(desc, e->c4_marks.p, k + 1, e->stream));
-                const bool last = k + 1 == nrounds;
-                hipStream_t ds = last ? e->stream : e->aux_stream;
-                if (!last) {
-                    HIP_TRY(e, hipEventRecord(e->round_ev[k], e->stream));
-                    HIP_TRY(e, hipStreamWaitEvent(e->aux_stream, e->round_ev[k], 0));
-                }
-                HIP_TRY(e, gnnvc::compact_fix(e->g, in, desc, e->c4_dirty.p, e->c4_dirty_cap, e->c4_agg16.p, e->c4_marks.p + k, ds,
-                                              /*blocks=*/64));
-                HIP_TRY(e, gnnvc::launch_dense_sigmoid(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, ra, rb,
-                                                       e->c4_acc.p, desc, e->c4_agg16.p, ds));
-            }
-            if (nrounds > 1) {
-                HIP_TRY(e, hipEventRecord(e->ev_join, e->aux_stream));
-                HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
-            }
-        }
+    if (c.sums == StageChoice::kLdsTable)
+        return hip_rc(e, gnnvc::launch_stage0_lds_table(sp, e->g, e->ws, e->params.p, in, out, lo, hi, e->lt_rows, e->lt_stepptr.p,
+                                                        e->lt_steps.p, e->lt_entries.p, e->lt_bytes.p, e->blk_acc.p, e->lt_bad.p,
+                                                        e->long_thresh, e->opt_mfma == 1, e->interleave, e->stream, emit,
+                                                        e->lt_last_entry));
+    if (c.sums == StageChoice::kBlocked)
+        return hip_rc(e, gnnvc::launch_stage0_blocked(sp, e->g, e->ws, e->params.p, in, out, lo, hi, e->blk_count, e->blk_ptr.p,
+                                                      e->blk_col.p, e->blk_acc.p, e->long_thresh, e->opt_mfma == 1, e->interleave,
+                                                      e->stream, emit));
+    const float *acc4 = nullptr;
+    uint32_t *desc = nullptr;
+    if (c.sums == StageChoice::kCompactPrepared || c.sums == StageChoice::kCompactWhole) {
+        desc = e->c4_desc.p + 8 * (stage - 1);
+        e->c4_last_desc = 8 * (stage - 1);
+        acc4 = e->c4_acc.p;
+        const bool whole = c.sums == StageChoice::kCompactWhole;
+        if (whole && !c.fused_counts) HIP_TRY(e, gnnvc::column_counts(in, e->g.n, e->c4_counts.p, e->stream));
+        const bool fused = whole && c.fused_counts;
+        // what: 1 = choose the columns + write the table, 2 = the sums; the prepared table only needs its sums, a call
+        // that runs its sums round by round (below) only the preparation
+        const int what = !whole ? 2 : (c.rounds ? 1 : 3);
+        HIP_TRY(e, gnnvc::launch_compact_gather(e->g, in, fused ? e->c4_emit_counts.p : e->c4_counts.p, fused ? 64 : 1, desc,
+                                                e->c4_table.p, e->c4_acc.p, lo, hi, e->c4_rows, e->c4_stepptr.p, e->c4_steps.p,
+                                                e->c4_entries.p, e->c4_dirty.p, e->c4_dirty_cap, e->c4_agg16.p, e->stream,
+                                                e->c4_block, e->c4_base, e->c4_end, e->c4_last_entry, what));
     }
+    {
+        int rc = arm_emit();
+        if (rc) return rc;
+    }
+    const gnnvc::SortedOrder *sop = c.sorted.n ? &c.sorted : nullptr;
+    HIP_TRY(e, gnnvc::launch_stage(sp, e->g, e->ws, e->params.p, in, out, logits, lo, hi, c.long_thresh, c.mfma, sop,
+                                   e->interleave, e->stream, acc4, desc, e->c4_agg16.p, e->opt_mfma == 1, emit,
+                                   /*dense_part=*/!c.rounds));
+    if (!c.rounds) return GNNVC_OK;
+    HIP_TRY(e, hipMemsetAsync(desc + 5, 0, sizeof(uint32_t), e->stream));        // dirty-row counter
+    HIP_TRY(e, hipMemsetAsync(e->c4_marks.p, 0, sizeof(uint32_t), e->stream));   // marks[0]
+    const uint32_t rows = e->c4_rows, c0 = (lo - e->c4_base) / rows, c1 = (hi - 1 - e->c4_base) / rows;
+    const uint32_t nrounds = (c1 - c0) / 256u + 1u;
+    if (nrounds + 1 > 64) return fail(e, GNNVC_ERR_UNSUPPORTED, "too many rounds of the compact-table plan");
+    {
+        int rc = ensure_round_events(e, nrounds);
+        if (rc) return rc;
+    }
+    for (uint32_t k = 0; k < nrounds; ++k) {
+        const uint32_t ca = c0 + 256u * k, cb = std::min(c1 + 1u, ca + 256u);
+        const uint32_t ra = std::max(lo, e->c4_base + ca * rows);
+        const uint32_t rb = (uint32_t)std::min<uint64_t>(hi, (uint64_t)e->c4_base + (uint64_t)cb * rows);
+        HIP_TRY(e, gnnvc::compact_sums(e->g, desc, e->c4_table.p, e->c4_acc.p, ra, rb, rows, e->c4_stepptr.p, e->c4_steps.p,
+                                       e->c4_entries.p, e->c4_dirty.p, e->c4_dirty_cap, e->stream, e->c4_block, e->c4_base,
+                                       e->c4_end, e->c4_last_entry, /*one_round=*/true));
+        HIP_TRY(e, gnnvc::compact_mark(desc, e->c4_marks.p, k + 1, e->stream));
+        const bool last = k + 1 == nrounds;
+        hipStream_t ds = last ? e->stream : e->aux_stream;
+        if (!last) {
+            HIP_TRY(e, hipEventRecord(e->round_ev[k], e->stream));
+            HIP_TRY(e, hipStreamWaitEvent(e->aux_stream, e->round_ev[k], 0));
+        }
+        HIP_TRY(e, gnnvc::compact_fix(e->g, in, desc, e->c4_dirty.p, e->c4_dirty_cap, e->c4_agg16.p, e->c4_marks.p + k, ds,
+                                      /*blocks=*/64));
+        HIP_TRY(e, gnnvc::launch_dense_sigmoid(sp, e->g, e->ws, e->params.p, in, out, logits, ra, rb, e->c4_acc.p, desc,
+                                               e->c4_agg16.p, ds));
+    }
+    if (nrounds > 1) {
+        HIP_TRY(e, hipEventRecord(e->ev_join, e->aux_stream));
+        HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
+    }
+    return GNNVC_OK;
+}
+
+int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float *in, float *out, float *logits,
+              bool in_forward = false) {
+    StageChoice c;
+    int rc = choose_stage(e, stage, lo, hi, in, out, in_forward, c);
+    if (rc) return rc;
+    const bool longs = e->n_long > 0;
+    if (longs) {
+        rc = launch_side_rows(e, stage, lo, hi, in, out, logits, c.long_thresh);
+        if (rc) return rc;
+    }
+    rc = launch_main(e, c, stage, lo, hi, in, out, logits);
+    if (rc) return rc;
     if (longs && e->opt_side_streams) {   // join
         HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
         if (e->n_giant) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_giant, 0));

@@ -2649,27 +2649,27 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
 #ifndef GNNVC_GATHER_S_SORTED
 #define GNNVC_GATHER_S_SORTED 3
 #endif
-#define GNNVC_LAUNCH_F16(N2_, N3_, SIG_, MF_, SRT_, LG_)                                              \
-    GNNVC_LAUNCH((k_stage_f16<32, N2_, N3_, SIG_, (SRT_) ? GNNVC_GATHER_S_SORTED : GNNVC_GATHER_S, MF_, SRT_>), grid, block, 0, stream, g, ws, in4, out, \
+#define GNNVC_LAUNCH_F16(N2_, N3_, SIG_, MF_, SRT_, S_, LG_)                                          \
+    GNNVC_LAUNCH((k_stage_f16<32, N2_, N3_, SIG_, S_, MF_, SRT_>), grid, block, 0, stream, g, ws, in4, out, \
                        LG_, P, row_lo, row_hi, long_thresh, sorted ? so->vertex : nullptr,                \
                        sorted ? so->meta : nullptr, sorted ? so->n : 0u, il,                              \
                        (const float4 *)nullptr, (sorted || !acc4) ? nullptr : c4desc, (const float4 *)nullptr,           \
                        (const uint32_t *)nullptr, (c4row *)nullptr, (unsigned long long *)nullptr)
     case 2:
-        if (sorted) GNNVC_LAUNCH_F16(32, 16, false, false, true, nullptr);
-        else GNNVC_LAUNCH_F16(32, 16, false, false, false, nullptr);
+        if (sorted) GNNVC_LAUNCH_F16(32, 16, false, false, true, GNNVC_GATHER_S_SORTED, nullptr);
+        else GNNVC_LAUNCH_F16(32, 16, false, false, false, GNNVC_GATHER_S, nullptr);
         break;
     case 3:
-        if (sorted) GNNVC_LAUNCH_F16(32, 16, false, true, true, nullptr);
-        else GNNVC_LAUNCH_F16(32, 16, false, true, false, nullptr);
+        if (sorted) GNNVC_LAUNCH_F16(32, 16, false, true, true, GNNVC_GATHER_S_SORTED, nullptr);
+        else GNNVC_LAUNCH_F16(32, 16, false, true, false, GNNVC_GATHER_S, nullptr);
         break;
     case 4:
-        if (sorted) GNNVC_LAUNCH_F16(16, 1, true, false, true, logits);
-        else GNNVC_LAUNCH_F16(16, 1, true, false, false, logits);
+        if (sorted) GNNVC_LAUNCH_F16(16, 1, true, false, true, GNNVC_GATHER_S_SORTED, logits);
+        else GNNVC_LAUNCH_F16(16, 1, true, false, false, GNNVC_GATHER_S, logits);
         break;
     case 5:
-        if (sorted) GNNVC_LAUNCH_F16(16, 1, true, true, true, logits);
-        else GNNVC_LAUNCH_F16(16, 1, true, true, false, logits);
+        if (sorted) GNNVC_LAUNCH_F16(16, 1, true, true, true, GNNVC_GATHER_S_SORTED, logits);
+        else GNNVC_LAUNCH_F16(16, 1, true, true, false, GNNVC_GATHER_S, logits);
         break;
 #undef GNNVC_LAUNCH_F16
     default:
