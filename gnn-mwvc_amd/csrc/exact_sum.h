@@ -93,8 +93,8 @@ XS_HD Map elem_map_f(uint32_t vbits, uint32_t E, bool &bad) {
     const float fr = t - fl;
     const uint32_t up = fr > 0.5f ? 1u : 0u, tie = fr == 0.5f ? 1u : 0u;
     Map r;
-    r.d0 = sat_(k + up + (tie & k));
-    r.d1 = sat_(k + up + (tie & (k + 1u)));
+    r.d0 = k + up + (tie & k);             // (<= kSat + 2: the caller saturates after a handful of appends)
+    r.d1 = k + up + (tie & (k + 1u));
     return r;
 }
 
@@ -108,12 +108,19 @@ XS_HD Map compose(const Map &a, const Map &b) {
     return c;
 }
 
-// append one addend to a running map (same as compose(run, elem_map(v)), written for the inner loop)
+// Append one addend to a running map (compose(run, elem_map(v)) without the saturation).  An addend's increments are
+// at most kSat + 2, so up to 31 appends fit 32 bits: the caller appends a lane's handful of addends, then calls
+// saturate() once (the parity bits that steer the selects stay exact as long as nothing wraps).
+constexpr int kMaxAppends = 31;
 template <bool FLOAT_DECODE = false>
 XS_HD void append(Map &run, uint32_t vbits, uint32_t E, bool &bad) {
     const Map e = FLOAT_DECODE ? elem_map_f(vbits, E, bad) : elem_map(vbits, E, bad);
-    run.d0 = sat(run.d0 + ((run.d0 & 1u) ? e.d1 : e.d0));
-    run.d1 = sat(run.d1 + ((run.d1 & 1u) ? e.d0 : e.d1));
+    run.d0 = run.d0 + ((run.d0 & 1u) ? e.d1 : e.d0);
+    run.d1 = run.d1 + ((run.d1 & 1u) ? e.d0 : e.d1);
+}
+XS_HD void saturate(Map &run) {
+    run.d0 = sat(run.d0);
+    run.d1 = sat(run.d1);
 }
 
 }  // namespace xsum

@@ -188,6 +188,13 @@ struct gnnvc_engine {
     double plan_build_ms = 0.0;          // host wall time spent building per-graph plans for the current graph (they end in stream syncs)
     int opt_ktrace = 0;                  // option "kernel_trace": HIP events around every main-stream kernel of a forward
     gnnvc::KernelTraceSink ktrace;
+    // the next graph derived from the resident one (gnnvc_derive_graph_begin / _commit)
+    DevBuf<uint32_t> rowptr2, col2, der_old_row, der_new_of, der_tail, der_tailptr, der_tailcols;
+    DevBuf<unsigned long long> hash_buf;
+    std::vector<uint32_t> der_tail_host;
+    uint32_t der_n_new = 0;
+    uint64_t der_nnz_new = 0, der_tail_total = 0;
+    bool der_open = false;
     bool empty_slice = false;            // gnnvc_attach_graph_slice with no rows: every stage call is a no-op
     uint32_t opt_giant_thresh = 16384;   // option "giant_row_threshold" (0 = off: k_long_* take every long row)
     int opt_side_streams = 1;            // option "side_streams": 0 = long / giant rows on the main stream, one after the other (profiling)
@@ -1160,6 +1167,8 @@ void gnnvc_destroy(gnnvc_engine *e) {
     e->c4_agg16.release(); e->c4_dirty.release(); e->c4_emit_counts.release();
     e->long_list.release(); e->long_count.release();
     e->gi_meta.release(); e->gi_off.release(); e->gi_slab.release(); e->gi_agg.release();
+    e->rowptr2.release(); e->col2.release(); e->der_old_row.release(); e->der_new_of.release(); e->der_tail.release();
+    e->der_tailptr.release(); e->der_tailcols.release(); e->hash_buf.release();
     e->pin_rowptr.release(); e->pin_col.release(); e->pin_w.release(); e->pin_nw.release();
     e->pin_small.release();
     for (auto &r : e->srt) { r.vertex.release(); r.meta.release(); }
@@ -1435,6 +1444,99 @@ static int attach_common(gnnvc_engine *e, const GraphDev &cand) {
     e->graph_uses = 0;          // driver uses every graph exactly once (src/GNN_VC.cpp:171-192)
     e->plan_build_ms = 0.0;
     return find_long(e);
+}
+
+/* ---- the next graph derived from the resident one ---------------------------------------------
+ * See the k_derive_* kernels: the device keeps the CSR of the last hand-off; the caller says which old row every vertex
+ * of the next graph was (or that it is new) and how long its list is now, learns how many trailing entries per row the
+ * device cannot derive, ships exactly those, and the engine assembles the next CSR in place of an upload of all of it. */
+int gnnvc_derive_graph_begin(gnnvc_engine *e, uint32_t n_new, const uint32_t *old_row, const uint32_t *rowptr_new, uint32_t *tail) {
+    if (!e) return GNNVC_ERR_INVALID;
+    e->der_open = false;
+    if (!e->have_graph || e->g.rowptr != e->rowptr.p || e->g.col != e->col.p || e->g.sliced() || e->empty_slice)
+        return fail(e, GNNVC_ERR_STATE, "no engine-owned whole graph is resident (hand one over with gnnvc_upload_graph or the staged calls first)");
+    if (n_new && (!old_row || !rowptr_new || !tail)) return fail(e, GNNVC_ERR_INVALID, "null arrays");
+    int rc = use_device(e);
+    if (rc) return rc;
+    const uint64_t nnz_new = n_new ? rowptr_new[n_new] : 0;
+    if (n_new && rowptr_new[0] != 0) return fail(e, GNNVC_ERR_INVALID, "rowptr_new[0] != 0");
+    if (nnz_new >= 0xFFFFFFFFull - GNNVC_COL_PAD) return fail(e, GNNVC_ERR_UNSUPPORTED, "nnz too large");
+    HIP_TRY(e, e->der_old_row.reserve(n_new));
+    HIP_TRY(e, e->rowptr2.reserve((size_t)n_new + 1));
+    HIP_TRY(e, e->der_new_of.reserve(std::max<uint32_t>(e->g.n, 1u)));
+    HIP_TRY(e, e->der_tail.reserve(n_new));
+    HIP_TRY(e, e->blk_flag.reserve(1));
+    if (n_new) {
+        HIP_TRY(e, hipMemcpyAsync(e->der_old_row.p, old_row, (size_t)n_new * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(e->rowptr2.p, rowptr_new, ((size_t)n_new + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    } else {
+        HIP_TRY(e, hipMemsetAsync(e->rowptr2.p, 0, sizeof(uint32_t), e->stream));
+    }
+    HIP_TRY(e, gnnvc::derive_tails(e->g, e->der_old_row.p, n_new, e->rowptr2.p, e->der_new_of.p, e->der_tail.p, e->blk_flag.p, e->stream));
+    uint32_t bad = 0;
+    if (n_new) HIP_TRY(e, hipMemcpyAsync(tail, e->der_tail.p, (size_t)n_new * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(&bad, e->blk_flag.p, sizeof bad, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (bad)
+        return fail(e, GNNVC_ERR_INVALID, "%s", (bad & 1u) ? "old_row[] names a row the resident graph does not have"
+                                                 : (bad & 2u) ? "two vertices of the next graph claim the same old row"
+                                                              : "a row has more surviving old neighbours than its new degree: not derived from the resident graph");
+    e->der_tail_host.assign(tail, tail + n_new);
+    uint64_t total = 0;
+    for (uint32_t u = 0; u < n_new; ++u) total += tail[u];
+    e->der_n_new = n_new;
+    e->der_nnz_new = nnz_new;
+    e->der_tail_total = total;
+    e->der_open = true;
+    return GNNVC_OK;
+}
+
+int gnnvc_derive_graph_commit(gnnvc_engine *e, const uint32_t *tail_cols, uint64_t n_tail, const uint32_t *w, const uint32_t *nw) {
+    if (!e) return GNNVC_ERR_INVALID;
+    if (!e->der_open) return fail(e, GNNVC_ERR_STATE, "gnnvc_derive_graph_begin first");
+    e->der_open = false;
+    const uint32_t n = e->der_n_new;
+    if (n_tail != e->der_tail_total) return fail(e, GNNVC_ERR_INVALID, "expected %llu tail entries, got %llu",
+                                                 (unsigned long long)e->der_tail_total, (unsigned long long)n_tail);
+    if ((n_tail && !tail_cols) || (n && (!w || !nw))) return fail(e, GNNVC_ERR_INVALID, "null arrays");
+    int rc = use_device(e);
+    if (rc) return rc;
+    std::vector<uint32_t> tptr((size_t)n + 1, 0);
+    for (uint32_t u = 0; u < n; ++u) tptr[u + 1] = tptr[u] + e->der_tail_host[u];
+    HIP_TRY(e, e->der_tailptr.reserve((size_t)n + 1));
+    HIP_TRY(e, e->der_tailcols.reserve(std::max<uint64_t>(n_tail, 1)));
+    HIP_TRY(e, e->col2.reserve(e->der_nnz_new + GNNVC_COL_PAD));
+    HIP_TRY(e, hipMemcpy(e->der_tailptr.p, tptr.data(), tptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (n_tail) HIP_TRY(e, hipMemcpyAsync(e->der_tailcols.p, tail_cols, n_tail * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, gnnvc::derive_fill(e->g, e->der_old_row.p, e->der_new_of.p, e->rowptr2.p, e->der_tailptr.p, e->der_tailcols.p, n,
+                                  e->col2.p, e->stream));
+    HIP_TRY(e, hipMemsetAsync(e->col2.p + e->der_nnz_new, 0, GNNVC_COL_PAD * sizeof(uint32_t), e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));   // (the old arrays are about to change hands)
+    std::swap(e->rowptr, e->rowptr2);
+    std::swap(e->col, e->col2);
+    e->have_graph = false;
+    HIP_TRY(e, e->w.reserve(n));
+    HIP_TRY(e, e->nw.reserve(n));
+    if (n) {
+        HIP_TRY(e, hipMemcpyAsync(e->w.p, w, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(e->nw.p, nw, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    }
+    return adopt_uploaded(e, n, e->der_nnz_new);
+}
+
+int gnnvc_graph_row_hashes(gnnvc_engine *e, uint64_t *hashes) {
+    if (!e) return GNNVC_ERR_INVALID;
+    if (!e->have_graph || e->empty_slice) return fail(e, GNNVC_ERR_STATE, "no graph attached");
+    const uint32_t rows = e->g.hi() - e->g.lo();
+    if (!rows) return GNNVC_OK;
+    if (!hashes) return fail(e, GNNVC_ERR_INVALID, "null output");
+    int rc = use_device(e);
+    if (rc) return rc;
+    HIP_TRY(e, e->hash_buf.reserve(rows));
+    HIP_TRY(e, gnnvc::row_hashes(e->g, e->hash_buf.p, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(hashes, e->hash_buf.p, (size_t)rows * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return GNNVC_OK;
 }
 
 int gnnvc_attach_graph_device(gnnvc_engine *e, uint32_t n, uint64_t nnz, const uint32_t *d_rowptr,

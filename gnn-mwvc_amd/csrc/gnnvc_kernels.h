@@ -210,6 +210,15 @@ hipError_t compact_mark(const uint32_t *desc, uint32_t *marks, uint32_t k, hipSt
 hipError_t compact_fix(const GraphDev &g, const float *in, const uint32_t *desc, const uint32_t *dirty_rows, uint32_t dirty_cap,
                        float *agg16, const uint32_t *marks, hipStream_t stream, uint32_t blocks = 4096);
 
+// The next graph derived from the resident one (see the k_derive_* kernels): new_of is scratch of
+// old_g.n words, tail receives per new row the number of entries the device cannot derive, *bad != 0 afterwards means
+// the mapping is inconsistent (bit0 old row out of range, bit1 claimed twice, bit2 more survivors than the new degree).
+hipError_t derive_tails(const GraphDev &old_g, const uint32_t *old_row, uint32_t n_new, const uint32_t *rowptr_new, uint32_t *new_of,
+                        uint32_t *tail, uint32_t *bad, hipStream_t stream);
+hipError_t derive_fill(const GraphDev &old_g, const uint32_t *old_row, const uint32_t *new_of, const uint32_t *rowptr_new,
+                       const uint32_t *tail_ptr, const uint32_t *tail_cols, uint32_t n_new, uint32_t *col_new, hipStream_t stream);
+hipError_t row_hashes(const GraphDev &g, unsigned long long *out, hipStream_t stream);
+
 hipError_t score_keys(const float *scores, size_t n, float *keys, uint8_t *above_half, hipStream_t stream);
 
 // feature-row codec of the inter-GPU exchange (16-column rows; a piece = dense rows + exception list)

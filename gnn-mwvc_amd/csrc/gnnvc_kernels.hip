@@ -1002,6 +1002,7 @@ __global__ __launch_bounds__(256) void k_long_f1(
 // the default): k_giant_sum adds lane-strided partial sums and combines them with a wave tree — the
 // tolerance mode of SURVEY.md §7; results then differ from the chain's in the last bits.
 constexpr int kGiantB = 16;                          // addends per lane and window
+static_assert(kGiantB <= xsum::kMaxAppends, "a lane's appends must fit 32 bits before saturate()");
 constexpr uint32_t kGiantWin = 64u * kGiantB;        // 1024: streams are padded to a multiple of this
 constexpr uint32_t kGiantBlk = 256;                  // neighbours per gather workgroup
 constexpr int kGiantRing = 4;                        // windows held in registers (three loads in flight)
@@ -1091,6 +1092,7 @@ __device__ __forceinline__ void giant_window(const f32x4 (&d)[kGiantB / 4], int 
                 const uint32_t vb = (i >= lo && i < hi) ? __float_as_uint(d[i >> 2][i & 3]) : 0u;
                 xsum::append<true>(run, vb, E, bad);
             }
+            xsum::saturate(run);
         }
         const unsigned long long badmask = __ballot(bad);
         if (!ok || __popcll(badmask) > 4) {
@@ -1219,6 +1221,64 @@ __global__ void k_stream_meta(uint4 *meta, unsigned long long *off, uint32_t str
     const uint32_t lpad = (len + kGiantWin - 1) / kGiantWin * kGiantWin;
     meta[i] = make_uint4(0u, 0u, len, 0u);
     if (i < streams) off[i] = (unsigned long long)i * lpad;
+}
+
+// ------------------------------------------------------------------ the next graph derived from the resident one (f-1)
+// Between two predict calls of the reference's driver the graph only SHRINKS, apart from the vertices its folds
+// create (include/reduction_graph.hpp:335-398: a fold appends a vertex with the largest id and puts it at the END
+// of its neighbours' lists; removals drop entries; relable_graph :537-587 renumbers the survivors in order).  So
+// the next CSR is: for a surviving row, its old entries that survive, in order, renumbered — followed by a short
+// TAIL of new-vertex ids; for a new vertex, a list that is all tail.  Given old_row[] (new vertex -> its row in the
+// resident graph, or none) the device derives everything but the tails from the CSR it already holds.
+constexpr uint32_t kNoVertex = 0xFFFFFFFFu;
+
+__global__ void k_derive_map(const uint32_t *__restrict__ old_row, uint32_t n_new, uint32_t n_old, uint32_t *__restrict__ new_of,
+                             uint32_t *__restrict__ bad) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_new) return;
+    const uint32_t o = old_row[u];
+    if (o == kNoVertex) return;
+    if (o >= n_old) { atomicOr(bad, 1u); return; }
+    if (atomicExch(&new_of[o], u) != kNoVertex) atomicOr(bad, 2u);   // two new vertices claim the same old row
+}
+
+// tail[u] = (degree of u in the new graph) - (old entries of its old row that survive)
+__global__ void k_derive_tails(GraphDev g, const uint32_t *__restrict__ old_row, const uint32_t *__restrict__ new_of,
+                               const uint32_t *__restrict__ rowptr_new, uint32_t n_new, uint32_t *__restrict__ tail,
+                               uint32_t *__restrict__ bad) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_new) return;
+    const uint32_t o = old_row[u];
+    uint32_t kept = 0;
+    if (o != kNoVertex)
+        for (uint32_t e = g.rowptr[o]; e < g.rowptr[o + 1]; ++e) kept += new_of[g.col[e]] != kNoVertex ? 1u : 0u;
+    const uint32_t deg = rowptr_new[u + 1] - rowptr_new[u];
+    if (rowptr_new[u + 1] < rowptr_new[u] || kept > deg) { atomicOr(bad, 4u); tail[u] = 0; return; }
+    tail[u] = deg - kept;
+}
+
+__global__ void k_derive_fill(GraphDev g, const uint32_t *__restrict__ old_row, const uint32_t *__restrict__ new_of,
+                              const uint32_t *__restrict__ rowptr_new, const uint32_t *__restrict__ tail_ptr,
+                              const uint32_t *__restrict__ tail_cols, uint32_t n_new, uint32_t *__restrict__ col_new) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_new) return;
+    const uint32_t o = old_row[u];
+    uint32_t pos = rowptr_new[u];
+    if (o != kNoVertex)
+        for (uint32_t e = g.rowptr[o]; e < g.rowptr[o + 1]; ++e) {
+            const uint32_t c = new_of[g.col[e]];
+            if (c != kNoVertex) col_new[pos++] = c;
+        }
+    for (uint32_t t = tail_ptr[u]; t < tail_ptr[u + 1]; ++t) col_new[pos++] = tail_cols[t];
+}
+
+// FNV-1a over a row's column ids in stored order: lets a caller compare the resident graph with its own lists
+__global__ void k_row_hashes(GraphDev g, unsigned long long *__restrict__ out) {
+    const uint32_t u = g.lo() + blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= g.hi()) return;
+    unsigned long long h = 1469598103934665603ull;
+    for (uint32_t e = g.rowptr[u]; e < g.rowptr[u + 1]; ++e) h = (h ^ (unsigned long long)g.col[e]) * 1099511628211ull;
+    out[u - g.lo()] = h;
 }
 
 // ---- LDS-table plan of the F = 1 stage ---------------------------------------------------------
@@ -3019,6 +3079,31 @@ hipError_t find_long_rows(const GraphDev &g, uint32_t thresh, uint32_t *list, ui
     hipError_t rc = hipMemsetAsync(count, 0, sizeof(uint32_t), stream);
     if (rc != hipSuccess || g.hi() <= g.lo()) return rc;
     GNNVC_LAUNCH(k_find_long, dim3((g.hi() - g.lo() + 255) / 256), dim3(256), 0, stream, g, thresh, list, count);
+    return hipGetLastError();
+}
+
+hipError_t derive_tails(const GraphDev &old_g, const uint32_t *old_row, uint32_t n_new, const uint32_t *rowptr_new, uint32_t *new_of,
+                        uint32_t *tail, uint32_t *bad, hipStream_t stream) {
+    hipError_t rc = hipMemsetAsync(new_of, 0xFF, (size_t)std::max<uint32_t>(old_g.n, 1u) * sizeof(uint32_t), stream);
+    if (rc == hipSuccess) rc = hipMemsetAsync(bad, 0, sizeof(uint32_t), stream);
+    if (rc != hipSuccess || n_new == 0) return rc;
+    const dim3 grid((n_new + 255) / 256), block(256);
+    GNNVC_LAUNCH(k_derive_map, grid, block, 0, stream, old_row, n_new, old_g.n, new_of, bad);
+    GNNVC_LAUNCH(k_derive_tails, grid, block, 0, stream, old_g, old_row, new_of, rowptr_new, n_new, tail, bad);
+    return hipGetLastError();
+}
+
+hipError_t derive_fill(const GraphDev &old_g, const uint32_t *old_row, const uint32_t *new_of, const uint32_t *rowptr_new,
+                       const uint32_t *tail_ptr, const uint32_t *tail_cols, uint32_t n_new, uint32_t *col_new, hipStream_t stream) {
+    if (n_new == 0) return hipSuccess;
+    GNNVC_LAUNCH(k_derive_fill, dim3((n_new + 255) / 256), dim3(256), 0, stream, old_g, old_row, new_of, rowptr_new, tail_ptr,
+                 tail_cols, n_new, col_new);
+    return hipGetLastError();
+}
+
+hipError_t row_hashes(const GraphDev &g, unsigned long long *out, hipStream_t stream) {
+    if (g.hi() <= g.lo()) return hipSuccess;
+    GNNVC_LAUNCH(k_row_hashes, dim3((g.hi() - g.lo() + 255) / 256), dim3(256), 0, stream, g, out);
     return hipGetLastError();
 }
 

@@ -23,6 +23,7 @@ ABI_SYMBOLS = [
     "gnnvc_set_weight_scale", "gnnvc_set_stream", "gnnvc_set_option", "gnnvc_get_info", "gnnvc_num_layers", "gnnvc_is_fused",
     "gnnvc_in_width", "gnnvc_out_width", "gnnvc_upload_graph", "gnnvc_attach_graph_device", "gnnvc_attach_graph_slice",
     "gnnvc_graph_staging", "gnnvc_staged_columns_ready", "gnnvc_commit_staged_graph",
+    "gnnvc_derive_graph_begin", "gnnvc_derive_graph_commit", "gnnvc_graph_row_hashes",
     "gnnvc_forward", "gnnvc_forward_device", "gnnvc_num_stages", "gnnvc_stage_widths",
     "gnnvc_stage_forward_device", "gnnvc_stage_input_ready", "gnnvc_live_columns", "gnnvc_column_counts", "gnnvc_pack_rows", "gnnvc_unpack_rows", "gnnvc_unpack_gathered",
     "gnnvc_reduction_flags", "gnnvc_score_keys", "gnnvc_synchronize", "gnnvc_last_forward_ms",
@@ -92,6 +93,9 @@ def load_library():
     L.gnnvc_upload_graph.argtypes = [vp, u32, vp, vp, vp, vp]
     L.gnnvc_attach_graph_device.argtypes = [vp, u32, u64, vp, vp, vp, vp]
     L.gnnvc_attach_graph_slice.argtypes = [vp, u32, u32, u32, u64, vp, vp, vp, vp]
+    L.gnnvc_derive_graph_begin.argtypes = [vp, u32, vp, vp, vp]
+    L.gnnvc_derive_graph_commit.argtypes = [vp, vp, u64, vp, vp]
+    L.gnnvc_graph_row_hashes.argtypes = [vp, vp]
     L.gnnvc_graph_staging.argtypes = [vp, u32, u64] + [C.POINTER(vp)] * 4
     L.gnnvc_staged_columns_ready.argtypes = [vp, u64, u64]
     L.gnnvc_commit_staged_graph.argtypes = [vp]
@@ -251,6 +255,30 @@ class Engine:
                                                      w_ptr, nw_ptr))
         self.n = n_global
         self._keep = keepalive
+
+    def derive_graph(self, g_new, old_row: np.ndarray):
+        """Make g_new current by deriving it on the device from the resident graph (gnnvc_derive_graph_begin/_commit):
+        old_row[u] = row of the resident graph that vertex u of g_new was, or 0xFFFFFFFF.  Returns the tail counts."""
+        n = int(g_new.n)
+        old_row = np.ascontiguousarray(old_row, dtype=np.uint32)
+        rp = np.ascontiguousarray(np.asarray(g_new.rowptr, dtype=np.uint64).astype(np.uint32))
+        tail = np.zeros(max(n, 1), dtype=np.uint32)
+        self._check(self._L.gnnvc_derive_graph_begin(self._h, n, _np_ptr(old_row), _np_ptr(rp), _np_ptr(tail)))
+        tail = tail[:n]
+        col = np.asarray(g_new.col, dtype=np.uint32)
+        ends = np.asarray(g_new.rowptr, dtype=np.int64)[1:]
+        pieces = [col[e - t: e] for e, t in zip(ends[tail > 0], tail[tail > 0])]
+        tails = np.ascontiguousarray(np.concatenate(pieces) if pieces else np.zeros(0, dtype=np.uint32), dtype=np.uint32)
+        w = np.ascontiguousarray(g_new.w, dtype=np.uint32)
+        nw = np.ascontiguousarray(g_new.nw, dtype=np.uint32)
+        self._check(self._L.gnnvc_derive_graph_commit(self._h, _np_ptr(tails), tails.size, _np_ptr(w), _np_ptr(nw)))
+        self.n = n
+        return tail
+
+    def row_hashes(self) -> np.ndarray:
+        out = np.zeros(max(self.n, 1), dtype=np.uint64)
+        self._check(self._L.gnnvc_graph_row_hashes(self._h, _np_ptr(out)))
+        return out[: self.n]
 
     # -- forward
     def forward(self, x: np.ndarray, want_logits: bool = True, out=None):

@@ -270,6 +270,79 @@ uint64_t hand_off_graph(gnnvc_engine *e, const G &g) {
     return nnz;
 }
 
+// predict's hand-off by DERIVATION (GNNVC_DELTA=1|2, off by default): the device still holds the graph of
+// the previous call; vertices are matched through the labels reduction_graph keeps for them (get_org_label,
+// include/reduction_graph.hpp:134-139 — stable across relable_graph), the engine derives every row's surviving entries
+// itself (gnnvc_derive_graph_begin) and only the tails — the fold vertices appended since — cross the bus.
+// What the public read interface of reduction_graph cannot promise is that a label seen again is the SAME vertex (an
+// undone fold frees its label for the next one), so mode 1 verifies: the engine's per-row hashes against hashes of the
+// host lists — an O(nnz) read, about what the pack costs — and falls back to the full hand-off on any mismatch.
+// Mode 2 skips the verification (measurements only).
+struct DeltaState {
+    std::vector<uint32_t> row_of_org;   // label -> row of the graph now resident on the device
+    bool valid = false;
+};
+std::map<const gnnvc_engine *, DeltaState> g_delta;
+
+template <class G>
+void remember_rows(DeltaState &st, const G &g) {
+    const uint32_t n = g.size();
+    uint32_t top = 0;
+    for (uint32_t u = 0; u < n; ++u) top = std::max<uint32_t>(top, g.get_org_label(u));
+    st.row_of_org.assign(n ? (size_t)top + 1 : 0, GNNVC_NEW_VERTEX);
+    for (uint32_t u = 0; u < n; ++u) st.row_of_org[g.get_org_label(u)] = u;
+    st.valid = n != 0;
+}
+
+template <class G>
+bool derive_hand_off(gnnvc_engine *e, const G &g, DeltaState &st, int mode, uint64_t &nnz_out) {
+    if (!st.valid) return false;
+    const uint32_t n = g.size();
+    std::vector<uint32_t> old_row(n), rowptr((size_t)n + 1, 0), w(n), nw(n), tail(n);
+    std::vector<uint64_t> part_sum(pack_threads() + 1, 0);
+    parallel_rows(n, [&](unsigned part, uint32_t lo, uint32_t hi) {
+        uint64_t sum = 0;
+        for (uint32_t u = lo; u < hi; ++u) {
+            const uint32_t org = g.get_org_label(u);
+            old_row[u] = org < st.row_of_org.size() ? st.row_of_org[org] : GNNVC_NEW_VERTEX;
+            const uint64_t len = (uint64_t)(g.end(u) - g.begin(u));
+            rowptr[u + 1] = (uint32_t)len;
+            sum += len;
+            w[u] = g.W(u);
+            nw[u] = g.NW(u);
+        }
+        part_sum[part + 1] = sum;
+    });
+    for (size_t i = 1; i < part_sum.size(); ++i) part_sum[i] += part_sum[i - 1];
+    if (part_sum.back() >= 0xFFFFFFFFull - 64) return false;
+    parallel_rows(n, [&](unsigned part, uint32_t lo, uint32_t hi) {
+        uint32_t run = (uint32_t)part_sum[part];
+        for (uint32_t u = lo; u < hi; ++u) {
+            run += rowptr[u + 1];
+            rowptr[u + 1] = run;
+        }
+    });
+    if (gnnvc_derive_graph_begin(e, n, old_row.data(), rowptr.data(), tail.data()) != GNNVC_OK) return false;
+    std::vector<uint32_t> tails;
+    for (uint32_t u = 0; u < n; ++u)
+        if (tail[u]) tails.insert(tails.end(), g.end(u) - tail[u], g.end(u));
+    if (gnnvc_derive_graph_commit(e, tails.data(), tails.size(), w.data(), nw.data()) != GNNVC_OK) return false;
+    if (mode == 1) {
+        std::vector<uint64_t> dev(n), host(n);
+        if (gnnvc_graph_row_hashes(e, dev.data()) != GNNVC_OK) return false;
+        parallel_rows(n, [&](unsigned, uint32_t lo, uint32_t hi) {
+            for (uint32_t u = lo; u < hi; ++u) {
+                uint64_t h = 1469598103934665603ull;
+                for (auto it = g.begin(u); it != g.end(u); ++it) h = (h ^ (uint64_t)*it) * 1099511628211ull;
+                host[u] = h;
+            }
+        });
+        if (dev != host) return false;
+    }
+    nnz_out = part_sum.back();
+    return true;
+}
+
 // Lossless text of a model in the reference's format (9 significant digits
 // round-trip fp32), used to hand the layers to gnnvc_create.
 std::string exact_text(const std::string &name, const std::vector<component> &layers) {
@@ -402,7 +475,20 @@ void model::predict(const matrix &in, matrix &out, const reduction_graph<Tn, Tw>
     using clk = std::chrono::steady_clock;
     const auto t0 = clk::now();
     check(gnnvc_set_weight_scale(e, scale_of(layers)), "gnnvc_set_weight_scale", e);
-    const uint64_t nnz = hand_off_graph(e, g);   // pack + copy, overlapped
+    static const int delta_mode = [] {
+        const char *v = std::getenv("GNNVC_DELTA");
+        return v && *v ? std::atoi(v) : 0;
+    }();
+    uint64_t nnz = 0;
+    bool derived = false;
+    if (delta_mode == 1 || delta_mode == 2) {
+        DeltaState &st = g_delta[e];
+        derived = derive_hand_off(e, g, st, delta_mode, nnz);
+        if (!derived) nnz = hand_off_graph(e, g);
+        remember_rows(st, g);
+    } else {
+        nnz = hand_off_graph(e, g);   // pack + copy, overlapped
+    }
     const auto t2 = clk::now();
     // The scores come straight from the device: its sigmoid evaluates glibc's expf algorithm in
     // fp64 (csrc/expf_glibc.h), bit-identical to the host libm on x86-64 hosts with FMA.  Hosts
@@ -430,9 +516,10 @@ void model::predict(const matrix &in, matrix &out, const reduction_graph<Tn, Tw>
         gnnvc_get_info(e, "long_rows", &longs);
         gnnvc_get_info(e, "sorted_tiles_active", &sorted);
         std::fprintf(stderr,
-                     "gnnvc predict n=%u nnz=%llu hand-off=%.3fms forward=%.3fms (device %.3fms: %.3f %.3f %.3f; "
+                     "gnnvc predict n=%u nnz=%llu hand-off=%.3fms%s forward=%.3fms (device %.3fms: %.3f %.3f %.3f; "
                      "long rows %ld, sorted tiles %ld)\n",
-                     n, (unsigned long long)nnz, ms(t0, t2), ms(t2, t3), dev_ms, st[0], st[1], st[2], longs, sorted);
+                     n, (unsigned long long)nnz, ms(t0, t2), derived ? " (derived on the device)" : "", ms(t2, t3), dev_ms, st[0],
+                     st[1], st[2], longs, sorted);
     }
 }
 

@@ -35,6 +35,9 @@ class reduction_graph {
     }
 
     Tn size() const { return (Tn)weights_.size(); }
+    // the reference keeps, per vertex, the label it had when it was created (include/reduction_graph.hpp:134-139); this
+    // read-only mirror never relabels, so a vertex's original label is its index
+    Tn get_org_label(Tn u) const { return u; }
     Tn D(Tn u) const { return (Tn)(offsets_[u + 1] - offsets_[u]); }
     Tw W(Tn u) const { return weights_[u]; }
     Tw NW(Tn u) const { return nbr_weights_[u]; }

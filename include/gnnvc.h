@@ -172,6 +172,29 @@ int gnnvc_graph_staging(gnnvc_engine *e, uint32_t n, uint64_t nnz, uint32_t **ro
 int gnnvc_staged_columns_ready(gnnvc_engine *e, uint64_t first, uint64_t count);
 int gnnvc_commit_staged_graph(gnnvc_engine *e);
 
+/* The NEXT graph derived from the one the device already holds.  Between two predict calls of the
+ * reference's driver (src/GNN_VC.cpp:171-192) the graph shrinks — vertices leave, lists lose entries, survivors are
+ * renumbered in order (include/reduction_graph.hpp:537-587) — and the only additions are the vertices its folds
+ * create, which carry the largest ids and therefore sit at the END of their neighbours' lists (:335-398).  So a row of
+ * the next graph is: the surviving entries of its old row, in order, renumbered — plus a short tail; a new vertex's
+ * row is all tail.  Protocol (the resident graph must have come through gnnvc_upload_graph / the staged calls / a
+ * previous derive, i.e. live in engine-owned memory):
+ *   1. gnnvc_derive_graph_begin(e, n_new, old_row, rowptr_new, tail): old_row[u] = the row of the RESIDENT graph that
+ *      vertex u of the next graph was, or GNNVC_NEW_VERTEX; rowptr_new = the next graph's 32-bit row pointers (n_new + 1).
+ *      The device counts every row's surviving old entries and returns tail[u] = degree(u) - survivors: how many
+ *      trailing entries of u's list it cannot derive.  An inconsistent mapping (a row with more survivors than its new
+ *      degree, an old row claimed twice, ...) is GNNVC_ERR_INVALID and leaves the resident graph as it was;
+ *   2. gnnvc_derive_graph_commit(e, tail_cols, n_tail, w, nw): the last tail[u] entries of every row, row after row
+ *      (n_tail = their total), and the next graph's W / NW.  The engine assembles the CSR on the device, runs the same
+ *      checks as an upload and makes it current.
+ * What crosses the bus: 8 bytes per vertex + the tails, instead of 4 bytes per adjacency entry.  What the engine
+ * cannot check is that the caller's lists really ARE "survivors + tail" (it never sees them): gnnvc_graph_row_hashes
+ * returns a 64-bit FNV-1a hash of every resident row (column ids in stored order) for callers that want to compare. */
+#define GNNVC_NEW_VERTEX 0xFFFFFFFFu
+int gnnvc_derive_graph_begin(gnnvc_engine *e, uint32_t n_new, const uint32_t *old_row, const uint32_t *rowptr_new, uint32_t *tail);
+int gnnvc_derive_graph_commit(gnnvc_engine *e, const uint32_t *tail_cols, uint64_t n_tail, const uint32_t *w, const uint32_t *nw);
+int gnnvc_graph_row_hashes(gnnvc_engine *e, uint64_t *hashes);
+
 /* ---- forward ----------------------------------------------------------------
  * gnnvc_forward replaces model::predict (reference src/gnn_inference.cpp:67-81)
  * for host callers: x is n x in_width (n x 1 for the shipped model:

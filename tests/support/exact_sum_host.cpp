@@ -38,6 +38,7 @@ float stream_sum(const float *v, size_t n, int B, Stats *st) {
                 if (idx < pos || idx >= n) continue;   // consumed already / past the end: no-op
                 if (ok) xsum::append<FD>(run, f2u(v[idx]), E, bad);
             }
+            xsum::saturate(run);
             lane_map[l] = run;
             lane_bad[l] = bad;
             nbad += bad;

@@ -220,3 +220,18 @@ int gnnvc_sgemm(gnnvc_engine *e, int ta, int tb, uint32_t m, uint32_t n, uint32_
         }
     return GNNVC_OK;
 }
+
+/* the device-side derivation of the next graph has no counterpart in this CPU double: the host wrapper falls back to
+ * its full hand-off when these refuse */
+int gnnvc_derive_graph_begin(gnnvc_engine *e, uint32_t n_new, const uint32_t *old_row, const uint32_t *rowptr_new, uint32_t *tail) {
+    (void)e; (void)n_new; (void)old_row; (void)rowptr_new; (void)tail;
+    return GNNVC_ERR_UNSUPPORTED;
+}
+int gnnvc_derive_graph_commit(gnnvc_engine *e, const uint32_t *tail_cols, uint64_t n_tail, const uint32_t *w, const uint32_t *nw) {
+    (void)e; (void)tail_cols; (void)n_tail; (void)w; (void)nw;
+    return GNNVC_ERR_UNSUPPORTED;
+}
+int gnnvc_graph_row_hashes(gnnvc_engine *e, uint64_t *hashes) {
+    (void)e; (void)hashes;
+    return GNNVC_ERR_UNSUPPORTED;
+}

@@ -129,3 +129,22 @@ def test_cli_fast_io_driver_identical_result(manifest, tmp_path):
     fields = r.stdout.strip().split(",")
     assert fields[0] == "er100k" and int(fields[1]) == spec["cli"]["final_cost"]
     assert hashlib.md5((tmp_path / "er100k.out").read_bytes()).hexdigest() == spec["cli"]["result_md5"]
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_cli_with_graphs_derived_on_the_device(manifest, tmp_path, mode):
+    """GNNVC_DELTA=1|2: from the second predict call on, the host wrapper has the engine derive the
+    next graph from the resident one (gnnvc_derive_graph_begin/_commit) instead of uploading it.  Same cover, byte for
+    byte — through every predict call of the run, fold vertices and relabelling included."""
+    import os
+    spec = manifest["er100k"]
+    g = _graph(spec)
+    (tmp_path / "er100k.graph").write_text(gg.metis_text(g))
+    env = dict(os.environ, GNNVC_DELTA=mode, GNNVC_TRACE="1")
+    r = subprocess.run([str(CLI), str(tmp_path / "er100k.graph"), str(tmp_path / "er100k.out"), "0", "-1", "0"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    fields = r.stdout.strip().split(",")
+    assert fields[0] == "er100k" and int(fields[1]) == spec["cli"]["final_cost"]
+    assert hashlib.md5((tmp_path / "er100k.out").read_bytes()).hexdigest() == spec["cli"]["result_md5"]
+    assert r.stderr.count("derived on the device") >= 3, r.stderr[-3000:]     # the path was really taken

@@ -1115,6 +1115,106 @@ def test_stage_input_announcement_does_not_outlive_its_input(model_text, oracle_
         e.close()
 
 
+# ---------------------------------------------------------------- the next graph derived on the device (f-1)
+
+def _shrunk_graph(g, rng, keep_frac, new_vertices, fan):
+    """(g1, old_row): what the reference's driver hands predict next — survivors of g renumbered in order, their
+    lists filtered, plus `new_vertices` fold vertices (largest ids) each adjacent to ~fan survivors / earlier new ones."""
+    keep = rng.random(g.n) < keep_frac
+    new_of = np.full(g.n, -1, dtype=np.int64)
+    ns = int(keep.sum())
+    new_of[keep] = np.arange(ns)
+    rp = g.rowptr.astype(np.int64)
+    src = np.repeat(np.arange(g.n), np.diff(rp))
+    dst = g.col.astype(np.int64)
+    m = keep[src] & keep[dst] & (src < dst)
+    a, b = new_of[src[m]], new_of[dst[m]]
+    ea, eb = [a], [b]
+    for k in range(new_vertices):
+        v = ns + k
+        nb = np.unique(rng.integers(0, v, size=min(fan, v))) if v else np.zeros(0, dtype=np.int64)
+        ea.append(nb)
+        eb.append(np.full(nb.size, v, dtype=np.int64))
+    a, b = np.concatenate(ea), np.concatenate(eb)
+    n1 = ns + new_vertices
+    key = np.unique(a * n1 + b)
+    w = rng.integers(20, 121, size=n1)
+    g1 = gg.csr_from_pairs(n1, key // n1, key % n1, w)
+    old_row = np.full(n1, 0xFFFFFFFF, dtype=np.uint32)
+    old_row[:ns] = np.nonzero(keep)[0]
+    return g1, old_row
+
+
+def _fnv_rows(g):
+    out = np.empty(g.n, dtype=np.uint64)
+    rp = g.rowptr.astype(np.int64)
+    with np.errstate(over="ignore"):
+        for u in range(g.n):
+            h = np.uint64(1469598103934665603)
+            for c in g.col[rp[u]:rp[u + 1]]:
+                h = (h ^ np.uint64(c)) * np.uint64(1099511628211)
+            out[u] = h
+    return out
+
+
+def test_graph_derived_on_the_device_equals_an_upload(model_text, oracle_model):
+    """gnnvc_derive_graph_begin / _commit: the engine builds the next graph from the CSR it already holds, the caller
+    ships the row mapping and the tails only.  The result is the graph an upload would have produced: same row hashes,
+    same forward bits; chained twice; hubs (long / giant rows) included."""
+    import gnn_mwvc_amd as G
+    rng = np.random.default_rng(17)
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_option("long_row_threshold", 64)
+        e.set_option("giant_row_threshold", 1000)
+        for g0 in (gg.erdos_renyi(4000, 24000, 5), gg.hub_graph(20000, 60000, 3, 4096, seed=7)):
+            e.upload_graph(g0)
+            g = g0
+            for step, (frac, nv, fan) in enumerate(((0.7, 50, 40), (0.5, 7, 300), (1.0, 0, 0))):
+                g1, old_row = _shrunk_graph(g, rng, frac, nv, fan)
+                tail = e.derive_graph(g1, old_row)
+                ns = int((old_row != 0xFFFFFFFF).sum())
+                deg1 = np.diff(g1.rowptr.astype(np.int64))
+                # survivors keep only new-vertex ids in their tails; new vertices' lists are all tail
+                want_tail = np.array([int((g1.col[int(g1.rowptr[u]):int(g1.rowptr[u + 1])] >= ns).sum()) if u < ns else deg1[u]
+                                      for u in range(g1.n)], dtype=np.uint32)
+                assert np.array_equal(tail, want_tail), step
+                if g1.n <= 5000:
+                    assert np.array_equal(e.row_hashes(), _fnv_rows(g1)), step
+                e.set_weight_scale(g1.ws)
+                oracle_model.set_weight_scale(g1.ws)
+                _, logits = e.forward(g1.x())
+                assert np.array_equal(bits(logits[:, 0]), bits(oracle_model.logits(g1))), step
+                g = g1
+        # inconsistent mappings are refused and leave the resident graph usable
+        g1, old_row = _shrunk_graph(g, rng, 0.6, 3, 10)
+        bad = old_row.copy()
+        bad[1] = bad[0]
+        with pytest.raises(G.GnnvcError):
+            e.derive_graph(g1, bad)
+        bad = old_row.copy()
+        bad[0] = g.n + 7
+        with pytest.raises(G.GnnvcError):
+            e.derive_graph(g1, bad)
+        shuffled = old_row.copy()
+        shuffled[: 100] = shuffled[: 100][::-1]          # rows mapped to the wrong old rows: survivors exceed the new degree somewhere
+        try:
+            e.derive_graph(g1, shuffled)
+            derived_wrong = True
+        except G.GnnvcError:
+            derived_wrong = False
+        if derived_wrong:                                  # the engine cannot see the caller's lists: the hashes tell
+            assert not np.array_equal(e.row_hashes(), _fnv_rows(g1)) or g1.n > 5000
+            e.upload_graph(g)
+        _, logits = e.forward(g.x()) if not derived_wrong else e.forward(g.x())
+        oracle_model.set_weight_scale(g.ws)
+        e.set_weight_scale(g.ws)
+        _, logits = e.forward(g.x())
+        assert np.array_equal(bits(logits[:, 0]), bits(oracle_model.logits(g)))
+    finally:
+        e.close()
+
+
 # ---------------------------------------------------------------- dense layers: MFMA vs VALU
 
 @pytest.mark.parametrize("mfma", [0, 1, 2])
