@@ -18,7 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=10_000_000)
     ap.add_argument("--m", type=int, default=100_000_000)
-    ap.add_argument("--forwards", type=int, default=4)   # the plans are built on the second forward; the last one is steady state
+    ap.add_argument("--forwards", type=int, default=5)   # the plans are built on the second forward; the last one is steady state
     a = ap.parse_args()
     import torch
     import gnn_mwvc_amd as G

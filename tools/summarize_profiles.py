@@ -54,6 +54,19 @@ for p in newest.values():
             cur = agg[k].get(r["Counter_Name"])
             if cur is None or did >= cur[0]:
                 agg[k][r["Counter_Name"]] = (did, float(r["Counter_Value"]))
+# One steady-state FORWARD: the engine zero-fills the two pad rows (k_zero_row x 2) at the start of every forward, so the
+# dispatches from the last such pair to the end of the run are exactly the last forward of the probe (kernels run one
+# after the other under --pmc, side-stream kernels included).
+forward = collections.defaultdict(float)
+for p in newest.values():
+    rows = [r for r in csv.DictReader(open(p)) if "gnnvc" in r["Kernel_Name"]]
+    zero_ids = sorted({int(r["Dispatch_Id"]) for r in rows if "k_zero_row" in r["Kernel_Name"]})
+    if len(zero_ids) < 2:
+        continue
+    start = zero_ids[-2]
+    for r in rows:
+        if int(r["Dispatch_Id"]) >= start:
+            forward[r["Counter_Name"]] += float(r["Counter_Value"])
 summary = {}
 for k, ctrs in sorted(agg.items()):
     m = {c: v for c, (_, v) in ctrs.items()}
@@ -71,5 +84,15 @@ for k, ctrs in sorted(agg.items()):
         d["mfma_util"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * kernel_cycles)
         d["mfma_instructions"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / 64.0   # 64 cycles per v_mfma_f32_32x32x2_f32
     summary[k] = d
+sys.path.insert(0, str(ROOT))
+import bench  # noqa: E402  (source_hash: the identity of the kernels these counters were taken from)
+meta = {"source_hash": bench.source_hash(), "probe": "tools/pmc_probe.py (metric graph), last of its forwards",
+        "forward_counters": dict(forward)}
+if "TCC_EA0_RDREQ_sum" in forward and "WRITE_SIZE" in forward:
+    meta["forward_fabric_read_bytes"] = forward["TCC_EA0_RDREQ_sum"] * 128
+    meta["forward_hbm_write_bytes"] = forward["WRITE_SIZE"] * 1024
+    meta["forward_traffic_bytes"] = meta["forward_fabric_read_bytes"] + meta["forward_hbm_write_bytes"]
+summary["_meta"] = meta
 (DST / "pmc_summary.json").write_text(json.dumps(summary, indent=1, sort_keys=True) + "\n")
-print(json.dumps({k: {c: round(v, 3) for c, v in d.items() if c in ("traffic_bytes", "fabric_read_bytes", "hbm_write_bytes", "mfma_util")} for k, d in summary.items()}, indent=1))
+print(json.dumps({k: {c: round(v, 3) for c, v in d.items() if c in ("traffic_bytes", "fabric_read_bytes", "hbm_write_bytes", "mfma_util")} for k, d in summary.items() if k != "_meta"}, indent=1))
+print(json.dumps({k: v for k, v in meta.items() if k != "forward_counters"}, indent=1))
