@@ -136,6 +136,7 @@ def main() -> int:
     ap.add_argument("--hub-mode", type=int, default=0, help="1 = tolerance mode for long rows (tree sums); never the default")
     ap.add_argument("--side-streams", type=int, default=1, help="0 = long / giant rows on the main stream (profiling: standalone kernel times)")
     ap.add_argument("--kernel-trace", type=int, default=1, help="HIP events around every main-stream kernel of the timed forwards")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="any engine option (A/B runs), repeatable")
     ap.add_argument("--sorted-tiles", type=int, default=-1, help="degree-sorted tiles: -1 auto, 0 off, 1 on")
     ap.add_argument("--sorted-long-threshold", type=int, default=0)
     ap.add_argument("--mfma", type=int, default=-1, help="dense layers: 0 VALU, 1 MFMA everywhere, 2 MFMA in the 16-wide stages (default)")
@@ -231,6 +232,9 @@ def main() -> int:
         e.set_option("sorted_tiles", args.sorted_tiles)
         if args.sorted_long_threshold > 0:
             e.set_option("sorted_long_row_threshold", args.sorted_long_threshold)
+        for kv in args.opt:
+            k, _, v = kv.partition("=")
+            e.set_option(k, int(v))
         for k, v in opts.items():
             e.set_option(k, v)
         return e
@@ -441,6 +445,11 @@ def main() -> int:
 
     traffic, traffic_src = measured_traffic(args.workload) if not multi else (None, None)
     plans = {"compact_gather_f16": bool(eng.get_info("compact_gather_active")),
+             "compact_gather_mapped": bool(eng.get_info("compact_gather_mapped")),
+             "compact_gather_last": {"fit": bool(eng.get_info("compact_gather_last_ok")), "passes": eng.get_info("compact_gather_last_passes"),
+                                     "dirty_rows": eng.get_info("compact_gather_last_dirty"), "column_blocks": eng.get_info("compact_gather_blocks"),
+                                     "steps": eng.get_info("compact_gather_steps"), "rows": eng.get_info("compact_gather_mapped_rows"),
+                                     "entries": eng.get_info("compact_gather_mapped_entries")},
              "lds_table_stage0": bool(eng.get_info("lds_table_active")),
              "blocked_stage0": bool(eng.get_info("blocked_stage0_active")),
              "column_blocks": eng.get_info("blocked_blocks"), "block_cols": eng.get_info("block_cols"),

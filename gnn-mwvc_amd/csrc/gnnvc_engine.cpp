@@ -129,8 +129,18 @@ struct gnnvc_engine {
     // compact-table plan of the 16-wide stages (built like the LDS-table plan, on the graph's second forward)
     int opt_compact = 1;            // 0 = off, 1 = when it applies, 2 = also on skewed graphs
     bool c4_ready = false, c4_tried = false;
-    uint32_t c4_rows = 0, c4_chunks = 0, c4_steps_total = 0, c4_block = 0, c4_last_entry = 0;
+    uint32_t c4_rows = 0, c4_chunks = 0, c4_steps_total = 0, c4_block = 0, c4_last_entry = 0, c4_nblocks = 0;
     DevBuf<uint32_t> c4_entries, c4_segcnt, c4_stepptr, c4_stepcnt, c4_desc;
+    // skewed graphs: the plan covers the rows below the long-row threshold, dealt from the degree-sorted list to slices of
+    // equal weight (c4_rowmap), over column blocks of equal entry mass (c4_bstart), with up to c4_max_passes tables per input
+    bool c4_mapped = false;
+    uint32_t c4_max_passes = 1, c4_nslices = 0, c4_mapped_rows = 0;
+    uint64_t c4_mapped_entries = 0;
+    DevBuf<uint32_t> c4_rowmap, c4_first, c4_bstart, c4_map_vertex;
+    DevBuf<uint4> c4_map_meta;
+    int opt_compact_skewed = 0;      // option "compact_skewed": 1 = skewed graphs take the mapped compact-table plan (measured: no gain on
+                                     // R-MAT-22 — three passes at ~110 G entries/s tie with the gathering kernel — so it is opt-in)
+    uint32_t opt_compact_passes = 3; // option "compact_passes": tables per input on skewed graphs (1..3)
     DevBuf<uint4> c4_steps;
     DevBuf<float> c4_table, c4_acc, c4_agg16;
     DevBuf<uint32_t> c4_marks;            // dirty-row slots handed out after each round of the aggregation grid
@@ -145,6 +155,7 @@ struct gnnvc_engine {
     const float *c4_prepared_in = nullptr;   // ... as found at this address
     int c4_fused_for = -1;          // stage whose input statistics (and table) the previous stage kernel of this forward produced
     int c4_last_desc = 0;           // word offset in c4_desc of the plan's last launch (tests / tools)
+    static constexpr int kDescWords = 16;   // per consumer stage (see k_c4_choose); the build flag follows the last stage's
 
     // option "mfma_dense": dense layers on the matrix cores (bit-identical to the VALU path).
     // 0 = VALU everywhere, 1 = MFMA everywhere, 2 = MFMA in the F = 16 stages only (default:
@@ -502,6 +513,36 @@ int find_long(gnnvc_engine *e) {
     return find_giant(e);
 }
 
+// The rows of [lo, hi) below the long-row threshold of the 16-wide stages, heaviest degree class first: vertex[] (+ per
+// row {first entry, end, W, NW} in meta[]); listed = how many, zero_rows = how many of them (the list's tail) have no entry.
+int sort_by_degree(gnnvc_engine *e, uint32_t lo, uint32_t hi, DevBuf<uint32_t> &vertex, DevBuf<uint4> &meta, uint32_t &listed,
+                   uint32_t &zero_rows) {
+    const GraphDev &g = e->g;
+    const uint32_t lt = e->thresh_f16;
+    const uint32_t bins = lt < 4096u ? lt + 1 : 4096u;
+    HIP_TRY(e, e->srt_hist.reserve(bins));
+    HIP_TRY(e, vertex.reserve(hi - lo));
+    HIP_TRY(e, meta.reserve(hi - lo));
+    // the scan's host round trip goes through page-locked memory: an async copy to or from
+    // pageable memory above a few KB pins it on the fly, which costs milliseconds the first time
+    HIP_TRY(e, e->pin_small.reserve(2 * (size_t)bins));
+    uint32_t *hist = e->pin_small.p, *start = e->pin_small.p + bins;
+    HIP_TRY(e, gnnvc::degree_histogram(g, lo, hi, lt, bins, e->srt_hist.p, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(hist, e->srt_hist.p, bins * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    uint32_t run = 0;
+    for (uint32_t d = bins; d-- > 0;) {   // heaviest degree class first
+        start[d] = run;
+        run += hist[d];
+    }
+    zero_rows = hist[0];
+    HIP_TRY(e, hipMemcpyAsync(e->srt_hist.p, start, bins * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, gnnvc::degree_scatter(g, lo, hi, lt, bins, e->srt_hist.p, vertex.p, meta.p, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));   // `start` is read by the async copy above
+    listed = run;
+    return GNNVC_OK;
+}
+
 // Degree-sorted tile order for rows [lo, hi) of the current graph.  A natural tile of 64
 // consecutive rows costs max-degree gather rounds; when the measured cost (64 x sum of
 // per-tile maxima) exceeds twice the useful work, tiles are formed from a degree-sorted list
@@ -528,29 +569,10 @@ int ensure_sorted(gnnvc_engine *e, uint32_t lo, uint32_t hi) {
     sr.n = 0;
     sr.stamp = ++e->srt_clock;
     e->srt_cur = victim;
-    const GraphDev &g = e->g;
-    if (!e->sorted_wanted || hi <= lo || g.nnz == 0) return GNNVC_OK;
-    const uint32_t lt = e->thresh_f16;
-    const uint32_t bins = lt < 4096u ? lt + 1 : 4096u;
-    HIP_TRY(e, e->srt_hist.reserve(bins));
-    HIP_TRY(e, sr.vertex.reserve(hi - lo));
-    HIP_TRY(e, sr.meta.reserve(hi - lo));
-    // the scan's host round trip goes through page-locked memory: an async copy to or from
-    // pageable memory above a few KB pins it on the fly, which costs milliseconds the first time
-    HIP_TRY(e, e->pin_small.reserve(2 * (size_t)bins));
-    uint32_t *hist = e->pin_small.p, *start = e->pin_small.p + bins;
-    HIP_TRY(e, gnnvc::degree_histogram(g, lo, hi, lt, bins, e->srt_hist.p, e->stream));
-    HIP_TRY(e, hipMemcpyAsync(hist, e->srt_hist.p, bins * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    uint32_t run = 0;
-    for (uint32_t d = bins; d-- > 0;) {   // heaviest degree class first
-        start[d] = run;
-        run += hist[d];
-    }
-    HIP_TRY(e, hipMemcpyAsync(e->srt_hist.p, start, bins * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(e, gnnvc::degree_scatter(g, lo, hi, lt, bins, e->srt_hist.p, sr.vertex.p, sr.meta.p, e->stream));
-    HIP_TRY(e, hipStreamSynchronize(e->stream));   // `start` is read by the async copy above
-    sr.n = run;
+    if (!e->sorted_wanted || hi <= lo || e->g.nnz == 0) return GNNVC_OK;
+    uint32_t zero_rows = 0;
+    int rc = sort_by_degree(e, lo, hi, sr.vertex, sr.meta, sr.n, zero_rows);
+    if (rc) return rc;
     sr.use = true;
     return GNNVC_OK;
 }
@@ -665,10 +687,17 @@ int build_lds_table_impl(gnnvc_engine *e) {
 
 // Compact-table plan of the 16-wide stages (kernels: k_c4_*): the same (chunk, column block, step) layout
 // as the LDS-table plan at 2 MiB column blocks.  Whether a forward's input really has at most four live
-// columns is decided on the device at every launch (k_c4_choose / k_c4_compact).
-int build_compact_impl(gnnvc_engine *e, uint32_t base, uint32_t end) {
+// columns (per pass) is decided on the device at every launch (k_c4_choose / k_c4_compact).
+//
+// Degree-uniform graphs: slices of consecutive rows, column blocks of one width, one table per input.
+// Skewed graphs (sorted tiles wanted, or long rows present; whole-graph plans only): the rows below the long-row
+// threshold are dealt from the degree-sorted list to slices of equal weight, the column blocks are cut at equal
+// entry mass (hub columns sit in narrow blocks), and an input may take up to three tables — the long and giant rows
+// stay with their own kernels beside the plan.
+int build_compact_impl(gnnvc_engine *e, uint32_t base, uint32_t end, bool allow_mapped) {
     e->c4_ready = false;
     e->c4_tried = true;
+    e->c4_mapped = false;
     e->c4_prepared_stage = -1;
     const GraphDev &g = e->g;
     if (end > g.n) end = g.n;
@@ -679,20 +708,52 @@ int build_compact_impl(gnnvc_engine *e, uint32_t base, uint32_t end) {
     for (size_t st = 1; st < e->stages.size(); ++st)
         if (e->stages[st].f != 16) return GNNVC_OK;
     if (g.n < e->opt_blocked_min_n || g.nnz == 0 || g.nnz >= (1ull << 31)) return GNNVC_OK;
-    if (e->opt_compact < 2 && (e->sorted_wanted || e->n_long > 0)) return GNNVC_OK;
-    if (e->n_long > 0) return GNNVC_OK;   // (the long-row kernels write their rows themselves)
+    const bool skewed = e->sorted_wanted || e->n_long > 0;
+    const bool mapped = skewed && e->opt_compact < 2 && e->opt_compact_skewed && allow_mapped && base == 0 && end == g.n && !g.sliced();
+    if (skewed && !mapped && e->opt_compact < 2) return GNNVC_OK;
+    if (!mapped && e->n_long > 0) return GNNVC_OK;   // (the long-row kernels write their rows themselves)
     // a chunk = 16 slices (one per wave of the workgroup that sums it); the plan is laid out per slice
     const uint32_t nsl = gnnvc::compact_slices();
     uint32_t max_rows = gnnvc::compact_max_rows();
     if (e->opt_plan_chunk_rows) max_rows = std::min(max_rows, std::max(nsl, e->opt_plan_chunk_rows / nsl * nsl));
-    uint32_t chunks = (span + max_rows - 1) / max_rows;
+    uint32_t plan_rows = span;          // rows the plan sums
+    uint64_t range_nnz = g.nnz;         // ... and their entries
+    if (mapped) {
+        uint32_t listed = 0, zero_rows = 0;
+        int rc = sort_by_degree(e, 0, g.n, e->c4_map_vertex, e->c4_map_meta, listed, zero_rows);
+        if (rc) return rc;
+        plan_rows = listed - zero_rows;   // (rows without entries keep the zeros their sums are initialised with)
+        if (plan_rows == 0) return GNNVC_OK;
+    }
+    uint32_t chunks = (plan_rows + max_rows - 1) / max_rows;
     chunks = (chunks + 255u) / 256u * 256u;
-    uint32_t rows = (span + chunks - 1) / chunks;
+    uint32_t rows = (plan_rows + chunks - 1) / chunks;
     rows = (rows + nsl - 1) / nsl * nsl;
-    chunks = (span + rows - 1) / rows;
+    chunks = (plan_rows + rows - 1) / rows;
     const uint32_t slice_rows = rows / nsl, slices = chunks * nsl;
-    uint64_t range_nnz = g.nnz;
-    if (span != g.n) {   // the range's share of the entries (on a slice g.nnz counts the slice's entries only)
+    HIP_TRY(e, e->pin_small.reserve((size_t)slices + 4100));
+    gnnvc::PlanMap pm;
+    if (mapped) {
+        HIP_TRY(e, e->c4_rowmap.reserve((size_t)slices * slice_rows));
+        HIP_TRY(e, e->c4_first.reserve((size_t)slices + 1));
+        HIP_TRY(e, e->c4_stepcnt.reserve(slices));
+        HIP_TRY(e, gnnvc::deal_rows(g, e->c4_map_vertex.p, plan_rows, slice_rows, slices, e->c4_rowmap.p, e->c4_stepcnt.p, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, e->c4_stepcnt.p, slices * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        uint64_t run = 0;
+        for (uint32_t c = 0; c < slices; ++c) {
+            const uint32_t w = e->pin_small.p[c];
+            e->pin_small.p[c] = (uint32_t)run;
+            run += w;
+        }
+        e->pin_small.p[slices] = (uint32_t)run;
+        range_nnz = run;
+        if (range_nnz == 0) return GNNVC_OK;
+        HIP_TRY(e, hipMemcpyAsync(e->c4_first.p, e->pin_small.p, ((size_t)slices + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));   // pin_small is reused below
+        pm.rowmap = e->c4_rowmap.p;
+        pm.first = e->c4_first.p;
+    } else if (span != g.n) {   // the range's share of the entries (on a slice g.nnz counts the slice's entries only)
         uint32_t rp[2] = {0, 0};
         HIP_TRY(e, hipMemcpyAsync(&rp[0], g.rowptr + base, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(e, hipMemcpyAsync(&rp[1], g.rowptr + end, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
@@ -704,30 +765,63 @@ int build_compact_impl(gnnvc_engine *e, uint32_t base, uint32_t end) {
     // the spread — a segment of 193 costs a second step that the other waves of the workgroup wait for; measured
     // on the metric graph: 0.70 / 0.78 / 0.83 / 0.88 / 0.93 of a step -> 4.71 / 4.66 / 4.65 / 4.82 / 5.26 ms), but at
     // most 160 K vertices = 2.5 MiB of table, which still sits in an XCD's 4 MiB L2 while its 32 CUs sweep it
-    uint32_t bc = gnnvc::compact_block();
-    {
-        const double per_slice = (double)range_nnz / slices;
-        const double want = (gnnvc::compact_step() * 5.0 / 6.0) * g.n / std::max(per_slice, 1.0);
+    const double per_slice = (double)range_nnz / slices;
+    const double fill = gnnvc::compact_step() * 5.0 / 6.0;
+    uint32_t bc = gnnvc::compact_block(), nblocks = 0;
+    if (!mapped) {
+        const double want = fill * g.n / std::max(per_slice, 1.0);
         bc = (uint32_t)std::min(160.0 * 1024, std::max(32.0 * 1024, want)) / 1024u * 1024u;
+        nblocks = (g.n + bc - 1) / bc;
+    } else {
+        // blocks of equal entry mass: on a symmetric adjacency the entries that point INTO columns [a, b) are as many as
+        // the entries of rows [a, b), so the cuts are read off rowptr (for any other adjacency they are a heuristic —
+        // nothing but the step fill depends on them).  Widths between 256 columns and 160 K.
+        const uint32_t maxw = 160u * 1024u, minw = 256u;
+        const double nb_want = std::max(1.0, per_slice / fill);
+        const unsigned long long target = (unsigned long long)std::max(1.0, (double)g.nnz / nb_want);
+        const uint32_t ncand = (uint32_t)std::min<unsigned long long>(g.nnz / target + 2, 4096);
+        HIP_TRY(e, e->c4_bstart.reserve(4100));
+        HIP_TRY(e, gnnvc::mass_bounds(g, target, ncand, e->c4_bstart.p, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, e->c4_bstart.p, ncand * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        std::vector<uint32_t> bs{0u};
+        auto cut = [&](uint32_t at) {
+            while (at - bs.back() > maxw) bs.push_back(bs.back() + maxw);
+            if (at > bs.back()) bs.push_back(at);
+        };
+        for (uint32_t k = 1; k < ncand; ++k) {
+            const uint32_t at = std::min(e->pin_small.p[k], g.n);
+            if (at >= g.n) break;
+            if (at - bs.back() >= minw) cut(at);
+        }
+        if (g.n - bs.back() < minw && bs.size() > 1) bs.pop_back();   // no sliver at the end
+        cut(g.n);                                                      // bs.back() == g.n: the end of the last block
+        nblocks = (uint32_t)bs.size() - 1;
+        if (nblocks == 0 || nblocks > 4096) return GNNVC_OK;
+        std::memcpy(e->pin_small.p, bs.data(), bs.size() * sizeof(uint32_t));
+        HIP_TRY(e, hipMemcpyAsync(e->c4_bstart.p, e->pin_small.p, bs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        pm.bstart = e->c4_bstart.p;
+        bc = maxw;   // (the widest a block may be: what the entry encoding has to hold)
     }
-    const uint32_t nblocks = (g.n + bc - 1) / bc;
     if (nblocks > 4096) return GNNVC_OK;
     // every (slice, block) segment starts at a multiple of 4 entries: up to 3 pad entries per segment
     const uint32_t slack = 3u * nblocks + 4u;
-    const uint64_t entry_cap = g.nnz + (uint64_t)slack * slices + 8;
+    const uint64_t entry_cap = (mapped ? range_nnz : g.nnz) + (uint64_t)slack * slices + 8;
     if (entry_cap >= (1ull << 31)) return GNNVC_OK;
-    HIP_TRY(e, e->c4_desc.reserve(24));   // 8 words per consumer stage (1, 2), word 16 = build flag
+    const uint32_t passes = mapped ? std::min(std::max(e->opt_compact_passes, 1u), gnnvc::compact_max_passes()) : 1u;
+    constexpr int kFlagWord = 2 * gnnvc_engine::kDescWords;   // after the descriptors of the two consumer stages
+    HIP_TRY(e, e->c4_desc.reserve(kFlagWord + 8));
     HIP_TRY(e, e->c4_counts.reserve(16));
     HIP_TRY(e, e->c4_emit_counts.reserve(gnnvc::kEmitCounters));
     HIP_TRY(e, e->c4_segcnt.reserve((size_t)slices * nblocks));
     HIP_TRY(e, e->c4_stepcnt.reserve(slices));
     HIP_TRY(e, e->c4_stepptr.reserve((size_t)slices + 2));
-    HIP_TRY(e, e->pin_small.reserve((size_t)slices + 3));
-    uint32_t *flag = e->c4_desc.p + 16;
-    HIP_TRY(e, hipMemsetAsync(e->c4_desc.p, 0, 24 * sizeof(uint32_t), e->stream));
-    HIP_TRY(e, gnnvc::lds_table_count(g, slice_rows, slices, nblocks, bc, e->c4_segcnt.p, flag, e->stream, base, end));
+    uint32_t *flag = e->c4_desc.p + kFlagWord;
+    HIP_TRY(e, hipMemsetAsync(e->c4_desc.p, 0, (kFlagWord + 8) * sizeof(uint32_t), e->stream));
+    HIP_TRY(e, gnnvc::lds_table_count(g, slice_rows, slices, nblocks, bc, e->c4_segcnt.p, flag, e->stream, base, end, pm));
     HIP_TRY(e, gnnvc::lds_table_steps(g, slice_rows, slices, nblocks, e->c4_segcnt.p, nullptr, e->c4_stepcnt.p, nullptr, false, e->stream,
-                                      base, end, gnnvc::compact_step(), slack));
+                                      base, end, gnnvc::compact_step(), slack, bc, pm));
     HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, e->c4_stepcnt.p, slices * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipMemcpyAsync(e->pin_small.p + slices, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -743,9 +837,11 @@ int build_compact_impl(gnnvc_engine *e, uint32_t base, uint32_t end) {
     ptr[slices + 1] = (uint32_t)total;   // slice `slices`: the empty one idle waves walk
     HIP_TRY(e, e->c4_steps.reserve(total + 8));
     HIP_TRY(e, e->c4_entries.reserve(entry_cap));
-    HIP_TRY(e, e->c4_table.reserve(((size_t)g.n + 1) * 4));
+    HIP_TRY(e, e->c4_table.reserve(((size_t)g.n + 1) * 4 * passes));
     HIP_TRY(e, e->c4_marks.reserve(64));
-    HIP_TRY(e, e->c4_acc.reserve((size_t)g.n * 4));
+    HIP_TRY(e, e->c4_acc.reserve((size_t)g.n * 4 * passes));
+    if (mapped)   // rows the plan does not hold (no entries, or long): their sums stay +0 (never read for the long ones)
+        HIP_TRY(e, hipMemsetAsync(e->c4_acc.p, 0, (size_t)g.n * 4 * passes * sizeof(float), e->stream));
     e->c4_dirty_cap = g.n;   // rows recomputed from full rows (every row could be one: the dense-only stage kernel never gathers)
     HIP_TRY(e, e->c4_dirty.reserve(e->c4_dirty_cap));
     HIP_TRY(e, e->c4_agg16.reserve((size_t)e->c4_dirty_cap * 16));
@@ -754,19 +850,44 @@ int build_compact_impl(gnnvc_engine *e, uint32_t base, uint32_t end) {
     HIP_TRY(e, hipMemsetAsync(e->c4_steps.p + total, 0, 8 * sizeof(uint4), e->stream));
     HIP_TRY(e, hipMemsetAsync(e->c4_entries.p, 0, entry_cap * sizeof(uint32_t), e->stream));   // (pad slots are read, never used)
     HIP_TRY(e, gnnvc::lds_table_steps(g, slice_rows, slices, nblocks, e->c4_segcnt.p, e->c4_stepptr.p, nullptr, e->c4_steps.p, true, e->stream,
-                                      base, end, gnnvc::compact_step(), slack));
+                                      base, end, gnnvc::compact_step(), slack, bc, pm));
     HIP_TRY(e, gnnvc::lds_table_scatter(g, slice_rows, slices, nblocks, bc, e->c4_segcnt.p, e->c4_entries.p, e->stream,
-                                        gnnvc::compact_shift(), base, end, slack));
+                                        gnnvc::compact_shift(), base, end, slack, pm));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
+    e->c4_map_meta.release();     // (only the dealing needed the list)
+    e->c4_map_vertex.release();
     e->c4_last_entry = (uint32_t)((entry_cap - 4) & ~3ull);
     e->c4_block = bc;
+    e->c4_nblocks = nblocks;
     e->c4_base = base;
     e->c4_end = end;
     e->c4_rows = rows;
     e->c4_chunks = chunks;
+    e->c4_nslices = slices;
     e->c4_steps_total = (uint32_t)total;
+    e->c4_mapped = mapped;
+    e->c4_max_passes = passes;
+    e->c4_mapped_rows = mapped ? plan_rows : 0;
+    e->c4_mapped_entries = mapped ? range_nnz : 0;
     e->c4_ready = true;
     return GNNVC_OK;
+}
+
+gnnvc::CompactPlan compact_plan(const gnnvc_engine *e) {
+    gnnvc::CompactPlan cp;
+    cp.rows_per_chunk = e->c4_rows;
+    cp.block_cols = e->c4_block;
+    cp.nblocks = e->c4_nblocks;
+    cp.plan_base = e->c4_base;
+    cp.plan_end = e->c4_end;
+    cp.last_entry = e->c4_last_entry;
+    cp.nslices = e->c4_nslices;
+    cp.max_passes = e->c4_max_passes;
+    cp.step_ptr = e->c4_stepptr.p;
+    cp.steps = e->c4_steps.p;
+    cp.entries = e->c4_entries.p;
+    cp.rowmap = e->c4_mapped ? e->c4_rowmap.p : nullptr;
+    return cp;
 }
 
 template <class F>
@@ -779,8 +900,8 @@ int timed_build(gnnvc_engine *e, F &&f) {
 }
 int build_blocked(gnnvc_engine *e) { return timed_build(e, [&] { return build_blocked_impl(e); }); }
 int build_lds_table(gnnvc_engine *e) { return timed_build(e, [&] { return build_lds_table_impl(e); }); }
-int build_compact(gnnvc_engine *e, uint32_t base = 0, uint32_t end = 0xFFFFFFFFu) {
-    return timed_build(e, [&] { return build_compact_impl(e, base, end); });
+int build_compact(gnnvc_engine *e, uint32_t base = 0, uint32_t end = 0xFFFFFFFFu, bool allow_mapped = true) {
+    return timed_build(e, [&] { return build_compact_impl(e, base, end, allow_mapped); });
 }
 
 int ensure_round_events(gnnvc_engine *e, size_t count) {
@@ -834,7 +955,7 @@ int choose_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const flo
     // its compact rows, so that stage can skip its two passes over the input.  Only the VALU variants emit.
     const int fused_in = in_forward ? e->c4_fused_for : -1;   // is THIS stage's input covered by the previous kernel?
     e->c4_fused_for = -1;
-    const bool may_emit = in_forward && e->c4_ready && !e->c4_range_mode && e->c4_base == 0 && e->c4_end == e->g.n && !longs &&
+    const bool may_emit = in_forward && e->c4_ready && !e->c4_mapped && !e->c4_range_mode && e->c4_base == 0 && e->c4_end == e->g.n && !longs &&
                           (size_t)stage + 1 < e->stages.size() && e->stages[stage + 1].f == 16 && lo == 0 && hi == e->g.n &&
                           e->opt_mfma != 1;
     c.long_thresh = (sp.f == 16) ? e->thresh_f16 : e->long_thresh;
@@ -864,11 +985,17 @@ int choose_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const flo
         const bool whole_plan = e->c4_ready && e->c4_base == 0 && e->c4_end == e->g.n;
         const bool prepared = e->c4_ready && e->c4_prepared_stage == stage && e->c4_prepared_in == in &&
                               lo >= e->c4_base && hi <= e->c4_end && hi > lo;
-        if (prepared && !longs) {
+        if (prepared && !longs && !e->c4_mapped) {
             // gnnvc_stage_input_ready wrote the table for this input: any call that fills at least half the
             // GPU with chunks takes the sums from it (smaller ones would leave most CUs idle for a chunk's time)
             const uint32_t nchunks = (hi - 1 - e->c4_base) / e->c4_rows - (lo - e->c4_base) / e->c4_rows + 1;
             if (nchunks >= 128u) c.sums = StageChoice::kCompactPrepared;
+        } else if (!e->c4_range_mode && whole_plan && e->c4_mapped) {
+            // a skewed graph's plan sums all of its rows at once: whole-graph calls only; long rows beside it as always
+            if (lo == 0 && hi == e->g.n) {
+                c.sums = StageChoice::kCompactWhole;
+                c.fused_counts = false;
+            }
         } else if (!e->c4_range_mode && whole_plan && !longs && (uint64_t)(hi - lo) * 2 >= e->g.n) {
             // worth its fixed cost (count + compact the whole input) only when this call covers most of the rows
             c.sums = StageChoice::kCompactWhole;
@@ -931,7 +1058,7 @@ int launch_main(gnnvc_engine *e, const StageChoice &c, int stage, uint32_t lo, u
     auto arm_emit = [&]() -> int {
         if (!c.emit) return GNNVC_OK;
         HIP_TRY(e, hipMemsetAsync(e->c4_emit_counts.p, 0, gnnvc::kEmitCounters * sizeof(unsigned long long), e->stream));
-        emit.spec = e->c4_desc.p + 8 * stage;          // consumer stage `stage + 1`: its 8 descriptor words
+        emit.spec = e->c4_desc.p + gnnvc_engine::kDescWords * stage;   // consumer stage `stage + 1`: its descriptor words
         emit.table = e->c4_table.p;
         emit.counts = e->c4_emit_counts.p;
         e->c4_fused_for = stage + 1;
@@ -953,8 +1080,8 @@ int launch_main(gnnvc_engine *e, const StageChoice &c, int stage, uint32_t lo, u
     const float *acc4 = nullptr;
     uint32_t *desc = nullptr;
     if (c.sums == StageChoice::kCompactPrepared || c.sums == StageChoice::kCompactWhole) {
-        desc = e->c4_desc.p + 8 * (stage - 1);
-        e->c4_last_desc = 8 * (stage - 1);
+        desc = e->c4_desc.p + gnnvc_engine::kDescWords * (stage - 1);
+        e->c4_last_desc = gnnvc_engine::kDescWords * (stage - 1);
         acc4 = e->c4_acc.p;
         const bool whole = c.sums == StageChoice::kCompactWhole;
         if (whole && !c.fused_counts) HIP_TRY(e, gnnvc::column_counts(in, e->g.n, e->c4_counts.p, e->stream));
@@ -962,10 +1089,9 @@ int launch_main(gnnvc_engine *e, const StageChoice &c, int stage, uint32_t lo, u
         // what: 1 = choose the columns + write the table, 2 = the sums; the prepared table only needs its sums, a call
         // that runs its sums round by round (below) only the preparation
         const int what = !whole ? 2 : (c.rounds ? 1 : 3);
-        HIP_TRY(e, gnnvc::launch_compact_gather(e->g, in, fused ? e->c4_emit_counts.p : e->c4_counts.p, fused ? 64 : 1, desc,
-                                                e->c4_table.p, e->c4_acc.p, lo, hi, e->c4_rows, e->c4_stepptr.p, e->c4_steps.p,
-                                                e->c4_entries.p, e->c4_dirty.p, e->c4_dirty_cap, e->c4_agg16.p, e->stream,
-                                                e->c4_block, e->c4_base, e->c4_end, e->c4_last_entry, what));
+        HIP_TRY(e, gnnvc::launch_compact_gather(e->g, compact_plan(e), in, fused ? e->c4_emit_counts.p : e->c4_counts.p, fused ? 64 : 1,
+                                                desc, e->c4_table.p, e->c4_acc.p, lo, hi, e->c4_dirty.p, e->c4_dirty_cap,
+                                                e->c4_agg16.p, e->stream, what));
     }
     {
         int rc = arm_emit();
@@ -989,9 +1115,8 @@ int launch_main(gnnvc_engine *e, const StageChoice &c, int stage, uint32_t lo, u
         const uint32_t ca = c0 + 256u * k, cb = std::min(c1 + 1u, ca + 256u);
         const uint32_t ra = std::max(lo, e->c4_base + ca * rows);
         const uint32_t rb = (uint32_t)std::min<uint64_t>(hi, (uint64_t)e->c4_base + (uint64_t)cb * rows);
-        HIP_TRY(e, gnnvc::compact_sums(e->g, desc, e->c4_table.p, e->c4_acc.p, ra, rb, rows, e->c4_stepptr.p, e->c4_steps.p,
-                                       e->c4_entries.p, e->c4_dirty.p, e->c4_dirty_cap, e->stream, e->c4_block, e->c4_base,
-                                       e->c4_end, e->c4_last_entry, /*one_round=*/true));
+        HIP_TRY(e, gnnvc::compact_sums(e->g, compact_plan(e), desc, e->c4_table.p, e->c4_acc.p, ra, rb, e->c4_dirty.p, e->c4_dirty_cap,
+                                       e->stream, /*one_round=*/true));
         HIP_TRY(e, gnnvc::compact_mark(desc, e->c4_marks.p, k + 1, e->stream));
         const bool last = k + 1 == nrounds;
         hipStream_t ds = last ? e->stream : e->aux_stream;
@@ -1163,7 +1288,7 @@ void gnnvc_destroy(gnnvc_engine *e) {
     e->lt_bytes.release(); e->lt_entries.release(); e->lt_segcnt.release(); e->lt_stepptr.release();
     e->lt_stepcnt.release(); e->lt_bad.release(); e->lt_steps.release();
     e->c4_entries.release(); e->c4_segcnt.release(); e->c4_stepptr.release(); e->c4_stepcnt.release();
-    e->c4_desc.release(); e->c4_steps.release(); e->c4_table.release(); e->c4_marks.release(); e->c4_acc.release(); e->c4_counts.release();
+    e->c4_desc.release(); e->c4_rowmap.release(); e->c4_first.release(); e->c4_bstart.release(); e->c4_map_vertex.release(); e->c4_map_meta.release(); e->c4_steps.release(); e->c4_table.release(); e->c4_marks.release(); e->c4_acc.release(); e->c4_counts.release();
     e->c4_agg16.release(); e->c4_dirty.release(); e->c4_emit_counts.release();
     e->long_list.release(); e->long_count.release();
     e->gi_meta.release(); e->gi_off.release(); e->gi_slab.release(); e->gi_agg.release();
@@ -1211,6 +1336,8 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "side_streams") e->opt_side_streams = value != 0 ? 1 : 0;
     else if (k == "kernel_trace") e->opt_ktrace = value != 0 ? 1 : 0;
     else if (k == "compact_gather") e->opt_compact = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
+    else if (k == "compact_skewed") { e->opt_compact_skewed = value != 0 ? 1 : 0; e->c4_tried = false; e->c4_ready = false; }
+    else if (k == "compact_passes") { e->opt_compact_passes = value < 1 ? 1u : (value > 3 ? 3u : (uint32_t)value); e->c4_tried = false; e->c4_ready = false; }
     else if (k == "lds_table") e->opt_lds_table = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else if (k == "sorted_min_nnz") e->opt_sorted_min_nnz = value > 0 ? (uint64_t)value : 0;
     else if (k == "sorted_long_row_threshold") e->opt_sorted_long_thresh = value > 0 ? (uint32_t)value : 1;
@@ -1228,7 +1355,12 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
     else if (k == "compact_gather_block_cols") *value = e->c4_ready ? (long)e->c4_block : 0;
     else if (k == "compact_gather_rows_per_chunk") *value = e->c4_ready ? (long)e->c4_rows : 0;
     else if (k == "compact_gather_steps") *value = e->c4_ready ? (long)e->c4_steps_total : 0;
-    else if (k == "compact_gather_last_ok" || k == "compact_gather_last_dirty") {
+    else if (k == "compact_gather_mapped") *value = e->c4_ready && e->c4_mapped ? 1 : 0;
+    else if (k == "compact_gather_blocks") *value = e->c4_ready ? (long)e->c4_nblocks : 0;
+    else if (k == "compact_gather_mapped_rows") *value = e->c4_ready ? (long)e->c4_mapped_rows : 0;
+    else if (k == "compact_gather_mapped_entries") *value = e->c4_ready ? (long)e->c4_mapped_entries : 0;
+    else if (k == "compact_gather_max_passes") *value = e->c4_ready ? (long)e->c4_max_passes : 0;
+    else if (k == "compact_gather_last_ok" || k == "compact_gather_last_dirty" || k == "compact_gather_last_passes") {
         // what the device decided at the last launch of the plan (waits for the stream; for tests and tools)
         *value = 0;
         if (e->c4_ready && e->c4_desc.p) {
@@ -1236,7 +1368,7 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
             if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess ||
                 hipMemcpy(d, e->c4_desc.p + e->c4_last_desc, sizeof d, hipMemcpyDeviceToHost) != hipSuccess)
                 return GNNVC_ERR_DEVICE;
-            *value = k == "compact_gather_last_ok" ? (long)d[0] : (long)d[5];
+            *value = k == "compact_gather_last_ok" ? (d[0] ? 1 : 0) : (k == "compact_gather_last_passes" ? (long)d[0] : (long)d[5]);
         }
     }
     else if (k == "lds_table_active") *value = e->lt_ready ? 1 : 0;
@@ -1664,7 +1796,7 @@ int gnnvc_stage_input_ready(gnnvc_engine *e, int stage, const float *d_in, uint3
     const bool same_range = e->c4_range_mode && e->c4_tried && e->c4_base == row_lo && e->c4_end == row_hi;
     e->c4_range_mode = true;
     if (!same_range) {
-        rc = build_compact(e, row_lo, row_hi);
+        rc = build_compact(e, row_lo, row_hi, /*allow_mapped=*/false);
         if (rc) return rc;
         if (!e->c4_ready) {   // remember what was tried, so that the next forward does not try again
             e->c4_base = row_lo;
@@ -1672,13 +1804,11 @@ int gnnvc_stage_input_ready(gnnvc_engine *e, int stage, const float *d_in, uint3
         }
     }
     if (!e->c4_ready || e->n_long > 0) return GNNVC_OK;   // the plan does not apply to this graph: nothing to prepare
-    uint32_t *desc = e->c4_desc.p + 8 * (stage - 1);
-    e->c4_last_desc = 8 * (stage - 1);
+    uint32_t *desc = e->c4_desc.p + gnnvc_engine::kDescWords * (stage - 1);
+    e->c4_last_desc = gnnvc_engine::kDescWords * (stage - 1);
     HIP_TRY(e, gnnvc::column_counts(d_in, e->g.n, e->c4_counts.p, e->stream));
-    HIP_TRY(e, gnnvc::launch_compact_gather(e->g, d_in, e->c4_counts.p, 1, desc, e->c4_table.p, e->c4_acc.p, e->c4_base, e->c4_end,
-                                            e->c4_rows, e->c4_stepptr.p, e->c4_steps.p, e->c4_entries.p, e->c4_dirty.p,
-                                            e->c4_dirty_cap, e->c4_agg16.p, e->stream, e->c4_block, e->c4_base, e->c4_end,
-                                            e->c4_last_entry, /*what=*/1));
+    HIP_TRY(e, gnnvc::launch_compact_gather(e->g, compact_plan(e), d_in, e->c4_counts.p, 1, desc, e->c4_table.p, e->c4_acc.p, e->c4_base,
+                                            e->c4_end, e->c4_dirty.p, e->c4_dirty_cap, e->c4_agg16.p, e->stream, /*what=*/1));
     e->c4_prepared_stage = stage;
     e->c4_prepared_in = d_in;
     return GNNVC_OK;

@@ -93,7 +93,7 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
 // the dense layers + sigmoid of the last stage when its aggregates are ready (compact-table plan)
 hipError_t launch_dense_sigmoid(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *in, float *out,
                                 float *logits, uint32_t row_lo, uint32_t row_hi, const float *acc4, const uint32_t *c4desc,
-                                const float *agg16, hipStream_t stream);
+                                const float *agg16, hipStream_t stream, uint32_t long_thresh = 0xFFFFFFFFu /* rows at least this long are not this kernel's */);
 
 // Building blocks of the degree-sorted order (the prefix over the few thousand degree classes
 // is done on the host).
@@ -167,16 +167,32 @@ hipError_t lds_table_wsteps(const GraphDev &g, uint32_t slice_rows, uint32_t nch
                             const uint32_t *step_ptr, uint32_t *step_count, uint32_t *recs, bool write, uint32_t slack,
                             hipStream_t stream);
 hipError_t lds_table_bytes(const uint32_t *w, uint32_t n, uint8_t *wb, uint32_t *bad, hipStream_t stream);
+// A plan over rows that are not consecutive (skewed graphs, compact-table plan): chunk c holds the rows
+// rowmap[c * rows_per_chunk ..] (0xFFFFFFFF = empty slot), its regrouped entries start at first[c] (+ the padding
+// slack), and column blocks may have any widths: block b = columns [bstart[b], bstart[b + 1]).  All null (the
+// default): consecutive rows, CSR offsets, blocks of block_cols columns.
+struct PlanMap {
+    const uint32_t *rowmap = nullptr, *first = nullptr, *bstart = nullptr;
+};
 hipError_t lds_table_count(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t block_cols,
                            uint32_t *seg_cnt, uint32_t *bad, hipStream_t stream, uint32_t row_base = 0,
-                           uint32_t row_end = 0xFFFFFFFFu);
+                           uint32_t row_end = 0xFFFFFFFFu, const PlanMap &pm = PlanMap());
 hipError_t lds_table_steps(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, const uint32_t *seg_cnt,
                            const uint32_t *step_ptr, uint32_t *step_count, void *steps, bool write, hipStream_t stream,
                            uint32_t row_base = 0, uint32_t row_end = 0xFFFFFFFFu, uint32_t cap = 0 /* entries per step, 0 = 2048 */,
-                           uint32_t slack = 0 /* != 0: segments start at multiples of 4, chunk c shifted by c * slack */);
+                           uint32_t slack = 0 /* != 0: segments start at multiples of 4, chunk c shifted by c * slack */,
+                           uint32_t block_cols = 0 /* the step descriptors' fourth word: the block's first column */,
+                           const PlanMap &pm = PlanMap());
 hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t block_cols,
                              const uint32_t *seg_cnt, uint32_t *entries, hipStream_t stream, uint32_t shift = 17,
-                             uint32_t row_base = 0, uint32_t row_end = 0xFFFFFFFFu, uint32_t slack = 0);
+                             uint32_t row_base = 0, uint32_t row_end = 0xFFFFFFFFu, uint32_t slack = 0,
+                             const PlanMap &pm = PlanMap());
+// rows of a degree-sorted list (heaviest first; the first m of it) dealt serpentine to nslices slices of slice_rows slots:
+// rowmap[s * slice_rows + t], weight[s] = entries of slice s
+hipError_t deal_rows(const GraphDev &g, const uint32_t *sorted_rows, uint32_t m, uint32_t slice_rows, uint32_t nslices,
+                     uint32_t *rowmap, uint32_t *weight, hipStream_t stream);
+// cand[k] = first row whose CSR offset reaches k * target: column ranges of equal entry mass on a symmetric adjacency
+hipError_t mass_bounds(const GraphDev &g, unsigned long long target, uint32_t count, uint32_t *cand, hipStream_t stream);
 hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *x,
                                    float *out, uint32_t row_lo, uint32_t row_hi, uint32_t rows_per_chunk,
                                    const uint32_t *step_ptr, const void *steps, const uint32_t *entries, const uint8_t *wbyte,
@@ -194,18 +210,26 @@ uint32_t compact_step();     // entries per step
 // counts: per-column non-zero counts of `in` — 16 counters from column_counts() (count_slots = 1) or the
 // producer's kEmitCounters (count_slots = 64: 17 counters per slot, the 17th = rows seen; the table may then
 // already hold the rows' compact form for the columns in desc, see EmitArgs)
-hipError_t launch_compact_gather(const GraphDev &g, const float *in, const unsigned long long *counts, int count_slots, uint32_t *desc,
-                                 float *table, float *acc4, uint32_t row_lo, uint32_t row_hi, uint32_t rows_per_chunk,
-                                 const uint32_t *step_ptr, const void *steps, const uint32_t *entries, uint32_t *dirty_rows,
-                                 uint32_t dirty_cap, float *agg16, hipStream_t stream, uint32_t block_cols,
-                                 uint32_t plan_base, uint32_t plan_end, uint32_t last_entry /* last index of entries[] a 16-byte read may start at */,
+struct CompactPlan {   // the per-graph part of the plan, as the launches need it
+    uint32_t rows_per_chunk = 0, block_cols = 0, nblocks = 0, plan_base = 0, plan_end = 0;
+    uint32_t last_entry = 0;             // last index of entries[] a 16-byte read may start at
+    uint32_t nslices = 0;                // mapped plans: slices in rowmap
+    uint32_t max_passes = 1;             // tables of four columns the device may choose for one input (<= compact_max_passes())
+    const uint32_t *step_ptr = nullptr;
+    const void *steps = nullptr;
+    const uint32_t *entries = nullptr;
+    const uint32_t *rowmap = nullptr;    // null: slices of consecutive rows
+};
+uint32_t compact_max_passes();
+// table: max_passes x (n + 1) rows of 16 bytes, acc4: max_passes x n
+hipError_t launch_compact_gather(const GraphDev &g, const CompactPlan &cp, const float *in, const unsigned long long *counts,
+                                 int count_slots, uint32_t *desc, float *table, float *acc4, uint32_t row_lo, uint32_t row_hi,
+                                 uint32_t *dirty_rows, uint32_t dirty_cap, float *agg16, hipStream_t stream,
                                  int what = 3 /* 1 = prepare, 2 = sums, 3 = both */);
 
 // the parts of launch_compact_gather's second half, for callers that run them round by round
-hipError_t compact_sums(const GraphDev &g, uint32_t *desc, const float *table, float *acc4, uint32_t row_lo, uint32_t row_hi,
-                        uint32_t rows_per_chunk, const uint32_t *step_ptr, const void *steps, const uint32_t *entries,
-                        uint32_t *dirty_rows, uint32_t dirty_cap, hipStream_t stream, uint32_t block_cols, uint32_t plan_base,
-                        uint32_t plan_end, uint32_t last_entry, bool one_round = false);
+hipError_t compact_sums(const GraphDev &g, const CompactPlan &cp, uint32_t *desc, const float *table, float *acc4, uint32_t row_lo,
+                        uint32_t row_hi, uint32_t *dirty_rows, uint32_t dirty_cap, hipStream_t stream, bool one_round = false);
 hipError_t compact_mark(const uint32_t *desc, uint32_t *marks, uint32_t k, hipStream_t stream);
 hipError_t compact_fix(const GraphDev &g, const float *in, const uint32_t *desc, const uint32_t *dirty_rows, uint32_t dirty_cap,
                        float *agg16, const uint32_t *marks, hipStream_t stream, uint32_t blocks = 4096);

@@ -293,7 +293,7 @@ __device__ __forceinline__ void c4_emit(const float *trow, uint32_t nz, uint32_t
     const uint32_t rows = (uint32_t)__popcll(__ballot(mine));
     if (lane == 16) my = rows;
     if (lane <= 16 && my) atomicAdd(&counts[(blockIdx.x & (kEmitSlots - 1)) * kEmitStride + lane], (unsigned long long)my);
-    if (spec[0] && mine) {
+    if (spec[0] == 1u && mine) {   // (a plan of several passes writes its tables in k_c4_compact)
         const uint32_t s0 = spec[1], s1 = spec[2], s2 = spec[3], s3 = spec[4];
         const float a = trow[s0], b = trow[s1], c = trow[s2], d = trow[s3];
         c4row out = {a == 0.0f ? 0.0f : a, b == 0.0f ? 0.0f : b, c == 0.0f ? 0.0f : c, d == 0.0f ? 0.0f : d};
@@ -391,24 +391,31 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
     for (int p = 0; p < 4; ++p) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
     const uint32_t zrow = g.n;  // all-zero pad row: x + 0.0f == x exactly
     if constexpr (AGGONLY) {
-        // this lane holds feature columns 4c .. 4c+3: which of them are table columns, and which slot
-        const uint32_t d0 = c4desc[1], d1 = c4desc[2], d2 = c4desc[3], d3 = c4desc[4];
-        int sel[4];
+        // this lane holds feature columns 4c .. 4c+3: which of them are table columns, of which pass, and which slot
+        const uint32_t npass = c4desc[0];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const uint32_t col = 4 * c + t;
-            sel[t] = col == d0 ? 0 : col == d1 ? 1 : col == d2 ? 2 : col == d3 ? 3 : -1;
-        }
+        for (int p = 0; p < 4; ++p) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 a0[4] = {acc4[urow[0]], acc4[urow[1]], acc4[urow[2]], acc4[urow[3]]};
+        for (uint32_t qp = 0; qp < npass; ++qp) {   // (uniform; 1 on degree-uniform graphs)
+            const uint32_t *dc = c4desc + (qp == 0 ? 1 : 4 + 4 * qp);   // columns of pass 0 at [1..4], pass 1 at [8..11], pass 2 at [12..15]
+            const uint32_t d0 = dc[0], d1 = dc[1], d2 = dc[2], d3 = dc[3];
+            int sel[4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const float4 a = acc4[urow[p]];
-            if ((__float_as_uint(a.x) >> 31) != 0) {   // dirty: met a neighbour with stray non-zeros; recomputed from full rows by k_c4_fix
-                acc[p] = agg16[(size_t)__float_as_uint(a.y) * 4 + c];
-            } else {
-                auto pick = [&](int j) { return j == 0 ? a.x : j == 1 ? a.y : j == 2 ? a.z : j == 3 ? a.w : 0.0f; };
-                acc[p] = make_float4(pick(sel[0]), pick(sel[1]), pick(sel[2]), pick(sel[3]));
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t col = 4 * c + t;
+                sel[t] = col == d0 ? 0 : col == d1 ? 1 : col == d2 ? 2 : col == d3 ? 3 : -1;
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float4 a = qp == 0 ? a0[p] : acc4[(size_t)qp * g.n + urow[p]];
+                auto pick = [&](int j, float old) { return j == 0 ? a.x : j == 1 ? a.y : j == 2 ? a.z : j == 3 ? a.w : old; };
+                acc[p] = make_float4(pick(sel[0], acc[p].x), pick(sel[1], acc[p].y), pick(sel[2], acc[p].z), pick(sel[3], acc[p].w));
             }
         }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if ((__float_as_uint(a0[p].x) >> 31) != 0)   // dirty: met a neighbour with stray non-zeros; recomputed from full rows by k_c4_fix
+                acc[p] = agg16[(size_t)__float_as_uint(a0[p].y) * 4 + c];
     }
     wave_lds_sync();            // staged indices visible to the whole wave
 
@@ -554,19 +561,27 @@ template <int N1, int N2>
 __global__ __launch_bounds__(kBlock) void k_dense_sigmoid(GraphDev g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
                                                           float *__restrict__ logits, const float *__restrict__ P, uint32_t row_lo,
                                                           uint32_t row_hi, const float4 *__restrict__ acc4,
-                                                          const uint32_t *__restrict__ c4desc, const float4 *__restrict__ agg16) {
+                                                          const uint32_t *__restrict__ c4desc, const float4 *__restrict__ agg16,
+                                                          uint32_t long_thresh) {
     if (c4desc[0] == 0) return;
     const uint32_t uu = row_lo + blockIdx.x * kBlock + threadIdx.x;
-    const bool mine = uu < row_hi;
-    const uint32_t u = mine ? uu : row_hi - 1;
-    const uint32_t d0 = c4desc[1], d1 = c4desc[2], d2 = c4desc[3], d3 = c4desc[4];
+    const uint32_t u = uu < row_hi ? uu : row_hi - 1;
+    const bool mine = uu < row_hi && g.rowptr[u + 1] - g.rowptr[u] < long_thresh;   // (longer rows: the long-row kernels')
+    const uint32_t npass = c4desc[0];
     const float4 a = acc4[u];
     const float4 h0 = fin[(size_t)u * 4], h1 = fin[(size_t)u * 4 + 1], h2 = fin[(size_t)u * 4 + 2], h3 = fin[(size_t)u * 4 + 3];
     // first-layer inputs in k order: 0..15 aggregate, 16 = h[0], 17 = degree, 18 = W/ws, 19 = NW/ws, 20..31 = h[4..15]
     float x0[32];
 #pragma unroll
-    for (int k = 0; k < 16; ++k)
-        x0[k] = ((uint32_t)k == d0) ? a.x : ((uint32_t)k == d1) ? a.y : ((uint32_t)k == d2) ? a.z : ((uint32_t)k == d3) ? a.w : 0.0f;
+    for (int k = 0; k < 16; ++k) x0[k] = 0.0f;
+    for (uint32_t qp = 0; qp < npass; ++qp) {   // (uniform)
+        const uint32_t *dc = c4desc + (qp == 0 ? 1 : 4 + 4 * qp);
+        const uint32_t d0 = dc[0], d1 = dc[1], d2 = dc[2], d3 = dc[3];
+        const float4 aq = qp == 0 ? a : acc4[(size_t)qp * g.n + u];
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            x0[k] = ((uint32_t)k == d0) ? aq.x : ((uint32_t)k == d1) ? aq.y : ((uint32_t)k == d2) ? aq.z : ((uint32_t)k == d3) ? aq.w : x0[k];
+    }
     const bool dirty = (__float_as_uint(a.x) >> 31) != 0;   // met a neighbour with stray non-zeros: recomputed from full rows by k_c4_fix
     if (__any(dirty)) {
         const size_t slot = dirty ? (size_t)__float_as_uint(a.y) : 0;
@@ -1314,21 +1329,48 @@ __global__ __launch_bounds__(256) void k_lt_bytes(const uint32_t *__restrict__ w
     if (__any(big) && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
 }
 
+// A plan over rows that are NOT consecutive (skewed graphs, compact-table plan): chunk c holds the rows
+// rowmap[c * rows_per_chunk ..] (0xFFFFFFFF = empty slot), its regrouped entries start at first[c] (+ the padding
+// slack), and column blocks may have any widths: block b = columns [bstart[b], bstart[b + 1]).  All null: consecutive
+// rows, CSR offsets, blocks of block_cols columns.
+// (struct PlanMap: gnnvc_kernels.h)
+__device__ __forceinline__ uint32_t lt_row(const PlanMap &pm, uint32_t c, uint32_t rows_per_chunk, uint32_t r0, uint32_t i) {
+    return pm.rowmap ? pm.rowmap[(size_t)c * rows_per_chunk + i] : r0 + i;
+}
+// block of column `col`, searched from block `from` on (a row's columns ascend)
+__device__ __forceinline__ uint32_t lt_block(const PlanMap &pm, uint32_t col, uint32_t block_cols, uint32_t nblocks, uint32_t from) {
+    if (!pm.bstart) return col / block_cols;
+    if (col < pm.bstart[from]) from = 0;            // (unsorted row: found anyway, flagged by the caller)
+    if (col < pm.bstart[from + 1]) return from;
+    uint32_t lo = from + 1, hi = nblocks - 1;       // last block whose start is <= col
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (pm.bstart[mid] <= col) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+__device__ __forceinline__ uint32_t lt_block_start(const PlanMap &pm, uint32_t b, uint32_t block_cols) {
+    return pm.bstart ? pm.bstart[b] : b * block_cols;
+}
+
 // entries of chunk `c` per column block -> seg_cnt[c * nblocks + b]; bad |= 2 if a row's blocks are
 // not ascending (unsorted adjacency: the plan would change the order of its sum)
 __global__ __launch_bounds__(1024) void k_lt_count(GraphDev g, uint32_t rows_per_chunk, uint32_t nblocks, uint32_t block_cols,
                                                    uint32_t *__restrict__ seg_cnt, uint32_t *bad, uint32_t row_base,
-                                                   uint32_t row_end) {
+                                                   uint32_t row_end, PlanMap pm) {
     __shared__ uint32_t hist[4096];
     const uint32_t c = blockIdx.x, tid = threadIdx.x;
     for (uint32_t i = tid; i < nblocks; i += 1024) hist[i] = 0;
     __syncthreads();
-    const uint32_t r0 = min(row_end, row_base + c * rows_per_chunk), r1 = min(row_end, r0 + rows_per_chunk);
+    const uint32_t r0 = min(row_end, row_base + c * rows_per_chunk), r1 = pm.rowmap ? r0 + rows_per_chunk : min(row_end, r0 + rows_per_chunk);
     bool unsorted = false;
-    for (uint32_t u = r0 + tid; u < r1; u += 1024) {
+    for (uint32_t i = tid; i < r1 - r0; i += 1024) {
+        const uint32_t u = lt_row(pm, c, rows_per_chunk, r0, i);
+        if (u >= row_end) continue;
         uint32_t prev = 0, run = 0;
         for (uint32_t e = g.rowptr[u]; e < g.rowptr[u + 1]; ++e) {
-            const uint32_t b = g.col[e] / block_cols;
+            const uint32_t b = lt_block(pm, g.col[e], block_cols, nblocks, prev);
             if (run && b != prev) {
                 atomicAdd(&hist[prev], run);
                 unsorted |= b < prev;
@@ -1349,9 +1391,9 @@ __global__ __launch_bounds__(1024) void k_lt_count(GraphDev g, uint32_t rows_per
 // (chunk, block) segment starts at a multiple of 4, and chunk c is shifted by c * slack, slack >= 3 * nblocks + 4
 // covering the padding of all chunks before it.
 __device__ __forceinline__ uint32_t lt_chunk_first(const GraphDev &g, uint32_t c, uint32_t rows_per_chunk, uint32_t row_base,
-                                                   uint32_t row_end, uint32_t slack) {
+                                                   uint32_t row_end, uint32_t slack, const uint32_t *mapped_first = nullptr) {
     const uint32_t r0 = (uint32_t)min((uint64_t)row_end, (uint64_t)row_base + (uint64_t)c * rows_per_chunk);
-    const uint32_t first = g.rowptr[r0];
+    const uint32_t first = mapped_first ? mapped_first[c] : g.rowptr[r0];
     return slack ? (first + c * slack + 3u) & ~3u : first;
 }
 
@@ -1360,17 +1402,18 @@ __device__ __forceinline__ uint32_t lt_chunk_first(const GraphDev &g, uint32_t c
 __global__ __launch_bounds__(256) void k_lt_steps(GraphDev g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks,
                                                   const uint32_t *__restrict__ seg_cnt, const uint32_t *__restrict__ step_ptr,
                                                   uint32_t *__restrict__ step_count, uint4 *__restrict__ steps, int write,
-                                                  uint32_t row_base, uint32_t row_end, uint32_t cap, uint32_t slack) {
+                                                  uint32_t row_base, uint32_t row_end, uint32_t cap, uint32_t slack,
+                                                  uint32_t block_cols, PlanMap pm) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
     const uint32_t *cnt = seg_cnt + (size_t)c * nblocks;
-    uint32_t first = lt_chunk_first(g, c, rows_per_chunk, row_base, row_end, slack);   // a chunk's entries are a CSR range
+    uint32_t first = lt_chunk_first(g, c, rows_per_chunk, row_base, row_end, slack, pm.first);   // a chunk's entries are a CSR range (or its mapped one)
     uint32_t pos = write ? step_ptr[c] : 0, made = 0;
     for (uint32_t b = 0; b < nblocks; ++b) {
         uint32_t left = cnt[b];
         while (left) {
             const uint32_t take = left < cap ? left : cap;
-            if (write) steps[pos + made] = make_uint4(b, first, take, 0u);
+            if (write) steps[pos + made] = make_uint4(b, first, take, lt_block_start(pm, b, block_cols));   // .w: the block's first column
             ++made;
             first += take;
             left -= take;
@@ -1389,12 +1432,12 @@ __global__ __launch_bounds__(256) void k_lt_steps(GraphDev g, uint32_t rows_per_
 __global__ __launch_bounds__(1024) void k_lt_scatter(GraphDev g, uint32_t rows_per_chunk, uint32_t nblocks, uint32_t block_cols,
                                                      uint32_t shift, const uint32_t *__restrict__ seg_cnt,
                                                      uint32_t *__restrict__ entries, uint32_t row_base, uint32_t row_end,
-                                                     uint32_t slack) {
+                                                     uint32_t slack, PlanMap pm) {
     __shared__ uint32_t cursor[4096];
     const uint32_t c = blockIdx.x, tid = threadIdx.x;
-    const uint32_t r0 = min(row_end, row_base + c * rows_per_chunk), r1 = min(row_end, r0 + rows_per_chunk);
+    const uint32_t r0 = min(row_end, row_base + c * rows_per_chunk), r1 = pm.rowmap ? r0 + rows_per_chunk : min(row_end, r0 + rows_per_chunk);
     if (tid == 0) {   // exclusive scan of <= 4096 counts: a few microseconds, once per graph
-        uint32_t run = lt_chunk_first(g, c, rows_per_chunk, row_base, row_end, slack);
+        uint32_t run = lt_chunk_first(g, c, rows_per_chunk, row_base, row_end, slack, pm.first);
         for (uint32_t b = 0; b < nblocks; ++b) {
             cursor[b] = run;
             run += seg_cnt[(size_t)c * nblocks + b];
@@ -1402,18 +1445,60 @@ __global__ __launch_bounds__(1024) void k_lt_scatter(GraphDev g, uint32_t rows_p
         }
     }
     __syncthreads();
-    for (uint32_t u = r0 + tid; u < r1; u += 1024) {
-        const uint32_t rl = (u - r0) << shift;
-        uint32_t e = g.rowptr[u];
+    for (uint32_t i = tid; i < r1 - r0; i += 1024) {
+        const uint32_t u = lt_row(pm, c, rows_per_chunk, r0, i);
+        if (u >= row_end) continue;
+        const uint32_t rl = i << shift;
+        uint32_t e = g.rowptr[u], b = 0;
         const uint32_t end = g.rowptr[u + 1];
         while (e < end) {
-            const uint32_t b = g.col[e] / block_cols;
+            b = lt_block(pm, g.col[e], block_cols, nblocks, b);
             uint32_t f = e + 1;
-            while (f < end && g.col[f] / block_cols == b) ++f;
+            while (f < end && lt_block(pm, g.col[f], block_cols, nblocks, b) == b) ++f;
             uint32_t pos = atomicAdd(&cursor[b], f - e);
-            for (; e < f; ++e) entries[pos++] = rl | (g.col[e] - b * block_cols);
+            const uint32_t bs = lt_block_start(pm, b, block_cols);
+            for (; e < f; ++e) entries[pos++] = rl | (g.col[e] - bs);
         }
     }
+}
+
+// Skewed graphs: the rows of the degree-sorted list (heaviest first) dealt to `nslices` slices, serpentine — round t
+// hands ranks t * nslices .. to the slices left to right, the next round right to left — so that every slice gets the
+// same weight to within one row.  rowmap[s * slice_rows + t] = the row (0xFFFFFFFF past the list's end),
+// weight[s] = the slice's entries.  One wave per slice.
+__global__ __launch_bounds__(256) void k_map_deal(GraphDev g, const uint32_t *__restrict__ sorted_rows, uint32_t m,
+                                                  uint32_t slice_rows, uint32_t nslices, uint32_t *__restrict__ rowmap,
+                                                  uint32_t *__restrict__ weight) {
+    const uint32_t s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= nslices) return;
+    uint32_t w = 0;
+    for (uint32_t t = lane; t < slice_rows; t += 64) {
+        const uint64_t idx = (uint64_t)t * nslices + ((t & 1u) ? nslices - 1u - s : s);
+        uint32_t u = 0xFFFFFFFFu;
+        if (idx < m) {
+            u = sorted_rows[idx];
+            w += g.rowptr[u + 1] - g.rowptr[u];
+        }
+        rowmap[(size_t)s * slice_rows + t] = u;
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) w += __shfl_xor(w, off);
+    if (lane == 0) weight[s] = w;
+}
+
+// cand[k] = the first row whose CSR offset reaches k * target (k = 0 .. count - 1): on a symmetric adjacency, column
+// ranges of equal entry mass
+__global__ __launch_bounds__(256) void k_mass_bounds(GraphDev g, unsigned long long target, uint32_t count, uint32_t *__restrict__ cand) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const unsigned long long want = (unsigned long long)g.rowptr[0] + target * k;
+    uint32_t lo = 0, hi = g.n;   // first row r with rowptr[r] >= want
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((unsigned long long)g.rowptr[mid] >= want) hi = mid;
+        else lo = mid + 1;
+    }
+    cand[k] = lo;
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -1644,11 +1729,15 @@ __global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ st
 //   k_stage_f16   takes a clean row's aggregate from the 4 sums (+0.0f elsewhere: a sum of zeros) and
 //                 gathers a dirty row the plain way, full rows in CSR order — so every aggregate is
 //                 exactly what the plain gather produces; then the dense layers as always.
-// desc words: [0] ok (1 = the plan applies to this input), [1..4] the chosen columns (ascending).
+// A skewed graph's input often has more than four live columns (R-MAT-22: ten after stage 1, seven after stage 2): the
+// plan then runs up to kC4MaxPasses passes, each with its own table of four columns and its own four sums per row.
+// desc words (16 per consumer stage): [0] passes (0 = the plan does not apply to this input), [1..4] the columns of pass 0
+// (ascending over all passes; 0xFFFFFFFF = none), [8..11] pass 1, [12..15] pass 2.
 constexpr uint32_t kC4Block = 131072;     // default vertices per column block: 2 MiB of compact rows (the engine sizes the
                                           // blocks so that a slice has about 160 entries per block: one step, 54 lanes busy)
 constexpr uint32_t kC4Shift = 18;         // entries: row_local << 18 | col_local (blocks of up to 262144 vertices)
 constexpr uint32_t kC4Slices = 16;        // slices per chunk = waves per workgroup
+constexpr uint32_t kC4MaxPasses = 3;      // tables of four columns a plan may use for one input
 constexpr uint32_t kC4SliceRows = 632;    // rows per slice: 16 x (16 B x rows + dirty bits) <= 160 KiB
 constexpr uint32_t kC4MaxRows = kC4Slices * kC4SliceRows;
 constexpr int kC4LaneEntries = 3;         // consecutive entries a lane takes per step
@@ -1657,13 +1746,13 @@ constexpr uint32_t kC4DirtyWords = (kC4SliceRows + 31) / 32;
 constexpr uint32_t kC4NoRow = (1u << (32 - kC4Shift)) - 1u;   // row field of a slot past the step's end
 static_assert(kC4SliceRows < kC4NoRow - 1u, "row field too narrow");
 
-// desc words: [0] ok, [1..4] the chosen columns (ascending), [5] dirty-row counter, [6] the table still has to be
-// written (k_c4_compact) — 0 when the producing stage kernel already wrote it for exactly these columns.
+// desc words: [0] passes, [1..4] / [8..11] / [12..15] the chosen columns, [5] dirty-row counter, [6] the table(s) still have to
+// be written (k_c4_compact) — 0 when the producing stage kernel already wrote the one table for exactly these columns.
 // slots == 1: counts[16] from k_column_counts.  slots == 64: the producer's counters (17 per slot; the 17th
 // counts the rows it saw — if that is not n, the producer that ran was not the emitting one and nothing here can
 // be trusted for this forward).  desc on entry = the previous forward's choice (the producer's spec).
 __global__ __launch_bounds__(64) void k_c4_choose(const unsigned long long *__restrict__ counts, int slots, uint32_t n,
-                                                  uint32_t *__restrict__ desc) {
+                                                  uint32_t *__restrict__ desc, uint32_t max_passes) {
     // one wave: lane sl sums nothing but reads slot sl's 17 counters; a butterfly adds the slots up
     const int lane = threadIdx.x;
     unsigned long long c[17];
@@ -1686,64 +1775,93 @@ __global__ __launch_bounds__(64) void k_c4_choose(const unsigned long long *__re
             c[i] += ((unsigned long long)hi << 32) | lo;
         }
     if (lane) return;
-    bool taken[16];
-    for (int i = 0; i < 16; ++i) taken[i] = false;
     const unsigned long long rows = c[16];
-    const bool prev_ok = desc[0] != 0;
+    const bool prev_ok = desc[0] == 1u;
     const uint32_t p1 = desc[1], p2 = desc[2], p3 = desc[3], p4 = desc[4];
     if (rows != n) {   // no (complete) statistics for this input
         desc[0] = 0;
         desc[6] = 0;
         return;
     }
-    for (int j = 0; j < 4; ++j) {            // four fullest columns (ties: lowest index)
+    // columns by fullness (ties: lowest index); the plan takes the 4, 8 or 12 fullest — as few as leave at most n / 512
+    // stray non-zeros outside them (every stray flags a vertex and dirties that vertex's neighbours, which are then
+    // recomputed from full rows: worth it only while they are few) — and no more than max_passes x 4
+    int order[16];
+    bool taken[16];
+    for (int i = 0; i < 16; ++i) taken[i] = false;
+    for (int j = 0; j < 16; ++j) {
         int best = -1;
         for (int i = 0; i < 16; ++i)
             if (!taken[i] && (best < 0 || c[i] > c[best])) best = i;
         taken[best] = true;
+        order[j] = best;
     }
-    unsigned long long rest = 0;
-    uint32_t k = 0, col[4];
-    for (int i = 0; i < 16; ++i) {
-        if (taken[i]) col[k++] = (uint32_t)i;
-        else rest += c[i];
+    uint32_t np = 0;
+    for (uint32_t t = 1; t <= max_passes && t <= 3u && !np; ++t) {
+        unsigned long long rest = 0;
+        for (uint32_t j = 4 * t; j < 16; ++j) rest += c[order[j]];
+        if (rest <= (unsigned long long)n / 512) np = t;
     }
-    // every stray non-zero flags a vertex and dirties that vertex's neighbours, which are then recomputed from
-    // full rows: worth it only while they are few
-    const uint32_t ok = rest <= (unsigned long long)n / 512 ? 1u : 0u;
-    const bool table_written = slots > 1 && prev_ok && p1 == col[0] && p2 == col[1] && p3 == col[2] && p4 == col[3];
-    desc[0] = ok;
-    desc[1] = col[0];
-    desc[2] = col[1];
-    desc[3] = col[2];
-    desc[4] = col[3];
-    desc[6] = (ok && !table_written) ? 1u : 0u;
+    uint32_t col[12];
+    {   // the chosen columns in ascending order, four per pass
+        bool in[16];
+        for (int i = 0; i < 16; ++i) in[i] = false;
+        for (uint32_t j = 0; j < 4 * np; ++j) in[order[j]] = true;
+        uint32_t k = 0;
+        for (int i = 0; i < 16; ++i)
+            if (in[i]) col[k++] = (uint32_t)i;
+        for (; k < 12; ++k) col[k] = 0xFFFFFFFFu;
+    }
+    const bool table_written = slots > 1 && prev_ok && np == 1u && p1 == col[0] && p2 == col[1] && p3 == col[2] && p4 == col[3];
+    desc[0] = np;
+    for (int k = 0; k < 4; ++k) desc[1 + k] = col[k];
+    for (int k = 4; k < 12; ++k) desc[4 + k] = col[k];   // pass 1 at [8..11], pass 2 at [12..15]
+    desc[6] = (np && !table_written) ? 1u : 0u;
 }
 
 __global__ __launch_bounds__(256) void k_c4_compact(const float4 *__restrict__ feat, uint32_t n, uint32_t *__restrict__ desc,
                                                     f32x4 *__restrict__ table) {
     if (!desc[0] || !desc[6]) return;   // not fit, or the producing kernel wrote the table already
     // (a block that finds a negative value below clears desc[0] for the kernels that follow)
-    const uint32_t c0 = desc[1], c1 = desc[2], c2 = desc[3], c3 = desc[4];
-    const uint32_t mask = (1u << c0) | (1u << c1) | (1u << c2) | (1u << c3);
+    // table of pass q at table + q * (n + 1): its four columns (0xFFFFFFFF = none: +0.0f); the sign bit of a vertex's
+    // first value says "has non-zeros in columns no pass carries" in EVERY pass's table
+    const uint32_t npass = desc[0];
+    uint32_t mask = 0;
+    for (uint32_t q = 0; q < npass; ++q)
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t cc = desc[(q == 0 ? 1 : 4 + 4 * q) + k];
+            if (cc < 16u) mask |= 1u << cc;
+        }
     bool negative = false;
     for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v <= n; v += (size_t)gridDim.x * blockDim.x) {
-        f32x4 out = {0.0f, 0.0f, 0.0f, 0.0f};
+        uint32_t nz = 0;
+        float r[16];
         if (v < n) {
             const float4 q0 = feat[v * 4], q1 = feat[v * 4 + 1], q2 = feat[v * 4 + 2], q3 = feat[v * 4 + 3];
-            const float r[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-            uint32_t nz = 0;
+            const float rr[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                nz |= (r[i] != 0.0f ? 1u : 0u) << i;
-                negative |= r[i] < 0.0f;
+                r[i] = rr[i];
+                nz |= (rr[i] != 0.0f ? 1u : 0u) << i;
+                negative |= rr[i] < 0.0f;
             }
-            const float *row = reinterpret_cast<const float *>(feat) + v * 16;   // the four picks: L1 hits
-            const float a = row[c0], b = row[c1], c = row[c2], d = row[c3];
-            out = f32x4{a == 0.0f ? 0.0f : a, b == 0.0f ? 0.0f : b, c == 0.0f ? 0.0f : c, d == 0.0f ? 0.0f : d};   // -0.0f -> +0.0f
-            if (nz & ~mask) out[0] = __uint_as_float(__float_as_uint(out[0]) | 0x80000000u);   // stray non-zeros: flag the vertex
         }
-        table[v] = out;   // row n: the zero row clamped reads land on
+        for (uint32_t q = 0; q < npass; ++q) {
+            f32x4 out = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (v < n) {
+                const uint32_t *dc = desc + (q == 0 ? 1 : 4 + 4 * q);
+                const float *row = reinterpret_cast<const float *>(feat) + v * 16;   // the four picks: L1 hits
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t cc = dc[k];
+                    const float a = cc < 16u ? row[cc] : 0.0f;
+                    out[k] = a == 0.0f ? 0.0f : a;                                    // -0.0f -> +0.0f
+                }
+                if (nz & ~mask) out[0] = __uint_as_float(__float_as_uint(out[0]) | 0x80000000u);   // stray non-zeros: flag the vertex
+            }
+            table[(size_t)q * ((size_t)n + 1) + v] = out;   // row n: the zero row clamped reads land on
+        }
+        (void)r;
     }
     if (__any(negative) && (threadIdx.x & 63) == 0) atomicAnd(&desc[0], 0u);
 }
@@ -1779,9 +1897,14 @@ __global__ __launch_bounds__(1024) void k_c4_agg(const uint32_t *__restrict__ st
                                                  f32x4 *__restrict__ agg, uint32_t n, uint32_t slice_rows, uint32_t slice0,
                                                  uint32_t slice1, uint32_t nslices, uint32_t last_entry, uint32_t *__restrict__ desc,
                                                  uint32_t *__restrict__ dirty_rows, uint32_t dirty_cap, uint32_t block_cols,
-                                                 uint32_t nblocks, uint32_t row_base, uint32_t row_end) {
+                                                 uint32_t nblocks, uint32_t row_base, uint32_t row_end, uint32_t pass,
+                                                 const uint32_t *__restrict__ rowmap) {
+    // pass: which of the plan's tables `table` is (desc[0] = how many the device chose for this input; the dirty rows are
+    // registered by pass 0 only — the flags are the same in every table).  rowmap != nullptr: slice s holds the rows
+    // rowmap[s * slice_rows ..] (0xFFFFFFFF = none) instead of slice_rows consecutive ones (skewed graphs: slices of
+    // equal weight dealt from the degree-sorted list).
     extern __shared__ __attribute__((aligned(16))) unsigned char c4_smem[];
-    if (!desc[0]) return;                                               // block-uniform
+    if (desc[0] <= pass) return;                                        // block-uniform
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 *A = reinterpret_cast<f32x4 *>(c4_smem) + wave * slice_rows;  // this wave's sums
     uint32_t *dirty = reinterpret_cast<uint32_t *>(c4_smem + (size_t)kC4Slices * slice_rows * 16) + wave * kC4DirtyWords;
@@ -1821,7 +1944,7 @@ __global__ __launch_bounds__(1024) void k_c4_agg(const uint32_t *__restrict__ st
                     const int slot = (j + 2) & 3;
                     const bool on = se >= 0 && se < nsteps && dsc_step == se;
                     const uint32_t first = dsc.y, count = on ? dsc.z : 0u;
-                    cb[slot] = dsc.x * block_cols;
+                    cb[slot] = dsc.w;                                        // the block's first column
                     bk[slot] = dsc.x;
                     cnt[slot] = count;
                     const uint32_t x0 = first + (uint32_t)E * lane;          // first is a multiple of 4
@@ -1930,17 +2053,21 @@ __global__ __launch_bounds__(1024) void k_c4_agg(const uint32_t *__restrict__ st
             ++cur_blk;
         }
         if (live)
-            for (uint32_t i = lane; i < slice_rows && row0 + i < row_end; i += 64) {
+            for (uint32_t i = lane; i < slice_rows; i += 64) {
+                const uint32_t row = rowmap ? rowmap[(size_t)wc * slice_rows + i] : row0 + i;
+                if (row >= row_end) continue;   // (0xFFFFFFFF: an unused slot of a mapped slice)
                 f32x4 a = A[i];
                 if (dirty[i >> 5] >> (i & 31) & 1u) {
                     // a dirty row: its aggregate is recomputed from full rows (k_c4_fix) into slot `slot` of the
                     // side buffer; the sums here are not used.  No slot left: the stage kernel gathers it itself.
-                    const uint32_t slot = atomicAdd(&desc[5], 1u);
-                    if (slot < dirty_cap) dirty_rows[slot] = row0 + i;
-                    a[0] = __uint_as_float(0x80000000u);
-                    a[1] = __uint_as_float(slot < dirty_cap ? slot : 0xFFFFFFFFu);
+                    if (pass == 0) {
+                        const uint32_t slot = atomicAdd(&desc[5], 1u);
+                        if (slot < dirty_cap) dirty_rows[slot] = row;
+                        a[0] = __uint_as_float(0x80000000u);
+                        a[1] = __uint_as_float(slot < dirty_cap ? slot : 0xFFFFFFFFu);
+                    }
                 }
-                agg[row0 + i] = a;
+                agg[row] = a;
             }
     }
 }
@@ -2655,13 +2782,13 @@ int stage_variant(int f, int n1, int n2, int n3, int sigmoid_last) {
 // the dense layers + sigmoid of the last stage when its aggregates are ready (compact-table plan): rows [row_lo, row_hi)
 hipError_t launch_dense_sigmoid(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *in, float *out,
                                 float *logits, uint32_t row_lo, uint32_t row_hi, const float *acc4, const uint32_t *c4desc,
-                                const float *agg16, hipStream_t stream) {
+                                const float *agg16, hipStream_t stream, uint32_t long_thresh) {
     if (row_hi <= row_lo) return hipSuccess;
     if (sp.f != 16 || sp.variant != 2 || !acc4 || !c4desc) return hipErrorInvalidValue;
     const dim3 grid((row_hi - row_lo + kBlock - 1) / kBlock), block(kBlock);
     GNNVC_LAUNCH((k_dense_sigmoid<32, 16>), grid, block, 0, stream, g, ws, reinterpret_cast<const float4 *>(in), out, logits,
                        params + sp.param_offset, row_lo, row_hi, reinterpret_cast<const float4 *>(acc4), c4desc,
-                       reinterpret_cast<const float4 *>(agg16));
+                       reinterpret_cast<const float4 *>(agg16), long_thresh);
     return hipGetLastError();
 }
 
@@ -2709,7 +2836,7 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
     GNNVC_LAUNCH((k_stage_f16<32, N2_, N3_, SIG_, S_, MF_, SRT_>), grid, block, 0, stream, g, ws, in4, out, \
                        LG_, P, row_lo, row_hi, long_thresh, sorted ? so->vertex : nullptr,                \
                        sorted ? so->meta : nullptr, sorted ? so->n : 0u, il,                              \
-                       (const float4 *)nullptr, (sorted || !acc4) ? nullptr : c4desc, (const float4 *)nullptr,           \
+                       (const float4 *)nullptr, acc4 ? c4desc : nullptr, (const float4 *)nullptr,                         \
                        (const uint32_t *)nullptr, (c4row *)nullptr, (unsigned long long *)nullptr)
     case 2:
         if (sorted) GNNVC_LAUNCH_F16(32, 16, false, false, true, GNNVC_GATHER_S_SORTED, nullptr);
@@ -2731,11 +2858,14 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
     default:
         return hipErrorInvalidValue;
     }
-    if (!sorted && acc4 && sp.f == 16 && dense_part) {
+    if (acc4 && sp.f == 16 && dense_part) {
         // compact-table plan: the aggregate-only variant does the launch when the device found the input fit for
         // it (the gathering variant above has then left at once, and the other way round).  Without gathers to
         // overlap with, the dense layers run faster on the VALU (one lane per vertex, weights from SGPRs) than on
-        // the fp32 matrix cores: 6.65 vs 7.16 ms per forward on the metric graph.
+        // the fp32 matrix cores: 6.65 vs 7.16 ms per forward on the metric graph.  It always walks natural tiles
+        // (nothing to balance without a gather, and consecutive rows read their sums coalesced).
+        const uint32_t nt = (row_hi - row_lo + kWave - 1) / kWave;
+        const dim3 grid((((nt + 7) / 8 + kWavesPerBlock - 1) / kWavesPerBlock) * 8);
 #define GNNVC_LAUNCH_AGG(N2_, N3_, SIG_, MF_, LG_)                                                        \
         GNNVC_LAUNCH((k_stage_f16<32, N2_, N3_, SIG_, 2, MF_, false, true>), grid, block, 0, stream, g, ws, in4, \
                            out, LG_, P, row_lo, row_hi, long_thresh, (const uint32_t *)nullptr, (const uint4 *)nullptr, \
@@ -2747,7 +2877,7 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
             else GNNVC_LAUNCH_AGG(32, 16, false, false, nullptr);
         } else {
             if (mfma_agg) GNNVC_LAUNCH_AGG(16, 1, true, true, logits);
-            else return launch_dense_sigmoid(sp, g, ws, params, in, out, logits, row_lo, row_hi, acc4, c4desc, agg16, stream);
+            else return launch_dense_sigmoid(sp, g, ws, params, in, out, logits, row_lo, row_hi, acc4, c4desc, agg16, stream, long_thresh);
         }
 #undef GNNVC_LAUNCH_AGG
     }
@@ -2892,33 +3022,49 @@ hipError_t lds_table_bytes(const uint32_t *w, uint32_t n, uint8_t *wb, uint32_t 
 }
 
 hipError_t lds_table_count(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t block_cols,
-                           uint32_t *seg_cnt, uint32_t *bad, hipStream_t stream, uint32_t row_base, uint32_t row_end) {
+                           uint32_t *seg_cnt, uint32_t *bad, hipStream_t stream, uint32_t row_base, uint32_t row_end,
+                           const PlanMap &pm) {
     if (row_end > g.n) row_end = g.n;
     if (nblocks > 4096 || block_cols > (1u << 18) || rows_per_chunk > (1u << 15)) return hipErrorInvalidValue;
     GNNVC_LAUNCH(k_lt_count, dim3(nchunks), dim3(1024), 0, stream, g, rows_per_chunk, nblocks, block_cols, seg_cnt, bad,
-                       row_base, row_end);
+                       row_base, row_end, pm);
     return hipGetLastError();
 }
 
 hipError_t lds_table_steps(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, const uint32_t *seg_cnt,
                            const uint32_t *step_ptr, uint32_t *step_count, void *steps, bool write, hipStream_t stream,
-                           uint32_t row_base, uint32_t row_end, uint32_t cap, uint32_t slack) {
+                           uint32_t row_base, uint32_t row_end, uint32_t cap, uint32_t slack, uint32_t block_cols,
+                           const PlanMap &pm) {
     if (row_end > g.n) row_end = g.n;
     if (cap == 0) cap = kLtStep;
     if (slack && slack < 3u * nblocks + 4u) return hipErrorInvalidValue;
     GNNVC_LAUNCH(k_lt_steps, dim3((nchunks + 255) / 256), dim3(256), 0, stream, g, rows_per_chunk, nchunks, nblocks,
-                       seg_cnt, step_ptr, step_count, reinterpret_cast<uint4 *>(steps), write ? 1 : 0, row_base, row_end, cap, slack);
+                       seg_cnt, step_ptr, step_count, reinterpret_cast<uint4 *>(steps), write ? 1 : 0, row_base, row_end, cap, slack,
+                       block_cols, pm);
     return hipGetLastError();
 }
 
 hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t block_cols,
                              const uint32_t *seg_cnt, uint32_t *entries, hipStream_t stream, uint32_t shift,
-                             uint32_t row_base, uint32_t row_end, uint32_t slack) {
+                             uint32_t row_base, uint32_t row_end, uint32_t slack, const PlanMap &pm) {
     if (block_cols > (1u << shift) || ((uint64_t)rows_per_chunk << shift) > (1ull << 32)) return hipErrorInvalidValue;
     if (slack && slack < 3u * nblocks + 4u) return hipErrorInvalidValue;
     if (row_end > g.n) row_end = g.n;
     GNNVC_LAUNCH(k_lt_scatter, dim3(nchunks), dim3(1024), 0, stream, g, rows_per_chunk, nblocks, block_cols, shift, seg_cnt,
-                       entries, row_base, row_end, slack);
+                       entries, row_base, row_end, slack, pm);
+    return hipGetLastError();
+}
+
+hipError_t deal_rows(const GraphDev &g, const uint32_t *sorted_rows, uint32_t m, uint32_t slice_rows, uint32_t nslices,
+                     uint32_t *rowmap, uint32_t *weight, hipStream_t stream) {
+    if (!nslices || !slice_rows) return hipErrorInvalidValue;
+    GNNVC_LAUNCH(k_map_deal, dim3((nslices + 3) / 4), dim3(256), 0, stream, g, sorted_rows, m, slice_rows, nslices, rowmap, weight);
+    return hipGetLastError();
+}
+
+hipError_t mass_bounds(const GraphDev &g, unsigned long long target, uint32_t count, uint32_t *cand, hipStream_t stream) {
+    if (!count) return hipSuccess;
+    GNNVC_LAUNCH(k_mass_bounds, dim3((count + 255) / 256), dim3(256), 0, stream, g, target, count, cand);
     return hipGetLastError();
 }
 
@@ -2968,41 +3114,41 @@ uint32_t compact_block() { return kC4Block; }
 uint32_t compact_shift() { return kC4Shift; }
 uint32_t compact_slices() { return kC4Slices; }
 uint32_t compact_step() { return kC4Step; }
+uint32_t compact_max_passes() { return kC4MaxPasses; }
 
-// counts -> desc -> table -> four sums per row of [row_lo, row_hi) (chunks that straddle the ends are done
-// whole).  `counts` holds the per-column non-zero counts of `in` (column_counts, same stream).
-hipError_t launch_compact_gather(const GraphDev &g, const float *in, const unsigned long long *counts, int count_slots, uint32_t *desc,
-                                 float *table, float *acc4, uint32_t row_lo, uint32_t row_hi, uint32_t rows_per_chunk,
-                                 const uint32_t *step_ptr, const void *steps, const uint32_t *entries, uint32_t *dirty_rows,
-                                 uint32_t dirty_cap, float *agg16, hipStream_t stream, uint32_t block_cols,
-                                 uint32_t plan_base, uint32_t plan_end, uint32_t last_entry, int what) {
-    if (row_hi <= row_lo || g.nnz == 0 || row_lo < plan_base || row_hi > plan_end) return hipErrorInvalidValue;
-    if (rows_per_chunk == 0 || rows_per_chunk > kC4MaxRows || rows_per_chunk % kC4Slices) return hipErrorInvalidValue;
-    if (what & 1) {   // prepare: choose the columns and (unless the producing kernel did) write the table
-        GNNVC_LAUNCH(k_c4_choose, dim3(1), dim3(64), 0, stream, counts, count_slots, g.n, desc);
+// counts -> desc -> table(s) -> four sums per pass and row of [row_lo, row_hi) (chunks that straddle the ends are done
+// whole; a mapped plan always does all of its rows).  `counts` holds the per-column non-zero counts of `in`
+// (column_counts, same stream).
+hipError_t launch_compact_gather(const GraphDev &g, const CompactPlan &cp, const float *in, const unsigned long long *counts,
+                                 int count_slots, uint32_t *desc, float *table, float *acc4, uint32_t row_lo, uint32_t row_hi,
+                                 uint32_t *dirty_rows, uint32_t dirty_cap, float *agg16, hipStream_t stream, int what) {
+    if (row_hi <= row_lo || g.nnz == 0 || row_lo < cp.plan_base || row_hi > cp.plan_end) return hipErrorInvalidValue;
+    if (cp.rows_per_chunk == 0 || cp.rows_per_chunk > kC4MaxRows || cp.rows_per_chunk % kC4Slices) return hipErrorInvalidValue;
+    if (cp.max_passes < 1 || cp.max_passes > kC4MaxPasses) return hipErrorInvalidValue;
+    if (what & 1) {   // prepare: choose the columns and (unless the producing kernel did) write the table(s)
+        GNNVC_LAUNCH(k_c4_choose, dim3(1), dim3(64), 0, stream, counts, count_slots, g.n, desc, cp.max_passes);
         GNNVC_LAUNCH(k_c4_compact, dim3(std::min<unsigned>((g.n + 256) / 256, 4096u)), dim3(256), 0, stream,
                            reinterpret_cast<const float4 *>(in), g.n, desc, reinterpret_cast<f32x4 *>(table));
     }
     if (!(what & 2)) return hipGetLastError();
     hipError_t rc0 = hipMemsetAsync(desc + 5, 0, sizeof(uint32_t), stream);   // dirty-row counter
     if (rc0 != hipSuccess) return rc0;
-    rc0 = compact_sums(g, desc, table, acc4, row_lo, row_hi, rows_per_chunk, step_ptr, steps, entries, dirty_rows, dirty_cap, stream,
-                       block_cols, plan_base, plan_end, last_entry);
+    rc0 = compact_sums(g, cp, desc, table, acc4, row_lo, row_hi, dirty_rows, dirty_cap, stream);
     if (rc0 != hipSuccess) return rc0;
     return compact_fix(g, in, desc, dirty_rows, dirty_cap, agg16, nullptr, stream);
 }
 
-// the sums of the chunks that hold rows [row_lo, row_hi) (the dirty-row counter desc[5] is the caller's to reset)
-hipError_t compact_sums(const GraphDev &g, uint32_t *desc, const float *table, float *acc4, uint32_t row_lo, uint32_t row_hi,
-                        uint32_t rows_per_chunk, const uint32_t *step_ptr, const void *steps, const uint32_t *entries,
-                        uint32_t *dirty_rows, uint32_t dirty_cap, hipStream_t stream, uint32_t block_cols, uint32_t plan_base,
-                        uint32_t plan_end, uint32_t last_entry, bool one_round) {
-    if (row_hi <= row_lo || g.nnz == 0 || row_lo < plan_base || row_hi > plan_end) return hipErrorInvalidValue;
-    if (rows_per_chunk == 0 || rows_per_chunk > kC4MaxRows || rows_per_chunk % kC4Slices) return hipErrorInvalidValue;
-    const uint32_t c0 = (row_lo - plan_base) / rows_per_chunk, c1 = (row_hi - 1 - plan_base) / rows_per_chunk + 1;
-    const uint32_t slice_rows = rows_per_chunk / kC4Slices;
-    const uint32_t nslices = ((plan_end - plan_base + rows_per_chunk - 1) / rows_per_chunk) * kC4Slices;
-    const uint32_t nblocks = (g.n + block_cols - 1) / block_cols;
+// the sums of the chunks that hold rows [row_lo, row_hi) (the dirty-row counter desc[5] is the caller's to reset): one
+// launch per pass the plan allows; the launches of passes the device did not choose (desc[0]) leave at once
+hipError_t compact_sums(const GraphDev &g, const CompactPlan &cp, uint32_t *desc, const float *table, float *acc4, uint32_t row_lo,
+                        uint32_t row_hi, uint32_t *dirty_rows, uint32_t dirty_cap, hipStream_t stream, bool one_round) {
+    if (row_hi <= row_lo || g.nnz == 0 || row_lo < cp.plan_base || row_hi > cp.plan_end) return hipErrorInvalidValue;
+    if (cp.rows_per_chunk == 0 || cp.rows_per_chunk > kC4MaxRows || cp.rows_per_chunk % kC4Slices) return hipErrorInvalidValue;
+    if (cp.rowmap && one_round) return hipErrorInvalidValue;
+    const uint32_t slice_rows = cp.rows_per_chunk / kC4Slices;
+    const uint32_t nslices = cp.rowmap ? cp.nslices : ((cp.plan_end - cp.plan_base + cp.rows_per_chunk - 1) / cp.rows_per_chunk) * kC4Slices;
+    const uint32_t c0 = cp.rowmap ? 0u : (row_lo - cp.plan_base) / cp.rows_per_chunk;
+    const uint32_t c1 = cp.rowmap ? nslices / kC4Slices : (row_hi - 1 - cp.plan_base) / cp.rows_per_chunk + 1;
     constexpr size_t lds_max = (size_t)kC4Slices * (kC4SliceRows * 16 + kC4DirtyWords * 4);
     static_assert(lds_max <= 160 * 1024, "LDS budget of k_c4_agg");
     const size_t lds = (size_t)kC4Slices * ((size_t)slice_rows * 16 + kC4DirtyWords * 4);
@@ -3014,16 +3160,18 @@ hipError_t compact_sums(const GraphDev &g, uint32_t *desc, const float *table, f
     }
     // a persistent grid of one workgroup per CU: they start together and sweep the column blocks together
     const dim3 grid(std::min<uint32_t>(256u, c1 - c0)), block(1024);
-    if (one_round)
-        GNNVC_LAUNCH(k_c4_agg<1>, grid, block, lds, stream, step_ptr,
-                           reinterpret_cast<const uint4 *>(steps), entries, reinterpret_cast<const f32x4 *>(table),
-                           reinterpret_cast<f32x4 *>(acc4), g.n, slice_rows, c0 * kC4Slices, std::min(c1 * kC4Slices, nslices), nslices,
-                           last_entry, desc, dirty_rows, dirty_cap, block_cols, nblocks, plan_base, plan_end);
-    else
-        GNNVC_LAUNCH(k_c4_agg<0>, grid, block, lds, stream, step_ptr,
-                           reinterpret_cast<const uint4 *>(steps), entries, reinterpret_cast<const f32x4 *>(table),
-                           reinterpret_cast<f32x4 *>(acc4), g.n, slice_rows, c0 * kC4Slices, std::min(c1 * kC4Slices, nslices), nslices,
-                           last_entry, desc, dirty_rows, dirty_cap, block_cols, nblocks, plan_base, plan_end);
+    for (uint32_t pass = 0; pass < cp.max_passes; ++pass) {
+        const f32x4 *tq = reinterpret_cast<const f32x4 *>(table) + (size_t)pass * ((size_t)g.n + 1);
+        f32x4 *aq = reinterpret_cast<f32x4 *>(acc4) + (size_t)pass * g.n;
+        if (one_round)
+            GNNVC_LAUNCH(k_c4_agg<1>, grid, block, lds, stream, cp.step_ptr, reinterpret_cast<const uint4 *>(cp.steps), cp.entries, tq, aq,
+                               g.n, slice_rows, c0 * kC4Slices, std::min(c1 * kC4Slices, nslices), nslices, cp.last_entry, desc,
+                               dirty_rows, dirty_cap, cp.block_cols, cp.nblocks, cp.plan_base, cp.plan_end, pass, cp.rowmap);
+        else
+            GNNVC_LAUNCH(k_c4_agg<0>, grid, block, lds, stream, cp.step_ptr, reinterpret_cast<const uint4 *>(cp.steps), cp.entries, tq, aq,
+                               g.n, slice_rows, c0 * kC4Slices, std::min(c1 * kC4Slices, nslices), nslices, cp.last_entry, desc,
+                               dirty_rows, dirty_cap, cp.block_cols, cp.nblocks, cp.plan_base, cp.plan_end, pass, cp.rowmap);
+    }
     return hipGetLastError();
 }
 

@@ -29,6 +29,24 @@ for wl in sys.argv[1:] or ["er10m"]:
         print(f"  stage {st}: live mask {e.live_columns(h[st].data_ptr(), g.n):#06x}  counts " +
               " ".join(f"{int(v)}" for v in c))
         print("           density " + " ".join(f"{v / g.n:.4f}" for v in c))
+        # entries that point to a vertex with a non-zero in the column (what a stray in that column would dirty), as a share
+        # of all entries, for all rows and for the rows below degree 1024 only
+        deg = (g.rowptr[1:] - g.rowptr[:-1]).to(torch.float64)[: g.n]
+        nzm = (h[st][: g.n] != 0).to(torch.float64)
+        print("           entry share " + " ".join(f"{float(v):.4f}" for v in (nzm * deg[:, None]).sum(0) / deg.sum()))
+        small = (deg < 1024).to(torch.float64)
+        print("           nz vertices of degree >= 1024 " + " ".join(f"{int(v)}" for v in (nzm * (1 - small)[:, None]).sum(0)))
+        # is "the row is all zero" a function of the degree?  per degree bucket: vertices, share with a non-zero row, share of all entries
+        anynz = (h[st][: g.n] != 0).any(1)
+        mx = int(deg[anynz].max()) if bool(anynz.any()) else -1
+        print(f"           vertices with a non-zero row: {int(anynz.sum())} of {g.n}; their largest degree {mx}; entries that point to them: "
+              f"{float((deg * anynz).sum() / deg.sum()):.4f} of all")
+        edges = [0, 1, 2, 4, 8, 16, 32, 48, 64, 96, 128, 192, 256, 384, 512, 1024, 1 << 30]
+        for a, b in zip(edges[:-1], edges[1:]):
+            m = (deg >= a) & (deg < b)
+            cnt = int(m.sum())
+            if cnt:
+                print(f"             degree [{a}, {b}): {cnt} vertices, {float((anynz & m).sum()) / cnt:.4f} non-zero, {float((deg * m).sum() / deg.sum()):.4f} of the entries")
         src = h[st]
     e.close()
     del g, h, x

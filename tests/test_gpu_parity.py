@@ -703,6 +703,80 @@ def test_compact_gather_long_runs(model_text, oracle_model):
             e.close()
 
 
+@pytest.mark.parametrize("maker,ncols,strays,passes_allowed,want_passes", [
+    (lambda: gg.rmat(14, 8, 3), 4, 0, 3, 1),                      # skewed, four live columns: one table
+    (lambda: gg.rmat(14, 8, 3), 7, 4, 3, 2),                      # seven live columns (+ strays): two tables
+    (lambda: gg.rmat(14, 8, 3), 10, 4, 3, 3),                     # ten: three
+    (lambda: gg.rmat(14, 8, 3), 13, 0, 3, 0),                     # thirteen: does not fit, the sorted gathering kernel runs
+    (lambda: gg.rmat(14, 8, 3), 7, 0, 1, 0),                      # two tables needed, one allowed: does not fit
+    (lambda: gg.hub_graph(30000, 200000, 3, 6000, seed=9), 6, 3, 3, 2),      # long AND giant rows beside the plan
+    (lambda: gg.chung_lu_hubs(40000, 8.0, 2.2, 2, 3000, seed=4), 9, 6, 3, 3),
+])
+def test_compact_gather_mapped_plan_is_bit_identical(model_text, oracle_model, maker, ncols, strays, passes_allowed, want_passes):
+    """The compact-table plan on SKEWED graphs: rows below the long-row threshold dealt from the degree-sorted list to
+    slices of equal weight, column blocks cut at equal entry mass, up to three tables of four columns per input; long and
+    giant rows keep their own kernels beside it.  Stage outputs equal the oracle's bit for bit whatever the device
+    decides (1, 2, 3 passes, or "does not fit" -> the gathering kernel)."""
+    import torch
+    import gnn_mwvc_amd as G
+    g = maker()
+    rng = np.random.default_rng(ncols * 7 + strays)
+    all_cols = [0, 1, 3, 5, 6, 7, 8, 10, 11, 14, 2, 4, 9]
+    live = sorted(all_cols[:ncols])
+    dens = [1.0 if i % 3 == 0 else (0.4 if i % 3 == 1 else 0.08) for i in range(ncols)]
+    dead = [c for c in range(16) if c not in live]
+    h = _sparse_features(g.n, rng, live, dens, strays, stray_cols=tuple(dead[:4]))
+    # what the device should decide: the 4 x passes fullest columns (ties: lowest index); a vertex with a non-zero outside
+    # them is a stray, and every row of the plan (1 <= degree < 512) that meets one is recomputed from full rows
+    counts = (h != 0).sum(axis=0)
+    order = sorted(range(16), key=lambda c: (-counts[c], c))
+    chosen = order[: 4 * want_passes]
+    stray_vertex = (h[:, [c for c in range(16) if c not in chosen]] != 0).any(axis=1)
+    rp = g.rowptr.astype(np.int64)
+    hits = np.concatenate(([0], np.cumsum(stray_vertex[g.col[: rp[-1]]])))
+    deg = np.diff(rp)
+    want_dirty = int(((hits[rp[1:]] > hits[rp[:-1]]) & (deg < 512)).sum()) if want_passes else 0
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_option("blocked_min_n", 0)
+        e.set_option("long_row_threshold", 256)
+        e.set_option("sorted_long_row_threshold", 512)
+        e.set_option("giant_row_threshold", 4096)
+        e.set_option("sorted_tiles", 1)
+        e.set_option("compact_skewed", 1)
+        e.set_option("compact_passes", passes_allowed)
+        e.set_weight_scale(g.ws)
+        oracle_model.set_weight_scale(g.ws)
+        e.upload_graph(g)
+        e.forward(g.x())
+        e.forward(g.x())
+        _, logits = e.forward(g.x())                       # third forward: every plan is built
+        assert e.get_info("compact_gather_active") == 1 and e.get_info("compact_gather_mapped") == 1
+        assert e.get_info("compact_gather_max_passes") == passes_allowed
+        assert np.array_equal(bits(logits[:, 0]), bits(oracle_model.logits(g)))
+        dev = torch.device("cuda:0")
+        hin = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+        hin[: g.n] = torch.from_numpy(h).to(dev)
+        for stage in (1, 2):
+            want = _oracle_stage(oracle_model, g, stage, h)
+            for lo, hi in ((0, g.n), (g.n // 4 // 64 * 64, g.n)):   # a mapped plan serves whole-graph calls only
+                out = torch.full((g.n + 1, 16 if stage == 1 else 1), 7.0, dtype=torch.float32, device=dev)
+                lg = torch.full((g.n + 1,), 7.0, dtype=torch.float32, device=dev)
+                torch.cuda.synchronize()
+                e.stage_forward_device(stage, lo, hi, hin.data_ptr(), out.data_ptr(), lg.data_ptr() if stage == 2 else 0)
+                e.synchronize()
+                if lo == 0:
+                    assert e.get_info("compact_gather_last_passes") == want_passes, (stage, e.get_info("compact_gather_last_passes"))
+                    if want_passes:
+                        assert e.get_info("compact_gather_last_dirty") == want_dirty
+                got = out[lo:hi].cpu().numpy() if stage == 1 else lg[lo:hi].cpu().numpy().reshape(-1, 1)
+                assert np.array_equal(bits(got), bits(want[lo:hi])), (stage, lo, hi)
+                rest = out[:lo].cpu().numpy() if stage == 1 else lg[:lo].cpu().numpy()
+                assert np.all(rest == 7.0)                 # rows outside the call are untouched
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("chunk_rows,overlap,maker", [
     (16, 1, lambda: gg.erdos_renyi(20000, 200000, 72)),     # one row per wave slice: 1250 chunks, five rounds of the grid
     (16, 0, lambda: gg.erdos_renyi(20000, 200000, 72)),     # the same with the last stage's dense layers after, not under, the sums
