@@ -154,6 +154,20 @@ struct gnnvc_engine {
     int c4_prepared_stage = -1;         // gnnvc_stage_input_ready: the table holds this stage's input ...
     const float *c4_prepared_in = nullptr;   // ... as found at this address
     int c4_fused_for = -1;          // stage whose input statistics (and table) the previous stage kernel of this forward produced
+    // pruned adjacency of the 16-wide stages (kernels: k_prune_*), one per consumer stage: built from the input the stage
+    // sees the second time the graph is scored; every later call proves on the device that its input still fits
+    struct PrunePlan {
+        bool tried = false, ready = false;
+        uint32_t bound = 0, observed = 0;   // vertices of degree >= bound are expected to have all-zero rows (largest degree seen with a non-zero row)
+        uint64_t kept = 0;                  // entries left
+        DevBuf<uint32_t> prp, pcol, heavy;
+    };
+    PrunePlan prune[4];
+    DevBuf<uint32_t> prune_flags, prune_scratch;   // flags: [stage] = this call's verdict (0 = the pruned adjacency applies), [3] = observe
+    int opt_prune = 1;               // option "prune_zero_rows"
+    int opt_prune_giant = 1;         // option "prune_giant_rows" (A/B): 0 = the giant rows keep their full streams
+    uint64_t opt_prune_min_nnz = 1u << 20;   // option "prune_min_entries": smaller graphs are not worth a plan
+    uint32_t opt_prune_min_drop = 15;   // option "prune_min_drop_percent": build only if at least this share of the entries goes
     int c4_last_desc = 0;           // word offset in c4_desc of the plan's last launch (tests / tools)
     static constexpr int kDescWords = 16;   // per consumer stage (see k_c4_choose); the build flag follows the last stage's
 
@@ -918,6 +932,61 @@ int ensure_round_events(gnnvc_engine *e, size_t count) {
     return GNNVC_OK;
 }
 
+// Pruned adjacency for consumer stage `stage` (see k_prune_*): built once per graph from the input `in` of the call at hand.
+int build_prune_impl(gnnvc_engine *e, int stage, const float *in) {
+    gnnvc_engine::PrunePlan &pp = e->prune[stage];
+    pp.tried = true;
+    pp.ready = false;
+    const GraphDev &g = e->g;
+    if (!e->opt_prune || g.sliced() || g.n == 0 || g.nnz < e->opt_prune_min_nnz) return GNNVC_OK;
+    HIP_TRY(e, e->prune_flags.reserve(8));
+    HIP_TRY(e, gnnvc::prune_observe(g, in, e->prune_flags.p + 3, e->stream));
+    uint32_t seen = 0;
+    HIP_TRY(e, hipMemcpyAsync(&seen, e->prune_flags.p + 3, sizeof seen, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    // the bound: some way above the largest degree that still had a non-zero row, so that inputs that differ a little
+    // from this one still pass the per-call check
+    pp.observed = seen;
+    pp.bound = seen + seen / 8 + 2;
+    HIP_TRY(e, pp.heavy.reserve(((size_t)g.n + 31) / 32 + 1));
+    HIP_TRY(e, pp.prp.reserve((size_t)g.n + 1));
+    HIP_TRY(e, e->prune_scratch.reserve(gnnvc::blocked_scan_scratch_elems((size_t)g.n + 1)));
+    HIP_TRY(e, gnnvc::prune_count(g, pp.bound, pp.heavy.p, pp.prp.p, e->prune_scratch.p, e->stream));
+    uint32_t kept = 0;
+    HIP_TRY(e, hipMemcpyAsync(&kept, pp.prp.p + g.n, sizeof kept, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    pp.kept = kept;
+    if ((uint64_t)kept * 100 > g.nnz * (uint64_t)(100 - std::min(e->opt_prune_min_drop, 100u))) {   // too little to gain
+        pp.prp.release();
+        pp.heavy.release();
+        return GNNVC_OK;
+    }
+    HIP_TRY(e, pp.pcol.reserve((size_t)kept + GNNVC_COL_PAD));
+    HIP_TRY(e, hipMemsetAsync(pp.pcol.p + kept, 0, GNNVC_COL_PAD * sizeof(uint32_t), e->stream));
+    HIP_TRY(e, gnnvc::prune_fill(g, pp.heavy.p, pp.prp.p, pp.pcol.p, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    pp.ready = true;
+    return GNNVC_OK;
+}
+
+// The graph as this call's gathering kernels see it: with the pruned adjacency attached when the stage has one (the
+// check of this very input is queued here, ahead of every kernel that reads its verdict).
+int gather_view(gnnvc_engine *e, int stage, const float *in, GraphDev &gv) {
+    gv = e->g;
+    if (stage < 1 || stage > 3 || e->stages[stage].f != 16 || !e->opt_prune) return GNNVC_OK;
+    gnnvc_engine::PrunePlan &pp = e->prune[stage];
+    if (!pp.tried && e->graph_uses >= 2) {
+        int rc = timed_build(e, [&] { return build_prune_impl(e, stage, in); });
+        if (rc) return rc;
+    }
+    if (!pp.ready) return GNNVC_OK;
+    HIP_TRY(e, gnnvc::prune_check(e->g, in, pp.heavy.p, e->prune_flags.p + stage, e->stream));
+    gv.prp = pp.prp.p;
+    gv.pcol = pp.pcol.p;
+    gv.prune_bad = e->prune_flags.p + stage;
+    return GNNVC_OK;
+}
+
 // ---------------------------------------------------------------- one stage call = plan selection, then launches
 //
 // choose_stage  decides WHAT a call runs: which of the per-graph plans serves the neighbour sums (building a plan the
@@ -1022,8 +1091,8 @@ int choose_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const flo
 }
 
 // fork: the long (and giant) rows of this stage beside the tile kernel
-int launch_side_rows(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float *in, float *out, float *logits,
-                     uint32_t thr) {
+int launch_side_rows(gnnvc_engine *e, const GraphDev &gv, int stage, uint32_t lo, uint32_t hi, const float *in, float *out,
+                     float *logits, uint32_t thr) {
     const bool side = e->opt_side_streams != 0;
     hipStream_t s_long = side ? e->aux_stream : e->stream, s_giant = side ? e->giant_stream : e->stream;
     if (side) {
@@ -1039,19 +1108,19 @@ int launch_side_rows(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const
         gr.off = e->gi_off.p;
         gr.slab = e->gi_slab.p;
         gr.agg = e->gi_agg.p;
-        HIP_TRY(e, gnnvc::launch_giant_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi, gr,
+        HIP_TRY(e, gnnvc::launch_giant_stage(e->stages[stage], e->opt_prune_giant ? gv : e->g, e->ws, e->params.p, in, out, logits, lo, hi, gr,
                                              e->opt_hub_mode == 1, s_giant));
         if (side) HIP_TRY(e, hipEventRecord(e->ev_giant, e->giant_stream));
     }
     if (e->n_giant < e->n_long)
-        HIP_TRY(e, gnnvc::launch_long_stage(e->stages[stage], e->g, e->ws, e->params.p, in, out, logits, lo, hi,
+        HIP_TRY(e, gnnvc::launch_long_stage(e->stages[stage], gv, e->ws, e->params.p, in, out, logits, lo, hi,
                                             e->long_list.p, e->n_long, thr, e->giant_thresh, s_long));
     if (side) HIP_TRY(e, hipEventRecord(e->ev_join, e->aux_stream));
     return GNNVC_OK;
 }
 
-int launch_main(gnnvc_engine *e, const StageChoice &c, int stage, uint32_t lo, uint32_t hi, const float *in, float *out,
-                float *logits) {
+int launch_main(gnnvc_engine *e, const StageChoice &c, const GraphDev &gv, int stage, uint32_t lo, uint32_t hi, const float *in,
+                float *out, float *logits) {
     const gnnvc::StagePlan &sp = e->stages[stage];
     gnnvc::EmitArgs emit;
     // (the counters are zeroed only AFTER this stage's own k_c4_choose has read what the previous stage kernel left in them)
@@ -1098,7 +1167,7 @@ int launch_main(gnnvc_engine *e, const StageChoice &c, int stage, uint32_t lo, u
         if (rc) return rc;
     }
     const gnnvc::SortedOrder *sop = c.sorted.n ? &c.sorted : nullptr;
-    HIP_TRY(e, gnnvc::launch_stage(sp, e->g, e->ws, e->params.p, in, out, logits, lo, hi, c.long_thresh, c.mfma, sop,
+    HIP_TRY(e, gnnvc::launch_stage(sp, gv, e->ws, e->params.p, in, out, logits, lo, hi, c.long_thresh, c.mfma, sop,
                                    e->interleave, e->stream, acc4, desc, e->c4_agg16.p, e->opt_mfma == 1, emit,
                                    /*dense_part=*/!c.rounds));
     if (!c.rounds) return GNNVC_OK;
@@ -1142,11 +1211,14 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
     int rc = choose_stage(e, stage, lo, hi, in, out, in_forward, c);
     if (rc) return rc;
     const bool longs = e->n_long > 0;
+    GraphDev gv;   // (the check behind a pruned adjacency is queued before the fork to the side streams)
+    rc = gather_view(e, stage, in, gv);
+    if (rc) return rc;
     if (longs) {
-        rc = launch_side_rows(e, stage, lo, hi, in, out, logits, c.long_thresh);
+        rc = launch_side_rows(e, gv, stage, lo, hi, in, out, logits, c.long_thresh);
         if (rc) return rc;
     }
-    rc = launch_main(e, c, stage, lo, hi, in, out, logits);
+    rc = launch_main(e, c, gv, stage, lo, hi, in, out, logits);
     if (rc) return rc;
     if (longs && e->opt_side_streams) {   // join
         HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
@@ -1290,6 +1362,8 @@ void gnnvc_destroy(gnnvc_engine *e) {
     e->c4_entries.release(); e->c4_segcnt.release(); e->c4_stepptr.release(); e->c4_stepcnt.release();
     e->c4_desc.release(); e->c4_rowmap.release(); e->c4_first.release(); e->c4_bstart.release(); e->c4_map_vertex.release(); e->c4_map_meta.release(); e->c4_steps.release(); e->c4_table.release(); e->c4_marks.release(); e->c4_acc.release(); e->c4_counts.release();
     e->c4_agg16.release(); e->c4_dirty.release(); e->c4_emit_counts.release();
+    for (auto &pp : e->prune) { pp.prp.release(); pp.pcol.release(); pp.heavy.release(); }
+    e->prune_flags.release(); e->prune_scratch.release();
     e->long_list.release(); e->long_count.release();
     e->gi_meta.release(); e->gi_off.release(); e->gi_slab.release(); e->gi_agg.release();
     e->rowptr2.release(); e->col2.release(); e->der_old_row.release(); e->der_new_of.release(); e->der_tail.release();
@@ -1336,6 +1410,10 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "side_streams") e->opt_side_streams = value != 0 ? 1 : 0;
     else if (k == "kernel_trace") e->opt_ktrace = value != 0 ? 1 : 0;
     else if (k == "compact_gather") e->opt_compact = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
+    else if (k == "prune_zero_rows") { e->opt_prune = value != 0 ? 1 : 0; for (auto &pp : e->prune) pp.tried = pp.ready = false; }
+    else if (k == "prune_giant_rows") e->opt_prune_giant = value != 0 ? 1 : 0;
+    else if (k == "prune_min_entries") e->opt_prune_min_nnz = value > 0 ? (uint64_t)value : 0;
+    else if (k == "prune_min_drop_percent") e->opt_prune_min_drop = value < 0 ? 0u : (value > 100 ? 100u : (uint32_t)value);
     else if (k == "compact_skewed") { e->opt_compact_skewed = value != 0 ? 1 : 0; e->c4_tried = false; e->c4_ready = false; }
     else if (k == "compact_passes") { e->opt_compact_passes = value < 1 ? 1u : (value > 3 ? 3u : (uint32_t)value); e->c4_tried = false; e->c4_ready = false; }
     else if (k == "lds_table") e->opt_lds_table = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
@@ -1355,6 +1433,22 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
     else if (k == "compact_gather_block_cols") *value = e->c4_ready ? (long)e->c4_block : 0;
     else if (k == "compact_gather_rows_per_chunk") *value = e->c4_ready ? (long)e->c4_rows : 0;
     else if (k == "compact_gather_steps") *value = e->c4_ready ? (long)e->c4_steps_total : 0;
+    else if (k == "pruned_stage1" || k == "pruned_stage2") *value = e->prune[k.back() - '0'].ready ? 1 : 0;
+    else if (k == "pruned_bound_stage1" || k == "pruned_bound_stage2") *value = e->prune[k.back() - '0'].ready ? (long)e->prune[k.back() - '0'].bound : 0;
+    else if (k == "pruned_observed_stage1" || k == "pruned_observed_stage2") *value = e->prune[k.back() - '0'].tried ? (long)e->prune[k.back() - '0'].observed : 0;
+    else if (k == "pruned_entries_stage1" || k == "pruned_entries_stage2") *value = e->prune[k.back() - '0'].ready ? (long)e->prune[k.back() - '0'].kept : 0;
+    else if (k == "pruned_last_ok_stage1" || k == "pruned_last_ok_stage2") {
+        // did the last call of that stage use its pruned adjacency?  (waits for the stream; tests and tools)
+        const int st = k.back() - '0';
+        *value = 0;
+        if (e->prune[st].ready) {
+            uint32_t bad = 1;
+            if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess ||
+                hipMemcpy(&bad, e->prune_flags.p + st, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess)
+                return GNNVC_ERR_DEVICE;
+            *value = bad == 0 ? 1 : 0;
+        }
+    }
     else if (k == "compact_gather_mapped") *value = e->c4_ready && e->c4_mapped ? 1 : 0;
     else if (k == "compact_gather_blocks") *value = e->c4_ready ? (long)e->c4_nblocks : 0;
     else if (k == "compact_gather_mapped_rows") *value = e->c4_ready ? (long)e->c4_mapped_rows : 0;
@@ -1429,6 +1523,7 @@ static int adopt_uploaded(gnnvc_engine *e, uint32_t n, uint64_t nnz) {
     if (rc) return rc;
     e->lt_ready = e->lt_tried = false;
     e->c4_ready = e->c4_tried = false;
+    for (auto &pp : e->prune) pp.tried = pp.ready = false;
     e->c4_range_mode = false;
     e->c4_prepared_stage = -1;
     e->blocked_ready = false;   // the column-blocked index is built on the graph's SECOND forward:
@@ -1569,6 +1664,7 @@ static int attach_common(gnnvc_engine *e, const GraphDev &cand) {
     if (rc) return rc;
     e->lt_ready = e->lt_tried = false;
     e->c4_ready = e->c4_tried = false;
+    for (auto &pp : e->prune) pp.tried = pp.ready = false;
     e->c4_range_mode = false;
     e->c4_prepared_stage = -1;
     e->blocked_ready = false;   // the column-blocked index is built on the graph's SECOND forward:

@@ -24,6 +24,11 @@ struct GraphDev {
     // still indexed by global row id (valid for those rows only, row pointers relative to the slice's first
     // entry), col holds the slice's nnz entries with GLOBAL column ids.  row_end == 0: the whole graph.
     uint32_t row_base = 0, row_end = 0;
+    // Pruned view of the adjacency for ONE call of a 16-wide stage (set by the engine for that call, see "pruned
+    // adjacency" in gnnvc_kernels.hip): the entries whose target row is known to be all zero in this call's input are
+    // left out of prp / pcol (n + 1 offsets, the kept entries in CSR order + GNNVC_COL_PAD).  The gathering kernels
+    // use it iff *prune_bad == 0 (decided on the device for this very input); rowptr stays the source of degrees.
+    const uint32_t *prp = nullptr, *pcol = nullptr, *prune_bad = nullptr;
 #if defined(__HIPCC__)
     __host__ __device__
 #endif
@@ -187,6 +192,13 @@ hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_
                              const uint32_t *seg_cnt, uint32_t *entries, hipStream_t stream, uint32_t shift = 17,
                              uint32_t row_base = 0, uint32_t row_end = 0xFFFFFFFFu, uint32_t slack = 0,
                              const PlanMap &pm = PlanMap());
+// Pruned adjacency (k_prune_*): observe = largest degree among the vertices with a non-zero row of feat (16 columns);
+// build = heavy-vertex bitmap (degree >= bound), prp (n + 1, scanned in place; scratch as for blocked_scan_scratch_elems(n + 1))
+// and, once the caller has sized pcol from prp[n], the kept entries; check = *bad |= 1 if a heavy vertex has a non-zero row.
+hipError_t prune_observe(const GraphDev &g, const float *feat, uint32_t *max_deg, hipStream_t stream);
+hipError_t prune_count(const GraphDev &g, uint32_t bound, uint32_t *heavy_bits, uint32_t *prp, uint32_t *scratch, hipStream_t stream);
+hipError_t prune_fill(const GraphDev &g, const uint32_t *heavy_bits, const uint32_t *prp, uint32_t *pcol, hipStream_t stream);
+hipError_t prune_check(const GraphDev &g, const float *feat, const uint32_t *heavy_bits, uint32_t *bad, hipStream_t stream);
 // rows of a degree-sorted list (heaviest first; the first m of it) dealt serpentine to nslices slices of slice_rows slots:
 // rowmap[s * slice_rows + t], weight[s] = entries of slice s
 hipError_t deal_rows(const GraphDev &g, const uint32_t *sorted_rows, uint32_t m, uint32_t slice_rows, uint32_t nslices,

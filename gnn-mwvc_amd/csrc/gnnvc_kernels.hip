@@ -330,6 +330,10 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
     const uint32_t tile = tile_for_wave(ntiles, SORTED || interleave);
     if (tile >= ntiles) return;
     const uint32_t v0 = row_lo + tile * kWave;   // natural order only
+    // the entries to gather: the whole adjacency, or (uniform; decided on the device for this input) the pruned one
+    const bool pruned = !AGGONLY && g.prune_bad != nullptr && *g.prune_bad == 0u;
+    const uint32_t *__restrict__ grp = pruned ? g.prp : g.rowptr;
+    const uint32_t *__restrict__ gcol = pruned ? g.pcol : g.col;
 
     // lane-per-vertex view of the tile
     uint32_t u, rs, re;
@@ -341,8 +345,8 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
         const uint32_t sl = mine ? slot : n_sorted - 1;
         u = srt_vertex[sl];
         const uint4 meta = srt_meta[sl];
-        rs = meta.x;
-        re = mine ? meta.y : rs;
+        rs = pruned ? grp[u] : meta.x;
+        re = mine ? (pruned ? grp[u + 1] : meta.y) : rs;
         f_deg = (float)(meta.y - meta.x);
         f_w = (float)meta.z / ws;
         f_nw = (float)meta.w / ws;
@@ -350,13 +354,14 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
         const uint32_t uu = v0 + lane;
         const bool valid = uu < row_hi;
         u = valid ? uu : row_hi - 1;
-        rs = g.rowptr[u];
-        const uint32_t re_full = valid ? g.rowptr[u + 1] : rs;
+        const uint32_t rs_full = g.rowptr[u];
+        const uint32_t re_full = valid ? g.rowptr[u + 1] : rs_full;
         // rows of degree >= long_thresh belong to the long-row kernel (k_long_f16): no gather,
         // no store for them here
-        mine = valid && (re_full - rs) < long_thresh;
-        re = mine ? re_full : rs;
-        f_deg = (float)(re_full - rs);
+        mine = valid && (re_full - rs_full) < long_thresh;
+        rs = pruned ? grp[u] : rs_full;
+        re = mine ? (pruned ? grp[u + 1] : re_full) : rs;
+        f_deg = (float)(re_full - rs_full);
         f_w = (float)g.w[u] / ws;
         f_nw = (float)g.nw[u] / ws;
     }
@@ -367,9 +372,9 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
     if constexpr (!SORTED && !AGGONLY) {
         const uint32_t c0 = __builtin_amdgcn_readfirstlane(rs);
         const uint32_t vend = (v0 + kWave < row_hi) ? v0 + kWave : row_hi;
-        const uint32_t c1 = g.rowptr[vend];   // wave-uniform: end of the tile's last valid row
+        const uint32_t c1 = grp[vend];        // wave-uniform: end of the tile's last valid row
         staged = (c1 - c0) <= kStageCap;
-        if (staged) sbase = stage_cols(g.col, c0, c1, stage, lane);
+        if (staged) sbase = stage_cols(gcol, c0, c1, stage, lane);
     }
 
     // ---- quad layout: quad q of lanes owns the tile's vertices 16p + q (p = 0..3),
@@ -429,7 +434,7 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
             for (int s = 0; s < S; ++s) {
                 const uint32_t ee = b[p] + s;
                 // staged: ee - sbase < 1792 + S always (ee <= c1 + S - 1); slots past c1 hold junk, masked below
-                const uint32_t cv = staged ? stage[ee - sbase] : g.col[ee];
+                const uint32_t cv = staged ? stage[ee - sbase] : gcol[ee];
                 idx[p][s] = (ee < e[p]) ? cv : zrow;
             }
         float4 r[4][S];
@@ -887,24 +892,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const uint32_t u = list[blockIdx.x];
     if (u < row_lo || u >= row_hi) return;   // block-uniform
     const int tid = threadIdx.x, q = tid >> 2, c = tid & 3;
-    const uint32_t rs = g.rowptr[u], re = g.rowptr[u + 1];
-    const uint32_t deg = re - rs;
+    const uint32_t deg = g.rowptr[u + 1] - g.rowptr[u];
     if (deg < min_deg) return;               // listed for another stage's threshold; a tile kernel has it here
     if (deg >= max_deg) return;              // a giant row: the k_giant_* kernels have it
+    // the entries to gather: the row's whole list, or its pruned one (see k_prune_*; gdeg may be 0)
+    const bool pruned = g.prune_bad != nullptr && *g.prune_bad == 0u;
+    const uint32_t *__restrict__ gcol = pruned ? g.pcol : g.col;
+    const uint32_t rs = pruned ? g.prp[u] : g.rowptr[u], re = pruned ? g.prp[u + 1] : g.rowptr[u + 1];
+    const uint32_t gdeg = re - rs, last = gdeg ? re - 1 : rs;   // (col arrays are padded: [rs] is readable)
     const uint32_t zrow = g.n;
     // Two register sets (A, B) alternate: while one round drains through the slab, the
     // 1024 row fetches of the next round and the column indices of the round after it are
     // in flight, so neither memory latency sits on the sequential add chain.
     constexpr int R = kLongR;
     constexpr uint32_t kRound = kLongRound;
-    const uint32_t nrounds = (deg + kRound - 1) / kRound;
+    const uint32_t nrounds = (gdeg + kRound - 1) / kRound;
     uint32_t idx[R];
     f32x4 ra[R], rb[R];
     const f32x4 *__restrict__ fv = reinterpret_cast<const f32x4 *>(fin);
 #define GNNVC_FETCH_IDX(rd_)                                              \
     _Pragma("unroll") for (int j = 0; j < R; ++j) {                        \
         const uint32_t e_ = rs + (rd_) * kRound + q + 64 * j;             \
-        idx[j] = g.col[e_ < re ? e_ : re - 1]; /* raw: not consumed until the next round */ \
+        idx[j] = gcol[e_ < re ? e_ : last]; /* raw: not consumed until the next round */ \
     }
 #define GNNVC_FETCH_ROWS(dst_, rd_)                                       \
     _Pragma("unroll") for (int j = 0; j < R; ++j) {                        \
@@ -921,11 +930,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     for (uint32_t rd = 0; rd < nrounds; rd += 2) {
         GNNVC_FETCH_ROWS(rb, rd + 1)
         GNNVC_FETCH_IDX(rd + 2)
-        long_drain_round(ra, slab, deg - rd * kRound, tid, q, c, acc);
+        long_drain_round(ra, slab, gdeg - rd * kRound, tid, q, c, acc);
         if (rd + 1 >= nrounds) break;
         GNNVC_FETCH_ROWS(ra, rd + 2)
         GNNVC_FETCH_IDX(rd + 3)
-        long_drain_round(rb, slab, deg - (rd + 1) * kRound, tid, q, c, acc);
+        long_drain_round(rb, slab, gdeg - (rd + 1) * kRound, tid, q, c, acc);
     }
 #undef GNNVC_FETCH_IDX
 #undef GNNVC_FETCH_ROWS
@@ -1049,15 +1058,21 @@ __global__ __launch_bounds__(256) void k_giant_gather16(GraphDev g, const float4
     const uint32_t i = giant_of_block(meta, n_giant, blockIdx.x);
     const uint4 mt = meta[i];
     if (mt.x < row_lo || mt.x >= row_hi) return;      // block-uniform
-    const uint32_t j0 = (blockIdx.x - mt.w) * kGiantBlk, deg = mt.z;
+    // the row's entries: all of them, or (pruned adjacency, see k_prune_*) those whose target row may be non-zero — the
+    // streams then are shorter, in the same slab region
+    const bool pruned = g.prune_bad != nullptr && *g.prune_bad == 0u;
+    const uint32_t *__restrict__ gcol = pruned ? g.pcol : g.col;
+    const uint32_t first = pruned ? g.prp[mt.x] : mt.y, deg = pruned ? g.prp[mt.x + 1] - first : mt.z;
+    const uint32_t j0 = (blockIdx.x - mt.w) * kGiantBlk;
     const uint32_t lpad = (deg + kGiantWin - 1) / kGiantWin * kGiantWin;
+    if (j0 >= lpad) return;                            // (block-uniform; only a pruned row has such blocks)
     const int tid = threadIdx.x, q = tid >> 2, c = tid & 3;
     const f32x4 *__restrict__ fv = reinterpret_cast<const f32x4 *>(fin);
     uint32_t idx[4];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
         const uint32_t j = j0 + q + 64 * jj;
-        idx[jj] = j < deg ? g.col[mt.y + j] : g.n;    // past the row's end: the all-zero pad row
+        idx[jj] = j < deg ? gcol[first + j] : g.n;     // past the row's end: the all-zero pad row
     }
     f32x4 r[4];
 #pragma unroll
@@ -1157,14 +1172,20 @@ __device__ __forceinline__ void giant_window(const f32x4 (&d)[kGiantB / 4], int 
 template <bool FAST>
 __global__ __launch_bounds__(64) void k_giant_sum(const float *__restrict__ slab, const uint4 *__restrict__ meta,
                                                   const unsigned long long *__restrict__ off, uint32_t F, float *__restrict__ agg,
-                                                  uint32_t row_lo, uint32_t row_hi) {
+                                                  uint32_t row_lo, uint32_t row_hi, const uint32_t *__restrict__ prp,
+                                                  const uint32_t *__restrict__ prune_bad) {
     const uint32_t i = blockIdx.x / F, c = blockIdx.x % F;
     const uint4 mt = meta[i];
     if (mt.x < row_lo || mt.x >= row_hi) return;
     const int lane = threadIdx.x;
-    const uint32_t len = mt.z;
+    const bool pruned = prune_bad != nullptr && *prune_bad == 0u;   // (the gather kernel wrote the shorter streams)
+    const uint32_t len = pruned ? prp[mt.x + 1] - prp[mt.x] : mt.z;
     const uint32_t lpad = (len + kGiantWin - 1) / kGiantWin * kGiantWin;
     const uint32_t nwin = lpad / kGiantWin;
+    if (nwin == 0) {   // nothing left of the row: a sum of no addends
+        if (lane == 0) agg[(size_t)i * 16 + c] = 0.0f;
+        return;
+    }
     const f32x4 *__restrict__ src = reinterpret_cast<const f32x4 *>(slab + off[i] + (size_t)c * lpad) + lane * (kGiantB / 4);
     f32x4 buf[kGiantRing][kGiantB / 4];
     // loads are unconditional (clamped to the last window) so that the in-order vmcnt waits cover exactly the window
@@ -2102,6 +2123,105 @@ __global__ __launch_bounds__(256) void k_c4_fix(GraphDev g, const float4 *__rest
 
 // marks[k] = the number of dirty-row slots handed out so far (after round k - 1 of the aggregation grid)
 __global__ void k_c4_mark(const uint32_t *__restrict__ desc, uint32_t *__restrict__ marks, uint32_t k) { marks[k] = desc[5]; }
+
+// ------------------------------------------------------------------ pruned adjacency (skewed graphs, 16-wide stages)
+// On skewed graphs the trained model drives the features of every high-degree vertex to zero: after the first stage
+// no vertex of R-MAT-22 above degree 145 has a non-zero among its 16 values (after the second: above 96), and 73 % /
+// 86 % of all adjacency entries point to such vertices.  Adding a row of zeros changes no bit of a sum (x + (+-0) == x,
+// and the sums start at +0), so those entries need not be gathered at all.  Per graph and consumer stage the engine
+// builds a second CSR without the entries whose target has degree >= a bound (taken from the input it sees when the plan
+// is built, plus a margin); per call k_prune_check proves on the device, for the input at hand, that every vertex of
+// degree >= bound really has an all-zero row — if one does not, the call uses the full adjacency.  Same sums, bit for bit.
+__global__ __launch_bounds__(256) void k_prune_observe(GraphDev g, const float4 *__restrict__ feat, uint32_t *__restrict__ max_deg) {
+    uint32_t best = 0;
+    bool any = false;
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < g.n; u += gridDim.x * blockDim.x) {
+        const float4 a = feat[(size_t)u * 4], b = feat[(size_t)u * 4 + 1], c = feat[(size_t)u * 4 + 2], d = feat[(size_t)u * 4 + 3];
+        const bool nz = a.x != 0.f || a.y != 0.f || a.z != 0.f || a.w != 0.f || b.x != 0.f || b.y != 0.f || b.z != 0.f || b.w != 0.f ||
+                        c.x != 0.f || c.y != 0.f || c.z != 0.f || c.w != 0.f || d.x != 0.f || d.y != 0.f || d.z != 0.f || d.w != 0.f;
+        if (nz) {   // (NaN != 0: a row with a NaN counts as non-zero)
+            const uint32_t deg = g.rowptr[u + 1] - g.rowptr[u];
+            best = deg > best ? deg : best;
+            any = true;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+        const uint32_t o = __shfl_xor(best, off);
+        best = o > best ? o : best;
+    }
+    if (__any(any) && (threadIdx.x & 63) == 0) atomicMax(max_deg, best);
+}
+
+// heavy_bits: bit v = degree(v) >= bound (one thread per word)
+__global__ __launch_bounds__(256) void k_prune_mark(GraphDev g, uint32_t bound, uint32_t *__restrict__ heavy_bits) {
+    const uint32_t wd = blockIdx.x * blockDim.x + threadIdx.x;
+    if (wd >= (g.n + 31) / 32) return;
+    uint32_t bits = 0;
+    for (uint32_t i = 0; i < 32; ++i) {
+        const uint32_t v = wd * 32 + i;
+        if (v < g.n && g.rowptr[v + 1] - g.rowptr[v] >= bound) bits |= 1u << i;
+    }
+    heavy_bits[wd] = bits;
+}
+
+// One wave per 64 consecutive rows.  Rows of fewer than 64 entries: one lane each.  Longer rows: the whole wave, 64 entries
+// at a time, kept entries ranked by a ballot — so the order of a row's kept entries is the CSR order.
+// FILL == false: kept[u] = number of kept entries.  FILL == true: pcol[prp[u] ...] = the kept entries.
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_prune_rows(GraphDev g, const uint32_t *__restrict__ heavy_bits, uint32_t *__restrict__ kept,
+                                                    const uint32_t *__restrict__ prp, uint32_t *__restrict__ pcol) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t ntiles = (g.n + 63) / 64;
+    for (uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += gridDim.x * 4) {
+        const uint32_t u = tile * 64 + lane;
+        const bool valid = u < g.n;
+        const uint32_t rs = valid ? g.rowptr[u] : 0u, re = valid ? g.rowptr[u + 1] : 0u;
+        const bool wide = re - rs >= 64u;
+        if (valid && !wide) {
+            uint32_t k = 0;
+            const uint32_t out = FILL ? prp[u] : 0u;
+            for (uint32_t e = rs; e < re; ++e) {
+                const uint32_t c = g.col[e];
+                if (!(heavy_bits[c >> 5] >> (c & 31) & 1u)) {
+                    if (FILL) pcol[out + k] = c;
+                    ++k;
+                }
+            }
+            if (!FILL) kept[u] = k;
+        }
+        unsigned long long todo = __ballot(valid && wide);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const uint32_t ru = tile * 64 + (uint32_t)src;
+            const uint32_t a = __shfl(rs, src), b = __shfl(re, src);
+            uint32_t k = FILL ? prp[ru] : 0u;
+            for (uint32_t e0 = a; e0 < b; e0 += 64) {
+                const uint32_t e = e0 + lane;
+                const uint32_t c = e < b ? g.col[e] : 0u;
+                const bool keep = e < b && !(heavy_bits[c >> 5] >> (c & 31) & 1u);
+                const unsigned long long m = __ballot(keep);
+                if (FILL && keep) pcol[k + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = c;
+                k += (uint32_t)__popcll(m);
+            }
+            if (!FILL && lane == 0) kept[ru] = k;
+        }
+    }
+}
+
+// *bad |= 1 if a heavy vertex has a non-zero among its 16 values
+__global__ __launch_bounds__(256) void k_prune_check(GraphDev g, const float4 *__restrict__ feat, const uint32_t *__restrict__ heavy_bits,
+                                                     uint32_t *__restrict__ bad) {
+    bool miss = false;
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < g.n; u += gridDim.x * blockDim.x) {
+        if (!(heavy_bits[u >> 5] >> (u & 31) & 1u)) continue;
+        const float4 a = feat[(size_t)u * 4], b = feat[(size_t)u * 4 + 1], c = feat[(size_t)u * 4 + 2], d = feat[(size_t)u * 4 + 3];
+        miss |= a.x != 0.f || a.y != 0.f || a.z != 0.f || a.w != 0.f || b.x != 0.f || b.y != 0.f || b.z != 0.f || b.w != 0.f ||
+                c.x != 0.f || c.y != 0.f || c.z != 0.f || c.w != 0.f || d.x != 0.f || d.y != 0.f || d.z != 0.f || d.w != 0.f;
+    }
+    if (__any(miss) && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
+}
 
 // ------------------------------------------------------------------ degree-sorted tile order
 // (built once per graph and row range when natural tiles would waste most of their rounds)
@@ -3055,6 +3175,39 @@ hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_
     return hipGetLastError();
 }
 
+hipError_t prune_observe(const GraphDev &g, const float *feat, uint32_t *max_deg, hipStream_t stream) {
+    hipError_t rc = hipMemsetAsync(max_deg, 0, sizeof(uint32_t), stream);
+    if (rc != hipSuccess || g.n == 0) return rc;
+    GNNVC_LAUNCH(k_prune_observe, dim3(std::min<unsigned>((g.n + 255) / 256, 4096u)), dim3(256), 0, stream, g,
+                 reinterpret_cast<const float4 *>(feat), max_deg);
+    return hipGetLastError();
+}
+
+hipError_t prune_count(const GraphDev &g, uint32_t bound, uint32_t *heavy_bits, uint32_t *prp, uint32_t *scratch, hipStream_t stream) {
+    if (g.n == 0) return hipSuccess;
+    GNNVC_LAUNCH(k_prune_mark, dim3(((g.n + 31) / 32 + 255) / 256), dim3(256), 0, stream, g, bound, heavy_bits);
+    hipError_t rc = hipMemsetAsync(prp + g.n, 0, sizeof(uint32_t), stream);
+    if (rc != hipSuccess) return rc;
+    GNNVC_LAUNCH(k_prune_rows<false>, dim3(std::min<unsigned>(((g.n + 63) / 64 + 3) / 4, 8192u)), dim3(256), 0, stream, g, heavy_bits,
+                 prp, (const uint32_t *)nullptr, (uint32_t *)nullptr);
+    return scan_u32(prp, (size_t)g.n + 1, scratch, stream);   // exclusive: prp[n] = kept entries
+}
+
+hipError_t prune_fill(const GraphDev &g, const uint32_t *heavy_bits, const uint32_t *prp, uint32_t *pcol, hipStream_t stream) {
+    if (g.n == 0) return hipSuccess;
+    GNNVC_LAUNCH(k_prune_rows<true>, dim3(std::min<unsigned>(((g.n + 63) / 64 + 3) / 4, 8192u)), dim3(256), 0, stream, g, heavy_bits,
+                 (uint32_t *)nullptr, prp, pcol);
+    return hipGetLastError();
+}
+
+hipError_t prune_check(const GraphDev &g, const float *feat, const uint32_t *heavy_bits, uint32_t *bad, hipStream_t stream) {
+    hipError_t rc = hipMemsetAsync(bad, 0, sizeof(uint32_t), stream);
+    if (rc != hipSuccess || g.n == 0) return rc;
+    GNNVC_LAUNCH(k_prune_check, dim3(std::min<unsigned>((g.n + 255) / 256, 2048u)), dim3(256), 0, stream, g,
+                 reinterpret_cast<const float4 *>(feat), heavy_bits, bad);
+    return hipGetLastError();
+}
+
 hipError_t deal_rows(const GraphDev &g, const uint32_t *sorted_rows, uint32_t m, uint32_t slice_rows, uint32_t nslices,
                      uint32_t *rowmap, uint32_t *weight, hipStream_t stream) {
     if (!nslices || !slice_rows) return hipErrorInvalidValue;
@@ -3268,6 +3421,7 @@ hipError_t launch_giant_stage(const StagePlan &sp, const GraphDev &g, float ws, 
     if (gr.n == 0 || row_hi <= row_lo) return hipSuccess;
     const uint4 *meta = reinterpret_cast<const uint4 *>(gr.meta);
     const uint32_t F = sp.f == 16 ? 16u : 1u;
+    const uint32_t *pr = sp.f == 16 ? g.prp : nullptr, *pb = sp.f == 16 ? g.prune_bad : nullptr;   // (pruned adjacency: 16-wide stages only)
     if (sp.f == 16)
         GNNVC_LAUNCH(k_giant_gather16, dim3(gr.blocks), dim3(256), 0, stream, g, reinterpret_cast<const float4 *>(in), gr.slab,
                            meta, gr.off, gr.n, row_lo, row_hi);
@@ -3276,9 +3430,9 @@ hipError_t launch_giant_stage(const StagePlan &sp, const GraphDev &g, float ws, 
     else
         return hipErrorInvalidValue;
     if (fast)
-        GNNVC_LAUNCH(k_giant_sum<true>, dim3(gr.n * F), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.agg, row_lo, row_hi);
+        GNNVC_LAUNCH(k_giant_sum<true>, dim3(gr.n * F), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.agg, row_lo, row_hi, pr, pb);
     else
-        GNNVC_LAUNCH(k_giant_sum<false>, dim3(gr.n * F), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.agg, row_lo, row_hi);
+        GNNVC_LAUNCH(k_giant_sum<false>, dim3(gr.n * F), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.agg, row_lo, row_hi, pr, pb);
     const float *P = params + sp.param_offset;
     const dim3 grid((gr.n + 63) / 64), block(64);
     switch (sp.variant) {
@@ -3298,10 +3452,10 @@ hipError_t stream_sums(const float *streams_dev, uint32_t streams, uint32_t len,
     GNNVC_LAUNCH(k_stream_meta, dim3((streams + 256) / 256), dim3(256), 0, stream, reinterpret_cast<uint4 *>(meta), off, streams, len);
     if (fast)
         GNNVC_LAUNCH(k_giant_sum<true>, dim3(streams), dim3(64), 0, stream, streams_dev, reinterpret_cast<const uint4 *>(meta), off,
-                           1u, agg, 0u, 1u);
+                           1u, agg, 0u, 1u, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
     else
         GNNVC_LAUNCH(k_giant_sum<false>, dim3(streams), dim3(64), 0, stream, streams_dev, reinterpret_cast<const uint4 *>(meta), off,
-                           1u, agg, 0u, 1u);
+                           1u, agg, 0u, 1u, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
     return hipGetLastError();
 }
 

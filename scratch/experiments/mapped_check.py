@@ -9,7 +9,7 @@ import gnn_mwvc_amd as G
 from tools import graphgen_torch as ggt
 
 name = sys.argv[1]
-opts = dict(kv.split("=") for kv in sys.argv[2:])
+opts = dict(kv.split("=") for kv in sys.argv[2:] if "=" in kv)
 dev = torch.device("cuda", 0)
 g, _ = bench.build_workload(name, ggt, dev)
 x = g.x().contiguous()
@@ -35,16 +35,23 @@ def run(extra):
     info = {k: e.get_info(k) for k in ("compact_gather_active", "compact_gather_mapped", "compact_gather_last_passes", "compact_gather_last_dirty",
                                        "compact_gather_blocks", "compact_gather_steps", "compact_gather_mapped_rows",
                                        "compact_gather_mapped_entries", "compact_gather_rows_per_chunk", "compact_gather_chunks",
-                                       "long_rows", "giant_rows", "plan_build_us")}
+                                       "long_rows", "giant_rows", "plan_build_us", "pruned_stage1", "pruned_stage2", "pruned_bound_stage1",
+                                       "pruned_bound_stage2", "pruned_entries_stage1", "pruned_entries_stage2", "pruned_last_ok_stage1",
+                                       "pruned_last_ok_stage2")}
+    info = {k: v for k, v in info.items() if v}
     e.close()
     return outs, ms, info
 
 
-ref, ms0, i0 = run({"compact_skewed": 0})
-got, ms1, i1 = run({"compact_skewed": 1})
 print(name, "n", g.n, "nnz", g.nnz)
+ref, ms0, i0 = run({"compact_skewed": 0, "prune_zero_rows": 0})
 print("plain ", round(ms0, 3), "ms", i0)
-print("mapped", round(ms1, 3), "ms", i1)
-for rep, ((s0, l0), (s1, l1)) in enumerate(zip(ref, got)):
-    print("forward", rep, "logit mismatches", int((l0.view(torch.int32) != l1.view(torch.int32)).sum()),
-          "score mismatches", int((s0.view(torch.int32) != s1.view(torch.int32)).sum()))
+variants = [("pruned", {"prune_zero_rows": 1})]
+if "--mapped" in sys.argv:
+    variants += [("mapped", {"compact_skewed": 1, "prune_zero_rows": 0}), ("pruned+mapped", {"compact_skewed": 1, "prune_zero_rows": 1})]
+for tag, extra in variants:
+    got, ms1, i1 = run(extra)
+    print(tag, round(ms1, 3), "ms", i1)
+    for rep, ((s0, l0), (s1, l1)) in enumerate(zip(ref, got)):
+        print("   forward", rep, "logit mismatches", int((l0.view(torch.int32) != l1.view(torch.int32)).sum()),
+              "score mismatches", int((s0.view(torch.int32) != s1.view(torch.int32)).sum()))

@@ -703,6 +703,78 @@ def test_compact_gather_long_runs(model_text, oracle_model):
             e.close()
 
 
+@pytest.mark.parametrize("maker", [
+    lambda: gg.rmat(14, 8, 3),
+    lambda: gg.hub_graph(30000, 200000, 3, 6000, seed=9),
+    lambda: gg.chung_lu_hubs(40000, 8.0, 2.2, 2, 3000, seed=4),
+])
+def test_pruned_adjacency_is_bit_identical(model_text, oracle_model, maker):
+    """k_prune_*: on skewed graphs the model drives the features of high-degree vertices to zero; the entries that point
+    to them are dropped from a second CSR, and every call proves on the device that its input fits (else the full
+    adjacency is used).  Whole forwards and single stages — fitting inputs, inputs that break the premise, row ranges —
+    equal the oracle bit for bit."""
+    import torch
+    import gnn_mwvc_amd as G
+    g = maker()
+    deg = np.diff(g.rowptr.astype(np.int64))
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_option("blocked_min_n", 0)
+        e.set_option("long_row_threshold", 256)
+        e.set_option("sorted_long_row_threshold", 512)
+        e.set_option("giant_row_threshold", 4096)
+        e.set_option("prune_min_drop_percent", 1)
+        e.set_option("prune_min_entries", 0)
+        e.set_weight_scale(g.ws)
+        oracle_model.set_weight_scale(g.ws)
+        e.upload_graph(g)
+        want_logits = oracle_model.logits(g)
+        for rep in range(4):                                 # the plans are built in the second forward
+            _, logits = e.forward(g.x())
+            assert np.array_equal(bits(logits[:, 0]), bits(want_logits)), rep
+        built = [e.get_info("pruned_stage1"), e.get_info("pruned_stage2")]
+        assert any(built), "no stage of this graph had entries to drop"
+        for st in (1, 2):
+            if built[st - 1]:
+                assert e.get_info(f"pruned_last_ok_stage{st}") == 1
+                assert 0 < e.get_info(f"pruned_entries_stage{st}") < g.nnz
+                assert e.get_info(f"pruned_bound_stage{st}") > e.get_info(f"pruned_observed_stage{st}")
+        dev = torch.device("cuda:0")
+        rng = np.random.default_rng(5)
+        for case in ("fits", "one_heavy_nonzero", "minus_zero_heavy", "all_dense"):
+            h = (rng.uniform(0.05, 2.0, (g.n, 16)) * (rng.random((g.n, 16)) < 0.5)).astype(np.float32)
+            for st in (1, 2):
+                bound = e.get_info(f"pruned_bound_stage{st}") if built[st - 1] else 1 << 30
+                hs = h.copy()
+                heavy = np.flatnonzero(deg >= bound)
+                if case != "all_dense":
+                    hs[heavy] = 0.0
+                if case == "one_heavy_nonzero" and len(heavy):
+                    hs[heavy[len(heavy) // 2], 7] = 0.5      # breaks the premise: this call must use the full adjacency
+                if case == "minus_zero_heavy" and len(heavy):
+                    hs[heavy[::2], 3] = -0.0                 # a zero of either sign is a zero
+                hin = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+                hin[: g.n] = torch.from_numpy(hs).to(dev)
+                want = _oracle_stage(oracle_model, g, st, hs)
+                for lo, hi in ((0, g.n), (g.n // 3 // 64 * 64, g.n // 3 * 2)):
+                    out = torch.full((g.n + 1, 16 if st == 1 else 1), 7.0, dtype=torch.float32, device=dev)
+                    lg = torch.full((g.n + 1,), 7.0, dtype=torch.float32, device=dev)
+                    torch.cuda.synchronize()
+                    e.stage_forward_device(st, lo, hi, hin.data_ptr(), out.data_ptr(), lg.data_ptr() if st == 2 else 0)
+                    e.synchronize()
+                    if built[st - 1] and len(heavy):
+                        fits = case in ("fits", "minus_zero_heavy")
+                        assert e.get_info(f"pruned_last_ok_stage{st}") == (1 if fits else 0), (case, st)
+                    got = out[lo:hi].cpu().numpy() if st == 1 else lg[lo:hi].cpu().numpy().reshape(-1, 1)
+                    assert np.array_equal(bits(got), bits(want[lo:hi])), (case, st, lo, hi)
+        e.set_option("prune_zero_rows", 0)                   # and the same forward without the plan
+        _, logits = e.forward(g.x())
+        assert e.get_info("pruned_stage1") == 0 and e.get_info("pruned_stage2") == 0
+        assert np.array_equal(bits(logits[:, 0]), bits(want_logits))
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("maker,ncols,strays,passes_allowed,want_passes", [
     (lambda: gg.rmat(14, 8, 3), 4, 0, 3, 1),                      # skewed, four live columns: one table
     (lambda: gg.rmat(14, 8, 3), 7, 4, 3, 2),                      # seven live columns (+ strays): two tables
