@@ -445,6 +445,11 @@ def main() -> int:
 
     traffic, traffic_src = measured_traffic(args.workload) if not multi else (None, None)
     plans = {"compact_gather_f16": bool(eng.get_info("compact_gather_active")),
+             "pruned_adjacency": {f"stage{st}": ({"entries_kept": eng.get_info(f"pruned_entries_stage{st}"),
+                                                  "zero_row_vertices": eng.get_info(f"pruned_vertices_stage{st}"),
+                                                  "degree_bound": eng.get_info(f"pruned_bound_stage{st}") or None,
+                                                  "last_call_fit": bool(eng.get_info(f"pruned_last_ok_stage{st}"))}
+                                                 if eng.get_info(f"pruned_stage{st}") else None) for st in (1, 2)},
              "compact_gather_mapped": bool(eng.get_info("compact_gather_mapped")),
              "compact_gather_last": {"fit": bool(eng.get_info("compact_gather_last_ok")), "passes": eng.get_info("compact_gather_last_passes"),
                                      "dirty_rows": eng.get_info("compact_gather_last_dirty"), "column_blocks": eng.get_info("compact_gather_blocks"),

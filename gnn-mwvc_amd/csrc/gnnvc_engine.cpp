@@ -160,11 +160,12 @@ struct gnnvc_engine {
         bool tried = false, ready = false;
         uint32_t bound = 0, observed = 0;   // vertices of degree >= bound are expected to have all-zero rows (largest degree seen with a non-zero row)
         uint64_t kept = 0;                  // entries left
+        uint64_t members = 0;               // vertices in the set
         DevBuf<uint32_t> prp, pcol, heavy;
     };
     PrunePlan prune[4];
     DevBuf<uint32_t> prune_flags, prune_scratch;   // flags: [stage] = this call's verdict (0 = the pruned adjacency applies), [3] = observe
-    int opt_prune = 1;               // option "prune_zero_rows"
+    int opt_prune = 1;               // option "prune_zero_rows": 1 = the rows found all zero when the plan is built, 2 = a degree bound, 0 = off
     int opt_prune_giant = 1;         // option "prune_giant_rows" (A/B): 0 = the giant rows keep their full streams
     uint64_t opt_prune_min_nnz = 1u << 20;   // option "prune_min_entries": smaller graphs are not worth a plan
     uint32_t opt_prune_min_drop = 15;   // option "prune_min_drop_percent": build only if at least this share of the entries goes
@@ -940,18 +941,42 @@ int build_prune_impl(gnnvc_engine *e, int stage, const float *in) {
     const GraphDev &g = e->g;
     if (!e->opt_prune || g.sliced() || g.n == 0 || g.nnz < e->opt_prune_min_nnz) return GNNVC_OK;
     HIP_TRY(e, e->prune_flags.reserve(8));
-    HIP_TRY(e, gnnvc::prune_observe(g, in, e->prune_flags.p + 3, e->stream));
     uint32_t seen = 0;
-    HIP_TRY(e, hipMemcpyAsync(&seen, e->prune_flags.p + 3, sizeof seen, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    // the bound: some way above the largest degree that still had a non-zero row, so that inputs that differ a little
-    // from this one still pass the per-call check
+    if (e->opt_prune == 2) {
+        HIP_TRY(e, gnnvc::prune_observe(g, in, e->prune_flags.p + 3, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(&seen, e->prune_flags.p + 3, sizeof seen, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+    }
     pp.observed = seen;
-    pp.bound = seen + seen / 8 + 2;
     HIP_TRY(e, pp.heavy.reserve(((size_t)g.n + 31) / 32 + 1));
     HIP_TRY(e, pp.prp.reserve((size_t)g.n + 1));
     HIP_TRY(e, e->prune_scratch.reserve(gnnvc::blocked_scan_scratch_elems((size_t)g.n + 1)));
-    HIP_TRY(e, gnnvc::prune_count(g, pp.bound, pp.heavy.p, pp.prp.p, e->prune_scratch.p, e->stream));
+    if (e->opt_prune == 2) {
+        // a degree bound some way above the largest degree that still had a non-zero row: inputs that differ a little from
+        // this one still pass the per-call check
+        pp.bound = seen + seen / 8 + 2;
+        HIP_TRY(e, gnnvc::prune_mark_degree(g, pp.bound, pp.heavy.p, e->stream));
+    } else {
+        // the very vertices whose rows are all zero in this input (a graph's stage inputs follow from its weights: the same on
+        // every forward; any other input fails the check and is served by the full adjacency)
+        pp.bound = 0;
+        HIP_TRY(e, gnnvc::prune_mark_zero(g, in, pp.heavy.p, e->stream));
+    }
+    {   // no vertex in the set (degree-uniform graphs: every row has a non-zero): nothing to prune, skip the passes over the entries
+        const size_t words = ((size_t)g.n + 31) / 32;
+        std::vector<uint32_t> bits(words);
+        HIP_TRY(e, hipMemcpyAsync(bits.data(), pp.heavy.p, words * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        uint64_t members = 0;
+        for (uint32_t w : bits) members += (uint64_t)__builtin_popcount(w);
+        pp.members = members;
+        if (members == 0) {
+            pp.prp.release();
+            pp.heavy.release();
+            return GNNVC_OK;
+        }
+    }
+    HIP_TRY(e, gnnvc::prune_count(g, pp.heavy.p, pp.prp.p, e->prune_scratch.p, e->stream));
     uint32_t kept = 0;
     HIP_TRY(e, hipMemcpyAsync(&kept, pp.prp.p + g.n, sizeof kept, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -1410,7 +1435,7 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "side_streams") e->opt_side_streams = value != 0 ? 1 : 0;
     else if (k == "kernel_trace") e->opt_ktrace = value != 0 ? 1 : 0;
     else if (k == "compact_gather") e->opt_compact = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
-    else if (k == "prune_zero_rows") { e->opt_prune = value != 0 ? 1 : 0; for (auto &pp : e->prune) pp.tried = pp.ready = false; }
+    else if (k == "prune_zero_rows") { e->opt_prune = value < 0 ? 0 : (value > 2 ? 2 : (int)value); for (auto &pp : e->prune) pp.tried = pp.ready = false; }
     else if (k == "prune_giant_rows") e->opt_prune_giant = value != 0 ? 1 : 0;
     else if (k == "prune_min_entries") e->opt_prune_min_nnz = value > 0 ? (uint64_t)value : 0;
     else if (k == "prune_min_drop_percent") e->opt_prune_min_drop = value < 0 ? 0u : (value > 100 ? 100u : (uint32_t)value);
@@ -1436,6 +1461,7 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
     else if (k == "pruned_stage1" || k == "pruned_stage2") *value = e->prune[k.back() - '0'].ready ? 1 : 0;
     else if (k == "pruned_bound_stage1" || k == "pruned_bound_stage2") *value = e->prune[k.back() - '0'].ready ? (long)e->prune[k.back() - '0'].bound : 0;
     else if (k == "pruned_observed_stage1" || k == "pruned_observed_stage2") *value = e->prune[k.back() - '0'].tried ? (long)e->prune[k.back() - '0'].observed : 0;
+    else if (k == "pruned_vertices_stage1" || k == "pruned_vertices_stage2") *value = e->prune[k.back() - '0'].ready ? (long)e->prune[k.back() - '0'].members : 0;
     else if (k == "pruned_entries_stage1" || k == "pruned_entries_stage2") *value = e->prune[k.back() - '0'].ready ? (long)e->prune[k.back() - '0'].kept : 0;
     else if (k == "pruned_last_ok_stage1" || k == "pruned_last_ok_stage2") {
         // did the last call of that stage use its pruned adjacency?  (waits for the stream; tests and tools)

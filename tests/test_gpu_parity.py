@@ -703,14 +703,16 @@ def test_compact_gather_long_runs(model_text, oracle_model):
             e.close()
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("maker", [
     lambda: gg.rmat(14, 8, 3),
     lambda: gg.hub_graph(30000, 200000, 3, 6000, seed=9),
     lambda: gg.chung_lu_hubs(40000, 8.0, 2.2, 2, 3000, seed=4),
 ])
-def test_pruned_adjacency_is_bit_identical(model_text, oracle_model, maker):
+def test_pruned_adjacency_is_bit_identical(model_text, oracle_model, maker, mode):
     """k_prune_*: on skewed graphs the model drives the features of high-degree vertices to zero; the entries that point
-    to them are dropped from a second CSR, and every call proves on the device that its input fits (else the full
+    to rows taken to be all zero — the rows found so when the plan is built (mode 1), or every vertex above a degree bound
+    (mode 2) — are dropped from a second CSR, and every call proves on the device that its input fits (else the full
     adjacency is used).  Whole forwards and single stages — fitting inputs, inputs that break the premise, row ranges —
     equal the oracle bit for bit."""
     import torch
@@ -723,6 +725,7 @@ def test_pruned_adjacency_is_bit_identical(model_text, oracle_model, maker):
         e.set_option("long_row_threshold", 256)
         e.set_option("sorted_long_row_threshold", 512)
         e.set_option("giant_row_threshold", 4096)
+        e.set_option("prune_zero_rows", mode)
         e.set_option("prune_min_drop_percent", 1)
         e.set_option("prune_min_entries", 0)
         e.set_weight_scale(g.ws)
@@ -734,25 +737,35 @@ def test_pruned_adjacency_is_bit_identical(model_text, oracle_model, maker):
             assert np.array_equal(bits(logits[:, 0]), bits(want_logits)), rep
         built = [e.get_info("pruned_stage1"), e.get_info("pruned_stage2")]
         assert any(built), "no stage of this graph had entries to drop"
+        # the vertices whose rows the plan of a stage takes to be zero
+        stage_in = {1: oracle_model.predict(g, g.x(), stop_after=6), 2: oracle_model.predict(g, g.x(), stop_after=13)}
+        zero_set = {}
         for st in (1, 2):
-            if built[st - 1]:
-                assert e.get_info(f"pruned_last_ok_stage{st}") == 1
-                assert 0 < e.get_info(f"pruned_entries_stage{st}") < g.nnz
+            if not built[st - 1]:
+                continue
+            assert e.get_info(f"pruned_last_ok_stage{st}") == 1
+            assert 0 < e.get_info(f"pruned_entries_stage{st}") < g.nnz
+            if mode == 2:
                 assert e.get_info(f"pruned_bound_stage{st}") > e.get_info(f"pruned_observed_stage{st}")
+                zero_set[st] = np.flatnonzero(deg >= e.get_info(f"pruned_bound_stage{st}"))
+            else:
+                zero_set[st] = np.flatnonzero(~(stage_in[st] != 0).any(axis=1))
+                rp = g.rowptr.astype(np.int64)
+                dropped = np.isin(g.col[: rp[-1]], zero_set[st]).sum()
+                assert e.get_info(f"pruned_entries_stage{st}") == g.nnz - dropped
         dev = torch.device("cuda:0")
         rng = np.random.default_rng(5)
-        for case in ("fits", "one_heavy_nonzero", "minus_zero_heavy", "all_dense"):
+        for case in ("fits", "one_nonzero", "minus_zero", "all_dense"):
             h = (rng.uniform(0.05, 2.0, (g.n, 16)) * (rng.random((g.n, 16)) < 0.5)).astype(np.float32)
             for st in (1, 2):
-                bound = e.get_info(f"pruned_bound_stage{st}") if built[st - 1] else 1 << 30
                 hs = h.copy()
-                heavy = np.flatnonzero(deg >= bound)
+                zs = zero_set.get(st, np.zeros(0, dtype=np.int64))
                 if case != "all_dense":
-                    hs[heavy] = 0.0
-                if case == "one_heavy_nonzero" and len(heavy):
-                    hs[heavy[len(heavy) // 2], 7] = 0.5      # breaks the premise: this call must use the full adjacency
-                if case == "minus_zero_heavy" and len(heavy):
-                    hs[heavy[::2], 3] = -0.0                 # a zero of either sign is a zero
+                    hs[zs] = 0.0
+                if case == "one_nonzero" and len(zs):
+                    hs[zs[len(zs) // 2], 7] = 0.5            # breaks the premise: this call must use the full adjacency
+                if case == "minus_zero" and len(zs):
+                    hs[zs[::2], 3] = -0.0                    # a zero of either sign is a zero
                 hin = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
                 hin[: g.n] = torch.from_numpy(hs).to(dev)
                 want = _oracle_stage(oracle_model, g, st, hs)
@@ -762,8 +775,8 @@ def test_pruned_adjacency_is_bit_identical(model_text, oracle_model, maker):
                     torch.cuda.synchronize()
                     e.stage_forward_device(st, lo, hi, hin.data_ptr(), out.data_ptr(), lg.data_ptr() if st == 2 else 0)
                     e.synchronize()
-                    if built[st - 1] and len(heavy):
-                        fits = case in ("fits", "minus_zero_heavy")
+                    if built[st - 1] and len(zs):
+                        fits = case in ("fits", "minus_zero")
                         assert e.get_info(f"pruned_last_ok_stage{st}") == (1 if fits else 0), (case, st)
                     got = out[lo:hi].cpu().numpy() if st == 1 else lg[lo:hi].cpu().numpy().reshape(-1, 1)
                     assert np.array_equal(bits(got), bits(want[lo:hi])), (case, st, lo, hi)
