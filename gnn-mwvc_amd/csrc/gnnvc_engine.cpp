@@ -939,7 +939,9 @@ int build_prune_impl(gnnvc_engine *e, int stage, const float *in) {
     pp.tried = true;
     pp.ready = false;
     const GraphDev &g = e->g;
-    if (!e->opt_prune || g.sliced() || g.n == 0 || g.nnz < e->opt_prune_min_nnz) return GNNVC_OK;
+    if (!e->opt_prune || g.n == 0 || e->empty_slice || g.nnz < e->opt_prune_min_nnz) return GNNVC_OK;
+    if (g.sliced() && e->opt_prune == 2) return GNNVC_OK;   // (a slice does not know the degrees of the vertices it does not hold)
+    const uint32_t held = g.hi() - g.lo();
     HIP_TRY(e, e->prune_flags.reserve(8));
     uint32_t seen = 0;
     if (e->opt_prune == 2) {
@@ -949,8 +951,8 @@ int build_prune_impl(gnnvc_engine *e, int stage, const float *in) {
     }
     pp.observed = seen;
     HIP_TRY(e, pp.heavy.reserve(((size_t)g.n + 31) / 32 + 1));
-    HIP_TRY(e, pp.prp.reserve((size_t)g.n + 1));
-    HIP_TRY(e, e->prune_scratch.reserve(gnnvc::blocked_scan_scratch_elems((size_t)g.n + 1)));
+    HIP_TRY(e, pp.prp.reserve((size_t)held + 1));
+    HIP_TRY(e, e->prune_scratch.reserve(gnnvc::blocked_scan_scratch_elems((size_t)held + 1)));
     if (e->opt_prune == 2) {
         // a degree bound some way above the largest degree that still had a non-zero row: inputs that differ a little from
         // this one still pass the per-call check
@@ -978,7 +980,7 @@ int build_prune_impl(gnnvc_engine *e, int stage, const float *in) {
     }
     HIP_TRY(e, gnnvc::prune_count(g, pp.heavy.p, pp.prp.p, e->prune_scratch.p, e->stream));
     uint32_t kept = 0;
-    HIP_TRY(e, hipMemcpyAsync(&kept, pp.prp.p + g.n, sizeof kept, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(&kept, pp.prp.p + held, sizeof kept, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     pp.kept = kept;
     if ((uint64_t)kept * 100 > g.nnz * (uint64_t)(100 - std::min(e->opt_prune_min_drop, 100u))) {   // too little to gain
@@ -1006,7 +1008,7 @@ int gather_view(gnnvc_engine *e, int stage, const float *in, GraphDev &gv) {
     }
     if (!pp.ready) return GNNVC_OK;
     HIP_TRY(e, gnnvc::prune_check(e->g, in, pp.heavy.p, e->prune_flags.p + stage, e->stream));
-    gv.prp = pp.prp.p;
+    gv.prp = pp.prp.p - e->g.lo();   // (indexed by global row id, like rowptr)
     gv.pcol = pp.pcol.p;
     gv.prune_bad = e->prune_flags.p + stage;
     return GNNVC_OK;

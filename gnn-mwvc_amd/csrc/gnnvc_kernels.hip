@@ -1774,70 +1774,61 @@ static_assert(kC4SliceRows < kC4NoRow - 1u, "row field too narrow");
 // be trusted for this forward).  desc on entry = the previous forward's choice (the producer's spec).
 __global__ __launch_bounds__(64) void k_c4_choose(const unsigned long long *__restrict__ counts, int slots, uint32_t n,
                                                   uint32_t *__restrict__ desc, uint32_t max_passes) {
-    // one wave: lane sl sums nothing but reads slot sl's 17 counters; a butterfly adds the slots up
+    // one wave, everything in registers: lane i < 17 ends up with the total of counter i (16 columns + the rows seen)
     const int lane = threadIdx.x;
-    unsigned long long c[17];
-#pragma unroll
-    for (int i = 0; i < 17; ++i) c[i] = 0;
+    unsigned long long mine = 0;
     if (slots == 1) {
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) c[i] = counts[i];
-            c[16] = n;
-        }
-    } else if (lane < slots) {
-#pragma unroll
-        for (int i = 0; i < 17; ++i) c[i] = counts[lane * kEmitStride + i];
+        mine = lane < 16 ? counts[lane] : (lane == 16 ? (unsigned long long)n : 0ull);
+    } else {
+        // slot sl's 17 counters sit at counts[sl * kEmitStride ..]: lane i adds counter i of every slot
+        if (lane < 17)
+            for (int sl = 0; sl < slots; ++sl) mine += counts[sl * kEmitStride + lane];
     }
-#pragma unroll
-    for (int i = 0; i < 17; ++i)
-        for (int off = 32; off; off >>= 1) {
-            const unsigned lo = __shfl_xor((unsigned)c[i], off), hi = __shfl_xor((unsigned)(c[i] >> 32), off);
-            c[i] += ((unsigned long long)hi << 32) | lo;
-        }
-    if (lane) return;
-    const unsigned long long rows = c[16];
+    const unsigned long long rows = ((unsigned long long)__shfl((unsigned)(mine >> 32), 16) << 32) | __shfl((unsigned)mine, 16);
     const bool prev_ok = desc[0] == 1u;
     const uint32_t p1 = desc[1], p2 = desc[2], p3 = desc[3], p4 = desc[4];
     if (rows != n) {   // no (complete) statistics for this input
-        desc[0] = 0;
-        desc[6] = 0;
+        if (lane == 0) {
+            desc[0] = 0;
+            desc[6] = 0;
+        }
         return;
     }
     // columns by fullness (ties: lowest index); the plan takes the 4, 8 or 12 fullest — as few as leave at most n / 512
     // stray non-zeros outside them (every stray flags a vertex and dirties that vertex's neighbours, which are then
     // recomputed from full rows: worth it only while they are few) — and no more than max_passes x 4
-    int order[16];
-    bool taken[16];
-    for (int i = 0; i < 16; ++i) taken[i] = false;
-    for (int j = 0; j < 16; ++j) {
-        int best = -1;
-        for (int i = 0; i < 16; ++i)
-            if (!taken[i] && (best < 0 || c[i] > c[best])) best = i;
-        taken[best] = true;
-        order[j] = best;
+    const unsigned long long c = lane < 16 ? mine : 0ull;
+    uint32_t rank = 0;   // how many columns are fuller than column `lane`
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const unsigned long long ck = ((unsigned long long)__shfl((unsigned)(c >> 32), k) << 32) | __shfl((unsigned)c, k);
+        rank += (ck > c || (ck == c && k < lane)) ? 1u : 0u;
     }
     uint32_t np = 0;
-    for (uint32_t t = 1; t <= max_passes && t <= 3u && !np; ++t) {
-        unsigned long long rest = 0;
-        for (uint32_t j = 4 * t; j < 16; ++j) rest += c[order[j]];
-        if (rest <= (unsigned long long)n / 512) np = t;
+#pragma unroll
+    for (uint32_t t = 3; t >= 1; --t) {   // the smallest t that fits wins
+        unsigned long long rest = (lane < 16 && rank >= 4 * t) ? c : 0ull;
+#pragma unroll
+        for (int off = 8; off; off >>= 1)
+            rest += ((unsigned long long)__shfl_xor((unsigned)(rest >> 32), off) << 32) | __shfl_xor((unsigned)rest, off);
+        rest = ((unsigned long long)__shfl((unsigned)(rest >> 32), 0) << 32) | __shfl((unsigned)rest, 0);
+        if (t <= max_passes && rest <= (unsigned long long)n / 512) np = t;
     }
-    uint32_t col[12];
-    {   // the chosen columns in ascending order, four per pass
-        bool in[16];
-        for (int i = 0; i < 16; ++i) in[i] = false;
-        for (uint32_t j = 0; j < 4 * np; ++j) in[order[j]] = true;
-        uint32_t k = 0;
-        for (int i = 0; i < 16; ++i)
-            if (in[i]) col[k++] = (uint32_t)i;
-        for (; k < 12; ++k) col[k] = 0xFFFFFFFFu;
+    // the chosen columns in ascending order, four per pass: pass 0 at desc[1..4], pass 1 at [8..11], pass 2 at [12..15]
+    const bool chosen = lane < 16 && rank < 4 * np;
+    const unsigned long long cm = __ballot(chosen);
+    const uint32_t pos = (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
+    const uint32_t c0 = (uint32_t)__builtin_ctzll(cm | (1ull << 63));
+    const uint32_t m1 = (uint32_t)(cm & (cm - 1)), m2 = m1 & (m1 - 1), m3 = m2 & (m2 - 1);   // (all within bits 0..15)
+    const uint32_t c1 = m1 ? (uint32_t)__builtin_ctz(m1) : 64u, c2 = m2 ? (uint32_t)__builtin_ctz(m2) : 64u,
+                   c3 = m3 ? (uint32_t)__builtin_ctz(m3) : 64u;
+    const bool table_written = slots > 1 && prev_ok && np == 1u && p1 == c0 && p2 == c1 && p3 == c2 && p4 == c3;
+    if (lane < 12) desc[lane < 4 ? 1 + lane : 4 + lane] = 0xFFFFFFFFu;   // (slots without a column)
+    if (chosen) desc[pos < 4 ? 1 + pos : 4 + pos] = (uint32_t)lane;
+    if (lane == 0) {
+        desc[0] = np;
+        desc[6] = (np && !table_written) ? 1u : 0u;
     }
-    const bool table_written = slots > 1 && prev_ok && np == 1u && p1 == col[0] && p2 == col[1] && p3 == col[2] && p4 == col[3];
-    desc[0] = np;
-    for (int k = 0; k < 4; ++k) desc[1 + k] = col[k];
-    for (int k = 4; k < 12; ++k) desc[4 + k] = col[k];   // pass 1 at [8..11], pass 2 at [12..15]
-    desc[6] = (np && !table_written) ? 1u : 0u;
 }
 
 __global__ __launch_bounds__(256) void k_c4_compact(const float4 *__restrict__ feat, uint32_t n, uint32_t *__restrict__ desc,
@@ -2189,11 +2180,12 @@ __global__ __launch_bounds__(256) void k_prune_mark_zero(const float4 *__restric
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_prune_rows(GraphDev g, const uint32_t *__restrict__ heavy_bits, uint32_t *__restrict__ kept,
                                                     const uint32_t *__restrict__ prp, uint32_t *__restrict__ pcol) {
+    // (a slice: the rows it holds; kept / prp are biased like rowptr, indexed by global row id)
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t ntiles = (g.n + 63) / 64;
+    const uint32_t ntiles = (g.hi() - g.lo() + 63) / 64;
     for (uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += gridDim.x * 4) {
-        const uint32_t u = tile * 64 + lane;
-        const bool valid = u < g.n;
+        const uint32_t u = g.lo() + tile * 64 + lane;
+        const bool valid = u < g.hi();
         const uint32_t rs = valid ? g.rowptr[u] : 0u, re = valid ? g.rowptr[u + 1] : 0u;
         const bool wide = re - rs >= 64u;
         if (valid && !wide) {
@@ -2212,7 +2204,7 @@ __global__ __launch_bounds__(256) void k_prune_rows(GraphDev g, const uint32_t *
         while (todo) {
             const int src = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
-            const uint32_t ru = tile * 64 + (uint32_t)src;
+            const uint32_t ru = g.lo() + tile * 64 + (uint32_t)src;
             const uint32_t a = __shfl(rs, src), b = __shfl(re, src);
             uint32_t k = FILL ? prp[ru] : 0u;
             for (uint32_t e0 = a; e0 < b; e0 += 64) {
@@ -3213,19 +3205,22 @@ hipError_t prune_mark_zero(const GraphDev &g, const float *feat, uint32_t *heavy
     return hipGetLastError();
 }
 
+// prp: rows + 1 words for the rows [g.lo(), g.hi()) this engine holds (NOT biased here)
 hipError_t prune_count(const GraphDev &g, const uint32_t *heavy_bits, uint32_t *prp, uint32_t *scratch, hipStream_t stream) {
-    if (g.n == 0) return hipSuccess;
-    hipError_t rc = hipMemsetAsync(prp + g.n, 0, sizeof(uint32_t), stream);
+    const uint32_t rows = g.hi() - g.lo();
+    if (rows == 0) return hipSuccess;
+    hipError_t rc = hipMemsetAsync(prp + rows, 0, sizeof(uint32_t), stream);
     if (rc != hipSuccess) return rc;
-    GNNVC_LAUNCH(k_prune_rows<false>, dim3(std::min<unsigned>(((g.n + 63) / 64 + 3) / 4, 8192u)), dim3(256), 0, stream, g, heavy_bits,
-                 prp, (const uint32_t *)nullptr, (uint32_t *)nullptr);
-    return scan_u32(prp, (size_t)g.n + 1, scratch, stream);   // exclusive: prp[n] = kept entries
+    GNNVC_LAUNCH(k_prune_rows<false>, dim3(std::min<unsigned>(((rows + 63) / 64 + 3) / 4, 8192u)), dim3(256), 0, stream, g, heavy_bits,
+                 prp - g.lo(), (const uint32_t *)nullptr, (uint32_t *)nullptr);
+    return scan_u32(prp, (size_t)rows + 1, scratch, stream);   // exclusive: prp[rows] = kept entries
 }
 
 hipError_t prune_fill(const GraphDev &g, const uint32_t *heavy_bits, const uint32_t *prp, uint32_t *pcol, hipStream_t stream) {
-    if (g.n == 0) return hipSuccess;
-    GNNVC_LAUNCH(k_prune_rows<true>, dim3(std::min<unsigned>(((g.n + 63) / 64 + 3) / 4, 8192u)), dim3(256), 0, stream, g, heavy_bits,
-                 (uint32_t *)nullptr, prp, pcol);
+    const uint32_t rows = g.hi() - g.lo();
+    if (rows == 0) return hipSuccess;
+    GNNVC_LAUNCH(k_prune_rows<true>, dim3(std::min<unsigned>(((rows + 63) / 64 + 3) / 4, 8192u)), dim3(256), 0, stream, g, heavy_bits,
+                 (uint32_t *)nullptr, prp - g.lo(), pcol);
     return hipGetLastError();
 }
 

@@ -1172,14 +1172,16 @@ def test_fast_hub_mode_is_within_its_tolerance(model_text, oracle_model):
 
 # ---------------------------------------------------------------- one rank's CSR slice
 
-@pytest.mark.parametrize("maker,world,mode", [
-    (lambda: gg.erdos_renyi(5000, 40000, 31), 2, "rows"),
-    (lambda: gg.hub_graph(20000, 60000, 3, 4096, seed=7), 3, "nnz"),       # long rows inside slices
-    (lambda: gg.hub_graph(30000, 40000, 2, 20000, seed=8), 4, "nnz"),      # giant rows inside slices
-    (lambda: gg.rmat(11, 16, 5), 3, "rows"),
-    (lambda: gg.erdos_renyi(100, 300, 5), 3, "rows"),                      # a short slice and an empty one
+@pytest.mark.parametrize("maker,world,mode,reps", [
+    (lambda: gg.erdos_renyi(5000, 40000, 31), 2, "rows", 1),
+    (lambda: gg.hub_graph(20000, 60000, 3, 4096, seed=7), 3, "nnz", 1),       # long rows inside slices
+    (lambda: gg.hub_graph(30000, 40000, 2, 20000, seed=8), 4, "nnz", 1),      # giant rows inside slices
+    (lambda: gg.rmat(11, 16, 5), 3, "rows", 1),
+    (lambda: gg.erdos_renyi(100, 300, 5), 3, "rows", 1),                      # a short slice and an empty one
+    (lambda: gg.rmat(14, 8, 3), 3, "nnz", 3),                                 # repeated forwards: each slice prunes its adjacency
+    (lambda: gg.chung_lu_hubs(40000, 8.0, 2.2, 2, 3000, seed=4), 2, "rows", 3),
 ])
-def test_sliced_engines_equal_the_whole_graph(model_text, oracle_model, maker, world, mode):
+def test_sliced_engines_equal_the_whole_graph(model_text, oracle_model, maker, world, mode, reps):
     """gnnvc_attach_graph_slice: `world` engines, each holding only its rows' CSR slice (row pointers relative to
     the slice, global column ids), driven stage by stage on shared full-size feature buffers — what the ranks of
     a vertex-partitioned run do between exchanges.  Same bits as the whole graph."""
@@ -1202,6 +1204,9 @@ def test_sliced_engines_equal_the_whole_graph(model_text, oracle_model, maker, w
             engines.append(e)
             e.set_option("long_row_threshold", 64)
             e.set_option("giant_row_threshold", 3000)
+            if reps > 1:
+                e.set_option("prune_min_entries", 0)
+                e.set_option("prune_min_drop_percent", 1)
             e.set_weight_scale(g.ws)
             sl = D.slice_csr(g.n, rp, col, w, nw, lo, hi)
             torch.cuda.synchronize()
@@ -1216,15 +1221,30 @@ def test_sliced_engines_equal_the_whole_graph(model_text, oracle_model, maker, w
         sc = torch.zeros(g.n, dtype=torch.float32, device=dev)
         lg = torch.zeros(g.n, dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
-        for st, (src, dst, lgt) in enumerate(((x, h1, None), (h1, h2, None), (h2, sc, lg))):
-            for e, (lo, hi) in zip(engines, bounds):
-                mid = lo + ((hi - lo) // 2) // 64 * 64
-                for r0, r1 in ((lo, mid), (mid, hi)):       # in two pieces, like a pipelined rank
-                    e.stage_forward_device(st, r0, r1, src.data_ptr(), dst.data_ptr(), lgt.data_ptr() if lgt is not None else 0)
-            for e in engines:
-                e.synchronize()                              # ("exchange": the buffers are shared here)
-        assert np.array_equal(bits(lg.cpu().numpy()), bits(oracle_model.logits(g)))
-        assert ulp(sc.cpu().numpy(), oracle_model.scores(g)).max() <= 1
+        for rep in range(reps):
+            if rep:
+                for t in (h1, h2, sc, lg):
+                    t.fill_(7.0)
+                h1[g.n] = 0.0
+                h2[g.n] = 0.0
+                torch.cuda.synchronize()
+            for st, (src, dst, lgt) in enumerate(((x, h1, None), (h1, h2, None), (h2, sc, lg))):
+                for e, (lo, hi) in zip(engines, bounds):
+                    mid = lo + ((hi - lo) // 2) // 64 * 64
+                    for r0, r1 in ((lo, mid), (mid, hi)):       # in two pieces, like a pipelined rank
+                        e.stage_forward_device(st, r0, r1, src.data_ptr(), dst.data_ptr(), lgt.data_ptr() if lgt is not None else 0)
+                for e in engines:
+                    e.synchronize()                              # ("exchange": the buffers are shared here)
+            assert np.array_equal(bits(lg.cpu().numpy()), bits(oracle_model.logits(g))), rep
+            assert ulp(sc.cpu().numpy(), oracle_model.scores(g)).max() <= 1
+        if reps > 1:   # every slice with entries found zero rows among its neighbours and used its pruned adjacency to the end
+            pruned = [(e.get_info("pruned_stage1"), e.get_info("pruned_stage2")) for e in engines]
+            assert all(any(p) for p in pruned), pruned
+            for e, p in zip(engines, pruned):
+                for st in (1, 2):
+                    if p[st - 1]:
+                        assert e.get_info(f"pruned_last_ok_stage{st}") == 1
+                        assert e.get_info(f"pruned_entries_stage{st}") < e.get_info("slice_entries")
         # outside its slice an engine has no adjacency, and says so
         e0, (lo0, hi0) = engines[0], bounds[0]
         if hi0 < g.n:
