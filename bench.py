@@ -561,7 +561,7 @@ def forward_variants(make_engine, attach_whole, x, n, dev):
     res["fresh_engine_first_forward_ms"] = run(e)
     res["fresh_engine_first_forward_device_ms"] = e.last_forward_ms()[0]
     e.close()
-    e = make_engine(lds_table=0, compact_gather=0)
+    e = make_engine(lds_table=0, compact_gather=0, prune_zero_rows=0)
     attach_whole(e)
     for _ in range(3):
         run(e)
@@ -569,7 +569,7 @@ def forward_variants(make_engine, attach_whole, x, n, dev):
     res["plain_forward_ms"] = ts[len(ts) // 2]
     res["plain_forward_device_ms"] = e.last_forward_ms()[0]
     res["plain_forward_plans"] = {"blocked_stage0": bool(e.get_info("blocked_stage0_active")), "lds_table": False,
-                                  "compact_gather": False}
+                                  "compact_gather": False, "pruned_adjacency": False}
     e.close()
     return res
 

@@ -164,7 +164,8 @@ struct gnnvc_engine {
         DevBuf<uint32_t> prp, pcol, heavy;
     };
     PrunePlan prune[4];
-    DevBuf<uint32_t> prune_flags, prune_scratch;   // flags: [stage] = this call's verdict (0 = the pruned adjacency applies), [3] = observe
+    DevBuf<uint32_t> prune_flags, prune_scratch, prune_off;   // (off / mask: per chunk of 64 entries, while a plan is built)
+    DevBuf<unsigned long long> prune_mask;   // flags: [stage] = this call's verdict (0 = the pruned adjacency applies), [3] = observe
     int opt_prune = 1;               // option "prune_zero_rows": 1 = the rows found all zero when the plan is built, 2 = a degree bound, 0 = off
     int opt_prune_giant = 1;         // option "prune_giant_rows" (A/B): 0 = the giant rows keep their full streams
     uint64_t opt_prune_min_nnz = 1u << 20;   // option "prune_min_entries": smaller graphs are not worth a plan
@@ -950,9 +951,12 @@ int build_prune_impl(gnnvc_engine *e, int stage, const float *in) {
         HIP_TRY(e, hipStreamSynchronize(e->stream));
     }
     pp.observed = seen;
+    if (g.nnz >= (1ull << 32)) return GNNVC_OK;
+    const size_t chunks = (size_t)((g.nnz + 63) / 64);
     HIP_TRY(e, pp.heavy.reserve(((size_t)g.n + 31) / 32 + 1));
-    HIP_TRY(e, pp.prp.reserve((size_t)held + 1));
-    HIP_TRY(e, e->prune_scratch.reserve(gnnvc::blocked_scan_scratch_elems((size_t)held + 1)));
+    HIP_TRY(e, e->prune_mask.reserve(chunks));
+    HIP_TRY(e, e->prune_off.reserve(chunks + 1));
+    HIP_TRY(e, e->prune_scratch.reserve(gnnvc::blocked_scan_scratch_elems(chunks + 1)));
     if (e->opt_prune == 2) {
         // a degree bound some way above the largest degree that still had a non-zero row: inputs that differ a little from
         // this one still pass the per-call check
@@ -973,24 +977,23 @@ int build_prune_impl(gnnvc_engine *e, int stage, const float *in) {
         for (uint32_t w : bits) members += (uint64_t)__builtin_popcount(w);
         pp.members = members;
         if (members == 0) {
-            pp.prp.release();
             pp.heavy.release();
             return GNNVC_OK;
         }
     }
-    HIP_TRY(e, gnnvc::prune_count(g, pp.heavy.p, pp.prp.p, e->prune_scratch.p, e->stream));
+    HIP_TRY(e, gnnvc::prune_count(g, pp.heavy.p, e->prune_mask.p, e->prune_off.p, e->prune_scratch.p, e->stream));
     uint32_t kept = 0;
-    HIP_TRY(e, hipMemcpyAsync(&kept, pp.prp.p + held, sizeof kept, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(&kept, e->prune_off.p + chunks, sizeof kept, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     pp.kept = kept;
     if ((uint64_t)kept * 100 > g.nnz * (uint64_t)(100 - std::min(e->opt_prune_min_drop, 100u))) {   // too little to gain
-        pp.prp.release();
         pp.heavy.release();
         return GNNVC_OK;
     }
+    HIP_TRY(e, pp.prp.reserve((size_t)held + 1));
     HIP_TRY(e, pp.pcol.reserve((size_t)kept + GNNVC_COL_PAD));
     HIP_TRY(e, hipMemsetAsync(pp.pcol.p + kept, 0, GNNVC_COL_PAD * sizeof(uint32_t), e->stream));
-    HIP_TRY(e, gnnvc::prune_fill(g, pp.heavy.p, pp.prp.p, pp.pcol.p, e->stream));
+    HIP_TRY(e, gnnvc::prune_fill(g, e->prune_mask.p, e->prune_off.p, pp.pcol.p, pp.prp.p, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     pp.ready = true;
     return GNNVC_OK;
@@ -1390,7 +1393,7 @@ void gnnvc_destroy(gnnvc_engine *e) {
     e->c4_desc.release(); e->c4_rowmap.release(); e->c4_first.release(); e->c4_bstart.release(); e->c4_map_vertex.release(); e->c4_map_meta.release(); e->c4_steps.release(); e->c4_table.release(); e->c4_marks.release(); e->c4_acc.release(); e->c4_counts.release();
     e->c4_agg16.release(); e->c4_dirty.release(); e->c4_emit_counts.release();
     for (auto &pp : e->prune) { pp.prp.release(); pp.pcol.release(); pp.heavy.release(); }
-    e->prune_flags.release(); e->prune_scratch.release();
+    e->prune_flags.release(); e->prune_scratch.release(); e->prune_off.release(); e->prune_mask.release();
     e->long_list.release(); e->long_count.release();
     e->gi_meta.release(); e->gi_off.release(); e->gi_slab.release(); e->gi_agg.release();
     e->rowptr2.release(); e->col2.release(); e->der_old_row.release(); e->der_new_of.release(); e->der_tail.release();

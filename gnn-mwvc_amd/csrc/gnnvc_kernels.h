@@ -194,14 +194,17 @@ hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_
                              const PlanMap &pm = PlanMap());
 // Pruned adjacency (k_prune_*).  observe = largest degree among the vertices with a non-zero row of feat (16 columns).
 // The set of vertices whose rows are taken to be all zero, as a bitmap: mark_degree (degree >= bound) or mark_zero (the rows
-// that ARE all zero in feat).  count = prp (n + 1, scanned in place; scratch as for blocked_scan_scratch_elems(n + 1));
-// fill = the kept entries, once the caller has sized pcol from prp[n]; check = *bad |= 1 if a vertex of the set has a
-// non-zero row in feat.
+// that ARE all zero in feat).  count = per chunk of 64 entries which are kept (mask) and, scanned in place, how many before
+// it (off: chunks + 1 words, off[chunks] = kept entries; scratch as for blocked_scan_scratch_elems(chunks + 1)); fill = the
+// kept entries (pcol, sized by the caller from off[chunks]) and the pruned row offsets (prp: rows + 1 words); check =
+// *bad |= 1 if a vertex of the set has a non-zero row in feat.
 hipError_t prune_observe(const GraphDev &g, const float *feat, uint32_t *max_deg, hipStream_t stream);
 hipError_t prune_mark_degree(const GraphDev &g, uint32_t bound, uint32_t *heavy_bits, hipStream_t stream);
 hipError_t prune_mark_zero(const GraphDev &g, const float *feat, uint32_t *heavy_bits, hipStream_t stream);
-hipError_t prune_count(const GraphDev &g, const uint32_t *heavy_bits, uint32_t *prp, uint32_t *scratch, hipStream_t stream);
-hipError_t prune_fill(const GraphDev &g, const uint32_t *heavy_bits, const uint32_t *prp, uint32_t *pcol, hipStream_t stream);
+hipError_t prune_count(const GraphDev &g, const uint32_t *heavy_bits, unsigned long long *mask, uint32_t *off, uint32_t *scratch,
+                       hipStream_t stream);
+hipError_t prune_fill(const GraphDev &g, const unsigned long long *mask, const uint32_t *off, uint32_t *pcol, uint32_t *prp,
+                      hipStream_t stream);
 hipError_t prune_check(const GraphDev &g, const float *feat, const uint32_t *heavy_bits, uint32_t *bad, hipStream_t stream);
 // rows of a degree-sorted list (heaviest first; the first m of it) dealt serpentine to nslices slices of slice_rows slots:
 // rowmap[s * slice_rows + t], weight[s] = entries of slice s

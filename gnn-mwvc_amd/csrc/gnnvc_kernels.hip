@@ -2174,50 +2174,55 @@ __global__ __launch_bounds__(256) void k_prune_mark_zero(const float4 *__restric
     if ((threadIdx.x & 63) == 1 && w0 + 1 < words) heavy_bits[w0 + 1] = (uint32_t)(m >> 32);
 }
 
-// One wave per 64 consecutive rows.  Rows of fewer than 64 entries: one lane each.  Longer rows: the whole wave, 64 entries
-// at a time, kept entries ranked by a ballot — so the order of a row's kept entries is the CSR order.
-// FILL == false: kept[u] = number of kept entries.  FILL == true: pcol[prp[u] ...] = the kept entries.
-template <bool FILL>
-__global__ __launch_bounds__(256) void k_prune_rows(GraphDev g, const uint32_t *__restrict__ heavy_bits, uint32_t *__restrict__ kept,
-                                                    const uint32_t *__restrict__ prp, uint32_t *__restrict__ pcol) {
-    // (a slice: the rows it holds; kept / prp are biased like rowptr, indexed by global row id)
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t ntiles = (g.hi() - g.lo() + 63) / 64;
-    for (uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += gridDim.x * 4) {
-        const uint32_t u = g.lo() + tile * 64 + lane;
-        const bool valid = u < g.hi();
-        const uint32_t rs = valid ? g.rowptr[u] : 0u, re = valid ? g.rowptr[u + 1] : 0u;
-        const bool wide = re - rs >= 64u;
-        if (valid && !wide) {
-            uint32_t k = 0;
-            const uint32_t out = FILL ? prp[u] : 0u;
-            for (uint32_t e = rs; e < re; ++e) {
-                const uint32_t c = g.col[e];
-                if (!(heavy_bits[c >> 5] >> (c & 31) & 1u)) {
-                    if (FILL) pcol[out + k] = c;
-                    ++k;
-                }
-            }
-            if (!FILL) kept[u] = k;
+// Building the pruned CSR: the engine's entries taken FLAT, in chunks of 64 (one wave trip), whatever rows they belong to —
+// a skewed graph's work is then balanced by construction (a first version walked 64-row tiles: R-MAT's hubs share a few
+// tiles, 19 ms per pass on R-MAT-22).  Kept entries keep their flat order, which is the CSR order of every row.
+//   k_prune_chunks   mask[k] = which of chunk k's 64 entries are kept, cnt[k] = how many      (then: exclusive scan of cnt)
+//   k_prune_fill     pcol[off[k] + rank] = the kept entries
+//   k_prune_offsets  prp[u] = kept entries before row u's first entry  (u = the engine's rows and one past them)
+__global__ __launch_bounds__(256) void k_prune_chunks(const uint32_t *__restrict__ col, uint32_t nnz, const uint32_t *__restrict__ heavy_bits,
+                                                      unsigned long long *__restrict__ mask, uint32_t *__restrict__ cnt) {
+    const uint32_t lane = threadIdx.x & 63, nchunks = (nnz + 63) / 64;
+    constexpr uint32_t U = 4;
+    for (uint32_t k0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * U; k0 < nchunks; k0 += gridDim.x * 4 * U) {
+        uint32_t c[U], w[U];
+#pragma unroll
+        for (uint32_t t = 0; t < U; ++t) {
+            const uint32_t e = (k0 + t) * 64 + lane;
+            c[t] = e < nnz ? col[e] : 0u;
         }
-        unsigned long long todo = __ballot(valid && wide);
-        while (todo) {
-            const int src = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const uint32_t ru = g.lo() + tile * 64 + (uint32_t)src;
-            const uint32_t a = __shfl(rs, src), b = __shfl(re, src);
-            uint32_t k = FILL ? prp[ru] : 0u;
-            for (uint32_t e0 = a; e0 < b; e0 += 64) {
-                const uint32_t e = e0 + lane;
-                const uint32_t c = e < b ? g.col[e] : 0u;
-                const bool keep = e < b && !(heavy_bits[c >> 5] >> (c & 31) & 1u);
-                const unsigned long long m = __ballot(keep);
-                if (FILL && keep) pcol[k + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = c;
-                k += (uint32_t)__popcll(m);
+#pragma unroll
+        for (uint32_t t = 0; t < U; ++t) w[t] = heavy_bits[c[t] >> 5];
+#pragma unroll
+        for (uint32_t t = 0; t < U; ++t) {
+            const uint32_t e = (k0 + t) * 64 + lane;
+            const unsigned long long km = __ballot(e < nnz && !(w[t] >> (c[t] & 31) & 1u));
+            if (lane == 0 && k0 + t < nchunks) {
+                mask[k0 + t] = km;
+                cnt[k0 + t] = (uint32_t)__popcll(km);
             }
-            if (!FILL && lane == 0) kept[ru] = k;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_prune_fill(const uint32_t *__restrict__ col, uint32_t nnz, const unsigned long long *__restrict__ mask,
+                                                    const uint32_t *__restrict__ off, uint32_t *__restrict__ pcol) {
+    const uint32_t lane = threadIdx.x & 63, nchunks = (nnz + 63) / 64;
+    for (uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 6); k < nchunks; k += gridDim.x * 4) {
+        const unsigned long long km = mask[k];
+        const uint32_t e = k * 64 + lane;
+        if (km >> lane & 1ull) pcol[off[k] + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = col[e];
+    }
+}
+
+// (a slice: rowptr / prp are biased by the caller, indexed by global row id; entries count from the slice's first)
+__global__ __launch_bounds__(256) void k_prune_offsets(GraphDev g, const unsigned long long *__restrict__ mask, const uint32_t *__restrict__ off,
+                                                       uint32_t nchunks, uint32_t *__restrict__ prp) {
+    const uint32_t u = g.lo() + blockIdx.x * blockDim.x + threadIdx.x;
+    if (u > g.hi()) return;
+    const uint32_t e = g.rowptr[u], k = e >> 6;
+    // (e == nnz on a chunk boundary: off[nchunks] = the total, and no mask word to read)
+    prp[u] = off[k] + (k < nchunks ? (uint32_t)__popcll(mask[k] & ((1ull << (e & 63u)) - 1ull)) : 0u);
 }
 
 // *bad |= 1 if a heavy vertex has a non-zero among its 16 values
@@ -3205,22 +3210,25 @@ hipError_t prune_mark_zero(const GraphDev &g, const float *feat, uint32_t *heavy
     return hipGetLastError();
 }
 
-// prp: rows + 1 words for the rows [g.lo(), g.hi()) this engine holds (NOT biased here)
-hipError_t prune_count(const GraphDev &g, const uint32_t *heavy_bits, uint32_t *prp, uint32_t *scratch, hipStream_t stream) {
-    const uint32_t rows = g.hi() - g.lo();
-    if (rows == 0) return hipSuccess;
-    hipError_t rc = hipMemsetAsync(prp + rows, 0, sizeof(uint32_t), stream);
+// mask: one 64-bit word per chunk of 64 entries, off: chunks + 1 words (scanned in place: off[chunks] = kept entries;
+// scratch as for blocked_scan_scratch_elems(chunks + 1))
+hipError_t prune_count(const GraphDev &g, const uint32_t *heavy_bits, unsigned long long *mask, uint32_t *off, uint32_t *scratch,
+                       hipStream_t stream) {
+    if (g.nnz == 0 || g.nnz >= (1ull << 32)) return hipErrorInvalidValue;
+    const uint32_t nnz = (uint32_t)g.nnz, chunks = (nnz + 63) / 64;
+    hipError_t rc = hipMemsetAsync(off + chunks, 0, sizeof(uint32_t), stream);
     if (rc != hipSuccess) return rc;
-    GNNVC_LAUNCH(k_prune_rows<false>, dim3(std::min<unsigned>(((rows + 63) / 64 + 3) / 4, 8192u)), dim3(256), 0, stream, g, heavy_bits,
-                 prp - g.lo(), (const uint32_t *)nullptr, (uint32_t *)nullptr);
-    return scan_u32(prp, (size_t)rows + 1, scratch, stream);   // exclusive: prp[rows] = kept entries
+    GNNVC_LAUNCH(k_prune_chunks, dim3(std::min<unsigned>((chunks + 15) / 16, 16384u)), dim3(256), 0, stream, g.col, nnz, heavy_bits, mask, off);
+    return scan_u32(off, (size_t)chunks + 1, scratch, stream);
 }
 
-hipError_t prune_fill(const GraphDev &g, const uint32_t *heavy_bits, const uint32_t *prp, uint32_t *pcol, hipStream_t stream) {
-    const uint32_t rows = g.hi() - g.lo();
-    if (rows == 0) return hipSuccess;
-    GNNVC_LAUNCH(k_prune_rows<true>, dim3(std::min<unsigned>(((rows + 63) / 64 + 3) / 4, 8192u)), dim3(256), 0, stream, g, heavy_bits,
-                 (uint32_t *)nullptr, prp - g.lo(), pcol);
+// pcol: the kept entries (+ pad); prp: rows + 1 words for the rows [g.lo(), g.hi()) this engine holds (NOT biased here)
+hipError_t prune_fill(const GraphDev &g, const unsigned long long *mask, const uint32_t *off, uint32_t *pcol, uint32_t *prp,
+                      hipStream_t stream) {
+    if (g.nnz == 0 || g.nnz >= (1ull << 32)) return hipErrorInvalidValue;
+    const uint32_t nnz = (uint32_t)g.nnz, chunks = (nnz + 63) / 64, rows = g.hi() - g.lo();
+    GNNVC_LAUNCH(k_prune_fill, dim3(std::min<unsigned>((chunks + 3) / 4, 32768u)), dim3(256), 0, stream, g.col, nnz, mask, off, pcol);
+    GNNVC_LAUNCH(k_prune_offsets, dim3((rows + 1 + 255) / 256), dim3(256), 0, stream, g, mask, off, chunks, prp - g.lo());
     return hipGetLastError();
 }
 
