@@ -162,11 +162,18 @@ struct gnnvc_engine {
         uint64_t kept = 0;                  // entries left
         uint64_t members = 0;               // vertices in the set
         DevBuf<uint32_t> prp, pcol, heavy;
+        DevBuf<uint32_t> svertex;            // skewed graphs: the engine's rows below the long-row threshold BY ENTRIES LEFT, heaviest first
+        DevBuf<uint4> smeta;                 // ... with their pruned ranges
+        uint32_t sn = 0;
+        bool slist = false;
+        uint32_t eff_thresh = 0xFFFFFFFFu;   // entries left from which a row goes to the long-row kernel
     };
     PrunePlan prune[4];
     DevBuf<uint32_t> prune_flags, prune_scratch, prune_off;   // (off / mask: per chunk of 64 entries, while a plan is built)
     DevBuf<unsigned long long> prune_mask;   // flags: [stage] = this call's verdict (0 = the pruned adjacency applies), [3] = observe
     int opt_prune = 1;               // option "prune_zero_rows": 1 = the rows found all zero when the plan is built, 2 = a degree bound, 0 = off
+    uint64_t opt_prune_heavy_entries = 16u << 20;   // option "prune_heavy_entries": from this many entries left, rows up to the sorted threshold stay with the tile kernel
+    int opt_prune_eff = 1;           // option "prune_class_by_entries_left" (A/B): 0 = rows keep the class their degree gives them
     int opt_prune_giant = 1;         // option "prune_giant_rows" (A/B): 0 = the giant rows keep their full streams
     uint64_t opt_prune_min_nnz = 1u << 20;   // option "prune_min_entries": smaller graphs are not worth a plan
     uint32_t opt_prune_min_drop = 15;   // option "prune_min_drop_percent": build only if at least this share of the entries goes
@@ -532,9 +539,12 @@ int find_long(gnnvc_engine *e) {
 // The rows of [lo, hi) below the long-row threshold of the 16-wide stages, heaviest degree class first: vertex[] (+ per
 // row {first entry, end, W, NW} in meta[]); listed = how many, zero_rows = how many of them (the list's tail) have no entry.
 int sort_by_degree(gnnvc_engine *e, uint32_t lo, uint32_t hi, DevBuf<uint32_t> &vertex, DevBuf<uint4> &meta, uint32_t &listed,
-                   uint32_t &zero_rows) {
-    const GraphDev &g = e->g;
-    const uint32_t lt = e->thresh_f16;
+                   uint32_t &zero_rows, const GraphDev *view = nullptr, const uint32_t *skip_rowptr = nullptr,
+                   uint32_t skip_from = 0xFFFFFFFFu, uint32_t class_thresh = 0) {
+    // view: the adjacency whose row lengths class the rows (a pruned one: the entries LEFT; then skip_rowptr / skip_from leave
+    // out the giant rows, which go by their degree)
+    const GraphDev &g = view ? *view : e->g;
+    const uint32_t lt = class_thresh ? class_thresh : e->thresh_f16;
     const uint32_t bins = lt < 4096u ? lt + 1 : 4096u;
     HIP_TRY(e, e->srt_hist.reserve(bins));
     HIP_TRY(e, vertex.reserve(hi - lo));
@@ -543,7 +553,7 @@ int sort_by_degree(gnnvc_engine *e, uint32_t lo, uint32_t hi, DevBuf<uint32_t> &
     // pageable memory above a few KB pins it on the fly, which costs milliseconds the first time
     HIP_TRY(e, e->pin_small.reserve(2 * (size_t)bins));
     uint32_t *hist = e->pin_small.p, *start = e->pin_small.p + bins;
-    HIP_TRY(e, gnnvc::degree_histogram(g, lo, hi, lt, bins, e->srt_hist.p, e->stream));
+    HIP_TRY(e, gnnvc::degree_histogram(g, lo, hi, lt, bins, e->srt_hist.p, e->stream, skip_rowptr, skip_from));
     HIP_TRY(e, hipMemcpyAsync(hist, e->srt_hist.p, bins * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     uint32_t run = 0;
@@ -553,7 +563,7 @@ int sort_by_degree(gnnvc_engine *e, uint32_t lo, uint32_t hi, DevBuf<uint32_t> &
     }
     zero_rows = hist[0];
     HIP_TRY(e, hipMemcpyAsync(e->srt_hist.p, start, bins * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(e, gnnvc::degree_scatter(g, lo, hi, lt, bins, e->srt_hist.p, vertex.p, meta.p, e->stream));
+    HIP_TRY(e, gnnvc::degree_scatter(g, lo, hi, lt, bins, e->srt_hist.p, vertex.p, meta.p, e->stream, skip_rowptr, skip_from));
     HIP_TRY(e, hipStreamSynchronize(e->stream));   // `start` is read by the async copy above
     listed = run;
     return GNNVC_OK;
@@ -995,25 +1005,58 @@ int build_prune_impl(gnnvc_engine *e, int stage, const float *in) {
     HIP_TRY(e, hipMemsetAsync(pp.pcol.p + kept, 0, GNNVC_COL_PAD * sizeof(uint32_t), e->stream));
     HIP_TRY(e, gnnvc::prune_fill(g, e->prune_mask.p, e->prune_off.p, pp.pcol.p, pp.prp.p, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
+    pp.slist = false;
+    pp.sn = 0;
+    // Rows are classed by the entries they have LEFT.  The tile kernel walks a row's entries three at a time, ~1.2 us a trip:
+    // a 1000-entry row holds its tile for ~0.4 ms — nothing beside the ~0.7 ms R-MAT-22's stage spends gathering, but the
+    // whole stage on the power-law graph (8 M entries left: 0.57 -> 0.64 ms at 1024; R-MAT-22: 1.35 -> 1.25 ms).
+    pp.eff_thresh = kept >= e->opt_prune_heavy_entries ? e->thresh_f16 : std::max(e->long_thresh, std::min(e->thresh_f16, 512u));
+    if (e->sorted_wanted && e->opt_prune_eff) {
+        // tiles of the 16-wide stages from the rows sorted by the entries they have LEFT; the giant rows (by degree) are not in it
+        GraphDev view = g;
+        view.rowptr = pp.prp.p - g.lo();
+        view.col = pp.pcol.p;
+        uint32_t zero_rows = 0;
+        int rc = sort_by_degree(e, g.lo(), g.hi(), pp.svertex, pp.smeta, pp.sn, zero_rows, &view, g.rowptr,
+                                e->n_giant ? e->giant_thresh : 0xFFFFFFFFu, pp.eff_thresh);
+        if (rc) return rc;
+        pp.slist = true;
+    }
     pp.ready = true;
     return GNNVC_OK;
 }
 
 // The graph as this call's gathering kernels see it: with the pruned adjacency attached when the stage has one (the
-// check of this very input is queued here, ahead of every kernel that reads its verdict).
-int gather_view(gnnvc_engine *e, int stage, const float *in, GraphDev &gv) {
+// check of this very input is queued here, ahead of every kernel that reads its verdict).  so_p: the tile order that goes
+// with classing the rows by the entries they have left (natural tiles need none).
+int gather_view(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float *in, bool gathering, bool sorted_tiles,
+                GraphDev &gv, gnnvc::SortedOrder &so_p) {
     gv = e->g;
+    so_p = gnnvc::SortedOrder();
     if (stage < 1 || stage > 3 || e->stages[stage].f != 16 || !e->opt_prune) return GNNVC_OK;
     gnnvc_engine::PrunePlan &pp = e->prune[stage];
     if (!pp.tried && e->graph_uses >= 2) {
         int rc = timed_build(e, [&] { return build_prune_impl(e, stage, in); });
         if (rc) return rc;
     }
-    if (!pp.ready) return GNNVC_OK;
+    if (!pp.ready || !gathering) return GNNVC_OK;   // (a compact-table plan has this call: its kernels do not gather)
     HIP_TRY(e, gnnvc::prune_check(e->g, in, pp.heavy.p, e->prune_flags.p + stage, e->stream));
     gv.prp = pp.prp.p - e->g.lo();   // (indexed by global row id, like rowptr)
     gv.pcol = pp.pcol.p;
     gv.prune_bad = e->prune_flags.p + stage;
+    if (e->opt_prune_eff) {
+        const bool whole = lo == e->g.lo() && hi == e->g.hi();
+        if (!sorted_tiles) {
+            gv.prune_eff = 1;
+        } else if (whole && pp.slist) {
+            gv.prune_eff = 1;
+            so_p.n = pp.sn;
+            so_p.vertex = pp.svertex.p;
+            so_p.meta = pp.smeta.p;
+        }
+        gv.eff_giant = e->n_giant ? e->giant_thresh : 0xFFFFFFFFu;
+        gv.eff_thresh = pp.eff_thresh;
+    }
     return GNNVC_OK;
 }
 
@@ -1149,8 +1192,8 @@ int launch_side_rows(gnnvc_engine *e, const GraphDev &gv, int stage, uint32_t lo
     return GNNVC_OK;
 }
 
-int launch_main(gnnvc_engine *e, const StageChoice &c, const GraphDev &gv, int stage, uint32_t lo, uint32_t hi, const float *in,
-                float *out, float *logits) {
+int launch_main(gnnvc_engine *e, const StageChoice &c, const GraphDev &gv, const gnnvc::SortedOrder &so_p, int stage, uint32_t lo,
+                uint32_t hi, const float *in, float *out, float *logits) {
     const gnnvc::StagePlan &sp = e->stages[stage];
     gnnvc::EmitArgs emit;
     // (the counters are zeroed only AFTER this stage's own k_c4_choose has read what the previous stage kernel left in them)
@@ -1199,7 +1242,7 @@ int launch_main(gnnvc_engine *e, const StageChoice &c, const GraphDev &gv, int s
     const gnnvc::SortedOrder *sop = c.sorted.n ? &c.sorted : nullptr;
     HIP_TRY(e, gnnvc::launch_stage(sp, gv, e->ws, e->params.p, in, out, logits, lo, hi, c.long_thresh, c.mfma, sop,
                                    e->interleave, e->stream, acc4, desc, e->c4_agg16.p, e->opt_mfma == 1, emit,
-                                   /*dense_part=*/!c.rounds));
+                                   /*dense_part=*/!c.rounds, so_p.vertex ? &so_p : nullptr));
     if (!c.rounds) return GNNVC_OK;
     HIP_TRY(e, hipMemsetAsync(desc + 5, 0, sizeof(uint32_t), e->stream));        // dirty-row counter
     HIP_TRY(e, hipMemsetAsync(e->c4_marks.p, 0, sizeof(uint32_t), e->stream));   // marks[0]
@@ -1242,13 +1285,14 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
     if (rc) return rc;
     const bool longs = e->n_long > 0;
     GraphDev gv;   // (the check behind a pruned adjacency is queued before the fork to the side streams)
-    rc = gather_view(e, stage, in, gv);
+    gnnvc::SortedOrder so_p;
+    rc = gather_view(e, stage, lo, hi, in, c.sums == StageChoice::kGather, c.sorted.n != 0, gv, so_p);
     if (rc) return rc;
     if (longs) {
         rc = launch_side_rows(e, gv, stage, lo, hi, in, out, logits, c.long_thresh);
         if (rc) return rc;
     }
-    rc = launch_main(e, c, gv, stage, lo, hi, in, out, logits);
+    rc = launch_main(e, c, gv, so_p, stage, lo, hi, in, out, logits);
     if (rc) return rc;
     if (longs && e->opt_side_streams) {   // join
         HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
@@ -1392,7 +1436,7 @@ void gnnvc_destroy(gnnvc_engine *e) {
     e->c4_entries.release(); e->c4_segcnt.release(); e->c4_stepptr.release(); e->c4_stepcnt.release();
     e->c4_desc.release(); e->c4_rowmap.release(); e->c4_first.release(); e->c4_bstart.release(); e->c4_map_vertex.release(); e->c4_map_meta.release(); e->c4_steps.release(); e->c4_table.release(); e->c4_marks.release(); e->c4_acc.release(); e->c4_counts.release();
     e->c4_agg16.release(); e->c4_dirty.release(); e->c4_emit_counts.release();
-    for (auto &pp : e->prune) { pp.prp.release(); pp.pcol.release(); pp.heavy.release(); }
+    for (auto &pp : e->prune) { pp.prp.release(); pp.pcol.release(); pp.heavy.release(); pp.svertex.release(); pp.smeta.release(); }
     e->prune_flags.release(); e->prune_scratch.release(); e->prune_off.release(); e->prune_mask.release();
     e->long_list.release(); e->long_count.release();
     e->gi_meta.release(); e->gi_off.release(); e->gi_slab.release(); e->gi_agg.release();
@@ -1441,6 +1485,8 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "kernel_trace") e->opt_ktrace = value != 0 ? 1 : 0;
     else if (k == "compact_gather") e->opt_compact = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else if (k == "prune_zero_rows") { e->opt_prune = value < 0 ? 0 : (value > 2 ? 2 : (int)value); for (auto &pp : e->prune) pp.tried = pp.ready = false; }
+    else if (k == "prune_class_by_entries_left") { e->opt_prune_eff = value != 0 ? 1 : 0; for (auto &pp : e->prune) pp.tried = pp.ready = false; }
+    else if (k == "prune_heavy_entries") { e->opt_prune_heavy_entries = value > 0 ? (uint64_t)value : 0; for (auto &pp : e->prune) pp.tried = pp.ready = false; }
     else if (k == "prune_giant_rows") e->opt_prune_giant = value != 0 ? 1 : 0;
     else if (k == "prune_min_entries") e->opt_prune_min_nnz = value > 0 ? (uint64_t)value : 0;
     else if (k == "prune_min_drop_percent") e->opt_prune_min_drop = value < 0 ? 0u : (value > 100 ? 100u : (uint32_t)value);

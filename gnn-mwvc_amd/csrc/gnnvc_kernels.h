@@ -29,6 +29,10 @@ struct GraphDev {
     // left out of prp / pcol (n + 1 offsets, the kept entries in CSR order + GNNVC_COL_PAD).  The gathering kernels
     // use it iff *prune_bad == 0 (decided on the device for this very input); rowptr stays the source of degrees.
     const uint32_t *prp = nullptr, *pcol = nullptr, *prune_bad = nullptr;
+    // prune_eff != 0: with the pruned adjacency in force a row goes to the tile kernel or to the long-row kernel by the
+    // number of entries it has LEFT (not by its degree) — except the giant rows, degree >= eff_giant, which stay with
+    // their kernels.  The engine sets it when the tile order of the call was built from those numbers too.
+    uint32_t prune_eff = 0, eff_giant = 0xFFFFFFFFu, eff_thresh = 0xFFFFFFFFu;   // eff_thresh: entries left from which a row is the long-row kernel's
 #if defined(__HIPCC__)
     __host__ __device__
 #endif
@@ -94,7 +98,8 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
                         const uint32_t *c4desc = nullptr, const float *agg16 = nullptr, bool mfma_agg = false,
                         const EmitArgs &emit = EmitArgs(),
                         bool dense_part = true /* false: only the gathering kernel (which leaves at once when the compact-table
-                                                  plan applies); the caller launches the sums and the dense kernel itself */);
+                                                  plan applies); the caller launches the sums and the dense kernel itself */,
+                        const SortedOrder *so_pruned = nullptr /* g.prune_eff: the tile order by entries left (meta = pruned ranges) */);
 // the dense layers + sigmoid of the last stage when its aggregates are ready (compact-table plan)
 hipError_t launch_dense_sigmoid(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *in, float *out,
                                 float *logits, uint32_t row_lo, uint32_t row_hi, const float *acc4, const uint32_t *c4desc,
@@ -104,10 +109,14 @@ hipError_t launch_dense_sigmoid(const StagePlan &sp, const GraphDev &g, float ws
 // is done on the host).
 hipError_t measure_tile_waste(const GraphDev &g, uint32_t row_lo, uint32_t row_hi, uint32_t long_thresh,
                               unsigned long long *sum_max, hipStream_t stream);
+// (degree_*: g.rowptr decides a row's class; skip_rowptr != nullptr: rows with skip_rowptr[u + 1] - skip_rowptr[u] >= skip_from
+// are left out as well — the giant rows when g.rowptr is a pruned adjacency's)
 hipError_t degree_histogram(const GraphDev &g, uint32_t row_lo, uint32_t row_hi, uint32_t long_thresh,
-                            uint32_t bins, uint32_t *hist, hipStream_t stream);
+                            uint32_t bins, uint32_t *hist, hipStream_t stream, const uint32_t *skip_rowptr = nullptr,
+                            uint32_t skip_from = 0xFFFFFFFFu);
 hipError_t degree_scatter(const GraphDev &g, uint32_t row_lo, uint32_t row_hi, uint32_t long_thresh,
-                          uint32_t bins, uint32_t *cursor, uint32_t *vertex, void *meta, hipStream_t stream);
+                          uint32_t bins, uint32_t *cursor, uint32_t *vertex, void *meta, hipStream_t stream,
+                          const uint32_t *skip_rowptr = nullptr, uint32_t skip_from = 0xFFFFFFFFu);
 
 // Long rows (degree >= thresh): listed once per graph, then one workgroup per row per
 // stage (same CSR-order sums).  The tile kernels above skip those rows when given the

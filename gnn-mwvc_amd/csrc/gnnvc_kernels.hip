@@ -313,7 +313,8 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
         uint32_t row_hi, uint32_t long_thresh, const uint32_t *__restrict__ srt_vertex,
         const uint4 *__restrict__ srt_meta, uint32_t n_sorted, int interleave,
         const float4 *__restrict__ acc4, const uint32_t *__restrict__ c4desc, const float4 *__restrict__ agg16,
-        const uint32_t *__restrict__ emit_spec, c4row *__restrict__ emit_table, unsigned long long *__restrict__ emit_counts) {
+        const uint32_t *__restrict__ emit_spec, c4row *__restrict__ emit_table, unsigned long long *__restrict__ emit_counts,
+        const uint32_t *__restrict__ srt_vertex_p = nullptr, const uint4 *__restrict__ srt_meta_p = nullptr, uint32_t n_sorted_p = 0) {
     __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kRegionFloats];
     const int lane = threadIdx.x & 63;
     float *T = lds[threadIdx.x >> 6];
@@ -323,17 +324,27 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
     } else {
         if (c4desc && c4desc[0] != 0) return; // uniform: the aggregate-only variant has this launch
     }
-    const uint32_t ntiles = SORTED ? (n_sorted + kWave - 1) / kWave : (row_hi - row_lo + kWave - 1) / kWave;
-    // natural order: XCD-contiguous ranges (locality).  Sorted order lists the heaviest tiles
-    // first, so they are dealt round-robin instead — consecutive blocks sit on different XCDs
-    // and every XCD gets the same mix of heavy and light tiles.
-    const uint32_t tile = tile_for_wave(ntiles, SORTED || interleave);
-    if (tile >= ntiles) return;
-    const uint32_t v0 = row_lo + tile * kWave;   // natural order only
     // the entries to gather: the whole adjacency, or (uniform; decided on the device for this input) the pruned one
     const bool pruned = !AGGONLY && g.prune_bad != nullptr && *g.prune_bad == 0u;
     const uint32_t *__restrict__ grp = pruned ? g.prp : g.rowptr;
     const uint32_t *__restrict__ gcol = pruned ? g.pcol : g.col;
+    // with the pruned adjacency a row's class (tile kernel / long-row kernel) goes by the entries it has left, and the
+    // sorted tiles come from the list built from those numbers (its meta holds the pruned ranges)
+    const bool by_left = pruned && g.prune_eff != 0u;
+    if (SORTED && by_left) {
+        srt_vertex = srt_vertex_p;
+        srt_meta = srt_meta_p;
+        n_sorted = n_sorted_p;
+    }
+    const uint32_t ntiles = SORTED ? (n_sorted + kWave - 1) / kWave : (row_hi - row_lo + kWave - 1) / kWave;
+    // natural order: XCD-contiguous ranges (locality).  Sorted order lists the heaviest tiles
+    // first, so they are dealt round-robin instead — consecutive blocks sit on different XCDs
+    // and every XCD gets the same mix of heavy and light tiles.
+    // (the grid is sized for the longer of the two lists: the same launch serves whichever the device picks)
+    const uint32_t grid_tiles = SORTED ? (max(n_sorted, n_sorted_p) + kWave - 1) / kWave : ntiles;
+    const uint32_t tile = tile_for_wave(grid_tiles, SORTED || interleave);
+    if (tile >= ntiles) return;
+    const uint32_t v0 = row_lo + tile * kWave;   // natural order only
 
     // lane-per-vertex view of the tile
     uint32_t u, rs, re;
@@ -345,9 +356,15 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
         const uint32_t sl = mine ? slot : n_sorted - 1;
         u = srt_vertex[sl];
         const uint4 meta = srt_meta[sl];
-        rs = pruned ? grp[u] : meta.x;
-        re = mine ? (pruned ? grp[u + 1] : meta.y) : rs;
-        f_deg = (float)(meta.y - meta.x);
+        if (by_left) {   // the list's meta holds the pruned range; the degree (a feature) comes from the adjacency itself
+            rs = meta.x;
+            re = mine ? meta.y : rs;
+            f_deg = (float)(g.rowptr[u + 1] - g.rowptr[u]);
+        } else {
+            rs = pruned ? grp[u] : meta.x;
+            re = mine ? (pruned ? grp[u + 1] : meta.y) : rs;
+            f_deg = (float)(meta.y - meta.x);
+        }
         f_w = (float)meta.z / ws;
         f_nw = (float)meta.w / ws;
     } else {
@@ -358,9 +375,10 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
         const uint32_t re_full = valid ? g.rowptr[u + 1] : rs_full;
         // rows of degree >= long_thresh belong to the long-row kernel (k_long_f16): no gather,
         // no store for them here
-        mine = valid && (re_full - rs_full) < long_thresh;
         rs = pruned ? grp[u] : rs_full;
-        re = mine ? (pruned ? grp[u + 1] : re_full) : rs;
+        const uint32_t re_p = pruned ? (valid ? grp[u + 1] : rs) : re_full;
+        mine = valid && (by_left ? (re_p - rs) < g.eff_thresh && (re_full - rs_full) < g.eff_giant : (re_full - rs_full) < long_thresh);
+        re = mine ? re_p : rs;
         f_deg = (float)(re_full - rs_full);
         f_w = (float)g.w[u] / ws;
         f_nw = (float)g.nw[u] / ws;
@@ -893,13 +911,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     if (u < row_lo || u >= row_hi) return;   // block-uniform
     const int tid = threadIdx.x, q = tid >> 2, c = tid & 3;
     const uint32_t deg = g.rowptr[u + 1] - g.rowptr[u];
-    if (deg < min_deg) return;               // listed for another stage's threshold; a tile kernel has it here
     if (deg >= max_deg) return;              // a giant row: the k_giant_* kernels have it
     // the entries to gather: the row's whole list, or its pruned one (see k_prune_*; gdeg may be 0)
     const bool pruned = g.prune_bad != nullptr && *g.prune_bad == 0u;
     const uint32_t *__restrict__ gcol = pruned ? g.pcol : g.col;
     const uint32_t rs = pruned ? g.prp[u] : g.rowptr[u], re = pruned ? g.prp[u + 1] : g.rowptr[u + 1];
     const uint32_t gdeg = re - rs, last = gdeg ? re - 1 : rs;   // (col arrays are padded: [rs] is readable)
+    // listed for another stage's threshold (or, classed by the entries it has left, short enough): a tile kernel has it here
+    if ((pruned && g.prune_eff) ? gdeg < g.eff_thresh : deg < min_deg) return;
     const uint32_t zrow = g.n;
     // Two register sets (A, B) alternate: while one round drains through the slab, the
     // 1024 row fetches of the next round and the column indices of the round after it are
@@ -2272,12 +2291,14 @@ __global__ __launch_bounds__(256) void k_tile_waste(GraphDev g, uint32_t row_lo,
 
 // histogram of min(degree, bins - 1) over the non-long rows of [row_lo, row_hi)
 __global__ __launch_bounds__(256) void k_deg_hist(GraphDev g, uint32_t row_lo, uint32_t row_hi, uint32_t long_thresh,
-                                                  uint32_t bins, uint32_t *__restrict__ hist) {
+                                                  uint32_t bins, uint32_t *__restrict__ hist, const uint32_t *__restrict__ skip_rowptr,
+                                                  uint32_t skip_from) {
     __shared__ uint32_t local[4096];   // bins <= 4096: a few degree classes take most rows, so count per block first
     for (uint32_t i = threadIdx.x; i < bins; i += blockDim.x) local[i] = 0;
     __syncthreads();
     for (uint32_t u = row_lo + blockIdx.x * blockDim.x + threadIdx.x; u < row_hi; u += gridDim.x * blockDim.x) {
         const uint32_t d = g.rowptr[u + 1] - g.rowptr[u];
+        if (skip_rowptr && skip_rowptr[u + 1] - skip_rowptr[u] >= skip_from) continue;
         if (d < long_thresh) atomicAdd(&local[d < bins ? d : bins - 1], 1u);
     }
     __syncthreads();
@@ -2289,7 +2310,8 @@ __global__ __launch_bounds__(256) void k_deg_hist(GraphDev g, uint32_t row_lo, u
 // so the heaviest tiles are dispatched first); entries carry what the tile kernel needs per vertex
 __global__ __launch_bounds__(256) void k_deg_scatter(GraphDev g, uint32_t row_lo, uint32_t row_hi, uint32_t long_thresh,
                                                      uint32_t bins, uint32_t *__restrict__ cursor,
-                                                     uint32_t *__restrict__ vertex, uint4 *__restrict__ meta) {
+                                                     uint32_t *__restrict__ vertex, uint4 *__restrict__ meta,
+                                                     const uint32_t *__restrict__ skip_rowptr, uint32_t skip_from) {
     // per block: count its rows per class in LDS, reserve one range per class with a single
     // global atomic, then hand out slots from LDS (global atomics: one per class per block)
     __shared__ uint32_t local[4096];
@@ -2301,7 +2323,8 @@ __global__ __launch_bounds__(256) void k_deg_scatter(GraphDev g, uint32_t row_lo
         rs = g.rowptr[u];
         re = g.rowptr[u + 1];
         const uint32_t d = re - rs;
-        if (d < long_thresh) {
+        const bool skip = skip_rowptr && skip_rowptr[u + 1] - skip_rowptr[u] >= skip_from;
+        if (d < long_thresh && !skip) {
             cls = d < bins ? d : bins - 1;
             rank_in_block = atomicAdd(&local[cls], 1u);
         }
@@ -2931,11 +2954,14 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
                         const float *in, float *out, float *logits, uint32_t row_lo,
                         uint32_t row_hi, uint32_t long_thresh, bool mfma, const SortedOrder *so,
                         bool interleave, hipStream_t stream, const float *acc4, const uint32_t *c4desc, const float *agg16,
-                        bool mfma_agg, const EmitArgs &emit, bool dense_part) {
+                        bool mfma_agg, const EmitArgs &emit, bool dense_part, const SortedOrder *so_pruned) {
     if (row_hi <= row_lo) return hipSuccess;
     const bool sorted = so && so->n > 0;
-    if (so && so->n == 0) return hipSuccess;   // every row of the range is a long row
-    const uint32_t ntiles = sorted ? (so->n + kWave - 1) / kWave : (row_hi - row_lo + kWave - 1) / kWave;
+    const bool with_p = sorted && g.prune_eff && so_pruned && so_pruned->vertex;
+    if (g.prune_eff && sorted && !with_p) return hipErrorInvalidValue;   // (classing by entries left needs the matching tile order)
+    if (so && so->n == 0 && !with_p) return hipSuccess;   // every row of the range is a long row
+    const uint32_t n_p = with_p ? so_pruned->n : 0u;
+    const uint32_t ntiles = sorted ? (std::max(so->n, n_p) + kWave - 1) / kWave : (row_hi - row_lo + kWave - 1) / kWave;
     const uint32_t per_xcd = (ntiles + 7) / 8;
     const uint32_t blocks_per_xcd = (per_xcd + kWavesPerBlock - 1) / kWavesPerBlock;
     const dim3 grid(blocks_per_xcd * 8), block(kBlock);
@@ -2972,7 +2998,8 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
                        LG_, P, row_lo, row_hi, long_thresh, sorted ? so->vertex : nullptr,                \
                        sorted ? so->meta : nullptr, sorted ? so->n : 0u, il,                              \
                        (const float4 *)nullptr, acc4 ? c4desc : nullptr, (const float4 *)nullptr,                         \
-                       (const uint32_t *)nullptr, (c4row *)nullptr, (unsigned long long *)nullptr)
+                       (const uint32_t *)nullptr, (c4row *)nullptr, (unsigned long long *)nullptr,                        \
+                       with_p ? so_pruned->vertex : nullptr, with_p ? so_pruned->meta : nullptr, n_p)
     case 2:
         if (sorted) GNNVC_LAUNCH_F16(32, 16, false, false, true, GNNVC_GATHER_S_SORTED, nullptr);
         else GNNVC_LAUNCH_F16(32, 16, false, false, false, GNNVC_GATHER_S, nullptr);
@@ -3386,19 +3413,20 @@ hipError_t measure_tile_waste(const GraphDev &g, uint32_t row_lo, uint32_t row_h
 }
 
 hipError_t degree_histogram(const GraphDev &g, uint32_t row_lo, uint32_t row_hi, uint32_t long_thresh,
-                            uint32_t bins, uint32_t *hist, hipStream_t stream) {
+                            uint32_t bins, uint32_t *hist, hipStream_t stream, const uint32_t *skip_rowptr, uint32_t skip_from) {
     hipError_t rc = hipMemsetAsync(hist, 0, bins * sizeof(uint32_t), stream);
     if (rc != hipSuccess || row_hi <= row_lo) return rc;
     const unsigned nb = std::min<unsigned>((row_hi - row_lo + 255) / 256, 2048u);
-    GNNVC_LAUNCH(k_deg_hist, dim3(nb), dim3(256), 0, stream, g, row_lo, row_hi, long_thresh, bins, hist);
+    GNNVC_LAUNCH(k_deg_hist, dim3(nb), dim3(256), 0, stream, g, row_lo, row_hi, long_thresh, bins, hist, skip_rowptr, skip_from);
     return hipGetLastError();
 }
 
 hipError_t degree_scatter(const GraphDev &g, uint32_t row_lo, uint32_t row_hi, uint32_t long_thresh,
-                          uint32_t bins, uint32_t *cursor, uint32_t *vertex, void *meta, hipStream_t stream) {
+                          uint32_t bins, uint32_t *cursor, uint32_t *vertex, void *meta, hipStream_t stream,
+                          const uint32_t *skip_rowptr, uint32_t skip_from) {
     if (row_hi <= row_lo) return hipSuccess;
     GNNVC_LAUNCH(k_deg_scatter, dim3((row_hi - row_lo + 255) / 256), dim3(256), 0, stream, g, row_lo, row_hi,
-                       long_thresh, bins, cursor, vertex, reinterpret_cast<uint4 *>(meta));
+                       long_thresh, bins, cursor, vertex, reinterpret_cast<uint4 *>(meta), skip_rowptr, skip_from);
     return hipGetLastError();
 }
 
