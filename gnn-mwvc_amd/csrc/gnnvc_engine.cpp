@@ -173,6 +173,7 @@ struct gnnvc_engine {
     DevBuf<unsigned long long> prune_mask;   // flags: [stage] = this call's verdict (0 = the pruned adjacency applies), [3] = observe
     int opt_prune = 1;               // option "prune_zero_rows": 1 = the rows found all zero when the plan is built, 2 = a degree bound, 0 = off
     uint64_t opt_prune_heavy_entries = 16u << 20;   // option "prune_heavy_entries": from this many entries left, rows up to the sorted threshold stay with the tile kernel
+    uint64_t opt_prune_early_nnz = 64u << 20;   // option "prune_early_entries": skewed graphs with at least this many entries build the plan in their first forward (0 = never)
     int opt_prune_eff = 1;           // option "prune_class_by_entries_left" (A/B): 0 = rows keep the class their degree gives them
     int opt_prune_giant = 1;         // option "prune_giant_rows" (A/B): 0 = the giant rows keep their full streams
     uint64_t opt_prune_min_nnz = 1u << 20;   // option "prune_min_entries": smaller graphs are not worth a plan
@@ -1035,7 +1036,13 @@ int gather_view(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const floa
     so_p = gnnvc::SortedOrder();
     if (stage < 1 || stage > 3 || e->stages[stage].f != 16 || !e->opt_prune) return GNNVC_OK;
     gnnvc_engine::PrunePlan &pp = e->prune[stage];
-    if (!pp.tried && e->graph_uses >= 2) {
+    // Built with the rest of the plans when the graph is scored a second time — but on a LARGE skewed graph (sorted tiles or
+    // long rows: that is where zero rows are found) already the first time its stage runs: the passes cost less than the
+    // gathers they save there (first forward R-MAT-22 6.95 -> 6.16 ms, R-MAT-24 34.5 -> 25.9 ms; R-MAT-20 and the power-law
+    // graph lose 0.3 - 0.5 ms to the fixed costs, hence the size bound).
+    const bool early = (e->sorted_wanted || e->n_long > 0) && e->opt_prune_early_nnz && e->g.nnz >= e->opt_prune_early_nnz;
+    const uint32_t uses_needed = early ? 1u : 2u;
+    if (!pp.tried && e->graph_uses >= uses_needed) {
         int rc = timed_build(e, [&] { return build_prune_impl(e, stage, in); });
         if (rc) return rc;
     }
@@ -1487,6 +1494,7 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "prune_zero_rows") { e->opt_prune = value < 0 ? 0 : (value > 2 ? 2 : (int)value); for (auto &pp : e->prune) pp.tried = pp.ready = false; }
     else if (k == "prune_class_by_entries_left") { e->opt_prune_eff = value != 0 ? 1 : 0; for (auto &pp : e->prune) pp.tried = pp.ready = false; }
     else if (k == "prune_heavy_entries") { e->opt_prune_heavy_entries = value > 0 ? (uint64_t)value : 0; for (auto &pp : e->prune) pp.tried = pp.ready = false; }
+    else if (k == "prune_early_entries") e->opt_prune_early_nnz = value > 0 ? (uint64_t)value : 0;
     else if (k == "prune_giant_rows") e->opt_prune_giant = value != 0 ? 1 : 0;
     else if (k == "prune_min_entries") e->opt_prune_min_nnz = value > 0 ? (uint64_t)value : 0;
     else if (k == "prune_min_drop_percent") e->opt_prune_min_drop = value < 0 ? 0u : (value > 100 ? 100u : (uint32_t)value);
