@@ -106,6 +106,28 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *                         would spend more than twice the useful gather rounds, the default)
  *   "sorted_min_nnz" n     in auto mode, graphs with fewer adjacency entries keep natural tiles
  *                         (default 4 Mi: the sort costs more than it saves on a graph used once)
+ *   "prune_zero_rows" 0|1|2  pruned adjacency of the 16-wide stages: adjacency entries whose target row is all zero in
+ *                         the stage's input are left out of a second CSR (adding a row of zeros changes no bit of a
+ *                         sum); EVERY call proves on the device that its input fits, else it uses the full adjacency.
+ *                         1 (default) = the set of vertices is the rows found all zero when the plan is built (a
+ *                         graph's stage inputs follow from its weights), 2 = every vertex above a degree bound taken
+ *                         from that input plus a margin, 0 = off.  Bit-identical results
+ *   "prune_min_entries" n  graphs with fewer adjacency entries do not prune (default 2^20);
+ *   "prune_min_drop_percent" p  nor do graphs where less than p % of the entries would go (default 15);
+ *   "prune_early_entries" n  skewed graphs with at least n entries build the plan in their first forward (default
+ *                         2^26; 0 = always with the other plans, in the second)
+ *   "prune_class_by_entries_left" 0|1, "prune_heavy_entries" n, "prune_giant_rows" 0|1  A/B switches of the plan: rows
+ *                         classed by the entries they have left (default 1), the entry count from which the tile
+ *                         kernel keeps rows of up to "sorted_long_row_threshold" entries (default 2^24; below: 512),
+ *                         giant rows pruned too (default 1)
+ *   "compact_skewed" 0|1, "compact_passes" 1..3  the compact-table plan on SKEWED graphs (rows dealt to slices of equal
+ *                         weight, column blocks of equal entry mass, up to three tables of four columns per input;
+ *                         long and giant rows beside it).  Default 0: measured no faster than the gathering kernels
+ *                         (DESIGN.md §5); bit-identical
+ * gnnvc_get_info keys (further): "pruned_stage1|2", "pruned_entries_stage1|2", "pruned_vertices_stage1|2",
+ * "pruned_bound_stage1|2", "pruned_last_ok_stage1|2" (did the last call of that stage use its pruned adjacency),
+ * "compact_gather_mapped", "compact_gather_last_ok", "compact_gather_last_passes", "compact_gather_last_dirty",
+ * "compact_gather_blocks", "compact_gather_steps", "plan_build_us".
  * gnnvc_get_info keys: "compact_gather_active", "compact_gather_chunks", "lds_table_active", "lds_table_chunks", "lds_table_steps", "mfma_dense", "sorted_tiles_active", "tile_waste_x100", "blocked_stage0_active", "blocked_blocks", "block_cols", "long_rows",
  * "long_row_threshold", "giant_rows", "giant_entries", "giant_row_threshold", "hub_mode". */
 int gnnvc_set_option(gnnvc_engine *e, const char *key, long value);
