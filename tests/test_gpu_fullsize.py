@@ -8,7 +8,8 @@ the highest-degree ones, which take the long-row path):
     from the device's own stage inputs (its neighbours' rows, in CSR order) — bit-identical;
   * determinism: two forwards give the same bits;
   * partition invariance: a stage run over two vertex ranges equals the whole-range run;
-  * plan invariance: LDS-table / column-blocked / compact-table / MFMA / long-row options do not change a single bit;
+  * plan invariance: LDS-table / column-blocked / compact-table / pruned-adjacency / MFMA / long-row options do not change a
+    single bit;
   * scores are sigmoid(logits) and lie in [0, 1] (strictly inside on the metric graph).
 """
 import numpy as np
@@ -126,6 +127,12 @@ def test_deterministic_and_plan_invariant(big):
     eng.forward_device(big["x"].data_ptr(), sc.data_ptr(), lg.data_ptr())
     eng.synchronize()
     assert torch.equal(lg.view(torch.int32), ref_lg.view(torch.int32))
+    if big["name"] != "er10m":   # skewed graphs: by now both 16-wide stages gather from their pruned adjacency
+        for st in (1, 2):
+            assert eng.get_info(f"pruned_stage{st}") == 1 and eng.get_info(f"pruned_last_ok_stage{st}") == 1
+            assert eng.get_info(f"pruned_entries_stage{st}") * 10 < g.nnz * 6   # (R-MAT: 73 - 86 % of the entries point to rows of zeros; power-law: 44 - 59 %)
+    else:
+        assert eng.get_info("pruned_stage1") == 0 and eng.get_info("pruned_stage2") == 0
     # (the stage-0 plans are built on a graph's second forward: every engine below runs two)
     plans = [{"blocked_stage0": 0, "lds_table": 0, "mfma_dense": 0},
              {"block_cols": 1 << 21, "mfma_dense": 2, "blocked_stage0": 2, "lds_table": 0}, {"lds_table": 2},
@@ -133,7 +140,10 @@ def test_deterministic_and_plan_invariant(big):
     if big["name"] == "er10m":
         plans.append({"mfma_dense": 1, "long_row_threshold": 40})
     else:   # skewed graphs: other long-row thresholds, forced sorted tiles with a low threshold
-        plans += [{"long_row_threshold": 2048, "mfma_dense": 1}, {"sorted_tiles": 1, "sorted_long_row_threshold": 600}]
+        plans += [{"long_row_threshold": 2048, "mfma_dense": 1}, {"sorted_tiles": 1, "sorted_long_row_threshold": 600},
+                  {"prune_zero_rows": 0}, {"prune_zero_rows": 2}, {"prune_class_by_entries_left": 0, "prune_giant_rows": 0}]
+        if big["name"] == "rmat22":
+            plans.append({"compact_skewed": 1})
     for opts in plans:
         e2 = G.Engine(G.default_model_text(), device=0)
         try:
