@@ -122,6 +122,11 @@ struct gnnvc_engine {
     // LDS-table plan of the F = 1 stage (same timing as the blocked plan: built on the graph's second forward)
     int opt_lds_table = 1;          // 0 = off, 1 = when it applies, 2 = also on skewed graphs
     bool lt_ready = false, lt_tried = false;
+    bool lt_mapped = false;              // skewed graphs: rows dealt to slices (lt_rowmap), blocks of equal mass, rows below lt_plan_thresh
+    uint32_t lt_plan_thresh = 0xFFFFFFFFu;
+    DevBuf<uint32_t> lt_rowmap, lt_first, lt_bstart;
+    uint32_t opt_lds_skewed_rows = 0;       // (0 = by the size of x) option "lds_table_skewed_rows": rows of at least this many entries stay outside the skewed-graph plan
+    int opt_lds_skewed = 1;              // option "lds_table_skewed": 0 = skewed graphs keep the gathering F = 1 kernels
     uint32_t lt_rows = 0, lt_chunks = 0, lt_blocks = 0, lt_steps_total = 0, lt_last_entry = 0;
     DevBuf<uint8_t> lt_bytes;
     DevBuf<uint32_t> lt_entries, lt_segcnt, lt_stepptr, lt_stepcnt, lt_bad;
@@ -137,6 +142,7 @@ struct gnnvc_engine {
     uint32_t c4_max_passes = 1, c4_nslices = 0, c4_mapped_rows = 0;
     uint64_t c4_mapped_entries = 0;
     DevBuf<uint32_t> c4_rowmap, c4_first, c4_bstart, c4_map_vertex;
+    DevBuf<uint32_t> map_coarse;      // uint16 per 256 columns: their block (scratch of the skewed-graph plan builders)
     DevBuf<uint4> c4_map_meta;
     int opt_compact_skewed = 0;      // option "compact_skewed": 1 = skewed graphs take the mapped compact-table plan (measured: no gain on
                                      // R-MAT-22 — three passes at ~110 G entries/s tie with the gathering kernel — so it is opt-in)
@@ -638,6 +644,106 @@ int build_blocked_impl(gnnvc_engine *e) {
     return GNNVC_OK;
 }
 
+// Layout of a plan over a SKEWED graph (LDS-table plan of the F = 1 stage, compact-table plan of the 16-wide stages): the rows
+// below `class_thresh` entries that have any are dealt serpentine from the degree-sorted list to slices of equal weight
+// (rowmap, first), and the column blocks are cut at equal entry mass (bstart) — on a symmetric adjacency the entries that
+// point INTO columns [a, b) are as many as the entries of rows [a, b), so the cuts are read off rowptr (for any other
+// adjacency they are a heuristic: nothing but the step fill depends on them); block widths between 256 columns and `maxw`,
+// cuts at multiples of `align`.
+struct SkewedLayout {
+    uint32_t plan_rows = 0, rows = 0, chunks = 0, slice_rows = 0, slices = 0, nblocks = 0;
+    uint64_t entries = 0;
+    gnnvc::PlanMap pm;
+};
+int layout_skewed_plan(gnnvc_engine *e, uint32_t class_thresh, uint32_t max_rows, uint32_t nsl, double fill, uint32_t maxw, uint32_t align,
+                       DevBuf<uint32_t> &rowmap, DevBuf<uint32_t> &first, DevBuf<uint32_t> &bstart, DevBuf<uint32_t> &weights,
+                       SkewedLayout &L) {
+    const GraphDev &g = e->g;
+    uint32_t listed = 0, zero_rows = 0;
+    int rc = sort_by_degree(e, 0, g.n, e->c4_map_vertex, e->c4_map_meta, listed, zero_rows, nullptr, nullptr, 0xFFFFFFFFu, class_thresh);
+    if (rc) return rc;
+    L.plan_rows = listed - zero_rows;   // (rows without entries keep the zeros their sums are initialised with)
+    if (L.plan_rows == 0) return GNNVC_OK;
+    uint32_t chunks = (L.plan_rows + max_rows - 1) / max_rows;
+    chunks = (chunks + 255u) / 256u * 256u;
+    uint32_t rows = (L.plan_rows + chunks - 1) / chunks;
+    rows = (rows + nsl - 1) / nsl * nsl;
+    chunks = (L.plan_rows + rows - 1) / rows;
+    L.rows = rows;
+    L.chunks = chunks;
+    L.slice_rows = rows / nsl;
+    L.slices = chunks * nsl;
+    const uint32_t slices = L.slices;
+    HIP_TRY(e, e->pin_small.reserve((size_t)slices + 4100));
+    HIP_TRY(e, rowmap.reserve((size_t)slices * L.slice_rows));
+    HIP_TRY(e, first.reserve((size_t)slices + 1));
+    HIP_TRY(e, weights.reserve(slices));
+    HIP_TRY(e, gnnvc::deal_rows(g, e->c4_map_vertex.p, L.plan_rows, L.slice_rows, slices, rowmap.p, weights.p, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, weights.p, slices * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    uint64_t run = 0;
+    for (uint32_t c = 0; c < slices; ++c) {
+        const uint32_t w = e->pin_small.p[c];
+        e->pin_small.p[c] = (uint32_t)run;
+        run += w;
+    }
+    e->pin_small.p[slices] = (uint32_t)run;
+    L.entries = run;
+    if (run == 0 || run >= (1ull << 31)) {
+        L.plan_rows = 0;
+        return GNNVC_OK;
+    }
+    HIP_TRY(e, hipMemcpyAsync(first.p, e->pin_small.p, ((size_t)slices + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));   // pin_small is reused below
+    const uint32_t minw = std::max(256u, align);
+    const double per_slice = (double)L.entries / slices;
+    const double nb_want = std::max(1.0, per_slice / fill);
+    const unsigned long long target = (unsigned long long)std::max(1.0, (double)g.nnz / nb_want);
+    const uint32_t ncand = (uint32_t)std::min<unsigned long long>(g.nnz / target + 2, 4096);
+    HIP_TRY(e, bstart.reserve(4100));
+    HIP_TRY(e, gnnvc::mass_bounds(g, target, ncand, bstart.p, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, bstart.p, ncand * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    std::vector<uint32_t> bs{0u};
+    auto cut = [&](uint32_t at) {
+        while (at - bs.back() > maxw) bs.push_back(bs.back() + maxw);
+        if (at > bs.back()) bs.push_back(at);
+    };
+    for (uint32_t k = 1; k < ncand; ++k) {
+        const uint32_t at = std::min(e->pin_small.p[k], g.n) / align * align;
+        if (at >= g.n) break;
+        if (at > bs.back() && at - bs.back() >= minw) cut(at);
+    }
+    if (g.n - bs.back() < minw && bs.size() > 1) bs.pop_back();   // no sliver at the end
+    cut(g.n);                                                      // bs.back() == g.n: the end of the last block
+    L.nblocks = (uint32_t)bs.size() - 1;
+    if (L.nblocks == 0 || L.nblocks > 4096) {
+        L.plan_rows = 0;
+        return GNNVC_OK;
+    }
+    std::memcpy(e->pin_small.p, bs.data(), bs.size() * sizeof(uint32_t));
+    HIP_TRY(e, hipMemcpyAsync(bstart.p, e->pin_small.p, bs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    {   // the block of every 256th column (the builders look a column's block up instead of searching for it)
+        const size_t granules = ((size_t)g.n + 255) / 256 + 1;
+        std::vector<uint16_t> coarse(granules);
+        uint32_t b = 0;
+        for (size_t k = 0; k < granules; ++k) {
+            const uint64_t c = (uint64_t)k * 256;
+            while (b + 1 < L.nblocks && c >= bs[b + 1]) ++b;
+            coarse[k] = (uint16_t)b;
+        }
+        HIP_TRY(e, e->map_coarse.reserve((granules + 1) / 2));
+        HIP_TRY(e, hipMemcpyAsync(e->map_coarse.p, coarse.data(), granules * sizeof(uint16_t), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));   // (coarse lives on this stack frame)
+    }
+    L.pm.rowmap = rowmap.p;
+    L.pm.first = first.p;
+    L.pm.bstart = bstart.p;
+    L.pm.coarse = reinterpret_cast<const uint16_t *>(e->map_coarse.p);
+    return GNNVC_OK;
+}
+
 // stage launcher shared by the whole-forward and the per-stage entry points
 // LDS-table plan of the current graph's F = 1 stage (kernels: k_lt_*).  Applies when every weight fits a
 // byte, adjacency lists ascend, no row is long enough for the long-row kernels and the graph is large and
@@ -645,39 +751,73 @@ int build_blocked_impl(gnnvc_engine *e) {
 int build_lds_table_impl(gnnvc_engine *e) {
     e->lt_ready = false;
     e->lt_tried = true;
+    e->lt_mapped = false;
     const GraphDev &g = e->g;
     if (!e->opt_lds_table || e->stages.empty() || e->stages[0].f != 1 || e->stages[0].variant != 0) return GNNVC_OK;
     if (g.sliced()) return GNNVC_OK;
     if (g.n < e->opt_blocked_min_n || g.nnz == 0 || g.nnz >= (1ull << 31)) return GNNVC_OK;
-    if (e->opt_lds_table < 2 && (e->sorted_wanted || e->n_long > 0)) return GNNVC_OK;   // long runs would serialise in one thread
+    // Skewed graphs (sorted tiles wanted, or long rows present): the plan covers the rows below the giant-row threshold, dealt
+    // from the degree-sorted list to slices of equal weight, over column blocks of equal entry mass (layout_skewed_plan); the
+    // giant rows keep their kernels.  "lds_table" 2 forces the consecutive-row layout onto such a graph instead (tests).
+    const bool skewed = e->sorted_wanted || e->n_long > 0;
+    const bool mapped = skewed && e->opt_lds_table < 2 && e->opt_lds_skewed;
+    if (skewed && !mapped && e->opt_lds_table < 2) return GNNVC_OK;   // long runs would serialise in one thread
     const uint32_t bc = gnnvc::lds_table_block();
     uint32_t max_rows = gnnvc::lds_table_max_rows();
     if (e->opt_plan_chunk_rows) max_rows = std::min(max_rows, std::max(16u, e->opt_plan_chunk_rows / 16u * 16u));
-    const uint32_t nblocks = (g.n + bc - 1) / bc;
-    if (nblocks > 4096) return GNNVC_OK;
-    // chunks: a multiple of the 256 CUs, each within the LDS budget; a chunk = 16 slices of rows (one per wave)
-    uint32_t chunks = (g.n + max_rows - 1) / max_rows;
-    chunks = (chunks + 255u) / 256u * 256u;
-    uint32_t rows = (g.n + chunks - 1) / chunks;
-    rows = (rows + 15u) / 16u * 16u;
-    chunks = (g.n + rows - 1) / rows;
-    const uint32_t slice_rows = rows / 16u, slices = chunks * 16u;
+    uint32_t nblocks = (g.n + bc - 1) / bc, chunks = 0, rows = 0, slice_rows = 0, slices = 0;
+    uint64_t plan_nnz = g.nnz;
+    gnnvc::PlanMap pm;
+    if (mapped) {
+        // rows of this many entries and more stay outside the plan: the giant rows (their own kernels), or, where there are
+        // none, whatever k_long_f1 is left with
+        // Rows of this many entries and more stay outside the plan.  A row's entries of one block are one run, folded in order
+        // lane after lane — a 16 K-entry row makes every step of its slice several times longer (R-MAT-22: k_lt_agg 0.58 ms with
+        // rows below 2048, 1.07 ms with everything below the giant rows), while k_long_f1 gathers such rows at ~100 G entries/s as
+        // long as x (4 N bytes) mostly sits in the L2s.  Beyond that (R-MAT-24: 67 MB, k_long_f1 at 34 G entries/s) the plan is
+        // the better place for them: forward 13.5 -> 12.8 ms.  "lds_table_skewed_rows" overrides.
+        const uint32_t below_giant = e->n_giant ? e->giant_thresh : 16384u;
+        const uint32_t want = e->opt_lds_skewed_rows ? e->opt_lds_skewed_rows : ((uint64_t)g.n * 4 > (32ull << 20) ? below_giant : 2048u);
+        e->lt_plan_thresh = std::max(e->long_thresh == 0xFFFFFFFFu ? 0u : e->long_thresh, std::min(want, below_giant));
+        SkewedLayout L;
+        int rc = layout_skewed_plan(e, e->lt_plan_thresh, max_rows, 16u, gnnvc::lds_table_step() * 5.0 / 6.0, bc, 16u, e->lt_rowmap,
+                                    e->lt_first, e->lt_bstart, e->lt_stepcnt, L);
+        if (rc) return rc;
+        if (L.plan_rows == 0) return GNNVC_OK;
+        chunks = L.chunks;
+        rows = L.rows;
+        slice_rows = L.slice_rows;
+        slices = L.slices;
+        nblocks = L.nblocks;
+        plan_nnz = L.entries;
+        pm = L.pm;
+    } else {
+        if (nblocks > 4096) return GNNVC_OK;
+        // chunks: a multiple of the 256 CUs, each within the LDS budget; a chunk = 16 slices of rows (one per wave)
+        chunks = (g.n + max_rows - 1) / max_rows;
+        chunks = (chunks + 255u) / 256u * 256u;
+        rows = (g.n + chunks - 1) / chunks;
+        rows = (rows + 15u) / 16u * 16u;
+        chunks = (g.n + rows - 1) / rows;
+        slice_rows = rows / 16u;
+        slices = chunks * 16u;
+    }
     const uint32_t slack = 3u * nblocks + 4u;   // every (slice, block) segment starts at a multiple of 4 entries
-    const uint64_t entry_cap = g.nnz + (uint64_t)slack * slices + 8;
+    const uint64_t entry_cap = plan_nnz + (uint64_t)slack * slices + 8;
     if (entry_cap >= (1ull << 31)) return GNNVC_OK;
     HIP_TRY(e, e->lt_bad.reserve(2));
     HIP_TRY(e, e->lt_bytes.reserve((size_t)g.n + 64));
     HIP_TRY(e, e->lt_segcnt.reserve((size_t)slices * nblocks));
-    HIP_TRY(e, e->lt_stepcnt.reserve(chunks));
+    HIP_TRY(e, e->lt_stepcnt.reserve(std::max(chunks, slices)));
     HIP_TRY(e, e->lt_stepptr.reserve((size_t)chunks + 1));
     HIP_TRY(e, e->pin_small.reserve((size_t)chunks + 2));
     uint32_t *flag = e->lt_bad.p + 1;   // word 0 is the per-forward flag
     HIP_TRY(e, hipMemsetAsync(flag, 0, sizeof(uint32_t), e->stream));
     HIP_TRY(e, hipMemsetAsync(e->lt_bytes.p + g.n, 0, 64, e->stream));
     HIP_TRY(e, gnnvc::lds_table_bytes(g.w, g.n, e->lt_bytes.p, flag, e->stream));
-    HIP_TRY(e, gnnvc::lds_table_count(g, slice_rows, slices, nblocks, bc, e->lt_segcnt.p, flag, e->stream));
+    HIP_TRY(e, gnnvc::lds_table_count(g, slice_rows, slices, nblocks, bc, e->lt_segcnt.p, flag, e->stream, 0, 0xFFFFFFFFu, pm));
     HIP_TRY(e, gnnvc::lds_table_wsteps(g, slice_rows, chunks, nblocks, e->lt_segcnt.p, nullptr, e->lt_stepcnt.p, nullptr, false, slack,
-                                       e->stream));
+                                       e->stream, pm));
     HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, e->lt_stepcnt.p, chunks * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipMemcpyAsync(e->pin_small.p + chunks, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -694,20 +834,25 @@ int build_lds_table_impl(gnnvc_engine *e) {
     HIP_TRY(e, e->lt_steps.reserve(rec_quads));
     HIP_TRY(e, e->lt_entries.reserve(entry_cap));
     HIP_TRY(e, e->blk_acc.reserve(g.n));
+    if (mapped)   // rows outside the plan (no entries, or giant): their sums stay +0 (never read for the giant ones)
+        HIP_TRY(e, hipMemsetAsync(e->blk_acc.p, 0, (size_t)g.n * sizeof(float), e->stream));
     std::memcpy(e->pin_small.p, ptr.data(), ptr.size() * sizeof(uint32_t));
     HIP_TRY(e, hipMemcpyAsync(e->lt_stepptr.p, e->pin_small.p, ptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipMemsetAsync(e->lt_steps.p, 0, rec_quads * sizeof(uint4), e->stream));
     HIP_TRY(e, hipMemsetAsync(e->lt_entries.p, 0, entry_cap * sizeof(uint32_t), e->stream));   // (pad slots are read, never used)
     HIP_TRY(e, gnnvc::lds_table_wsteps(g, slice_rows, chunks, nblocks, e->lt_segcnt.p, e->lt_stepptr.p, nullptr,
-                                       reinterpret_cast<uint32_t *>(e->lt_steps.p), true, slack, e->stream));
+                                       reinterpret_cast<uint32_t *>(e->lt_steps.p), true, slack, e->stream, pm));
     HIP_TRY(e, gnnvc::lds_table_scatter(g, slice_rows, slices, nblocks, bc, e->lt_segcnt.p, e->lt_entries.p, e->stream, 17, 0,
-                                        0xFFFFFFFFu, slack));
+                                        0xFFFFFFFFu, slack, pm));
     HIP_TRY(e, hipStreamSynchronize(e->stream));   // pin_small is reused by others
+    e->c4_map_meta.release();     // (only the dealing needed the list)
+    e->c4_map_vertex.release();
     e->lt_last_entry = (uint32_t)((entry_cap - 4) & ~3ull);
     e->lt_rows = rows;
     e->lt_chunks = chunks;
     e->lt_blocks = nblocks;
     e->lt_steps_total = (uint32_t)total;
+    e->lt_mapped = mapped;
     e->lt_ready = true;
     return GNNVC_OK;
 }
@@ -745,91 +890,49 @@ int build_compact_impl(gnnvc_engine *e, uint32_t base, uint32_t end, bool allow_
     if (e->opt_plan_chunk_rows) max_rows = std::min(max_rows, std::max(nsl, e->opt_plan_chunk_rows / nsl * nsl));
     uint32_t plan_rows = span;          // rows the plan sums
     uint64_t range_nnz = g.nnz;         // ... and their entries
-    if (mapped) {
-        uint32_t listed = 0, zero_rows = 0;
-        int rc = sort_by_degree(e, 0, g.n, e->c4_map_vertex, e->c4_map_meta, listed, zero_rows);
-        if (rc) return rc;
-        plan_rows = listed - zero_rows;   // (rows without entries keep the zeros their sums are initialised with)
-        if (plan_rows == 0) return GNNVC_OK;
-    }
-    uint32_t chunks = (plan_rows + max_rows - 1) / max_rows;
-    chunks = (chunks + 255u) / 256u * 256u;
-    uint32_t rows = (plan_rows + chunks - 1) / chunks;
-    rows = (rows + nsl - 1) / nsl * nsl;
-    chunks = (plan_rows + rows - 1) / rows;
-    const uint32_t slice_rows = rows / nsl, slices = chunks * nsl;
-    HIP_TRY(e, e->pin_small.reserve((size_t)slices + 4100));
-    gnnvc::PlanMap pm;
-    if (mapped) {
-        HIP_TRY(e, e->c4_rowmap.reserve((size_t)slices * slice_rows));
-        HIP_TRY(e, e->c4_first.reserve((size_t)slices + 1));
-        HIP_TRY(e, e->c4_stepcnt.reserve(slices));
-        HIP_TRY(e, gnnvc::deal_rows(g, e->c4_map_vertex.p, plan_rows, slice_rows, slices, e->c4_rowmap.p, e->c4_stepcnt.p, e->stream));
-        HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, e->c4_stepcnt.p, slices * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
-        uint64_t run = 0;
-        for (uint32_t c = 0; c < slices; ++c) {
-            const uint32_t w = e->pin_small.p[c];
-            e->pin_small.p[c] = (uint32_t)run;
-            run += w;
-        }
-        e->pin_small.p[slices] = (uint32_t)run;
-        range_nnz = run;
-        if (range_nnz == 0) return GNNVC_OK;
-        HIP_TRY(e, hipMemcpyAsync(e->c4_first.p, e->pin_small.p, ((size_t)slices + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(e, hipStreamSynchronize(e->stream));   // pin_small is reused below
-        pm.rowmap = e->c4_rowmap.p;
-        pm.first = e->c4_first.p;
-    } else if (span != g.n) {   // the range's share of the entries (on a slice g.nnz counts the slice's entries only)
-        uint32_t rp[2] = {0, 0};
-        HIP_TRY(e, hipMemcpyAsync(&rp[0], g.rowptr + base, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(e, hipMemcpyAsync(&rp[1], g.rowptr + end, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
-        range_nnz = rp[1] - rp[0];
-        if (range_nnz == 0) return GNNVC_OK;
-    }
     // column blocks: wide enough that a slice brings about 160 entries per block (5/6 of a 192-entry step: room for
     // the spread — a segment of 193 costs a second step that the other waves of the workgroup wait for; measured
     // on the metric graph: 0.70 / 0.78 / 0.83 / 0.88 / 0.93 of a step -> 4.71 / 4.66 / 4.65 / 4.82 / 5.26 ms), but at
     // most 160 K vertices = 2.5 MiB of table, which still sits in an XCD's 4 MiB L2 while its 32 CUs sweep it
-    const double per_slice = (double)range_nnz / slices;
     const double fill = gnnvc::compact_step() * 5.0 / 6.0;
-    uint32_t bc = gnnvc::compact_block(), nblocks = 0;
-    if (!mapped) {
+    uint32_t chunks = 0, rows = 0, slice_rows = 0, slices = 0, bc = gnnvc::compact_block(), nblocks = 0;
+    gnnvc::PlanMap pm;
+    if (mapped) {
+        SkewedLayout L;
+        HIP_TRY(e, e->c4_stepcnt.reserve(1));
+        int rc = layout_skewed_plan(e, 0, max_rows, nsl, fill, 160u * 1024u, 1u, e->c4_rowmap, e->c4_first, e->c4_bstart, e->c4_stepcnt, L);
+        if (rc) return rc;
+        if (L.plan_rows == 0) return GNNVC_OK;
+        plan_rows = L.plan_rows;
+        range_nnz = L.entries;
+        chunks = L.chunks;
+        rows = L.rows;
+        slice_rows = L.slice_rows;
+        slices = L.slices;
+        nblocks = L.nblocks;
+        pm = L.pm;
+        bc = 160u * 1024u;   // (the widest a block may be: what the entry encoding has to hold)
+    } else {
+        chunks = (plan_rows + max_rows - 1) / max_rows;
+        chunks = (chunks + 255u) / 256u * 256u;
+        rows = (plan_rows + chunks - 1) / chunks;
+        rows = (rows + nsl - 1) / nsl * nsl;
+        chunks = (plan_rows + rows - 1) / rows;
+        slice_rows = rows / nsl;
+        slices = chunks * nsl;
+        HIP_TRY(e, e->pin_small.reserve((size_t)slices + 4100));
+        if (span != g.n) {   // the range's share of the entries (on a slice g.nnz counts the slice's entries only)
+            uint32_t rp[2] = {0, 0};
+            HIP_TRY(e, hipMemcpyAsync(&rp[0], g.rowptr + base, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(e, hipMemcpyAsync(&rp[1], g.rowptr + end, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(e, hipStreamSynchronize(e->stream));
+            range_nnz = rp[1] - rp[0];
+            if (range_nnz == 0) return GNNVC_OK;
+        }
+        const double per_slice = (double)range_nnz / slices;
         const double want = fill * g.n / std::max(per_slice, 1.0);
         bc = (uint32_t)std::min(160.0 * 1024, std::max(32.0 * 1024, want)) / 1024u * 1024u;
         nblocks = (g.n + bc - 1) / bc;
-    } else {
-        // blocks of equal entry mass: on a symmetric adjacency the entries that point INTO columns [a, b) are as many as
-        // the entries of rows [a, b), so the cuts are read off rowptr (for any other adjacency they are a heuristic —
-        // nothing but the step fill depends on them).  Widths between 256 columns and 160 K.
-        const uint32_t maxw = 160u * 1024u, minw = 256u;
-        const double nb_want = std::max(1.0, per_slice / fill);
-        const unsigned long long target = (unsigned long long)std::max(1.0, (double)g.nnz / nb_want);
-        const uint32_t ncand = (uint32_t)std::min<unsigned long long>(g.nnz / target + 2, 4096);
-        HIP_TRY(e, e->c4_bstart.reserve(4100));
-        HIP_TRY(e, gnnvc::mass_bounds(g, target, ncand, e->c4_bstart.p, e->stream));
-        HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, e->c4_bstart.p, ncand * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
-        std::vector<uint32_t> bs{0u};
-        auto cut = [&](uint32_t at) {
-            while (at - bs.back() > maxw) bs.push_back(bs.back() + maxw);
-            if (at > bs.back()) bs.push_back(at);
-        };
-        for (uint32_t k = 1; k < ncand; ++k) {
-            const uint32_t at = std::min(e->pin_small.p[k], g.n);
-            if (at >= g.n) break;
-            if (at - bs.back() >= minw) cut(at);
-        }
-        if (g.n - bs.back() < minw && bs.size() > 1) bs.pop_back();   // no sliver at the end
-        cut(g.n);                                                      // bs.back() == g.n: the end of the last block
-        nblocks = (uint32_t)bs.size() - 1;
-        if (nblocks == 0 || nblocks > 4096) return GNNVC_OK;
-        std::memcpy(e->pin_small.p, bs.data(), bs.size() * sizeof(uint32_t));
-        HIP_TRY(e, hipMemcpyAsync(e->c4_bstart.p, e->pin_small.p, bs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
-        pm.bstart = e->c4_bstart.p;
-        bc = maxw;   // (the widest a block may be: what the entry encoding has to hold)
     }
     if (nblocks > 4096) return GNNVC_OK;
     // every (slice, block) segment starts at a multiple of 4 entries: up to 3 pad entries per segment
@@ -1117,13 +1220,16 @@ int choose_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const flo
             int rc = build_lds_table(e);
             if (rc) return rc;
         }
-        const bool lt_fits = e->lt_ready && hi > lo && ((hi - 1) / e->lt_rows - lo / e->lt_rows + 1) >= 192u;
+        // (a skewed graph's plan sums all of its rows at once: whole-graph calls only)
+        const bool lt_fits = e->lt_ready && hi > lo &&
+                             (e->lt_mapped ? (lo == 0 && hi == e->g.n) : ((hi - 1) / e->lt_rows - lo / e->lt_rows + 1) >= 192u);
         if (e->graph_uses >= 1 && !lt_fits && !e->blocked_tried) {
             int rc = build_blocked(e);
             if (rc) return rc;
         }
         ++e->graph_uses;
         c.sums = lt_fits ? StageChoice::kLdsTable : (e->blocked_ready ? StageChoice::kBlocked : StageChoice::kGather);
+        if (lt_fits && e->lt_mapped) c.long_thresh = e->lt_plan_thresh;   // the plan holds every row below the giant ones
         c.emit = may_emit;
         if (c.sums != StageChoice::kGather) return GNNVC_OK;   // (those two bring their own tile order)
     } else if (sp.f == 16) {
@@ -1192,7 +1298,7 @@ int launch_side_rows(gnnvc_engine *e, const GraphDev &gv, int stage, uint32_t lo
                                              e->opt_hub_mode == 1, s_giant));
         if (side) HIP_TRY(e, hipEventRecord(e->ev_giant, e->giant_stream));
     }
-    if (e->n_giant < e->n_long)
+    if (e->n_giant < e->n_long && thr < e->giant_thresh)   // (thr == the giant threshold: a plan has every row in between)
         HIP_TRY(e, gnnvc::launch_long_stage(e->stages[stage], gv, e->ws, e->params.p, in, out, logits, lo, hi,
                                             e->long_list.p, e->n_long, thr, e->giant_thresh, s_long));
     if (side) HIP_TRY(e, hipEventRecord(e->ev_join, e->aux_stream));
@@ -1220,8 +1326,9 @@ int launch_main(gnnvc_engine *e, const StageChoice &c, const GraphDev &gv, const
     if (c.sums == StageChoice::kLdsTable)
         return hip_rc(e, gnnvc::launch_stage0_lds_table(sp, e->g, e->ws, e->params.p, in, out, lo, hi, e->lt_rows, e->lt_stepptr.p,
                                                         e->lt_steps.p, e->lt_entries.p, e->lt_bytes.p, e->blk_acc.p, e->lt_bad.p,
-                                                        e->long_thresh, e->opt_mfma == 1, e->interleave, e->stream, emit,
-                                                        e->lt_last_entry));
+                                                        c.long_thresh, e->opt_mfma == 1, e->interleave, e->stream, emit,
+                                                        e->lt_last_entry, e->lt_mapped ? e->lt_rowmap.p : nullptr,
+                                                        e->lt_mapped ? e->lt_chunks : 0u));
     if (c.sums == StageChoice::kBlocked)
         return hip_rc(e, gnnvc::launch_stage0_blocked(sp, e->g, e->ws, e->params.p, in, out, lo, hi, e->blk_count, e->blk_ptr.p,
                                                       e->blk_col.p, e->blk_acc.p, e->long_thresh, e->opt_mfma == 1, e->interleave,
@@ -1439,9 +1546,9 @@ void gnnvc_destroy(gnnvc_engine *e) {
     e->blk_ptr.release(); e->blk_col.release(); e->blk_scratch.release(); e->blk_flag.release();
     e->blk_acc.release();
     e->lt_bytes.release(); e->lt_entries.release(); e->lt_segcnt.release(); e->lt_stepptr.release();
-    e->lt_stepcnt.release(); e->lt_bad.release(); e->lt_steps.release();
+    e->lt_stepcnt.release(); e->lt_bad.release(); e->lt_steps.release(); e->lt_rowmap.release(); e->lt_first.release(); e->lt_bstart.release();
     e->c4_entries.release(); e->c4_segcnt.release(); e->c4_stepptr.release(); e->c4_stepcnt.release();
-    e->c4_desc.release(); e->c4_rowmap.release(); e->c4_first.release(); e->c4_bstart.release(); e->c4_map_vertex.release(); e->c4_map_meta.release(); e->c4_steps.release(); e->c4_table.release(); e->c4_marks.release(); e->c4_acc.release(); e->c4_counts.release();
+    e->c4_desc.release(); e->c4_rowmap.release(); e->c4_first.release(); e->c4_bstart.release(); e->c4_map_vertex.release(); e->c4_map_meta.release(); e->map_coarse.release(); e->c4_steps.release(); e->c4_table.release(); e->c4_marks.release(); e->c4_acc.release(); e->c4_counts.release();
     e->c4_agg16.release(); e->c4_dirty.release(); e->c4_emit_counts.release();
     for (auto &pp : e->prune) { pp.prp.release(); pp.pcol.release(); pp.heavy.release(); pp.svertex.release(); pp.smeta.release(); }
     e->prune_flags.release(); e->prune_scratch.release(); e->prune_off.release(); e->prune_mask.release();
@@ -1500,6 +1607,8 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "prune_min_drop_percent") e->opt_prune_min_drop = value < 0 ? 0u : (value > 100 ? 100u : (uint32_t)value);
     else if (k == "compact_skewed") { e->opt_compact_skewed = value != 0 ? 1 : 0; e->c4_tried = false; e->c4_ready = false; }
     else if (k == "compact_passes") { e->opt_compact_passes = value < 1 ? 1u : (value > 3 ? 3u : (uint32_t)value); e->c4_tried = false; e->c4_ready = false; }
+    else if (k == "lds_table_skewed") e->opt_lds_skewed = value != 0 ? 1 : 0;
+    else if (k == "lds_table_skewed_rows") e->opt_lds_skewed_rows = value > 0 ? (uint32_t)value : 0u;
     else if (k == "lds_table") e->opt_lds_table = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else if (k == "sorted_min_nnz") e->opt_sorted_min_nnz = value > 0 ? (uint64_t)value : 0;
     else if (k == "sorted_long_row_threshold") e->opt_sorted_long_thresh = value > 0 ? (uint32_t)value : 1;
@@ -1551,6 +1660,8 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
         }
     }
     else if (k == "lds_table_active") *value = e->lt_ready ? 1 : 0;
+    else if (k == "lds_table_mapped") *value = e->lt_ready && e->lt_mapped ? 1 : 0;
+    else if (k == "lds_table_blocks") *value = e->lt_ready ? (long)e->lt_blocks : 0;
     else if (k == "lds_table_chunks") *value = e->lt_ready ? (long)e->lt_chunks : 0;
     else if (k == "lds_table_steps") *value = e->lt_ready ? (long)e->lt_steps_total : 0;
     else if (k == "blocked_stage0_active") *value = e->blocked_ready ? 1 : 0;

@@ -173,21 +173,22 @@ hipError_t launch_sgemm(int ta, int tb, uint32_t m, uint32_t n, uint32_t k, cons
 
 // LDS-table plan of the F = 1 stage (see the kernels): build steps, then the per-forward launch
 uint32_t lds_table_max_rows();
-uint32_t lds_table_block();
-uint32_t lds_table_step();
-uint32_t lds_table_record_words();
-// workgroup steps of the F = 1 plan: one record per (chunk, block, up to 256 entries per slice); a chunk = 16 slices
-hipError_t lds_table_wsteps(const GraphDev &g, uint32_t slice_rows, uint32_t nchunks, uint32_t nblocks, const uint32_t *seg_cnt,
-                            const uint32_t *step_ptr, uint32_t *step_count, uint32_t *recs, bool write, uint32_t slack,
-                            hipStream_t stream);
-hipError_t lds_table_bytes(const uint32_t *w, uint32_t n, uint8_t *wb, uint32_t *bad, hipStream_t stream);
 // A plan over rows that are not consecutive (skewed graphs, compact-table plan): chunk c holds the rows
 // rowmap[c * rows_per_chunk ..] (0xFFFFFFFF = empty slot), its regrouped entries start at first[c] (+ the padding
 // slack), and column blocks may have any widths: block b = columns [bstart[b], bstart[b + 1]).  All null (the
 // default): consecutive rows, CSR offsets, blocks of block_cols columns.
 struct PlanMap {
     const uint32_t *rowmap = nullptr, *first = nullptr, *bstart = nullptr;
+    const uint16_t *coarse = nullptr;   // with bstart: the block of column 256 k, for every k (a column's block is that one or, rarely, a later one)
 };
+uint32_t lds_table_block();
+uint32_t lds_table_step();
+uint32_t lds_table_record_words();
+// workgroup steps of the F = 1 plan: one record per (chunk, block, up to 256 entries per slice); a chunk = 16 slices
+hipError_t lds_table_wsteps(const GraphDev &g, uint32_t slice_rows, uint32_t nchunks, uint32_t nblocks, const uint32_t *seg_cnt,
+                            const uint32_t *step_ptr, uint32_t *step_count, uint32_t *recs, bool write, uint32_t slack,
+                            hipStream_t stream, const PlanMap &pm = PlanMap());
+hipError_t lds_table_bytes(const uint32_t *w, uint32_t n, uint8_t *wb, uint32_t *bad, hipStream_t stream);
 hipError_t lds_table_count(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t block_cols,
                            uint32_t *seg_cnt, uint32_t *bad, hipStream_t stream, uint32_t row_base = 0,
                            uint32_t row_end = 0xFFFFFFFFu, const PlanMap &pm = PlanMap());
@@ -225,7 +226,9 @@ hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float
                                    float *out, uint32_t row_lo, uint32_t row_hi, uint32_t rows_per_chunk,
                                    const uint32_t *step_ptr, const void *steps, const uint32_t *entries, const uint8_t *wbyte,
                                    float *acc, uint32_t *bad, uint32_t long_thresh, bool mfma, bool interleave,
-                                   hipStream_t stream, const EmitArgs &emit, uint32_t last_entry);
+                                   hipStream_t stream, const EmitArgs &emit, uint32_t last_entry,
+                                   const uint32_t *rowmap = nullptr /* skewed graphs: the plan's rows, slice by slice */,
+                                   uint32_t mapped_chunks = 0);
 
 // compact-table plan of the 16-wide stages (see the k_c4_* kernels); the step layout is built with the
 // lds_table_* functions per SLICE (rows_per_chunk / compact_slices() rows), compact_step() entries per step,

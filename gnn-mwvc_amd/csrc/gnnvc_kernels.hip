@@ -1380,6 +1380,11 @@ __device__ __forceinline__ uint32_t lt_row(const PlanMap &pm, uint32_t c, uint32
 // block of column `col`, searched from block `from` on (a row's columns ascend)
 __device__ __forceinline__ uint32_t lt_block(const PlanMap &pm, uint32_t col, uint32_t block_cols, uint32_t nblocks, uint32_t from) {
     if (!pm.bstart) return col / block_cols;
+    if (pm.coarse) {                                // the block of the column's 256-granule, then forward (blocks are >= 256 wide but for remainders)
+        uint32_t b = pm.coarse[col >> 8];
+        while (b + 1 < nblocks && col >= pm.bstart[b + 1]) ++b;
+        return b;
+    }
     if (col < pm.bstart[from]) from = 0;            // (unsorted row: found anyway, flagged by the caller)
     if (col < pm.bstart[from + 1]) return from;
     uint32_t lo = from + 1, hi = nblocks - 1;       // last block whose start is <= col
@@ -1560,12 +1565,13 @@ constexpr uint32_t kLtwRec = 36;
 __global__ __launch_bounds__(64) void k_ltw_steps(GraphDev g, uint32_t slice_rows, uint32_t nchunks, uint32_t nblocks,
                                                   const uint32_t *__restrict__ seg_cnt, const uint32_t *__restrict__ step_ptr,
                                                   uint32_t *__restrict__ step_count, uint32_t *__restrict__ recs, int write,
-                                                  uint32_t cap, uint32_t slack) {
+                                                  uint32_t cap, uint32_t slack, uint32_t block_cols, PlanMap pm) {
+    // record words [1] = the block's first column, [34] = the 16-byte piece of the byte table its last column sits in
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
     uint32_t first[16];
 #pragma unroll
-    for (uint32_t w = 0; w < 16; ++w) first[w] = lt_chunk_first(g, c * 16 + w, slice_rows, 0, g.n, slack);
+    for (uint32_t w = 0; w < 16; ++w) first[w] = lt_chunk_first(g, c * 16 + w, slice_rows, 0, g.n, slack, pm.first);
     const uint32_t pos = write ? step_ptr[c] : 0;
     uint32_t made = 0, last_block = 0;
     for (uint32_t b = 0; b < nblocks; ++b) {
@@ -1579,13 +1585,14 @@ __global__ __launch_bounds__(64) void k_ltw_steps(GraphDev g, uint32_t slice_row
             if (write) {
                 uint32_t *rec = recs + (size_t)(pos + made) * kLtwRec;
                 rec[0] = b;
-                rec[1] = 0;
+                rec[1] = lt_block_start(pm, b, block_cols);
 #pragma unroll
                 for (uint32_t w = 0; w < 16; ++w) {
                     rec[2 + w] = first[w] + t * cap;
                     rec[18 + w] = cnt[w] > t * cap ? min(cap, cnt[w] - t * cap) : 0u;
                 }
-                rec[34] = rec[35] = 0;
+                rec[34] = (min(lt_block_start(pm, b + 1, block_cols), g.n) + 15u) / 16u;
+                rec[35] = 0;
             }
             ++made;
             last_block = b;
@@ -1602,6 +1609,8 @@ __global__ __launch_bounds__(64) void k_ltw_steps(GraphDev g, uint32_t slice_row
             uint32_t *rec = recs + (size_t)(pos + made) * kLtwRec;
             for (uint32_t i = 0; i < kLtwRec; ++i) rec[i] = 0;
             rec[0] = last_block;
+            rec[1] = lt_block_start(pm, last_block, block_cols);
+            rec[34] = (min(lt_block_start(pm, last_block + 1, block_cols), g.n) + 15u) / 16u;
         }
     else
         step_count[c] = padded;
@@ -1627,7 +1636,10 @@ __device__ __forceinline__ float ltw_sel(bool c, float v) { return c ? v : 0.0f;
 __global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ step_ptr, const uint32_t *__restrict__ recs,
                                                  const uint32_t *__restrict__ entries, const uint8_t *__restrict__ wbyte, float ws,
                                                  float *__restrict__ agg, uint32_t n, uint32_t slice_rows, uint32_t chunk0,
-                                                 uint32_t last_entry, const uint32_t *__restrict__ bad) {
+                                                 uint32_t last_entry, const uint32_t *__restrict__ bad,
+                                                 const uint32_t *__restrict__ rowmap) {
+    // rowmap != nullptr (skewed graphs): slice s holds the rows rowmap[s * slice_rows ..] (0xFFFFFFFF = none), dealt from
+    // the degree-sorted list, and the column blocks have their own widths (record words 1 and 34)
     extern __shared__ __attribute__((aligned(16))) unsigned char lt_smem[];
     if (*bad) return;                                                   // block-uniform
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1652,7 +1664,9 @@ __global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ st
     }
     u32x4 sr[SW];
     // descriptor of the step whose entries are loaded next: block, this wave's first entry and count
-    uint32_t d_blk = recs[(size_t)st0 * kLtwRec], d_first = recs[(size_t)st0 * kLtwRec + 2 + wave], d_cnt = recs[(size_t)st0 * kLtwRec + 18 + wave];
+    uint32_t d_blk = recs[(size_t)st0 * kLtwRec + 1] / 16u, d_first = recs[(size_t)st0 * kLtwRec + 2 + wave], d_cnt = recs[(size_t)st0 * kLtwRec + 18 + wave];
+    uint32_t d_end = recs[(size_t)st0 * kLtwRec + 34];   // (d_blk: the first 16-byte piece of the block's bytes, d_end: its last)
+    uint32_t be[4] = {0, 0, 0, 0};
     int d_step = 0;
     for (int u = -4; u < nsteps; u += 4) {
 #pragma unroll
@@ -1663,6 +1677,7 @@ __global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ st
                 const int slot = (j + 2) & 3;
                 const bool on = se >= 0 && se < nsteps && d_step == se;
                 bk[slot] = d_blk;
+                be[slot] = d_end;
                 cnt[slot] = on ? d_cnt : 0u;
                 const uint32_t x = d_first + 4u * lane;                  // first is a multiple of 4
                 const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(entries + (x < last_entry ? x : last_entry)));
@@ -1670,17 +1685,18 @@ __global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ st
                 const int nx = se + 1;
                 const uint32_t nxc = (uint32_t)(nx < 0 ? 0 : (nx < nsteps ? nx : nsteps - 1));
                 const uint32_t *rec = recs + (size_t)(st0 + nxc) * kLtwRec;
-                d_blk = rec[0];              // (wave-uniform values, left in vector registers: nothing waits for
+                d_blk = rec[1] / 16u;        // (wave-uniform values, left in vector registers: nothing waits for
                 d_first = rec[2 + wave];     //  them before the next trip)
                 d_cnt = rec[18 + wave];
+                d_end = rec[34];
                 d_step = nx;
             }
             {   // the byte slice of step s + 1's block, into registers
-                const uint32_t b = bk[(j + 1) & 3];
+                const uint32_t b = bk[(j + 1) & 3], pe = min(be[(j + 1) & 3], last_piece);
 #pragma unroll
                 for (int k = 0; k < SW; ++k) {
-                    uint32_t piece = b * (kLtwBlock / 16) + tid + 1024u * k;
-                    piece = piece < last_piece ? piece : last_piece;
+                    uint32_t piece = b + tid + 1024u * k;    // (pieces past the block's end are never looked at: one clamped address)
+                    piece = piece < pe ? piece : pe;
                     sr[k] = reinterpret_cast<const u32x4 *>(wbyte)[piece];
                 }
             }
@@ -1750,7 +1766,10 @@ __global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ st
             __syncthreads();                 // the slice of step s + 1 is in place
         }
     }
-    for (uint32_t i = lane; i < slice_rows && row0 + i < n; i += 64) agg[row0 + i] = A[i];
+    for (uint32_t i = lane; i < slice_rows; i += 64) {
+        const uint32_t row = rowmap ? rowmap[(size_t)(chunk * 16 + wave) * slice_rows + i] : row0 + i;
+        if (row < n) agg[row] = A[i];
+    }
 }
 
 // ---- compact-table plan of the 16-wide stages ---------------------------------------------------
@@ -2289,7 +2308,14 @@ __global__ __launch_bounds__(256) void k_tile_waste(GraphDev g, uint32_t row_lo,
     }
 }
 
-// histogram of min(degree, bins - 1) over the non-long rows of [row_lo, row_hi)
+// Degree class of a row in the sorted lists: the degree itself below 2048, eight degrees to a class above (so that
+// thresholds of up to 16 K fit the kernels' 4096 LDS counters; the order inside a class is free)
+__device__ __forceinline__ uint32_t deg_class(uint32_t d, uint32_t bins) {
+    const uint32_t c = d < 2048u ? d : 2048u + ((d - 2048u) >> 3);
+    return c < bins ? c : bins - 1;
+}
+
+// histogram of the degree classes over the non-long rows of [row_lo, row_hi)
 __global__ __launch_bounds__(256) void k_deg_hist(GraphDev g, uint32_t row_lo, uint32_t row_hi, uint32_t long_thresh,
                                                   uint32_t bins, uint32_t *__restrict__ hist, const uint32_t *__restrict__ skip_rowptr,
                                                   uint32_t skip_from) {
@@ -2299,7 +2325,7 @@ __global__ __launch_bounds__(256) void k_deg_hist(GraphDev g, uint32_t row_lo, u
     for (uint32_t u = row_lo + blockIdx.x * blockDim.x + threadIdx.x; u < row_hi; u += gridDim.x * blockDim.x) {
         const uint32_t d = g.rowptr[u + 1] - g.rowptr[u];
         if (skip_rowptr && skip_rowptr[u + 1] - skip_rowptr[u] >= skip_from) continue;
-        if (d < long_thresh) atomicAdd(&local[d < bins ? d : bins - 1], 1u);
+        if (d < long_thresh) atomicAdd(&local[deg_class(d, bins)], 1u);
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < bins; i += blockDim.x)
@@ -2325,7 +2351,7 @@ __global__ __launch_bounds__(256) void k_deg_scatter(GraphDev g, uint32_t row_lo
         const uint32_t d = re - rs;
         const bool skip = skip_rowptr && skip_rowptr[u + 1] - skip_rowptr[u] >= skip_from;
         if (d < long_thresh && !skip) {
-            cls = d < bins ? d : bins - 1;
+            cls = deg_class(d, bins);
             rank_in_block = atomicAdd(&local[cls], 1u);
         }
     }
@@ -3170,10 +3196,10 @@ uint32_t lds_table_record_words() { return kLtwRec; }
 
 hipError_t lds_table_wsteps(const GraphDev &g, uint32_t slice_rows, uint32_t nchunks, uint32_t nblocks, const uint32_t *seg_cnt,
                             const uint32_t *step_ptr, uint32_t *step_count, uint32_t *recs, bool write, uint32_t slack,
-                            hipStream_t stream) {
+                            hipStream_t stream, const PlanMap &pm) {
     if (slack < 3u * nblocks + 4u) return hipErrorInvalidValue;
     GNNVC_LAUNCH(k_ltw_steps, dim3((nchunks + 63) / 64), dim3(64), 0, stream, g, slice_rows, nchunks, nblocks, seg_cnt,
-                       step_ptr, step_count, recs, write ? 1 : 0, kLtwStep, slack);
+                       step_ptr, step_count, recs, write ? 1 : 0, kLtwStep, slack, kLtwBlock, pm);
     return hipGetLastError();
 }
 
@@ -3284,8 +3310,10 @@ hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float
                                    float *out, uint32_t row_lo, uint32_t row_hi, uint32_t rows_per_chunk,
                                    const uint32_t *step_ptr, const void *steps, const uint32_t *entries, const uint8_t *wbyte,
                                    float *acc, uint32_t *bad, uint32_t long_thresh, bool mfma, bool interleave,
-                                   hipStream_t stream, const EmitArgs &emit, uint32_t last_entry) {
+                                   hipStream_t stream, const EmitArgs &emit, uint32_t last_entry, const uint32_t *rowmap,
+                                   uint32_t mapped_chunks) {
     if (row_hi <= row_lo) return hipSuccess;
+    if (rowmap && (row_lo != 0 || row_hi != g.n || mapped_chunks == 0)) return hipErrorInvalidValue;   // (a mapped plan sums all of its rows)
     if (sp.variant != 0 || rows_per_chunk == 0 || rows_per_chunk > 16u * kLtwSliceRows || rows_per_chunk % 16u || g.nnz == 0)
         return hipErrorInvalidValue;
     // does this forward's input match the table?  decided on the device: no host round trip
@@ -3293,7 +3321,7 @@ hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float
     if (rc != hipSuccess) return rc;
     GNNVC_LAUNCH(k_lt_check_x, dim3(std::min<unsigned>((g.n + 255) / 256, 4096u)), dim3(256), 0, stream, x, g.w, ws, g.n,
                        bad);
-    const uint32_t c0 = row_lo / rows_per_chunk, c1 = (row_hi - 1) / rows_per_chunk;
+    const uint32_t c0 = rowmap ? 0u : row_lo / rows_per_chunk, c1 = rowmap ? mapped_chunks - 1 : (row_hi - 1) / rows_per_chunk;
     const uint32_t slice_rows = rows_per_chunk / 16u;
     constexpr size_t lds_max = (size_t)16 * kLtwSliceRows * 4 + 1024 + kLtwBlock;
     static_assert(lds_max <= 160 * 1024, "LDS budget of k_lt_agg");
@@ -3302,7 +3330,7 @@ hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float
     rc = allow_dynamic_lds(reinterpret_cast<const void *>(k_lt_agg), (int)lds_max, lds_ok);
     if (rc != hipSuccess) return rc;
     GNNVC_LAUNCH(k_lt_agg, dim3(c1 - c0 + 1), dim3(1024), lds, stream, step_ptr, reinterpret_cast<const uint32_t *>(steps),
-                       entries, wbyte, ws, acc, g.n, slice_rows, c0, last_entry, bad);
+                       entries, wbyte, ws, acc, g.n, slice_rows, c0, last_entry, bad, rowmap);
     const uint32_t ntiles = (row_hi - row_lo + kWave - 1) / kWave;
     const uint32_t per_xcd = (ntiles + 7) / 8;
     const uint32_t blocks_per_xcd = (per_xcd + kWavesPerBlock - 1) / kWavesPerBlock;

@@ -158,9 +158,10 @@ def test_deterministic_and_plan_invariant(big):
                 e2.forward_device(big["x"].data_ptr(), sc.data_ptr(), lg.data_ptr())
                 e2.synchronize()
                 assert torch.equal(lg.view(torch.int32), ref_lg.view(torch.int32)), opts
-            if big["name"] == "er10m":      # the plan the options ask for really ran (long rows rule the LDS table out)
-                want_lt = 1 if (opts.get("lds_table", 1) and "long_row_threshold" not in opts) else 0
+            if big["name"] == "er10m":      # the plan the options ask for really ran (with long rows: the LDS table's skewed-graph layout)
+                want_lt = 1 if opts.get("lds_table", 1) else 0
                 assert e2.get_info("lds_table_active") == want_lt, opts
+                assert e2.get_info("lds_table_mapped") == (1 if "long_row_threshold" in opts else 0), opts
                 if opts.get("blocked_stage0") == 2:
                     assert e2.get_info("blocked_stage0_active") == 1, opts
                 want_c4 = 1 if (opts.get("compact_gather", 1) and "long_row_threshold" not in opts) else 0

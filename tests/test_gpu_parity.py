@@ -559,6 +559,7 @@ def test_lds_table_plan_steps_aside(model_text, oracle_model):
         unsorted = gg.CsrGraph(g7.n, g7.rowptr, col, g7.w, g7.nw)
         hubs = gg.hub_graph(20000, 60000, 3, 4096, seed=7)
         for gr in (big_w, unsorted, hubs):
+            e.set_option("lds_table_skewed", 0)         # (the skewed-graph layout has its own test below)
             e.set_weight_scale(gr.ws)
             oracle_model.set_weight_scale(gr.ws)
             e.upload_graph(gr)
@@ -566,6 +567,61 @@ def test_lds_table_plan_steps_aside(model_text, oracle_model):
             _, logits = e.forward(gr.x())
             assert e.get_info("lds_table_active") == 0
             assert np.array_equal(bits(logits[:, 0]), bits(oracle_model.logits(gr)))
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("maker,giant", [
+    (lambda: gg.rmat(14, 8, 3), 4096),
+    (lambda: gg.rmat(14, 8, 3), 0),                                          # no giant rows: k_long_f1 keeps what the plan leaves
+    (lambda: gg.hub_graph(30000, 200000, 3, 6000, seed=9), 4096),            # giant rows beside the plan
+    (lambda: gg.chung_lu_hubs(40000, 8.0, 2.2, 2, 3000, seed=4), 2048),
+    (lambda: gg.hub_graph(200000, 900000, 4, 30000, seed=3), 16384),         # several column blocks, rows of 30 000 entries in the plan's neighbourhood
+])
+def test_lds_table_plan_on_skewed_graphs(model_text, oracle_model, maker, giant):
+    """The LDS-table plan of the F = 1 stage with the skewed-graph layout: every row below the giant-row threshold dealt
+    from the degree-sorted list to slices of equal weight, column blocks of equal entry mass; giant rows beside it.
+    Same bits as the oracle — also for inputs that are not W / ws (the device-side check) and for row sub-ranges."""
+    import torch
+    import gnn_mwvc_amd as G
+    g = maker()
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_option("blocked_min_n", 0)
+        e.set_option("blocked_stage0", 0)
+        e.set_option("long_row_threshold", 256)
+        e.set_option("giant_row_threshold", giant)
+        e.set_weight_scale(g.ws)
+        oracle_model.set_weight_scale(g.ws)
+        e.upload_graph(g)
+        want = oracle_model.logits(g)
+        for rep in range(3):
+            _, logits = e.forward(g.x())
+            assert np.array_equal(bits(logits[:, 0]), bits(want)), rep
+            assert e.get_info("lds_table_active") == (1 if rep else 0)
+        assert e.get_info("lds_table_mapped") == 1
+        assert e.get_info("lds_table_steps") >= 4 * e.get_info("lds_table_chunks")
+        dev = torch.device("cuda:0")
+        x = torch.from_numpy(g.x()).to(dev)
+        h1 = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+        want_h1 = oracle_model.predict(g, g.x(), stop_after=6)
+        torch.cuda.synchronize()
+        e.stage_forward_device(0, 0, g.n, x.data_ptr(), h1.data_ptr())      # the whole range: the plan
+        e.synchronize()
+        assert np.array_equal(bits(h1[:-1].cpu().numpy()), bits(want_h1))
+        h1.fill_(7.0)
+        torch.cuda.synchronize()
+        mid = (g.n // 3) // 64 * 64
+        for lo, hi in ((mid, g.n), (0, mid)):                              # sub-ranges: the gathering kernels
+            e.stage_forward_device(0, lo, hi, x.data_ptr(), h1.data_ptr())
+        e.synchronize()
+        assert np.array_equal(bits(h1[:-1].cpu().numpy()), bits(want_h1))
+        rng = np.random.default_rng(5)
+        x2 = rng.uniform(0.1, 1.0, size=(g.n, 1)).astype(np.float32)        # not W / ws: the check sends every row down the plain gather
+        _, lg2 = e.forward(x2)
+        assert np.array_equal(bits(lg2[:, 0]), bits(oracle_model.predict(g, x2, stop_after=oracle_model.n_layers - 2)[:, 0]))
+        _, back = e.forward(g.x())
+        assert np.array_equal(bits(back[:, 0]), bits(want))
     finally:
         e.close()
 
