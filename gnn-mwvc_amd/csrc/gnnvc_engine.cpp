@@ -244,7 +244,10 @@ struct gnnvc_engine {
     uint64_t giant_entries = 0;
     DevBuf<uint4> gi_meta;
     DevBuf<unsigned long long> gi_off;
-    DevBuf<float> gi_slab, gi_agg;
+    DevBuf<float> gi_slab, gi_agg, gi_segsum;   // (segsum / segmap: one stream on several waves, see k_giant_segmap)
+    DevBuf<uint4> gi_segmap;
+    uint32_t gi_maxseg = 0;
+    int opt_giant_segments = -1;  // option "giant_segments": 1 = a stream on several waves, 0 = one wave walks it, -1 = by the graph (default)
 
     std::string err;
 };
@@ -462,6 +465,19 @@ int find_giant(gnnvc_engine *e) {
     HIP_TRY(e, e->gi_off.reserve(cnt));
     HIP_TRY(e, e->gi_slab.reserve(floats));
     HIP_TRY(e, e->gi_agg.reserve((size_t)cnt * 16));
+    e->gi_maxseg = gnnvc::giant_segments(meta[0].z);   // (the list is sorted: its first row is the longest)
+    // One stream on several waves pays when the longest stream's walk (~2 ns per addend) is what a stage waits for — the
+    // power-law graph: 0.39 ms against ~0.15 ms of gathering, forward 1.56 -> 1.16 ms.  Where the stage is busy gathering
+    // anyway (R-MAT-22: 0.32 ms of walk inside a 1.2 ms stage) the extra kernels of the high-priority stream only take
+    // slots from the tile kernel: 2.98 -> 3.16 ms.  Auto: on when the walk exceeds half of nnz / 50 G entries per second.
+    bool segments = e->opt_giant_segments > 0;
+    if (e->opt_giant_segments < 0) segments = (double)meta[0].z * 2.0e-9 > 0.5 * (double)e->g.nnz / 50.0e9;
+    if (segments && e->gi_maxseg > 1 && (uint64_t)cnt * 16 * e->gi_maxseg < (1ull << 31)) {
+        HIP_TRY(e, e->gi_segsum.reserve((size_t)cnt * 16 * e->gi_maxseg));
+        HIP_TRY(e, e->gi_segmap.reserve((size_t)cnt * 16 * e->gi_maxseg));
+    } else {
+        e->gi_maxseg = 0;
+    }
     HIP_TRY(e, hipMemcpy(e->gi_meta.p, meta.data(), ((size_t)cnt + 1) * sizeof(uint4), hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(e->gi_off.p, off.data(), (size_t)cnt * sizeof(unsigned long long), hipMemcpyHostToDevice));
     if (!e->giant_stream) {
@@ -1294,6 +1310,11 @@ int launch_side_rows(gnnvc_engine *e, const GraphDev &gv, int stage, uint32_t lo
         gr.off = e->gi_off.p;
         gr.slab = e->gi_slab.p;
         gr.agg = e->gi_agg.p;
+        if (e->gi_maxseg > 1) {
+            gr.segsum = e->gi_segsum.p;
+            gr.segmap = e->gi_segmap.p;
+            gr.maxseg = e->gi_maxseg;
+        }
         HIP_TRY(e, gnnvc::launch_giant_stage(e->stages[stage], e->opt_prune_giant ? gv : e->g, e->ws, e->params.p, in, out, logits, lo, hi, gr,
                                              e->opt_hub_mode == 1, s_giant));
         if (side) HIP_TRY(e, hipEventRecord(e->ev_giant, e->giant_stream));
@@ -1553,7 +1574,7 @@ void gnnvc_destroy(gnnvc_engine *e) {
     for (auto &pp : e->prune) { pp.prp.release(); pp.pcol.release(); pp.heavy.release(); pp.svertex.release(); pp.smeta.release(); }
     e->prune_flags.release(); e->prune_scratch.release(); e->prune_off.release(); e->prune_mask.release();
     e->long_list.release(); e->long_count.release();
-    e->gi_meta.release(); e->gi_off.release(); e->gi_slab.release(); e->gi_agg.release();
+    e->gi_meta.release(); e->gi_off.release(); e->gi_slab.release(); e->gi_agg.release(); e->gi_segsum.release(); e->gi_segmap.release();
     e->rowptr2.release(); e->col2.release(); e->der_old_row.release(); e->der_new_of.release(); e->der_tail.release();
     e->der_tailptr.release(); e->der_tailcols.release(); e->hash_buf.release();
     e->pin_rowptr.release(); e->pin_col.release(); e->pin_w.release(); e->pin_nw.release();
@@ -1595,6 +1616,7 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "long_row_threshold") e->opt_long_thresh = value > 0 ? (uint32_t)value : 0;
     else if (k == "giant_row_threshold") e->opt_giant_thresh = value > 0 ? (uint32_t)std::max<long>(value, 64) : 0;
     else if (k == "hub_mode") e->opt_hub_mode = value == 1 ? 1 : 0;
+    else if (k == "giant_segments") e->opt_giant_segments = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "side_streams") e->opt_side_streams = value != 0 ? 1 : 0;
     else if (k == "kernel_trace") e->opt_ktrace = value != 0 ? 1 : 0;
     else if (k == "compact_gather") e->opt_compact = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
@@ -1672,6 +1694,7 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
     else if (k == "slice_rows") *value = e->empty_slice ? 0 : (long)(e->g.hi() - e->g.lo());
     else if (k == "slice_entries") *value = (long)e->g.nnz;
     else if (k == "giant_rows") *value = (long)e->n_giant;
+    else if (k == "giant_segments") *value = e->n_giant ? (long)e->gi_maxseg : 0;
     else if (k == "giant_entries") *value = (long)e->giant_entries;
     else if (k == "giant_row_threshold") *value = e->n_giant ? (long)e->giant_thresh : 0;
     else if (k == "hub_mode") *value = e->opt_hub_mode;
@@ -2382,7 +2405,7 @@ int gnnvc_stream_sum(gnnvc_engine *e, const float *values, uint32_t streams, uin
     if (!e) return GNNVC_ERR_INVALID;
     if (!streams) return GNNVC_OK;
     if (!sums || (len && !values)) return fail(e, GNNVC_ERR_INVALID, "null host buffers");
-    if (mode != 0 && mode != 1) return fail(e, GNNVC_ERR_INVALID, "mode %d (0 = exact, 1 = fast)", mode);
+    if (mode < 0 || mode > 2) return fail(e, GNNVC_ERR_INVALID, "mode %d (0 = exact, 1 = fast, 2 = exact on one wave per stream)", mode);
     if (len == 0) {
         for (uint32_t i = 0; i < streams; ++i) sums[i] = 0.0f;
         return GNNVC_OK;
@@ -2391,10 +2414,13 @@ int gnnvc_stream_sum(gnnvc_engine *e, const float *values, uint32_t streams, uin
     if (rc) return rc;
     const uint32_t win = gnnvc::giant_window();
     const size_t lpad = ((size_t)len + win - 1) / win * win;
-    DevBuf<float> slab, agg;
-    DevBuf<uint4> meta;
+    DevBuf<float> slab, agg, segsum;
+    DevBuf<uint4> meta, segmap;
     DevBuf<unsigned long long> off;
+    const size_t segs = (size_t)streams * gnnvc::giant_segments(len);
     hipError_t h = slab.reserve(lpad * streams);
+    if (h == hipSuccess && mode == 0) h = segsum.reserve(segs);
+    if (h == hipSuccess && mode == 0) h = segmap.reserve(segs);
     if (h == hipSuccess) h = agg.reserve((size_t)streams * 16);
     if (h == hipSuccess) h = meta.reserve((size_t)streams + 1);
     if (h == hipSuccess) h = off.reserve(streams);
@@ -2402,11 +2428,11 @@ int gnnvc_stream_sum(gnnvc_engine *e, const float *values, uint32_t streams, uin
     if (h == hipSuccess)
         h = hipMemcpy2DAsync(slab.p, lpad * sizeof(float), values, (size_t)len * sizeof(float), (size_t)len * sizeof(float), streams,
                              hipMemcpyHostToDevice, e->stream);
-    if (h == hipSuccess) h = gnnvc::stream_sums(slab.p, streams, len, meta.p, off.p, agg.p, mode == 1, e->stream);
+    if (h == hipSuccess) h = gnnvc::stream_sums(slab.p, streams, len, meta.p, off.p, agg.p, mode, e->stream, segsum.p, segmap.p);
     std::vector<float> host((size_t)streams * 16);
     if (h == hipSuccess) h = hipMemcpyAsync(host.data(), agg.p, host.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream);
     if (h == hipSuccess) h = hipStreamSynchronize(e->stream);
-    slab.release(); agg.release(); meta.release(); off.release();
+    slab.release(); agg.release(); meta.release(); off.release(); segsum.release(); segmap.release();
     if (h != hipSuccess) return fail(e, h == hipErrorOutOfMemory ? GNNVC_ERR_NOMEM : GNNVC_ERR_DEVICE, "stream sum: %s", hipGetErrorString(h));
     for (uint32_t i = 0; i < streams; ++i) sums[i] = host[(size_t)i * 16];
     return GNNVC_OK;

@@ -136,7 +136,12 @@ struct GiantRows {
     const void *meta = nullptr;
     const unsigned long long *off = nullptr;
     float *slab = nullptr, *agg = nullptr;
+    // one stream on several waves (k_giant_segsum / k_giant_segmap): n x F x maxseg floats / uint4; null or maxseg <= 1: one wave per stream
+    float *segsum = nullptr;
+    void *segmap = nullptr;
+    uint32_t maxseg = 0;
 };
+uint32_t giant_segments(uint32_t len);
 uint32_t giant_window();
 uint32_t giant_block();
 hipError_t find_giant_rows(const GraphDev &g, const uint32_t *list, uint32_t n_long, uint32_t thresh, void *meta, uint32_t *count,
@@ -144,7 +149,8 @@ hipError_t find_giant_rows(const GraphDev &g, const uint32_t *list, uint32_t n_l
 hipError_t launch_giant_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *in, float *out,
                               float *logits, uint32_t row_lo, uint32_t row_hi, const GiantRows &gr, bool fast, hipStream_t stream);
 hipError_t stream_sums(const float *streams_dev, uint32_t streams, uint32_t len, void *meta, unsigned long long *off, float *agg,
-                       bool fast, hipStream_t stream);
+                       int mode /* 0 exact on several waves, 1 fast, 2 exact on one wave */, hipStream_t stream, float *segsum = nullptr,
+                       void *segmap = nullptr);
 
 // Column-blocked F = 1 stage (bit-identical to launch_stage on stage 0; see the kernels).
 // bp: uint32[nblocks * n + 1] block-major entry pointers, colb: uint32[nnz + pad] re-bucketed

@@ -1188,11 +1188,106 @@ __device__ __forceinline__ void giant_window(const f32x4 (&d)[kGiantB / 4], int 
     }
 }
 
+// One stream on several waves.  The parity maps compose across waves as they do across lanes, given the accumulator's
+// binade at the start of each piece.  Segments of kGiantSeg windows:
+//   k_giant_segsum   a plain float sum per segment (any order): enough to ESTIMATE the running sum in front of a segment
+//   k_giant_segmap   per segment k >= 1: the binade E of that estimate and the segment's composed map relative to E
+//   k_giant_sum      walks the segments in order with the EXACT accumulator: where it sits in the segment's binade E and
+//                    m + D[m & 1] < 2^24 (addends are >= 0 — a negative or non-finite one marks the segment — so no carry at
+//                    the end means none inside), the segment is one step; otherwise (estimate off by a binade, the sum
+//                    crosses into the next one — about log2(length) times per stream — or a marked segment) its windows are
+//                    walked as before.  The result never depends on the estimate, only the time does (host emulation with
+//                    estimates that are right, one off and random: tests/test_exact_sum_host.py).
+constexpr uint32_t kGiantSeg = 4;   // windows per segment: 4096 addends
+
+__global__ __launch_bounds__(64) void k_giant_segsum(const float *__restrict__ slab, const uint4 *__restrict__ meta,
+                                                     const unsigned long long *__restrict__ off, uint32_t F, uint32_t maxseg,
+                                                     float *__restrict__ segsum, uint32_t row_lo, uint32_t row_hi,
+                                                     const uint32_t *__restrict__ prp, const uint32_t *__restrict__ prune_bad) {
+    const uint32_t st = blockIdx.x / maxseg, sg = blockIdx.x % maxseg, i = st / F, c = st % F;
+    const uint4 mt = meta[i];
+    if (mt.x < row_lo || mt.x >= row_hi) return;
+    const int lane = threadIdx.x;
+    const bool pruned = prune_bad != nullptr && *prune_bad == 0u;
+    const uint32_t len = pruned ? prp[mt.x + 1] - prp[mt.x] : mt.z;
+    const uint32_t lpad = (len + kGiantWin - 1) / kGiantWin * kGiantWin, nwin = lpad / kGiantWin;
+    const uint32_t w0 = sg * kGiantSeg, w1 = min(nwin, w0 + kGiantSeg);
+    if (w0 >= nwin) return;
+    const f32x4 *__restrict__ src = reinterpret_cast<const f32x4 *>(slab + off[i] + (size_t)c * lpad) + lane * (kGiantB / 4);
+    float part = 0.0f;
+    for (uint32_t w = w0; w < w1; ++w) {   // (the streams are padded with zeros up to lpad)
+#pragma unroll
+        for (int k = 0; k < kGiantB / 4; ++k) {
+            const f32x4 q = src[(size_t)w * (kGiantWin / 4) + k];
+            part += (q[0] + q[1]) + (q[2] + q[3]);
+        }
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) part += __shfl_xor(part, s);
+    if (lane == 0) segsum[(size_t)st * maxseg + sg] = part;
+}
+
+__global__ __launch_bounds__(64) void k_giant_segmap(const float *__restrict__ slab, const uint4 *__restrict__ meta,
+                                                     const unsigned long long *__restrict__ off, uint32_t F, uint32_t maxseg,
+                                                     const float *__restrict__ segsum, uint4 *__restrict__ segmap, uint32_t row_lo,
+                                                     uint32_t row_hi, const uint32_t *__restrict__ prp,
+                                                     const uint32_t *__restrict__ prune_bad) {
+    const uint32_t st = blockIdx.x / maxseg, sg = blockIdx.x % maxseg, i = st / F, c = st % F;
+    if (sg == 0) return;                                  // (the first segment is always walked: nothing in front of it to estimate)
+    const uint4 mt = meta[i];
+    if (mt.x < row_lo || mt.x >= row_hi) return;
+    const int lane = threadIdx.x;
+    const bool pruned = prune_bad != nullptr && *prune_bad == 0u;
+    const uint32_t len = pruned ? prp[mt.x + 1] - prp[mt.x] : mt.z;
+    const uint32_t lpad = (len + kGiantWin - 1) / kGiantWin * kGiantWin, nwin = lpad / kGiantWin;
+    const uint32_t w0 = sg * kGiantSeg, w1 = min(nwin, w0 + kGiantSeg);
+    if (w0 >= nwin) return;
+    // the running sum in front of the segment, to a few parts in 10^5: its binade
+    float pre = 0.0f;
+    for (uint32_t j = lane; j < sg; j += 64) pre += segsum[(size_t)st * maxseg + j];
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) pre += __shfl_xor(pre, s);
+    const uint32_t pb = __float_as_uint(pre), pe = (pb >> 23) & 0xFFu;
+    const uint32_t E = pe ? pe : 1u;
+    bool bad = (pb >> 31) != 0u || pe == 255u;            // (then no accumulator will match: the segment is walked)
+    const f32x4 *__restrict__ src = reinterpret_cast<const f32x4 *>(slab + off[i] + (size_t)c * lpad) + lane * (kGiantB / 4);
+    xsum::Map total = {0u, 0u};
+    for (uint32_t w = w0; w < w1; ++w) {
+        f32x4 d[kGiantB / 4];
+#pragma unroll
+        for (int k = 0; k < kGiantB / 4; ++k) d[k] = src[(size_t)w * (kGiantWin / 4) + k];
+        const long long left = (long long)len - (long long)w * kGiantWin - (long long)lane * kGiantB;
+        const int hi = left <= 0 ? 0 : (left >= kGiantB ? kGiantB : (int)left);
+        xsum::Map run = {0u, 0u};
+#pragma unroll
+        for (int t = 0; t < kGiantB; ++t) {
+            const uint32_t vb = t < hi ? __float_as_uint(d[t >> 2][t & 3]) : 0u;
+            xsum::append<true>(run, vb, E, bad);
+        }
+        xsum::saturate(run);
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {                // inclusive scan of the lanes' maps (earlier lanes first)
+            xsum::Map a;
+            a.d0 = __shfl_up(run.d0, s);
+            a.d1 = __shfl_up(run.d1, s);
+            const xsum::Map cmb = xsum::compose(a, run);
+            if (lane >= s) run = cmb;
+        }
+        xsum::Map wt;
+        wt.d0 = __builtin_amdgcn_readlane(run.d0, 63);
+        wt.d1 = __builtin_amdgcn_readlane(run.d1, 63);
+        total = xsum::compose(total, wt);
+    }
+    const bool any_bad = __ballot(bad) != 0ull;
+    if (lane == 0) segmap[(size_t)st * maxseg + sg] = make_uint4(E, total.d0, total.d1, any_bad ? 1u : 0u);
+}
+
 template <bool FAST>
 __global__ __launch_bounds__(64) void k_giant_sum(const float *__restrict__ slab, const uint4 *__restrict__ meta,
                                                   const unsigned long long *__restrict__ off, uint32_t F, float *__restrict__ agg,
                                                   uint32_t row_lo, uint32_t row_hi, const uint32_t *__restrict__ prp,
-                                                  const uint32_t *__restrict__ prune_bad) {
+                                                  const uint32_t *__restrict__ prune_bad, const uint4 *__restrict__ segmap,
+                                                  uint32_t maxseg) {
     const uint32_t i = blockIdx.x / F, c = blockIdx.x % F;
     const uint4 mt = meta[i];
     if (mt.x < row_lo || mt.x >= row_hi) return;
@@ -1222,14 +1317,30 @@ __global__ __launch_bounds__(64) void k_giant_sum(const float *__restrict__ slab
         giant_window<FAST>(buf[slot_], lane, hi_, acc, part);                              \
     }
     float acc = 0.0f, part = 0.0f;
+    const bool segmented = !FAST && segmap != nullptr;
+    const uint32_t segw = segmented ? kGiantSeg : nwin;      // (no maps: the whole stream is one walk)
+    for (uint32_t w0 = 0, sg = 0; w0 < nwin; w0 += segw, ++sg) {
+        const uint32_t w1 = min(nwin, w0 + segw);
+        if (segmented && sg > 0) {   // the segment in one step, if its map was made for the binade the accumulator is in
+            const uint4 mp = segmap[(size_t)blockIdx.x * maxseg + sg];
+            uint32_t E = 0, m = 0;
+            if (mp.w == 0u && xsum::decode_acc(__float_as_uint(acc), E, m) && E == mp.x) {
+                const uint32_t D = (m & 1u) ? mp.z : mp.y;
+                if (m + D < xsum::kCarry) {
+                    acc = __uint_as_float(xsum::encode_acc(E, m + D));
+                    continue;
+                }
+            }
+        }
 #pragma unroll
-    for (int s = 0; s < kGiantRing - 1; ++s) GNNVC_GIANT_LOAD(s, (uint32_t)s)
-    for (uint32_t w = 0; w < nwin; w += kGiantRing) {
+        for (int s = 0; s < kGiantRing - 1; ++s) GNNVC_GIANT_LOAD(s, w0 + (uint32_t)s)
+        for (uint32_t w = w0; w < w1; w += kGiantRing) {
 #pragma unroll
-        for (int j = 0; j < kGiantRing; ++j) {
-            if (w + j >= nwin) break;
-            GNNVC_GIANT_LOAD((j + kGiantRing - 1) % kGiantRing, w + j + kGiantRing - 1)
-            GNNVC_GIANT_USE(j, w + j)
+            for (int j = 0; j < kGiantRing; ++j) {
+                if (w + j >= w1) break;
+                GNNVC_GIANT_LOAD((j + kGiantRing - 1) % kGiantRing, w + j + kGiantRing - 1)
+                GNNVC_GIANT_USE(j, w + j)
+            }
         }
     }
 #undef GNNVC_GIANT_LOAD
@@ -3517,10 +3628,20 @@ hipError_t launch_giant_stage(const StagePlan &sp, const GraphDev &g, float ws, 
         GNNVC_LAUNCH(k_giant_gather1, dim3(gr.blocks), dim3(256), 0, stream, g, in, gr.slab, meta, gr.off, gr.n, row_lo, row_hi);
     else
         return hipErrorInvalidValue;
-    if (fast)
-        GNNVC_LAUNCH(k_giant_sum<true>, dim3(gr.n * F), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.agg, row_lo, row_hi, pr, pb);
-    else
-        GNNVC_LAUNCH(k_giant_sum<false>, dim3(gr.n * F), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.agg, row_lo, row_hi, pr, pb);
+    if (fast) {
+        GNNVC_LAUNCH(k_giant_sum<true>, dim3(gr.n * F), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.agg, row_lo, row_hi, pr, pb,
+                     (const uint4 *)nullptr, 0u);
+    } else {
+        const bool seg = gr.segsum && gr.segmap && gr.maxseg > 1;   // one stream on several waves (see k_giant_segmap)
+        if (seg) {
+            GNNVC_LAUNCH(k_giant_segsum, dim3(gr.n * F * gr.maxseg), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.maxseg, gr.segsum,
+                         row_lo, row_hi, pr, pb);
+            GNNVC_LAUNCH(k_giant_segmap, dim3(gr.n * F * gr.maxseg), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.maxseg, gr.segsum,
+                         reinterpret_cast<uint4 *>(gr.segmap), row_lo, row_hi, pr, pb);
+        }
+        GNNVC_LAUNCH(k_giant_sum<false>, dim3(gr.n * F), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.agg, row_lo, row_hi, pr, pb,
+                     seg ? reinterpret_cast<const uint4 *>(gr.segmap) : nullptr, gr.maxseg);
+    }
     const float *P = params + sp.param_offset;
     const dim3 grid((gr.n + 63) / 64), block(64);
     switch (sp.variant) {
@@ -3534,16 +3655,33 @@ hipError_t launch_giant_stage(const StagePlan &sp, const GraphDev &g, float ws, 
 
 // sums[i] = the sequential fp32 sum of streams[i * lpad .. + len) (lpad = len rounded up to giant_window()); meta needs
 // streams + 1 entries, off streams entries
+uint32_t giant_segments(uint32_t len) {   // segments of a stream of `len` addends
+    const uint32_t nwin = (len + kGiantWin - 1) / kGiantWin;
+    return (nwin + kGiantSeg - 1) / kGiantSeg;
+}
+
+// mode: 0 = exact, the stream on several waves (segsum / segmap: streams x giant_segments(len) floats / uint4, may be null:
+// then as mode 2), 1 = fast (tolerance), 2 = exact, one wave walks the whole stream
 hipError_t stream_sums(const float *streams_dev, uint32_t streams, uint32_t len, void *meta, unsigned long long *off, float *agg,
-                       bool fast, hipStream_t stream) {
+                       int mode, hipStream_t stream, float *segsum, void *segmap) {
     if (!streams) return hipSuccess;
     GNNVC_LAUNCH(k_stream_meta, dim3((streams + 256) / 256), dim3(256), 0, stream, reinterpret_cast<uint4 *>(meta), off, streams, len);
-    if (fast)
-        GNNVC_LAUNCH(k_giant_sum<true>, dim3(streams), dim3(64), 0, stream, streams_dev, reinterpret_cast<const uint4 *>(meta), off,
-                           1u, agg, 0u, 1u, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
-    else
-        GNNVC_LAUNCH(k_giant_sum<false>, dim3(streams), dim3(64), 0, stream, streams_dev, reinterpret_cast<const uint4 *>(meta), off,
-                           1u, agg, 0u, 1u, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+    const uint4 *mt = reinterpret_cast<const uint4 *>(meta);
+    const uint32_t *none = nullptr;
+    if (mode == 1) {
+        GNNVC_LAUNCH(k_giant_sum<true>, dim3(streams), dim3(64), 0, stream, streams_dev, mt, off, 1u, agg, 0u, 1u, none, none,
+                     (const uint4 *)nullptr, 0u);
+        return hipGetLastError();
+    }
+    const uint32_t maxseg = giant_segments(len);
+    const bool seg = mode == 0 && segsum && segmap && maxseg > 1;
+    if (seg) {
+        GNNVC_LAUNCH(k_giant_segsum, dim3(streams * maxseg), dim3(64), 0, stream, streams_dev, mt, off, 1u, maxseg, segsum, 0u, 1u, none, none);
+        GNNVC_LAUNCH(k_giant_segmap, dim3(streams * maxseg), dim3(64), 0, stream, streams_dev, mt, off, 1u, maxseg, segsum,
+                     reinterpret_cast<uint4 *>(segmap), 0u, 1u, none, none);
+    }
+    GNNVC_LAUNCH(k_giant_sum<false>, dim3(streams), dim3(64), 0, stream, streams_dev, mt, off, 1u, agg, 0u, 1u, none, none,
+                 seg ? reinterpret_cast<const uint4 *>(segmap) : nullptr, maxseg);
     return hipGetLastError();
 }
 

@@ -91,6 +91,9 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *                         their neighbour values are gathered by every CU into per-column streams and each stream's
  *                         sequential fp32 sum is evaluated with a parallel scan that reproduces the chain's
  *                         roundings (csrc/exact_sum.h); bit-identical results
+ *   "giant_segments" -1|0|1  1 = a giant row's streams are cut into segments of 4096 addends summarised by many waves
+ *                         at once (k_giant_segmap) and joined by one walk; 0 = one wave walks each stream; -1 (default) =
+ *                         segments where the longest stream's walk would be what a stage waits for.  Same bits
  *   "side_streams"   0|1  1 (default) = long / giant rows on side streams beside the tile kernel; 0 = on the main
  *                         stream, one after the other (profiling: standalone kernel times)
  *   "kernel_trace"   0|1  HIP events around every main-stream kernel of a forward (gnnvc_kernel_trace)
@@ -337,7 +340,10 @@ int gnnvc_sigmoid_forward(gnnvc_engine *e, size_t count, const float *in, float 
  * sums[i] = (((0 + v[i][0]) + v[i][1]) + ...) + v[i][len-1], one rounded fp32 add per element, for `streams`
  * rows of `len` floats (host pointers, row-major).  mode 0 evaluates that chain with the engine's parallel
  * giant-row kernels and returns its exact bits whatever the data holds; mode 1 is the tolerance mode (tree
- * sums: a few ulp off).  The layer-level handle on the path rows of degree >= "giant_row_threshold" take. */
+ * sums: a few ulp off).  The layer-level handle on the path rows of degree >= "giant_row_threshold" take.
+ * mode 0 runs a stream on several waves (segments of 4096 addends, each with its own parity map relative to an estimated
+ * binade, used by the final walk only where the exact accumulator confirms it); mode 2 is the same result with one wave
+ * walking the whole stream ("giant_segments" 0 for the engine's own rows). */
 int gnnvc_stream_sum(gnnvc_engine *e, const float *values, uint32_t streams, uint32_t len, int mode, float *sums);
 
 /* dot() (reference src/matrix.cpp:106-122, the cblas_sgemm seam):

@@ -25,12 +25,23 @@ def xs():
     L.xsum_stream.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
     L.xsum_sequential.restype = C.c_float
     L.xsum_sequential.argtypes = [C.c_void_p, C.c_size_t]
+    L.xsum_stream_segmented.restype = C.c_float
+    L.xsum_stream_segmented.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p]
     return L
 
 
 def _check(L, v, B=16, want_fast=None):
     _check1(L, v, B, want_fast)
     _check1(L, v, -B, want_fast)     # the floating-point decode of the addends
+    # the segmented evaluation (one stream on several waves): whatever binade a segment's map was built for — the estimate
+    # the kernels use, one above, one below, a pseudo-random one — the result is the chain's
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    want = np.float32(L.xsum_sequential(v.ctypes.data, v.size))
+    for seg_windows, guess in ((4, 0), (4, 1), (4, 2), (4, 4), (1, 0), (7, 0)):
+        st = np.zeros(3, dtype=np.uint64)
+        got = np.float32(L.xsum_stream_segmented(v.ctypes.data, v.size, -B, seg_windows, guess, st.ctypes.data))
+        assert got.view(np.uint32) == want.view(np.uint32) or (np.isnan(got) and np.isnan(want)), \
+            f"segmented ({seg_windows} windows, guess {guess}): {got!r} != {want!r}, n={v.size}, stats={st}"
 
 
 def _check1(L, v, B, want_fast):
@@ -132,3 +143,18 @@ def test_random_bit_patterns(xs):
         bits = rng.integers(0, 1 << 31, n).astype(np.uint32)          # non-negative floats of any exponent
         bits[(bits >> 23) == 255] &= 0x7F000000                       # keep them finite
         _check(xs, bits.view(np.float32), B=int(rng.choice([4, 8, 16])))
+
+
+def test_segments_are_taken_in_one_step(xs):
+    """On streams like the kernels see (non-negative activations, 200 K addends) nearly every segment after the first few is
+    applied as ONE map: the binade estimate from the float sums is right and the segment does not carry."""
+    rng = np.random.default_rng(7)
+    n = 200_000
+    v = rng.gamma(2.0, 0.7, n).astype(np.float32)
+    v[rng.random(n) < 0.4] = 0.0
+    st = np.zeros(3, dtype=np.uint64)
+    got = np.float32(xs.xsum_stream_segmented(v.ctypes.data, v.size, -16, 4, 0, st.ctypes.data))
+    assert got.view(np.uint32) == np.float32(xs.xsum_sequential(v.ctypes.data, v.size)).view(np.uint32)
+    nseg = (n + 4095) // 4096
+    assert st[1] >= nseg - 8, (st, nseg)       # all but a handful (the first, and those where the sum crosses a binade)
+    assert st[0] <= 8 * 4 + 16                 # ... so the window walk did little

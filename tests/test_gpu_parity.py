@@ -1114,15 +1114,18 @@ def test_stream_sum_entry_point_is_the_sequential_chain(engine):
     bitsr = rng.integers(0, 1 << 31, n).astype(np.uint32); bitsr[(bitsr >> 23) == 255] &= 0x7F000000
     streams.append(bitsr.view(np.float32))
     V = np.stack(streams)
-    got = engine.stream_sum(V)
     with np.errstate(all="ignore"):
         want = np.array([_seq_sum(r) for r in V], dtype=np.float32)
-    same = (bits(got) == bits(want)) | (np.isnan(got) & np.isnan(want))
-    assert same.all(), f"streams {np.nonzero(~same)[0].tolist()} differ: {got[~same]} vs {want[~same]}"
-    # ragged lengths around the window size (1024 addends) and the lane size (16)
-    for ln in (1, 15, 16, 17, 1023, 1024, 1025, 2048, 5000):
+    for mode in (0, 2):     # a stream on several waves (segments of 4096 addends with their own parity maps) / on one wave
+        got = engine.stream_sum(V, mode=mode)
+        same = (bits(got) == bits(want)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), f"mode {mode}: streams {np.nonzero(~same)[0].tolist()} differ: {got[~same]} vs {want[~same]}"
+    # ragged lengths around the window size (1024 addends), the segment size (4096) and the lane size (16)
+    for ln in (1, 15, 16, 17, 1023, 1024, 1025, 2048, 4095, 4096, 4097, 5000, 8192, 8193, 12289, 300_000):
         r = rng.gamma(2.0, 0.7, (3, ln)).astype(np.float32)
-        assert np.array_equal(bits(engine.stream_sum(r)), bits(np.array([_seq_sum(x) for x in r], dtype=np.float32))), ln
+        ws = bits(np.array([_seq_sum(x) for x in r], dtype=np.float32))
+        assert np.array_equal(bits(engine.stream_sum(r)), ws), ln
+        assert np.array_equal(bits(engine.stream_sum(r, mode=2)), ws), ln
     assert engine.stream_sum(np.zeros((2, 0), dtype=np.float32)).tolist() == [0.0, 0.0]
     # the tolerance mode is close, not equal
     fast = engine.stream_sum(V[:2], mode=1)
@@ -1144,12 +1147,15 @@ def test_giant_row_path_is_bit_identical(model_text, oracle_model, giant, long_t
                   gg.hub_graph(30000, 40000, 2, 20000, seed=8),
                   gg.from_edge_list(700, [(0, i) for i in range(1, 700)] + [(1, i) for i in range(2, 300)],
                                     [20 + (i % 101) for i in range(700)])]
-        for g in graphs:
+        for g, segments in [(g, s) for g in graphs for s in (0, 1)]:   # one wave per stream / a stream on several waves
+            e.set_option("giant_segments", segments)
             e.set_weight_scale(g.ws)
             oracle_model.set_weight_scale(g.ws)
             e.upload_graph(g)
             deg = np.diff(g.rowptr.astype(np.int64))
             assert e.get_info("giant_rows") == int((deg >= max(giant, long_t)).sum())
+            if e.get_info("giant_rows"):
+                assert (e.get_info("giant_segments") > 1) == (segments == 1 and deg.max() > 4096)
             assert e.get_info("giant_entries") == int(deg[deg >= max(giant, long_t)].sum())
             scores, logits = e.forward(g.x())
             assert np.array_equal(bits(logits[:, 0]), bits(oracle_model.logits(g)))
