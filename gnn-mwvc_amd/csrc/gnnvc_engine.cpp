@@ -219,6 +219,7 @@ struct gnnvc_engine {
 
     // long rows (degree >= long_thresh): one workgroup each, on aux_stream beside the tile kernel
     uint32_t opt_long_thresh = 512;   // option "long_row_threshold" (0 = off)
+    bool opt_long_auto = true;        // no explicit threshold: 256 where few rows are that long, else 512
     uint32_t long_thresh = 0xFFFFFFFFu, n_long = 0;
     DevBuf<uint32_t> long_list, long_count;
     hipStream_t aux_stream = nullptr;
@@ -539,14 +540,29 @@ int find_long(gnnvc_engine *e) {
     // One list at the base threshold serves every stage.  With degree-sorted tiles the 16-wide
     // tile kernel copes with longer rows, so those stages send only rows >= thresh_f16 long
     // (the others return at once from the long kernel and sit in the sorted tile list instead).
-    const uint32_t thresh = e->opt_long_thresh;
+    uint32_t thresh = e->opt_long_thresh;
     e->thresh_f16 = 0xFFFFFFFFu;
     HIP_TRY(e, e->long_list.reserve(ghi - glo));
     HIP_TRY(e, e->long_count.reserve(1));
-    HIP_TRY(e, gnnvc::find_long_rows(g, thresh, e->long_list.p, e->long_count.p, e->stream));
     uint32_t cnt = 0;
-    HIP_TRY(e, hipMemcpyAsync(&cnt, e->long_count.p, sizeof cnt, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    bool few_long = false;
+    if (e->opt_long_auto) {
+        // A row of d entries holds its tile for d / 3 gather trips (~1.2 us each): with only a few thousand rows above 256 the
+        // graph's stages are as long as those tiles (power-law 1 M: 1.16 -> 1.03 ms with the threshold at 256), so they get
+        // workgroups of their own; where a hundred thousand rows sit there (R-MAT-22: 110 K) a workgroup each costs more than
+        // the tiles (6.2 vs 3.0 ms) and the threshold stays at 512.
+        HIP_TRY(e, gnnvc::find_long_rows(g, 256u, e->long_list.p, e->long_count.p, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(&cnt, e->long_count.p, sizeof cnt, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        if (cnt == 0) return GNNVC_OK;   // (no row of 256 entries: none of 512 either)
+        few_long = cnt <= 16384u && (uint64_t)cnt * 64 <= (uint64_t)(ghi - glo);   // (few, and the exception among the rows: not a dense graph)
+        if (few_long) thresh = 256u;
+    }
+    if (!few_long) {
+        HIP_TRY(e, gnnvc::find_long_rows(g, thresh, e->long_list.p, e->long_count.p, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(&cnt, e->long_count.p, sizeof cnt, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+    }
     if (cnt == 0) return GNNVC_OK;   // nothing long: the tile kernels keep every row
     if (!e->aux_stream) {
         HIP_TRY(e, hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking));
@@ -555,7 +571,7 @@ int find_long(gnnvc_engine *e) {
     }
     e->n_long = cnt;
     e->long_thresh = thresh;
-    e->thresh_f16 = e->sorted_wanted ? std::max(thresh, e->opt_sorted_long_thresh) : thresh;
+    e->thresh_f16 = (e->sorted_wanted && !few_long) ? std::max(thresh, e->opt_sorted_long_thresh) : thresh;
     return find_giant(e);
 }
 
@@ -1613,7 +1629,7 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "blocked_min_n") e->opt_blocked_min_n = value > 0 ? (uint32_t)value : 0;
     else if (k == "plan_chunk_rows") e->opt_plan_chunk_rows = value > 0 ? (uint32_t)value : 0;
     else if (k == "overlap_dense") e->opt_overlap = value != 0 ? 1 : 0;
-    else if (k == "long_row_threshold") e->opt_long_thresh = value > 0 ? (uint32_t)value : 0;
+    else if (k == "long_row_threshold") { e->opt_long_thresh = value > 0 ? (uint32_t)value : 0; e->opt_long_auto = false; }
     else if (k == "giant_row_threshold") e->opt_giant_thresh = value > 0 ? (uint32_t)std::max<long>(value, 64) : 0;
     else if (k == "hub_mode") e->opt_hub_mode = value == 1 ? 1 : 0;
     else if (k == "giant_segments") e->opt_giant_segments = value < 0 ? -1 : (value ? 1 : 0);
@@ -1633,7 +1649,7 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "lds_table_skewed_rows") e->opt_lds_skewed_rows = value > 0 ? (uint32_t)value : 0u;
     else if (k == "lds_table") e->opt_lds_table = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else if (k == "sorted_min_nnz") e->opt_sorted_min_nnz = value > 0 ? (uint64_t)value : 0;
-    else if (k == "sorted_long_row_threshold") e->opt_sorted_long_thresh = value > 0 ? (uint32_t)value : 1;
+    else if (k == "sorted_long_row_threshold") { e->opt_sorted_long_thresh = value > 0 ? (uint32_t)value : 1; e->opt_long_auto = false; }
     else if (k == "mfma_dense") e->opt_mfma = (value >= 0 && value <= 2) ? (int)value : 2;
     else if (k == "sorted_tiles") { e->opt_sorted = value < 0 ? -1 : (value ? 1 : 0); for (auto &r : e->srt) r.valid = false; }
     else return fail(e, GNNVC_ERR_INVALID, "unknown option '%s'", key);
