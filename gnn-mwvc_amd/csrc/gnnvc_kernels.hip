@@ -1512,20 +1512,45 @@ __device__ __forceinline__ uint32_t lt_block_start(const PlanMap &pm, uint32_t b
 
 // entries of chunk `c` per column block -> seg_cnt[c * nblocks + b]; bad |= 2 if a row's blocks are
 // not ascending (unsorted adjacency: the plan would change the order of its sum)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// whole-wave shifts by one lane (DPP wave_shl / wave_shr, zero shifted in)
+__device__ __forceinline__ uint32_t lane_next(uint32_t x) {   // lane i <- lane i + 1
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t lane_prev(uint32_t x) {   // lane i <- lane i - 1
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xF, 0xF, true);
+}
+__device__ __forceinline__ float lane_next(float v) { return __uint_as_float(lane_next(__float_as_uint(v))); }
+
+constexpr uint32_t kLtLongRow = 128;    // plan builders: rows of at least this many entries are walked by a whole wave
+constexpr uint32_t kLtLongCap = 1280;   // >= the rows of a slice (kLtwSliceRows, kC4SliceRows)
+__device__ __forceinline__ unsigned long long lanes_upto(uint32_t lane) {   // bits 0 .. lane
+    return lane >= 63u ? ~0ull : ((1ull << (lane + 1u)) - 1ull);
+}
+
 __global__ __launch_bounds__(1024) void k_lt_count(GraphDev g, uint32_t rows_per_chunk, uint32_t nblocks, uint32_t block_cols,
                                                    uint32_t *__restrict__ seg_cnt, uint32_t *bad, uint32_t row_base,
                                                    uint32_t row_end, PlanMap pm) {
     __shared__ uint32_t hist[4096];
-    const uint32_t c = blockIdx.x, tid = threadIdx.x;
+    __shared__ uint32_t longrow[kLtLongCap];
+    __shared__ uint32_t nlong;
+    const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (uint32_t i = tid; i < nblocks; i += 1024) hist[i] = 0;
+    if (tid == 0) nlong = 0;
     __syncthreads();
     const uint32_t r0 = min(row_end, row_base + c * rows_per_chunk), r1 = pm.rowmap ? r0 + rows_per_chunk : min(row_end, r0 + rows_per_chunk);
     bool unsorted = false;
-    for (uint32_t i = tid; i < r1 - r0; i += 1024) {
+    for (uint32_t i = tid; i < r1 - r0; i += 1024) {   // short rows: a thread each; long ones are listed for the waves
         const uint32_t u = lt_row(pm, c, rows_per_chunk, r0, i);
         if (u >= row_end) continue;
+        const uint32_t rs = g.rowptr[u], re = g.rowptr[u + 1];
+        if (re - rs >= kLtLongRow && i < kLtLongCap) {
+            longrow[atomicAdd(&nlong, 1u)] = u;
+            continue;
+        }
         uint32_t prev = 0, run = 0;
-        for (uint32_t e = g.rowptr[u]; e < g.rowptr[u + 1]; ++e) {
+        for (uint32_t e = rs; e < re; ++e) {
             const uint32_t b = lt_block(pm, g.col[e], block_cols, nblocks, prev);
             if (run && b != prev) {
                 atomicAdd(&hist[prev], run);
@@ -1536,6 +1561,29 @@ __global__ __launch_bounds__(1024) void k_lt_count(GraphDev g, uint32_t rows_per
             ++run;
         }
         if (run) atomicAdd(&hist[prev], run);
+    }
+    __syncthreads();
+    for (uint32_t k = wave; k < nlong; k += 16) {      // a long row: 64 entries a trip, one LDS add per run of equal blocks
+        const uint32_t u = longrow[k];
+        const uint32_t rs = g.rowptr[u], re = g.rowptr[u + 1];
+        uint32_t carry = 0;                            // block of the previous trip's last entry (blocks must not descend)
+        for (uint32_t e0 = rs; e0 < re; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            const bool in = e < re;
+            const uint32_t b = in ? lt_block(pm, g.col[e], block_cols, nblocks, 0) : 0xFFFFFFFFu;
+            uint32_t bp = lane_prev(b);
+            if (lane == 0) bp = carry;
+            unsorted |= in && b < bp;
+            const bool head = in && (lane == 0 || b != bp);   // (a trip's first entry always starts a count of its own)
+            const unsigned long long hm = __ballot(head);
+            const uint32_t nin = (uint32_t)__popcll(__ballot(in));
+            if (head) {
+                const unsigned long long later = hm & ~lanes_upto(lane);
+                const uint32_t nh = later ? (uint32_t)__builtin_ctzll(later) : nin;
+                atomicAdd(&hist[b], nh - lane);
+            }
+            carry = __shfl(b, (int)(nin - 1u));
+        }
     }
     __syncthreads();
     for (uint32_t i = tid; i < nblocks; i += 1024) seg_cnt[(size_t)c * nblocks + i] = hist[i];
@@ -1590,7 +1638,9 @@ __global__ __launch_bounds__(1024) void k_lt_scatter(GraphDev g, uint32_t rows_p
                                                      uint32_t *__restrict__ entries, uint32_t row_base, uint32_t row_end,
                                                      uint32_t slack, PlanMap pm) {
     __shared__ uint32_t cursor[4096];
-    const uint32_t c = blockIdx.x, tid = threadIdx.x;
+    __shared__ uint32_t longrow[kLtLongCap];   // slot index in the slice
+    __shared__ uint32_t nlong;
+    const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t r0 = min(row_end, row_base + c * rows_per_chunk), r1 = pm.rowmap ? r0 + rows_per_chunk : min(row_end, r0 + rows_per_chunk);
     if (tid == 0) {   // exclusive scan of <= 4096 counts: a few microseconds, once per graph
         uint32_t run = lt_chunk_first(g, c, rows_per_chunk, row_base, row_end, slack, pm.first);
@@ -1599,14 +1649,19 @@ __global__ __launch_bounds__(1024) void k_lt_scatter(GraphDev g, uint32_t rows_p
             run += seg_cnt[(size_t)c * nblocks + b];
             if (slack) run = (run + 3u) & ~3u;
         }
+        nlong = 0;
     }
     __syncthreads();
-    for (uint32_t i = tid; i < r1 - r0; i += 1024) {
+    for (uint32_t i = tid; i < r1 - r0; i += 1024) {   // short rows: a thread each; long ones are listed for the waves
         const uint32_t u = lt_row(pm, c, rows_per_chunk, r0, i);
         if (u >= row_end) continue;
         const uint32_t rl = i << shift;
         uint32_t e = g.rowptr[u], b = 0;
         const uint32_t end = g.rowptr[u + 1];
+        if (end - e >= kLtLongRow && i < kLtLongCap) {
+            longrow[atomicAdd(&nlong, 1u)] = i;
+            continue;
+        }
         while (e < end) {
             b = lt_block(pm, g.col[e], block_cols, nblocks, b);
             uint32_t f = e + 1;
@@ -1614,6 +1669,57 @@ __global__ __launch_bounds__(1024) void k_lt_scatter(GraphDev g, uint32_t rows_p
             uint32_t pos = atomicAdd(&cursor[b], f - e);
             const uint32_t bs = lt_block_start(pm, b, block_cols);
             for (; e < f; ++e) entries[pos++] = rl | (g.col[e] - bs);
+        }
+    }
+    __syncthreads();
+    // A long row, 64 entries a trip.  A row's entries of one block must land as ONE adjacent run, in order: the lane at the
+    // head of a run reserves the whole run at once — for the trip's last run, which may go on, after counting how far it
+    // goes — and the trips that follow write the rest of that run behind what is already there.
+    for (uint32_t k = wave; k < nlong; k += 16) {
+        const uint32_t i = longrow[k], u = lt_row(pm, c, rows_per_chunk, r0, i), rl = i << shift;
+        const uint32_t rs = g.rowptr[u], re = g.rowptr[u + 1];
+        uint32_t cb = 0xFFFFFFFFu, pos_base = 0;      // the run open at the start of a trip: its block, where its next entry goes
+        for (uint32_t e0 = rs; e0 < re; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            const bool in = e < re;
+            const uint32_t col = in ? g.col[e] : 0u;
+            const uint32_t b = in ? lt_block(pm, col, block_cols, nblocks, 0) : 0xFFFFFFFEu;
+            uint32_t bp = lane_prev(b);
+            if (lane == 0) bp = cb;
+            const bool head = in && b != bp;
+            const unsigned long long hm = __ballot(head);
+            const uint32_t nin = (uint32_t)__popcll(__ballot(in));
+            const uint32_t first_head = hm ? (uint32_t)__builtin_ctzll(hm) : nin;   // lanes in front of it continue the open run
+            if (in && lane < first_head) entries[pos_base + lane] = rl | (col - lt_block_start(pm, cb, block_cols));
+            pos_base += first_head;
+            if (hm == 0ull) continue;                  // (uniform) the whole trip belonged to the open run
+            const uint32_t last_h = 63u - (uint32_t)__builtin_clzll(hm);
+            const unsigned long long mine = hm & lanes_upto(lane);
+            const uint32_t my_head = mine ? 63u - (uint32_t)__builtin_clzll(mine) : 0u;
+            uint32_t len = 0;
+            if (head) {
+                const unsigned long long later = hm & ~lanes_upto(lane);
+                len = (later ? (uint32_t)__builtin_ctzll(later) : nin) - lane;
+            }
+            uint32_t extra = 0;                        // entries of the last run beyond this trip
+            if (e0 + 64 < re) {
+                const uint32_t bo = __shfl(b, (int)last_h);
+                for (uint32_t f0 = e0 + 64; f0 < re; f0 += 64) {
+                    const uint32_t f = f0 + lane;
+                    const bool in2 = f < re;
+                    const bool same = in2 && lt_block(pm, g.col[in2 ? f : re - 1], block_cols, nblocks, 0) == bo;
+                    const unsigned long long sm = __ballot(same);
+                    const uint32_t lead = ~sm ? (uint32_t)__builtin_ctzll(~sm) : 64u;   // (blocks ascend: the same-block lanes are a prefix)
+                    extra += lead;
+                    if (lead < 64u) break;
+                }
+            }
+            uint32_t pos = 0;
+            if (head) pos = atomicAdd(&cursor[b], len + (lane == last_h ? extra : 0u));
+            const uint32_t p = __shfl(pos, (int)my_head);
+            if (in && lane >= first_head) entries[p + (lane - my_head)] = rl | (col - lt_block_start(pm, b, block_cols));
+            cb = __shfl(b, (int)last_h);
+            pos_base = __shfl(pos, (int)last_h) + __shfl(len, (int)last_h);
         }
     }
 }
@@ -1657,16 +1763,6 @@ __global__ __launch_bounds__(256) void k_mass_bounds(GraphDev g, unsigned long l
     cand[k] = lo;
 }
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-// whole-wave shifts by one lane (DPP wave_shl / wave_shr, zero shifted in)
-__device__ __forceinline__ uint32_t lane_next(uint32_t x) {   // lane i <- lane i + 1
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xF, 0xF, true);
-}
-__device__ __forceinline__ uint32_t lane_prev(uint32_t x) {   // lane i <- lane i - 1
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xF, 0xF, true);
-}
-__device__ __forceinline__ float lane_next(float v) { return __uint_as_float(lane_next(__float_as_uint(v))); }
 
 // Workgroup steps of the LDS-table plan.  A chunk = 16 slices of rows, one per wave; a step = one column block
 // (whose byte slice the workgroup stages in LDS) with up to 256 entries per slice.  Record (kLtwRec words):
