@@ -73,7 +73,8 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *   "lds_table"      0|1|2  LDS-table plan of the F = 1 stage: when every weight fits a byte and the
  *                         input is x[v] = (float)W(v)/ws (checked on the device at every forward), the
  *                         neighbour values are read from byte slices held in LDS instead of gathered from
- *                         memory (default 1 = large, non-skewed graphs; 2 = any large graph; 0 = off).
+ *                         memory (default 1 = large graphs, skewed ones in their own layout; 2 = the consecutive-row
+ *                         layout on any large graph; 0 = off).
  *                         Takes precedence over "blocked_stage0"; bit-identical results
  *   "compact_gather" 0|1|2  compact-table plan of the 16-wide stages: when at most four feature columns carry
  *                         (nearly) all non-zeros of a stage's input — decided on the device at every forward —
@@ -85,8 +86,13 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *                         stream, under the next round's sums (default 1; bit-identical either way)
  *   "plan_chunk_rows" n   cap on the rows per chunk of the LDS-table and compact-table plans (default 0 = what
  *                         fits LDS); smaller chunks mean more rounds of the persistent grids — a test hook
- *   "long_row_threshold" d  rows of degree >= d get a workgroup of their own (default 512,
- *                         0 = off); same CSR-order sums, bit-identical results
+ *   "long_row_threshold" d  rows of degree >= d get a workgroup of their own (0 = off); same CSR-order sums,
+ *                         bit-identical results.  Default: by the graph — 256 where at most 16 Ki rows (and one row in
+ *                         64) are that long, 512 otherwise; setting it (or "sorted_long_row_threshold") fixes it
+ *   "lds_table_skewed" 0|1, "lds_table_skewed_rows" d  the LDS-table plan on SKEWED graphs (default 1): rows below d
+ *                         entries dealt to slices of equal weight, column blocks of equal entry mass, giant rows (and
+ *                         the rows from d on) beside it; d = 0 (default): 2048 while x (4 N bytes) fits the L2s
+ *                         together, else everything below the giant rows.  Bit-identical
  *   "giant_row_threshold" d  long rows of degree >= d (default 16384, 0 = off) are summed by many waves at once:
  *                         their neighbour values are gathered by every CU into per-column streams and each stream's
  *                         sequential fp32 sum is evaluated with a parallel scan that reproduces the chain's
