@@ -242,6 +242,17 @@ struct gnnvc_engine {
     int opt_side_streams = 1;            // option "side_streams": 0 = long / giant rows on the main stream, one after the other (profiling)
     int opt_hub_mode = 0;                // option "hub_mode": 0 = exact (the chain's bits), 1 = fast (tree sums, tolerance mode)
     uint32_t giant_thresh = 0xFFFFFFFFu, n_giant = 0, giant_blocks = 0;
+    uint32_t opt_giant_f16 = 65536;     // option "giant_row_threshold_f16": the 16-wide stages send only rows from this degree on the giant way
+    bool giant_f16_auto = true, giant_walk_bound = false;   // (walk_bound: the longest stream's walk is what a stage waits for, find_giant)
+    uint32_t giant_f16() const {
+        if (!n_giant) return 0xFFFFFFFFu;
+        // by the graph: a 65 536-entry row's add chain in k_long_f16 is ~0.26 ms — lost in the stages of a graph with 64 M entries
+        // and more (R-MAT-22 2.98 -> 2.88 ms, R-MAT-24 12.6 -> 11.6 ms), what the stages of a smaller one would wait for (R-MAT-20
+        // 0.99 -> 1.05 ms, power-law 1.03 -> 1.30 ms)
+        if (opt_hub_mode == 1 || (giant_f16_auto && g.nnz < (64ull << 20))) return giant_thresh;
+        return std::max(giant_thresh, opt_giant_f16);
+    }   // (16 streams per row: three times a
+                                        // long row's traffic — worth it only for the rows whose add chain a stage would wait for)
     uint64_t giant_entries = 0;
     DevBuf<uint4> gi_meta;
     DevBuf<unsigned long long> gi_off;
@@ -471,8 +482,9 @@ int find_giant(gnnvc_engine *e) {
     // power-law graph: 0.39 ms against ~0.15 ms of gathering, forward 1.56 -> 1.16 ms.  Where the stage is busy gathering
     // anyway (R-MAT-22: 0.32 ms of walk inside a 1.2 ms stage) the extra kernels of the high-priority stream only take
     // slots from the tile kernel: 2.98 -> 3.16 ms.  Auto: on when the walk exceeds half of nnz / 50 G entries per second.
+    e->giant_walk_bound = (double)meta[0].z * 2.0e-9 > 0.5 * (double)e->g.nnz / 50.0e9;
     bool segments = e->opt_giant_segments > 0;
-    if (e->opt_giant_segments < 0) segments = (double)meta[0].z * 2.0e-9 > 0.5 * (double)e->g.nnz / 50.0e9;
+    if (e->opt_giant_segments < 0) segments = e->giant_walk_bound;
     if (segments && e->gi_maxseg > 1 && (uint64_t)cnt * 16 * e->gi_maxseg < (1ull << 31)) {
         HIP_TRY(e, e->gi_segsum.reserve((size_t)cnt * 16 * e->gi_maxseg));
         HIP_TRY(e, e->gi_segmap.reserve((size_t)cnt * 16 * e->gi_maxseg));
@@ -1154,7 +1166,7 @@ int build_prune_impl(gnnvc_engine *e, int stage, const float *in) {
         view.col = pp.pcol.p;
         uint32_t zero_rows = 0;
         int rc = sort_by_degree(e, g.lo(), g.hi(), pp.svertex, pp.smeta, pp.sn, zero_rows, &view, g.rowptr,
-                                e->n_giant ? e->giant_thresh : 0xFFFFFFFFu, pp.eff_thresh);
+                                e->giant_f16(), pp.eff_thresh);
         if (rc) return rc;
         pp.slist = true;
     }
@@ -1196,7 +1208,7 @@ int gather_view(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const floa
             so_p.vertex = pp.svertex.p;
             so_p.meta = pp.smeta.p;
         }
-        gv.eff_giant = e->n_giant ? e->giant_thresh : 0xFFFFFFFFu;
+        gv.eff_giant = e->giant_f16();
         gv.eff_thresh = pp.eff_thresh;
     }
     return GNNVC_OK;
@@ -1317,6 +1329,8 @@ int launch_side_rows(gnnvc_engine *e, const GraphDev &gv, int stage, uint32_t lo
         HIP_TRY(e, hipEventRecord(e->ev_fork, e->stream));
         HIP_TRY(e, hipStreamWaitEvent(e->aux_stream, e->ev_fork, 0));
     }
+    // rows from this degree on go the giant way in this stage (hub_mode 1: every long row does)
+    const uint32_t giant_from = e->stages[stage].f == 16 ? e->giant_f16() : e->giant_thresh;
     if (e->n_giant) {   // the heaviest rows: beside the tile kernel AND beside the other long rows
         if (side) HIP_TRY(e, hipStreamWaitEvent(e->giant_stream, e->ev_fork, 0));
         gnnvc::GiantRows gr;
@@ -1332,12 +1346,12 @@ int launch_side_rows(gnnvc_engine *e, const GraphDev &gv, int stage, uint32_t lo
             gr.maxseg = e->gi_maxseg;
         }
         HIP_TRY(e, gnnvc::launch_giant_stage(e->stages[stage], e->opt_prune_giant ? gv : e->g, e->ws, e->params.p, in, out, logits, lo, hi, gr,
-                                             e->opt_hub_mode == 1, s_giant));
+                                             e->opt_hub_mode == 1, s_giant, giant_from));
         if (side) HIP_TRY(e, hipEventRecord(e->ev_giant, e->giant_stream));
     }
-    if (e->n_giant < e->n_long && thr < e->giant_thresh)   // (thr == the giant threshold: a plan has every row in between)
+    if ((e->n_giant < e->n_long || giant_from > e->giant_thresh) && thr < giant_from)   // (thr == giant_from: a plan has every row in between)
         HIP_TRY(e, gnnvc::launch_long_stage(e->stages[stage], gv, e->ws, e->params.p, in, out, logits, lo, hi,
-                                            e->long_list.p, e->n_long, thr, e->giant_thresh, s_long));
+                                            e->long_list.p, e->n_long, thr, giant_from, s_long));
     if (side) HIP_TRY(e, hipEventRecord(e->ev_join, e->aux_stream));
     return GNNVC_OK;
 }
@@ -1630,8 +1644,13 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "plan_chunk_rows") e->opt_plan_chunk_rows = value > 0 ? (uint32_t)value : 0;
     else if (k == "overlap_dense") e->opt_overlap = value != 0 ? 1 : 0;
     else if (k == "long_row_threshold") { e->opt_long_thresh = value > 0 ? (uint32_t)value : 0; e->opt_long_auto = false; }
-    else if (k == "giant_row_threshold") e->opt_giant_thresh = value > 0 ? (uint32_t)std::max<long>(value, 64) : 0;
+    else if (k == "giant_row_threshold") {   // (an explicit threshold holds for every stage; "giant_row_threshold_f16" afterwards refines it)
+        e->opt_giant_thresh = value > 0 ? (uint32_t)std::max<long>(value, 64) : 0;
+        e->opt_giant_f16 = e->opt_giant_thresh ? e->opt_giant_thresh : 1u;
+        e->giant_f16_auto = false;
+    }
     else if (k == "hub_mode") e->opt_hub_mode = value == 1 ? 1 : 0;
+    else if (k == "giant_row_threshold_f16") { e->opt_giant_f16 = value > 0 ? (uint32_t)value : 1u; e->giant_f16_auto = false; for (auto &pp : e->prune) pp.tried = pp.ready = false; }
     else if (k == "giant_segments") e->opt_giant_segments = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "side_streams") e->opt_side_streams = value != 0 ? 1 : 0;
     else if (k == "kernel_trace") e->opt_ktrace = value != 0 ? 1 : 0;

@@ -1072,11 +1072,11 @@ __global__ void k_find_giant(GraphDev g, const uint32_t *__restrict__ list, uint
 
 __global__ __launch_bounds__(256) void k_giant_gather16(GraphDev g, const float4 *__restrict__ fin, float *__restrict__ slab,
                                                         const uint4 *__restrict__ meta, const unsigned long long *__restrict__ off,
-                                                        uint32_t n_giant, uint32_t row_lo, uint32_t row_hi) {
+                                                        uint32_t n_giant, uint32_t row_lo, uint32_t row_hi, uint32_t min_deg) {
     __shared__ __attribute__((aligned(16))) float tile[16][kGiantBlk + 4];
     const uint32_t i = giant_of_block(meta, n_giant, blockIdx.x);
     const uint4 mt = meta[i];
-    if (mt.x < row_lo || mt.x >= row_hi) return;      // block-uniform
+    if (mt.x < row_lo || mt.x >= row_hi || mt.z < min_deg) return;      // block-uniform (min_deg: this stage leaves shorter rows to k_long_*)
     // the row's entries: all of them, or (pruned adjacency, see k_prune_*) those whose target row may be non-zero — the
     // streams then are shorter, in the same slab region
     const bool pruned = g.prune_bad != nullptr && *g.prune_bad == 0u;
@@ -1203,10 +1203,10 @@ constexpr uint32_t kGiantSeg = 4;   // windows per segment: 4096 addends
 __global__ __launch_bounds__(64) void k_giant_segsum(const float *__restrict__ slab, const uint4 *__restrict__ meta,
                                                      const unsigned long long *__restrict__ off, uint32_t F, uint32_t maxseg,
                                                      float *__restrict__ segsum, uint32_t row_lo, uint32_t row_hi,
-                                                     const uint32_t *__restrict__ prp, const uint32_t *__restrict__ prune_bad) {
+                                                     const uint32_t *__restrict__ prp, const uint32_t *__restrict__ prune_bad, uint32_t min_deg) {
     const uint32_t st = blockIdx.x / maxseg, sg = blockIdx.x % maxseg, i = st / F, c = st % F;
     const uint4 mt = meta[i];
-    if (mt.x < row_lo || mt.x >= row_hi) return;
+    if (mt.x < row_lo || mt.x >= row_hi || mt.z < min_deg) return;
     const int lane = threadIdx.x;
     const bool pruned = prune_bad != nullptr && *prune_bad == 0u;
     const uint32_t len = pruned ? prp[mt.x + 1] - prp[mt.x] : mt.z;
@@ -1231,11 +1231,11 @@ __global__ __launch_bounds__(64) void k_giant_segmap(const float *__restrict__ s
                                                      const unsigned long long *__restrict__ off, uint32_t F, uint32_t maxseg,
                                                      const float *__restrict__ segsum, uint4 *__restrict__ segmap, uint32_t row_lo,
                                                      uint32_t row_hi, const uint32_t *__restrict__ prp,
-                                                     const uint32_t *__restrict__ prune_bad) {
+                                                     const uint32_t *__restrict__ prune_bad, uint32_t min_deg) {
     const uint32_t st = blockIdx.x / maxseg, sg = blockIdx.x % maxseg, i = st / F, c = st % F;
     if (sg == 0) return;                                  // (the first segment is always walked: nothing in front of it to estimate)
     const uint4 mt = meta[i];
-    if (mt.x < row_lo || mt.x >= row_hi) return;
+    if (mt.x < row_lo || mt.x >= row_hi || mt.z < min_deg) return;
     const int lane = threadIdx.x;
     const bool pruned = prune_bad != nullptr && *prune_bad == 0u;
     const uint32_t len = pruned ? prp[mt.x + 1] - prp[mt.x] : mt.z;
@@ -1287,10 +1287,10 @@ __global__ __launch_bounds__(64) void k_giant_sum(const float *__restrict__ slab
                                                   const unsigned long long *__restrict__ off, uint32_t F, float *__restrict__ agg,
                                                   uint32_t row_lo, uint32_t row_hi, const uint32_t *__restrict__ prp,
                                                   const uint32_t *__restrict__ prune_bad, const uint4 *__restrict__ segmap,
-                                                  uint32_t maxseg) {
+                                                  uint32_t maxseg, uint32_t min_deg) {
     const uint32_t i = blockIdx.x / F, c = blockIdx.x % F;
     const uint4 mt = meta[i];
-    if (mt.x < row_lo || mt.x >= row_hi) return;
+    if (mt.x < row_lo || mt.x >= row_hi || mt.z < min_deg) return;
     const int lane = threadIdx.x;
     const bool pruned = prune_bad != nullptr && *prune_bad == 0u;   // (the gather kernel wrote the shorter streams)
     const uint32_t len = pruned ? prp[mt.x + 1] - prp[mt.x] : mt.z;
@@ -1358,11 +1358,11 @@ template <int VARIANT>
 __global__ __launch_bounds__(64) void k_giant_dense(GraphDev g, float ws, const float *__restrict__ in, float *__restrict__ out,
                                                     float *__restrict__ logits, const float *__restrict__ P,
                                                     const uint4 *__restrict__ meta, uint32_t n_giant,
-                                                    const float *__restrict__ agg, uint32_t row_lo, uint32_t row_hi) {
+                                                    const float *__restrict__ agg, uint32_t row_lo, uint32_t row_hi, uint32_t min_deg) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n_giant) return;
     const uint4 mt = meta[i];
-    if (mt.x < row_lo || mt.x >= row_hi) return;
+    if (mt.x < row_lo || mt.x >= row_hi || mt.z < min_deg) return;
     if constexpr (VARIANT == 0) {
         long_tail_f1<32, 32, 16>(g, ws, in, out, P, mt.x, mt.z, agg[(size_t)i * 16]);
     } else {
@@ -3712,38 +3712,38 @@ uint32_t giant_window() { return kGiantWin; }
 uint32_t giant_block() { return kGiantBlk; }
 
 hipError_t launch_giant_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *in, float *out,
-                              float *logits, uint32_t row_lo, uint32_t row_hi, const GiantRows &gr, bool fast, hipStream_t stream) {
+                              float *logits, uint32_t row_lo, uint32_t row_hi, const GiantRows &gr, bool fast, hipStream_t stream, uint32_t min_deg) {
     if (gr.n == 0 || row_hi <= row_lo) return hipSuccess;
     const uint4 *meta = reinterpret_cast<const uint4 *>(gr.meta);
     const uint32_t F = sp.f == 16 ? 16u : 1u;
     const uint32_t *pr = sp.f == 16 ? g.prp : nullptr, *pb = sp.f == 16 ? g.prune_bad : nullptr;   // (pruned adjacency: 16-wide stages only)
     if (sp.f == 16)
         GNNVC_LAUNCH(k_giant_gather16, dim3(gr.blocks), dim3(256), 0, stream, g, reinterpret_cast<const float4 *>(in), gr.slab,
-                           meta, gr.off, gr.n, row_lo, row_hi);
+                           meta, gr.off, gr.n, row_lo, row_hi, min_deg);
     else if (sp.f == 1)
         GNNVC_LAUNCH(k_giant_gather1, dim3(gr.blocks), dim3(256), 0, stream, g, in, gr.slab, meta, gr.off, gr.n, row_lo, row_hi);
     else
         return hipErrorInvalidValue;
     if (fast) {
         GNNVC_LAUNCH(k_giant_sum<true>, dim3(gr.n * F), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.agg, row_lo, row_hi, pr, pb,
-                     (const uint4 *)nullptr, 0u);
+                     (const uint4 *)nullptr, 0u, min_deg);
     } else {
         const bool seg = gr.segsum && gr.segmap && gr.maxseg > 1;   // one stream on several waves (see k_giant_segmap)
         if (seg) {
             GNNVC_LAUNCH(k_giant_segsum, dim3(gr.n * F * gr.maxseg), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.maxseg, gr.segsum,
-                         row_lo, row_hi, pr, pb);
+                         row_lo, row_hi, pr, pb, min_deg);
             GNNVC_LAUNCH(k_giant_segmap, dim3(gr.n * F * gr.maxseg), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.maxseg, gr.segsum,
-                         reinterpret_cast<uint4 *>(gr.segmap), row_lo, row_hi, pr, pb);
+                         reinterpret_cast<uint4 *>(gr.segmap), row_lo, row_hi, pr, pb, min_deg);
         }
         GNNVC_LAUNCH(k_giant_sum<false>, dim3(gr.n * F), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.agg, row_lo, row_hi, pr, pb,
-                     seg ? reinterpret_cast<const uint4 *>(gr.segmap) : nullptr, gr.maxseg);
+                     seg ? reinterpret_cast<const uint4 *>(gr.segmap) : nullptr, gr.maxseg, min_deg);
     }
     const float *P = params + sp.param_offset;
     const dim3 grid((gr.n + 63) / 64), block(64);
     switch (sp.variant) {
-    case 0: GNNVC_LAUNCH(k_giant_dense<0>, grid, block, 0, stream, g, ws, in, out, logits, P, meta, gr.n, gr.agg, row_lo, row_hi); break;
-    case 1: GNNVC_LAUNCH(k_giant_dense<1>, grid, block, 0, stream, g, ws, in, out, logits, P, meta, gr.n, gr.agg, row_lo, row_hi); break;
-    case 2: GNNVC_LAUNCH(k_giant_dense<2>, grid, block, 0, stream, g, ws, in, out, logits, P, meta, gr.n, gr.agg, row_lo, row_hi); break;
+    case 0: GNNVC_LAUNCH(k_giant_dense<0>, grid, block, 0, stream, g, ws, in, out, logits, P, meta, gr.n, gr.agg, row_lo, row_hi, min_deg); break;
+    case 1: GNNVC_LAUNCH(k_giant_dense<1>, grid, block, 0, stream, g, ws, in, out, logits, P, meta, gr.n, gr.agg, row_lo, row_hi, min_deg); break;
+    case 2: GNNVC_LAUNCH(k_giant_dense<2>, grid, block, 0, stream, g, ws, in, out, logits, P, meta, gr.n, gr.agg, row_lo, row_hi, min_deg); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -3766,18 +3766,18 @@ hipError_t stream_sums(const float *streams_dev, uint32_t streams, uint32_t len,
     const uint32_t *none = nullptr;
     if (mode == 1) {
         GNNVC_LAUNCH(k_giant_sum<true>, dim3(streams), dim3(64), 0, stream, streams_dev, mt, off, 1u, agg, 0u, 1u, none, none,
-                     (const uint4 *)nullptr, 0u);
+                     (const uint4 *)nullptr, 0u, 0u);
         return hipGetLastError();
     }
     const uint32_t maxseg = giant_segments(len);
     const bool seg = mode == 0 && segsum && segmap && maxseg > 1;
     if (seg) {
-        GNNVC_LAUNCH(k_giant_segsum, dim3(streams * maxseg), dim3(64), 0, stream, streams_dev, mt, off, 1u, maxseg, segsum, 0u, 1u, none, none);
+        GNNVC_LAUNCH(k_giant_segsum, dim3(streams * maxseg), dim3(64), 0, stream, streams_dev, mt, off, 1u, maxseg, segsum, 0u, 1u, none, none, 0u);
         GNNVC_LAUNCH(k_giant_segmap, dim3(streams * maxseg), dim3(64), 0, stream, streams_dev, mt, off, 1u, maxseg, segsum,
-                     reinterpret_cast<uint4 *>(segmap), 0u, 1u, none, none);
+                     reinterpret_cast<uint4 *>(segmap), 0u, 1u, none, none, 0u);
     }
     GNNVC_LAUNCH(k_giant_sum<false>, dim3(streams), dim3(64), 0, stream, streams_dev, mt, off, 1u, agg, 0u, 1u, none, none,
-                 seg ? reinterpret_cast<const uint4 *>(segmap) : nullptr, maxseg);
+                 seg ? reinterpret_cast<const uint4 *>(segmap) : nullptr, maxseg, 0u);
     return hipGetLastError();
 }
 
