@@ -97,11 +97,11 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *                         their neighbour values are gathered by every CU into per-column streams and each stream's
  *                         sequential fp32 sum is evaluated with a parallel scan that reproduces the chain's
  *                         roundings (csrc/exact_sum.h); bit-identical results
- *   "giant_row_threshold_f16" d  the 16-wide stages send only rows of degree >= d the giant way (default 65536: sixteen
- *                         streams per row are three times a long row's traffic, worth it for the rows whose add chain a
- *                         stage would wait for; on smaller graphs, where a 65 536-entry chain is what a stage waits for, i.e.
- *                         power-law config, the default is "giant_row_threshold"); setting "giant_row_threshold" sets
- *                         this one too
+ *   "giant_row_threshold_f16" d  the 16-wide stages send only rows of degree >= d the giant way.  Default: 65536 on graphs
+ *                         of 64 Mi adjacency entries and more (sixteen streams per row are three times a long row's
+ *                         traffic: worth it for the rows whose add chain a stage would wait for), "giant_row_threshold"
+ *                         on smaller ones (there a 65 536-entry chain IS what a stage waits for); setting
+ *                         "giant_row_threshold" sets this one too
  *   "giant_segments" -1|0|1  1 = a giant row's streams are cut into segments of 4096 addends summarised by many waves
  *                         at once (k_giant_segmap) and joined by one walk; 0 = one wave walks each stream; -1 (default) =
  *                         segments where the longest stream's walk would be what a stage waits for.  Same bits
