@@ -270,7 +270,7 @@ hipError_t compact_sums(const GraphDev &g, const CompactPlan &cp, uint32_t *desc
                         uint32_t row_hi, uint32_t *dirty_rows, uint32_t dirty_cap, hipStream_t stream, bool one_round = false);
 hipError_t compact_mark(const uint32_t *desc, uint32_t *marks, uint32_t k, hipStream_t stream);
 hipError_t compact_fix(const GraphDev &g, const float *in, const uint32_t *desc, const uint32_t *dirty_rows, uint32_t dirty_cap,
-                       float *agg16, const uint32_t *marks, hipStream_t stream, uint32_t blocks = 4096);
+                       float *agg16, const uint32_t *marks, hipStream_t stream, uint32_t blocks = 1024);
 
 // The next graph derived from the resident one (see the k_derive_* kernels): new_of is scratch of
 // old_g.n words, tail receives per new row the number of entries the device cannot derive, *bad != 0 afterwards means
