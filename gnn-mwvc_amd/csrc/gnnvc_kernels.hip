@@ -117,6 +117,9 @@ __device__ __forceinline__ uint32_t tile_for_wave(uint32_t ntiles, bool interlea
 //   2. dense-layer input tile: 64 rows x 32 floats in the first layer's k order
 //      [aggregate 0..15 | h0 | degree | W/ws | NW/ws | h4..h15], pitch 33;
 //   3. output tile: 64 rows x 17 floats, read back row-wise for full-row stores.
+#ifndef GNNVC_SORTED_MIX
+#define GNNVC_SORTED_MIX 1   // degree-sorted tiles are dispatched alternating between the two ends of the list (A/B: 0)
+#endif
 constexpr int kRegionFloats = 2112;          // 8448 B per wave, 33 KiB per workgroup
 constexpr int kInPitch = 33;                 // 32 inputs in k order; odd pitch: conflict-free ds_read_b32 down a column
 constexpr int kOutPitch = 17;
@@ -342,8 +345,14 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
     // and every XCD gets the same mix of heavy and light tiles.
     // (the grid is sized for the longer of the two lists: the same launch serves whichever the device picks)
     const uint32_t grid_tiles = SORTED ? (max(n_sorted, n_sorted_p) + kWave - 1) / kWave : ntiles;
-    const uint32_t tile = tile_for_wave(grid_tiles, SORTED || interleave);
+    uint32_t tile = tile_for_wave(grid_tiles, SORTED || interleave);
     if (tile >= ntiles) return;
+    if (SORTED && GNNVC_SORTED_MIX) {
+        // The list runs from the heaviest rows to rows without entries; dispatched in that order the kernel would first only
+        // gather (every wave waiting on the fabric) and at the end only run dense layers (the fabric idle).  Alternating
+        // between the two ends gives every workgroup tiles of both kinds at any time; the heavy tiles still start first.
+        tile = (tile & 1u) ? ntiles - 1u - (tile >> 1) : (tile >> 1);
+    }
     const uint32_t v0 = row_lo + tile * kWave;   // natural order only
 
     // lane-per-vertex view of the tile
@@ -660,8 +669,9 @@ __global__ __launch_bounds__(kBlock) void k_stage_f1(
     float *T = lds[threadIdx.x >> 6];
     uint32_t *stage = reinterpret_cast<uint32_t *>(T);
     const uint32_t ntiles = sorted ? (n_sorted + kWave - 1) / kWave : (row_hi - row_lo + kWave - 1) / kWave;
-    const uint32_t tile = tile_for_wave(ntiles, sorted || interleave != 0);
+    uint32_t tile = tile_for_wave(ntiles, sorted || interleave != 0);
     if (tile >= ntiles) return;
+    if (sorted && GNNVC_SORTED_MIX) tile = (tile & 1u) ? ntiles - 1u - (tile >> 1) : (tile >> 1);   // (heavy and light tiles side by side: see k_stage_f16)
     const uint32_t v0 = row_lo + tile * kWave;   // natural order only
     uint32_t u, uc, deg, rs, re;
     bool mine, staged = false;
