@@ -112,6 +112,7 @@ struct gnnvc_engine {
     int opt_blocked = 1;            // option "blocked_stage0"
     uint32_t opt_block_cols = 0;    // option "block_cols" (0 = default)
     uint32_t opt_blocked_min_n = 1u << 20;  // below this x fits the L2s anyway
+    uint32_t opt_compact_min_n = 1u << 19;  // option "compact_min_n": the compact-table plan's own bound (the smaller of the two counts)
     uint32_t opt_plan_chunk_rows = 0;       // != 0: cap on the rows per chunk of the LDS-table / compact-table plans
     bool blocked_ready = false;
     bool blocked_tried = false;     // build attempted for the current graph
@@ -923,7 +924,9 @@ int build_compact_impl(gnnvc_engine *e, uint32_t base, uint32_t end, bool allow_
     if (!e->opt_compact || e->stages.size() < 2) return GNNVC_OK;
     for (size_t st = 1; st < e->stages.size(); ++st)
         if (e->stages[st].f != 16) return GNNVC_OK;
-    if (g.n < e->opt_blocked_min_n || g.nnz == 0 || g.nnz >= (1ull << 31)) return GNNVC_OK;
+    // (the 64-byte feature rows outgrow the L2s long before x does: the 16-wide stages' plan pays from half a million vertices on —
+    // ER-1M 0.87 -> 0.58 ms per forward — the F = 1 plans from a million)
+    if (g.n < std::min(e->opt_blocked_min_n, e->opt_compact_min_n) || g.nnz == 0 || g.nnz >= (1ull << 31)) return GNNVC_OK;
     const bool skewed = e->sorted_wanted || e->n_long > 0;
     const bool mapped = skewed && e->opt_compact < 2 && e->opt_compact_skewed && allow_mapped && base == 0 && end == g.n && !g.sliced();
     if (skewed && !mapped && e->opt_compact < 2) return GNNVC_OK;
@@ -1641,6 +1644,7 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     if (k == "blocked_stage0") e->opt_blocked = value < 0 ? 0 : (value > 2 ? 2 : (int)value);   // 2 = also on skewed graphs
     else if (k == "block_cols") e->opt_block_cols = value > 0 ? (uint32_t)value : 0;
     else if (k == "blocked_min_n") e->opt_blocked_min_n = value > 0 ? (uint32_t)value : 0;
+    else if (k == "compact_min_n") e->opt_compact_min_n = value > 0 ? (uint32_t)value : 0;
     else if (k == "plan_chunk_rows") e->opt_plan_chunk_rows = value > 0 ? (uint32_t)value : 0;
     else if (k == "overlap_dense") e->opt_overlap = value != 0 ? 1 : 0;
     else if (k == "long_row_threshold") { e->opt_long_thresh = value > 0 ? (uint32_t)value : 0; e->opt_long_auto = false; }

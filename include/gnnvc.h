@@ -81,7 +81,8 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *                         neighbours are read from a 16-byte-per-vertex table swept block by block through L2
  *                         instead of 64-byte rows from memory (default 1 = large, non-skewed graphs); bit-identical
  *   "block_cols"     n    vertices per column block (default 524288 = 2 MiB of x)
- *   "blocked_min_n"  n    graphs with fewer vertices are not blocked (default 2^20)
+ *   "blocked_min_n"  n    graphs with fewer vertices get none of the per-graph plans of the F = 1 stage (default 2^20)
+ *   "compact_min_n"  n    ... nor the compact-table plan below the smaller of this (default 2^19) and "blocked_min_n"
  *   "overlap_dense"  0|1  last stage under the compact-table plan: dense layers of one round of the sums on a second
  *                         stream, under the next round's sums (default 1; bit-identical either way)
  *   "plan_chunk_rows" n   cap on the rows per chunk of the LDS-table and compact-table plans (default 0 = what
