@@ -127,6 +127,7 @@ struct gnnvc_engine {
     uint32_t lt_plan_thresh = 0xFFFFFFFFu;
     DevBuf<uint32_t> lt_rowmap, lt_first, lt_bstart;
     uint32_t opt_lds_skewed_rows = 0;       // (0 = by the size of x) option "lds_table_skewed_rows": rows of at least this many entries stay outside the skewed-graph plan
+    uint32_t opt_lds_skewed_min_n = 1u << 21;
     int opt_lds_skewed = 1;              // option "lds_table_skewed": 0 = skewed graphs keep the gathering F = 1 kernels
     uint32_t lt_rows = 0, lt_chunks = 0, lt_blocks = 0, lt_steps_total = 0, lt_last_entry = 0;
     DevBuf<uint8_t> lt_bytes;
@@ -805,7 +806,10 @@ int build_lds_table_impl(gnnvc_engine *e) {
     // from the degree-sorted list to slices of equal weight, over column blocks of equal entry mass (layout_skewed_plan); the
     // giant rows keep their kernels.  "lds_table" 2 forces the consecutive-row layout onto such a graph instead (tests).
     const bool skewed = e->sorted_wanted || e->n_long > 0;
-    const bool mapped = skewed && e->opt_lds_table < 2 && e->opt_lds_skewed;
+    // (on a skewed graph most gathers of x go to hubs, which the L2s hold: the plan pays from 2 M vertices on — R-MAT-22 stage 0
+    // 1.07 -> 0.86 ms, R-MAT-20 0.27 -> 0.34 ms; a lowered "blocked_min_n" — tests — lowers this bound too)
+    const uint32_t skewed_min_n = e->opt_blocked_min_n < (1u << 20) ? e->opt_blocked_min_n : e->opt_lds_skewed_min_n;
+    const bool mapped = skewed && e->opt_lds_table < 2 && e->opt_lds_skewed && g.n >= skewed_min_n;
     if (skewed && !mapped && e->opt_lds_table < 2) return GNNVC_OK;   // long runs would serialise in one thread
     const uint32_t bc = gnnvc::lds_table_block();
     uint32_t max_rows = gnnvc::lds_table_max_rows();
