@@ -1,0 +1,70 @@
+"""Randomised plan fuzz (GPU box): random small graphs x random thresholds / plan options, three forwards each, logits
+against the oracle bit for bit.  python scratch/experiments/fuzz_plans.py [cases=150] [seed0=0]"""
+import sys, pathlib, time
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
+import numpy as np
+import gnn_mwvc_amd as G
+from oracle import oracle_py
+from tools import graphgen as gg
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+om = oracle_py.OracleModel(G.default_model_text())
+bits = lambda a: np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+bad = 0
+t0 = time.time()
+for case in range(cases):
+    rng = np.random.default_rng(seed0 + case)
+    kind = rng.choice(["er", "rmat", "hub", "chung", "dense"])
+    if kind == "er":
+        n = int(rng.integers(2000, 60000)); g = gg.erdos_renyi(n, int(n * rng.uniform(2, 12)), int(rng.integers(1 << 30)))
+    elif kind == "rmat":
+        g = gg.rmat(int(rng.integers(11, 16)), int(rng.integers(4, 17)), int(rng.integers(1 << 30)))
+    elif kind == "hub":
+        n = int(rng.integers(5000, 50000))
+        g = gg.hub_graph(n, int(n * rng.uniform(2, 8)), int(rng.integers(1, 5)), int(rng.integers(300, min(n - 1, 20000))), seed=int(rng.integers(1 << 30)))
+    elif kind == "chung":
+        n = int(rng.integers(5000, 50000))
+        g = gg.chung_lu_hubs(n, float(rng.uniform(4, 12)), float(rng.uniform(2.0, 2.6)), int(rng.integers(0, 4)), int(rng.integers(300, min(n - 1, 9000))), seed=int(rng.integers(1 << 30)))
+    else:
+        n = int(rng.integers(1500, 4000)); g = gg.erdos_renyi(n, n * int(rng.integers(60, 200)), int(rng.integers(1 << 30)))
+    opts = {"blocked_min_n": 0, "prune_min_entries": 0, "prune_min_drop_percent": int(rng.integers(0, 30))}
+    if rng.random() < 0.7: opts["long_row_threshold"] = int(rng.choice([0, 8, 40, 64, 128, 256, 512]))
+    if rng.random() < 0.5: opts["sorted_long_row_threshold"] = int(rng.choice([64, 256, 512, 1024, 2048]))
+    if rng.random() < 0.7: opts["giant_row_threshold"] = int(rng.choice([0, 64, 300, 1000, 4096, 16384]))
+    if rng.random() < 0.4: opts["giant_row_threshold_f16"] = int(rng.choice([64, 1000, 5000, 65536]))
+    opts["giant_segments"] = int(rng.choice([-1, 0, 1]))
+    opts["sorted_tiles"] = int(rng.choice([-1, 0, 1]))
+    opts["prune_zero_rows"] = int(rng.choice([0, 1, 1, 2]))
+    opts["prune_class_by_entries_left"] = int(rng.choice([0, 1, 1]))
+    opts["prune_giant_rows"] = int(rng.choice([0, 1, 1]))
+    opts["prune_heavy_entries"] = int(rng.choice([1, 1 << 24]))
+    opts["lds_table"] = int(rng.choice([0, 1, 1]))
+    opts["lds_table_skewed_rows"] = int(rng.choice([0, 64, 512, 2048, 16384]))
+    opts["compact_gather"] = int(rng.choice([0, 1, 1]))
+    opts["compact_skewed"] = int(rng.choice([0, 0, 1]))
+    opts["compact_passes"] = int(rng.choice([1, 2, 3]))
+    opts["mfma_dense"] = int(rng.choice([0, 1, 2]))
+    opts["overlap_dense"] = int(rng.choice([0, 1]))
+    if rng.random() < 0.3: opts["plan_chunk_rows"] = int(rng.choice([16, 48, 256, 4096]))
+    e = G.Engine(G.default_model_text(), device=0)
+    try:
+        for k, v in opts.items():
+            e.set_option(k, v)
+        e.set_weight_scale(g.ws); om.set_weight_scale(g.ws)
+        e.upload_graph(g)
+        want = om.logits(g)
+        for rep in range(3):
+            _, lg = e.forward(g.x())
+            if not np.array_equal(bits(lg[:, 0]), bits(want)):
+                bad += 1
+                d = np.flatnonzero(bits(lg[:, 0]) != bits(want))
+                deg = np.diff(g.rowptr.astype(np.int64))
+                print(f"MISMATCH case {seed0 + case} kind {kind} n {g.n} nnz {g.nnz} forward {rep}: {len(d)} rows, first {d[:5].tolist()} degrees {deg[d[:5]].tolist()} opts {opts}", flush=True)
+                break
+    finally:
+        e.close()
+    if case % 25 == 24:
+        print(f"{case + 1} cases, {bad} bad, {time.time() - t0:.0f} s", flush=True)
+print("done:", cases, "cases,", bad, "mismatching")
+sys.exit(1 if bad else 0)

@@ -1,0 +1,82 @@
+"""Randomised plan fuzz: random small graphs (Erdős–Rényi, R-MAT, hubs, power-law, dense) x random thresholds and plan
+options — long / giant / sorted thresholds, pruned adjacency in both modes, the F = 1 and compact-table plans in their
+skewed layouts, giant streams on one or several waves, MFMA or VALU dense layers, small plan chunks — three forwards each,
+logits against the oracle bit for bit.  (`scratch/experiments/fuzz_plans.py` is the long form: 3 000 cases, 0 mismatches.)"""
+import numpy as np
+import pytest
+
+from tools import graphgen as gg
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _graph(rng):
+    kind = rng.choice(["er", "rmat", "hub", "chung", "dense"])
+    seed = int(rng.integers(1 << 30))
+    if kind == "er":
+        n = int(rng.integers(2000, 60000))
+        return gg.erdos_renyi(n, int(n * rng.uniform(2, 12)), seed)
+    if kind == "rmat":
+        return gg.rmat(int(rng.integers(11, 16)), int(rng.integers(4, 17)), seed)
+    if kind == "hub":
+        n = int(rng.integers(5000, 50000))
+        return gg.hub_graph(n, int(n * rng.uniform(2, 8)), int(rng.integers(1, 5)), int(rng.integers(300, min(n - 1, 20000))), seed=seed)
+    if kind == "chung":
+        n = int(rng.integers(5000, 50000))
+        return gg.chung_lu_hubs(n, float(rng.uniform(4, 12)), float(rng.uniform(2.0, 2.6)), int(rng.integers(0, 4)),
+                                int(rng.integers(300, min(n - 1, 9000))), seed=seed)
+    n = int(rng.integers(1500, 4000))
+    return gg.erdos_renyi(n, n * int(rng.integers(60, 200)), seed)
+
+
+def _options(rng):
+    o = {"blocked_min_n": 0, "prune_min_entries": 0, "prune_min_drop_percent": int(rng.integers(0, 30))}
+    if rng.random() < 0.7:
+        o["long_row_threshold"] = int(rng.choice([0, 8, 40, 64, 128, 256, 512]))
+    if rng.random() < 0.5:
+        o["sorted_long_row_threshold"] = int(rng.choice([64, 256, 512, 1024, 2048]))
+    if rng.random() < 0.7:
+        o["giant_row_threshold"] = int(rng.choice([0, 64, 300, 1000, 4096, 16384]))
+    if rng.random() < 0.4:
+        o["giant_row_threshold_f16"] = int(rng.choice([64, 1000, 5000, 65536]))
+    o["giant_segments"] = int(rng.choice([-1, 0, 1]))
+    o["sorted_tiles"] = int(rng.choice([-1, 0, 1]))
+    o["prune_zero_rows"] = int(rng.choice([0, 1, 1, 2]))
+    o["prune_class_by_entries_left"] = int(rng.choice([0, 1, 1]))
+    o["prune_giant_rows"] = int(rng.choice([0, 1, 1]))
+    o["prune_heavy_entries"] = int(rng.choice([1, 1 << 24]))
+    o["lds_table"] = int(rng.choice([0, 1, 1]))
+    o["lds_table_skewed_rows"] = int(rng.choice([0, 64, 512, 2048, 16384]))
+    o["compact_gather"] = int(rng.choice([0, 1, 1]))
+    o["compact_skewed"] = int(rng.choice([0, 0, 1]))
+    o["compact_passes"] = int(rng.choice([1, 2, 3]))
+    o["mfma_dense"] = int(rng.choice([0, 1, 2]))
+    o["overlap_dense"] = int(rng.choice([0, 1]))
+    if rng.random() < 0.3:
+        o["plan_chunk_rows"] = int(rng.choice([16, 48, 256, 4096]))
+    return o
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_random_graphs_and_plan_options(model_text, oracle_model, block):
+    import gnn_mwvc_amd as G
+    for case in range(block * 15, block * 15 + 15):
+        rng = np.random.default_rng(90_000 + case)
+        g, opts = _graph(rng), _options(rng)
+        e = G.Engine(model_text, device=0)
+        try:
+            for k, v in opts.items():
+                e.set_option(k, v)
+            e.set_weight_scale(g.ws)
+            oracle_model.set_weight_scale(g.ws)
+            e.upload_graph(g)
+            want = oracle_model.logits(g)
+            for rep in range(3):
+                _, lg = e.forward(g.x())
+                assert np.array_equal(bits(lg[:, 0]), bits(want)), (case, rep, g.n, g.nnz, opts)
+        finally:
+            e.close()
