@@ -585,7 +585,9 @@ int find_long(gnnvc_engine *e) {
     }
     e->n_long = cnt;
     e->long_thresh = thresh;
-    e->thresh_f16 = (e->sorted_wanted && !few_long) ? std::max(thresh, e->opt_sorted_long_thresh) : thresh;
+    // (never above the giant threshold: the rows from there on have their own kernels in every stage)
+    const uint32_t gt = e->opt_giant_thresh ? std::max(e->opt_giant_thresh, thresh) : 0xFFFFFFFFu;
+    e->thresh_f16 = (e->sorted_wanted && !few_long) ? std::max(thresh, std::min(e->opt_sorted_long_thresh, gt)) : thresh;
     return find_giant(e);
 }
 
@@ -1356,7 +1358,9 @@ int launch_side_rows(gnnvc_engine *e, const GraphDev &gv, int stage, uint32_t lo
                                              e->opt_hub_mode == 1, s_giant, giant_from));
         if (side) HIP_TRY(e, hipEventRecord(e->ev_giant, e->giant_stream));
     }
-    if ((e->n_giant < e->n_long || giant_from > e->giant_thresh) && thr < giant_from)   // (thr == giant_from: a plan has every row in between)
+    // (with rows classed by the entries they have left, k_long_* takes rows from gv.eff_thresh entries on whatever their degree)
+    const uint32_t long_from = gv.prune_eff ? std::min(thr, gv.eff_thresh) : thr;
+    if ((e->n_giant < e->n_long || giant_from > e->giant_thresh) && long_from < giant_from)   // (equal: a plan or the giant kernels have every row in between)
         HIP_TRY(e, gnnvc::launch_long_stage(e->stages[stage], gv, e->ws, e->params.p, in, out, logits, lo, hi,
                                             e->long_list.p, e->n_long, thr, giant_from, s_long));
     if (side) HIP_TRY(e, hipEventRecord(e->ev_join, e->aux_stream));

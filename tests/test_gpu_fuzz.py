@@ -80,3 +80,79 @@ def test_random_graphs_and_plan_options(model_text, oracle_model, block):
                 assert np.array_equal(bits(lg[:, 0]), bits(want)), (case, rep, g.n, g.nnz, opts)
         finally:
             e.close()
+
+
+def _oracle_stage(oracle_model, g, stage, h):
+    from oracle import oracle_py
+    a = oracle_py.graph_layer(g, g.ws, np.ascontiguousarray(h, dtype=np.float32))
+    for i, (W, b) in enumerate(oracle_model.linear_params()[3 * stage: 3 * stage + 3]):
+        a = oracle_py.linear_layer(a, W, b)
+        if not (stage == 2 and i == 2):
+            a = oracle_py.relu(a)
+    return a
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_random_stage_inputs(model_text, oracle_model, block):
+    """The 16-wide stage entry point with plans built from the graph's own forwards and then ARBITRARY inputs: random live
+    columns, zero rows that do or do not match what the pruned adjacency was built for, strays, a negative value, -0.0;
+    whole range and sub-ranges.  (Long form: scratch/experiments/fuzz_stage_inputs.py — it found the one bug of this kind:
+    with the giant threshold at or below the sorted long-row threshold, rows classed "long" by the entries they had left
+    were nobody's.)"""
+    import torch
+    import gnn_mwvc_amd as G
+    dev = torch.device("cuda:0")
+    for case in range(block * 12, block * 12 + 12):
+        rng = np.random.default_rng(70_000 + case)
+        g = _graph(rng)
+        if g.n > 40000:
+            g = gg.rmat(13, 8, int(rng.integers(1 << 30)))
+        deg = np.diff(g.rowptr.astype(np.int64))
+        opts = {"blocked_min_n": 0, "prune_min_entries": 0, "prune_min_drop_percent": int(rng.integers(0, 20)),
+                "long_row_threshold": int(rng.choice([64, 128, 256, 512])), "giant_row_threshold": int(rng.choice([300, 1000, 4096, 16384])),
+                "sorted_tiles": int(rng.choice([-1, 0, 1])), "prune_zero_rows": int(rng.choice([1, 1, 2])),
+                "compact_skewed": int(rng.choice([0, 1])), "compact_passes": int(rng.choice([1, 2, 3])),
+                "giant_segments": int(rng.choice([0, 1]))}
+        e = G.Engine(model_text, device=0)
+        try:
+            for k, v in opts.items():
+                e.set_option(k, v)
+            e.set_weight_scale(g.ws)
+            oracle_model.set_weight_scale(g.ws)
+            e.upload_graph(g)
+            for _ in range(3):
+                e.forward(g.x())
+            for trial in range(2):
+                live = rng.choice(16, int(rng.integers(1, 17)), replace=False)
+                h = np.zeros((g.n, 16), dtype=np.float32)
+                for c in live:
+                    h[:, c] = rng.uniform(0.05, 2.0, g.n).astype(np.float32) * (rng.random(g.n) < rng.choice([1.0, 0.5, 0.1, 0.01]))
+                mode = rng.choice(["as_built", "degree_zero", "random_zero", "none"])
+                if mode == "degree_zero":
+                    h[deg >= int(rng.choice([20, 60, 150]))] = 0.0
+                elif mode == "random_zero":
+                    h[rng.random(g.n) < 0.3] = 0.0
+                elif mode == "as_built":
+                    real = oracle_model.predict(g, g.x(), stop_after=6 if rng.random() < 0.5 else 13)
+                    h[~(real != 0).any(axis=1)] = 0.0
+                for i in rng.choice(g.n, int(rng.integers(0, 6)), replace=False):
+                    h[i, int(rng.integers(16))] = 1.0 + (i % 5)
+                if rng.random() < 0.15:
+                    h[int(rng.integers(g.n)), int(rng.integers(16))] = -0.5
+                if rng.random() < 0.3:
+                    h[::7, int(rng.integers(16))] = -0.0
+                hin = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+                hin[: g.n] = torch.from_numpy(h).to(dev)
+                for st in (1, 2):
+                    want = _oracle_stage(oracle_model, g, st, h)
+                    lo = int(rng.integers(0, g.n // 2)) // 64 * 64
+                    for a, b in ((0, g.n), (lo, g.n), (0, max(64, lo))):
+                        out = torch.full((g.n + 1, 16 if st == 1 else 1), 7.0, dtype=torch.float32, device=dev)
+                        lg = torch.full((g.n + 1,), 7.0, dtype=torch.float32, device=dev)
+                        torch.cuda.synchronize()
+                        e.stage_forward_device(st, a, b, hin.data_ptr(), out.data_ptr(), lg.data_ptr() if st == 2 else 0)
+                        e.synchronize()
+                        got = out[a:b].cpu().numpy() if st == 1 else lg[a:b].cpu().numpy().reshape(-1, 1)
+                        assert np.array_equal(bits(got), bits(want[a:b])), (case, trial, mode, st, a, b, opts)
+        finally:
+            e.close()
