@@ -113,7 +113,10 @@ class OracleModel:
 
     def __del__(self):
         if getattr(self, "_m", None):
-            lib().oracle_model_free(self._m)
+            try:
+                lib().oracle_model_free(self._m)
+            except TypeError:      # interpreter shutdown: the module's globals are gone, and so is the process in a moment
+                pass
             self._m = None
 
     @property
