@@ -1192,6 +1192,7 @@ int gather_view(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const floa
     so_p = gnnvc::SortedOrder();
     if (stage < 1 || stage > 3 || e->stages[stage].f != 16 || !e->opt_prune) return GNNVC_OK;
     gnnvc_engine::PrunePlan &pp = e->prune[stage];
+    if (!gathering) return GNNVC_OK;   // (a compact-table plan has this call: its kernels do not gather, nothing to build or check)
     // Built with the rest of the plans when the graph is scored a second time — but on a LARGE skewed graph (sorted tiles or
     // long rows: that is where zero rows are found) already the first time its stage runs: the passes cost less than the
     // gathers they save there (first forward R-MAT-22 6.95 -> 6.16 ms, R-MAT-24 34.5 -> 25.9 ms; R-MAT-20 and the power-law
@@ -1202,7 +1203,7 @@ int gather_view(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const floa
         int rc = timed_build(e, [&] { return build_prune_impl(e, stage, in); });
         if (rc) return rc;
     }
-    if (!pp.ready || !gathering) return GNNVC_OK;   // (a compact-table plan has this call: its kernels do not gather)
+    if (!pp.ready) return GNNVC_OK;
     HIP_TRY(e, gnnvc::prune_check(e->g, in, pp.heavy.p, e->prune_flags.p + stage, e->stream));
     gv.prp = pp.prp.p - e->g.lo();   // (indexed by global row id, like rowptr)
     gv.pcol = pp.pcol.p;

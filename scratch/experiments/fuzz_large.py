@@ -1,0 +1,60 @@
+"""The engine's own decisions at scale (GPU box): random LARGE graphs (0.3 - 4 M vertices, up to ~100 M entries) with default
+options — every threshold and plan chosen by the engine — against the same graph with every per-graph plan switched off,
+logits and scores bit for bit over four forwards.  python scratch/experiments/fuzz_large.py [cases=30] [seed0=0]"""
+import sys, pathlib, time
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
+import numpy as np, torch
+import gnn_mwvc_amd as G
+from tools import graphgen_torch as ggt
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+dev = torch.device("cuda", 0)
+PLAIN = {"lds_table": 0, "compact_gather": 0, "blocked_stage0": 0, "prune_zero_rows": 0, "giant_segments": 0, "sorted_tiles": 0,
+         "long_row_threshold": 512, "giant_row_threshold": 16384}
+INFO = ("lds_table_active", "lds_table_mapped", "compact_gather_active", "pruned_stage1", "pruned_stage2", "sorted_tiles_active", "long_rows",
+        "long_row_threshold", "giant_rows", "giant_segments", "blocked_stage0_active")
+
+
+def run(g, x, opts, reps):
+    e = G.Engine(G.default_model_text(), device=0)
+    for k, v in opts.items():
+        e.set_option(k, v)
+    e.set_weight_scale(g.ws)
+    e.attach_graph_device(g.n, g.nnz, g.rowptr.data_ptr(), g.col.data_ptr(), g.w.data_ptr(), g.nw.data_ptr(), keepalive=g)
+    sc = torch.zeros(g.n, device=dev); lg = torch.zeros(g.n, device=dev)
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(reps):
+        e.forward_device(x.data_ptr(), sc.data_ptr(), lg.data_ptr()); e.synchronize()
+        outs.append((sc.clone(), lg.clone()))
+    info = {k: e.get_info(k) for k in INFO}
+    e.close()
+    return outs, {k: v for k, v in info.items() if v}
+
+
+bad = 0
+t0 = time.time()
+for case in range(cases):
+    rng = np.random.default_rng(seed0 + case)
+    kind = rng.choice(["er", "rmat", "powerlaw", "er_dense"])
+    s = int(rng.integers(1 << 30))
+    if kind == "er":
+        n = int(rng.integers(300_000, 4_000_000)); g = ggt.erdos_renyi(n, int(n * rng.uniform(3, 14)), s, dev)
+    elif kind == "rmat":
+        g = ggt.rmat(int(rng.integers(17, 22)), int(rng.integers(4, 20)), s, dev)
+    elif kind == "powerlaw":
+        n = int(rng.integers(300_000, 3_000_000))
+        g = ggt.power_law_hubs(n, float(rng.uniform(6, 20)), float(rng.uniform(2.0, 2.5)), int(rng.integers(0, 9)), int(rng.integers(1000, 200_000)), s, dev)
+    else:
+        n = int(rng.integers(300_000, 900_000)); g = ggt.erdos_renyi(n, int(n * rng.uniform(30, 60)), s, dev)
+    x = g.x().contiguous()
+    ref, _ = run(g, x, PLAIN, 1)
+    got, info = run(g, x, {}, 4)
+    miss = [int((r[1].view(torch.int32) != ref[0][1].view(torch.int32)).sum()) + int((r[0].view(torch.int32) != ref[0][0].view(torch.int32)).sum()) for r in got]
+    tag = "MISMATCH" if any(miss) else "ok"
+    bad += any(miss)
+    print(f"{tag} case {seed0 + case} {kind} n {g.n} nnz {g.nnz}: mismatches per forward {miss}; plans {info}; {time.time() - t0:.0f} s", flush=True)
+    del g, x, ref, got
+    torch.cuda.empty_cache()
+print("done:", cases, "cases,", bad, "mismatching")
