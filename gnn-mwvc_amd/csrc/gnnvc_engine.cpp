@@ -186,6 +186,13 @@ struct gnnvc_engine {
     int opt_prune_giant = 1;         // option "prune_giant_rows" (A/B): 0 = the giant rows keep their full streams
     uint64_t opt_prune_min_nnz = 1u << 20;   // option "prune_min_entries": smaller graphs are not worth a plan
     uint32_t opt_prune_min_drop = 15;   // option "prune_min_drop_percent": build only if at least this share of the entries goes
+    // Does the device keep finding a stage's input unfit for the plan (more than its tables' columns live: low-degree graphs)?
+    // Whole forwards copy the verdicts out behind themselves; three misses in a row switch the plan off for that stage of this
+    // graph — its counting, choosing and empty launches cost up to 17 % of a forward that then gathers anyway.
+    PinBuf<uint32_t> fit_pin;
+    hipEvent_t ev_fit = nullptr;
+    bool fit_pending = false, fit_used[4] = {false, false, false, false}, c4_stage_off[4] = {false, false, false, false};
+    uint32_t c4_unfit_runs[4] = {0, 0, 0, 0};
     int c4_last_desc = 0;           // word offset in c4_desc of the plan's last launch (tests / tools)
     static constexpr int kDescWords = 16;   // per consumer stage (see k_c4_choose); the build flag follows the last stage's
 
@@ -1263,7 +1270,7 @@ int choose_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const flo
     e->c4_fused_for = -1;
     const bool may_emit = in_forward && e->c4_ready && !e->c4_mapped && !e->c4_range_mode && e->c4_base == 0 && e->c4_end == e->g.n && !longs &&
                           (size_t)stage + 1 < e->stages.size() && e->stages[stage + 1].f == 16 && lo == 0 && hi == e->g.n &&
-                          e->opt_mfma != 1;
+                          e->opt_mfma != 1 && !e->c4_stage_off[stage + 1];
     c.long_thresh = (sp.f == 16) ? e->thresh_f16 : e->long_thresh;
     c.mfma = e->opt_mfma == 1 || (e->opt_mfma == 2 && sp.f == 16);
     if (stage == 0) {
@@ -1291,7 +1298,7 @@ int choose_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const flo
             int rc = build_compact(e);
             if (rc) return rc;
         }
-        const bool whole_plan = e->c4_ready && e->c4_base == 0 && e->c4_end == e->g.n;
+        const bool whole_plan = e->c4_ready && e->c4_base == 0 && e->c4_end == e->g.n && !e->c4_stage_off[stage];
         const bool prepared = e->c4_ready && e->c4_prepared_stage == stage && e->c4_prepared_in == in &&
                               lo >= e->c4_base && hi <= e->c4_end && hi > lo;
         if (prepared && !longs && !e->c4_mapped) {
@@ -1401,6 +1408,7 @@ int launch_main(gnnvc_engine *e, const StageChoice &c, const GraphDev &gv, const
     if (c.sums == StageChoice::kCompactPrepared || c.sums == StageChoice::kCompactWhole) {
         desc = e->c4_desc.p + gnnvc_engine::kDescWords * (stage - 1);
         e->c4_last_desc = gnnvc_engine::kDescWords * (stage - 1);
+        if (c.sums == StageChoice::kCompactWhole) e->fit_used[stage] = true;
         acc4 = e->c4_acc.p;
         const bool whole = c.sums == StageChoice::kCompactWhole;
         if (whole && !c.fused_counts) HIP_TRY(e, gnnvc::column_counts(in, e->g.n, e->c4_counts.p, e->stream));
@@ -1619,7 +1627,8 @@ void gnnvc_destroy(gnnvc_engine *e) {
     e->gi_meta.release(); e->gi_off.release(); e->gi_slab.release(); e->gi_agg.release(); e->gi_segsum.release(); e->gi_segmap.release();
     e->rowptr2.release(); e->col2.release(); e->der_old_row.release(); e->der_new_of.release(); e->der_tail.release();
     e->der_tailptr.release(); e->der_tailcols.release(); e->hash_buf.release();
-    e->pin_rowptr.release(); e->pin_col.release(); e->pin_w.release(); e->pin_nw.release();
+    e->pin_rowptr.release(); e->pin_col.release(); e->pin_w.release(); e->pin_nw.release(); e->fit_pin.release();
+    if (e->ev_fit) (void)hipEventDestroy(e->ev_fit);
     e->pin_small.release();
     for (auto &r : e->srt) { r.vertex.release(); r.meta.release(); }
     e->srt_hist.release(); e->srt_sum.release();
@@ -1713,6 +1722,7 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
             *value = bad == 0 ? 1 : 0;
         }
     }
+    else if (k == "compact_gather_off_stage1" || k == "compact_gather_off_stage2") *value = e->c4_stage_off[k.back() - '0'] ? 1 : 0;
     else if (k == "compact_gather_mapped") *value = e->c4_ready && e->c4_mapped ? 1 : 0;
     else if (k == "compact_gather_blocks") *value = e->c4_ready ? (long)e->c4_nblocks : 0;
     else if (k == "compact_gather_mapped_rows") *value = e->c4_ready ? (long)e->c4_mapped_rows : 0;
@@ -1791,6 +1801,8 @@ static int adopt_uploaded(gnnvc_engine *e, uint32_t n, uint64_t nnz) {
     e->lt_ready = e->lt_tried = false;
     e->c4_ready = e->c4_tried = false;
     for (auto &pp : e->prune) pp.tried = pp.ready = false;
+    for (int s = 0; s < 4; ++s) { e->c4_stage_off[s] = false; e->c4_unfit_runs[s] = 0; e->fit_used[s] = false; }
+    e->fit_pending = false;
     e->c4_range_mode = false;
     e->c4_prepared_stage = -1;
     e->blocked_ready = false;   // the column-blocked index is built on the graph's SECOND forward:
@@ -1932,6 +1944,8 @@ static int attach_common(gnnvc_engine *e, const GraphDev &cand) {
     e->lt_ready = e->lt_tried = false;
     e->c4_ready = e->c4_tried = false;
     for (auto &pp : e->prune) pp.tried = pp.ready = false;
+    for (int s = 0; s < 4; ++s) { e->c4_stage_off[s] = false; e->c4_unfit_runs[s] = 0; e->fit_used[s] = false; }
+    e->fit_pending = false;
     e->c4_range_mode = false;
     e->c4_prepared_stage = -1;
     e->blocked_ready = false;   // the column-blocked index is built on the graph's SECOND forward:
@@ -2126,6 +2140,18 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
     const float *cur = d_x;
     e->c4_fused_for = -1;
     e->c4_prepared_stage = -1;
+    if (e->fit_pending && hipEventQuery(e->ev_fit) == hipSuccess) {   // the previous forward's verdicts have arrived
+        e->fit_pending = false;
+        for (int s = 1; s <= 2; ++s) {
+            if (!e->fit_used[s]) continue;
+            // (a stage whose statistics were to come from a producer that itself fell back had no chance: not its miss)
+            if (s == 2 && e->fit_used[1] && e->fit_pin.p[0] == 0u) continue;
+            e->c4_unfit_runs[s] = e->fit_pin.p[s - 1] == 0u ? e->c4_unfit_runs[s] + 1 : 0u;
+            if (e->c4_unfit_runs[s] >= 3u) e->c4_stage_off[s] = true;
+        }
+    }
+    if (!e->fit_pending)
+        for (int s = 0; s < 4; ++s) e->fit_used[s] = false;
     if (e->opt_ktrace && e->ktrace.used < 16384) {   // records pile up over forwards until gnnvc_kernel_trace reads them
         e->ktrace.stream = e->stream;
         gnnvc::set_kernel_trace(&e->ktrace);
@@ -2142,6 +2168,15 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
     gnnvc::set_kernel_trace(nullptr);
     if (rc) return rc;
     e->ev_count = (int)ns + 1;
+    if (!e->fit_pending && (e->fit_used[1] || e->fit_used[2]) && e->c4_ready && e->c4_desc.p) {   // this forward's verdicts, copied out behind it
+        if (!e->ev_fit) HIP_TRY(e, hipEventCreateWithFlags(&e->ev_fit, hipEventDisableTiming));
+        HIP_TRY(e, e->fit_pin.reserve(4));
+        for (int s = 1; s <= 2; ++s)
+            HIP_TRY(e, hipMemcpyAsync(e->fit_pin.p + (s - 1), e->c4_desc.p + gnnvc_engine::kDescWords * (s - 1), sizeof(uint32_t),
+                                      hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipEventRecord(e->ev_fit, e->stream));
+        e->fit_pending = true;
+    }
     return GNNVC_OK;
 }
 

@@ -28,9 +28,14 @@ def run(g, x, opts, reps):
     for _ in range(reps):
         e.forward_device(x.data_ptr(), sc.data_ptr(), lg.data_ptr()); e.synchronize()
         outs.append((sc.clone(), lg.clone()))
+    t = time.perf_counter()
+    for _ in range(5):
+        e.forward_device(x.data_ptr(), sc.data_ptr(), lg.data_ptr())
+    e.synchronize()
+    ms = (time.perf_counter() - t) * 200.0
     info = {k: e.get_info(k) for k in INFO}
     e.close()
-    return outs, {k: v for k, v in info.items() if v}
+    return outs, {k: v for k, v in info.items() if v}, ms
 
 
 bad = 0
@@ -49,12 +54,12 @@ for case in range(cases):
     else:
         n = int(rng.integers(300_000, 900_000)); g = ggt.erdos_renyi(n, int(n * rng.uniform(30, 60)), s, dev)
     x = g.x().contiguous()
-    ref, _ = run(g, x, PLAIN, 1)
-    got, info = run(g, x, {}, 4)
+    ref, _, ms_plain = run(g, x, PLAIN, 4)
+    got, info, ms = run(g, x, {}, 4)
     miss = [int((r[1].view(torch.int32) != ref[0][1].view(torch.int32)).sum()) + int((r[0].view(torch.int32) != ref[0][0].view(torch.int32)).sum()) for r in got]
     tag = "MISMATCH" if any(miss) else "ok"
     bad += any(miss)
-    print(f"{tag} case {seed0 + case} {kind} n {g.n} nnz {g.nnz}: mismatches per forward {miss}; plans {info}; {time.time() - t0:.0f} s", flush=True)
+    print(f"{tag} case {seed0 + case} {kind} n {g.n} nnz {g.nnz}: mismatches per forward {miss}; default {ms:.3f} ms, plans off {ms_plain:.3f} ms, ratio {ms / ms_plain:.2f}; plans {info}; {time.time() - t0:.0f} s", flush=True)
     del g, x, ref, got
     torch.cuda.empty_cache()
 print("done:", cases, "cases,", bad, "mismatching")

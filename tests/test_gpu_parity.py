@@ -844,6 +844,42 @@ def test_pruned_adjacency_is_bit_identical(model_text, oracle_model, maker, mode
         e.close()
 
 
+def test_compact_gather_plan_steps_aside_for_good(model_text, oracle_model):
+    """A graph whose stage inputs never fit the plan (low degrees: more than four live columns): after three forwards in a row
+    that the device sent down the gathering kernels, the engine stops queuing the plan's counting, choosing and empty
+    launches for that stage of this graph; a new graph starts afresh.  Same logits throughout."""
+    import gnn_mwvc_amd as G
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_option("blocked_min_n", 0)
+        g = gg.erdos_renyi(30000, 120000, 77)              # 8 entries per row
+        e.set_weight_scale(g.ws)
+        oracle_model.set_weight_scale(g.ws)
+        e.upload_graph(g)
+        want = oracle_model.logits(g)
+        off = []
+        for rep in range(12):
+            _, lg = e.forward(g.x())
+            assert np.array_equal(bits(lg[:, 0]), bits(want)), rep
+            e.synchronize()
+            off.append((e.get_info("compact_gather_off_stage1"), e.get_info("compact_gather_off_stage2")))
+        assert e.get_info("compact_gather_active") == 1
+        fits = [e.get_info("compact_gather_last_ok")]
+        assert off[2] == (0, 0)                              # not before three verdicts are in
+        assert off[-1] != (0, 0), off                        # at least one stage gave up
+        g2 = gg.erdos_renyi(20000, 200000, 70)               # the graph of the plan's own test: fits
+        e.set_weight_scale(g2.ws)
+        oracle_model.set_weight_scale(g2.ws)
+        e.upload_graph(g2)
+        for rep in range(6):
+            _, lg = e.forward(g2.x())
+            assert np.array_equal(bits(lg[:, 0]), bits(oracle_model.logits(g2))), rep
+        assert e.get_info("compact_gather_off_stage1") == 0 and e.get_info("compact_gather_off_stage2") == 0
+        assert e.get_info("compact_gather_last_ok") == 1
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("maker,ncols,strays,passes_allowed,want_passes", [
     (lambda: gg.rmat(14, 8, 3), 4, 0, 3, 1),                      # skewed, four live columns: one table
     (lambda: gg.rmat(14, 8, 3), 7, 4, 3, 2),                      # seven live columns (+ strays): two tables
