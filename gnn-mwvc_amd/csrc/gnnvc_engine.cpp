@@ -112,7 +112,8 @@ struct gnnvc_engine {
     int opt_blocked = 1;            // option "blocked_stage0"
     uint32_t opt_block_cols = 0;    // option "block_cols" (0 = default)
     uint32_t opt_blocked_min_n = 1u << 20;  // below this x fits the L2s anyway
-    uint32_t opt_compact_min_n = 1u << 19;  // option "compact_min_n": the compact-table plan's own bound (the smaller of the two counts)
+    uint32_t opt_compact_min_n = 1u << 18;  // option "compact_min_n": the compact-table plan's own bound (the smaller of the two counts)
+    uint64_t opt_compact_min_nnz = 8u << 20;   // ... and its entries bound (default sizes only)
     uint32_t opt_plan_chunk_rows = 0;       // != 0: cap on the rows per chunk of the LDS-table / compact-table plans
     bool blocked_ready = false;
     bool blocked_tried = false;     // build attempted for the current graph
@@ -674,6 +675,7 @@ int build_blocked_impl(gnnvc_engine *e) {
     if (!e->opt_blocked || e->stages.empty() || e->stages[0].f != 1 || e->stages[0].variant != 0) return GNNVC_OK;
     if (g.sliced()) return GNNVC_OK;   // (the per-graph plans index whole graphs)
     if (g.n < e->opt_blocked_min_n || g.nnz == 0) return GNNVC_OK;
+    if (e->opt_blocked_min_n >= (1u << 20) && g.nnz < (uint64_t)g.n * 10) return GNNVC_OK;   // (as for the LDS-table plan: too few entries per row)
     // skewed graphs gather mostly from a few hot (hub) entries of x that stay cached anyway, and
     // the per-row accumulate passes run in lockstep to each wave's largest count: measured slower
     if (e->sorted_wanted && e->opt_blocked < 2) return GNNVC_OK;
@@ -811,6 +813,9 @@ int build_lds_table_impl(gnnvc_engine *e) {
     if (!e->opt_lds_table || e->stages.empty() || e->stages[0].f != 1 || e->stages[0].variant != 0) return GNNVC_OK;
     if (g.sliced()) return GNNVC_OK;
     if (g.n < e->opt_blocked_min_n || g.nnz == 0 || g.nnz >= (1ull << 31)) return GNNVC_OK;
+    // (every chunk streams the whole byte table whatever the rows hold: below ~10 entries per row the gathering kernel is as fast —
+    // 0.56 vs 0.50 ms per forward on an Erdős–Rényi graph of 1.1 M vertices and 8 entries per row)
+    if (e->opt_blocked_min_n >= (1u << 20) && g.nnz < (uint64_t)g.n * 10) return GNNVC_OK;
     // Skewed graphs (sorted tiles wanted, or long rows present): the plan covers the rows below the giant-row threshold, dealt
     // from the degree-sorted list to slices of equal weight, over column blocks of equal entry mass (layout_skewed_plan); the
     // giant rows keep their kernels.  "lds_table" 2 forces the consecutive-row layout onto such a graph instead (tests).
@@ -937,9 +942,11 @@ int build_compact_impl(gnnvc_engine *e, uint32_t base, uint32_t end, bool allow_
     if (!e->opt_compact || e->stages.size() < 2) return GNNVC_OK;
     for (size_t st = 1; st < e->stages.size(); ++st)
         if (e->stages[st].f != 16) return GNNVC_OK;
-    // (the 64-byte feature rows outgrow the L2s long before x does: the 16-wide stages' plan pays from half a million vertices on —
+    // (the 64-byte feature rows outgrow the L2s long before x does: the 16-wide stages' plan pays from a quarter of a million vertices on —
     // ER-1M 0.87 -> 0.58 ms per forward — the F = 1 plans from a million)
     if (g.n < std::min(e->opt_blocked_min_n, e->opt_compact_min_n) || g.nnz == 0 || g.nnz >= (1ull << 31)) return GNNVC_OK;
+    // (... and the plan's fixed ~0.1 ms per forward needs entries to earn it back: ~25 ps per entry and stage)
+    if (e->opt_blocked_min_n >= (1u << 20) && g.nnz < e->opt_compact_min_nnz) return GNNVC_OK;
     const bool skewed = e->sorted_wanted || e->n_long > 0;
     const bool mapped = skewed && e->opt_compact < 2 && e->opt_compact_skewed && allow_mapped && base == 0 && end == g.n && !g.sliced();
     if (skewed && !mapped && e->opt_compact < 2) return GNNVC_OK;

@@ -82,7 +82,9 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *                         instead of 64-byte rows from memory (default 1 = large, non-skewed graphs); bit-identical
  *   "block_cols"     n    vertices per column block (default 524288 = 2 MiB of x)
  *   "blocked_min_n"  n    graphs with fewer vertices get none of the per-graph plans of the F = 1 stage (default 2^20)
- *   "compact_min_n"  n    ... nor the compact-table plan below the smaller of this (default 2^19) and "blocked_min_n"
+ *   "compact_min_n"  n    ... nor the compact-table plan below the smaller of this (default 2^18) and "blocked_min_n"
+ *                         (with default bounds the plans also want entries: 8 Mi for the compact table, 10 per row for the
+ *                         F = 1 plans)
  *   "overlap_dense"  0|1  last stage under the compact-table plan: dense layers of one round of the sums on a second
  *                         stream, under the next round's sums (default 1; bit-identical either way)
  *   "plan_chunk_rows" n   cap on the rows per chunk of the LDS-table and compact-table plans (default 0 = what
