@@ -556,7 +556,10 @@ int find_long(gnnvc_engine *e) {
         e->srt_waste = 64.0 * (double)sum_max / (double)g.nnz;
         // below a few million entries a 16-wide stage takes tens of microseconds either way and the
         // sort (two kernels and a host round trip) costs more than it saves on a graph used once
-        e->sorted_wanted = e->opt_sorted > 0 || (e->srt_waste >= 2.0 && g.nnz >= e->opt_sorted_min_nnz);
+        // ... and where the heaviest row of a tile is short anyway (sparse degree-uniform graphs: Poisson(6) has tiles of maximum
+        // ~13 against a mean of 6 — "waste" 2.2 — and loses 35 % to the sorted order's uncoalesced rows and per-row records)
+        const double mean_tile_max = (double)sum_max / (double)((ghi - glo + 63) / 64);
+        e->sorted_wanted = e->opt_sorted > 0 || (e->srt_waste >= 2.0 && g.nnz >= e->opt_sorted_min_nnz && mean_tile_max >= 24.0);
     }
     if (!e->opt_long_thresh) return GNNVC_OK;
     // One list at the base threshold serves every stage.  With degree-sorted tiles the 16-wide
