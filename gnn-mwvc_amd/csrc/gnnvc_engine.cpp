@@ -223,7 +223,7 @@ struct gnnvc_engine {
     SortedRange srt[kSortedRanges];
     int srt_cur = -1;                  // the entry ensure_sorted selected for the call in progress
     uint64_t srt_clock = 0;
-    double srt_waste = 0.0;
+    double srt_waste = 0.0, srt_tail = 0.0;
     DevBuf<uint32_t> srt_hist;
     DevBuf<unsigned long long> srt_sum;
 
@@ -548,18 +548,26 @@ int find_long(gnnvc_engine *e) {
     const uint32_t base_thresh = e->opt_long_thresh ? e->opt_long_thresh : 0xFFFFFFFFu;
     if (e->opt_sorted != 0 && g.nnz) {
         // lockstep cost of natural 64-row tiles (64 x sum of per-tile maxima) against the useful work
-        HIP_TRY(e, e->srt_sum.reserve(1));
-        HIP_TRY(e, gnnvc::measure_tile_waste(g, glo, ghi, base_thresh, e->srt_sum.p, e->stream));
-        unsigned long long sum_max = 0;
-        HIP_TRY(e, hipMemcpyAsync(&sum_max, e->srt_sum.p, sizeof sum_max, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, e->srt_sum.reserve(2));
+        const uint32_t heavy_from = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, std::max<uint64_t>(1, 4 * g.nnz / std::max<uint32_t>(ghi - glo, 1)));
+        HIP_TRY(e, gnnvc::measure_tile_waste(g, glo, ghi, base_thresh, e->srt_sum.p, e->stream, heavy_from));
+        unsigned long long sums[2] = {0, 0};
+        HIP_TRY(e, hipMemcpyAsync(sums, e->srt_sum.p, sizeof sums, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(e, hipStreamSynchronize(e->stream));
+        const unsigned long long sum_max = sums[0];
         e->srt_waste = 64.0 * (double)sum_max / (double)g.nnz;
         // below a few million entries a 16-wide stage takes tens of microseconds either way and the
         // sort (two kernels and a host round trip) costs more than it saves on a graph used once
         // ... and where the heaviest row of a tile is short anyway (sparse degree-uniform graphs: Poisson(6) has tiles of maximum
         // ~13 against a mean of 6 — "waste" 2.2 — and loses 35 % to the sorted order's uncoalesced rows and per-row records)
         const double mean_tile_max = (double)sum_max / (double)((ghi - glo + 63) / 64);
-        e->sorted_wanted = e->opt_sorted > 0 || (e->srt_waste >= 2.0 && g.nnz >= e->opt_sorted_min_nnz && mean_tile_max >= 24.0);
+        // ... and where the graph has no heavy TAIL: a degree-uniform graph with a few hubs also shows "waste" 2.5 - 4.5, but its tiles'
+        // maxima are a few times the mean — short chains, the kernel stays bound by the fabric, and sorting costs 10 - 25 %.  What
+        // separates the families (fuzz_large.py, 130 graphs): the share of entries in non-long rows of at least 4 x the mean degree —
+        // at most 0.05 there, 0.16 and more on power-law and R-MAT graphs (sorted tiles 1.1 - 3 x faster on those).
+        e->srt_tail = (double)sums[1] / (double)g.nnz;
+        e->sorted_wanted = e->opt_sorted > 0 ||
+                           (e->srt_waste >= 2.0 && g.nnz >= e->opt_sorted_min_nnz && mean_tile_max >= 24.0 && e->srt_tail >= 0.10);
     }
     if (!e->opt_long_thresh) return GNNVC_OK;
     // One list at the base threshold serves every stage.  With degree-sorted tiles the 16-wide
@@ -1769,6 +1777,7 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
     else if (k == "mfma_dense") *value = e->opt_mfma;
     else if (k == "sorted_tiles_active") *value = e->sorted_wanted ? 1 : 0;
     else if (k == "tile_waste_x100") *value = (long)(e->srt_waste * 100.0);
+    else if (k == "heavy_tail_x1000") *value = (long)(e->srt_tail * 1000.0);
     else if (k == "interleaved_tiles") *value = e->interleave ? 1 : 0;
     else if (k == "long_row_threshold") *value = e->n_long ? (long)e->long_thresh : 0;
     else return GNNVC_ERR_INVALID;

@@ -108,7 +108,7 @@ hipError_t launch_dense_sigmoid(const StagePlan &sp, const GraphDev &g, float ws
 // Building blocks of the degree-sorted order (the prefix over the few thousand degree classes
 // is done on the host).
 hipError_t measure_tile_waste(const GraphDev &g, uint32_t row_lo, uint32_t row_hi, uint32_t long_thresh,
-                              unsigned long long *sum_max, hipStream_t stream);
+                              unsigned long long *sum_max /* [2] */, hipStream_t stream, uint32_t heavy_from = 0xFFFFFFFFu);
 // (degree_*: g.rowptr decides a row's class; skip_rowptr != nullptr: rows with skip_rowptr[u + 1] - skip_rowptr[u] >= skip_from
 // are left out as well — the giant rows when g.rowptr is a pruned adjacency's)
 hipError_t degree_histogram(const GraphDev &g, uint32_t row_lo, uint32_t row_hi, uint32_t long_thresh,

@@ -2497,11 +2497,13 @@ __global__ __launch_bounds__(256) void k_prune_check(GraphDev g, const float4 *_
 // (built once per graph and row range when natural tiles would waste most of their rounds)
 // lockstep cost of natural tiles: sum over tiles of the tile's largest (non-long) degree
 __global__ __launch_bounds__(256) void k_tile_waste(GraphDev g, uint32_t row_lo, uint32_t row_hi,
-                                                    uint32_t long_thresh, unsigned long long *__restrict__ sum_max) {
-    // one wave = one 64-row tile per trip; per-wave sums, one atomic per block (every wave hitting the
-    // same 8 bytes with its own atomic cost 1.9 ms on the metric graph)
-    __shared__ unsigned long long part[4];
-    unsigned long long mine = 0;
+                                                    uint32_t long_thresh, unsigned long long *__restrict__ sum_max,
+                                                    uint32_t heavy_from) {
+    // sum_max[0] += the tiles' largest (non-long) degrees; sum_max[1] += the entries of the non-long rows of at least heavy_from
+    // entries (how much of the graph sits in a heavy tail).  One wave = one 64-row tile per trip; per-wave sums, one atomic per
+    // block (every wave hitting the same 8 bytes with its own atomic cost 1.9 ms on the metric graph)
+    __shared__ unsigned long long part[4], tail[4];
+    unsigned long long mine = 0, heavy = 0;
     const uint32_t ntiles = (row_hi - row_lo + 63) / 64;
     for (uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6); t < ntiles; t += gridDim.x * 4) {
         const uint32_t u = row_lo + t * 64 + (threadIdx.x & 63);
@@ -2510,18 +2512,25 @@ __global__ __launch_bounds__(256) void k_tile_waste(GraphDev g, uint32_t row_lo,
             d = g.rowptr[u + 1] - g.rowptr[u];
             if (d >= long_thresh) d = 0;
         }
+        uint32_t h = d >= heavy_from ? d : 0u;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const uint32_t o = __shfl_xor(d, off);
             d = o > d ? o : d;
+            h += __shfl_xor(h, off);
         }
         mine += d;
+        heavy += h;
     }
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;
+    if ((threadIdx.x & 63) == 0) {
+        part[threadIdx.x >> 6] = mine;
+        tail[threadIdx.x >> 6] = heavy;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned long long s = part[0] + part[1] + part[2] + part[3];
+        const unsigned long long s = part[0] + part[1] + part[2] + part[3], h = tail[0] + tail[1] + tail[2] + tail[3];
         if (s) atomicAdd(sum_max, s);
+        if (h) atomicAdd(sum_max + 1, h);
     }
 }
 
@@ -3649,11 +3658,12 @@ hipError_t compact_fix(const GraphDev &g, const float *in, const uint32_t *desc,
 
 // ---- degree-sorted tile order ------------------------------------------------------------
 hipError_t measure_tile_waste(const GraphDev &g, uint32_t row_lo, uint32_t row_hi, uint32_t long_thresh,
-                              unsigned long long *sum_max, hipStream_t stream) {
-    hipError_t rc = hipMemsetAsync(sum_max, 0, sizeof(unsigned long long), stream);
+                              unsigned long long *sum_max /* [2]: tile maxima, entries of the heavy rows */, hipStream_t stream,
+                              uint32_t heavy_from) {
+    hipError_t rc = hipMemsetAsync(sum_max, 0, 2 * sizeof(unsigned long long), stream);
     if (rc != hipSuccess || row_hi <= row_lo) return rc;
     GNNVC_LAUNCH(k_tile_waste, dim3(std::min<unsigned>((row_hi - row_lo + 255) / 256, 2048u)), dim3(256), 0, stream, g,
-                       row_lo, row_hi, long_thresh, sum_max);
+                       row_lo, row_hi, long_thresh, sum_max, heavy_from);
     return hipGetLastError();
 }
 

@@ -13,7 +13,7 @@ big = len(sys.argv) > 3 and sys.argv[3] == "big"   # 3 - 12 M vertices, up to ~2
 dev = torch.device("cuda", 0)
 PLAIN = {"lds_table": 0, "compact_gather": 0, "blocked_stage0": 0, "prune_zero_rows": 0, "giant_segments": 0, "sorted_tiles": 0,
          "long_row_threshold": 512, "giant_row_threshold": 16384}
-INFO = ("lds_table_active", "lds_table_mapped", "compact_gather_active", "pruned_stage1", "pruned_stage2", "sorted_tiles_active", "long_rows",
+INFO = ("tile_waste_x100", "lds_table_active", "lds_table_mapped", "compact_gather_active", "pruned_stage1", "pruned_stage2", "sorted_tiles_active", "long_rows",
         "long_row_threshold", "giant_rows", "giant_segments", "blocked_stage0_active")
 
 
@@ -43,7 +43,7 @@ bad = 0
 t0 = time.time()
 for case in range(cases):
     rng = np.random.default_rng(seed0 + case)
-    kind = rng.choice(["er", "rmat", "powerlaw", "er_dense"])
+    kind = rng.choice(["er", "rmat", "powerlaw", "er_dense", "uniform_hubs"])
     s = int(rng.integers(1 << 30))
     if kind == "er":
         n = int(rng.integers(4_000_000, 12_000_000) if big else rng.integers(300_000, 4_000_000)); g = ggt.erdos_renyi(n, int(n * rng.uniform(3, 14)), s, dev)
@@ -52,15 +52,27 @@ for case in range(cases):
     elif kind == "powerlaw":
         n = int(rng.integers(3_000_000, 8_000_000) if big else rng.integers(300_000, 3_000_000))
         g = ggt.power_law_hubs(n, float(rng.uniform(6, 20)), float(rng.uniform(2.0, 2.5)), int(rng.integers(0, 9)), int(rng.integers(1000, 200_000)), s, dev)
+    elif kind == "uniform_hubs":   # nearly degree-uniform + a few hubs
+        n = int(rng.integers(3_000_000, 8_000_000) if big else rng.integers(300_000, 3_000_000))
+        g = ggt.power_law_hubs(n, float(rng.uniform(8, 24)), float(rng.uniform(3.5, 5.0)), int(rng.integers(1, 9)), int(rng.integers(5000, 300_000)), s, dev)
     else:
         n = int(rng.integers(1_000_000, 2_500_000) if big else rng.integers(300_000, 900_000)); g = ggt.erdos_renyi(n, int(n * rng.uniform(30, 60)), s, dev)
     x = g.x().contiguous()
+    deg = (g.rowptr[1:] - g.rowptr[:-1]).to(torch.float64)[: g.n]
+    mean = float(deg.sum()) / g.n
+    tails = {f"tail{k}": round(float(deg[(deg >= k * mean) & (deg < 512)].sum() / deg.sum()), 3) for k in (2, 4, 8)}
     ref, _, ms_plain = run(g, x, PLAIN, 4)
     got, info, ms = run(g, x, {}, 4)
+    extra = ""
+    if len(sys.argv) > 4:      # a second set of options to compare with: key=value,key=value
+        alt = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in sys.argv[4].split(",")}
+        got2, info2, ms2 = run(g, x, alt, 4)
+        m2 = sum(int((r[1].view(torch.int32) != ref[0][1].view(torch.int32)).sum()) for r in got2)
+        extra = f" alt {ms2:.3f} ms ({m2} mismatches) alt/default {ms2 / ms:.2f};"
     miss = [int((r[1].view(torch.int32) != ref[0][1].view(torch.int32)).sum()) + int((r[0].view(torch.int32) != ref[0][0].view(torch.int32)).sum()) for r in got]
     tag = "MISMATCH" if any(miss) else "ok"
     bad += any(miss)
-    print(f"{tag} case {seed0 + case} {kind} n {g.n} nnz {g.nnz}: mismatches per forward {miss}; default {ms:.3f} ms, plans off {ms_plain:.3f} ms, ratio {ms / ms_plain:.2f}; plans {info}; {time.time() - t0:.0f} s", flush=True)
+    print(f"{tag} case {seed0 + case} {kind} n {g.n} nnz {g.nnz}: mismatches per forward {miss}; default {ms:.3f} ms, plans off {ms_plain:.3f} ms, ratio {ms / ms_plain:.2f};{extra} tails {tails}; plans {info}; {time.time() - t0:.0f} s", flush=True)
     del g, x, ref, got
     torch.cuda.empty_cache()
 print("done:", cases, "cases,", bad, "mismatching")
