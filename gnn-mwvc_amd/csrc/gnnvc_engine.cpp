@@ -166,7 +166,7 @@ struct gnnvc_engine {
     // pruned adjacency of the 16-wide stages (kernels: k_prune_*), one per consumer stage: built from the input the stage
     // sees the second time the graph is scored; every later call proves on the device that its input still fits
     struct PrunePlan {
-        bool tried = false, ready = false;
+        bool tried = false, ready = false, deferred = false;
         uint32_t bound = 0, observed = 0;   // vertices of degree >= bound are expected to have all-zero rows (largest degree seen with a non-zero row)
         uint64_t kept = 0;                  // entries left
         uint64_t members = 0;               // vertices in the set
@@ -1127,7 +1127,7 @@ int ensure_round_events(gnnvc_engine *e, size_t count) {
 }
 
 // Pruned adjacency for consumer stage `stage` (see k_prune_*): built once per graph from the input `in` of the call at hand.
-int build_prune_impl(gnnvc_engine *e, int stage, const float *in) {
+int build_prune_impl(gnnvc_engine *e, int stage, const float *in, bool early) {
     gnnvc_engine::PrunePlan &pp = e->prune[stage];
     pp.tried = true;
     pp.ready = false;
@@ -1169,6 +1169,22 @@ int build_prune_impl(gnnvc_engine *e, int stage, const float *in) {
         for (uint32_t w : bits) members += (uint64_t)__builtin_popcount(w);
         pp.members = members;
         if (members == 0) {
+            pp.heavy.release();
+            return GNNVC_OK;
+        }
+    }
+    if (!g.sliced()) {   // a cheap look before the passes over the entries: the degrees of the set's vertices ~ the entries that would go
+        unsigned long long mass = 0;
+        HIP_TRY(e, gnnvc::prune_mass(g, pp.heavy.p, reinterpret_cast<unsigned long long *>(e->prune_mask.p), e->stream));
+        HIP_TRY(e, hipMemcpyAsync(&mass, e->prune_mask.p, sizeof mass, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        if (mass * 100 < g.nnz * (uint64_t)std::min(e->opt_prune_min_drop, 100u) / 2) {   // (half the bound: the estimate is exact only for symmetric graphs)
+            pp.heavy.release();
+            return GNNVC_OK;
+        }
+        if (early && mass * 100 < g.nnz * 40ull) {   // in a graph's FIRST forward the build has to pay within that forward: not at a 15 - 25 % cut
+            pp.tried = false;                         // (nearly degree-uniform graphs with hubs: first forward 1.1 - 1.2 x) — with the other plans, then
+            pp.deferred = true;
             pp.heavy.release();
             return GNNVC_OK;
         }
@@ -1223,9 +1239,10 @@ int gather_view(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const floa
     // gathers they save there (first forward R-MAT-22 6.95 -> 6.16 ms, R-MAT-24 34.5 -> 25.9 ms; R-MAT-20 and the power-law
     // graph lose 0.3 - 0.5 ms to the fixed costs, hence the size bound).
     const bool early = (e->sorted_wanted || e->n_long > 0) && e->opt_prune_early_nnz && e->g.nnz >= e->opt_prune_early_nnz;
-    const uint32_t uses_needed = early ? 1u : 2u;
+    const uint32_t uses_needed = (early && !pp.deferred) ? 1u : 2u;
     if (!pp.tried && e->graph_uses >= uses_needed) {
-        int rc = timed_build(e, [&] { return build_prune_impl(e, stage, in); });
+        const bool first_forward = e->graph_uses < 2;
+        int rc = timed_build(e, [&] { return build_prune_impl(e, stage, in, first_forward); });
         if (rc) return rc;
     }
     if (!pp.ready) return GNNVC_OK;
@@ -1819,7 +1836,7 @@ static int adopt_uploaded(gnnvc_engine *e, uint32_t n, uint64_t nnz) {
     if (rc) return rc;
     e->lt_ready = e->lt_tried = false;
     e->c4_ready = e->c4_tried = false;
-    for (auto &pp : e->prune) pp.tried = pp.ready = false;
+    for (auto &pp : e->prune) pp.tried = pp.ready = pp.deferred = false;
     for (int s = 0; s < 4; ++s) { e->c4_stage_off[s] = false; e->c4_unfit_runs[s] = 0; e->fit_used[s] = false; }
     e->fit_pending = false;
     e->c4_range_mode = false;
@@ -1962,7 +1979,7 @@ static int attach_common(gnnvc_engine *e, const GraphDev &cand) {
     if (rc) return rc;
     e->lt_ready = e->lt_tried = false;
     e->c4_ready = e->c4_tried = false;
-    for (auto &pp : e->prune) pp.tried = pp.ready = false;
+    for (auto &pp : e->prune) pp.tried = pp.ready = pp.deferred = false;
     for (int s = 0; s < 4; ++s) { e->c4_stage_off[s] = false; e->c4_unfit_runs[s] = 0; e->fit_used[s] = false; }
     e->fit_pending = false;
     e->c4_range_mode = false;

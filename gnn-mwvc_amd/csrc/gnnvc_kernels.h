@@ -218,6 +218,8 @@ hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_
 hipError_t prune_observe(const GraphDev &g, const float *feat, uint32_t *max_deg, hipStream_t stream);
 hipError_t prune_mark_degree(const GraphDev &g, uint32_t bound, uint32_t *heavy_bits, hipStream_t stream);
 hipError_t prune_mark_zero(const GraphDev &g, const float *feat, uint32_t *heavy_bits, hipStream_t stream);
+// *mass = sum of the degrees of the set's vertices (whole graphs: the entries that point to them, if the adjacency is symmetric)
+hipError_t prune_mass(const GraphDev &g, const uint32_t *heavy_bits, unsigned long long *mass, hipStream_t stream);
 hipError_t prune_count(const GraphDev &g, const uint32_t *heavy_bits, unsigned long long *mask, uint32_t *off, uint32_t *scratch,
                        hipStream_t stream);
 hipError_t prune_fill(const GraphDev &g, const unsigned long long *mask, const uint32_t *off, uint32_t *pcol, uint32_t *prp,

@@ -2429,6 +2429,17 @@ __global__ __launch_bounds__(256) void k_prune_mark_zero(const float4 *__restric
     if ((threadIdx.x & 63) == 1 && w0 + 1 < words) heavy_bits[w0 + 1] = (uint32_t)(m >> 32);
 }
 
+// *mass += the degrees of the set's vertices: on a symmetric adjacency, the entries that point to them
+__global__ __launch_bounds__(256) void k_prune_mass(GraphDev g, const uint32_t *__restrict__ heavy_bits, unsigned long long *__restrict__ mass) {
+    unsigned long long mine = 0;
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < g.n; u += gridDim.x * blockDim.x)
+        if (heavy_bits[u >> 5] >> (u & 31) & 1u) mine += g.rowptr[u + 1] - g.rowptr[u];
+#pragma unroll
+    for (int off = 32; off; off >>= 1)
+        mine += ((unsigned long long)__shfl_xor((unsigned)(mine >> 32), off) << 32) | __shfl_xor((unsigned)mine, off);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(mass, mine);
+}
+
 // Building the pruned CSR: the engine's entries taken FLAT, in chunks of 64 (one wave trip), whatever rows they belong to —
 // a skewed graph's work is then balanced by construction (a first version walked 64-row tiles: R-MAT's hubs share a few
 // tiles, 19 ms per pass on R-MAT-22).  Kept entries keep their flat order, which is the CSR order of every row.
@@ -3491,6 +3502,13 @@ hipError_t prune_mark_zero(const GraphDev &g, const float *feat, uint32_t *heavy
 
 // mask: one 64-bit word per chunk of 64 entries, off: chunks + 1 words (scanned in place: off[chunks] = kept entries;
 // scratch as for blocked_scan_scratch_elems(chunks + 1))
+hipError_t prune_mass(const GraphDev &g, const uint32_t *heavy_bits, unsigned long long *mass, hipStream_t stream) {
+    hipError_t rc = hipMemsetAsync(mass, 0, sizeof(unsigned long long), stream);
+    if (rc != hipSuccess || g.n == 0) return rc;
+    GNNVC_LAUNCH(k_prune_mass, dim3(std::min<unsigned>((g.n + 255) / 256, 2048u)), dim3(256), 0, stream, g, heavy_bits, mass);
+    return hipGetLastError();
+}
+
 hipError_t prune_count(const GraphDev &g, const uint32_t *heavy_bits, unsigned long long *mask, uint32_t *off, uint32_t *scratch,
                        hipStream_t stream) {
     if (g.nnz == 0 || g.nnz >= (1ull << 32)) return hipErrorInvalidValue;
