@@ -456,6 +456,10 @@ def main() -> int:
                                      "steps": eng.get_info("compact_gather_steps"), "rows": eng.get_info("compact_gather_mapped_rows"),
                                      "entries": eng.get_info("compact_gather_mapped_entries")},
              "lds_table_stage0": bool(eng.get_info("lds_table_active")),
+             "lds_table_skewed_layout": bool(eng.get_info("lds_table_mapped")),
+             "compact_gather_switched_off": [bool(eng.get_info("compact_gather_off_stage1")), bool(eng.get_info("compact_gather_off_stage2"))],
+             "heavy_tail_share": eng.get_info("heavy_tail_x1000") / 1000.0,
+             "giant_stream_segments": eng.get_info("giant_segments"),
              "blocked_stage0": bool(eng.get_info("blocked_stage0_active")),
              "column_blocks": eng.get_info("blocked_blocks"), "block_cols": eng.get_info("block_cols"),
              "mfma_dense": eng.get_info("mfma_dense"),
