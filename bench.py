@@ -11,10 +11,11 @@ fixed, so scaling is "strong".
 
 What the ONE JSON line on rank 0 says (contract in the project brief, read as VERDICT r1 asked):
   value / ms_per_step   the STEADY STATE of a graph that is scored again and again: the engine builds per-graph
-                        plans inside a graph's second and third forward, the timed region starts after them.
+                        plans inside a graph's first forwards, the timed region starts after them.
   first_forward_ms      what a caller gets who hands over a fresh graph and scores it once — the reference's own
-                        driver does that (src/GNN_VC.cpp:171-192) — plus second / third forward (which build the
-                        plans, plan_build_ms) and plain_forward_ms (steady state with the plans switched off).
+                        driver does that (src/GNN_VC.cpp:171-192); on graphs of 128 Mi entries and more it builds and
+                        uses the 16-wide stages' plan already — plus second / third forward (the second builds the rest
+                        of the plans; plan_build_ms = all builds) and plain_forward_ms (steady state, plans switched off).
   roofline              frac = the forward-level fraction of SURVEY.md §8d: (288 E + 300 N) algorithmic bytes /
                         ms_per_step / 8 TB/s.  dominant_kernel: the kernel with the largest share of a forward, its
                         HIP-event time (events on the launch stream, every timed step), its own algorithmic bytes
@@ -477,7 +478,7 @@ def main() -> int:
         "mode": "fast" if args.hub_mode else "exact",
         "config": {"workload": workload_desc, "vertices": n, "edges": n_edges,
                    "graph": args.workload, "partition": f"1d-vertex x{world} ({part_mode}-balanced)",
-                   "timed_state": "steady state of a graph scored repeatedly: per-graph plans built in its 2nd / 3rd forward, "
+                   "timed_state": "steady state of a graph scored repeatedly: per-graph plans built in its first two forwards, "
                                   "before the warm-up; see first_forward_ms for a graph scored once",
                    "csr_bytes_per_rank": csr_bytes_rank, "csr_bytes_whole_graph": csr_bytes_full,
                    "exchange": "none" if not multi else "all-gather of the N feature rows (16 fp32, or only their live "

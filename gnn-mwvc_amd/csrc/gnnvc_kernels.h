@@ -206,9 +206,9 @@ hipError_t lds_table_steps(const GraphDev &g, uint32_t rows_per_chunk, uint32_t 
                            uint32_t block_cols = 0 /* the step descriptors' fourth word: the block's first column */,
                            const PlanMap &pm = PlanMap());
 hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t block_cols,
-                             const uint32_t *seg_cnt, uint32_t *entries, hipStream_t stream, uint32_t shift = 17,
-                             uint32_t row_base = 0, uint32_t row_end = 0xFFFFFFFFu, uint32_t slack = 0,
-                             const PlanMap &pm = PlanMap());
+                             const uint32_t *seg_cnt, uint32_t *entries, hipStream_t stream, uint32_t shift,
+                             uint32_t row_base, uint32_t row_end, uint32_t slack, const PlanMap &pm,
+                             uint32_t *bad);   // *bad |= 2 if a row's blocks do not ascend (the flat walk checks here, not in the count pass)
 // Pruned adjacency (k_prune_*).  observe = largest degree among the vertices with a non-zero row of feat (16 columns).
 // The set of vertices whose rows are taken to be all zero, as a bitmap: mark_degree (degree >= bound) or mark_zero (the rows
 // that ARE all zero in feat).  count = per chunk of 64 entries which are kept (mask) and, scanned in place, how many before

@@ -47,6 +47,7 @@ for case in range(cases):
     opts["mfma_dense"] = int(rng.choice([0, 1, 2]))
     opts["overlap_dense"] = int(rng.choice([0, 1]))
     if rng.random() < 0.3: opts["plan_chunk_rows"] = int(rng.choice([16, 48, 256, 4096]))
+    if rng.random() < 0.5: opts["compact_first_forward_entries"] = 1   # the 16-wide stages' plan built inside the first forward
     e = G.Engine(G.default_model_text(), device=0)
     try:
         for k, v in opts.items():
