@@ -1543,9 +1543,6 @@ __device__ __forceinline__ unsigned long long lanes_upto(uint32_t lane) {   // b
 // CSR offsets in LDS.
 constexpr uint32_t kLtFlatRows = 2048;
 constexpr uint32_t kLtTrips = 4;
-__device__ __forceinline__ bool lt_flat_walk(const PlanMap &pm, uint32_t rows) {
-    return !pm.rowmap && !pm.bstart && rows <= kLtFlatRows;
-}
 // first row of wave w's share: the first row that starts at or after w / nwaves of the chunk's entries
 __device__ __forceinline__ uint32_t lt_wave_cut(const uint32_t *rp, uint32_t nr, uint32_t w, uint32_t nwaves) {
     if (w >= nwaves) return nr;
@@ -1581,45 +1578,12 @@ __global__ __launch_bounds__(1024) void k_lt_count(GraphDev g, uint32_t rows_per
     __shared__ uint32_t longrow[kLtLongCap];
     __shared__ uint32_t nlong;
     const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t nthreads = blockDim.x, nwaves = nthreads >> 6;   // (a multiple of 64)
-    const uint32_t r0 = min(row_end, row_base + c * rows_per_chunk), r1 = pm.rowmap ? r0 + rows_per_chunk : min(row_end, r0 + rows_per_chunk);
-    const bool flat = lt_flat_walk(pm, r1 - r0);
-    for (uint32_t i = tid; i < nblocks; i += nthreads) hist[i] = 0;
+    for (uint32_t i = tid; i < nblocks; i += 1024) hist[i] = 0;
     if (tid == 0) nlong = 0;
     __syncthreads();
+    const uint32_t r0 = min(row_end, row_base + c * rows_per_chunk), r1 = pm.rowmap ? r0 + rows_per_chunk : min(row_end, r0 + rows_per_chunk);
     bool unsorted = false;
-    if (flat) {
-        // Consecutive rows, uniform blocks: the chunk's entries are one CSR range — every wave walks an equal share of it, 64
-        // entries a trip, coalesced.  (Whether a row's blocks ascend is checked by the scatter pass, which knows the rows.)
-        const uint32_t es = g.rowptr[r0], all = g.rowptr[r1] - es;
-        const uint32_t ee = es + (uint32_t)((uint64_t)all * (wave + 1u) / nwaves);
-        const uint32_t magic = block_cols > 1u ? (uint32_t)(0x100000000ull / block_cols) : 0u;
-        for (uint32_t eg = es + (uint32_t)((uint64_t)all * wave / nwaves); eg < ee; eg += 64 * kLtTrips) {   // kLtTrips trips' loads in flight at once
-            uint32_t colv[kLtTrips];
-#pragma unroll
-            for (uint32_t j = 0; j < kLtTrips; ++j) {
-                const uint32_t e = eg + 64 * j + lane;
-                colv[j] = e < ee ? g.col[e] : 0u;
-            }
-#pragma unroll
-            for (uint32_t j = 0; j < kLtTrips; ++j) {
-                const uint32_t e0 = eg + 64 * j, e = e0 + lane;
-                if (e0 >= ee) break;                   // (uniform)
-                const bool in = e < ee;
-                const uint32_t b = in ? lt_div(colv[j], block_cols, magic) : 0xFFFFFFFFu;
-                const uint32_t bp = lane_prev(b);
-                const bool head = in && (lane == 0 || b != bp);   // (a trip's first entry always starts a count of its own)
-                const unsigned long long hm = __ballot(head);
-                const uint32_t nin = min(64u, ee - e0);
-                if (head) {
-                    const unsigned long long later = hm & ~lanes_upto(lane);
-                    const uint32_t nh = later ? (uint32_t)__builtin_ctzll(later) : nin;
-                    atomicAdd(&hist[b], nh - lane);
-                }
-            }
-        }
-    }
-    for (uint32_t i = tid; !flat && i < r1 - r0; i += nthreads) {   // short rows: a thread each; long ones are listed for the waves
+    for (uint32_t i = tid; i < r1 - r0; i += 1024) {   // short rows: a thread each; long ones are listed for the waves
         const uint32_t u = lt_row(pm, c, rows_per_chunk, r0, i);
         if (u >= row_end) continue;
         const uint32_t rs = g.rowptr[u], re = g.rowptr[u + 1];
@@ -1641,7 +1605,7 @@ __global__ __launch_bounds__(1024) void k_lt_count(GraphDev g, uint32_t rows_per
         if (run) atomicAdd(&hist[prev], run);
     }
     __syncthreads();
-    for (uint32_t k = wave; k < nlong; k += nwaves) {  // a long row: 64 entries a trip, one LDS add per run of equal blocks
+    for (uint32_t k = wave; k < nlong; k += 16) {      // a long row: 64 entries a trip, one LDS add per run of equal blocks
         const uint32_t u = longrow[k];
         const uint32_t rs = g.rowptr[u], re = g.rowptr[u + 1];
         uint32_t carry = 0;                            // block of the previous trip's last entry (blocks must not descend)
@@ -1664,7 +1628,7 @@ __global__ __launch_bounds__(1024) void k_lt_count(GraphDev g, uint32_t rows_per
         }
     }
     __syncthreads();
-    for (uint32_t i = tid; i < nblocks; i += nthreads) seg_cnt[(size_t)c * nblocks + i] = hist[i];
+    for (uint32_t i = tid; i < nblocks; i += 1024) seg_cnt[(size_t)c * nblocks + i] = hist[i];
     if (__any(unsorted) && (tid & 63) == 0) atomicOr(bad, 2u);
 }
 
@@ -1710,133 +1674,27 @@ __global__ __launch_bounds__(256) void k_lt_steps(GraphDev g, uint32_t rows_per_
 }
 
 // regroup the chunk's CSR entries by column block: entries[...] = row_local << 17 | col_local; a row's
-// entries of one block are written as one adjacent run, in order (the order among rows is free).
-// The regrouped range of a chunk is put together in LDS (`stage_cap` words of dynamic LDS) and written out in one
-// coalesced sweep (scattered 4-byte stores run into the fabric's ~50 G requests/s like the gathers do); a chunk whose
-// range is longer than the staging area stores directly.
-extern __shared__ uint32_t lt_stage[];
+// entries of one block are written as one adjacent run, in order (the order among rows is free)
 __global__ __launch_bounds__(1024) void k_lt_scatter(GraphDev g, uint32_t rows_per_chunk, uint32_t nblocks, uint32_t block_cols,
                                                      uint32_t shift, const uint32_t *__restrict__ seg_cnt,
                                                      uint32_t *__restrict__ entries, uint32_t row_base, uint32_t row_end,
-                                                     uint32_t slack, PlanMap pm, uint32_t stage_cap, uint32_t *bad) {
+                                                     uint32_t slack, PlanMap pm) {
     __shared__ uint32_t cursor[4096];
     __shared__ uint32_t longrow[kLtLongCap];   // slot index in the slice
-    __shared__ uint32_t rp[kLtFlatRows + 1];
-    __shared__ uint32_t nlong, range_end;
-    __shared__ uint32_t wave_sum[16];
+    __shared__ uint32_t nlong;
     const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t nthreads = blockDim.x, nwaves = nthreads >> 6;   // (a multiple of 64)
     const uint32_t r0 = min(row_end, row_base + c * rows_per_chunk), r1 = pm.rowmap ? r0 + rows_per_chunk : min(row_end, r0 + rows_per_chunk);
-    const uint32_t first = lt_chunk_first(g, c, rows_per_chunk, row_base, row_end, slack, pm.first);
-    const bool flat = lt_flat_walk(pm, r1 - r0);
-    bool unsorted = false;
-    if (flat)
-        for (uint32_t i = tid; i <= r1 - r0; i += nthreads) rp[i] = g.rowptr[r0 + i];
-    {   // cursor[b] = first + exclusive scan of the (padded) counts: thread t takes blocks [t * per, (t + 1) * per)
-        const uint32_t per = (nblocks + nthreads - 1) / nthreads, b0 = tid * per;
-        const uint32_t *cnt = seg_cnt + (size_t)c * nblocks;
-        uint32_t local = 0;
-        for (uint32_t k = 0; k < per && b0 + k < nblocks; ++k) local += slack ? (cnt[b0 + k] + 3u) & ~3u : cnt[b0 + k];
-        uint32_t incl = local;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = __shfl_up(incl, off);
-            if ((int)lane >= off) incl += t;
+    if (tid == 0) {   // exclusive scan of <= 4096 counts: a few microseconds, once per graph
+        uint32_t run = lt_chunk_first(g, c, rows_per_chunk, row_base, row_end, slack, pm.first);
+        for (uint32_t b = 0; b < nblocks; ++b) {
+            cursor[b] = run;
+            run += seg_cnt[(size_t)c * nblocks + b];
+            if (slack) run = (run + 3u) & ~3u;
         }
-        if (lane == 63) wave_sum[wave] = incl;
-        if (tid == 0) nlong = 0;
-        __syncthreads();
-        uint32_t run = first + incl - local;
-        for (uint32_t w = 0; w < wave; ++w) run += wave_sum[w];
-        for (uint32_t k = 0; k < per && b0 + k < nblocks; ++k) {
-            cursor[b0 + k] = run;
-            run += slack ? (cnt[b0 + k] + 3u) & ~3u : cnt[b0 + k];
-        }
-        if (tid == nthreads - 1) range_end = run;
-        __syncthreads();
+        nlong = 0;
     }
-    const uint32_t span = range_end - first;
-    const bool staged = span <= stage_cap;             // (uniform over the workgroup)
-    if (staged) {
-        for (uint32_t i = tid; i < span; i += nthreads) lt_stage[i] = 0;   // (pad slots are read, never used)
-        __syncthreads();
-    }
-    auto put = [&](uint32_t pos, uint32_t v) {
-        if (staged) lt_stage[pos - first] = v;
-        else entries[pos] = v;
-    };
-    if (flat) {
-        // Consecutive rows, uniform blocks: every wave walks an equal share of the chunk's CSR range (cut at row boundaries)
-        // 64 entries a trip, coalesced.  A run = the adjacent entries of one row in one block; the lane at its head reserves
-        // it whole — the trip's last run, which may go on, after counting how far it goes — as for the long rows below.
-        const uint32_t nr = r1 - r0, i0 = lt_wave_cut(rp, nr, wave, nwaves), i1 = lt_wave_cut(rp, nr, wave + 1, nwaves);
-        uint32_t ck = 0xFFFFFFFFu, pos_base = 0;       // the run open at the start of a trip: its key, where its next entry goes
-        uint32_t from = i0;                            // row of the previous trip's last entry
-        const uint32_t ee = rp[i1], magic = block_cols > 1u ? (uint32_t)(0x100000000ull / block_cols) : 0u;
-        for (uint32_t eg = rp[i0]; eg < ee; eg += 64 * kLtTrips) {   // kLtTrips trips' loads in flight at once
-          uint32_t colv[kLtTrips], rowv[kLtTrips];
-#pragma unroll
-          for (uint32_t j = 0; j < kLtTrips; ++j) {
-              const uint32_t e = eg + 64 * j + lane;
-              colv[j] = e < ee ? g.col[e] : 0u;
-          }
-          {   // rows of the group's entries: kLtTrips independent searches a lane, from the row the previous group ended in
-              const uint32_t e_last = min(ee, eg + 64 * kLtTrips) - 1u;
-              uint32_t hi = min(i1 - 1u, from + 64u * kLtTrips);   // (entries without empty rows between them: a row each at most)
-              if (hi + 1u < i1 && rp[hi + 1u] <= e_last) hi = i1 - 1u;
-#pragma unroll
-              for (uint32_t j = 0; j < kLtTrips; ++j) rowv[j] = lt_row_of(rp, from, hi, min(eg + 64 * j + lane, e_last));
-              from = __shfl(rowv[kLtTrips - 1], 63);
-          }
-#pragma unroll
-          for (uint32_t j = 0; j < kLtTrips; ++j) {
-            const uint32_t e0 = eg + 64 * j, e = e0 + lane;
-            if (e0 >= ee) break;                       // (uniform)
-            const bool in = e < ee;
-            const uint32_t nin = min(64u, ee - e0);
-            const uint32_t col = colv[j];
-            const uint32_t b = in ? lt_div(col, block_cols, magic) : 0u;
-            const uint32_t r = rowv[j];
-            const uint32_t key = in ? (r << 12 | b) : 0xFFFFFFFEu;   // (r <= 2048, b < 4096)
-            const uint32_t val = (r << shift) | (col - b * block_cols);
-            uint32_t kp = lane_prev(key);
-            if (lane == 0) kp = ck;
-            unsorted |= in && key < kp && (key >> 12) == (kp >> 12);   // the row's blocks must ascend
-            const bool head = in && key != kp;
-            const unsigned long long hm = __ballot(head);
-            const uint32_t first_head = hm ? (uint32_t)__builtin_ctzll(hm) : nin;   // lanes in front of it continue the open run
-            if (in && lane < first_head) put(pos_base + lane, val);
-            pos_base += first_head;
-            if (hm == 0ull) continue;                  // (uniform) the whole trip belonged to the open run
-            const uint32_t last_h = 63u - (uint32_t)__builtin_clzll(hm);
-            const unsigned long long mine = hm & lanes_upto(lane);
-            const uint32_t my_head = mine ? 63u - (uint32_t)__builtin_clzll(mine) : 0u;
-            uint32_t len = 0;
-            if (head) {
-                const unsigned long long later = hm & ~lanes_upto(lane);
-                len = (later ? (uint32_t)__builtin_ctzll(later) : nin) - lane;
-            }
-            uint32_t extra = 0;                        // entries of the last run beyond this trip
-            const uint32_t bo = __shfl(b, (int)last_h), row_end_e = rp[__shfl(r, (int)last_h) + 1u];
-            for (uint32_t f0 = e0 + 64; f0 < row_end_e; f0 += 64) {
-                const uint32_t f = f0 + lane;
-                const bool in2 = f < row_end_e;
-                const bool same = in2 && lt_div(g.col[in2 ? f : row_end_e - 1], block_cols, magic) == bo;
-                const unsigned long long sm = __ballot(same);
-                const uint32_t lead = ~sm ? (uint32_t)__builtin_ctzll(~sm) : 64u;   // (blocks ascend: the same-block lanes are a prefix)
-                extra += lead;
-                if (lead < 64u) break;
-            }
-            uint32_t pos = 0;
-            if (head) pos = atomicAdd(&cursor[b], len + (lane == last_h ? extra : 0u));
-            const uint32_t p = __shfl(pos, (int)my_head);
-            if (in && lane >= first_head) put(p + (lane - my_head), val);
-            ck = __shfl(key, (int)last_h);
-            pos_base = __shfl(pos, (int)last_h) + __shfl(len, (int)last_h);
-          }
-        }
-    }
-    for (uint32_t i = tid; !flat && i < r1 - r0; i += nthreads) {   // short rows: a thread each; long ones are listed for the waves
+    __syncthreads();
+    for (uint32_t i = tid; i < r1 - r0; i += 1024) {   // short rows: a thread each; long ones are listed for the waves
         const uint32_t u = lt_row(pm, c, rows_per_chunk, r0, i);
         if (u >= row_end) continue;
         const uint32_t rl = i << shift;
@@ -1852,14 +1710,14 @@ __global__ __launch_bounds__(1024) void k_lt_scatter(GraphDev g, uint32_t rows_p
             while (f < end && lt_block(pm, g.col[f], block_cols, nblocks, b) == b) ++f;
             uint32_t pos = atomicAdd(&cursor[b], f - e);
             const uint32_t bs = lt_block_start(pm, b, block_cols);
-            for (; e < f; ++e) put(pos++, rl | (g.col[e] - bs));
+            for (; e < f; ++e) entries[pos++] = rl | (g.col[e] - bs);
         }
     }
     __syncthreads();
     // A long row, 64 entries a trip.  A row's entries of one block must land as ONE adjacent run, in order: the lane at the
     // head of a run reserves the whole run at once — for the trip's last run, which may go on, after counting how far it
     // goes — and the trips that follow write the rest of that run behind what is already there.
-    for (uint32_t k = wave; k < nlong; k += nwaves) {
+    for (uint32_t k = wave; k < nlong; k += 16) {
         const uint32_t i = longrow[k], u = lt_row(pm, c, rows_per_chunk, r0, i), rl = i << shift;
         const uint32_t rs = g.rowptr[u], re = g.rowptr[u + 1];
         uint32_t cb = 0xFFFFFFFFu, pos_base = 0;      // the run open at the start of a trip: its block, where its next entry goes
@@ -1874,7 +1732,7 @@ __global__ __launch_bounds__(1024) void k_lt_scatter(GraphDev g, uint32_t rows_p
             const unsigned long long hm = __ballot(head);
             const uint32_t nin = (uint32_t)__popcll(__ballot(in));
             const uint32_t first_head = hm ? (uint32_t)__builtin_ctzll(hm) : nin;   // lanes in front of it continue the open run
-            if (in && lane < first_head) put(pos_base + lane, rl | (col - lt_block_start(pm, cb, block_cols)));
+            if (in && lane < first_head) entries[pos_base + lane] = rl | (col - lt_block_start(pm, cb, block_cols));
             pos_base += first_head;
             if (hm == 0ull) continue;                  // (uniform) the whole trip belonged to the open run
             const uint32_t last_h = 63u - (uint32_t)__builtin_clzll(hm);
@@ -1901,16 +1759,178 @@ __global__ __launch_bounds__(1024) void k_lt_scatter(GraphDev g, uint32_t rows_p
             uint32_t pos = 0;
             if (head) pos = atomicAdd(&cursor[b], len + (lane == last_h ? extra : 0u));
             const uint32_t p = __shfl(pos, (int)my_head);
-            if (in && lane >= first_head) put(p + (lane - my_head), rl | (col - lt_block_start(pm, b, block_cols)));
+            if (in && lane >= first_head) entries[p + (lane - my_head)] = rl | (col - lt_block_start(pm, b, block_cols));
             cb = __shfl(b, (int)last_h);
             pos_base = __shfl(pos, (int)last_h) + __shfl(len, (int)last_h);
         }
     }
-    if (staged) {
-        __syncthreads();
-        for (uint32_t i = tid; i < span; i += nthreads) entries[first + i] = lt_stage[i];
+}
+
+// ... of a plan over consecutive rows and uniform blocks (lt_flat_plan): the chunk's entries are one CSR range — every wave
+// walks an equal share of it, 64 entries a trip, coalesced.  Whether a row's blocks ascend is checked by the scatter pass,
+// which knows the rows.  Dynamic LDS: nblocks counters.
+__global__ __launch_bounds__(256) void k_lt_count_flat(GraphDev g, uint32_t rows_per_chunk, uint32_t nblocks, uint32_t block_cols,
+                                                       uint32_t *__restrict__ seg_cnt, uint32_t row_base, uint32_t row_end) {
+    extern __shared__ uint32_t lt_dyn[];
+    uint32_t *hist = lt_dyn;
+    const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nthreads = blockDim.x, nwaves = nthreads >> 6;   // (a multiple of 64)
+    const uint32_t r0 = min(row_end, row_base + c * rows_per_chunk), r1 = min(row_end, r0 + rows_per_chunk);
+    for (uint32_t i = tid; i < nblocks; i += nthreads) hist[i] = 0;
+    __syncthreads();
+    const uint32_t es = g.rowptr[r0], all = g.rowptr[r1] - es;
+    const uint32_t ee = es + (uint32_t)((uint64_t)all * (wave + 1u) / nwaves);
+    const uint32_t magic = block_cols > 1u ? (uint32_t)(0x100000000ull / block_cols) : 0u;
+    for (uint32_t eg = es + (uint32_t)((uint64_t)all * wave / nwaves); eg < ee; eg += 64 * kLtTrips) {   // kLtTrips trips' loads in flight at once
+        uint32_t colv[kLtTrips];
+#pragma unroll
+        for (uint32_t j = 0; j < kLtTrips; ++j) {
+            const uint32_t e = eg + 64 * j + lane;
+            colv[j] = e < ee ? g.col[e] : 0u;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kLtTrips; ++j) {
+            const uint32_t e0 = eg + 64 * j, e = e0 + lane;
+            if (e0 >= ee) break;                       // (uniform)
+            const bool in = e < ee;
+            const uint32_t b = in ? lt_div(colv[j], block_cols, magic) : 0xFFFFFFFFu;
+            const uint32_t bp = lane_prev(b);
+            const bool head = in && (lane == 0 || b != bp);   // one LDS add per run of equal blocks (a trip's first entry starts one)
+            const unsigned long long hm = __ballot(head);
+            const uint32_t nin = min(64u, ee - e0);
+            if (head) {
+                const unsigned long long later = hm & ~lanes_upto(lane);
+                const uint32_t nh = later ? (uint32_t)__builtin_ctzll(later) : nin;
+                atomicAdd(&hist[b], nh - lane);
+            }
+        }
     }
-    if (bad && __any(unsorted) && lane == 0) atomicOr(bad, 2u);
+    __syncthreads();
+    for (uint32_t i = tid; i < nblocks; i += nthreads) seg_cnt[(size_t)c * nblocks + i] = hist[i];
+}
+
+// ... of a plan over consecutive rows and uniform blocks (lt_flat_plan).  Every wave walks an equal share of the chunk's CSR
+// range (cut at row boundaries) 64 entries a trip, coalesced.  A run = the adjacent entries of one row in one block; the lane
+// at its head reserves it whole — the trip's last run, which may go on, after counting how far it goes.  *bad |= 2 if a
+// row's blocks do not ascend.  Dynamic LDS: nblocks cursors, rows + 1 offsets, 64 flags a wave.
+__global__ __launch_bounds__(256) void k_lt_scatter_flat(GraphDev g, uint32_t rows_per_chunk, uint32_t nblocks, uint32_t block_cols,
+                                                         uint32_t shift, const uint32_t *__restrict__ seg_cnt,
+                                                         uint32_t *__restrict__ entries, uint32_t row_base, uint32_t row_end,
+                                                         uint32_t slack, uint32_t *bad) {
+    extern __shared__ uint32_t lt_dyn[];
+    __shared__ uint32_t wave_sum[4];
+    uint32_t *cursor = lt_dyn, *rp = lt_dyn + nblocks, *row_flag = rp + rows_per_chunk + 1;
+    const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nthreads = blockDim.x, nwaves = nthreads >> 6;   // (a multiple of 64, at most 256)
+    const uint32_t r0 = min(row_end, row_base + c * rows_per_chunk), r1 = min(row_end, r0 + rows_per_chunk);
+    const uint32_t first = lt_chunk_first(g, c, rows_per_chunk, row_base, row_end, slack, nullptr);
+    bool unsorted = false;
+    for (uint32_t i = tid; i <= r1 - r0; i += nthreads) rp[i] = g.rowptr[r0 + i];
+    {   // cursor[b] = first + exclusive scan of the (padded) counts: thread t takes blocks [t * per, (t + 1) * per)
+        const uint32_t per = (nblocks + nthreads - 1) / nthreads, b0 = tid * per;
+        const uint32_t *cnt = seg_cnt + (size_t)c * nblocks;
+        uint32_t local = 0;
+        for (uint32_t k = 0; k < per && b0 + k < nblocks; ++k) local += slack ? (cnt[b0 + k] + 3u) & ~3u : cnt[b0 + k];
+        uint32_t incl = local;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off);
+            if ((int)lane >= off) incl += t;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        uint32_t run = first + incl - local;
+        for (uint32_t w = 0; w < wave; ++w) run += wave_sum[w];
+        for (uint32_t k = 0; k < per && b0 + k < nblocks; ++k) {
+            cursor[b0 + k] = run;
+            run += slack ? (cnt[b0 + k] + 3u) & ~3u : cnt[b0 + k];
+        }
+        __syncthreads();
+    }
+#define LT_PUT(pos_, v_) entries[(pos_)] = (v_)
+    {
+        const uint32_t nr = r1 - r0, i0 = lt_wave_cut(rp, nr, wave, nwaves), i1 = lt_wave_cut(rp, nr, wave + 1, nwaves);
+        uint32_t ck = 0xFFFFFFFFu, pos_base = 0;       // the run open at the start of a trip: its key, where its next entry goes
+        uint32_t from = i0;                            // row of the previous trip's last entry
+        const uint32_t ee = rp[i1], magic = block_cols > 1u ? (uint32_t)(0x100000000ull / block_cols) : 0u;
+        for (uint32_t eg = rp[i0]; eg < ee; eg += 64 * kLtTrips) {   // kLtTrips trips' loads in flight at once
+          uint32_t colv[kLtTrips];
+#pragma unroll
+          for (uint32_t j = 0; j < kLtTrips; ++j) {
+              const uint32_t e = eg + 64 * j + lane;
+              colv[j] = e < ee ? g.col[e] : 0u;
+          }
+#pragma unroll
+          for (uint32_t j = 0; j < kLtTrips; ++j) {
+            const uint32_t e0 = eg + 64 * j, e = e0 + lane;
+            if (e0 >= ee) break;                       // (uniform)
+            const bool in = e < ee;
+            const uint32_t nin = min(64u, ee - e0);
+            const uint32_t col = colv[j];
+            const uint32_t b = in ? lt_div(col, block_cols, magic) : 0u;
+            // Rows of the trip's entries.  `from` holds the entry before the trip (or is the share's first row); without
+            // empty rows the rows that start inside the trip are among the next 64: lane l looks at row from + 1 + l, flags
+            // the trip position where it starts, and an entry's row = from + the flags up to its position.  An empty row
+            // among them (two rows starting at one position) sends the trip to the search instead.
+            uint32_t r;
+            {
+                const uint32_t s0 = rp[min(from + 1u + lane, nr)], s1 = rp[min(from + 2u + lane, nr)];
+                const bool inside = s0 >= e0 && s0 < e0 + nin;
+                if (__any(inside && s0 == s1)) {
+                    r = lt_row_of(rp, from, i1 - 1u, in ? e : e0 + nin - 1u);
+                } else {
+                    uint32_t *flag = row_flag + wave * 64u;
+                    flag[lane] = 0u;
+                    wave_lds_sync();
+                    if (inside) flag[s0 - e0] = 1u;
+                    wave_lds_sync();
+                    const unsigned long long starts = __ballot(flag[lane] != 0u);
+                    wave_lds_sync();                   // (the next trip clears the flags again)
+                    r = from + (uint32_t)__popcll(starts & lanes_upto(lane));
+                }
+                from = __shfl(r, (int)(nin - 1u));
+            }
+            const uint32_t key = in ? (r << 12 | b) : 0xFFFFFFFEu;   // (r <= 2048, b < 4096)
+            const uint32_t val = (r << shift) | (col - b * block_cols);
+            uint32_t kp = lane_prev(key);
+            if (lane == 0) kp = ck;
+            unsorted |= in && key < kp && (key >> 12) == (kp >> 12);   // the row's blocks must ascend
+            const bool head = in && key != kp;
+            const unsigned long long hm = __ballot(head);
+            const uint32_t first_head = hm ? (uint32_t)__builtin_ctzll(hm) : nin;   // lanes in front of it continue the open run
+            if (in && lane < first_head) LT_PUT(pos_base + lane, val);
+            pos_base += first_head;
+            if (hm == 0ull) continue;                  // (uniform) the whole trip belonged to the open run
+            const uint32_t last_h = 63u - (uint32_t)__builtin_clzll(hm);
+            const unsigned long long mine = hm & lanes_upto(lane);
+            const uint32_t my_head = mine ? 63u - (uint32_t)__builtin_clzll(mine) : 0u;
+            uint32_t len = 0;
+            if (head) {
+                const unsigned long long later = hm & ~lanes_upto(lane);
+                len = (later ? (uint32_t)__builtin_ctzll(later) : nin) - lane;
+            }
+            uint32_t extra = 0;                        // entries of the last run beyond this trip
+            const uint32_t bo = __shfl(b, (int)last_h), row_end_e = rp[__shfl(r, (int)last_h) + 1u];
+            for (uint32_t f0 = e0 + 64; f0 < row_end_e; f0 += 64) {
+                const uint32_t f = f0 + lane;
+                const bool in2 = f < row_end_e;
+                const bool same = in2 && lt_div(g.col[in2 ? f : row_end_e - 1], block_cols, magic) == bo;
+                const unsigned long long sm = __ballot(same);
+                const uint32_t lead = ~sm ? (uint32_t)__builtin_ctzll(~sm) : 64u;   // (blocks ascend: the same-block lanes are a prefix)
+                extra += lead;
+                if (lead < 64u) break;
+            }
+            uint32_t pos = 0;
+            if (head) pos = atomicAdd(&cursor[b], len + (lane == last_h ? extra : 0u));
+            const uint32_t p = __shfl(pos, (int)my_head);
+            if (in && lane >= first_head) LT_PUT(p + (lane - my_head), val);
+            ck = __shfl(key, (int)last_h);
+            pos_base = __shfl(pos, (int)last_h) + __shfl(len, (int)last_h);
+          }
+        }
+    }
+#undef LT_PUT
+    if (__any(unsorted) && lane == 0) atomicOr(bad, 2u);
 }
 
 // Skewed graphs: the rows of the degree-sorted list (heaviest first) dealt to `nslices` slices, serpentine — round t
@@ -3605,12 +3625,10 @@ static hipError_t allow_dynamic_lds(const void *func, int bytes, std::atomic<uin
     return rc;
 }
 
-// plan builders, flat walk (consecutive rows, uniform blocks): a wave per ~512 entries of a mean chunk; otherwise a thread per
-// row and a wave per long row: every wave the workgroup can have
-static uint32_t lt_builder_threads(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, const PlanMap &pm) {
-    if (pm.rowmap || pm.bstart || rows_per_chunk > kLtFlatRows) return 1024u;
-    const uint64_t mean = nchunks ? g.nnz / nchunks : 0;
-    return (uint32_t)std::min<uint64_t>(1024u, std::max<uint64_t>(256u, (mean / 512u + 1u) * 64u));
+// plan builders: the flat kernels serve plans over consecutive rows and uniform blocks
+static bool lt_flat_plan(uint32_t rows_per_chunk, const PlanMap &pm) { return !pm.rowmap && !pm.bstart && rows_per_chunk <= kLtFlatRows; }
+static uint32_t lt_flat_threads() {
+    return 256u;
 }
 
 uint32_t lds_table_max_rows() { return 16u * kLtwSliceRows; }
@@ -3638,8 +3656,13 @@ hipError_t lds_table_count(const GraphDev &g, uint32_t rows_per_chunk, uint32_t 
                            const PlanMap &pm) {
     if (row_end > g.n) row_end = g.n;
     if (nblocks > 4096 || block_cols > (1u << 18) || rows_per_chunk > (1u << 15)) return hipErrorInvalidValue;
-    GNNVC_LAUNCH(k_lt_count, dim3(nchunks), dim3(lt_builder_threads(g, rows_per_chunk, nchunks, pm)), 0, stream, g, rows_per_chunk,
-                       nblocks, block_cols, seg_cnt, bad, row_base, row_end, pm);
+    if (lt_flat_plan(rows_per_chunk, pm)) {
+        GNNVC_LAUNCH(k_lt_count_flat, dim3(nchunks), dim3(lt_flat_threads()), nblocks * sizeof(uint32_t), stream, g, rows_per_chunk,
+                     nblocks, block_cols, seg_cnt, row_base, row_end);
+        return hipGetLastError();
+    }
+    GNNVC_LAUNCH(k_lt_count, dim3(nchunks), dim3(1024), 0, stream, g, rows_per_chunk, nblocks, block_cols, seg_cnt, bad,
+                       row_base, row_end, pm);
     return hipGetLastError();
 }
 
@@ -3662,15 +3685,15 @@ hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_
     if (block_cols > (1u << shift) || ((uint64_t)rows_per_chunk << shift) > (1ull << 32)) return hipErrorInvalidValue;
     if (slack && slack < 3u * nblocks + 4u) return hipErrorInvalidValue;
     if (row_end > g.n) row_end = g.n;
-    // staging area: about twice a chunk's mean range (entries + pad slots), 16 .. 96 KiB
-    static std::atomic<uint64_t> lds_ok{0};
-    constexpr uint32_t kStageMax = 24u * 1024u;
-    hipError_t rc = allow_dynamic_lds(reinterpret_cast<const void *>(k_lt_scatter), (int)(kStageMax * sizeof(uint32_t)), lds_ok);
-    if (rc != hipSuccess) return rc;
-    const uint64_t mean = nchunks ? g.nnz / nchunks : 0;
-    uint32_t stage = (uint32_t)std::min<uint64_t>(kStageMax, std::max<uint64_t>(4096u, (2 * mean + 3ull * nblocks + 1023ull) / 1024ull * 1024ull));
-    GNNVC_LAUNCH(k_lt_scatter, dim3(nchunks), dim3(lt_builder_threads(g, rows_per_chunk, nchunks, pm)), stage * sizeof(uint32_t),
-                       stream, g, rows_per_chunk, nblocks, block_cols, shift, seg_cnt, entries, row_base, row_end, slack, pm, stage, bad);
+    if (lt_flat_plan(rows_per_chunk, pm)) {
+        const uint32_t threads = lt_flat_threads();
+        const size_t lds = ((size_t)nblocks + rows_per_chunk + 1 + threads) * sizeof(uint32_t);   // cursors, offsets, 64 flags a wave
+        GNNVC_LAUNCH(k_lt_scatter_flat, dim3(nchunks), dim3(threads), lds, stream, g, rows_per_chunk, nblocks, block_cols, shift,
+                     seg_cnt, entries, row_base, row_end, slack, bad);
+        return hipGetLastError();
+    }
+    GNNVC_LAUNCH(k_lt_scatter, dim3(nchunks), dim3(1024), 0, stream, g, rows_per_chunk, nblocks, block_cols, shift, seg_cnt,
+                       entries, row_base, row_end, slack, pm);
     return hipGetLastError();
 }
 
