@@ -880,6 +880,95 @@ def test_compact_gather_plan_steps_aside_for_good(model_text, oracle_model):
         e.close()
 
 
+def test_plan_built_inside_the_first_forward(model_text, oracle_model):
+    """"compact_first_forward_entries": a graph with that many entries builds the compact-table plan inside its first forward
+    and uses it there (what a score-once caller runs); the LDS-table plan follows in the second.  Same logits throughout, and
+    the same as with the plan built one forward later."""
+    import gnn_mwvc_amd as G
+    g = gg.erdos_renyi(20000, 200000, 70)
+    oracle_model.set_weight_scale(g.ws)
+    want = oracle_model.logits(g)
+    for first_too in (1, 0):
+        e = G.Engine(model_text, device=0)
+        try:
+            e.set_option("blocked_min_n", 0)
+            e.set_option("compact_first_forward_entries", g.nnz if first_too else 0)
+            e.set_weight_scale(g.ws)
+            e.upload_graph(g)
+            _, lg = e.forward(g.x())
+            assert np.array_equal(bits(lg[:, 0]), bits(want))
+            assert e.get_info("compact_gather_active") == first_too
+            if first_too:
+                assert e.get_info("compact_gather_last_ok") == 1      # ... and the device took the plan's route
+            assert e.get_info("lds_table_active") == 0
+            for rep in range(3):
+                _, lg = e.forward(g.x())
+                assert np.array_equal(bits(lg[:, 0]), bits(want)), rep
+            assert e.get_info("compact_gather_active") == 1 and e.get_info("lds_table_active") == 1
+        finally:
+            e.close()
+
+
+@pytest.mark.parametrize("maker", [
+    lambda: gg.erdos_renyi(30000, 45000, 81),                      # 3 entries per row: one row in twenty is empty, often several in a row
+    lambda: gg.from_edge_list(3000, [(i, i + 1) for i in range(0, 2999, 7)] + [(5, j) for j in range(900, 1100)], [20 + i % 100 for i in range(3000)]),   # mostly empty rows, one of 200 entries
+    lambda: _dense_graph(3000, 300, 63),                           # runs of a row that cross trips and waves' shares
+])
+def test_flat_plan_builders_on_ragged_rows(model_text, oracle_model, maker):
+    """k_lt_count_flat / k_lt_scatter_flat (plans over consecutive rows): empty rows (the row of an entry is then searched, not
+    read off the row-start flags), rows longer than a trip, slices with a handful of entries."""
+    import gnn_mwvc_amd as G
+    g = maker()
+    oracle_model.set_weight_scale(g.ws)
+    want = oracle_model.logits(g)
+    for chunk_rows in (0, 48):
+        e = G.Engine(model_text, device=0)
+        try:
+            e.set_option("blocked_min_n", 0)
+            e.set_option("long_row_threshold", 0)                  # no long-row kernels: the plans hold every row
+            e.set_option("giant_row_threshold", 0)
+            e.set_option("sorted_tiles", 0)
+            e.set_option("compact_first_forward_entries", 1)
+            if chunk_rows:
+                e.set_option("plan_chunk_rows", chunk_rows)
+            e.set_weight_scale(g.ws)
+            e.upload_graph(g)
+            for rep in range(3):
+                _, lg = e.forward(g.x())
+                assert np.array_equal(bits(lg[:, 0]), bits(want)), (chunk_rows, rep)
+            assert e.get_info("lds_table_active") == 1 and e.get_info("compact_gather_active") == 1
+        finally:
+            e.close()
+
+
+def test_compact_gather_plan_rejects_unsorted_lists(model_text, oracle_model):
+    """The flat builders check while regrouping that a row's column blocks ascend: with descending adjacency lists over several
+    column blocks neither plan may be used (regrouping by block would change the order of the sums)."""
+    import gnn_mwvc_amd as G
+    g7 = gg.erdos_renyi(200000, 800000, 65)
+    rp = g7.rowptr.astype(np.int64)
+    row = np.repeat(np.arange(g7.n), np.diff(rp))
+    k = np.arange(rp[-1]) - rp[row]
+    col = g7.col.copy()
+    col[: rp[-1]] = g7.col[rp[row + 1] - 1 - k]                    # every adjacency list reversed
+    g = gg.CsrGraph(g7.n, g7.rowptr, col, g7.w, g7.nw)
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_option("blocked_min_n", 0)
+        e.set_option("blocked_stage0", 0)
+        e.set_option("compact_first_forward_entries", 1)
+        e.set_weight_scale(g.ws)
+        oracle_model.set_weight_scale(g.ws)
+        e.upload_graph(g)
+        want = oracle_model.logits(g)
+        for rep in range(3):
+            _, lg = e.forward(g.x())
+            assert np.array_equal(bits(lg[:, 0]), bits(want)), rep
+        assert e.get_info("compact_gather_active") == 0 and e.get_info("lds_table_active") == 0
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("maker,ncols,strays,passes_allowed,want_passes", [
     (lambda: gg.rmat(14, 8, 3), 4, 0, 3, 1),                      # skewed, four live columns: one table
     (lambda: gg.rmat(14, 8, 3), 7, 4, 3, 2),                      # seven live columns (+ strays): two tables
