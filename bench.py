@@ -13,7 +13,7 @@ What the ONE JSON line on rank 0 says (contract in the project brief, read as VE
   value / ms_per_step   the STEADY STATE of a graph that is scored again and again: the engine builds per-graph
                         plans inside a graph's first forwards, the timed region starts after them.
   first_forward_ms      what a caller gets who hands over a fresh graph and scores it once — the reference's own
-                        driver does that (src/GNN_VC.cpp:171-192); on graphs of 128 Mi entries and more it builds and
+                        driver does that (src/GNN_VC.cpp:171-192); on graphs of 48 Mi entries and more it builds and
                         uses the 16-wide stages' plan already — plus second / third forward (the second builds the rest
                         of the plans; plan_build_ms = all builds) and plain_forward_ms (steady state, plans switched off).
   roofline              frac = the forward-level fraction of SURVEY.md §8d: (288 E + 300 N) algorithmic bytes /

@@ -114,9 +114,9 @@ struct gnnvc_engine {
     uint32_t opt_blocked_min_n = 1u << 20;  // below this x fits the L2s anyway
     uint32_t opt_compact_min_n = 1u << 18;  // option "compact_min_n": the compact-table plan's own bound (the smaller of the two counts)
     uint64_t opt_compact_min_nnz = 8u << 20;   // ... and its entries bound (default sizes only)
-    uint64_t opt_compact_first_entries = 128ull << 20;   // option "compact_first_forward_entries": graphs of this many entries build
+    uint64_t opt_compact_first_entries = 48ull << 20;   // option "compact_first_forward_entries": graphs of this many entries build
                                                // the plan inside their FIRST forward (0 = never; otherwise it is built in the second).
-                                               // Metric graph (200 M entries): first forward 10.99 -> 9.81 ms; ER-3M (60 M): 3.06 -> 2.96;
+                                               // Metric graph (200 M entries): first forward 10.96 -> 9.18 ms; ER-3M (60 M): 3.03 -> 2.69;
                                                // ER-1M (20 M): 0.92 -> 1.14
     uint32_t opt_plan_chunk_rows = 0;       // != 0: cap on the rows per chunk of the LDS-table / compact-table plans
     bool blocked_ready = false;

@@ -1813,15 +1813,16 @@ __global__ __launch_bounds__(256) void k_lt_count_flat(GraphDev g, uint32_t rows
 // range (cut at row boundaries) 64 entries a trip, coalesced.  A run = the adjacent entries of one row in one block; the lane
 // at its head reserves it whole — the trip's last run, which may go on, after counting how far it goes.  *bad |= 2 if a
 // row's blocks do not ascend.  Dynamic LDS: nblocks cursors, rows + 1 offsets, 64 flags a wave.
-__global__ __launch_bounds__(256) void k_lt_scatter_flat(GraphDev g, uint32_t rows_per_chunk, uint32_t nblocks, uint32_t block_cols,
-                                                         uint32_t shift, const uint32_t *__restrict__ seg_cnt,
-                                                         uint32_t *__restrict__ entries, uint32_t row_base, uint32_t row_end,
-                                                         uint32_t slack, uint32_t *bad) {
+__global__ __launch_bounds__(1024) void k_lt_scatter_flat(GraphDev g, uint32_t rows_per_chunk, uint32_t nblocks, uint32_t block_cols,
+                                                          uint32_t shift, const uint32_t *__restrict__ seg_cnt,
+                                                          uint32_t *__restrict__ entries, uint32_t row_base, uint32_t row_end,
+                                                          uint32_t slack, uint32_t *bad, uint32_t stage_cap) {
     extern __shared__ uint32_t lt_dyn[];
-    __shared__ uint32_t wave_sum[4];
-    uint32_t *cursor = lt_dyn, *rp = lt_dyn + nblocks, *row_flag = rp + rows_per_chunk + 1;
+    __shared__ uint32_t wave_sum[16];
+    __shared__ uint32_t range_end;
+    uint32_t *cursor = lt_dyn, *rp = lt_dyn + nblocks, *row_flag = rp + rows_per_chunk + 1, *stage = row_flag + blockDim.x;
     const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t nthreads = blockDim.x, nwaves = nthreads >> 6;   // (a multiple of 64, at most 256)
+    const uint32_t nthreads = blockDim.x, nwaves = nthreads >> 6;   // (a multiple of 64)
     const uint32_t r0 = min(row_end, row_base + c * rows_per_chunk), r1 = min(row_end, r0 + rows_per_chunk);
     const uint32_t first = lt_chunk_first(g, c, rows_per_chunk, row_base, row_end, slack, nullptr);
     bool unsorted = false;
@@ -1845,9 +1846,18 @@ __global__ __launch_bounds__(256) void k_lt_scatter_flat(GraphDev g, uint32_t ro
             cursor[b0 + k] = run;
             run += slack ? (cnt[b0 + k] + 3u) & ~3u : cnt[b0 + k];
         }
+        if (tid == nthreads - 1) range_end = run;
         __syncthreads();
     }
-#define LT_PUT(pos_, v_) entries[(pos_)] = (v_)
+    // The chunk's regrouped range is put together in LDS and written out in one coalesced sweep (scattered 4-byte stores
+    // were half of this kernel's time); a chunk whose range is longer than the staging area stores directly.
+    const uint32_t span = range_end - first;
+    const bool staged = span <= stage_cap;             // (uniform over the workgroup)
+    if (staged) {
+        for (uint32_t i = tid; i < span; i += nthreads) stage[i] = 0;   // (pad slots are read, never used)
+        __syncthreads();
+    }
+#define LT_PUT(pos_, v_) do { if (staged) stage[(pos_) - first] = (v_); else entries[(pos_)] = (v_); } while (0)
     {
         const uint32_t nr = r1 - r0, i0 = lt_wave_cut(rp, nr, wave, nwaves), i1 = lt_wave_cut(rp, nr, wave + 1, nwaves);
         uint32_t ck = 0xFFFFFFFFu, pos_base = 0;       // the run open at the start of a trip: its key, where its next entry goes
@@ -1930,6 +1940,10 @@ __global__ __launch_bounds__(256) void k_lt_scatter_flat(GraphDev g, uint32_t ro
         }
     }
 #undef LT_PUT
+    if (staged) {
+        __syncthreads();
+        for (uint32_t i = tid; i < span; i += nthreads) entries[first + i] = stage[i];
+    }
     if (__any(unsorted) && lane == 0) atomicOr(bad, 2u);
 }
 
@@ -3686,10 +3700,19 @@ hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_
     if (slack && slack < 3u * nblocks + 4u) return hipErrorInvalidValue;
     if (row_end > g.n) row_end = g.n;
     if (lt_flat_plan(rows_per_chunk, pm)) {
-        const uint32_t threads = lt_flat_threads();
-        const size_t lds = ((size_t)nblocks + rows_per_chunk + 1 + threads) * sizeof(uint32_t);   // cursors, offsets, 64 flags a wave
-        GNNVC_LAUNCH(k_lt_scatter_flat, dim3(nchunks), dim3(threads), lds, stream, g, rows_per_chunk, nblocks, block_cols, shift,
-                     seg_cnt, entries, row_base, row_end, slack, bad);
+        // staging area for a chunk's regrouped range: its mean length and a margin (entries + pad slots) within the 160 KiB of a
+        // CU's LDS; the workgroup as large as it can be, since the area bounds how many of them a CU holds
+        static std::atomic<uint64_t> lds_ok{0};
+        constexpr size_t kLdsMax = 156u * 1024u;
+        hipError_t rc = allow_dynamic_lds(reinterpret_cast<const void *>(k_lt_scatter_flat), (int)kLdsMax, lds_ok);
+        if (rc != hipSuccess) return rc;
+        const uint64_t mean = nchunks ? g.nnz / nchunks : 0;
+        const uint32_t threads = 1024u;
+        const size_t fixed = ((size_t)nblocks + rows_per_chunk + 1 + threads) * sizeof(uint32_t);   // cursors, offsets, 64 flags a wave
+        uint64_t stage = (mean + mean / 8 + 3ull * nblocks + 64 + 255) / 256 * 256;
+        if (fixed + stage * sizeof(uint32_t) > kLdsMax) stage = (kLdsMax - fixed) / sizeof(uint32_t);
+        GNNVC_LAUNCH(k_lt_scatter_flat, dim3(nchunks), dim3(threads), fixed + stage * sizeof(uint32_t), stream, g, rows_per_chunk,
+                     nblocks, block_cols, shift, seg_cnt, entries, row_base, row_end, slack, bad, (uint32_t)stage);
         return hipGetLastError();
     }
     GNNVC_LAUNCH(k_lt_scatter, dim3(nchunks), dim3(1024), 0, stream, g, rows_per_chunk, nblocks, block_cols, shift, seg_cnt,

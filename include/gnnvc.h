@@ -87,7 +87,7 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *                         F = 1 plans)
  *   "compact_first_forward_entries" n  the plans are built inside a graph's second forward; a graph with at least this
  *                         many adjacency entries builds the compact-table plan inside its FIRST forward, which one use
- *                         repays there (default 2^27; 0 = never) — what a caller gets who scores every graph once
+ *                         repays there (default 48 Mi; 0 = never) — what a caller gets who scores every graph once
  *   "overlap_dense"  0|1  last stage under the compact-table plan: dense layers of one round of the sums on a second
  *                         stream, under the next round's sums (default 1; bit-identical either way)
  *   "plan_chunk_rows" n   cap on the rows per chunk of the LDS-table and compact-table plans (default 0 = what
