@@ -15,7 +15,8 @@ What the ONE JSON line on rank 0 says (contract in the project brief, read as VE
   first_forward_ms      what a caller gets who hands over a fresh graph and scores it once — the reference's own
                         driver does that (src/GNN_VC.cpp:171-192); on graphs of 48 Mi entries and more it builds and
                         uses the 16-wide stages' plan already — plus second / third forward (the second builds the rest
-                        of the plans; plan_build_ms = all builds) and plain_forward_ms (steady state, plans switched off).
+                        of the plans; plan_build_ms = wall time of all builds, the first one running under stage 0's kernels) and
+                        plain_forward_ms (steady state, plans switched off).
   roofline              frac = the forward-level fraction of SURVEY.md §8d: (288 E + 300 N) algorithmic bytes /
                         ms_per_step / 8 TB/s.  dominant_kernel: the kernel with the largest share of a forward, its
                         HIP-event time (events on the launch stream, every timed step), its own algorithmic bytes

@@ -2214,6 +2214,17 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
         rc = run_stage(e, (int)s, 0, n, cur, dst, last ? d_logits : nullptr, /*in_forward=*/true);
         if (rc) break;
         if (hipEventRecord(e->ev[s + 1], e->stream) != hipSuccess) { rc = fail(e, GNNVC_ERR_DEVICE, "hipEventRecord failed"); break; }
+        if (s == 0 && ns >= 2 && !e->c4_tried && !e->c4_range_mode && e->aux_stream && e->n_long == 0 && !e->sorted_wanted &&
+            e->opt_compact_first_entries && e->g.nnz >= e->opt_compact_first_entries) {
+            // A large graph's first forward: the compact-table plan of the stages to come depends on the graph alone — it is
+            // built now, on the second stream, under the kernels of stage 0 that were just queued (the build synchronises with
+            // its own stream only; it is complete when it returns).
+            hipStream_t main_stream = e->stream;
+            e->stream = e->aux_stream;
+            rc = build_compact(e);
+            e->stream = main_stream;
+            if (rc) break;
+        }
         cur = dst;
     }
     gnnvc::set_kernel_trace(nullptr);
