@@ -2219,6 +2219,8 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
             // A large graph's first forward: the compact-table plan of the stages to come depends on the graph alone — it is
             // built now, on the second stream, under the kernels of stage 0 that were just queued (the build synchronises with
             // its own stream only; it is complete when it returns).
+            // (behind whatever the caller had queued before this forward — it may still be writing the graph's arrays)
+            HIP_TRY(e, hipStreamWaitEvent(e->aux_stream, e->ev[0], 0));
             hipStream_t main_stream = e->stream;
             e->stream = e->aux_stream;
             rc = build_compact(e);
