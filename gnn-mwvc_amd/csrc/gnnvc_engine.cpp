@@ -924,7 +924,11 @@ int build_lds_table_impl(gnnvc_engine *e) {
                                         0xFFFFFFFFu, slack, pm, flag));
     HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));   // pin_small is reused by others
-    if (e->pin_small.p[0]) return GNNVC_OK;        // an unsorted row (the flat walk finds it while regrouping)
+    if (e->pin_small.p[0]) {                       // an unsorted row (the flat walk finds it while regrouping): no plan
+        e->lt_entries.release();
+        e->lt_steps.release();
+        return GNNVC_OK;
+    }
     e->c4_map_meta.release();     // (only the dealing needed the list)
     e->c4_map_vertex.release();
     e->lt_last_entry = (uint32_t)((entry_cap - 4) & ~3ull);
@@ -1069,7 +1073,11 @@ int build_compact_impl(gnnvc_engine *e, uint32_t base, uint32_t end, bool allow_
                                         gnnvc::compact_shift(), base, end, slack, pm, flag));
     HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
-    if (e->pin_small.p[0]) return GNNVC_OK;        // an unsorted row (the flat walk finds it while regrouping)
+    if (e->pin_small.p[0]) {                       // an unsorted row (the flat walk finds it while regrouping): no plan
+        e->c4_entries.release(); e->c4_steps.release(); e->c4_table.release(); e->c4_acc.release();
+        e->c4_dirty.release(); e->c4_agg16.release();
+        return GNNVC_OK;
+    }
     e->c4_map_meta.release();     // (only the dealing needed the list)
     e->c4_map_vertex.release();
     e->c4_last_entry = (uint32_t)((entry_cap - 4) & ~3ull);
