@@ -23,11 +23,18 @@ What the ONE JSON line on rank 0 says (contract in the project brief, read as VE
                         and fraction — which may exceed 1 where a plan serves the gathers from L2 or LDS instead
                         of memory; that is flagged, not hidden.  traffic: measured bytes per forward from the
                         committed PMC summary, only if it was taken from the kernels as they are now (source hash).
+  score_once            attach_ms + first_forward_ms = attach_plus_first_forward_ms: everything a caller pays who hands over
+                        a graph and scores it once (round 3: the plans one use repays are built at hand-off, the table
+                        columns of the first forward come from a pilot), next to the same with plans_at_handoff = 0.
   cpu_baseline          the oracle run the way the reference runs (serial aggregation; products through a discovered
-                        OpenBLAS, all cores) on a bounded sample of the workload's graph family, a second labelled
-                        line with the row-parallel aggregation its inert OpenMP pragma intended, and the parity
-                        checks: GPU logits == oracle on the sample (bitwise), and on the TIMED graph exact sampled
-                        rows + every logit of the timed configuration against the stage-by-stage path.
+                        OpenBLAS, all cores) ON THE METRIC GRAPH ITSELF, same run (one warm-up + one timed forward, ~50 s;
+                        --cpu-sample NxM falls back to a bounded sample of the family), a second labelled line with the
+                        row-parallel aggregation its inert OpenMP pragma intended, and the parity checks: EVERY logit of
+                        the timed graph, timed configuration, against the oracle (bitwise), every logit against the
+                        stage-by-stage path, exact sampled rows.
+  workloads             the other single-GPU configs of BASELINE.json (er100k = configs[1], rmat22 = configs[2],
+                        powerlaw1m = configs[4]), each on a fresh engine: attach, first forward, steady state (K timed
+                        steps after W warm-ups), forward-level fraction, every logit against the oracle.
 """
 from __future__ import annotations
 
@@ -129,8 +136,12 @@ def main() -> int:
     ap.add_argument("--no-lds-table", action="store_true", help="F = 1 stage without the LDS-table plan")
     ap.add_argument("--no-compact", action="store_true", help="16-wide stages without the compact-table plan")
     ap.add_argument("--no-overlap", action="store_true", help="dense layers after the sums instead of under the next round's")
-    ap.add_argument("--cpu-sample", default="2000000x20000000",
-                    help="n x m of the CPU-baseline sample graph (Erdős–Rényi workloads)")
+    ap.add_argument("--cpu-sample", default="",
+                    help="CPU baseline on a bounded sample 'NxM' of the workload's family instead of the workload graph itself "
+                         "(default: the graph itself — ~50 s of CPU work on the metric graph)")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the `workloads` block (er100k, rmat22, powerlaw1m)")
+    ap.add_argument("--workloads", default="er100k,rmat22,powerlaw1m", help="comma-separated side workloads of the default run")
+    ap.add_argument("--no-host-path", action="store_true", help="skip host_path_ms (PCIe-inclusive gnnvc_forward)")
     ap.add_argument("--no-blocked", action="store_true", help="disable the column-blocked F=1 stage (A/B)")
     ap.add_argument("--block-cols", type=int, default=0)
     ap.add_argument("--long-threshold", type=int, default=-1, help="degree at which a row gets its own workgroup")
@@ -520,9 +531,17 @@ def main() -> int:
         if not exchange_ok:
             out["invalid"] = "an exception list of the compressed exchange overflowed in the timed region"
     if rank == 0 and not multi:
+        # what a caller pays who hands a graph over and scores it once (the reference's driver, src/GNN_VC.cpp:171-192)
+        out["score_once"] = {"attach_ms": t_attach * 1e3, "first_forward_ms": early_ms[0],
+                             "attach_plus_first_forward_ms": t_attach * 1e3 + early_ms[0],
+                             "handoff_build_ms": eng.get_info("handoff_build_us") / 1e3,
+                             "plans_at_handoff": eng.get_info("plans_at_handoff"),
+                             "first_forward_over_steady": early_ms[0] / ms_per_step,
+                             "note": "attach = device-side checks + row classes + the plans built at hand-off + every buffer of the "
+                                     "forward (a fresh engine: allocations included); device-resident CSR, no PCIe copy in it"}
         if not args.no_variants:
             out.update(forward_variants(make_engine, attach_whole, x, n, dev))
-        if args.host_path:
+        if args.host_path or not args.no_host_path:
             # PCIe-inclusive path (host x in, host scores + logits out); never `value`
             xh = x.cpu().numpy()
             keep = eng.forward(xh)          # the caller's output buffers, reused like the reference's `out` matrix
@@ -530,9 +549,18 @@ def main() -> int:
             for _ in range(3):
                 eng.forward(xh, out=keep)
             out["host_path_ms"] = (time.perf_counter() - t1) * 1e3 / 3
+            del xh, keep
         if not args.no_cpu_baseline:
-            out["cpu_baseline"], out["cpu_baseline_openmp_aggregation"], out["parity"] = \
-                cpu_baseline(args, dev, eng, ggt, g, x, fwd_logits)
+            out["cpu_baseline"], out["cpu_baseline_openmp_aggregation"], out["parity"], handoff = \
+                cpu_baseline(args, dev, eng, ggt, g, x, fwd_logits, make_engine)
+            out["score_once"].update(handoff)
+        if not args.no_workloads and args.workload == "er10m":
+            eng.close()
+            del g, x
+            torch.cuda.empty_cache()
+            out["workloads"] = {}
+            for name in [w for w in args.workloads.split(",") if w]:
+                out["workloads"][name] = side_workload(name, args, dev, make_engine, ggt)
 
     if rank == 0:
         sys.stdout.flush()
@@ -567,6 +595,15 @@ def forward_variants(make_engine, attach_whole, x, n, dev):
     res["fresh_engine_first_forward_ms"] = run(e)
     res["fresh_engine_first_forward_device_ms"] = e.last_forward_ms()[0]
     e.close()
+    e = make_engine(plans_at_handoff=0)      # round 2's timing: plans inside the graph's first two forwards
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    attach_whole(e)
+    e.synchronize()
+    a0 = (time.perf_counter() - t) * 1e3
+    f0 = run(e)
+    res["plans_in_forward"] = {"attach_ms": a0, "first_forward_ms": f0, "attach_plus_first_forward_ms": a0 + f0}
+    e.close()
     e = make_engine(lds_table=0, compact_gather=0, prune_zero_rows=0)
     attach_whole(e)
     for _ in range(3):
@@ -597,7 +634,7 @@ def measured_traffic(workload: str):
     return float(meta["forward_traffic_bytes"]), str(prof[-1].relative_to(ROOT))
 
 
-def cpu_baseline(args, dev, eng, ggt, g, x, timed_logits):
+def cpu_baseline(args, dev, eng, ggt, g, x, timed_logits, make_engine):
     """The CPU leg (rank 0, N = 1): baseline timings of the oracle and the parity checks that need it."""
     import numpy as np
     import torch
@@ -653,9 +690,12 @@ def cpu_baseline(args, dev, eng, ggt, g, x, timed_logits):
     oracle_py.set_num_threads(threads)
     del h1, h2, sc, lg
 
-    # ---- the CPU baseline on a bounded sample of the workload's family
+    # ---- the CPU baseline: on the workload graph itself, same run (default), or on a bounded sample of its family
     spec = WORKLOADS[args.workload]
-    if spec[0] == "rmat":
+    on_workload = not args.cpu_sample
+    if on_workload:
+        gs, what = g, "the timed graph itself"
+    elif spec[0] == "rmat":
         gs, what = ggt.rmat(20, 16, 99, dev), "r-mat scale=20 edge_factor=16 (same generator, seed 99)"
     elif spec[0] == "powerlaw":
         gs, what = ggt.power_law_hubs(1_000_000, 16.0, 2.1, 8, 65536, 99, dev), "the same power-law construction, seed 99"
@@ -665,30 +705,53 @@ def cpu_baseline(args, dev, eng, ggt, g, x, timed_logits):
     hg = gs.to_host()
     om.set_weight_scale(hg.ws)
     xh = hg.x()
+    reps = 1 if hg.n_edges >= 50_000_000 else 3   # (the shipped-serial variant takes ~25 s per forward on the metric graph)
 
     def timed(**kw):
-        om.predict(hg, xh, **kw)                         # warm-up (page faults, thread pools)
+        om.predict(hg, xh, stop_after=om.n_layers - 2, **kw)   # warm-up (page faults, thread pools)
         ts, res = [], None
-        for _ in range(3):
+        for _ in range(reps):
             t0 = time.perf_counter()
             res = om.predict(hg, xh, stop_after=om.n_layers - 2, **kw)[:, 0]
             ts.append(time.perf_counter() - t0)
-        return sorted(ts)[1], res                        # median of 3 after 1 warm-up
+        return sorted(ts)[len(ts) // 2], res              # median of 3 after 1 warm-up; 1 + 1 on the metric graph
 
     t_ship, want = timed(as_shipped=True)
     t_omp, want2 = timed(parallel_agg=True)
-    # parity of the GPU path on the same sample (first forward on a fresh graph: the plain kernels)
-    eng.set_weight_scale(gs.ws)
-    eng.attach_graph_device(gs.n, gs.nnz, gs.rowptr.data_ptr(), gs.col.data_ptr(),
-                            gs.w.data_ptr(), gs.nw.data_ptr(), keepalive=gs)
-    sc = torch.zeros(gs.n, dtype=torch.float32, device=dev)
-    lg = torch.zeros(gs.n, dtype=torch.float32, device=dev)
-    eng.forward_device(gs.x().contiguous().data_ptr(), sc.data_ptr(), lg.data_ptr())
-    eng.synchronize()
-    got = lg.cpu().numpy()
+    handoff = {}
+    if on_workload:
+        # every logit of the TIMED graph in the TIMED configuration (plans in force) against the oracle
+        got = timed_logits.cpu().numpy()
+        # ... and the reference's call pattern through the host ABI on a fresh engine: upload (PCIe + hand-off plans), one forward
+        e3 = make_engine()
+        try:
+            t0 = time.perf_counter()
+            e3.upload_graph(hg)
+            e3.synchronize()
+            up = (time.perf_counter() - t0) * 1e3
+            t0 = time.perf_counter()
+            sc3, lg3 = e3.forward(xh)
+            ff = (time.perf_counter() - t0) * 1e3
+            handoff = {"host_upload_ms": up, "host_first_forward_ms": ff, "host_upload_plus_first_forward_ms": up + ff,
+                       "host_upload_handoff_build_ms": e3.get_info("handoff_build_us") / 1e3,
+                       "host_first_forward_logit_bit_mismatches_vs_oracle": int((lg3[:, 0].view(np.uint32) != want.view(np.uint32)).sum())}
+            del sc3, lg3
+        finally:
+            e3.close()
+    else:
+        # parity of the GPU path on the same sample (first forward on a fresh graph)
+        eng.set_weight_scale(gs.ws)
+        eng.attach_graph_device(gs.n, gs.nnz, gs.rowptr.data_ptr(), gs.col.data_ptr(),
+                                gs.w.data_ptr(), gs.nw.data_ptr(), keepalive=gs)
+        sc = torch.zeros(gs.n, dtype=torch.float32, device=dev)
+        lg = torch.zeros(gs.n, dtype=torch.float32, device=dev)
+        eng.forward_device(gs.x().contiguous().data_ptr(), sc.data_ptr(), lg.data_ptr())
+        eng.synchronize()
+        got = lg.cpu().numpy()
     mism = int((got.view(np.uint32) != want.view(np.uint32)).sum())
+    how_timed = "one forward after a warm-up" if reps == 1 else "one forward, median of 3 after a warm-up"
     base = {"value": hg.n_edges / t_ship, "unit": "edges/s", "cores": threads, "kind": "port",
-            "sample": f"{what}: {hg.n} vertices / {hg.n_edges} edges, one forward, median of 3 after a warm-up",
+            "sample": f"{what}: {hg.n} vertices / {hg.n_edges} edges, {how_timed}",
             "how": "the reference's call pattern (src/gnn_inference.cpp:20-52): aggregation serial as shipped (its OpenMP pragma "
                    "is inert, Makefile:4,30-32), every linear layer through cblas_sgemm + serial bias add, serial ReLU",
             "sgemm": blas or "internal sequential-k fmaf loops on OpenMP threads (no OpenBLAS found on this host)",
@@ -698,11 +761,84 @@ def cpu_baseline(args, dev, eng, ggt, g, x, timed_logits):
                     "src/gnn_inference.cpp:31's inert pragma intended), dense layers row-parallel; same bits",
            "sample": base["sample"], "seconds": t_omp,
            "same_bits_as_shipped_variant": bool(np.array_equal(want.view(np.uint32), want2.view(np.uint32)))}
-    parity = {"sample_vertices": hg.n, "logit_bit_mismatches_vs_oracle": mism,
+    parity = {"oracle_graph": what, "oracle_vertices": hg.n, "logit_bit_mismatches_vs_oracle": mism,
+              "every_logit_of_the_timed_graph_checked": bool(on_workload),
               "timed_graph": {"whole_forward_vs_stage_path_logit_bit_mismatches": whole_vs_staged,
                               "sampled_rows": int(len(sample)), "stages_checked": 3,
                               "sampled_row_bit_mismatches_vs_oracle": row_mismatch}}
-    return base, omp, parity
+    return base, omp, parity, handoff
+
+
+def side_workload(name, args, dev, make_engine, ggt):
+    """One of BASELINE.json's other single-GPU configs on a fresh engine: attach, first forward, steady state, fraction of
+    the forward-level roofline, and every logit against the oracle's whole forward."""
+    import numpy as np
+    import torch
+    import gnn_mwvc_amd as G
+    from oracle import oracle_py
+    g, desc = build_workload(name, ggt, dev)
+    torch.cuda.synchronize()
+    n, nnz = g.n, g.nnz
+    x = g.x().contiguous()
+    sc = torch.zeros(n, dtype=torch.float32, device=dev)
+    lg = torch.zeros(n, dtype=torch.float32, device=dev)
+    e = make_engine()
+    e.set_weight_scale(g.ws)
+    torch.cuda.synchronize()
+
+    def run():
+        t = time.perf_counter()
+        e.forward_device(x.data_ptr(), sc.data_ptr(), lg.data_ptr())
+        e.synchronize()
+        return (time.perf_counter() - t) * 1e3
+
+    t = time.perf_counter()
+    e.attach_graph_device(n, nnz, g.rowptr.data_ptr(), g.col.data_ptr(), g.w.data_ptr(), g.nw.data_ptr(), keepalive=g)
+    e.synchronize()
+    attach_ms = (time.perf_counter() - t) * 1e3
+    early = [run() for _ in range(3)]
+    first_lg = None
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(args.steps):
+        e.forward_device(x.data_ptr(), sc.data_ptr(), lg.data_ptr())
+    e.synchronize()
+    ms = (time.perf_counter() - t) * 1e3 / args.steps
+    fwd_bytes = sum(stage_bytes(i, n, nnz) for i in range(3))
+    res = {"workload": desc, "vertices": n, "edges": g.n_edges, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": ms, "value": g.n_edges / (ms * 1e-3), "unit": "edges/s",
+           "attach_ms": attach_ms, "first_forward_ms": early[0], "attach_plus_first_forward_ms": attach_ms + early[0],
+           "second_forward_ms": early[1], "third_forward_ms": early[2], "first_forward_over_steady": early[0] / ms,
+           "roofline_frac": fwd_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "forward_bytes": fwd_bytes,
+           "plan": {"lds_table": bool(e.get_info("lds_table_active")), "compact_gather": bool(e.get_info("compact_gather_active")),
+                    "pruned_stage1": bool(e.get_info("pruned_stage1")), "pruned_stage2": bool(e.get_info("pruned_stage2")),
+                    "sorted_tiles": bool(e.get_info("sorted_tiles_active")), "long_rows": e.get_info("long_rows"),
+                    "giant_rows": e.get_info("giant_rows")}}
+    if not args.no_cpu_baseline:
+        # steady-state logits (plans in force) AND a fresh engine's first-forward logits, every one against the oracle
+        om = oracle_py.OracleModel(G.default_model_text())
+        hg = g.to_host()
+        om.set_weight_scale(hg.ws)
+        want = om.predict(hg, hg.x(), stop_after=om.n_layers - 2, parallel_agg=True)[:, 0]
+        got = lg.cpu().numpy()
+        res["logit_bit_mismatches_vs_oracle"] = int((got.view(np.uint32) != want.view(np.uint32)).sum())
+        e2 = make_engine()
+        e2.set_weight_scale(g.ws)
+        e2.attach_graph_device(n, nnz, g.rowptr.data_ptr(), g.col.data_ptr(), g.w.data_ptr(), g.nw.data_ptr(), keepalive=g)
+        lg.zero_()
+        torch.cuda.synchronize()
+        e2.forward_device(x.data_ptr(), sc.data_ptr(), lg.data_ptr())
+        e2.synchronize()
+        res["first_forward_logit_bit_mismatches_vs_oracle"] = int((lg.cpu().numpy().view(np.uint32) != want.view(np.uint32)).sum())
+        res["logits_checked"] = int(n)
+        e2.close()
+        del hg, want, got
+    e.close()
+    del g, x, sc, lg, first_lg
+    torch.cuda.empty_cache()
+    return res
 
 
 if __name__ == "__main__":

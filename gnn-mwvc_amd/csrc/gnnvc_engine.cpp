@@ -274,6 +274,21 @@ struct gnnvc_engine {
     DevBuf<uint4> gi_segmap;
     uint32_t gi_maxseg = 0;
     int opt_giant_segments = -1;  // option "giant_segments": 1 = a stream on several waves, 0 = one wave walks it, -1 = by the graph (default)
+    // Plans at hand-off (round 3).  The reference's driver scores every graph exactly once (src/GNN_VC.cpp:171-192), so a plan
+    // built inside a graph's second forward never serves it.  What depends on the graph alone is built when the graph is handed
+    // over (upload / staged commit / attach): 1 (default) = the plans one use repays (degree-uniform graphs of at least
+    // opt_handoff_min_nnz entries: LDS table + compact table; every graph: the tile order and every buffer a forward would
+    // otherwise allocate), 2 = every plan whatever its cost (callers who score a graph many times, or hide the build under a
+    // copy), 0 = as in round 2 (inside the first two forwards).
+    int opt_handoff = 1;
+    uint64_t opt_handoff_min_nnz = 48ull << 20;
+    // First use of the compact-table plan on a graph: a pilot over the first opt_pilot_rows rows of the producing stage picks
+    // the consumer's table columns, so the producer can write the table on its way (see launch_main)
+    uint32_t opt_pilot_rows = 65536;
+    bool c4_seeded[4] = {false, false, false, false};
+    PinBuf<uint32_t> pin_info;   // small device -> host results that outlive the call that asked for them (never reallocated)
+    DevBuf<uint32_t> dev_info;
+    double handoff_build_ms = 0.0;
 
     std::string err;
 };
@@ -616,34 +631,35 @@ int find_long(gnnvc_engine *e) {
 
 // The rows of [lo, hi) below the long-row threshold of the 16-wide stages, heaviest degree class first: vertex[] (+ per
 // row {first entry, end, W, NW} in meta[]); listed = how many, zero_rows = how many of them (the list's tail) have no entry.
-int sort_by_degree(gnnvc_engine *e, uint32_t lo, uint32_t hi, DevBuf<uint32_t> &vertex, DevBuf<uint4> &meta, uint32_t &listed,
-                   uint32_t &zero_rows, const GraphDev *view = nullptr, const uint32_t *skip_rowptr = nullptr,
-                   uint32_t skip_from = 0xFFFFFFFFu, uint32_t class_thresh = 0) {
+int sort_by_degree_async(gnnvc_engine *e, uint32_t lo, uint32_t hi, DevBuf<uint32_t> &vertex, DevBuf<uint4> &meta, uint32_t *pin_out /* [2] */,
+                         const GraphDev *view = nullptr, const uint32_t *skip_rowptr = nullptr, uint32_t skip_from = 0xFFFFFFFFu,
+                         uint32_t class_thresh = 0) {
     // view: the adjacency whose row lengths class the rows (a pruned one: the entries LEFT; then skip_rowptr / skip_from leave
-    // out the giant rows, which go by their degree)
+    // out the giant rows, which go by their degree).  Everything is queued on the engine's stream — the scan over the degree
+    // classes runs on the device — and pin_out[0] = rows listed, pin_out[1] = rows without entries arrive with the stream.
     const GraphDev &g = view ? *view : e->g;
     const uint32_t lt = class_thresh ? class_thresh : e->thresh_f16;
     const uint32_t bins = lt < 4096u ? lt + 1 : 4096u;
-    HIP_TRY(e, e->srt_hist.reserve(bins));
+    HIP_TRY(e, e->srt_hist.reserve(4096));
+    HIP_TRY(e, e->dev_info.reserve(64));
     HIP_TRY(e, vertex.reserve(hi - lo));
     HIP_TRY(e, meta.reserve(hi - lo));
-    // the scan's host round trip goes through page-locked memory: an async copy to or from
-    // pageable memory above a few KB pins it on the fly, which costs milliseconds the first time
-    HIP_TRY(e, e->pin_small.reserve(2 * (size_t)bins));
-    uint32_t *hist = e->pin_small.p, *start = e->pin_small.p + bins;
     HIP_TRY(e, gnnvc::degree_histogram(g, lo, hi, lt, bins, e->srt_hist.p, e->stream, skip_rowptr, skip_from));
-    HIP_TRY(e, hipMemcpyAsync(hist, e->srt_hist.p, bins * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    uint32_t run = 0;
-    for (uint32_t d = bins; d-- > 0;) {   // heaviest degree class first
-        start[d] = run;
-        run += hist[d];
-    }
-    zero_rows = hist[0];
-    HIP_TRY(e, hipMemcpyAsync(e->srt_hist.p, start, bins * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, gnnvc::degree_starts(e->srt_hist.p, bins, e->dev_info.p + 8, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(pin_out, e->dev_info.p + 8, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, gnnvc::degree_scatter(g, lo, hi, lt, bins, e->srt_hist.p, vertex.p, meta.p, e->stream, skip_rowptr, skip_from));
-    HIP_TRY(e, hipStreamSynchronize(e->stream));   // `start` is read by the async copy above
-    listed = run;
+    return GNNVC_OK;
+}
+
+int sort_by_degree(gnnvc_engine *e, uint32_t lo, uint32_t hi, DevBuf<uint32_t> &vertex, DevBuf<uint4> &meta, uint32_t &listed,
+                   uint32_t &zero_rows, const GraphDev *view = nullptr, const uint32_t *skip_rowptr = nullptr,
+                   uint32_t skip_from = 0xFFFFFFFFu, uint32_t class_thresh = 0) {
+    HIP_TRY(e, e->pin_info.reserve(64));
+    int rc = sort_by_degree_async(e, lo, hi, vertex, meta, e->pin_info.p + 8, view, skip_rowptr, skip_from, class_thresh);
+    if (rc) return rc;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    listed = e->pin_info.p[8];
+    zero_rows = e->pin_info.p[9];
     return GNNVC_OK;
 }
 
@@ -955,6 +971,7 @@ int build_compact_impl(gnnvc_engine *e, uint32_t base, uint32_t end, bool allow_
     e->c4_tried = true;
     e->c4_mapped = false;
     e->c4_prepared_stage = -1;
+    for (bool &b : e->c4_seeded) b = false;
     const GraphDev &g = e->g;
     if (end > g.n) end = g.n;
     if (base >= end) return GNNVC_OK;
@@ -1142,7 +1159,32 @@ int ensure_round_events(gnnvc_engine *e, size_t count) {
     return GNNVC_OK;
 }
 
+// Buffers of the pruned adjacency sized by what the GRAPH allows (the kept entries are at most all of them), so that a plan
+// built inside a forward allocates nothing there.
+int reserve_prune(gnnvc_engine *e, int stage) {
+    gnnvc_engine::PrunePlan &pp = e->prune[stage];
+    const GraphDev &g = e->g;
+    const uint32_t held = g.hi() - g.lo();
+    const size_t chunks = (size_t)((g.nnz + 63) / 64);
+    HIP_TRY(e, e->prune_flags.reserve(8));
+    HIP_TRY(e, e->pin_info.reserve(64));
+    HIP_TRY(e, e->dev_info.reserve(64));
+    HIP_TRY(e, pp.heavy.reserve(((size_t)g.n + 31) / 32 + 1));
+    HIP_TRY(e, e->prune_mask.reserve(std::max<size_t>(chunks, 2)));
+    HIP_TRY(e, e->prune_off.reserve(chunks + 1));
+    HIP_TRY(e, e->prune_scratch.reserve(gnnvc::blocked_scan_scratch_elems(chunks + 1)));
+    HIP_TRY(e, pp.prp.reserve((size_t)held + 1));
+    HIP_TRY(e, pp.pcol.reserve((size_t)g.nnz + GNNVC_COL_PAD));
+    if (e->sorted_wanted && e->opt_prune_eff) {
+        HIP_TRY(e, pp.svertex.reserve(held));
+        HIP_TRY(e, pp.smeta.reserve(held));
+        HIP_TRY(e, e->srt_hist.reserve(4096));
+    }
+    return GNNVC_OK;
+}
+
 // Pruned adjacency for consumer stage `stage` (see k_prune_*): built once per graph from the input `in` of the call at hand.
+// Two host round trips: the size of the set and what it promises (before any pass over the entries), and what came of it.
 int build_prune_impl(gnnvc_engine *e, int stage, const float *in, bool early) {
     gnnvc_engine::PrunePlan &pp = e->prune[stage];
     pp.tried = true;
@@ -1150,21 +1192,19 @@ int build_prune_impl(gnnvc_engine *e, int stage, const float *in, bool early) {
     const GraphDev &g = e->g;
     if (!e->opt_prune || g.n == 0 || e->empty_slice || g.nnz < e->opt_prune_min_nnz) return GNNVC_OK;
     if (g.sliced() && e->opt_prune == 2) return GNNVC_OK;   // (a slice does not know the degrees of the vertices it does not hold)
-    const uint32_t held = g.hi() - g.lo();
-    HIP_TRY(e, e->prune_flags.reserve(8));
+    if (g.nnz >= (1ull << 32)) return GNNVC_OK;
+    int rc = reserve_prune(e, stage);
+    if (rc) return rc;
+    uint32_t *pin = e->pin_info.p;   // [0..3] = {mass lo, mass hi, members lo, members hi}, [4] = kept, [5] = observed, [6..7] = listed rows, rows without entries
     uint32_t seen = 0;
     if (e->opt_prune == 2) {
         HIP_TRY(e, gnnvc::prune_observe(g, in, e->prune_flags.p + 3, e->stream));
-        HIP_TRY(e, hipMemcpyAsync(&seen, e->prune_flags.p + 3, sizeof seen, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(pin + 5, e->prune_flags.p + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(e, hipStreamSynchronize(e->stream));
+        seen = pin[5];
     }
     pp.observed = seen;
-    if (g.nnz >= (1ull << 32)) return GNNVC_OK;
     const size_t chunks = (size_t)((g.nnz + 63) / 64);
-    HIP_TRY(e, pp.heavy.reserve(((size_t)g.n + 31) / 32 + 1));
-    HIP_TRY(e, e->prune_mask.reserve(chunks));
-    HIP_TRY(e, e->prune_off.reserve(chunks + 1));
-    HIP_TRY(e, e->prune_scratch.reserve(gnnvc::blocked_scan_scratch_elems(chunks + 1)));
     if (e->opt_prune == 2) {
         // a degree bound some way above the largest degree that still had a non-zero row: inputs that differ a little from
         // this one still pass the per-call check
@@ -1176,64 +1216,52 @@ int build_prune_impl(gnnvc_engine *e, int stage, const float *in, bool early) {
         pp.bound = 0;
         HIP_TRY(e, gnnvc::prune_mark_zero(g, in, pp.heavy.p, e->stream));
     }
-    {   // no vertex in the set (degree-uniform graphs: every row has a non-zero): nothing to prune, skip the passes over the entries
-        const size_t words = ((size_t)g.n + 31) / 32;
-        std::vector<uint32_t> bits(words);
-        HIP_TRY(e, hipMemcpyAsync(bits.data(), pp.heavy.p, words * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
-        uint64_t members = 0;
-        for (uint32_t w : bits) members += (uint64_t)__builtin_popcount(w);
-        pp.members = members;
-        if (members == 0) {
-            pp.heavy.release();
+    // a cheap look before the passes over the entries: how many vertices the set has, and (whole graphs) their degrees ~ the
+    // entries that would go
+    unsigned long long *mass_dev = reinterpret_cast<unsigned long long *>(e->prune_mask.p);
+    HIP_TRY(e, gnnvc::prune_mass(g, pp.heavy.p, mass_dev, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(pin, mass_dev, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    const uint64_t mass = (uint64_t)pin[0] | ((uint64_t)pin[1] << 32), members = (uint64_t)pin[2] | ((uint64_t)pin[3] << 32);
+    pp.members = members;
+    if (members == 0) return GNNVC_OK;   // degree-uniform graphs: every row has a non-zero, nothing to prune
+    if (!g.sliced()) {
+        if (mass * 100 < g.nnz * (uint64_t)std::min(e->opt_prune_min_drop, 100u) / 2)   // (half the bound: the estimate is exact only for symmetric graphs)
             return GNNVC_OK;
-        }
-    }
-    if (!g.sliced()) {   // a cheap look before the passes over the entries: the degrees of the set's vertices ~ the entries that would go
-        unsigned long long mass = 0;
-        HIP_TRY(e, gnnvc::prune_mass(g, pp.heavy.p, reinterpret_cast<unsigned long long *>(e->prune_mask.p), e->stream));
-        HIP_TRY(e, hipMemcpyAsync(&mass, e->prune_mask.p, sizeof mass, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
-        if (mass * 100 < g.nnz * (uint64_t)std::min(e->opt_prune_min_drop, 100u) / 2) {   // (half the bound: the estimate is exact only for symmetric graphs)
-            pp.heavy.release();
-            return GNNVC_OK;
-        }
         if (early && mass * 100 < g.nnz * 40ull) {   // in a graph's FIRST forward the build has to pay within that forward: not at a 15 - 25 % cut
             pp.tried = false;                         // (nearly degree-uniform graphs with hubs: first forward 1.1 - 1.2 x) — with the other plans, then
             pp.deferred = true;
-            pp.heavy.release();
             return GNNVC_OK;
         }
     }
     HIP_TRY(e, gnnvc::prune_count(g, pp.heavy.p, e->prune_mask.p, e->prune_off.p, e->prune_scratch.p, e->stream));
-    uint32_t kept = 0;
-    HIP_TRY(e, hipMemcpyAsync(&kept, e->prune_off.p + chunks, sizeof kept, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    pp.kept = kept;
-    if ((uint64_t)kept * 100 > g.nnz * (uint64_t)(100 - std::min(e->opt_prune_min_drop, 100u))) {   // too little to gain
-        pp.heavy.release();
-        return GNNVC_OK;
-    }
-    HIP_TRY(e, pp.prp.reserve((size_t)held + 1));
-    HIP_TRY(e, pp.pcol.reserve((size_t)kept + GNNVC_COL_PAD));
-    HIP_TRY(e, hipMemsetAsync(pp.pcol.p + kept, 0, GNNVC_COL_PAD * sizeof(uint32_t), e->stream));
+    HIP_TRY(e, hipMemcpyAsync(pin + 4, e->prune_off.p + chunks, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    // (pcol holds room for every entry + the pad: reads a little past the kept entries — the gathering kernels' look-ahead —
+    // stay inside it whatever the count turns out to be; what they find there is masked, never used as an index)
     HIP_TRY(e, gnnvc::prune_fill(g, e->prune_mask.p, e->prune_off.p, pp.pcol.p, pp.prp.p, e->stream));
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
     pp.slist = false;
     pp.sn = 0;
     // Rows are classed by the entries they have LEFT.  The tile kernel walks a row's entries three at a time, ~1.2 us a trip:
     // a 1000-entry row holds its tile for ~0.4 ms — nothing beside the ~0.7 ms R-MAT-22's stage spends gathering, but the
     // whole stage on the power-law graph (8 M entries left: 0.57 -> 0.64 ms at 1024; R-MAT-22: 1.35 -> 1.25 ms).
-    pp.eff_thresh = kept >= e->opt_prune_heavy_entries ? e->thresh_f16 : std::max(e->long_thresh, std::min(e->thresh_f16, 512u));
-    if (e->sorted_wanted && e->opt_prune_eff) {
+    // (decided from the estimate of the entries left: the count itself arrives with the second round trip)
+    const uint64_t kept_est = g.sliced() ? g.nnz : g.nnz - std::min<uint64_t>(mass, g.nnz);
+    pp.eff_thresh = kept_est >= e->opt_prune_heavy_entries ? e->thresh_f16 : std::max(e->long_thresh, std::min(e->thresh_f16, 512u));
+    const bool slist = e->sorted_wanted && e->opt_prune_eff;
+    if (slist) {
         // tiles of the 16-wide stages from the rows sorted by the entries they have LEFT; the giant rows (by degree) are not in it
         GraphDev view = g;
         view.rowptr = pp.prp.p - g.lo();
         view.col = pp.pcol.p;
-        uint32_t zero_rows = 0;
-        int rc = sort_by_degree(e, g.lo(), g.hi(), pp.svertex, pp.smeta, pp.sn, zero_rows, &view, g.rowptr,
-                                e->giant_f16(), pp.eff_thresh);
+        rc = sort_by_degree_async(e, g.lo(), g.hi(), pp.svertex, pp.smeta, pin + 6, &view, g.rowptr, e->giant_f16(), pp.eff_thresh);
         if (rc) return rc;
+    }
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    const uint32_t kept = pin[4];
+    pp.kept = kept;
+    if ((uint64_t)kept * 100 > g.nnz * (uint64_t)(100 - std::min(e->opt_prune_min_drop, 100u))) return GNNVC_OK;   // too little to gain
+    if (slist) {
+        pp.sn = pin[6];
         pp.slist = true;
     }
     pp.ready = true;
@@ -1443,8 +1471,32 @@ int launch_main(gnnvc_engine *e, const StageChoice &c, const GraphDev &gv, const
         e->c4_fused_for = stage + 1;
         return GNNVC_OK;
     };
+    // First use of the compact-table plan on this graph: no earlier forward has said which four columns the NEXT stage's
+    // table holds, so this stage's kernel could only count, and the consumer would make a pass of its own over its whole
+    // input to write the table (k_c4_compact: 0.25 ms per stage on the metric graph — what a graph scored ONCE pays in full).
+    // A pilot — the plain gathering kernel over the first rows of this very stage — makes that choice ahead of the real
+    // run, which then writes the table on its way.  The consumer's k_c4_choose still decides from the counts of ALL rows
+    // and has the table rewritten if the pilot chose otherwise: the pilot changes time, never a result.
+    auto pilot = [&]() -> int {
+        if (!c.emit || e->c4_seeded[stage + 1] || !e->opt_pilot_rows) return GNNVC_OK;
+        e->c4_seeded[stage + 1] = true;
+        const uint32_t rows = std::min(e->opt_pilot_rows, hi - lo);
+        if ((uint64_t)rows * 8 > (uint64_t)(hi - lo)) return GNNVC_OK;   // (a graph this small is its own pilot: not worth a launch)
+        uint32_t *cons = e->c4_desc.p + gnnvc_engine::kDescWords * stage;   // consumer stage `stage + 1`
+        HIP_TRY(e, hipMemsetAsync(e->c4_emit_counts.p, 0, gnnvc::kEmitCounters * sizeof(unsigned long long), e->stream));
+        gnnvc::EmitArgs pe;
+        pe.spec = e->c4_desc.p + 2 * gnnvc_engine::kDescWords + 4;   // a word that is always 0: count, do not write table rows
+        pe.table = e->c4_table.p;
+        pe.counts = e->c4_emit_counts.p;
+        HIP_TRY(e, gnnvc::launch_stage(sp, e->g, e->ws, e->params.p, in, out, nullptr, lo, lo + rows, 0xFFFFFFFFu, /*mfma=*/false, nullptr,
+                                       /*interleave=*/true, e->stream, nullptr, nullptr, nullptr, false, pe));
+        HIP_TRY(e, gnnvc::compact_choose(e->c4_emit_counts.p, 64, rows, cons, 1u, e->stream));
+        return GNNVC_OK;
+    };
     if (c.sums == StageChoice::kLdsTable || c.sums == StageChoice::kBlocked) {
-        int rc = arm_emit();
+        int rc = pilot();
+        if (rc) return rc;
+        rc = arm_emit();
         if (rc) return rc;
     }
     if (c.sums == StageChoice::kLdsTable)
@@ -1474,8 +1526,10 @@ int launch_main(gnnvc_engine *e, const StageChoice &c, const GraphDev &gv, const
                                                 desc, e->c4_table.p, e->c4_acc.p, lo, hi, e->c4_dirty.p, e->c4_dirty_cap,
                                                 e->c4_agg16.p, e->stream, what));
     }
-    {
-        int rc = arm_emit();
+    if (c.sums != StageChoice::kLdsTable && c.sums != StageChoice::kBlocked) {
+        int rc = pilot();
+        if (rc) return rc;
+        rc = arm_emit();
         if (rc) return rc;
     }
     const gnnvc::SortedOrder *sop = c.sorted.n ? &c.sorted : nullptr;
@@ -1558,6 +1612,48 @@ int ensure_events(gnnvc_engine *e, size_t count) {
         HIP_TRY(e, hipEventCreate(&v));
         e->ev.push_back(v);
     }
+    return GNNVC_OK;
+}
+
+// What a forward needs that depends on the GRAPH alone, made when the graph is handed over (round 3): the
+// reference's driver scores every graph once (src/GNN_VC.cpp:171-192), and a plan built inside a later forward never
+// serves such a caller.  Runs behind find_long (which classed the graph) on the engine's stream; complete when it returns.
+int prepare_plans(gnnvc_engine *e) {
+    e->handoff_build_ms = 0.0;
+    if (!e->opt_handoff || e->stages.empty() || e->g.n == 0 || e->empty_slice) return GNNVC_OK;
+    const GraphDev &g = e->g;
+    const double before = e->plan_build_ms;
+    const bool skewed = e->sorted_wanted || e->n_long > 0;
+    int rc = GNNVC_OK;
+    HIP_TRY(e, e->pin_info.reserve(64));
+    HIP_TRY(e, e->dev_info.reserve(64));
+    // the tile order of the engine's rows: the first forward needs it anyway (whole-graph calls, a rank's whole slice)
+    if (e->sorted_wanted) {
+        rc = timed_build(e, [&] { return ensure_sorted(e, g.lo(), g.hi()); });
+        if (rc) return rc;
+    }
+    // The per-graph plans.  By default only where ONE use repays the build: degree-uniform graphs from opt_handoff_min_nnz
+    // entries on (metric graph: ~3.5 ms of builds against 4.3 ms saved in the very first forward; a skewed graph's F = 1 plan
+    // costs 9 - 29 ms to build and saves 0.2 - 2 ms a forward — it keeps waiting for a second forward unless asked for, "2").
+    if (!g.sliced() && (e->opt_handoff >= 2 || (!skewed && g.nnz >= e->opt_handoff_min_nnz))) {
+        if (!e->lt_tried) rc = build_lds_table(e);
+        if (rc) return rc;
+        if (!e->c4_tried && !e->c4_range_mode) rc = build_compact(e);
+        if (rc) return rc;
+    }
+    // pruned adjacency: it needs a stage's INPUT and is built inside a forward — with every buffer it wants already here
+    if (skewed && e->opt_prune && g.nnz >= e->opt_prune_min_nnz && g.nnz < (1ull << 32) && !(g.sliced() && e->opt_prune == 2)) {
+        for (int st = 1; st < (int)e->stages.size() && st < 4; ++st)
+            if (e->stages[st].f == 16) {
+                rc = reserve_prune(e, st);
+                if (rc) return rc;
+            }
+    }
+    if (!g.sliced()) {
+        rc = ensure_events(e, e->stages.size() + 1);
+        if (rc) return rc;
+    }
+    e->handoff_build_ms = e->plan_build_ms - before;
     return GNNVC_OK;
 }
 
@@ -1687,6 +1783,8 @@ void gnnvc_destroy(gnnvc_engine *e) {
     e->pin_rowptr.release(); e->pin_col.release(); e->pin_w.release(); e->pin_nw.release(); e->fit_pin.release();
     if (e->ev_fit) (void)hipEventDestroy(e->ev_fit);
     e->pin_small.release();
+    e->pin_info.release();
+    e->dev_info.release();
     for (auto &r : e->srt) { r.vertex.release(); r.meta.release(); }
     e->srt_hist.release(); e->srt_sum.release();
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -1747,6 +1845,9 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "lds_table_skewed") e->opt_lds_skewed = value != 0 ? 1 : 0;
     else if (k == "lds_table_skewed_rows") e->opt_lds_skewed_rows = value > 0 ? (uint32_t)value : 0u;
     else if (k == "lds_table") e->opt_lds_table = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
+    else if (k == "plans_at_handoff") e->opt_handoff = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
+    else if (k == "handoff_min_entries") e->opt_handoff_min_nnz = value > 0 ? (uint64_t)value : 0;
+    else if (k == "pilot_rows") e->opt_pilot_rows = value > 0 ? (uint32_t)value : 0u;
     else if (k == "sorted_min_nnz") e->opt_sorted_min_nnz = value > 0 ? (uint64_t)value : 0;
     else if (k == "sorted_long_row_threshold") { e->opt_sorted_long_thresh = value > 0 ? (uint32_t)value : 1; e->opt_long_auto = false; }
     else if (k == "mfma_dense") e->opt_mfma = (value >= 0 && value <= 2) ? (int)value : 2;
@@ -1786,7 +1887,8 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
     else if (k == "compact_gather_mapped_rows") *value = e->c4_ready ? (long)e->c4_mapped_rows : 0;
     else if (k == "compact_gather_mapped_entries") *value = e->c4_ready ? (long)e->c4_mapped_entries : 0;
     else if (k == "compact_gather_max_passes") *value = e->c4_ready ? (long)e->c4_max_passes : 0;
-    else if (k == "compact_gather_last_ok" || k == "compact_gather_last_dirty" || k == "compact_gather_last_passes") {
+    else if (k == "compact_gather_last_ok" || k == "compact_gather_last_dirty" || k == "compact_gather_last_passes" ||
+             k == "compact_table_written_by_producer") {
         // what the device decided at the last launch of the plan (waits for the stream; for tests and tools)
         *value = 0;
         if (e->c4_ready && e->c4_desc.p) {
@@ -1794,7 +1896,8 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
             if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess ||
                 hipMemcpy(d, e->c4_desc.p + e->c4_last_desc, sizeof d, hipMemcpyDeviceToHost) != hipSuccess)
                 return GNNVC_ERR_DEVICE;
-            *value = k == "compact_gather_last_ok" ? (d[0] ? 1 : 0) : (k == "compact_gather_last_passes" ? (long)d[0] : (long)d[5]);
+            if (k == "compact_table_written_by_producer") *value = (d[0] && !d[6]) ? 1 : 0;   // (no compaction pass was needed)
+            else *value = k == "compact_gather_last_ok" ? (d[0] ? 1 : 0) : (k == "compact_gather_last_passes" ? (long)d[0] : (long)d[5]);
         }
     }
     else if (k == "lds_table_active") *value = e->lt_ready ? 1 : 0;
@@ -1807,6 +1910,9 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
     else if (k == "block_cols") *value = e->blocked_ready ? (long)e->blk_cols : 0;
     else if (k == "long_rows") *value = (long)e->n_long;
     else if (k == "plan_build_us") *value = (long)(e->plan_build_ms * 1000.0);
+    else if (k == "handoff_build_us") *value = (long)(e->handoff_build_ms * 1000.0);
+    else if (k == "plans_at_handoff") *value = e->opt_handoff;
+    else if (k == "graph_uses") *value = (long)e->graph_uses;
     else if (k == "slice_rows") *value = e->empty_slice ? 0 : (long)(e->g.hi() - e->g.lo());
     else if (k == "slice_entries") *value = (long)e->g.nnz;
     else if (k == "giant_rows") *value = (long)e->n_giant;
@@ -1855,6 +1961,7 @@ static int adopt_uploaded(gnnvc_engine *e, uint32_t n, uint64_t nnz) {
     e->g = GraphDev{n, nnz, e->rowptr.p, e->col.p, e->w.p, e->nw.p};
     e->have_graph = true;
     e->empty_slice = false;
+    e->der_open = false;   // (a derivation begun against the previous graph must not be committed against this one)
     int rc = reserve_features(e, n);
     if (rc) return rc;
     e->lt_ready = e->lt_tried = false;
@@ -1868,7 +1975,10 @@ static int adopt_uploaded(gnnvc_engine *e, uint32_t n, uint64_t nnz) {
     e->blocked_tried = false;   // it costs about as much as it saves on one, and the reference's
     e->graph_uses = 0;          // driver uses every graph exactly once (src/GNN_VC.cpp:171-192)
     e->plan_build_ms = 0.0;
-    return find_long(e);
+    for (bool &b : e->c4_seeded) b = false;
+    rc = find_long(e);
+    if (rc) return rc;
+    return prepare_plans(e);   // ... which is why what depends on the graph alone is built here, not in a later forward
 }
 
 int gnnvc_upload_graph(gnnvc_engine *e, uint32_t n, const uint64_t *rowptr, const uint32_t *col,
@@ -1881,6 +1991,7 @@ int gnnvc_upload_graph(gnnvc_engine *e, uint32_t n, const uint64_t *rowptr, cons
     if (nnz >= 0xFFFFFFFFull - GNNVC_COL_PAD)
         return fail(e, GNNVC_ERR_UNSUPPORTED, "nnz %llu does not fit 32-bit row pointers", (unsigned long long)nnz);
     if (nnz && !col) return fail(e, GNNVC_ERR_INVALID, "null column array");
+    e->der_open = false;
     HIP_TRY(e, e->rowptr.reserve((size_t)n + 1));
     HIP_TRY(e, e->col.reserve(nnz + GNNVC_COL_PAD));
     HIP_TRY(e, e->w.reserve(n));
@@ -1944,6 +2055,7 @@ int gnnvc_staged_columns_ready(gnnvc_engine *e, uint64_t first, uint64_t count) 
     if (rc) return rc;
     if (!e->staged_sent) {   // first piece: the device array is about to be overwritten
         e->have_graph = false;
+        e->der_open = false;
         HIP_TRY(e, e->col.reserve(e->staged_nnz + GNNVC_COL_PAD));
     }
     HIP_TRY(e, hipMemcpyAsync(e->col.p + first, e->pin_col.p + first, count * sizeof(uint32_t), hipMemcpyHostToDevice,
@@ -1998,6 +2110,7 @@ static int attach_common(gnnvc_engine *e, const GraphDev &cand) {
     e->g = cand;
     e->have_graph = true;
     e->empty_slice = false;
+    e->der_open = false;
     int rc = reserve_features(e, cand.n);
     if (rc) return rc;
     e->lt_ready = e->lt_tried = false;
@@ -2011,7 +2124,10 @@ static int attach_common(gnnvc_engine *e, const GraphDev &cand) {
     e->blocked_tried = false;   // it costs about as much as it saves on one, and the reference's
     e->graph_uses = 0;          // driver uses every graph exactly once (src/GNN_VC.cpp:171-192)
     e->plan_build_ms = 0.0;
-    return find_long(e);
+    for (bool &b : e->c4_seeded) b = false;
+    rc = find_long(e);
+    if (rc) return rc;
+    return prepare_plans(e);   // ... which is why what depends on the graph alone is built here, not in a later forward
 }
 
 /* ---- the next graph derived from the resident one ---------------------------------------------
@@ -2063,6 +2179,8 @@ int gnnvc_derive_graph_commit(gnnvc_engine *e, const uint32_t *tail_cols, uint64
     if (!e) return GNNVC_ERR_INVALID;
     if (!e->der_open) return fail(e, GNNVC_ERR_STATE, "gnnvc_derive_graph_begin first");
     e->der_open = false;
+    if (!e->have_graph || e->g.rowptr != e->rowptr.p || e->g.col != e->col.p || e->g.sliced() || e->empty_slice)
+        return fail(e, GNNVC_ERR_STATE, "the resident graph changed since gnnvc_derive_graph_begin");
     const uint32_t n = e->der_n_new;
     if (n_tail != e->der_tail_total) return fail(e, GNNVC_ERR_INVALID, "expected %llu tail entries, got %llu",
                                                  (unsigned long long)e->der_tail_total, (unsigned long long)n_tail);
@@ -2133,6 +2251,7 @@ int gnnvc_attach_graph_slice(gnnvc_engine *e, uint32_t n_global, uint32_t row_lo
     cand.row_base = row_lo;
     cand.row_end = row_hi ? row_hi : 0;
     if (row_lo == 0 && row_hi == n_global) cand.row_end = 0;   // the whole graph after all
+    e->der_open = false;
     if (row_hi == 0) {   // an empty slice at the front: nothing to compute, nothing to index
         e->g = GraphDev{n_global, 0, d_rowptr_local, d_col_local, d_w_local, d_nw_local};
         e->g.row_base = 0;
@@ -2211,6 +2330,9 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
     }
     if (!e->fit_pending)
         for (int s = 0; s < 4; ++s) e->fit_used[s] = false;
+    struct SinkGuard {   // the thread-local sink never outlives this call, whichever way it returns
+        ~SinkGuard() { gnnvc::set_kernel_trace(nullptr); }
+    } sink_guard;
     if (e->opt_ktrace && e->ktrace.used < 16384) {   // records pile up over forwards until gnnvc_kernel_trace reads them
         e->ktrace.stream = e->stream;
         gnnvc::set_kernel_trace(&e->ktrace);
@@ -2288,10 +2410,15 @@ int gnnvc_forward(gnnvc_engine *e, const float *x, float *scores, float *logits)
     if (!e) return GNNVC_ERR_INVALID;
     if (!e->have_graph) return fail(e, GNNVC_ERR_STATE, "no graph attached");
     const uint32_t n = e->g.n;
+    if (e->layers.empty()) return fail(e, GNNVC_ERR_STATE, "engine was created without a model");
     if (n == 0) return GNNVC_OK;
+    // (before the copy below: a sliced engine has no feature buffers of its own — e->x may be null or sized for an earlier graph)
+    if (e->g.sliced() || e->empty_slice)
+        return fail(e, GNNVC_ERR_STATE, "this engine holds a slice of the graph: run it stage by stage (gnnvc_stage_forward_device)");
     if (!x || !scores) return fail(e, GNNVC_ERR_INVALID, "null host buffers");
     int rc = use_device(e);
     if (rc) return rc;
+    if (e->x.cap < ((size_t)n + 1) * (size_t)e->in_width) return fail(e, GNNVC_ERR_STATE, "feature buffers are not sized for this graph");
     const size_t in_b = (size_t)n * e->in_width * sizeof(float);
     const size_t out_b = (size_t)n * e->out_width * sizeof(float);
     HIP_TRY(e, hipMemcpyAsync(e->x.p, x, in_b, hipMemcpyHostToDevice, e->stream));

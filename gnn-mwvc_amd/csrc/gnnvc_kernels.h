@@ -42,6 +42,9 @@ struct GraphDev {
 #endif
     uint32_t hi() const { return row_end ? row_end : n; }
     bool sliced() const { return row_end != 0 && (row_base != 0 || row_end != n); }
+#if defined(__HIPCC__)
+    __host__ __device__ bool sliced_dev() const { return row_end != 0 && (row_base != 0 || row_end != n); }
+#endif
 };
 
 // One fused stage = graph layer (input width F) followed by up to three dense
@@ -114,6 +117,9 @@ hipError_t measure_tile_waste(const GraphDev &g, uint32_t row_lo, uint32_t row_h
 hipError_t degree_histogram(const GraphDev &g, uint32_t row_lo, uint32_t row_hi, uint32_t long_thresh,
                             uint32_t bins, uint32_t *hist, hipStream_t stream, const uint32_t *skip_rowptr = nullptr,
                             uint32_t skip_from = 0xFFFFFFFFu);
+// hist (degree_histogram) -> in place the first slot of every class, heaviest class first; info[0] = rows listed, info[1] = rows
+// without entries (device memory, 2 words)
+hipError_t degree_starts(uint32_t *hist, uint32_t bins, uint32_t *info, hipStream_t stream);
 hipError_t degree_scatter(const GraphDev &g, uint32_t row_lo, uint32_t row_hi, uint32_t long_thresh,
                           uint32_t bins, uint32_t *cursor, uint32_t *vertex, void *meta, hipStream_t stream,
                           const uint32_t *skip_rowptr = nullptr, uint32_t skip_from = 0xFFFFFFFFu);
@@ -218,7 +224,8 @@ hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_
 hipError_t prune_observe(const GraphDev &g, const float *feat, uint32_t *max_deg, hipStream_t stream);
 hipError_t prune_mark_degree(const GraphDev &g, uint32_t bound, uint32_t *heavy_bits, hipStream_t stream);
 hipError_t prune_mark_zero(const GraphDev &g, const float *feat, uint32_t *heavy_bits, hipStream_t stream);
-// *mass = sum of the degrees of the set's vertices (whole graphs: the entries that point to them, if the adjacency is symmetric)
+// mass[0] = sum of the degrees of the set's vertices (whole graphs: the entries that point to them, if the adjacency is symmetric;
+// 0 on a slice), mass[1] = vertices in the set
 hipError_t prune_mass(const GraphDev &g, const uint32_t *heavy_bits, unsigned long long *mass, hipStream_t stream);
 hipError_t prune_count(const GraphDev &g, const uint32_t *heavy_bits, unsigned long long *mask, uint32_t *off, uint32_t *scratch,
                        hipStream_t stream);
@@ -267,6 +274,8 @@ hipError_t launch_compact_gather(const GraphDev &g, const CompactPlan &cp, const
                                  uint32_t *dirty_rows, uint32_t dirty_cap, float *agg16, hipStream_t stream,
                                  int what = 3 /* 1 = prepare, 2 = sums, 3 = both */);
 
+hipError_t compact_choose(const unsigned long long *counts, int count_slots, uint32_t rows, uint32_t *desc, uint32_t max_passes,
+                          hipStream_t stream);
 // the parts of launch_compact_gather's second half, for callers that run them round by round
 hipError_t compact_sums(const GraphDev &g, const CompactPlan &cp, uint32_t *desc, const float *table, float *acc4, uint32_t row_lo,
                         uint32_t row_hi, uint32_t *dirty_rows, uint32_t dirty_cap, hipStream_t stream, bool one_round = false);

@@ -2642,15 +2642,26 @@ __global__ __launch_bounds__(256) void k_prune_mark_zero(const float4 *__restric
     if ((threadIdx.x & 63) == 1 && w0 + 1 < words) heavy_bits[w0 + 1] = (uint32_t)(m >> 32);
 }
 
-// *mass += the degrees of the set's vertices: on a symmetric adjacency, the entries that point to them
+// mass[0] += the degrees of the set's vertices (on a symmetric adjacency: the entries that point to them; whole graphs only —
+// a slice does not hold the other rows' degrees), mass[1] += the number of vertices in the set
 __global__ __launch_bounds__(256) void k_prune_mass(GraphDev g, const uint32_t *__restrict__ heavy_bits, unsigned long long *__restrict__ mass) {
     unsigned long long mine = 0;
+    uint32_t members = 0;
+    const bool degrees = !g.sliced_dev();
     for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < g.n; u += gridDim.x * blockDim.x)
-        if (heavy_bits[u >> 5] >> (u & 31) & 1u) mine += g.rowptr[u + 1] - g.rowptr[u];
+        if (heavy_bits[u >> 5] >> (u & 31) & 1u) {
+            if (degrees) mine += g.rowptr[u + 1] - g.rowptr[u];
+            ++members;
+        }
 #pragma unroll
-    for (int off = 32; off; off >>= 1)
+    for (int off = 32; off; off >>= 1) {
         mine += ((unsigned long long)__shfl_xor((unsigned)(mine >> 32), off) << 32) | __shfl_xor((unsigned)mine, off);
-    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(mass, mine);
+        members += __shfl_xor(members, off);
+    }
+    if ((threadIdx.x & 63) == 0 && members) {
+        if (mine) atomicAdd(mass, mine);
+        atomicAdd(mass + 1, (unsigned long long)members);
+    }
 }
 
 // Building the pruned CSR: the engine's entries taken FLAT, in chunks of 64 (one wave trip), whatever rows they belong to —
@@ -2780,6 +2791,35 @@ __global__ __launch_bounds__(256) void k_deg_hist(GraphDev g, uint32_t row_lo, u
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < bins; i += blockDim.x)
         if (local[i]) atomicAdd(&hist[i], local[i]);
+}
+
+// hist[d] (rows of degree class d) -> in place, the first slot of class d with the classes laid out by DEscending degree;
+// info[0] = rows listed, info[1] = rows of class 0 (no entry).  One wave; bins <= 4096.
+__global__ __launch_bounds__(64) void k_deg_starts(uint32_t *__restrict__ hist, uint32_t bins, uint32_t *__restrict__ info) {
+    const uint32_t lane = threadIdx.x, per = (bins + 63u) / 64u;
+    // lane l owns classes [hi - per, hi) counted from the top: lane 0 the heaviest
+    const uint32_t top = bins > lane * per ? bins - lane * per : 0u, bot = top > per ? top - per : 0u;
+    uint32_t mine = 0;
+    for (uint32_t d = bot; d < top; ++d) mine += hist[d];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off);
+        if ((int)lane >= off) incl += t;
+    }
+    const uint32_t zero_rows = hist[0];
+    const uint32_t total = __shfl(incl, 63);
+    __builtin_amdgcn_s_waitcnt(0);   // (hist[0] above is read before any lane overwrites it: one wave, program order)
+    uint32_t run = incl - mine;
+    for (uint32_t d = top; d-- > bot;) {
+        const uint32_t h = hist[d];
+        hist[d] = run;
+        run += h;
+    }
+    if (lane == 0) {
+        info[0] = total;
+        info[1] = zero_rows;
+    }
 }
 
 // cursor[d] holds the next free slot of degree class d (classes laid out by DEscending degree,
@@ -3474,7 +3514,8 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
                        LG_, P, row_lo, row_hi, long_thresh, sorted ? so->vertex : nullptr,                \
                        sorted ? so->meta : nullptr, sorted ? so->n : 0u, il,                              \
                        (const float4 *)nullptr, acc4 ? c4desc : nullptr, (const float4 *)nullptr,                         \
-                       (const uint32_t *)nullptr, (c4row *)nullptr, (unsigned long long *)nullptr,                        \
+                       (MF_ || SIG_) ? nullptr : emit.spec, reinterpret_cast<c4row *>((MF_ || SIG_) ? nullptr : emit.table), \
+                       (MF_ || SIG_) ? nullptr : emit.counts,                                                             \
                        with_p ? so_pruned->vertex : nullptr, with_p ? so_pruned->meta : nullptr, n_p)
     case 2:
         if (sorted) GNNVC_LAUNCH_F16(32, 16, false, false, true, GNNVC_GATHER_S_SORTED, nullptr);
@@ -3743,7 +3784,7 @@ hipError_t prune_mark_zero(const GraphDev &g, const float *feat, uint32_t *heavy
 // mask: one 64-bit word per chunk of 64 entries, off: chunks + 1 words (scanned in place: off[chunks] = kept entries;
 // scratch as for blocked_scan_scratch_elems(chunks + 1))
 hipError_t prune_mass(const GraphDev &g, const uint32_t *heavy_bits, unsigned long long *mass, hipStream_t stream) {
-    hipError_t rc = hipMemsetAsync(mass, 0, sizeof(unsigned long long), stream);
+    hipError_t rc = hipMemsetAsync(mass, 0, 2 * sizeof(unsigned long long), stream);
     if (rc != hipSuccess || g.n == 0) return rc;
     GNNVC_LAUNCH(k_prune_mass, dim3(std::min<unsigned>((g.n + 255) / 256, 2048u)), dim3(256), 0, stream, g, heavy_bits, mass);
     return hipGetLastError();
@@ -3862,6 +3903,13 @@ hipError_t launch_compact_gather(const GraphDev &g, const CompactPlan &cp, const
     return compact_fix(g, in, desc, dirty_rows, dirty_cap, agg16, nullptr, stream);
 }
 
+// the choice of table columns alone, from counters that cover `rows` rows (a pilot over the first rows of a stage's output)
+hipError_t compact_choose(const unsigned long long *counts, int count_slots, uint32_t rows, uint32_t *desc, uint32_t max_passes,
+                          hipStream_t stream) {
+    GNNVC_LAUNCH(k_c4_choose, dim3(1), dim3(64), 0, stream, counts, count_slots, rows, desc, max_passes);
+    return hipGetLastError();
+}
+
 // the sums of the chunks that hold rows [row_lo, row_hi) (the dirty-row counter desc[5] is the caller's to reset): one
 // launch per pass the plan allows; the launches of passes the device did not choose (desc[0]) leave at once
 hipError_t compact_sums(const GraphDev &g, const CompactPlan &cp, uint32_t *desc, const float *table, float *acc4, uint32_t row_lo,
@@ -3931,6 +3979,12 @@ hipError_t degree_histogram(const GraphDev &g, uint32_t row_lo, uint32_t row_hi,
     if (rc != hipSuccess || row_hi <= row_lo) return rc;
     const unsigned nb = std::min<unsigned>((row_hi - row_lo + 255) / 256, 2048u);
     GNNVC_LAUNCH(k_deg_hist, dim3(nb), dim3(256), 0, stream, g, row_lo, row_hi, long_thresh, bins, hist, skip_rowptr, skip_from);
+    return hipGetLastError();
+}
+
+hipError_t degree_starts(uint32_t *hist, uint32_t bins, uint32_t *info, hipStream_t stream) {
+    if (bins == 0 || bins > 4096) return hipErrorInvalidValue;
+    GNNVC_LAUNCH(k_deg_starts, dim3(1), dim3(64), 0, stream, hist, bins, info);
     return hipGetLastError();
 }
 

@@ -45,13 +45,15 @@ def library_path() -> pathlib.Path:
 
 def build_library(force: bool = False) -> pathlib.Path:
     """hipcc --offload-arch=gfx950 build of csrc/ (cross-compiles without a GPU)."""
-    srcs = [_PKG / "csrc" / n for n in ("gnnvc_kernels.hip", "gnnvc_engine.cpp", "gnnvc_kernels.h")]
-    srcs.append(_PKG.parent / "include" / "gnnvc.h")
-    stale = (not _LIB.exists()) or any(s.stat().st_mtime > _LIB.stat().st_mtime for s in srcs)
-    if force or stale:
-        r = subprocess.run(["make", "-C", str(_PKG / "csrc")], capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("building libgnnvc_hip.so failed:\n" + r.stdout + r.stderr)
+    if os.environ.get("GNNVC_LIBRARY"):
+        # an external build was asked for: it is the caller's to keep current (make only knows the in-tree library)
+        if not _LIB.exists():
+            raise FileNotFoundError(f"GNNVC_LIBRARY={_LIB} does not exist")
+        return _LIB
+    # make decides what is stale (csrc/Makefile lists every source and header the library depends on)
+    r = subprocess.run(["make", "-C", str(_PKG / "csrc")] + (["-B"] if force else []), capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libgnnvc_hip.so failed:\n" + r.stdout + r.stderr)
     return _LIB
 
 

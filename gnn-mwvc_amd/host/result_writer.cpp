@@ -19,7 +19,8 @@ std::string write_cover_file(const std::string &path, const uint8_t *in_cover, s
     if (!f) return "cannot open " + path + ": " + std::strerror(errno);
     const std::string text = cover_text(in_cover, n);
     const size_t done = text.empty() ? 0 : std::fwrite(text.data(), 1, text.size(), f);
-    const bool ok = done == text.size() && std::fclose(f) == 0;
+    const bool closed = std::fclose(f) == 0;   // (always: a short write must not leak the handle)
+    const bool ok = done == text.size() && closed;
     if (!ok) return "short write to " + path;
     return "";
 }

@@ -68,6 +68,18 @@ int gnnvc_set_weight_scale(gnnvc_engine *e, float ws);
 int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
 
 /* Tuning options (take effect at the next graph upload / attach):
+ *   "plans_at_handoff" 0|1|2  WHEN the per-graph plans below are built.  The reference's driver hands predict a new graph every
+ *                         call and scores it once (src/GNN_VC.cpp:171-192), so what depends on the graph alone is built when
+ *                         the graph is handed over (upload / staged commit / attach), not inside a later forward: 1 (default) =
+ *                         the plans that ONE forward repays (degree-uniform graphs of at least "handoff_min_entries"
+ *                         adjacency entries, default 48 Mi: LDS table + compact table; every graph: its tile order and
+ *                         every buffer a forward would otherwise allocate), 2 = every plan the graph qualifies for whatever
+ *                         it costs (callers who score a graph many times, or hide the build under a copy), 0 = inside the
+ *                         graph's first two forwards (round 2's behaviour).  gnnvc_get_info "handoff_build_us" = what it took
+ *   "pilot_rows"     n    first use of the compact-table plan on a graph: the producing stage's plain kernel over its first n
+ *                         rows (default 65536, 0 = off) picks the next stage's table columns ahead of the real run, which
+ *                         then writes the table on its way; the choice is re-made from the counts of all rows, so the pilot
+ *                         changes time, never a result
  *   "blocked_stage0" 0|1  column-blocked plan of the F = 1 stage (default 1; results are
  *                         bit-identical either way, it only changes memory traffic)
  *   "lds_table"      0|1|2  LDS-table plan of the F = 1 stage: when every weight fits a byte and the
@@ -330,9 +342,10 @@ int gnnvc_synchronize(gnnvc_engine *e);
  * engine's stream: total and per stage, in milliseconds (waits for them). */
 int gnnvc_last_forward_ms(gnnvc_engine *e, float *total_ms, float *stage_ms, int max_stages);
 
-/* Per-kernel HIP-event timings of the last gnnvc_forward_device, when option "kernel_trace" is 1 (bench.py's
- * roofline block): every kernel the forward launched on the engine's stream, in launch order — names[i] (static
- * strings: the kernel as written at its launch site) and ms[i]; *count = how many there were (may exceed max).
+/* Per-kernel HIP-event timings of the gnnvc_forward_device calls made since the last call of this function, when
+ * option "kernel_trace" is 1 (bench.py's roofline block): every kernel those forwards launched on the engine's
+ * stream, in launch order — names[i] (static strings: the kernel as written at its launch site) and ms[i];
+ * *count = how many there were (may exceed max; at most 16384 are kept).  Reading clears the records.
  * Kernels on the engine's side streams (long / giant rows, overlapped dense rounds) are not listed.  Waits. */
 int gnnvc_kernel_trace(gnnvc_engine *e, int max, const char **names, float *ms, int *count);
 

@@ -909,6 +909,155 @@ def test_plan_built_inside_the_first_forward(model_text, oracle_model):
             e.close()
 
 
+@pytest.mark.parametrize("route", ["upload", "staged", "attach"])
+def test_plans_built_at_hand_off(model_text, oracle_model, route):
+    """"plans_at_handoff" (round 3): what depends on the graph alone exists when the hand-off returns — before any forward —
+    on every hand-off route, the first forward runs on it (table columns from the pilot), and the bits are the oracle's.
+    With 0 the plans wait for the graph's first forwards as in round 2."""
+    import gnn_mwvc_amd as G
+    g = gg.erdos_renyi(40000, 400000, 73)
+    oracle_model.set_weight_scale(g.ws)
+    want = oracle_model.logits(g)
+
+    def hand_over(e):
+        if route == "upload":
+            e.upload_graph(g)
+        elif route == "staged":
+            e.upload_graph_staged(g, pieces=3)
+        else:
+            import torch
+            from tools import graphgen_torch as ggt
+            dg = ggt.from_host(g, torch.device("cuda:0"))
+            torch.cuda.synchronize()
+            e.attach_graph_device(dg.n, dg.nnz, dg.rowptr.data_ptr(), dg.col.data_ptr(), dg.w.data_ptr(), dg.nw.data_ptr(), keepalive=dg)
+
+    for handoff in (1, 2, 0):
+        e = G.Engine(model_text, device=0)
+        try:
+            e.set_option("blocked_min_n", 0)              # let the plans apply to a small graph
+            e.set_option("plans_at_handoff", handoff)
+            e.set_option("handoff_min_entries", 1)
+            e.set_option("pilot_rows", 2048)
+            e.set_weight_scale(g.ws)
+            hand_over(e)
+            assert e.get_info("graph_uses") == 0
+            built = 1 if handoff else 0
+            assert e.get_info("lds_table_active") == built and e.get_info("compact_gather_active") == built, (route, handoff)
+            assert (e.get_info("handoff_build_us") > 0) == bool(built)
+            _, lg = e.forward(g.x())
+            assert np.array_equal(bits(lg[:, 0]), bits(want)), (route, handoff)
+            if built:
+                assert e.get_info("compact_gather_last_ok") == 1      # the device took the plan's route in the FIRST forward
+            for rep in range(3):
+                _, lg = e.forward(g.x())
+                assert np.array_equal(bits(lg[:, 0]), bits(want)), (route, handoff, rep)
+            assert e.get_info("lds_table_active") == 1 and e.get_info("compact_gather_active") == 1
+            # the next graph handed to the same engine gets its own plans (and none of this one's)
+            g2 = gg.erdos_renyi(30000, 330000, 74)
+            e.set_weight_scale(g2.ws)
+            oracle_model.set_weight_scale(g2.ws)
+            e.upload_graph(g2)
+            assert e.get_info("lds_table_active") == built and e.get_info("graph_uses") == 0
+            _, lg = e.forward(g2.x())
+            assert np.array_equal(bits(lg[:, 0]), bits(oracle_model.logits(g2))), (route, handoff)
+            oracle_model.set_weight_scale(g.ws)
+        finally:
+            e.close()
+
+
+def test_pilot_choice_never_changes_a_result(model_text, oracle_model):
+    """The pilot picks the next stage's table columns from the FIRST rows of a stage.  Here those rows are unlike the rest
+    (their weights are tiny, other columns light up): the consumer's choice from all rows differs, the table is rewritten,
+    the logits are the oracle's — on the first forward and on the ones after it."""
+    import gnn_mwvc_amd as G
+    g = gg.erdos_renyi(40000, 400000, 75)
+    w = g.w.copy()
+    w[:4096] = 1
+    g = gg.CsrGraph(g.n, g.rowptr, g.col, w, gg.neighbourhood_weights(g.rowptr, g.col, w))
+    oracle_model.set_weight_scale(g.ws)
+    want = oracle_model.logits(g)
+    for pilot in (2048, 0):
+        e = G.Engine(model_text, device=0)
+        try:
+            e.set_option("blocked_min_n", 0)
+            e.set_option("handoff_min_entries", 1)
+            e.set_option("pilot_rows", pilot)
+            e.set_weight_scale(g.ws)
+            e.upload_graph(g)
+            for rep in range(3):
+                _, lg = e.forward(g.x())
+                assert np.array_equal(bits(lg[:, 0]), bits(want)), (pilot, rep)
+        finally:
+            e.close()
+
+
+def test_whole_graph_calls_on_a_slice_are_state_errors(model_text):
+    """the host-pointer gnnvc_forward on an engine that holds a slice (or an empty slice) must say
+    GNNVC_ERR_STATE before it touches a buffer — a sliced engine has no feature buffers of its own."""
+    import gnn_mwvc_amd as G
+    import torch
+    from gnn_mwvc_amd import distributed as D
+    g = gg.erdos_renyi(3000, 20000, 9)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(a.astype(np.int64)).to(torch.int32).to(dev)
+    rp, col, w, nw = t(g.rowptr), t(g.col), t(g.w), t(g.nw)
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_weight_scale(g.ws)
+        for lo, hi in ((1000, 2500), (0, 0), (1200, 1200)):
+            sl = D.slice_csr(g.n, rp, col, w, nw, lo, hi)
+            torch.cuda.synchronize()
+            e.attach_graph_slice(g.n, lo, hi, sl.nnz, sl.rowptr.data_ptr(), sl.col.data_ptr(), sl.w.data_ptr(), sl.nw.data_ptr(),
+                                 keepalive=sl)
+            e.n = g.n
+            with pytest.raises(G.GnnvcError) as err:
+                e.forward(g.x())
+            assert err.value.code == -4, (lo, hi, err.value)          # GNNVC_ERR_STATE
+        # ... also right after the engine held a (smaller) whole graph: its stale buffers must not be written
+        small = gg.erdos_renyi(100, 300, 1)
+        e.upload_graph(small)
+        e.forward(small.x())
+        sl = D.slice_csr(g.n, rp, col, w, nw, 500, 2000)
+        torch.cuda.synchronize()
+        e.attach_graph_slice(g.n, 500, 2000, sl.nnz, sl.rowptr.data_ptr(), sl.col.data_ptr(), sl.w.data_ptr(), sl.nw.data_ptr(), keepalive=sl)
+        e.n = g.n
+        with pytest.raises(G.GnnvcError) as err:
+            e.forward(g.x())
+        assert err.value.code == -4
+    finally:
+        e.close()
+
+
+def test_derive_commit_after_a_graph_change_is_refused(model_text, oracle_model):
+    """a derivation begun against one resident graph cannot be committed against another."""
+    import ctypes as C
+    import gnn_mwvc_amd as G
+    rng = np.random.default_rng(3)
+    g0 = gg.erdos_renyi(4000, 24000, 5)
+    other = gg.erdos_renyi(900, 3000, 6)
+    g1, old_row = _shrunk_graph(g0, rng, 0.7, 20, 10)
+    e = G.Engine(model_text, device=0)
+    try:
+        e.upload_graph(g0)
+        L = e._L
+        rp = np.ascontiguousarray(g1.rowptr.astype(np.uint32))
+        tail = np.zeros(g1.n, dtype=np.uint32)
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        assert L.gnnvc_derive_graph_begin(e._h, g1.n, ptr(np.ascontiguousarray(old_row, dtype=np.uint32)), ptr(rp), ptr(tail)) == 0
+        e.upload_graph(other)                                # the resident graph changes between begin and commit
+        ends = g1.rowptr.astype(np.int64)[1:]
+        pieces = [g1.col[en - t: en] for en, t in zip(ends[tail > 0], tail[tail > 0])]
+        tails = np.ascontiguousarray(np.concatenate(pieces) if pieces else np.zeros(0, np.uint32), dtype=np.uint32)
+        rc = L.gnnvc_derive_graph_commit(e._h, ptr(tails), tails.size, ptr(np.ascontiguousarray(g1.w)), ptr(np.ascontiguousarray(g1.nw)))
+        assert rc == -4                                      # GNNVC_ERR_STATE
+        e.set_weight_scale(other.ws)                         # ... and the graph that IS resident still scores
+        oracle_model.set_weight_scale(other.ws)
+        _, lg = e.forward(other.x())
+        assert np.array_equal(bits(lg[:, 0]), bits(oracle_model.logits(other)))
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("maker", [
     lambda: gg.erdos_renyi(30000, 45000, 81),                      # 3 entries per row: one row in twenty is empty, often several in a row
     lambda: gg.from_edge_list(3000, [(i, i + 1) for i in range(0, 2999, 7)] + [(5, j) for j in range(900, 1100)], [20 + i % 100 for i in range(3000)]),   # mostly empty rows, one of 200 entries
