@@ -20,6 +20,7 @@
 
 #include "../../include/gnnvc.h"
 #include "gnnvc_kernels.h"
+#include "gnnvc_multi.h"
 
 using gnnvc::GraphDev;
 using gnnvc::StagePlan;
@@ -81,6 +82,9 @@ struct PinBuf {
 
 struct gnnvc_engine {
     int device = 0;
+    // gnnvc_create_multi: this handle is the FRONT of several devices — an ordinary engine on devices[0] (model, layer-level
+    // entry points, staging memory, the assembled scores) whose graph hand-offs and forwards go to `multi` (gnnvc_multi.cpp)
+    gnnvc::MultiState *multi = nullptr;
     std::string name;
     std::vector<Layer> layers;
     std::vector<StagePlan> stages;  // non-empty iff fused
@@ -313,6 +317,12 @@ int fail(gnnvc_engine *e, int code, const char *fmt, ...) {
         if (rc_ != hipSuccess)                                                             \
             return fail((e), rc_ == hipErrorOutOfMemory ? GNNVC_ERR_NOMEM : GNNVC_ERR_DEVICE, \
                         "%s: %s", #call, hipGetErrorString(rc_));                          \
+    } while (0)
+
+// entry points that read ONE device's resident graph have no meaning on the front of several devices
+#define NOT_ON_MULTI(e, what)                                                                                          \
+    do {                                                                                                               \
+        if ((e)->multi) return fail((e), GNNVC_ERR_UNSUPPORTED, what " is not available on a multi-device handle (gnnvc_create_multi)"); \
     } while (0)
 
 int hip_rc(gnnvc_engine *e, hipError_t rc) {
@@ -1606,6 +1616,15 @@ int reserve_features(gnnvc_engine *e, uint32_t n) {
     return GNNVC_OK;
 }
 
+// the front of a multi-device handle keeps the input and the assembled scores / logits of the host-pointer forward on its device
+int reserve_multi_front(gnnvc_engine *e, uint32_t n) {
+    const size_t rows = (size_t)n + 1;
+    HIP_TRY(e, e->x.reserve(rows * (size_t)e->in_width));
+    HIP_TRY(e, e->scores.reserve(rows * (size_t)e->out_width));
+    HIP_TRY(e, e->logits.reserve(rows * (size_t)e->out_width));
+    return GNNVC_OK;
+}
+
 int ensure_events(gnnvc_engine *e, size_t count) {
     while (e->ev.size() < count) {
         hipEvent_t v;
@@ -1756,8 +1775,36 @@ int gnnvc_create(gnnvc_engine **out, const char *model_text, size_t len, int dev
     return GNNVC_OK;
 }
 
+int gnnvc_create_multi(gnnvc_engine **out, const char *model_text, size_t len, const int *devices, int n_devices) {
+    if (!out || !model_text || !devices || n_devices < 1) return GNNVC_ERR_INVALID;
+    *out = nullptr;
+    gnnvc_engine *e = nullptr;
+    int rc = gnnvc_create(&e, model_text, len, devices[0]);
+    if (rc != GNNVC_OK) return rc;
+    std::string err;
+    try {
+        rc = gnnvc::multi_create(&e->multi, model_text, len, devices, n_devices, err);
+    } catch (const std::bad_alloc &) {
+        rc = GNNVC_ERR_NOMEM;
+    } catch (...) {
+        rc = GNNVC_ERR_INVALID;
+    }
+    if (rc != GNNVC_OK) {
+        if (!err.empty()) fprintf(stderr, "gnnvc_create_multi: %s\n", err.c_str());
+        gnnvc_destroy(e);
+        return rc;
+    }
+    (void)hipSetDevice(devices[0]);
+    *out = e;
+    return GNNVC_OK;
+}
+
 void gnnvc_destroy(gnnvc_engine *e) {
     if (!e) return;
+    if (e->multi) {
+        gnnvc::multi_destroy(e->multi);
+        e->multi = nullptr;
+    }
     if (e->own_stream) {
         (void)hipSetDevice(e->device);
         (void)hipStreamSynchronize(e->own_stream);
@@ -1802,6 +1849,7 @@ void gnnvc_destroy(gnnvc_engine *e) {
 int gnnvc_set_weight_scale(gnnvc_engine *e, float ws) {
     if (!e) return GNNVC_ERR_INVALID;
     e->ws = ws;
+    if (e->multi) return gnnvc::multi_set_weight_scale(e->multi, ws);
     return GNNVC_OK;
 }
 
@@ -1853,13 +1901,23 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "mfma_dense") e->opt_mfma = (value >= 0 && value <= 2) ? (int)value : 2;
     else if (k == "sorted_tiles") { e->opt_sorted = value < 0 ? -1 : (value ? 1 : 0); for (auto &r : e->srt) r.valid = false; }
     else return fail(e, GNNVC_ERR_INVALID, "unknown option '%s'", key);
+    if (e->multi) return gnnvc::multi_set_option(e->multi, key, value);
     return GNNVC_OK;
 }
 
 int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
     if (!e || !key || !value) return GNNVC_ERR_INVALID;
     const std::string k(key);
-    if (k == "compact_gather_active") *value = e->c4_ready ? 1 : 0;
+    if (k == "devices") *value = e->multi ? gnnvc::multi_devices(e->multi) : 1;
+    else if (e->multi && (k.rfind("part_rows_", 0) == 0 || k.rfind("part_entries_", 0) == 0)) {   // "part_rows_<r>", "part_entries_<r>"
+        const int r = atoi(k.c_str() + k.rfind('_') + 1);
+        uint32_t lo = 0, hi = 0;
+        uint64_t en = 0;
+        if (gnnvc::multi_part_info(e->multi, r, &lo, &hi, &en) != GNNVC_OK) return GNNVC_ERR_INVALID;
+        *value = k[5] == 'r' ? (long)(hi - lo) : (long)en;
+    }
+    else if (k == "multi_last_forward_us") *value = e->multi ? (long)(gnnvc::multi_last_forward_ms(e->multi) * 1000.0) : 0;
+    else if (k == "compact_gather_active") *value = e->c4_ready ? 1 : 0;
     else if (k == "compact_gather_chunks") *value = e->c4_ready ? (long)e->c4_chunks : 0;
     else if (k == "compact_gather_block_cols") *value = e->c4_ready ? (long)e->c4_block : 0;
     else if (k == "compact_gather_rows_per_chunk") *value = e->c4_ready ? (long)e->c4_rows : 0;
@@ -1987,6 +2045,15 @@ int gnnvc_upload_graph(gnnvc_engine *e, uint32_t n, const uint64_t *rowptr, cons
     if (n && (!rowptr || !w || !nw)) return fail(e, GNNVC_ERR_INVALID, "null graph arrays");
     int rc = use_device(e);
     if (rc) return rc;
+    if (e->multi) {
+        if (n && rowptr[n] && !col) return fail(e, GNNVC_ERR_INVALID, "null column array");
+        std::string err;
+        rc = gnnvc::multi_upload(e->multi, n, rowptr, nullptr, col, w, nw, err);
+        (void)hipSetDevice(e->device);
+        if (rc) return fail(e, rc, "%s", err.c_str());
+        e->have_graph = false;   // (the front itself holds no graph: the parts do)
+        return reserve_multi_front(e, n);
+    }
     const uint64_t nnz = n ? rowptr[n] : 0;
     if (nnz >= 0xFFFFFFFFull - GNNVC_COL_PAD)
         return fail(e, GNNVC_ERR_UNSUPPORTED, "nnz %llu does not fit 32-bit row pointers", (unsigned long long)nnz);
@@ -2051,6 +2118,10 @@ int gnnvc_staged_columns_ready(gnnvc_engine *e, uint64_t first, uint64_t count) 
         return fail(e, GNNVC_ERR_INVALID, "column pieces must be announced in order (expected offset %llu)",
                     (unsigned long long)e->staged_sent);
     if (!count) return GNNVC_OK;
+    if (e->multi) {   // (the slices are cut when the whole graph is known: nothing leaves before the commit)
+        e->staged_sent = first + count;
+        return GNNVC_OK;
+    }
     int rc = use_device(e);
     if (rc) return rc;
     if (!e->staged_sent) {   // first piece: the device array is about to be overwritten
@@ -2074,6 +2145,14 @@ int gnnvc_commit_staged_graph(gnnvc_engine *e) {
     e->staging = false;
     e->have_graph = false;
     if (n && e->pin_rowptr.p[n] != nnz) return fail(e, GNNVC_ERR_INVALID, "staged rowptr[n] differs from the staged nnz");
+    if (e->multi) {
+        e->staged_sent = 0;
+        std::string err;
+        rc = gnnvc::multi_upload(e->multi, n, nullptr, e->pin_rowptr.p, e->pin_col.p, e->pin_w.p, e->pin_nw.p, err);
+        (void)hipSetDevice(e->device);
+        if (rc) return fail(e, rc, "%s", err.c_str());
+        return reserve_multi_front(e, n);
+    }
     HIP_TRY(e, e->rowptr.reserve((size_t)n + 1));
     HIP_TRY(e, e->col.reserve(nnz + GNNVC_COL_PAD));
     HIP_TRY(e, e->w.reserve(n));
@@ -2136,6 +2215,7 @@ static int attach_common(gnnvc_engine *e, const GraphDev &cand) {
  * device cannot derive, ships exactly those, and the engine assembles the next CSR in place of an upload of all of it. */
 int gnnvc_derive_graph_begin(gnnvc_engine *e, uint32_t n_new, const uint32_t *old_row, const uint32_t *rowptr_new, uint32_t *tail) {
     if (!e) return GNNVC_ERR_INVALID;
+    NOT_ON_MULTI(e, "gnnvc_derive_graph_begin");
     e->der_open = false;
     if (!e->have_graph || e->g.rowptr != e->rowptr.p || e->g.col != e->col.p || e->g.sliced() || e->empty_slice)
         return fail(e, GNNVC_ERR_STATE, "no engine-owned whole graph is resident (hand one over with gnnvc_upload_graph or the staged calls first)");
@@ -2177,6 +2257,7 @@ int gnnvc_derive_graph_begin(gnnvc_engine *e, uint32_t n_new, const uint32_t *ol
 
 int gnnvc_derive_graph_commit(gnnvc_engine *e, const uint32_t *tail_cols, uint64_t n_tail, const uint32_t *w, const uint32_t *nw) {
     if (!e) return GNNVC_ERR_INVALID;
+    NOT_ON_MULTI(e, "gnnvc_derive_graph_commit");
     if (!e->der_open) return fail(e, GNNVC_ERR_STATE, "gnnvc_derive_graph_begin first");
     e->der_open = false;
     if (!e->have_graph || e->g.rowptr != e->rowptr.p || e->g.col != e->col.p || e->g.sliced() || e->empty_slice)
@@ -2212,6 +2293,7 @@ int gnnvc_derive_graph_commit(gnnvc_engine *e, const uint32_t *tail_cols, uint64
 
 int gnnvc_graph_row_hashes(gnnvc_engine *e, uint64_t *hashes) {
     if (!e) return GNNVC_ERR_INVALID;
+    NOT_ON_MULTI(e, "gnnvc_graph_row_hashes");
     if (!e->have_graph || e->empty_slice) return fail(e, GNNVC_ERR_STATE, "no graph attached");
     const uint32_t rows = e->g.hi() - e->g.lo();
     if (!rows) return GNNVC_OK;
@@ -2228,6 +2310,7 @@ int gnnvc_graph_row_hashes(gnnvc_engine *e, uint64_t *hashes) {
 int gnnvc_attach_graph_device(gnnvc_engine *e, uint32_t n, uint64_t nnz, const uint32_t *d_rowptr,
                               const uint32_t *d_col, const uint32_t *d_w, const uint32_t *d_nw) {
     if (!e) return GNNVC_ERR_INVALID;
+    NOT_ON_MULTI(e, "gnnvc_attach_graph_device");
     if (n && (!d_rowptr || !d_col || !d_w || !d_nw)) return fail(e, GNNVC_ERR_INVALID, "null device graph arrays");
     if (nnz >= 0xFFFFFFFFull - GNNVC_COL_PAD) return fail(e, GNNVC_ERR_UNSUPPORTED, "nnz too large");
     int rc = use_device(e);
@@ -2239,6 +2322,7 @@ int gnnvc_attach_graph_slice(gnnvc_engine *e, uint32_t n_global, uint32_t row_lo
                              const uint32_t *d_rowptr_local, const uint32_t *d_col_local, const uint32_t *d_w_local,
                              const uint32_t *d_nw_local) {
     if (!e) return GNNVC_ERR_INVALID;
+    NOT_ON_MULTI(e, "gnnvc_attach_graph_slice");
     if (row_lo > row_hi || row_hi > n_global) return fail(e, GNNVC_ERR_INVALID, "slice [%u, %u) outside a graph of %u vertices", row_lo, row_hi, n_global);
     if (!d_rowptr_local || !d_col_local || (row_hi > row_lo && (!d_w_local || !d_nw_local)))
         return fail(e, GNNVC_ERR_INVALID, "null device graph arrays");
@@ -2275,6 +2359,7 @@ int gnnvc_attach_graph_slice(gnnvc_engine *e, uint32_t n_global, uint32_t row_lo
 int gnnvc_stage_forward_device(gnnvc_engine *e, int stage, uint32_t row_lo, uint32_t row_hi,
                                const float *d_in, float *d_out, float *d_logits) {
     if (!e) return GNNVC_ERR_INVALID;
+    NOT_ON_MULTI(e, "gnnvc_stage_forward_device");
     if (!e->have_graph) return fail(e, GNNVC_ERR_STATE, "no graph attached");
     if (stage < 0 || stage >= (int)e->stages.size()) return fail(e, GNNVC_ERR_INVALID, "stage %d out of range", stage);
     if (row_lo > row_hi || row_hi > e->g.n) return fail(e, GNNVC_ERR_INVALID, "row range [%u,%u) outside graph of %u", row_lo, row_hi, e->g.n);
@@ -2290,6 +2375,19 @@ int gnnvc_stage_forward_device(gnnvc_engine *e, int stage, uint32_t row_lo, uint
 
 int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, float *d_logits) {
     if (!e) return GNNVC_ERR_INVALID;
+    if (e->multi) {   // pointers on the first device; complete (every device drained) when it returns
+        if (!gnnvc::multi_has_graph(e->multi)) return fail(e, GNNVC_ERR_STATE, "no graph attached");
+        if (gnnvc::multi_vertices(e->multi) == 0) return GNNVC_OK;
+        if (!d_x || !d_scores) return fail(e, GNNVC_ERR_INVALID, "null feature buffers");
+        int rc = use_device(e);
+        if (rc) return rc;
+        HIP_TRY(e, hipStreamSynchronize(e->stream));   // (whatever produced d_x on this handle's stream)
+        std::string err;
+        rc = gnnvc::multi_forward_device(e->multi, d_x, d_scores, d_logits, err);
+        (void)hipSetDevice(e->device);
+        if (rc) return fail(e, rc, "%s", err.c_str());
+        return GNNVC_OK;
+    }
     if (!e->have_graph) return fail(e, GNNVC_ERR_STATE, "no graph attached");
     const uint32_t n = e->g.n;
     e->ev_count = 0;
@@ -2376,6 +2474,7 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
 
 int gnnvc_stage_input_ready(gnnvc_engine *e, int stage, const float *d_in, uint32_t row_lo, uint32_t row_hi) {
     if (!e) return GNNVC_ERR_INVALID;
+    NOT_ON_MULTI(e, "gnnvc_stage_input_ready");
     if (!e->have_graph) return fail(e, GNNVC_ERR_STATE, "no graph attached");
     if (e->stages.empty()) return fail(e, GNNVC_ERR_UNSUPPORTED, "model is not fused into stages");
     if (stage < 1 || stage >= (int)e->stages.size()) return fail(e, GNNVC_ERR_INVALID, "stage %d has no 16-wide input", stage);
@@ -2408,6 +2507,23 @@ int gnnvc_stage_input_ready(gnnvc_engine *e, int stage, const float *d_in, uint3
 
 int gnnvc_forward(gnnvc_engine *e, const float *x, float *scores, float *logits) {
     if (!e) return GNNVC_ERR_INVALID;
+    if (e->multi) {
+        if (!gnnvc::multi_has_graph(e->multi)) return fail(e, GNNVC_ERR_STATE, "no graph attached");
+        const uint32_t n = gnnvc::multi_vertices(e->multi);
+        if (n == 0) return GNNVC_OK;
+        if (!x || !scores) return fail(e, GNNVC_ERR_INVALID, "null host buffers");
+        int rc = use_device(e);
+        if (rc) return rc;
+        const size_t bytes = (size_t)n * sizeof(float);
+        HIP_TRY(e, hipMemcpyAsync(e->x.p, x, bytes, hipMemcpyHostToDevice, e->stream));
+        const bool want_logits = logits && e->ends_in_sigmoid;
+        rc = gnnvc_forward_device(e, e->x.p, e->scores.p, want_logits ? e->logits.p : nullptr);
+        if (rc) return rc;
+        HIP_TRY(e, hipMemcpyAsync(scores, e->scores.p, bytes, hipMemcpyDeviceToHost, e->stream));
+        if (want_logits) HIP_TRY(e, hipMemcpyAsync(logits, e->logits.p, bytes, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        return GNNVC_OK;
+    }
     if (!e->have_graph) return fail(e, GNNVC_ERR_STATE, "no graph attached");
     const uint32_t n = e->g.n;
     if (e->layers.empty()) return fail(e, GNNVC_ERR_STATE, "engine was created without a model");
@@ -2434,6 +2550,7 @@ int gnnvc_forward(gnnvc_engine *e, const float *x, float *scores, float *logits)
 
 int gnnvc_reduction_flags(gnnvc_engine *e, uint32_t max_degree, uint8_t *flags) {
     if (!e) return GNNVC_ERR_INVALID;
+    NOT_ON_MULTI(e, "gnnvc_reduction_flags");
     if (!e->have_graph) return fail(e, GNNVC_ERR_STATE, "no graph attached");
     const uint32_t n = e->g.n;
     if (n == 0) return GNNVC_OK;
@@ -2540,8 +2657,10 @@ int gnnvc_unpack_gathered(gnnvc_engine *e, const float *d_buf, uint32_t world, u
 int gnnvc_score_keys(gnnvc_engine *e, const float *d_scores, uint32_t n, float *keys, uint8_t *above_half) {
     if (!e) return GNNVC_ERR_INVALID;
     if (!d_scores) {   // the scores the last gnnvc_forward left on the device
-        if (!e->have_graph || e->out_width != 1) return fail(e, GNNVC_ERR_STATE, "no single-column scores on the device");
-        if (n != e->g.n) return fail(e, GNNVC_ERR_INVALID, "n = %u, the current graph has %u vertices", n, e->g.n);
+        const bool have = e->multi ? gnnvc::multi_has_graph(e->multi) : e->have_graph;
+        const uint32_t cur = e->multi ? gnnvc::multi_vertices(e->multi) : e->g.n;
+        if (!have || e->out_width != 1) return fail(e, GNNVC_ERR_STATE, "no single-column scores on the device");
+        if (n != cur) return fail(e, GNNVC_ERR_INVALID, "n = %u, the current graph has %u vertices", n, cur);
         d_scores = e->scores.p;
     }
     if (!n) return GNNVC_OK;
@@ -2563,11 +2682,23 @@ int gnnvc_synchronize(gnnvc_engine *e) {
     int rc = use_device(e);
     if (rc) return rc;
     HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (e->multi) {
+        rc = gnnvc::multi_synchronize(e->multi);
+        (void)hipSetDevice(e->device);
+        if (rc) return fail(e, rc, "a device of the multi-device handle failed to synchronise");
+    }
     return GNNVC_OK;
 }
 
 int gnnvc_last_forward_ms(gnnvc_engine *e, float *total_ms, float *stage_ms, int max_stages) {
     if (!e) return GNNVC_ERR_INVALID;
+    if (e->multi) {   // (host wall time of the last forward over all devices; no per-stage split)
+        const double ms = gnnvc::multi_last_forward_ms(e->multi);
+        if (ms <= 0.0) return fail(e, GNNVC_ERR_STATE, "no timed forward yet");
+        if (total_ms) *total_ms = (float)ms;
+        for (int s = 0; stage_ms && s < max_stages; ++s) stage_ms[s] = 0.0f;
+        return GNNVC_OK;
+    }
     if (e->ev_count < 2) return fail(e, GNNVC_ERR_STATE, "no timed forward yet");
     int rc = use_device(e);
     if (rc) return rc;
@@ -2622,6 +2753,7 @@ static int run_host_op(gnnvc_engine *e, size_t in_count, const float *in, size_t
 
 int gnnvc_graph_layer_forward(gnnvc_engine *e, uint32_t f, const float *in, float *out) {
     if (!e) return GNNVC_ERR_INVALID;
+    NOT_ON_MULTI(e, "gnnvc_graph_layer_forward");
     if (!e->have_graph) return fail(e, GNNVC_ERR_STATE, "no graph attached");
     if (f == 0) return fail(e, GNNVC_ERR_INVALID, "zero feature width");
     const uint32_t n = e->g.n;

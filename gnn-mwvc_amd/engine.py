@@ -19,7 +19,7 @@ _LIB = pathlib.Path(os.environ["GNNVC_LIBRARY"]).resolve() if os.environ.get("GN
 
 # every symbol include/gnnvc.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
-    "gnnvc_abi_version", "gnnvc_strerror", "gnnvc_last_error", "gnnvc_create", "gnnvc_destroy",
+    "gnnvc_abi_version", "gnnvc_strerror", "gnnvc_last_error", "gnnvc_create", "gnnvc_create_multi", "gnnvc_destroy",
     "gnnvc_set_weight_scale", "gnnvc_set_stream", "gnnvc_set_option", "gnnvc_get_info", "gnnvc_num_layers", "gnnvc_is_fused",
     "gnnvc_in_width", "gnnvc_out_width", "gnnvc_upload_graph", "gnnvc_attach_graph_device", "gnnvc_attach_graph_slice",
     "gnnvc_graph_staging", "gnnvc_staged_columns_ready", "gnnvc_commit_staged_graph",
@@ -82,6 +82,7 @@ def load_library():
     L.gnnvc_last_error.restype = C.c_char_p
     L.gnnvc_last_error.argtypes = [vp]
     L.gnnvc_create.argtypes = [C.POINTER(vp), C.c_char_p, C.c_size_t, C.c_int]
+    L.gnnvc_create_multi.argtypes = [C.POINTER(vp), C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.c_int]
     L.gnnvc_destroy.argtypes = [vp]
     L.gnnvc_destroy.restype = None
     L.gnnvc_set_weight_scale.argtypes = [vp, C.c_float]
@@ -139,11 +140,16 @@ def _np_ptr(a: np.ndarray):
 class Engine:
     """One engine = one model on one GPU (mirrors `gnn::model`)."""
 
-    def __init__(self, model_text: str | None = None, device: int = 0):
+    def __init__(self, model_text: str | None = None, device: int = 0, devices=None):
+        """devices = [ordinals]: several devices behind this one handle (gnnvc_create_multi); an ordinal may repeat."""
         self._L = load_library()
         self._h = C.c_void_p()
         raw = (model_text if model_text is not None else default_model_text()).encode()
-        rc = self._L.gnnvc_create(C.byref(self._h), raw, len(raw), device)
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*devices)
+            rc = self._L.gnnvc_create_multi(C.byref(self._h), raw, len(raw), arr, len(devices))
+        else:
+            rc = self._L.gnnvc_create(C.byref(self._h), raw, len(raw), device)
         if rc != 0:
             self._h = C.c_void_p()
             raise GnnvcError(rc, self._L.gnnvc_strerror(rc).decode())

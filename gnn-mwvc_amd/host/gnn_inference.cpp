@@ -42,6 +42,24 @@ int device_ordinal() {
     return s ? std::atoi(s) : 0;
 }
 
+std::vector<int> device_list() {
+    std::vector<int> out;
+    const char *s = std::getenv("GNNVC_DEVICES");
+    if (!s || !*s) return out;
+    if (std::strchr(s, ',')) {
+        for (const char *p = s; *p;) {
+            out.push_back(std::atoi(p));
+            const char *c = std::strchr(p, ',');
+            if (!c) break;
+            p = c + 1;
+        }
+    } else {
+        const int n = std::atoi(s);
+        for (int i = 0; i < n; ++i) out.push_back(i);
+    }
+    return out;
+}
+
 void check(int rc, const char *what, const gnnvc_engine *e) {
     if (rc == GNNVC_OK) return;
     std::fprintf(stderr, "gnnvc: %s failed: %s%s%s\n", what, gnnvc_strerror(rc),
@@ -385,7 +403,13 @@ gnnvc_engine *engine_for(const void *key, const std::string &name, const std::ve
     if (b.eng && b.text == text) return b.eng;
     if (b.eng) gnnvc_destroy(b.eng);
     b.eng = nullptr;
-    check(gnnvc_create(&b.eng, text.data(), text.size(), gnnvc_host::device_ordinal()), "gnnvc_create(model)");
+    // GNNVC_DEVICES ("GNNVC_DEVICES=n", CLI unchanged): "4" = devices 0 .. 3 behind this one model, "0,0,1" = that
+    // very list of ordinals (an ordinal may repeat: a one-GPU machine rehearsing the partitioned path).  Unset: one device.
+    const std::vector<int> devs = gnnvc_host::device_list();
+    if (devs.empty())
+        check(gnnvc_create(&b.eng, text.data(), text.size(), gnnvc_host::device_ordinal()), "gnnvc_create(model)");
+    else
+        check(gnnvc_create_multi(&b.eng, text.data(), text.size(), devs.data(), (int)devs.size()), "gnnvc_create_multi(model)");
     b.text = std::move(text);
     return b.eng;
 }

@@ -3,6 +3,8 @@
 // policy (the reference signals no errors, src/GNN_VC.cpp prints and returns; a
 // missing GPU library must not silently produce numbers, so we abort).
 #pragma once
+#include <vector>
+
 #include "gnnvc.h"
 
 namespace gnnvc_host {
@@ -15,5 +17,8 @@ gnnvc_engine *ops_engine();
 void check(int rc, const char *what, const gnnvc_engine *e = nullptr);
 
 int device_ordinal();
+
+// GNNVC_DEVICES: "4" = ordinals 0 .. 3, "0,0,1" = that list; empty when unset (one device: device_ordinal()).
+std::vector<int> device_list();
 
 }  // namespace gnnvc_host

@@ -59,6 +59,27 @@ const char *gnnvc_last_error(const gnnvc_engine *e);
 int gnnvc_create(gnnvc_engine **out, const char *model_text, size_t len, int device);
 void gnnvc_destroy(gnnvc_engine *e);
 
+/* Several devices behind ONE handle (SURVEY.md §8b's `n_devices`; §5: "one process driving 8 devices").  The reference has one
+ * call site, m.predict(x, out, g) on one thread (src/GNN_VC.cpp:192, include/gnn_inference.hpp:50): a drop-in that wants more
+ * than one GPU has to partition behind that call, and this handle does.  devices[0 .. n_devices) are HIP ordinals (an ordinal
+ * may repeat: several parts then share a device — how a one-GPU machine rehearses the path).  On such a handle
+ *   gnnvc_upload_graph / the staged hand-off   cut the graph into n_devices contiguous row ranges of equal entry count (multiples
+ *                         of 64 rows) and give device r the CSR slice of its rows (global column ids) — 1 / n_devices of the
+ *                         graph's memory each — next to full-size replicated feature buffers;
+ *   gnnvc_forward / gnnvc_forward_device        run every stage range by range and, after the first and second stage, let each
+ *                         device copy the rows it computed straight into every peer's buffer (hipMemcpyPeerAsync: a direct
+ *                         all-gather, one xGMI link per peer, no ring, no host hop); the scores (and logits) are assembled on
+ *                         devices[0].  gnnvc_forward_device takes pointers on devices[0] and is complete when it returns;
+ *   gnnvc_set_weight_scale / gnnvc_set_option / gnnvc_synchronize / gnnvc_score_keys / gnnvc_last_forward_ms (total only)
+ *                         and the layer-level entry points without a graph (linear, relu, sigmoid, sgemm, stream_sum) work
+ *                         as on any handle; gnnvc_get_info adds "devices", "part_rows_<r>", "part_entries_<r>";
+ *   the entry points that read ONE device's resident graph (attach_graph_device / _slice, stage_forward_device,
+ *                         stage_input_ready, derive_graph_*, graph_row_hashes, reduction_flags, graph_layer_forward) return
+ *                         GNNVC_ERR_UNSUPPORTED.
+ * Results are those of a single device, bit for bit: a row is summed on one device in stored order.  n_devices = 1 is a
+ * single engine behind the same code path. */
+int gnnvc_create_multi(gnnvc_engine **out, const char *model_text, size_t len, const int *devices, int n_devices);
+
 /* model::set_weight_scale (reference src/gnn_inference.cpp:83-90): sets
  * graph_layer::WEIGHT_SCALE of every graph layer (default 120). */
 int gnnvc_set_weight_scale(gnnvc_engine *e, float ws);

@@ -53,6 +53,12 @@ int gnnvc_create(gnnvc_engine **out, const char *text, size_t len, int device) {
     return GNNVC_OK;
 }
 
+/* (the double has no devices: a multi-device handle is the same engine) */
+int gnnvc_create_multi(gnnvc_engine **out, const char *text, size_t len, const int *devices, int n_devices) {
+    if (!devices || n_devices < 1) return GNNVC_ERR_INVALID;
+    return gnnvc_create(out, text, len, devices[0]);
+}
+
 static void drop_graph(gnnvc_engine *e) {
     free(e->rowptr); free(e->col); free(e->w); free(e->nw);
     e->rowptr = NULL; e->col = e->w = e->nw = NULL;

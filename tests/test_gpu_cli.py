@@ -148,3 +148,23 @@ def test_cli_with_graphs_derived_on_the_device(manifest, tmp_path, mode):
     assert fields[0] == "er100k" and int(fields[1]) == spec["cli"]["final_cost"]
     assert hashlib.md5((tmp_path / "er100k.out").read_bytes()).hexdigest() == spec["cli"]["result_md5"]
     assert r.stderr.count("derived on the device") >= 3, r.stderr[-3000:]     # the path was really taken
+
+
+@pytest.mark.parametrize("devices", ["0,0,0", "1"])
+def test_cli_on_a_multi_device_handle(manifest, tmp_path, devices):
+    """GNNVC_DEVICES (SURVEY.md §5, §8b `n_devices`): the reference's driver, unchanged, with gnn::model bound to
+    gnnvc_create_multi — every predict call's graph is cut into row ranges, each range's CSR slice lives in its own
+    engine, rows are exchanged device to device between the stages.  Here all "devices" are GPU 0 (the box has one);
+    the cover is the golden one, byte for byte, through every predict call of the run (down to the empty graph)."""
+    import os
+    spec = manifest["er100k"]
+    g = _graph(spec)
+    (tmp_path / "er100k.graph").write_text(gg.metis_text(g))
+    env = dict(os.environ, GNNVC_DEVICES=devices, GNNVC_TRACE="1")
+    r = subprocess.run([str(CLI), str(tmp_path / "er100k.graph"), str(tmp_path / "er100k.out"), "0", "-1", "0"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    fields = r.stdout.strip().split(",")
+    assert fields[0] == "er100k" and int(fields[1]) == spec["cli"]["final_cost"]
+    assert hashlib.md5((tmp_path / "er100k.out").read_bytes()).hexdigest() == spec["cli"]["result_md5"]
+    assert r.stderr.count("gnnvc predict") >= 5, r.stderr[-2000:]

@@ -1593,6 +1593,75 @@ def test_sliced_engines_equal_the_whole_graph(model_text, oracle_model, maker, w
             e.close()
 
 
+# ---------------------------------------------------------------- several devices behind one handle (gnnvc_create_multi)
+
+@pytest.mark.parametrize("maker,devices", [
+    (lambda: gg.erdos_renyi(5000, 40000, 31), [0, 0]),
+    (lambda: gg.hub_graph(20000, 60000, 3, 4096, seed=7), [0, 0, 0]),          # long rows inside parts
+    (lambda: gg.rmat(13, 16, 5), [0, 0, 0, 0]),                                 # skewed: nnz-balanced cuts, sorted tiles per part
+    (lambda: gg.erdos_renyi(100, 300, 5), [0] * 8),                             # more parts than 64-row tiles: empty parts
+    (lambda: gg.erdos_renyi(3000, 20000, 9), [0]),                              # one device behind the same code path
+])
+def test_multi_device_handle_equals_single_engine(model_text, oracle_model, maker, devices):
+    """gnnvc_create_multi through the C ABI: upload / staged hand-off partition internally, forward exchanges rows device
+    to device (all parts on GPU 0 here), host and device-pointer forwards, repeated forwards, graph replacement, N = 0.
+    Logits bit-identical to the oracle — what a single engine gives."""
+    import gnn_mwvc_amd as G
+    import torch
+    g = maker()
+    e = G.Engine(model_text, devices=devices)
+    try:
+        assert e.get_info("devices") == len(devices)
+        for route in ("upload", "staged"):
+            e.set_weight_scale(g.ws)
+            oracle_model.set_weight_scale(g.ws)
+            (e.upload_graph if route == "upload" else e.upload_graph_staged)(g)
+            rows = [e.get_info(f"part_rows_{r}") for r in range(len(devices))]
+            entries = [e.get_info(f"part_entries_{r}") for r in range(len(devices))]
+            assert sum(rows) == g.n and sum(entries) == g.nnz
+            if len(devices) > 1 and g.nnz > 64 * 64 * len(devices):            # the cuts balance the entries
+                assert max(entries) < 2.0 * g.nnz / len(devices) + 64 * (g.nnz // g.n + 4096)
+            want = oracle_model.logits(g)
+            for rep in range(3):
+                scores, logits = e.forward(g.x())
+                assert np.array_equal(bits(logits[:, 0]), bits(want)), (route, rep)
+                assert ulp(scores[:, 0], oracle_model.scores(g)).max() <= 1
+            keys, above = e.score_keys()
+            ok, oa = oracle_py.score_keys(scores[:, 0])
+            assert np.array_equal(bits(keys), bits(ok)) and np.array_equal(above, oa)
+        # device-pointer forward (pointers on the first device)
+        dev = torch.device("cuda:0")
+        x = torch.from_numpy(g.x()).to(dev)
+        sc = torch.zeros(g.n, device=dev)
+        lg = torch.zeros(g.n, device=dev)
+        torch.cuda.synchronize()
+        e.forward_device(x.data_ptr(), sc.data_ptr(), lg.data_ptr())
+        assert np.array_equal(bits(lg.cpu().numpy()), bits(want))
+        # another graph, then the empty one (the reference's last predict call)
+        g2 = gg.erdos_renyi(777, 4000, 3)
+        e.set_weight_scale(g2.ws)
+        oracle_model.set_weight_scale(g2.ws)
+        e.upload_graph(g2)
+        _, logits = e.forward(g2.x())
+        assert np.array_equal(bits(logits[:, 0]), bits(oracle_model.logits(g2)))
+        e.upload_graph(gg.from_edge_list(0, [], []))
+        s0, _ = e.forward(np.zeros(0, dtype=np.float32))
+        assert s0.shape == (0, 1)
+        # what reads ONE device's resident graph is refused, loudly
+        with pytest.raises(G.GnnvcError) as err:
+            e.reduction_flags()
+        assert err.value.code == -5
+        with pytest.raises(G.GnnvcError):
+            e.stage_forward_device(0, 0, 1, x.data_ptr(), sc.data_ptr())
+        # malformed graphs are refused by the parts' device-side checks
+        bad = gg.erdos_renyi(500, 2000, 2)
+        bad.col[7] = 500
+        with pytest.raises(G.GnnvcError):
+            e.upload_graph(bad)
+    finally:
+        e.close()
+
+
 def test_stage_input_announcement_does_not_outlive_its_input(model_text, oracle_model):
     """gnnvc_stage_input_ready is matched on (stage, buffer address, row range); the contents of that buffer change
     from one forward to the next.  A caller that announces in one forward and not in the next (same buffers) must
