@@ -305,10 +305,16 @@ def main() -> int:
     stage_evt = [[torch.cuda.Event(enable_timing=True) for _ in range(6)]
                  for _ in range(args.steps)]
 
-    # pieces per stage: with the compact-table plan over a rank's rows a piece should be a whole number of
-    # 256-chunk rounds (3 at 2 ranks, 2 at 3-4 ranks on the metric graph); otherwise 4
-    use_prepare = bool(args.prepare_input) and 2 <= world <= 3   # (from 4 ranks on a rank's pieces are too small to gain)
-    chunks = args.pipeline_chunks if args.pipeline_chunks >= 0 else ((3 if world == 2 else 2) if use_prepare else 4)
+    # Per-rank plans (round 3: both plans can be laid out over the rows a rank holds).  Measured on one GPU with rank 0's slice
+    # of the metric graph, each stage over the whole slice (scratch/experiments/rank_compute.py; ms per stage, plans vs plain
+    # kernels): P = 2: 0.50 / 1.28 / 1.16 vs 1.75 / 2.0 / 2.0;  P = 4: 0.41 / 0.84 / 0.77 vs 0.88 / 1.01 / 0.99;
+    # P = 8: 0.36 / 0.67 / 0.64 vs 0.44 / 0.53 / 0.51 — the compact table's fixed passes over ALL N rows (count, compact: ~0.3 ms)
+    # stop paying once a rank has an eighth of the rows.  So: up to 4 ranks announce each 16-wide stage's input (compact table
+    # over the rank's rows) and cut a stage into pieces of whole 256-chunk rounds (3 at 2 ranks, 2 at 3) or, at 4 ranks, run it
+    # as ONE piece (so that stage 0 takes the LDS-table plan over the slice too); beyond 4 ranks: 4 pipelined pieces of the plain
+    # kernels, whose all-gathers overlap the next piece's gathers.
+    use_prepare = bool(args.prepare_input) and 2 <= world <= 4
+    chunks = args.pipeline_chunks if args.pipeline_chunks >= 0 else ((3 if world == 2 else 2 if world == 3 else 1) if use_prepare else 4)
     prepare_fn = (lambda st, src, r0, r1: eng.stage_input_ready(st, src.data_ptr(), r0, r1)) if use_prepare else None
     piece_rows = [0]   # set after the first forward: pieces of 256 of the engine's chunks, so that no piece ends inside one
     fwd_scores = torch.zeros(n, dtype=torch.float32, device=dev)

@@ -139,6 +139,8 @@ struct gnnvc_engine {
     uint32_t opt_lds_skewed_min_n = 1u << 21;
     int opt_lds_skewed = 1;              // option "lds_table_skewed": 0 = skewed graphs keep the gathering F = 1 kernels
     uint32_t lt_rows = 0, lt_chunks = 0, lt_blocks = 0, lt_steps_total = 0, lt_last_entry = 0;
+    uint32_t lt_base = 0, lt_end = 0;       // the plan's row range: the rows this engine holds when it was built
+    uint32_t opt_lt_min_chunks = 128;       // option "lds_table_min_chunks": a short row range is cut into at least this many chunks
     DevBuf<uint8_t> lt_bytes;
     DevBuf<uint32_t> lt_entries, lt_segcnt, lt_stepptr, lt_stepcnt, lt_bad;
     DevBuf<uint4> lt_steps;
@@ -852,11 +854,15 @@ int build_lds_table_impl(gnnvc_engine *e) {
     e->lt_mapped = false;
     const GraphDev &g = e->g;
     if (!e->opt_lds_table || e->stages.empty() || e->stages[0].f != 1 || e->stages[0].variant != 0) return GNNVC_OK;
-    if (g.sliced()) return GNNVC_OK;
+    // The plan covers the rows this engine holds: the whole graph, or (round 3) the SLICE of one rank of a partitioned run —
+    // the byte table is made from each forward's x (replicated on every rank), not from the vertex weights, so a slice has
+    // everything the plan needs; the columns are always the whole graph's.
+    const uint32_t base = g.lo(), end = g.hi(), held = end - base;
+    if (e->empty_slice || held == 0) return GNNVC_OK;
     if (g.n < e->opt_blocked_min_n || g.nnz == 0 || g.nnz >= (1ull << 31)) return GNNVC_OK;
     // (every chunk streams the whole byte table whatever the rows hold: below ~10 entries per row the gathering kernel is as fast —
     // 0.56 vs 0.50 ms per forward on an Erdős–Rényi graph of 1.1 M vertices and 8 entries per row)
-    if (e->opt_blocked_min_n >= (1u << 20) && g.nnz < (uint64_t)g.n * 10) return GNNVC_OK;
+    if (e->opt_blocked_min_n >= (1u << 20) && g.nnz < (uint64_t)held * 10) return GNNVC_OK;
     // Skewed graphs (sorted tiles wanted, or long rows present): the plan covers the rows below the giant-row threshold, dealt
     // from the degree-sorted list to slices of equal weight, over column blocks of equal entry mass (layout_skewed_plan); the
     // giant rows keep their kernels.  "lds_table" 2 forces the consecutive-row layout onto such a graph instead (tests).
@@ -864,7 +870,7 @@ int build_lds_table_impl(gnnvc_engine *e) {
     // (on a skewed graph most gathers of x go to hubs, which the L2s hold: the plan pays from 2 M vertices on — R-MAT-22 stage 0
     // 1.07 -> 0.86 ms, R-MAT-20 0.27 -> 0.34 ms; a lowered "blocked_min_n" — tests — lowers this bound too)
     const uint32_t skewed_min_n = e->opt_blocked_min_n < (1u << 20) ? e->opt_blocked_min_n : e->opt_lds_skewed_min_n;
-    const bool mapped = skewed && e->opt_lds_table < 2 && e->opt_lds_skewed && g.n >= skewed_min_n;
+    const bool mapped = skewed && e->opt_lds_table < 2 && e->opt_lds_skewed && g.n >= skewed_min_n && !g.sliced();   // (the skewed layout deals whole graphs)
     if (skewed && !mapped && e->opt_lds_table < 2) return GNNVC_OK;   // long runs would serialise in one thread
     const uint32_t bc = gnnvc::lds_table_block();
     uint32_t max_rows = gnnvc::lds_table_max_rows();
@@ -897,12 +903,15 @@ int build_lds_table_impl(gnnvc_engine *e) {
         pm = L.pm;
     } else {
         if (nblocks > 4096) return GNNVC_OK;
-        // chunks: a multiple of the 256 CUs, each within the LDS budget; a chunk = 16 slices of rows (one per wave)
-        chunks = (g.n + max_rows - 1) / max_rows;
-        chunks = (chunks + 255u) / 256u * 256u;
-        rows = (g.n + chunks - 1) / chunks;
+        // chunks: a multiple of the 256 CUs, each within the LDS budget; a chunk = 16 slices of rows (one per wave).  Every chunk
+        // streams the whole byte table once, so a range of FEW rows (a rank's slice at 8 ranks: 64 full chunks) is not cut finer
+        // than the CUs need to be busy at half a chunk's rows each — opt_lt_min_chunks — instead of a full multiple of 256.
+        chunks = (held + max_rows - 1) / max_rows;
+        if (chunks >= 256u) chunks = (chunks + 255u) / 256u * 256u;
+        else chunks = std::max(chunks, std::min(e->opt_lt_min_chunks, (held + 255u) / 256u));
+        rows = (held + chunks - 1) / chunks;
         rows = (rows + 15u) / 16u * 16u;
-        chunks = (g.n + rows - 1) / rows;
+        chunks = (held + rows - 1) / rows;
         slice_rows = rows / 16u;
         slices = chunks * 16u;
     }
@@ -918,10 +927,12 @@ int build_lds_table_impl(gnnvc_engine *e) {
     uint32_t *flag = e->lt_bad.p + 1;   // word 0 is the per-forward flag
     HIP_TRY(e, hipMemsetAsync(flag, 0, sizeof(uint32_t), e->stream));
     HIP_TRY(e, hipMemsetAsync(e->lt_bytes.p + g.n, 0, 64, e->stream));
-    HIP_TRY(e, gnnvc::lds_table_bytes(g.w, g.n, e->lt_bytes.p, flag, e->stream));
-    HIP_TRY(e, gnnvc::lds_table_count(g, slice_rows, slices, nblocks, bc, e->lt_segcnt.p, flag, e->stream, 0, 0xFFFFFFFFu, pm));
+    // (the table itself is rewritten from x by every forward; this pass only says whether the weights of the rows held here fit a
+    // byte at all — if not, x = W / ws never will, and the plan is not worth building)
+    HIP_TRY(e, gnnvc::lds_table_bytes(g.w + base, held, e->lt_bytes.p + base, flag, e->stream));
+    HIP_TRY(e, gnnvc::lds_table_count(g, slice_rows, slices, nblocks, bc, e->lt_segcnt.p, flag, e->stream, base, end, pm));
     HIP_TRY(e, gnnvc::lds_table_wsteps(g, slice_rows, chunks, nblocks, e->lt_segcnt.p, nullptr, e->lt_stepcnt.p, nullptr, false, slack,
-                                       e->stream, pm));
+                                       e->stream, pm, base, end));
     HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, e->lt_stepcnt.p, chunks * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipMemcpyAsync(e->pin_small.p + chunks, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -945,9 +956,9 @@ int build_lds_table_impl(gnnvc_engine *e) {
     HIP_TRY(e, hipMemsetAsync(e->lt_steps.p, 0, rec_quads * sizeof(uint4), e->stream));
     HIP_TRY(e, hipMemsetAsync(e->lt_entries.p, 0, entry_cap * sizeof(uint32_t), e->stream));   // (pad slots are read, never used)
     HIP_TRY(e, gnnvc::lds_table_wsteps(g, slice_rows, chunks, nblocks, e->lt_segcnt.p, e->lt_stepptr.p, nullptr,
-                                       reinterpret_cast<uint32_t *>(e->lt_steps.p), true, slack, e->stream, pm));
-    HIP_TRY(e, gnnvc::lds_table_scatter(g, slice_rows, slices, nblocks, bc, e->lt_segcnt.p, e->lt_entries.p, e->stream, 17, 0,
-                                        0xFFFFFFFFu, slack, pm, flag));
+                                       reinterpret_cast<uint32_t *>(e->lt_steps.p), true, slack, e->stream, pm, base, end));
+    HIP_TRY(e, gnnvc::lds_table_scatter(g, slice_rows, slices, nblocks, bc, e->lt_segcnt.p, e->lt_entries.p, e->stream, 17, base,
+                                        end, slack, pm, flag));
     HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));   // pin_small is reused by others
     if (e->pin_small.p[0]) {                       // an unsorted row (the flat walk finds it while regrouping): no plan
@@ -959,6 +970,8 @@ int build_lds_table_impl(gnnvc_engine *e) {
     e->c4_map_vertex.release();
     e->lt_last_entry = (uint32_t)((entry_cap - 4) & ~3ull);
     e->lt_rows = rows;
+    e->lt_base = base;
+    e->lt_end = end;
     e->lt_chunks = chunks;
     e->lt_blocks = nblocks;
     e->lt_steps_total = (uint32_t)total;
@@ -1371,8 +1384,13 @@ int choose_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const flo
             if (rc) return rc;
         }
         // (a skewed graph's plan sums all of its rows at once: whole-graph calls only)
+        // (consecutive-row layout: any call that covers at least three quarters of the chunks a full GPU takes — or of the plan's
+        // own, where the plan is a rank's slice of fewer)
+        const uint32_t lt_need = std::min(192u, e->lt_chunks - e->lt_chunks / 4u);
         const bool lt_fits = e->lt_ready && hi > lo &&
-                             (e->lt_mapped ? (lo == 0 && hi == e->g.n) : ((hi - 1) / e->lt_rows - lo / e->lt_rows + 1) >= 192u);
+                             (e->lt_mapped ? (lo == 0 && hi == e->g.n)
+                                           : (lo >= e->lt_base && hi <= e->lt_end &&
+                                              ((hi - 1 - e->lt_base) / e->lt_rows - (lo - e->lt_base) / e->lt_rows + 1) >= lt_need));
         if (e->graph_uses >= 1 && !lt_fits && !e->blocked_tried) {
             int rc = build_blocked(e);
             if (rc) return rc;
@@ -1514,7 +1532,7 @@ int launch_main(gnnvc_engine *e, const StageChoice &c, const GraphDev &gv, const
                                                         e->lt_steps.p, e->lt_entries.p, e->lt_bytes.p, e->blk_acc.p, e->lt_bad.p,
                                                         c.long_thresh, e->opt_mfma == 1, e->interleave, e->stream, emit,
                                                         e->lt_last_entry, e->lt_mapped ? e->lt_rowmap.p : nullptr,
-                                                        e->lt_mapped ? e->lt_chunks : 0u));
+                                                        e->lt_mapped ? e->lt_chunks : 0u, e->lt_base, e->lt_end));
     if (c.sums == StageChoice::kBlocked)
         return hip_rc(e, gnnvc::launch_stage0_blocked(sp, e->g, e->ws, e->params.p, in, out, lo, hi, e->blk_count, e->blk_ptr.p,
                                                       e->blk_col.p, e->blk_acc.p, e->long_thresh, e->opt_mfma == 1, e->interleave,
@@ -1612,6 +1630,10 @@ int reserve_features(gnnvc_engine *e, uint32_t n) {
     HIP_TRY(e, e->logits.reserve(rows * (size_t)e->out_width));
     if (!e->stages.empty()) {
         for (auto &b : e->h) HIP_TRY(e, b.reserve(rows * 16));
+        // the pad rows (index n) of the 16-wide feature buffers must read as zero; no kernel ever writes them, so once per
+        // graph will do (not two launches per forward: a small graph's forward is a handful of launches in all)
+        for (auto &b : e->h) HIP_TRY(e, gnnvc::launch_zero_pad_row(b.p, n, 16, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));   // (a later forward may run on another stream: gnnvc_set_stream)
     }
     return GNNVC_OK;
 }
@@ -1893,6 +1915,7 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "lds_table_skewed") e->opt_lds_skewed = value != 0 ? 1 : 0;
     else if (k == "lds_table_skewed_rows") e->opt_lds_skewed_rows = value > 0 ? (uint32_t)value : 0u;
     else if (k == "lds_table") e->opt_lds_table = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
+    else if (k == "lds_table_min_chunks") e->opt_lt_min_chunks = value > 0 ? (uint32_t)value : 1u;
     else if (k == "plans_at_handoff") e->opt_handoff = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else if (k == "handoff_min_entries") e->opt_handoff_min_nnz = value > 0 ? (uint64_t)value : 0;
     else if (k == "pilot_rows") e->opt_pilot_rows = value > 0 ? (uint32_t)value : 0u;
@@ -2411,9 +2434,7 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
     const size_t ns = e->stages.size();
     rc = ensure_events(e, ns + 1);
     if (rc) return rc;
-    // pad rows (index n) of the 16-wide feature buffers must read as zero
-    for (auto &b : e->h) HIP_TRY(e, gnnvc::launch_zero_pad_row(b.p, n, 16, e->stream));
-    const float *cur = d_x;
+    const float *cur = d_x;   // (the pad rows of e->h were zeroed when the graph was handed over: reserve_features)
     e->c4_fused_for = -1;
     e->c4_prepared_stage = -1;
     if (e->fit_pending && hipEventQuery(e->ev_fit) == hipSuccess) {   // the previous forward's verdicts have arrived

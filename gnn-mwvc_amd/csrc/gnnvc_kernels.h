@@ -200,7 +200,7 @@ uint32_t lds_table_record_words();
 // workgroup steps of the F = 1 plan: one record per (chunk, block, up to 256 entries per slice); a chunk = 16 slices
 hipError_t lds_table_wsteps(const GraphDev &g, uint32_t slice_rows, uint32_t nchunks, uint32_t nblocks, const uint32_t *seg_cnt,
                             const uint32_t *step_ptr, uint32_t *step_count, uint32_t *recs, bool write, uint32_t slack,
-                            hipStream_t stream, const PlanMap &pm = PlanMap());
+                            hipStream_t stream, const PlanMap &pm = PlanMap(), uint32_t row_base = 0, uint32_t row_end = 0xFFFFFFFFu);
 hipError_t lds_table_bytes(const uint32_t *w, uint32_t n, uint8_t *wb, uint32_t *bad, hipStream_t stream);
 hipError_t lds_table_count(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t block_cols,
                            uint32_t *seg_cnt, uint32_t *bad, hipStream_t stream, uint32_t row_base = 0,
@@ -240,11 +240,13 @@ hipError_t deal_rows(const GraphDev &g, const uint32_t *sorted_rows, uint32_t m,
 hipError_t mass_bounds(const GraphDev &g, unsigned long long target, uint32_t count, uint32_t *cand, hipStream_t stream);
 hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *x,
                                    float *out, uint32_t row_lo, uint32_t row_hi, uint32_t rows_per_chunk,
-                                   const uint32_t *step_ptr, const void *steps, const uint32_t *entries, const uint8_t *wbyte,
+                                   const uint32_t *step_ptr, const void *steps, const uint32_t *entries,
+                                   uint8_t *wbyte /* n + 64 bytes, pad zeroed: rewritten from x by every launch */,
                                    float *acc, uint32_t *bad, uint32_t long_thresh, bool mfma, bool interleave,
                                    hipStream_t stream, const EmitArgs &emit, uint32_t last_entry,
                                    const uint32_t *rowmap = nullptr /* skewed graphs: the plan's rows, slice by slice */,
-                                   uint32_t mapped_chunks = 0);
+                                   uint32_t mapped_chunks = 0,
+                                   uint32_t plan_base = 0, uint32_t plan_end = 0xFFFFFFFFu /* the plan's row range (a rank's rows) */);
 
 // compact-table plan of the 16-wide stages (see the k_c4_* kernels); the step layout is built with the
 // lds_table_* functions per SLICE (rows_per_chunk / compact_slices() rows), compact_step() entries per step,

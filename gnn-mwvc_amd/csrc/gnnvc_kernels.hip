@@ -1468,12 +1468,34 @@ __global__ void k_row_hashes(GraphDev g, unsigned long long *__restrict__ out) {
 // streams the whole byte table once per chunk (512 chunks x 10 MB on the metric graph) from L2 into LDS.
 constexpr uint32_t kLtStep = 2048;        // default entries per step of the plan builder
 
-// bad |= 1 unless x[v] == (float)w[v] / ws (bit for bit) for every vertex
-__global__ __launch_bounds__(256) void k_lt_check_x(const float *__restrict__ x, const uint32_t *__restrict__ w, float ws,
-                                                    uint32_t n, uint32_t *bad) {
+// The byte table of THIS forward, made from its input alone: wb[v] = k with x[v] == (float)k / ws bit for bit, k <= 255 — the
+// expression the kernel's look-up table is made of; bad |= 1 if some x[v] is no such value (the plan then steps aside for this
+// forward).  For the reference's driver x[v] = (float)W(v) / ws (src/GNN_VC.cpp:189-191): k = W(v).  Needs no vertex weights,
+// so a rank that holds a SLICE of the graph (and the replicated x) can use the plan too.
+__global__ __launch_bounds__(256) void k_lt_bytes_x(const float *__restrict__ x, float ws, uint32_t n, uint8_t *__restrict__ wb,
+                                                    uint32_t *bad) {
     bool miss = false;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        miss |= __float_as_uint(x[i]) != __float_as_uint((float)w[i] / ws);
+    // four vertices per thread: one 16-byte load, one 4-byte store (an x that is not 16-byte aligned: one vertex per thread)
+    const uint32_t quads = (reinterpret_cast<uintptr_t>(x) & 15u) ? 0u : n / 4u;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4 *>(x)[q];
+        const float f[4] = {v.x, v.y, v.z, v.w};
+        uint32_t packed = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float t = f[i] * ws;                       // k (1 + eps), eps <= 2^-23: rounds to k for k <= 255
+            uint32_t k = (t >= 0.0f && t < 255.5f) ? (uint32_t)(t + 0.5f) : 0u;
+            miss |= __float_as_uint((float)k / ws) != __float_as_uint(f[i]);
+            packed |= k << (8 * i);
+        }
+        reinterpret_cast<uint32_t *>(wb)[q] = packed;
+    }
+    for (uint32_t v = quads * 4u + blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {   // the tail (or all of it)
+        const float t = x[v] * ws;
+        const uint32_t k = (t >= 0.0f && t < 255.5f) ? (uint32_t)(t + 0.5f) : 0u;
+        miss |= __float_as_uint((float)k / ws) != __float_as_uint(x[v]);
+        wb[v] = (uint8_t)k;
+    }
     if (__any(miss) && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
 }
 
@@ -1995,13 +2017,14 @@ constexpr uint32_t kLtwRec = 36;
 __global__ __launch_bounds__(64) void k_ltw_steps(GraphDev g, uint32_t slice_rows, uint32_t nchunks, uint32_t nblocks,
                                                   const uint32_t *__restrict__ seg_cnt, const uint32_t *__restrict__ step_ptr,
                                                   uint32_t *__restrict__ step_count, uint32_t *__restrict__ recs, int write,
-                                                  uint32_t cap, uint32_t slack, uint32_t block_cols, PlanMap pm) {
+                                                  uint32_t cap, uint32_t slack, uint32_t block_cols, PlanMap pm, uint32_t row_base,
+                                                  uint32_t row_end) {
     // record words [1] = the block's first column, [34] = the 16-byte piece of the byte table its last column sits in
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
     uint32_t first[16];
 #pragma unroll
-    for (uint32_t w = 0; w < 16; ++w) first[w] = lt_chunk_first(g, c * 16 + w, slice_rows, 0, g.n, slack, pm.first);
+    for (uint32_t w = 0; w < 16; ++w) first[w] = lt_chunk_first(g, c * 16 + w, slice_rows, row_base, row_end, slack, pm.first);
     const uint32_t pos = write ? step_ptr[c] : 0;
     uint32_t made = 0, last_block = 0;
     for (uint32_t b = 0; b < nblocks; ++b) {
@@ -2067,7 +2090,9 @@ __global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ st
                                                  const uint32_t *__restrict__ entries, const uint8_t *__restrict__ wbyte, float ws,
                                                  float *__restrict__ agg, uint32_t n, uint32_t slice_rows, uint32_t chunk0,
                                                  uint32_t last_entry, const uint32_t *__restrict__ bad,
-                                                 const uint32_t *__restrict__ rowmap) {
+                                                 const uint32_t *__restrict__ rowmap, uint32_t row_base, uint32_t row_end) {
+    // (row_base / row_end: the plan's row range — the whole graph, or the rows one rank of a partitioned run holds; n = the
+    // number of COLUMNS, i.e. the whole graph's vertices)
     // rowmap != nullptr (skewed graphs): slice s holds the rows rowmap[s * slice_rows ..] (0xFFFFFFFF = none), dealt from
     // the degree-sorted list, and the column blocks have their own widths (record words 1 and 34)
     extern __shared__ __attribute__((aligned(16))) unsigned char lt_smem[];
@@ -2077,7 +2102,7 @@ __global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ st
     float *lut = reinterpret_cast<float *>(lt_smem) + 16 * slice_rows;  // 256 floats
     uint8_t *slice = reinterpret_cast<uint8_t *>(lut + 256);            // kLtwBlock bytes (16-byte aligned: slice_rows * 64 is)
     const uint32_t chunk = chunk0 + blockIdx.x;
-    const uint32_t row0 = (chunk * 16 + wave) * slice_rows;
+    const uint32_t row0 = row_base + (chunk * 16 + wave) * slice_rows;
     for (uint32_t i = lane; i < slice_rows; i += 64) A[i] = 0.0f;
     if (tid < 256) lut[tid] = (float)tid / ws;                          // the very expression that makes x (checked per forward)
     const uint32_t st0 = __builtin_amdgcn_readfirstlane(step_ptr[chunk]);
@@ -2198,7 +2223,7 @@ __global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ st
     }
     for (uint32_t i = lane; i < slice_rows; i += 64) {
         const uint32_t row = rowmap ? rowmap[(size_t)(chunk * 16 + wave) * slice_rows + i] : row0 + i;
-        if (row < n) agg[row] = A[i];
+        if (row < row_end) agg[row] = A[i];
     }
 }
 
@@ -3693,10 +3718,11 @@ uint32_t lds_table_record_words() { return kLtwRec; }
 
 hipError_t lds_table_wsteps(const GraphDev &g, uint32_t slice_rows, uint32_t nchunks, uint32_t nblocks, const uint32_t *seg_cnt,
                             const uint32_t *step_ptr, uint32_t *step_count, uint32_t *recs, bool write, uint32_t slack,
-                            hipStream_t stream, const PlanMap &pm) {
+                            hipStream_t stream, const PlanMap &pm, uint32_t row_base, uint32_t row_end) {
     if (slack < 3u * nblocks + 4u) return hipErrorInvalidValue;
+    if (row_end > g.n) row_end = g.n;
     GNNVC_LAUNCH(k_ltw_steps, dim3((nchunks + 63) / 64), dim3(64), 0, stream, g, slice_rows, nchunks, nblocks, seg_cnt,
-                       step_ptr, step_count, recs, write ? 1 : 0, kLtwStep, slack, kLtwBlock, pm);
+                       step_ptr, step_count, recs, write ? 1 : 0, kLtwStep, slack, kLtwBlock, pm, row_base, row_end);
     return hipGetLastError();
 }
 
@@ -3833,20 +3859,22 @@ hipError_t mass_bounds(const GraphDev &g, unsigned long long target, uint32_t co
 
 hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *x,
                                    float *out, uint32_t row_lo, uint32_t row_hi, uint32_t rows_per_chunk,
-                                   const uint32_t *step_ptr, const void *steps, const uint32_t *entries, const uint8_t *wbyte,
+                                   const uint32_t *step_ptr, const void *steps, const uint32_t *entries, uint8_t *wbyte,
                                    float *acc, uint32_t *bad, uint32_t long_thresh, bool mfma, bool interleave,
                                    hipStream_t stream, const EmitArgs &emit, uint32_t last_entry, const uint32_t *rowmap,
-                                   uint32_t mapped_chunks) {
+                                   uint32_t mapped_chunks, uint32_t plan_base, uint32_t plan_end) {
     if (row_hi <= row_lo) return hipSuccess;
+    if (plan_end > g.n) plan_end = g.n;
+    if (row_lo < plan_base || row_hi > plan_end) return hipErrorInvalidValue;
     if (rowmap && (row_lo != 0 || row_hi != g.n || mapped_chunks == 0)) return hipErrorInvalidValue;   // (a mapped plan sums all of its rows)
     if (sp.variant != 0 || rows_per_chunk == 0 || rows_per_chunk > 16u * kLtwSliceRows || rows_per_chunk % 16u || g.nnz == 0)
         return hipErrorInvalidValue;
     // does this forward's input match the table?  decided on the device: no host round trip
     hipError_t rc = hipMemsetAsync(bad, 0, sizeof(uint32_t), stream);
     if (rc != hipSuccess) return rc;
-    GNNVC_LAUNCH(k_lt_check_x, dim3(std::min<unsigned>((g.n + 255) / 256, 4096u)), dim3(256), 0, stream, x, g.w, ws, g.n,
-                       bad);
-    const uint32_t c0 = rowmap ? 0u : row_lo / rows_per_chunk, c1 = rowmap ? mapped_chunks - 1 : (row_hi - 1) / rows_per_chunk;
+    GNNVC_LAUNCH(k_lt_bytes_x, dim3(std::min<unsigned>((g.n / 4 + 255) / 256 + 1, 4096u)), dim3(256), 0, stream, x, ws, g.n,
+                 wbyte, bad);
+    const uint32_t c0 = rowmap ? 0u : (row_lo - plan_base) / rows_per_chunk, c1 = rowmap ? mapped_chunks - 1 : (row_hi - 1 - plan_base) / rows_per_chunk;
     const uint32_t slice_rows = rows_per_chunk / 16u;
     constexpr size_t lds_max = (size_t)16 * kLtwSliceRows * 4 + 1024 + kLtwBlock;
     static_assert(lds_max <= 160 * 1024, "LDS budget of k_lt_agg");
@@ -3855,7 +3883,7 @@ hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float
     rc = allow_dynamic_lds(reinterpret_cast<const void *>(k_lt_agg), (int)lds_max, lds_ok);
     if (rc != hipSuccess) return rc;
     GNNVC_LAUNCH(k_lt_agg, dim3(c1 - c0 + 1), dim3(1024), lds, stream, step_ptr, reinterpret_cast<const uint32_t *>(steps),
-                       entries, wbyte, ws, acc, g.n, slice_rows, c0, last_entry, bad, rowmap);
+                       entries, wbyte, ws, acc, g.n, slice_rows, c0, last_entry, bad, rowmap, rowmap ? 0u : plan_base, rowmap ? g.n : plan_end);
     const uint32_t ntiles = (row_hi - row_lo + kWave - 1) / kWave;
     const uint32_t per_xcd = (ntiles + 7) / 8;
     const uint32_t blocks_per_xcd = (per_xcd + kWavesPerBlock - 1) / kWavesPerBlock;

@@ -1662,6 +1662,72 @@ def test_multi_device_handle_equals_single_engine(model_text, oracle_model, make
         e.close()
 
 
+@pytest.mark.parametrize("world", [4, 8])
+def test_sliced_engines_run_their_range_plans(model_text, oracle_model, world):
+    """Per-rank plans for any P (round 3): every rank's engine holds only its slice and runs each stage over its whole row
+    range — stage 0 from the LDS-table plan laid out over the slice (byte table made from x: no vertex weights needed),
+    the 16-wide stages from the compact-table plan announced per stage.  Same bits as the oracle; the plans really ran."""
+    import gnn_mwvc_amd as G
+    import torch
+    from gnn_mwvc_amd import distributed as D
+    g = gg.erdos_renyi(160000, 3200000, 79)     # 40 entries per row: at most four live feature columns
+    dev = torch.device("cuda:0")
+    oracle_model.set_weight_scale(g.ws)
+    want = oracle_model.logits(g)
+    bounds = D.partition_bounds(g.n, world)
+    t = lambda a: torch.from_numpy(a.astype(np.int64)).to(torch.int32).to(dev)
+    rp, col, w, nw = t(g.rowptr), t(g.col), t(g.w), t(g.nw)
+    engines = []
+    try:
+        for lo, hi in bounds:
+            e = G.Engine(model_text, device=0)
+            engines.append(e)
+            e.set_option("blocked_min_n", 0)          # let the plans apply to a small graph
+            e.set_weight_scale(g.ws)
+            sl = D.slice_csr(g.n, rp, col, w, nw, lo, hi)
+            torch.cuda.synchronize()
+            e.attach_graph_slice(g.n, lo, hi, sl.nnz, sl.rowptr.data_ptr(), sl.col.data_ptr(), sl.w.data_ptr(), sl.nw.data_ptr(),
+                                 keepalive=sl)
+        x = torch.from_numpy(g.x()).to(dev)
+        h1 = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+        h2 = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+        sc = torch.zeros(g.n, dtype=torch.float32, device=dev)
+        lg = torch.zeros(g.n, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        for rep in range(4):
+            if rep:
+                for buf in (h1, h2, sc, lg):
+                    buf.fill_(7.0)
+                h1[g.n] = 0.0
+                h2[g.n] = 0.0
+                torch.cuda.synchronize()
+            for st, (src, dst, lgt) in enumerate(((x, h1, None), (h1, h2, None), (h2, sc, lg))):
+                for e, (lo, hi) in zip(engines, bounds):
+                    if st >= 1:
+                        e.stage_input_ready(st, src.data_ptr(), lo, hi)
+                    e.stage_forward_device(st, lo, hi, src.data_ptr(), dst.data_ptr(), lgt.data_ptr() if lgt is not None else 0)
+                for e in engines:
+                    e.synchronize()                              # ("exchange": the buffers are shared here)
+            assert np.array_equal(bits(lg.cpu().numpy()), bits(want)), rep
+        for e, (lo, hi) in zip(engines, bounds):
+            assert e.get_info("lds_table_active") == 1 and e.get_info("lds_table_chunks") >= 16, (lo, hi)
+            assert e.get_info("compact_gather_active") == 1 and e.get_info("compact_gather_last_ok") == 1, (lo, hi)
+        # a rank whose x is NOT k / ws (k <= 255): the byte table cannot hold it, the plan steps aside, same bits as the oracle
+        x2 = (g.x() * np.float32(0.37)).astype(np.float32)
+        want2 = oracle_model.predict(g, x2, stop_after=oracle_model.n_layers - 2)[:, 0]
+        xt = torch.from_numpy(x2).to(dev)
+        torch.cuda.synchronize()
+        for st, (src, dst, lgt) in enumerate(((xt, h1, None), (h1, h2, None), (h2, sc, lg))):
+            for e, (lo, hi) in zip(engines, bounds):
+                e.stage_forward_device(st, lo, hi, src.data_ptr(), dst.data_ptr(), lgt.data_ptr() if lgt is not None else 0)
+            for e in engines:
+                e.synchronize()
+        assert np.array_equal(bits(lg.cpu().numpy()), bits(want2))
+    finally:
+        for e in engines:
+            e.close()
+
+
 def test_stage_input_announcement_does_not_outlive_its_input(model_text, oracle_model):
     """gnnvc_stage_input_ready is matched on (stage, buffer address, row range); the contents of that buffer change
     from one forward to the next.  A caller that announces in one forward and not in the next (same buffers) must
