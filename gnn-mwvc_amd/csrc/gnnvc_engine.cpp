@@ -287,7 +287,7 @@ struct gnnvc_engine {
     // otherwise allocate), 2 = every plan whatever its cost (callers who score a graph many times, or hide the build under a
     // copy), 0 = as in round 2 (inside the first two forwards).
     int opt_handoff = 1;
-    uint64_t opt_handoff_min_nnz = 48ull << 20;
+    uint64_t opt_handoff_min_nnz = 24ull << 20;   // (the builds cost ~20 ps per entry and plan, a first forward saves ~40: from ~20 Mi entries on one use repays them)
     // First use of the compact-table plan on a graph: a pilot over the first opt_pilot_rows rows of the producing stage picks
     // the consumer's table columns, so the producer can write the table on its way (see launch_main)
     uint32_t opt_pilot_rows = 65536;

@@ -799,57 +799,69 @@ __global__ void k_find_long(GraphDev g, uint32_t thresh, uint32_t *__restrict__ 
     if (g.rowptr[u + 1] - g.rowptr[u] >= thresh) list[atomicAdd(count, 1u)] = u;
 }
 
-// The dense layers of one long row on one lane, given its aggregate (the tail of k_long_* and k_giant_dense).
-template <int N1, int N2, int N3, bool SIGMOID>
-__device__ __forceinline__ void long_tail_f16(const GraphDev &g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
-                                              float *__restrict__ logits, const float *__restrict__ P, uint32_t u, uint32_t deg,
-                                              const float (&agg)[16]) {
-    float x0[32];
+// The dense layers of ONE row on one WAVE (round 3): lane j holds output j of a layer, input k arrives from lane k through
+// v_readlane, and every output's chain still runs k = 0, 1, ... from +0.0f with one fused multiply-add per term and a separately
+// rounded bias add — the order dense<>() uses, hence the same bits.  A long row's tail used to be one LANE walking all
+// 2 656 (1 696) multiply-adds one after the other, ~15 - 30 us with the weights coming through a cold scalar cache — longer
+// than gathering a 2 000-entry row; a wave does it in about a microsecond.
+template <int K, int N, int ACT>
+__device__ __forceinline__ float wave_layer(float xin, const float *__restrict__ W, const float *__restrict__ b, int lane) {
+    const int j = lane < N ? lane : 0;
+    float wv[K];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) x0[j] = agg[j];
-    const float4 h0 = fin[(size_t)u * 4 + 0], h1 = fin[(size_t)u * 4 + 1];
-    const float4 h2 = fin[(size_t)u * 4 + 2], h3 = fin[(size_t)u * 4 + 3];
-    x0[16] = h0.x;
-    x0[17] = (float)deg;
-    x0[18] = (float)g.w[u] / ws;
-    x0[19] = (float)g.nw[u] / ws;
-    x0[20] = h1.x; x0[21] = h1.y; x0[22] = h1.z; x0[23] = h1.w;
-    x0[24] = h2.x; x0[25] = h2.y; x0[26] = h2.z; x0[27] = h2.w;
-    x0[28] = h3.x; x0[29] = h3.y; x0[30] = h3.z; x0[31] = h3.w;
-    const float *W1 = P, *b1 = W1 + 35 * N1;
+    for (int k = 0; k < K; ++k) wv[k] = W[k * N + j];    // (one coalesced 4 N-byte load per k, all in flight at once)
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        acc = __builtin_fmaf(__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(xin), k)), wv[k], acc);
+    const float t = acc + b[j];
+    return (ACT == 0) ? relu_ref(t) : t;
+}
+
+// x0: lane k holds input k of the first layer (K1 = 32 of the 35 for a 16-wide stage: the last three meet exact zeros; 5 for the
+// F = 1 stage); returns this lane's output of the last layer (lanes >= N3: a copy of lane 0's)
+template <int K1, int N1, int N2, int N3, bool SIGMOID>
+__device__ __forceinline__ float wave_tail(const float *__restrict__ P, int k1_rows, float x0, int lane) {
+    const float *W1 = P, *b1 = W1 + k1_rows * N1;
     const float *W2 = b1 + N1, *b2 = W2 + N1 * N2;
     const float *W3 = b2 + N2, *b3 = W3 + N2 * N3;
-    float x1[N1], x2[N2], x3[N3];
-    dense<32, 32, N1, 0>(x0, x1, W1, b1);
-    dense<N1, N1, N2, 0>(x1, x2, W2, b2);
-    dense<N2, N2, N3, SIGMOID ? 1 : 0>(x2, x3, W3, b3);
+    const float x1 = wave_layer<K1, N1, 0>(x0, W1, b1, lane);
+    const float x2 = wave_layer<N1, N2, 0>(x1, W2, b2, lane);
+    return wave_layer<N2, N3, SIGMOID ? 1 : 0>(x2, W3, b3, lane);
+}
+
+template <int N1, int N2, int N3, bool SIGMOID>
+__device__ __forceinline__ void wave_tail_f16(const GraphDev &g, float ws, const float *__restrict__ fin, float *__restrict__ fout,
+                                              float *__restrict__ logits, const float *__restrict__ P, uint32_t u, uint32_t deg,
+                                              float agg_lane /* lanes 0..15: the row's aggregate */, int lane) {
+    // first-layer inputs in k order: 0..15 aggregate, 16 = h[0], 17 = degree, 18 = W/ws, 19 = NW/ws, 20..31 = h[4..15]
+    float x0 = agg_lane;
+    if (lane == 16) x0 = fin[(size_t)u * 16];
+    if (lane == 17) x0 = (float)deg;
+    if (lane == 18) x0 = (float)g.w[u] / ws;
+    if (lane == 19) x0 = (float)g.nw[u] / ws;
+    if (lane >= 20 && lane < 32) x0 = fin[(size_t)u * 16 + (lane - 16)];
+    const float y = wave_tail<32, N1, N2, N3, SIGMOID>(P, 35, x0, lane);
     if constexpr (SIGMOID) {
-        if (logits) logits[u] = x3[0];
-        fout[u] = sigmoid_ref(x3[0]);
+        if (lane == 0) {
+            if (logits) logits[u] = y;
+            fout[u] = sigmoid_ref(y);
+        }
     } else {
-#pragma unroll
-        for (int j = 0; j < N3; ++j) fout[(size_t)u * N3 + j] = x3[j];
+        if (lane < N3) fout[(size_t)u * N3 + lane] = y;
     }
 }
 
 template <int N1, int N2, int N3>
-__device__ __forceinline__ void long_tail_f1(const GraphDev &g, float ws, const float *__restrict__ xin, float *__restrict__ fout,
-                                             const float *__restrict__ P, uint32_t u, uint32_t deg, float agg) {
-    float x0[5];
-    x0[0] = agg;
-    x0[1] = xin[u];
-    x0[2] = (float)deg;
-    x0[3] = (float)g.w[u] / ws;
-    x0[4] = (float)g.nw[u] / ws;
-    const float *W1 = P, *b1 = W1 + 5 * N1;
-    const float *W2 = b1 + N1, *b2 = W2 + N1 * N2;
-    const float *W3 = b2 + N2, *b3 = W3 + N2 * N3;
-    float x1[N1], x2[N2], x3[N3];
-    dense<5, 5, N1, 0>(x0, x1, W1, b1);
-    dense<N1, N1, N2, 0>(x1, x2, W2, b2);
-    dense<N2, N2, N3, 0>(x2, x3, W3, b3);
-#pragma unroll
-    for (int j = 0; j < N3; ++j) fout[(size_t)u * N3 + j] = x3[j];
+__device__ __forceinline__ void wave_tail_f1(const GraphDev &g, float ws, const float *__restrict__ xin, float *__restrict__ fout,
+                                             const float *__restrict__ P, uint32_t u, uint32_t deg, float agg, int lane) {
+    float x0 = agg;                                   // lane 0
+    if (lane == 1) x0 = xin[u];
+    if (lane == 2) x0 = (float)deg;
+    if (lane == 3) x0 = (float)g.w[u] / ws;
+    if (lane == 4) x0 = (float)g.nw[u] / ws;
+    const float y = wave_tail<5, N1, N2, N3, false>(P, 5, x0, lane);
+    if (lane < N3) fout[(size_t)u * N3 + lane] = y;
 }
 
 constexpr int kLongChunk = 256;
@@ -967,14 +979,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     }
 #undef GNNVC_FETCH_IDX
 #undef GNNVC_FETCH_ROWS
-    __syncthreads();
-    if (tid < 16) slab[0][tid] = acc;
-    __syncthreads();
-    if (tid != 0) return;
-    float agg[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) agg[j] = slab[0][j];
-    long_tail_f16<N1, N2, N3, SIGMOID>(g, ws, fin, fout, logits, P, u, deg, agg);
+    if (tid >= 64) return;   // the first wave holds the sums (lanes 0..15) and runs the row's dense layers
+    wave_tail_f16<N1, N2, N3, SIGMOID>(g, ws, reinterpret_cast<const float *>(fin), fout, logits, P, u, deg, acc, tid);
 }
 
 template <int N1, int N2, int N3>
@@ -1031,8 +1037,8 @@ __global__ __launch_bounds__(256) void k_long_f1(
     }
 #undef GNNVC_FETCH_IDX1
 #undef GNNVC_FETCH_VAL1
-    if (tid != 0) return;
-    long_tail_f1<N1, N2, N3>(g, ws, xin, fout, P, u, deg, agg);
+    if (tid >= 64) return;   // (thread 0 holds the sum)
+    wave_tail_f1<N1, N2, N3>(g, ws, xin, fout, P, u, deg, agg, tid);
 }
 
 // ------------------------------------------------------------------ giant rows
@@ -1369,20 +1375,19 @@ __global__ __launch_bounds__(64) void k_giant_dense(GraphDev g, float ws, const 
                                                     float *__restrict__ logits, const float *__restrict__ P,
                                                     const uint4 *__restrict__ meta, uint32_t n_giant,
                                                     const float *__restrict__ agg, uint32_t row_lo, uint32_t row_hi, uint32_t min_deg) {
-    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t i = blockIdx.x;                       // one wave per giant row (wave_tail)
+    const int lane = threadIdx.x;
     if (i >= n_giant) return;
     const uint4 mt = meta[i];
     if (mt.x < row_lo || mt.x >= row_hi || mt.z < min_deg) return;
     if constexpr (VARIANT == 0) {
-        long_tail_f1<32, 32, 16>(g, ws, in, out, P, mt.x, mt.z, agg[(size_t)i * 16]);
+        wave_tail_f1<32, 32, 16>(g, ws, in, out, P, mt.x, mt.z, agg[(size_t)i * 16], lane);
     } else {
-        float a[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) a[j] = agg[(size_t)i * 16 + j];
+        const float a = agg[(size_t)i * 16 + (lane & 15)];
         if constexpr (VARIANT == 1)
-            long_tail_f16<32, 32, 16, false>(g, ws, reinterpret_cast<const float4 *>(in), out, nullptr, P, mt.x, mt.z, a);
+            wave_tail_f16<32, 32, 16, false>(g, ws, in, out, nullptr, P, mt.x, mt.z, a, lane);
         else
-            long_tail_f16<32, 16, 1, true>(g, ws, reinterpret_cast<const float4 *>(in), out, logits, P, mt.x, mt.z, a);
+            wave_tail_f16<32, 16, 1, true>(g, ws, in, out, logits, P, mt.x, mt.z, a, lane);
     }
 }
 
@@ -4099,7 +4104,7 @@ hipError_t launch_giant_stage(const StagePlan &sp, const GraphDev &g, float ws, 
                      seg ? reinterpret_cast<const uint4 *>(gr.segmap) : nullptr, gr.maxseg, min_deg);
     }
     const float *P = params + sp.param_offset;
-    const dim3 grid((gr.n + 63) / 64), block(64);
+    const dim3 grid(gr.n), block(64);
     switch (sp.variant) {
     case 0: GNNVC_LAUNCH(k_giant_dense<0>, grid, block, 0, stream, g, ws, in, out, logits, P, meta, gr.n, gr.agg, row_lo, row_hi, min_deg); break;
     case 1: GNNVC_LAUNCH(k_giant_dense<1>, grid, block, 0, stream, g, ws, in, out, logits, P, meta, gr.n, gr.agg, row_lo, row_hi, min_deg); break;

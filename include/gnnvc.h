@@ -93,7 +93,7 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *                         call and scores it once (src/GNN_VC.cpp:171-192), so what depends on the graph alone is built when
  *                         the graph is handed over (upload / staged commit / attach), not inside a later forward: 1 (default) =
  *                         the plans that ONE forward repays (degree-uniform graphs of at least "handoff_min_entries"
- *                         adjacency entries, default 48 Mi: LDS table + compact table; every graph: its tile order and
+ *                         adjacency entries, default 24 Mi: LDS table + compact table; every graph: its tile order and
  *                         every buffer a forward would otherwise allocate), 2 = every plan the graph qualifies for whatever
  *                         it costs (callers who score a graph many times, or hide the build under a copy), 0 = inside the
  *                         graph's first two forwards (round 2's behaviour).  gnnvc_get_info "handoff_build_us" = what it took

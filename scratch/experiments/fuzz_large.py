@@ -11,8 +11,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 big = len(sys.argv) > 3 and sys.argv[3] == "big"   # 3 - 12 M vertices, up to ~250 M entries
 dev = torch.device("cuda", 0)
-PLAIN = {"lds_table": 0, "compact_gather": 0, "blocked_stage0": 0, "prune_zero_rows": 0, "giant_segments": 0, "sorted_tiles": 0,
-         "long_row_threshold": 512, "giant_row_threshold": 16384}
+from tools.panel_graphs import PLAIN, panel_graph
 INFO = ("tile_waste_x100", "lds_table_active", "lds_table_mapped", "compact_gather_active", "pruned_stage1", "pruned_stage2", "sorted_tiles_active", "long_rows",
         "long_row_threshold", "giant_rows", "giant_segments", "blocked_stage0_active")
 
@@ -47,21 +46,7 @@ def run(g, x, opts, reps):
 bad = 0
 t0 = time.time()
 for case in range(cases):
-    rng = np.random.default_rng(seed0 + case)
-    kind = rng.choice(["er", "rmat", "powerlaw", "er_dense", "uniform_hubs"])
-    s = int(rng.integers(1 << 30))
-    if kind == "er":
-        n = int(rng.integers(4_000_000, 12_000_000) if big else rng.integers(300_000, 4_000_000)); g = ggt.erdos_renyi(n, int(n * rng.uniform(3, 14)), s, dev)
-    elif kind == "rmat":
-        g = ggt.rmat(int(rng.integers(21, 24) if big else rng.integers(17, 22)), int(rng.integers(4, 20)), s, dev)
-    elif kind == "powerlaw":
-        n = int(rng.integers(3_000_000, 8_000_000) if big else rng.integers(300_000, 3_000_000))
-        g = ggt.power_law_hubs(n, float(rng.uniform(6, 20)), float(rng.uniform(2.0, 2.5)), int(rng.integers(0, 9)), int(rng.integers(1000, 200_000)), s, dev)
-    elif kind == "uniform_hubs":   # nearly degree-uniform + a few hubs
-        n = int(rng.integers(3_000_000, 8_000_000) if big else rng.integers(300_000, 3_000_000))
-        g = ggt.power_law_hubs(n, float(rng.uniform(8, 24)), float(rng.uniform(3.5, 5.0)), int(rng.integers(1, 9)), int(rng.integers(5000, 300_000)), s, dev)
-    else:
-        n = int(rng.integers(1_000_000, 2_500_000) if big else rng.integers(300_000, 900_000)); g = ggt.erdos_renyi(n, int(n * rng.uniform(30, 60)), s, dev)
+    kind, g = panel_graph(seed0 + case, dev, big)
     x = g.x().contiguous()
     deg = (g.rowptr[1:] - g.rowptr[:-1]).to(torch.float64)[: g.n]
     mean = float(deg.sum()) / g.n
