@@ -2688,9 +2688,16 @@ __global__ __launch_bounds__(256) void k_prune_mass(GraphDev g, const uint32_t *
         mine += ((unsigned long long)__shfl_xor((unsigned)(mine >> 32), off) << 32) | __shfl_xor((unsigned)mine, off);
         members += __shfl_xor(members, off);
     }
-    if ((threadIdx.x & 63) == 0 && members) {
-        if (mine) atomicAdd(mass, mine);
-        atomicAdd(mass + 1, (unsigned long long)members);
+    __shared__ unsigned long long part[4][2];
+    if ((threadIdx.x & 63) == 0) {
+        part[threadIdx.x >> 6][0] = mine;
+        part[threadIdx.x >> 6][1] = members;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {   // (one pair of atomics per block: per wave they queue up behind each other)
+        const unsigned long long m0 = part[0][0] + part[1][0] + part[2][0] + part[3][0], m1 = part[0][1] + part[1][1] + part[2][1] + part[3][1];
+        if (m0) atomicAdd(mass, m0);
+        if (m1) atomicAdd(mass + 1, m1);
     }
 }
 
