@@ -140,6 +140,23 @@ struct gnnvc_engine {
     int opt_lds_skewed = 1;              // option "lds_table_skewed": 0 = skewed graphs keep the gathering F = 1 kernels
     uint32_t lt_rows = 0, lt_chunks = 0, lt_blocks = 0, lt_steps_total = 0, lt_last_entry = 0;
     uint32_t lt_base = 0, lt_end = 0;       // the plan's row range: the rows this engine holds when it was built
+    // A plan being put together (round 3).  The expensive passes — counting and regrouping a slice's entries by column block —
+    // need nothing but that slice's rows, so a hand-off runs them piece by piece on the second stream while the rest of the
+    // column array is still crossing the bus (flat layouts: consecutive rows, uniform blocks); begin = eligibility, geometry,
+    // buffers; advance = count + regroup the slices up to a given one; finish = the step records (they need every slice's
+    // counts) and the verdict.
+    struct PlanBuild {
+        bool open = false, mapped = false;
+        uint32_t base = 0, end = 0, slice_rows = 0, slices = 0, chunks = 0, rows = 0, nblocks = 0, bc = 0, slack = 0, done = 0;
+        uint32_t plan_rows = 0, passes = 1;
+        uint64_t entry_cap = 0, plan_nnz = 0;
+        gnnvc::PlanMap pm;
+    };
+    PlanBuild lt_pb, c4_pb;
+    // a host hand-off in progress whose plans are being built while the column array arrives (handoff_early / handoff_progress)
+    bool early_open = false, early_declined = false;
+    hipEvent_t ev_piece = nullptr;
+    double early_ms = 0.0;      // host time the hand-off spent classing the graph and queuing builds before the commit
     uint32_t opt_lt_min_chunks = 128;       // option "lds_table_min_chunks": a short row range is cut into at least this many chunks
     DevBuf<uint8_t> lt_bytes;
     DevBuf<uint32_t> lt_entries, lt_segcnt, lt_stepptr, lt_stepcnt, lt_bad;
@@ -848,10 +865,13 @@ int layout_skewed_plan(gnnvc_engine *e, uint32_t class_thresh, uint32_t max_rows
 // LDS-table plan of the current graph's F = 1 stage (kernels: k_lt_*).  Applies when every weight fits a
 // byte, adjacency lists ascend, no row is long enough for the long-row kernels and the graph is large and
 // not skewed; whether a given forward's input really is W / ws is checked on the device at every launch.
-int build_lds_table_impl(gnnvc_engine *e) {
+// lt_begin: eligibility, geometry, buffers (on e->stream); leaves lt_pb.open set if there is a plan to build.
+int lt_begin(gnnvc_engine *e) {
     e->lt_ready = false;
     e->lt_tried = true;
     e->lt_mapped = false;
+    gnnvc_engine::PlanBuild &pb = e->lt_pb;
+    pb = gnnvc_engine::PlanBuild();
     const GraphDev &g = e->g;
     if (!e->opt_lds_table || e->stages.empty() || e->stages[0].f != 1 || e->stages[0].variant != 0) return GNNVC_OK;
     // The plan covers the rows this engine holds: the whole graph, or (round 3) the SLICE of one rank of a partitioned run —
@@ -877,10 +897,7 @@ int build_lds_table_impl(gnnvc_engine *e) {
     if (e->opt_plan_chunk_rows) max_rows = std::min(max_rows, std::max(16u, e->opt_plan_chunk_rows / 16u * 16u));
     uint32_t nblocks = (g.n + bc - 1) / bc, chunks = 0, rows = 0, slice_rows = 0, slices = 0;
     uint64_t plan_nnz = g.nnz;
-    gnnvc::PlanMap pm;
     if (mapped) {
-        // rows of this many entries and more stay outside the plan: the giant rows (their own kernels), or, where there are
-        // none, whatever k_long_f1 is left with
         // Rows of this many entries and more stay outside the plan.  A row's entries of one block are one run, folded in order
         // lane after lane — a 16 K-entry row makes every step of its slice several times longer (R-MAT-22: k_lt_agg 0.58 ms with
         // rows below 2048, 1.07 ms with everything below the giant rows), while k_long_f1 gathers such rows at ~100 G entries/s as
@@ -900,7 +917,7 @@ int build_lds_table_impl(gnnvc_engine *e) {
         slices = L.slices;
         nblocks = L.nblocks;
         plan_nnz = L.entries;
-        pm = L.pm;
+        pb.pm = L.pm;
     } else {
         if (nblocks > 4096) return GNNVC_OK;
         // chunks: a multiple of the 256 CUs, each within the LDS budget; a chunk = 16 slices of rows (one per wave).  Every chunk
@@ -923,20 +940,67 @@ int build_lds_table_impl(gnnvc_engine *e) {
     HIP_TRY(e, e->lt_segcnt.reserve((size_t)slices * nblocks));
     HIP_TRY(e, e->lt_stepcnt.reserve(std::max(chunks, slices)));
     HIP_TRY(e, e->lt_stepptr.reserve((size_t)chunks + 1));
-    HIP_TRY(e, e->pin_small.reserve((size_t)chunks + 2));
+    HIP_TRY(e, e->lt_entries.reserve(entry_cap));
+    HIP_TRY(e, e->blk_acc.reserve(g.n));
     uint32_t *flag = e->lt_bad.p + 1;   // word 0 is the per-forward flag
     HIP_TRY(e, hipMemsetAsync(flag, 0, sizeof(uint32_t), e->stream));
     HIP_TRY(e, hipMemsetAsync(e->lt_bytes.p + g.n, 0, 64, e->stream));
+    HIP_TRY(e, hipMemsetAsync(e->lt_entries.p, 0, entry_cap * sizeof(uint32_t), e->stream));   // (pad slots are read, never used)
+    if (mapped)   // rows outside the plan (no entries, or giant): their sums stay +0 (never read for the giant ones)
+        HIP_TRY(e, hipMemsetAsync(e->blk_acc.p, 0, (size_t)g.n * sizeof(float), e->stream));
     // (the table itself is rewritten from x by every forward; this pass only says whether the weights of the rows held here fit a
     // byte at all — if not, x = W / ws never will, and the plan is not worth building)
     HIP_TRY(e, gnnvc::lds_table_bytes(g.w + base, held, e->lt_bytes.p + base, flag, e->stream));
-    HIP_TRY(e, gnnvc::lds_table_count(g, slice_rows, slices, nblocks, bc, e->lt_segcnt.p, flag, e->stream, base, end, pm));
-    HIP_TRY(e, gnnvc::lds_table_wsteps(g, slice_rows, chunks, nblocks, e->lt_segcnt.p, nullptr, e->lt_stepcnt.p, nullptr, false, slack,
-                                       e->stream, pm, base, end));
+    pb.open = true;
+    pb.mapped = mapped;
+    pb.base = base;
+    pb.end = end;
+    pb.slice_rows = slice_rows;
+    pb.slices = slices;
+    pb.chunks = chunks;
+    pb.rows = rows;
+    pb.nblocks = nblocks;
+    pb.bc = bc;
+    pb.slack = slack;
+    pb.entry_cap = entry_cap;
+    pb.plan_nnz = plan_nnz;
+    pb.done = 0;
+    return GNNVC_OK;
+}
+
+// count and regroup the entries of slices [done, upto) on `stream` (flat layouts: any sub-range; mapped ones: all at once)
+int lt_advance(gnnvc_engine *e, uint32_t upto, hipStream_t stream) {
+    gnnvc_engine::PlanBuild &pb = e->lt_pb;
+    if (!pb.open) return GNNVC_OK;
+    upto = std::min(upto, pb.slices);
+    if (upto <= pb.done) return GNNVC_OK;
+    uint32_t *flag = e->lt_bad.p + 1;
+    HIP_TRY(e, gnnvc::lds_table_count(e->g, pb.slice_rows, pb.slices, pb.nblocks, pb.bc, e->lt_segcnt.p, flag, stream, pb.base, pb.end,
+                                      pb.pm, pb.done, upto));
+    HIP_TRY(e, gnnvc::lds_table_scatter(e->g, pb.slice_rows, pb.slices, pb.nblocks, pb.bc, e->lt_segcnt.p, e->lt_entries.p, stream, 17, pb.base,
+                                        pb.end, pb.slack, pb.pm, flag, pb.done, upto));
+    pb.done = upto;
+    return GNNVC_OK;
+}
+
+// the step records (they need every slice's counts) and the verdict; on e->stream, behind whatever lt_advance queued there
+int lt_finish(gnnvc_engine *e) {
+    gnnvc_engine::PlanBuild &pb = e->lt_pb;
+    if (!pb.open) return GNNVC_OK;
+    pb.open = false;
+    const GraphDev &g = e->g;
+    uint32_t *flag = e->lt_bad.p + 1;
+    const uint32_t chunks = pb.chunks;
+    HIP_TRY(e, e->pin_small.reserve((size_t)chunks + 2));
+    HIP_TRY(e, gnnvc::lds_table_wsteps(g, pb.slice_rows, chunks, pb.nblocks, e->lt_segcnt.p, nullptr, e->lt_stepcnt.p, nullptr, false, pb.slack,
+                                       e->stream, pb.pm, pb.base, pb.end));
     HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, e->lt_stepcnt.p, chunks * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipMemcpyAsync(e->pin_small.p + chunks, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
-    if (e->pin_small.p[chunks]) return GNNVC_OK;   // a weight above 255 or an unsorted row: the plan does not apply
+    if (e->pin_small.p[chunks]) {   // a weight above 255, or an unsorted row (the regrouping would change the order of its sum): no plan
+        e->lt_entries.release();
+        return GNNVC_OK;
+    }
     std::vector<uint32_t> ptr((size_t)chunks + 1, 0);
     uint64_t total = 0;
     for (uint32_t c = 0; c < chunks; ++c) {
@@ -947,37 +1011,31 @@ int build_lds_table_impl(gnnvc_engine *e) {
     ptr[chunks] = (uint32_t)total;
     const size_t rec_quads = ((total + 8) * gnnvc::lds_table_record_words() + 3) / 4;   // lt_steps counts in 16-byte units
     HIP_TRY(e, e->lt_steps.reserve(rec_quads));
-    HIP_TRY(e, e->lt_entries.reserve(entry_cap));
-    HIP_TRY(e, e->blk_acc.reserve(g.n));
-    if (mapped)   // rows outside the plan (no entries, or giant): their sums stay +0 (never read for the giant ones)
-        HIP_TRY(e, hipMemsetAsync(e->blk_acc.p, 0, (size_t)g.n * sizeof(float), e->stream));
     std::memcpy(e->pin_small.p, ptr.data(), ptr.size() * sizeof(uint32_t));
     HIP_TRY(e, hipMemcpyAsync(e->lt_stepptr.p, e->pin_small.p, ptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipMemsetAsync(e->lt_steps.p, 0, rec_quads * sizeof(uint4), e->stream));
-    HIP_TRY(e, hipMemsetAsync(e->lt_entries.p, 0, entry_cap * sizeof(uint32_t), e->stream));   // (pad slots are read, never used)
-    HIP_TRY(e, gnnvc::lds_table_wsteps(g, slice_rows, chunks, nblocks, e->lt_segcnt.p, e->lt_stepptr.p, nullptr,
-                                       reinterpret_cast<uint32_t *>(e->lt_steps.p), true, slack, e->stream, pm, base, end));
-    HIP_TRY(e, gnnvc::lds_table_scatter(g, slice_rows, slices, nblocks, bc, e->lt_segcnt.p, e->lt_entries.p, e->stream, 17, base,
-                                        end, slack, pm, flag));
-    HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, gnnvc::lds_table_wsteps(g, pb.slice_rows, chunks, pb.nblocks, e->lt_segcnt.p, e->lt_stepptr.p, nullptr,
+                                       reinterpret_cast<uint32_t *>(e->lt_steps.p), true, pb.slack, e->stream, pb.pm, pb.base, pb.end));
     HIP_TRY(e, hipStreamSynchronize(e->stream));   // pin_small is reused by others
-    if (e->pin_small.p[0]) {                       // an unsorted row (the flat walk finds it while regrouping): no plan
-        e->lt_entries.release();
-        e->lt_steps.release();
-        return GNNVC_OK;
-    }
     e->c4_map_meta.release();     // (only the dealing needed the list)
     e->c4_map_vertex.release();
-    e->lt_last_entry = (uint32_t)((entry_cap - 4) & ~3ull);
-    e->lt_rows = rows;
-    e->lt_base = base;
-    e->lt_end = end;
+    e->lt_last_entry = (uint32_t)((pb.entry_cap - 4) & ~3ull);
+    e->lt_rows = pb.rows;
+    e->lt_base = pb.base;
+    e->lt_end = pb.end;
     e->lt_chunks = chunks;
-    e->lt_blocks = nblocks;
+    e->lt_blocks = pb.nblocks;
     e->lt_steps_total = (uint32_t)total;
-    e->lt_mapped = mapped;
+    e->lt_mapped = pb.mapped;
     e->lt_ready = true;
     return GNNVC_OK;
+}
+
+int build_lds_table_impl(gnnvc_engine *e) {
+    int rc = lt_begin(e);
+    if (rc == GNNVC_OK) rc = lt_advance(e, 0xFFFFFFFFu, e->stream);
+    if (rc == GNNVC_OK) rc = lt_finish(e);
+    return rc;
 }
 
 // Compact-table plan of the 16-wide stages (kernels: k_c4_*): the same (chunk, column block, step) layout
@@ -989,12 +1047,15 @@ int build_lds_table_impl(gnnvc_engine *e) {
 // threshold are dealt from the degree-sorted list to slices of equal weight, the column blocks are cut at equal
 // entry mass (hub columns sit in narrow blocks), and an input may take up to three tables — the long and giant rows
 // stay with their own kernels beside the plan.
-int build_compact_impl(gnnvc_engine *e, uint32_t base, uint32_t end, bool allow_mapped) {
+// c4_begin: eligibility, geometry, buffers (on e->stream); leaves c4_pb.open set if there is a plan to build.
+int c4_begin(gnnvc_engine *e, uint32_t base, uint32_t end, bool allow_mapped) {
     e->c4_ready = false;
     e->c4_tried = true;
     e->c4_mapped = false;
     e->c4_prepared_stage = -1;
     for (bool &b : e->c4_seeded) b = false;
+    gnnvc_engine::PlanBuild &pb = e->c4_pb;
+    pb = gnnvc_engine::PlanBuild();
     const GraphDev &g = e->g;
     if (end > g.n) end = g.n;
     if (base >= end) return GNNVC_OK;
@@ -1024,7 +1085,6 @@ int build_compact_impl(gnnvc_engine *e, uint32_t base, uint32_t end, bool allow_
     // most 160 K vertices = 2.5 MiB of table, which still sits in an XCD's 4 MiB L2 while its 32 CUs sweep it
     const double fill = gnnvc::compact_step() * 5.0 / 6.0;
     uint32_t chunks = 0, rows = 0, slice_rows = 0, slices = 0, bc = gnnvc::compact_block(), nblocks = 0;
-    gnnvc::PlanMap pm;
     if (mapped) {
         SkewedLayout L;
         HIP_TRY(e, e->c4_stepcnt.reserve(1));
@@ -1038,7 +1098,7 @@ int build_compact_impl(gnnvc_engine *e, uint32_t base, uint32_t end, bool allow_
         slice_rows = L.slice_rows;
         slices = L.slices;
         nblocks = L.nblocks;
-        pm = L.pm;
+        pb.pm = L.pm;
         bc = 160u * 1024u;   // (the widest a block may be: what the entry encoding has to hold)
     } else {
         chunks = (plan_rows + max_rows - 1) / max_rows;
@@ -1048,7 +1108,6 @@ int build_compact_impl(gnnvc_engine *e, uint32_t base, uint32_t end, bool allow_
         chunks = (plan_rows + rows - 1) / rows;
         slice_rows = rows / nsl;
         slices = chunks * nsl;
-        HIP_TRY(e, e->pin_small.reserve((size_t)slices + 4100));
         if (span != g.n) {   // the range's share of the entries (on a slice g.nnz counts the slice's entries only)
             uint32_t rp[2] = {0, 0};
             HIP_TRY(e, hipMemcpyAsync(&rp[0], g.rowptr + base, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
@@ -1075,15 +1134,68 @@ int build_compact_impl(gnnvc_engine *e, uint32_t base, uint32_t end, bool allow_
     HIP_TRY(e, e->c4_segcnt.reserve((size_t)slices * nblocks));
     HIP_TRY(e, e->c4_stepcnt.reserve(slices));
     HIP_TRY(e, e->c4_stepptr.reserve((size_t)slices + 2));
-    uint32_t *flag = e->c4_desc.p + kFlagWord;
+    HIP_TRY(e, e->c4_entries.reserve(entry_cap));
+    HIP_TRY(e, e->c4_table.reserve(((size_t)g.n + 1) * 4 * passes));
+    HIP_TRY(e, e->c4_marks.reserve(64));
+    HIP_TRY(e, e->c4_acc.reserve((size_t)g.n * 4 * passes));
+    e->c4_dirty_cap = g.n;   // rows recomputed from full rows (every row could be one: the dense-only stage kernel never gathers)
+    HIP_TRY(e, e->c4_dirty.reserve(e->c4_dirty_cap));
+    HIP_TRY(e, e->c4_agg16.reserve((size_t)e->c4_dirty_cap * 16));
     HIP_TRY(e, hipMemsetAsync(e->c4_desc.p, 0, (kFlagWord + 8) * sizeof(uint32_t), e->stream));
-    HIP_TRY(e, gnnvc::lds_table_count(g, slice_rows, slices, nblocks, bc, e->c4_segcnt.p, flag, e->stream, base, end, pm));
-    HIP_TRY(e, gnnvc::lds_table_steps(g, slice_rows, slices, nblocks, e->c4_segcnt.p, nullptr, e->c4_stepcnt.p, nullptr, false, e->stream,
-                                      base, end, gnnvc::compact_step(), slack, bc, pm));
+    HIP_TRY(e, hipMemsetAsync(e->c4_entries.p, 0, entry_cap * sizeof(uint32_t), e->stream));   // (pad slots are read, never used)
+    if (mapped)   // rows the plan does not hold (no entries, or long): their sums stay +0 (never read for the long ones)
+        HIP_TRY(e, hipMemsetAsync(e->c4_acc.p, 0, (size_t)g.n * 4 * passes * sizeof(float), e->stream));
+    pb.open = true;
+    pb.mapped = mapped;
+    pb.base = base;
+    pb.end = end;
+    pb.slice_rows = slice_rows;
+    pb.slices = slices;
+    pb.chunks = chunks;
+    pb.rows = rows;
+    pb.nblocks = nblocks;
+    pb.bc = bc;
+    pb.slack = slack;
+    pb.entry_cap = entry_cap;
+    pb.plan_nnz = range_nnz;
+    pb.plan_rows = plan_rows;
+    pb.passes = passes;
+    pb.done = 0;
+    return GNNVC_OK;
+}
+
+int c4_advance(gnnvc_engine *e, uint32_t upto, hipStream_t stream) {
+    gnnvc_engine::PlanBuild &pb = e->c4_pb;
+    if (!pb.open) return GNNVC_OK;
+    upto = std::min(upto, pb.slices);
+    if (upto <= pb.done) return GNNVC_OK;
+    uint32_t *flag = e->c4_desc.p + 2 * gnnvc_engine::kDescWords;
+    HIP_TRY(e, gnnvc::lds_table_count(e->g, pb.slice_rows, pb.slices, pb.nblocks, pb.bc, e->c4_segcnt.p, flag, stream, pb.base, pb.end, pb.pm,
+                                      pb.done, upto));
+    HIP_TRY(e, gnnvc::lds_table_scatter(e->g, pb.slice_rows, pb.slices, pb.nblocks, pb.bc, e->c4_segcnt.p, e->c4_entries.p, stream,
+                                        gnnvc::compact_shift(), pb.base, pb.end, pb.slack, pb.pm, flag, pb.done, upto));
+    pb.done = upto;
+    return GNNVC_OK;
+}
+
+int c4_finish(gnnvc_engine *e) {
+    gnnvc_engine::PlanBuild &pb = e->c4_pb;
+    if (!pb.open) return GNNVC_OK;
+    pb.open = false;
+    const GraphDev &g = e->g;
+    const uint32_t slices = pb.slices;
+    uint32_t *flag = e->c4_desc.p + 2 * gnnvc_engine::kDescWords;
+    HIP_TRY(e, e->pin_small.reserve((size_t)slices + 4100));
+    HIP_TRY(e, gnnvc::lds_table_steps(g, pb.slice_rows, slices, pb.nblocks, e->c4_segcnt.p, nullptr, e->c4_stepcnt.p, nullptr, false, e->stream,
+                                      pb.base, pb.end, gnnvc::compact_step(), pb.slack, pb.bc, pb.pm));
     HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, e->c4_stepcnt.p, slices * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipMemcpyAsync(e->pin_small.p + slices, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
-    if (e->pin_small.p[slices]) return GNNVC_OK;   // an unsorted row: regrouping by block would change the order of its sum
+    if (e->pin_small.p[slices]) {   // an unsorted row: regrouping by block would change the order of its sum
+        e->c4_entries.release(); e->c4_table.release(); e->c4_acc.release();
+        e->c4_dirty.release(); e->c4_agg16.release();
+        return GNNVC_OK;
+    }
     std::vector<uint32_t> ptr((size_t)slices + 2, 0);
     uint64_t total = 0;
     for (uint32_t c = 0; c < slices; ++c) {
@@ -1094,47 +1206,36 @@ int build_compact_impl(gnnvc_engine *e, uint32_t base, uint32_t end, bool allow_
     ptr[slices] = (uint32_t)total;
     ptr[slices + 1] = (uint32_t)total;   // slice `slices`: the empty one idle waves walk
     HIP_TRY(e, e->c4_steps.reserve(total + 8));
-    HIP_TRY(e, e->c4_entries.reserve(entry_cap));
-    HIP_TRY(e, e->c4_table.reserve(((size_t)g.n + 1) * 4 * passes));
-    HIP_TRY(e, e->c4_marks.reserve(64));
-    HIP_TRY(e, e->c4_acc.reserve((size_t)g.n * 4 * passes));
-    if (mapped)   // rows the plan does not hold (no entries, or long): their sums stay +0 (never read for the long ones)
-        HIP_TRY(e, hipMemsetAsync(e->c4_acc.p, 0, (size_t)g.n * 4 * passes * sizeof(float), e->stream));
-    e->c4_dirty_cap = g.n;   // rows recomputed from full rows (every row could be one: the dense-only stage kernel never gathers)
-    HIP_TRY(e, e->c4_dirty.reserve(e->c4_dirty_cap));
-    HIP_TRY(e, e->c4_agg16.reserve((size_t)e->c4_dirty_cap * 16));
     std::memcpy(e->pin_small.p, ptr.data(), ptr.size() * sizeof(uint32_t));
     HIP_TRY(e, hipMemcpyAsync(e->c4_stepptr.p, e->pin_small.p, ptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipMemsetAsync(e->c4_steps.p + total, 0, 8 * sizeof(uint4), e->stream));
-    HIP_TRY(e, hipMemsetAsync(e->c4_entries.p, 0, entry_cap * sizeof(uint32_t), e->stream));   // (pad slots are read, never used)
-    HIP_TRY(e, gnnvc::lds_table_steps(g, slice_rows, slices, nblocks, e->c4_segcnt.p, e->c4_stepptr.p, nullptr, e->c4_steps.p, true, e->stream,
-                                      base, end, gnnvc::compact_step(), slack, bc, pm));
-    HIP_TRY(e, gnnvc::lds_table_scatter(g, slice_rows, slices, nblocks, bc, e->c4_segcnt.p, e->c4_entries.p, e->stream,
-                                        gnnvc::compact_shift(), base, end, slack, pm, flag));
-    HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, gnnvc::lds_table_steps(g, pb.slice_rows, slices, pb.nblocks, e->c4_segcnt.p, e->c4_stepptr.p, nullptr, e->c4_steps.p, true, e->stream,
+                                      pb.base, pb.end, gnnvc::compact_step(), pb.slack, pb.bc, pb.pm));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
-    if (e->pin_small.p[0]) {                       // an unsorted row (the flat walk finds it while regrouping): no plan
-        e->c4_entries.release(); e->c4_steps.release(); e->c4_table.release(); e->c4_acc.release();
-        e->c4_dirty.release(); e->c4_agg16.release();
-        return GNNVC_OK;
-    }
     e->c4_map_meta.release();     // (only the dealing needed the list)
     e->c4_map_vertex.release();
-    e->c4_last_entry = (uint32_t)((entry_cap - 4) & ~3ull);
-    e->c4_block = bc;
-    e->c4_nblocks = nblocks;
-    e->c4_base = base;
-    e->c4_end = end;
-    e->c4_rows = rows;
-    e->c4_chunks = chunks;
+    e->c4_last_entry = (uint32_t)((pb.entry_cap - 4) & ~3ull);
+    e->c4_block = pb.bc;
+    e->c4_nblocks = pb.nblocks;
+    e->c4_base = pb.base;
+    e->c4_end = pb.end;
+    e->c4_rows = pb.rows;
+    e->c4_chunks = pb.chunks;
     e->c4_nslices = slices;
     e->c4_steps_total = (uint32_t)total;
-    e->c4_mapped = mapped;
-    e->c4_max_passes = passes;
-    e->c4_mapped_rows = mapped ? plan_rows : 0;
-    e->c4_mapped_entries = mapped ? range_nnz : 0;
+    e->c4_mapped = pb.mapped;
+    e->c4_max_passes = pb.passes;
+    e->c4_mapped_rows = pb.mapped ? pb.plan_rows : 0;
+    e->c4_mapped_entries = pb.mapped ? pb.plan_nnz : 0;
     e->c4_ready = true;
     return GNNVC_OK;
+}
+
+int build_compact_impl(gnnvc_engine *e, uint32_t base, uint32_t end, bool allow_mapped) {
+    int rc = c4_begin(e, base, end, allow_mapped);
+    if (rc == GNNVC_OK) rc = c4_advance(e, 0xFFFFFFFFu, e->stream);
+    if (rc == GNNVC_OK) rc = c4_finish(e);
+    return rc;
 }
 
 gnnvc::CompactPlan compact_plan(const gnnvc_engine *e) {
@@ -1676,6 +1777,16 @@ int prepare_plans(gnnvc_engine *e) {
     // The per-graph plans.  By default only where ONE use repays the build: degree-uniform graphs from opt_handoff_min_nnz
     // entries on (metric graph: ~3.5 ms of builds against 4.3 ms saved in the very first forward; a skewed graph's F = 1 plan
     // costs 9 - 29 ms to build and saves 0.2 - 2 ms a forward — it keeps waiting for a second forward unless asked for, "2").
+    if (e->lt_pb.open || e->c4_pb.open) {   // begun while the column array was arriving (handoff_early): the rest, and the step records
+        rc = timed_build(e, [&] {
+            int r = lt_advance(e, 0xFFFFFFFFu, e->stream);
+            if (r == GNNVC_OK) r = c4_advance(e, 0xFFFFFFFFu, e->stream);
+            if (r == GNNVC_OK) r = lt_finish(e);
+            if (r == GNNVC_OK) r = c4_finish(e);
+            return r;
+        });
+        if (rc) return rc;
+    }
     if (!g.sliced() && (e->opt_handoff >= 2 || (!skewed && g.nnz >= e->opt_handoff_min_nnz))) {
         if (!e->lt_tried) rc = build_lds_table(e);
         if (rc) return rc;
@@ -1851,6 +1962,7 @@ void gnnvc_destroy(gnnvc_engine *e) {
     e->der_tailptr.release(); e->der_tailcols.release(); e->hash_buf.release();
     e->pin_rowptr.release(); e->pin_col.release(); e->pin_w.release(); e->pin_nw.release(); e->fit_pin.release();
     if (e->ev_fit) (void)hipEventDestroy(e->ev_fit);
+    if (e->ev_piece) (void)hipEventDestroy(e->ev_piece);
     e->pin_small.release();
     e->pin_info.release();
     e->dev_info.release();
@@ -1992,6 +2104,7 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
     else if (k == "long_rows") *value = (long)e->n_long;
     else if (k == "plan_build_us") *value = (long)(e->plan_build_ms * 1000.0);
     else if (k == "handoff_build_us") *value = (long)(e->handoff_build_ms * 1000.0);
+    else if (k == "handoff_early_us") *value = (long)(e->early_ms * 1000.0);
     else if (k == "plans_at_handoff") *value = e->opt_handoff;
     else if (k == "graph_uses") *value = (long)e->graph_uses;
     else if (k == "slice_rows") *value = e->empty_slice ? 0 : (long)(e->g.hi() - e->g.lo());
@@ -2026,27 +2139,11 @@ int gnnvc_stage_widths(const gnnvc_engine *e, int stage, int *in_width, int *out
 
 // Common tail of the host hand-offs: device-side sanity checks of the arrays now in
 // e->rowptr/col/w/nw, then make them the engine's graph.
-static int adopt_uploaded(gnnvc_engine *e, uint32_t n, uint64_t nnz) {
-    {
-        const GraphDev cand{n, nnz, e->rowptr.p, e->col.p, e->w.p, e->nw.p};
-        HIP_TRY(e, gnnvc::validate_graph(cand, e->blk_flag.p, e->stream));
-        uint32_t bad = 0;
-        HIP_TRY(e, hipMemcpyAsync(&bad, e->blk_flag.p, sizeof bad, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
-        if (bad) {
-            e->have_graph = false;
-            return fail(e, GNNVC_ERR_INVALID, "%s", (bad & 1u) ? "a column id is not a vertex of this graph (col[i] >= n)"
-                                                                 : "row pointers are not monotone from 0 to nnz");
-        }
-    }
-    e->g = GraphDev{n, nnz, e->rowptr.p, e->col.p, e->w.p, e->nw.p};
-    e->have_graph = true;
-    e->empty_slice = false;
-    e->der_open = false;   // (a derivation begun against the previous graph must not be committed against this one)
-    int rc = reserve_features(e, n);
-    if (rc) return rc;
+// per-graph state of the plans: nothing of the previous graph's survives
+static void reset_graph_state(gnnvc_engine *e) {
     e->lt_ready = e->lt_tried = false;
     e->c4_ready = e->c4_tried = false;
+    e->lt_pb.open = e->c4_pb.open = false;
     for (auto &pp : e->prune) pp.tried = pp.ready = pp.deferred = false;
     for (int s = 0; s < 4; ++s) { e->c4_stage_off[s] = false; e->c4_unfit_runs[s] = 0; e->fit_used[s] = false; }
     e->fit_pending = false;
@@ -2056,9 +2153,115 @@ static int adopt_uploaded(gnnvc_engine *e, uint32_t n, uint64_t nnz) {
     e->blocked_tried = false;   // it costs about as much as it saves on one, and the reference's
     e->graph_uses = 0;          // driver uses every graph exactly once (src/GNN_VC.cpp:171-192)
     e->plan_build_ms = 0.0;
+    e->early_ms = 0.0;
     for (bool &b : e->c4_seeded) b = false;
-    rc = find_long(e);
+}
+
+// Slices of an open plan build whose rows' column entries lie inside the first `sent` entries of the column array (rp: the
+// HOST copy of the row pointers the hand-off was given).
+extern "C++" {
+template <class RP>
+static uint32_t slices_arrived(const gnnvc_engine::PlanBuild &pb, const RP *rp, uint32_t n, uint64_t sent) {
+    uint32_t lo = 0, hi = pb.slices;   // largest s with rp[min(n, base + s * slice_rows)] <= sent
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo + 1) / 2;
+        const uint64_t row = std::min<uint64_t>(n, (uint64_t)pb.base + (uint64_t)mid * pb.slice_rows);
+        if ((uint64_t)rp[row] <= sent) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+}   // extern "C++"
+
+// A host hand-off (upload / staged) of a large graph: the row pointers and weights are on the device before most of the
+// column array is.  That is enough to class the graph (find_long reads row pointers only) and to lay out the flat plans;
+// their count / regroup passes then run on the second stream for every slice whose entries have arrived, under the copies
+// of the rest ("built at hand-off, on the second stream, as the column pieces arrive").  The column ids have
+// not been validated at that point — the builders clamp what they index with them, and a hand-off that fails validation at
+// the end throws the plans away.  Called with e->rowptr / w / nw holding the new graph's arrays (stream-ordered).
+static int handoff_early(gnnvc_engine *e, uint32_t n, uint64_t nnz) {
+    if (e->early_open || e->early_declined) return GNNVC_OK;
+    e->early_declined = true;
+    if (!e->opt_handoff || e->multi || e->stages.empty() || n == 0 || !e->aux_stream) return GNNVC_OK;
+    if (e->opt_handoff < 2 && nnz < e->opt_handoff_min_nnz) return GNNVC_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    e->have_graph = false;
+    e->empty_slice = false;
+    e->g = GraphDev{n, nnz, e->rowptr.p, e->col.p, e->w.p, e->nw.p};
+    reset_graph_state(e);
+    int rc = find_long(e);
     if (rc) return rc;
+    const bool skewed = e->sorted_wanted || e->n_long > 0;
+    if (!skewed) {
+        rc = lt_begin(e);
+        if (rc) return rc;
+        rc = c4_begin(e, 0, 0xFFFFFFFFu, true);
+        if (rc) return rc;
+        // (only the flat builders work piece by piece; anything else waits for the commit)
+        if (e->lt_pb.open && !gnnvc::lds_table_is_flat(e->lt_pb.slice_rows, e->lt_pb.pm)) e->lt_pb.open = false, e->lt_tried = false;
+        if (e->c4_pb.open && !gnnvc::lds_table_is_flat(e->c4_pb.slice_rows, e->c4_pb.pm)) e->c4_pb.open = false, e->c4_tried = false;
+    }
+    if (!e->ev_piece) HIP_TRY(e, hipEventCreateWithFlags(&e->ev_piece, hipEventDisableTiming));
+    e->early_open = true;
+    e->early_declined = false;
+    e->early_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return GNNVC_OK;
+}
+
+// the first `sent` column entries are on their way (queued on e->stream): regroup the slices they complete, on the second stream
+extern "C++" {
+template <class RP>
+static int handoff_progress(gnnvc_engine *e, const RP *rp, uint32_t n, uint64_t sent) {
+    if (!e->early_open || (!e->lt_pb.open && !e->c4_pb.open)) return GNNVC_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint32_t lt_to = e->lt_pb.open ? slices_arrived(e->lt_pb, rp, n, sent) : 0u;
+    const uint32_t c4_to = e->c4_pb.open ? slices_arrived(e->c4_pb, rp, n, sent) : 0u;
+    if ((e->lt_pb.open && lt_to > e->lt_pb.done) || (e->c4_pb.open && c4_to > e->c4_pb.done)) {
+        HIP_TRY(e, hipEventRecord(e->ev_piece, e->stream));
+        HIP_TRY(e, hipStreamWaitEvent(e->aux_stream, e->ev_piece, 0));
+        int rc = lt_advance(e, lt_to, e->aux_stream);
+        if (rc == GNNVC_OK) rc = c4_advance(e, c4_to, e->aux_stream);
+        if (rc) return rc;
+    }
+    e->early_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return GNNVC_OK;
+}
+}   // extern "C++"
+
+static int adopt_uploaded(gnnvc_engine *e, uint32_t n, uint64_t nnz) {
+    if (e->early_open) {   // whatever the second stream still regroups has to be done before the plans are finished on this one
+        HIP_TRY(e, hipEventRecord(e->ev_piece, e->aux_stream));
+        HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_piece, 0));
+    }
+    {
+        const GraphDev cand{n, nnz, e->rowptr.p, e->col.p, e->w.p, e->nw.p};
+        HIP_TRY(e, gnnvc::validate_graph(cand, e->blk_flag.p, e->stream));
+        uint32_t bad = 0;
+        HIP_TRY(e, hipMemcpyAsync(&bad, e->blk_flag.p, sizeof bad, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        if (bad) {
+            e->have_graph = false;
+            if (e->early_open) {   // plans begun from this graph's arrays: worthless
+                e->early_open = false;
+                reset_graph_state(e);
+            }
+            return fail(e, GNNVC_ERR_INVALID, "%s", (bad & 1u) ? "a column id is not a vertex of this graph (col[i] >= n)"
+                                                                 : "row pointers are not monotone from 0 to nnz");
+        }
+    }
+    const bool early = e->early_open;   // the graph was classed and its plans begun while the column array was arriving
+    e->early_open = false;
+    e->g = GraphDev{n, nnz, e->rowptr.p, e->col.p, e->w.p, e->nw.p};
+    e->have_graph = true;
+    e->empty_slice = false;
+    e->der_open = false;   // (a derivation begun against the previous graph must not be committed against this one)
+    int rc = reserve_features(e, n);
+    if (rc) return rc;
+    if (!early) {
+        reset_graph_state(e);
+        rc = find_long(e);
+        if (rc) return rc;
+    }
     return prepare_plans(e);   // ... which is why what depends on the graph alone is built here, not in a later forward
 }
 
@@ -2099,7 +2302,21 @@ int gnnvc_upload_graph(gnnvc_engine *e, uint32_t n, const uint64_t *rowptr, cons
     } else {
         HIP_TRY(e, hipMemsetAsync(e->rowptr.p, 0, sizeof(uint32_t), e->stream));
     }
-    if (nnz) HIP_TRY(e, hipMemcpyAsync(e->col.p, col, nnz * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    e->early_open = e->early_declined = false;
+    rc = handoff_early(e, n, nnz);   // (large graphs: classed now, plans begun — see handoff_early)
+    if (rc) return rc;
+    if (e->early_open && (e->lt_pb.open || e->c4_pb.open)) {
+        // the column array in pieces: while piece k + 1 crosses the bus the second stream regroups the slices piece k completed
+        const uint64_t piece = 16ull << 20;
+        for (uint64_t at = 0; at < nnz; at += piece) {
+            const uint64_t cnt = std::min(piece, nnz - at);
+            HIP_TRY(e, hipMemcpyAsync(e->col.p + at, col + at, cnt * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+            rc = handoff_progress(e, rowptr, n, at + cnt);
+            if (rc) return rc;
+        }
+    } else if (nnz) {
+        HIP_TRY(e, hipMemcpyAsync(e->col.p, col, nnz * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    }
     HIP_TRY(e, hipMemsetAsync(e->col.p + nnz, 0, GNNVC_COL_PAD * sizeof(uint32_t), e->stream));
     return adopt_uploaded(e, n, nnz);
 }
@@ -2125,7 +2342,10 @@ int gnnvc_graph_staging(gnnvc_engine *e, uint32_t n, uint64_t nnz, uint32_t **ro
     HIP_TRY(e, e->pin_col.reserve(nnz));
     e->staged_n = n;
     e->staged_nnz = nnz;
-    if (!e->staging) e->staged_sent = 0;
+    if (!e->staging) {
+        e->staged_sent = 0;
+        e->early_open = e->early_declined = false;
+    }
     e->staging = true;
     if (rowptr) *rowptr = e->pin_rowptr.p;
     if (col) *col = e->pin_col.p;
@@ -2155,7 +2375,21 @@ int gnnvc_staged_columns_ready(gnnvc_engine *e, uint64_t first, uint64_t count) 
     HIP_TRY(e, hipMemcpyAsync(e->col.p + first, e->pin_col.p + first, count * sizeof(uint32_t), hipMemcpyHostToDevice,
                               e->stream));
     e->staged_sent = first + count;
-    return GNNVC_OK;
+    // Large graphs: the row pointers and weights are final by now (step 1 of the protocol) — they go out, the graph is classed
+    // and its plans begun, and from here on every announced piece lets the second stream regroup the slices it completes.
+    if (!e->early_open && !e->early_declined && e->opt_handoff && e->staged_n &&
+        (e->opt_handoff >= 2 || e->staged_nnz >= e->opt_handoff_min_nnz) && e->pin_rowptr.p[e->staged_n] == e->staged_nnz) {
+        const uint32_t n = e->staged_n;
+        HIP_TRY(e, e->rowptr.reserve((size_t)n + 1));
+        HIP_TRY(e, e->w.reserve(n));
+        HIP_TRY(e, e->nw.reserve(n));
+        HIP_TRY(e, hipMemcpyAsync(e->rowptr.p, e->pin_rowptr.p, ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(e->w.p, e->pin_w.p, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(e->nw.p, e->pin_nw.p, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        rc = handoff_early(e, n, e->staged_nnz);
+        if (rc) return rc;
+    }
+    return handoff_progress(e, e->pin_rowptr.p, e->staged_n, e->staged_sent);
 }
 
 int gnnvc_commit_staged_graph(gnnvc_engine *e) {
@@ -2181,11 +2415,11 @@ int gnnvc_commit_staged_graph(gnnvc_engine *e) {
     HIP_TRY(e, e->w.reserve(n));
     HIP_TRY(e, e->nw.reserve(n));
     HIP_TRY(e, e->blk_flag.reserve(1));
-    if (n) {
+    if (n && !e->early_open) {   // (an early hand-off sent them with its first piece)
         HIP_TRY(e, hipMemcpyAsync(e->rowptr.p, e->pin_rowptr.p, ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
         HIP_TRY(e, hipMemcpyAsync(e->w.p, e->pin_w.p, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
         HIP_TRY(e, hipMemcpyAsync(e->nw.p, e->pin_nw.p, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
-    } else {
+    } else if (!n) {
         HIP_TRY(e, hipMemsetAsync(e->rowptr.p, 0, sizeof(uint32_t), e->stream));
     }
     if (nnz > e->staged_sent)
@@ -2283,6 +2517,7 @@ int gnnvc_derive_graph_commit(gnnvc_engine *e, const uint32_t *tail_cols, uint64
     NOT_ON_MULTI(e, "gnnvc_derive_graph_commit");
     if (!e->der_open) return fail(e, GNNVC_ERR_STATE, "gnnvc_derive_graph_begin first");
     e->der_open = false;
+    e->early_open = e->early_declined = false;   // (an abandoned staged hand-off must not pass for this graph's)
     if (!e->have_graph || e->g.rowptr != e->rowptr.p || e->g.col != e->col.p || e->g.sliced() || e->empty_slice)
         return fail(e, GNNVC_ERR_STATE, "the resident graph changed since gnnvc_derive_graph_begin");
     const uint32_t n = e->der_n_new;

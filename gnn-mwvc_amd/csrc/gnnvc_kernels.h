@@ -202,9 +202,13 @@ hipError_t lds_table_wsteps(const GraphDev &g, uint32_t slice_rows, uint32_t nch
                             const uint32_t *step_ptr, uint32_t *step_count, uint32_t *recs, bool write, uint32_t slack,
                             hipStream_t stream, const PlanMap &pm = PlanMap(), uint32_t row_base = 0, uint32_t row_end = 0xFFFFFFFFu);
 hipError_t lds_table_bytes(const uint32_t *w, uint32_t n, uint8_t *wb, uint32_t *bad, hipStream_t stream);
+// (chunk0 / chunk1: only chunks [chunk0, chunk1) of the plan — the flat builders, lds_table_is_flat(), work piece by piece, so a
+// hand-off can regroup the rows whose column entries have arrived while the rest is still on its way; the steps come last)
+bool lds_table_is_flat(uint32_t rows_per_chunk, const PlanMap &pm = PlanMap());
 hipError_t lds_table_count(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t block_cols,
                            uint32_t *seg_cnt, uint32_t *bad, hipStream_t stream, uint32_t row_base = 0,
-                           uint32_t row_end = 0xFFFFFFFFu, const PlanMap &pm = PlanMap());
+                           uint32_t row_end = 0xFFFFFFFFu, const PlanMap &pm = PlanMap(), uint32_t chunk0 = 0,
+                           uint32_t chunk1 = 0xFFFFFFFFu);
 hipError_t lds_table_steps(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, const uint32_t *seg_cnt,
                            const uint32_t *step_ptr, uint32_t *step_count, void *steps, bool write, hipStream_t stream,
                            uint32_t row_base = 0, uint32_t row_end = 0xFFFFFFFFu, uint32_t cap = 0 /* entries per step, 0 = 2048 */,
@@ -214,7 +218,8 @@ hipError_t lds_table_steps(const GraphDev &g, uint32_t rows_per_chunk, uint32_t 
 hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t block_cols,
                              const uint32_t *seg_cnt, uint32_t *entries, hipStream_t stream, uint32_t shift,
                              uint32_t row_base, uint32_t row_end, uint32_t slack, const PlanMap &pm,
-                             uint32_t *bad);   // *bad |= 2 if a row's blocks do not ascend (the flat walk checks here, not in the count pass)
+                             uint32_t *bad /* |= 2 if a row's blocks do not ascend (the flat walk checks here, not in the count pass) */,
+                             uint32_t chunk0 = 0, uint32_t chunk1 = 0xFFFFFFFFu);
 // Pruned adjacency (k_prune_*).  observe = largest degree among the vertices with a non-zero row of feat (16 columns).
 // The set of vertices whose rows are taken to be all zero, as a bitmap: mark_degree (degree >= bound) or mark_zero (the rows
 // that ARE all zero in feat).  count = per chunk of 64 entries which are kept (mask) and, scanned in place, how many before

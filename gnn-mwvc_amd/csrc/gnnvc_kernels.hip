@@ -1797,10 +1797,13 @@ __global__ __launch_bounds__(1024) void k_lt_scatter(GraphDev g, uint32_t rows_p
 // walks an equal share of it, 64 entries a trip, coalesced.  Whether a row's blocks ascend is checked by the scatter pass,
 // which knows the rows.  Dynamic LDS: nblocks counters.
 __global__ __launch_bounds__(256) void k_lt_count_flat(GraphDev g, uint32_t rows_per_chunk, uint32_t nblocks, uint32_t block_cols,
-                                                       uint32_t *__restrict__ seg_cnt, uint32_t row_base, uint32_t row_end) {
+                                                       uint32_t *__restrict__ seg_cnt, uint32_t row_base, uint32_t row_end, uint32_t chunk0) {
+    // chunk0: the launch covers chunks chunk0 .. (a hand-off builds the plan piece by piece, as the column array arrives).  A
+    // column id may not have been checked yet when this runs (the hand-off validates at the end): its block is clamped, so a
+    // malformed graph costs a wrong plan that is then thrown away, never an access outside the counters.
     extern __shared__ uint32_t lt_dyn[];
     uint32_t *hist = lt_dyn;
-    const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t c = chunk0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nthreads = blockDim.x, nwaves = nthreads >> 6;   // (a multiple of 64)
     const uint32_t r0 = min(row_end, row_base + c * rows_per_chunk), r1 = min(row_end, r0 + rows_per_chunk);
     for (uint32_t i = tid; i < nblocks; i += nthreads) hist[i] = 0;
@@ -1820,7 +1823,7 @@ __global__ __launch_bounds__(256) void k_lt_count_flat(GraphDev g, uint32_t rows
             const uint32_t e0 = eg + 64 * j, e = e0 + lane;
             if (e0 >= ee) break;                       // (uniform)
             const bool in = e < ee;
-            const uint32_t b = in ? lt_div(colv[j], block_cols, magic) : 0xFFFFFFFFu;
+            const uint32_t b = in ? min(lt_div(colv[j], block_cols, magic), nblocks - 1u) : 0xFFFFFFFFu;
             const uint32_t bp = lane_prev(b);
             const bool head = in && (lane == 0 || b != bp);   // one LDS add per run of equal blocks (a trip's first entry starts one)
             const unsigned long long hm = __ballot(head);
@@ -1843,12 +1846,12 @@ __global__ __launch_bounds__(256) void k_lt_count_flat(GraphDev g, uint32_t rows
 __global__ __launch_bounds__(1024) void k_lt_scatter_flat(GraphDev g, uint32_t rows_per_chunk, uint32_t nblocks, uint32_t block_cols,
                                                           uint32_t shift, const uint32_t *__restrict__ seg_cnt,
                                                           uint32_t *__restrict__ entries, uint32_t row_base, uint32_t row_end,
-                                                          uint32_t slack, uint32_t *bad, uint32_t stage_cap) {
+                                                          uint32_t slack, uint32_t *bad, uint32_t stage_cap, uint32_t chunk0) {
     extern __shared__ uint32_t lt_dyn[];
     __shared__ uint32_t wave_sum[16];
     __shared__ uint32_t range_end;
     uint32_t *cursor = lt_dyn, *rp = lt_dyn + nblocks, *row_flag = rp + rows_per_chunk + 1, *stage = row_flag + blockDim.x;
-    const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t c = chunk0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nthreads = blockDim.x, nwaves = nthreads >> 6;   // (a multiple of 64)
     const uint32_t r0 = min(row_end, row_base + c * rows_per_chunk), r1 = min(row_end, r0 + rows_per_chunk);
     const uint32_t first = lt_chunk_first(g, c, rows_per_chunk, row_base, row_end, slack, nullptr);
@@ -1904,7 +1907,7 @@ __global__ __launch_bounds__(1024) void k_lt_scatter_flat(GraphDev g, uint32_t r
             const bool in = e < ee;
             const uint32_t nin = min(64u, ee - e0);
             const uint32_t col = colv[j];
-            const uint32_t b = in ? lt_div(col, block_cols, magic) : 0u;
+            const uint32_t b = in ? min(lt_div(col, block_cols, magic), nblocks - 1u) : 0u;   // (clamped: see k_lt_count_flat)
             // Rows of the trip's entries.  `from` holds the entry before the trip (or is the share's first row); without
             // empty rows the rows that start inside the trip are among the next 64: lane l looks at row from + 1 + l, flags
             // the trip position where it starts, and an entry's row = from + the flags up to its position.  An empty row
@@ -1951,7 +1954,7 @@ __global__ __launch_bounds__(1024) void k_lt_scatter_flat(GraphDev g, uint32_t r
             for (uint32_t f0 = e0 + 64; f0 < row_end_e; f0 += 64) {
                 const uint32_t f = f0 + lane;
                 const bool in2 = f < row_end_e;
-                const bool same = in2 && lt_div(g.col[in2 ? f : row_end_e - 1], block_cols, magic) == bo;
+                const bool same = in2 && min(lt_div(g.col[in2 ? f : row_end_e - 1], block_cols, magic), nblocks - 1u) == bo;
                 const unsigned long long sm = __ballot(same);
                 const uint32_t lead = ~sm ? (uint32_t)__builtin_ctzll(~sm) : 64u;   // (blocks ascend: the same-block lanes are a prefix)
                 extra += lead;
@@ -3744,16 +3747,21 @@ hipError_t lds_table_bytes(const uint32_t *w, uint32_t n, uint8_t *wb, uint32_t 
     return hipGetLastError();
 }
 
+bool lds_table_is_flat(uint32_t rows_per_chunk, const PlanMap &pm) { return lt_flat_plan(rows_per_chunk, pm); }
+
 hipError_t lds_table_count(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t block_cols,
                            uint32_t *seg_cnt, uint32_t *bad, hipStream_t stream, uint32_t row_base, uint32_t row_end,
-                           const PlanMap &pm) {
+                           const PlanMap &pm, uint32_t chunk0, uint32_t chunk1) {
     if (row_end > g.n) row_end = g.n;
     if (nblocks > 4096 || block_cols > (1u << 18) || rows_per_chunk > (1u << 15)) return hipErrorInvalidValue;
+    if (chunk1 > nchunks) chunk1 = nchunks;
+    if (chunk0 >= chunk1) return hipSuccess;
     if (lt_flat_plan(rows_per_chunk, pm)) {
-        GNNVC_LAUNCH(k_lt_count_flat, dim3(nchunks), dim3(lt_flat_threads()), nblocks * sizeof(uint32_t), stream, g, rows_per_chunk,
-                     nblocks, block_cols, seg_cnt, row_base, row_end);
+        GNNVC_LAUNCH(k_lt_count_flat, dim3(chunk1 - chunk0), dim3(lt_flat_threads()), nblocks * sizeof(uint32_t), stream, g, rows_per_chunk,
+                     nblocks, block_cols, seg_cnt, row_base, row_end, chunk0);
         return hipGetLastError();
     }
+    if (chunk0 != 0 || chunk1 != nchunks) return hipErrorInvalidValue;   // (only the flat builders work piece by piece)
     GNNVC_LAUNCH(k_lt_count, dim3(nchunks), dim3(1024), 0, stream, g, rows_per_chunk, nblocks, block_cols, seg_cnt, bad,
                        row_base, row_end, pm);
     return hipGetLastError();
@@ -3774,10 +3782,14 @@ hipError_t lds_table_steps(const GraphDev &g, uint32_t rows_per_chunk, uint32_t 
 
 hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_t nchunks, uint32_t nblocks, uint32_t block_cols,
                              const uint32_t *seg_cnt, uint32_t *entries, hipStream_t stream, uint32_t shift,
-                             uint32_t row_base, uint32_t row_end, uint32_t slack, const PlanMap &pm, uint32_t *bad) {
+                             uint32_t row_base, uint32_t row_end, uint32_t slack, const PlanMap &pm, uint32_t *bad, uint32_t chunk0,
+                             uint32_t chunk1) {
     if (block_cols > (1u << shift) || ((uint64_t)rows_per_chunk << shift) > (1ull << 32)) return hipErrorInvalidValue;
     if (slack && slack < 3u * nblocks + 4u) return hipErrorInvalidValue;
     if (row_end > g.n) row_end = g.n;
+    if (chunk1 > nchunks) chunk1 = nchunks;
+    if (chunk0 >= chunk1) return hipSuccess;
+    if (!lt_flat_plan(rows_per_chunk, pm) && (chunk0 != 0 || chunk1 != nchunks)) return hipErrorInvalidValue;
     if (lt_flat_plan(rows_per_chunk, pm)) {
         // staging area for a chunk's regrouped range: its mean length and a margin (entries + pad slots) within the 160 KiB of a
         // CU's LDS; the workgroup as large as it can be, since the area bounds how many of them a CU holds
@@ -3790,8 +3802,8 @@ hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_
         const size_t fixed = ((size_t)nblocks + rows_per_chunk + 1 + threads) * sizeof(uint32_t);   // cursors, offsets, 64 flags a wave
         uint64_t stage = (mean + mean / 8 + 3ull * nblocks + 64 + 255) / 256 * 256;
         if (fixed + stage * sizeof(uint32_t) > kLdsMax) stage = (kLdsMax - fixed) / sizeof(uint32_t);
-        GNNVC_LAUNCH(k_lt_scatter_flat, dim3(nchunks), dim3(threads), fixed + stage * sizeof(uint32_t), stream, g, rows_per_chunk,
-                     nblocks, block_cols, shift, seg_cnt, entries, row_base, row_end, slack, bad, (uint32_t)stage);
+        GNNVC_LAUNCH(k_lt_scatter_flat, dim3(chunk1 - chunk0), dim3(threads), fixed + stage * sizeof(uint32_t), stream, g, rows_per_chunk,
+                     nblocks, block_cols, shift, seg_cnt, entries, row_base, row_end, slack, bad, (uint32_t)stage, chunk0);
         return hipGetLastError();
     }
     GNNVC_LAUNCH(k_lt_scatter, dim3(nchunks), dim3(1024), 0, stream, g, rows_per_chunk, nblocks, block_cols, shift, seg_cnt,
