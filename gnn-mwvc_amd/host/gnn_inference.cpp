@@ -410,6 +410,18 @@ gnnvc_engine *engine_for(const void *key, const std::string &name, const std::ve
         check(gnnvc_create(&b.eng, text.data(), text.size(), gnnvc_host::device_ordinal()), "gnnvc_create(model)");
     else
         check(gnnvc_create_multi(&b.eng, text.data(), text.size(), devs.data(), (int)devs.size()), "gnnvc_create_multi(model)");
+    // GNNVC_OPTIONS="key=value,key=value": engine options (include/gnnvc.h) for a driver that cannot call gnnvc_set_option itself
+    if (const char *opts = std::getenv("GNNVC_OPTIONS")) {
+        std::string all(opts);
+        for (size_t at = 0; at < all.size();) {
+            const size_t end = std::min(all.find(',', at), all.size());
+            const std::string kv = all.substr(at, end - at);
+            const size_t eq = kv.find('=');
+            if (eq != std::string::npos && eq > 0)
+                check(gnnvc_set_option(b.eng, kv.substr(0, eq).c_str(), std::atol(kv.c_str() + eq + 1)), "gnnvc_set_option(GNNVC_OPTIONS)", b.eng);
+            at = end + 1;
+        }
+    }
     b.text = std::move(text);
     return b.eng;
 }

@@ -168,3 +168,21 @@ def test_cli_on_a_multi_device_handle(manifest, tmp_path, devices):
     assert fields[0] == "er100k" and int(fields[1]) == spec["cli"]["final_cost"]
     assert hashlib.md5((tmp_path / "er100k.out").read_bytes()).hexdigest() == spec["cli"]["result_md5"]
     assert r.stderr.count("gnnvc predict") >= 5, r.stderr[-2000:]
+
+
+def test_cli_with_plans_built_under_the_hand_off(manifest, tmp_path):
+    """GNNVC_OPTIONS: the engine option "handoff_min_entries" lowered so that EVERY predict call of the ER-1M run (20 M entries
+    down to a few hundred) classes its graph and regroups the compact-table plan on the second stream while the wrapper's pack
+    pool is still announcing pieces of the column array (handoff_early / handoff_progress) — and the first forward of every
+    graph runs on that plan.  Same result file, byte for byte."""
+    import os
+    spec = manifest["er1m"]
+    g = _graph(spec)
+    (tmp_path / "er1m.graph").write_text(gg.metis_text(g))
+    env = dict(os.environ, GNNVC_OPTIONS="handoff_min_entries=1,blocked_min_n=0", GNNVC_TRACE="1")
+    r = subprocess.run([str(CLI), str(tmp_path / "er1m.graph"), str(tmp_path / "er1m.out"), "0", "-1", "0"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    fields = r.stdout.strip().split(",")
+    assert fields[0] == "er1m" and int(fields[1]) == spec["cli"]["final_cost"]
+    assert hashlib.md5((tmp_path / "er1m.out").read_bytes()).hexdigest() == spec["cli"]["result_md5"]
