@@ -155,6 +155,38 @@ def test_first_forward_of_a_fresh_graph_runs_with_the_plans(big):
         e2.close()
 
 
+def test_eight_parts_behind_one_handle_equal_the_single_engine(big):
+    """BASELINE.json configs[3] — R-MAT scale 24 vertex-partitioned over 8 GPUs with a row exchange between the stages — as far
+    as ONE GPU can rehearse it: the whole graph handed to a gnnvc_create_multi handle of eight parts (all on device 0), each part
+    holding only its rows' CSR slice (cut at equal entry counts), stage by stage with the rows copied part to part in between
+    (the same hipMemcpyPeerAsync calls that cross xGMI on an 8-GPU node).  Every logit equals the single engine's.  Also run
+    on the metric graph (the configuration the scaling metric is quoted on)."""
+    import torch
+    import gnn_mwvc_amd as G
+    if big["name"] not in ("rmat24", "er10m"):
+        pytest.skip("the partitioned configurations of BASELINE.json: rmat24 (configs[3]) and the metric graph")
+    g, dev = big["g"], big["dev"]
+    hg = g.to_host()
+    lg = torch.zeros(g.n, device=dev)
+    sc = torch.zeros(g.n, device=dev)
+    torch.cuda.synchronize()
+    e = G.Engine(G.default_model_text(), devices=[0] * 8)
+    try:
+        e.set_weight_scale(g.ws)
+        e.upload_graph(hg)
+        rows = [e.get_info(f"part_rows_{r}") for r in range(8)]
+        entries = [e.get_info(f"part_entries_{r}") for r in range(8)]
+        assert sum(rows) == g.n and sum(entries) == g.nnz
+        assert max(entries) < 1.25 * g.nnz / 8 + 64 * 300_000      # equal entry counts up to one 64-row tile of the heaviest rows
+        for rep in range(2):
+            e.forward_device(big["x"].data_ptr(), sc.data_ptr(), lg.data_ptr())
+            assert torch.equal(lg.view(torch.int32), big["lg"].view(torch.int32)), rep
+            assert torch.equal(sc.view(torch.int32), big["sc"].view(torch.int32)), rep
+    finally:
+        e.close()
+        del hg
+
+
 def test_scores_are_sigmoid_of_logits(big):
     lg = big["lg"].cpu().numpy()
     sc = big["sc"].cpu().numpy()
