@@ -92,7 +92,8 @@ def stage_bytes(stage: int, n: int, nnz: int) -> int:
 def source_hash() -> str:
     """Identity of the kernels a PMC summary was taken from."""
     h = hashlib.sha256()
-    for rel in ("gnn-mwvc_amd/csrc/gnnvc_kernels.hip", "gnn-mwvc_amd/csrc/gnnvc_engine.cpp", "gnn-mwvc_amd/csrc/exact_sum.h"):
+    for rel in ("gnn-mwvc_amd/csrc/gnnvc_kernels.hip", "gnn-mwvc_amd/csrc/gnnvc_engine.cpp", "gnn-mwvc_amd/csrc/gnnvc_plans.cpp",
+                "gnn-mwvc_amd/csrc/gnnvc_engine_state.h", "gnn-mwvc_amd/csrc/exact_sum.h"):
         h.update((ROOT / rel).read_bytes())
     return h.hexdigest()[:16]
 
@@ -842,6 +843,7 @@ def side_workload(name, args, dev, make_engine, ggt):
            "roofline_frac": fwd_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "forward_bytes": fwd_bytes,
            "plan": {"lds_table": bool(e.get_info("lds_table_active")), "compact_gather": bool(e.get_info("compact_gather_active")),
                     "pruned_stage1": bool(e.get_info("pruned_stage1")), "pruned_stage2": bool(e.get_info("pruned_stage2")),
+                    "pruned_stage2_from_stage1_entries": bool(e.get_info("pruned_from_previous_stage2")),
                     "sorted_tiles": bool(e.get_info("sorted_tiles_active")), "long_rows": e.get_info("long_rows"),
                     "giant_rows": e.get_info("giant_rows")}}
     # a fresh engine's first-forward logits too (what a score-once caller reads)

@@ -231,7 +231,9 @@ hipError_t prune_mark_degree(const GraphDev &g, uint32_t bound, uint32_t *heavy_
 hipError_t prune_mark_zero(const GraphDev &g, const float *feat, uint32_t *heavy_bits, hipStream_t stream);
 // mass[0] = sum of the degrees of the set's vertices (whole graphs: the entries that point to them, if the adjacency is symmetric;
 // 0 on a slice), mass[1] = vertices in the set
-hipError_t prune_mass(const GraphDev &g, const uint32_t *heavy_bits, unsigned long long *mass, hipStream_t stream);
+// (prev_bits: another set — mass[2] = its vertices outside this one; mass has room for 3 words)
+hipError_t prune_mass(const GraphDev &g, const uint32_t *heavy_bits, unsigned long long *mass, hipStream_t stream,
+                      const uint32_t *prev_bits = nullptr);
 hipError_t prune_count(const GraphDev &g, const uint32_t *heavy_bits, unsigned long long *mask, uint32_t *off, uint32_t *scratch,
                        hipStream_t stream);
 hipError_t prune_fill(const GraphDev &g, const unsigned long long *mask, const uint32_t *off, uint32_t *pcol, uint32_t *prp,

@@ -2677,30 +2677,39 @@ __global__ __launch_bounds__(256) void k_prune_mark_zero(const float4 *__restric
 
 // mass[0] += the degrees of the set's vertices (on a symmetric adjacency: the entries that point to them; whole graphs only —
 // a slice does not hold the other rows' degrees), mass[1] += the number of vertices in the set
-__global__ __launch_bounds__(256) void k_prune_mass(GraphDev g, const uint32_t *__restrict__ heavy_bits, unsigned long long *__restrict__ mass) {
+__global__ __launch_bounds__(256) void k_prune_mass(GraphDev g, const uint32_t *__restrict__ heavy_bits, unsigned long long *__restrict__ mass,
+                                                    const uint32_t *__restrict__ prev_bits) {
+    // prev_bits (may be null): another stage's set — mass[2] += its vertices that are NOT in this one (0 = this set contains it)
     unsigned long long mine = 0;
-    uint32_t members = 0;
+    uint32_t members = 0, outside = 0;
     const bool degrees = !g.sliced_dev();
-    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < g.n; u += gridDim.x * blockDim.x)
-        if (heavy_bits[u >> 5] >> (u & 31) & 1u) {
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < g.n; u += gridDim.x * blockDim.x) {
+        const bool in = heavy_bits[u >> 5] >> (u & 31) & 1u;
+        if (in) {
             if (degrees) mine += g.rowptr[u + 1] - g.rowptr[u];
             ++members;
+        } else if (prev_bits && (prev_bits[u >> 5] >> (u & 31) & 1u)) {
+            ++outside;
         }
+    }
 #pragma unroll
     for (int off = 32; off; off >>= 1) {
         mine += ((unsigned long long)__shfl_xor((unsigned)(mine >> 32), off) << 32) | __shfl_xor((unsigned)mine, off);
         members += __shfl_xor(members, off);
+        outside += __shfl_xor(outside, off);
     }
-    __shared__ unsigned long long part[4][2];
+    __shared__ unsigned long long part[4][3];
     if ((threadIdx.x & 63) == 0) {
         part[threadIdx.x >> 6][0] = mine;
         part[threadIdx.x >> 6][1] = members;
+        part[threadIdx.x >> 6][2] = outside;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {   // (one pair of atomics per block: per wave they queue up behind each other)
-        const unsigned long long m0 = part[0][0] + part[1][0] + part[2][0] + part[3][0], m1 = part[0][1] + part[1][1] + part[2][1] + part[3][1];
-        if (m0) atomicAdd(mass, m0);
-        if (m1) atomicAdd(mass + 1, m1);
+    if (threadIdx.x == 0) {   // (one set of atomics per block: per wave they queue up behind each other)
+        unsigned long long m[3];
+        for (int k = 0; k < 3; ++k) m[k] = part[0][k] + part[1][k] + part[2][k] + part[3][k];
+        for (int k = 0; k < 3; ++k)
+            if (m[k]) atomicAdd(mass + k, m[k]);
     }
 }
 
@@ -3833,10 +3842,10 @@ hipError_t prune_mark_zero(const GraphDev &g, const float *feat, uint32_t *heavy
 
 // mask: one 64-bit word per chunk of 64 entries, off: chunks + 1 words (scanned in place: off[chunks] = kept entries;
 // scratch as for blocked_scan_scratch_elems(chunks + 1))
-hipError_t prune_mass(const GraphDev &g, const uint32_t *heavy_bits, unsigned long long *mass, hipStream_t stream) {
-    hipError_t rc = hipMemsetAsync(mass, 0, 2 * sizeof(unsigned long long), stream);
+hipError_t prune_mass(const GraphDev &g, const uint32_t *heavy_bits, unsigned long long *mass, hipStream_t stream, const uint32_t *prev_bits) {
+    hipError_t rc = hipMemsetAsync(mass, 0, 3 * sizeof(unsigned long long), stream);
     if (rc != hipSuccess || g.n == 0) return rc;
-    GNNVC_LAUNCH(k_prune_mass, dim3(std::min<unsigned>((g.n + 255) / 256, 2048u)), dim3(256), 0, stream, g, heavy_bits, mass);
+    GNNVC_LAUNCH(k_prune_mass, dim3(std::min<unsigned>((g.n + 255) / 256, 2048u)), dim3(256), 0, stream, g, heavy_bits, mass, prev_bits);
     return hipGetLastError();
 }
 
