@@ -2281,9 +2281,25 @@ __global__ __launch_bounds__(64) void k_c4_choose(const unsigned long long *__re
     if (slots == 1) {
         mine = lane < 16 ? counts[lane] : (lane == 16 ? (unsigned long long)n : 0ull);
     } else {
-        // slot sl's 17 counters sit at counts[sl * kEmitStride ..]: lane i adds counter i of every slot
-        if (lane < 17)
-            for (int sl = 0; sl < slots; ++sl) mine += counts[sl * kEmitStride + lane];
+        // slot sl's 17 counters sit at counts[sl * kEmitStride ..]: the 64 lanes read 64 counters a trip (coalesced, all trips
+        // in flight at once — a lane walking its counter through the slots one dependent load after the other took 22 us), and
+        // counter i's total is gathered from the lanes that hold its pieces
+        unsigned long long part[kEmitStride];
+#pragma unroll
+        for (int t = 0; t < kEmitStride; ++t) {
+            const int idx = t * 64 + lane;                 // counts[idx] = counter idx % 17 of slot idx / 17
+            part[t] = idx < slots * kEmitStride ? counts[idx] : 0ull;
+        }
+        // lane L holds pieces of counters (t * 64 + L) % 17, t = 0..16; sum per counter over all lanes and trips
+        for (int c = 0; c < kEmitStride; ++c) {
+            unsigned long long v = 0;
+#pragma unroll
+            for (int t = 0; t < kEmitStride; ++t) v += ((t * 64 + lane) % kEmitStride == c) ? part[t] : 0ull;
+#pragma unroll
+            for (int off = 32; off; off >>= 1)
+                v += ((unsigned long long)__shfl_xor((unsigned)(v >> 32), off) << 32) | __shfl_xor((unsigned)v, off);
+            if (lane == c) mine = v;
+        }
     }
     const unsigned long long rows = ((unsigned long long)__shfl((unsigned)(mine >> 32), 16) << 32) | __shfl((unsigned)mine, 16);
     const bool prev_ok = desc[0] == 1u;

@@ -54,16 +54,18 @@ for p in newest.values():
             cur = agg[k].get(r["Counter_Name"])
             if cur is None or did >= cur[0]:
                 agg[k][r["Counter_Name"]] = (did, float(r["Counter_Value"]))
-# One steady-state FORWARD: the engine zero-fills the two pad rows (k_zero_row x 2) at the start of every forward, so the
-# dispatches from the last such pair to the end of the run are exactly the last forward of the probe (kernels run one
-# after the other under --pmc, side-stream kernels included).
+# One steady-state FORWARD: a forward of the metric graph starts with k_lt_bytes_x (the F = 1 stage's byte table, made from that
+# forward's x; graphs without that plan: with the stage-0 tile kernel k_stage_f1), so the dispatches from the last such launch to
+# the end of the run are exactly the last forward of the probe (kernels run one after the other under --pmc, side-stream
+# kernels included).
 forward = collections.defaultdict(float)
 for p in newest.values():
     rows = [r for r in csv.DictReader(open(p)) if "gnnvc" in r["Kernel_Name"]]
-    zero_ids = sorted({int(r["Dispatch_Id"]) for r in rows if "k_zero_row" in r["Kernel_Name"]})
-    if len(zero_ids) < 2:
+    first_ids = sorted({int(r["Dispatch_Id"]) for r in rows if "k_lt_bytes_x" in r["Kernel_Name"]}) or \
+        sorted({int(r["Dispatch_Id"]) for r in rows if "k_stage_f1<" in r["Kernel_Name"]})
+    if not first_ids:
         continue
-    start = zero_ids[-2]
+    start = first_ids[-1]
     for r in rows:
         if int(r["Dispatch_Id"]) >= start:
             forward[r["Counter_Name"]] += float(r["Counter_Value"])
