@@ -115,7 +115,9 @@ def kernel_algorithmic_bytes(name: str, n: int, nnz: int, calls_per_forward: flo
         return nnz * 8
     if name.startswith("k_stage_f1<"):            # own values and scalars in, one 64-byte row out (+ the gather when no plan has it)
         return n * 80
-    if name.startswith("k_stage_f16<32,32,16") and name.endswith(",true>"):    # aggregate-only: own row, scalars, output row
+    targs = name[name.index("<") + 1:name.rindex(">")].split(",") if "<" in name else []
+    # k_stage_f16<N1, N2, N3, SIGMOID, S, MFMA, SORTED, AGGONLY = false, FILTER = false>
+    if name.startswith("k_stage_f16<32,32,16") and len(targs) >= 8 and targs[7] == "true":   # aggregate-only: own row, scalars, output row
         return n * (76 + 64)
     if name.startswith("k_stage_f16<32,32,16"):   # gathering feature stage
         return nnz * 68 + n * (76 + 64)

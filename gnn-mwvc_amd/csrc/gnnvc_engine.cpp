@@ -276,10 +276,10 @@ int choose_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const flo
 int launch_side_rows(gnnvc_engine *e, const GraphDev &gv, int stage, uint32_t lo, uint32_t hi, const float *in, float *out,
                      float *logits, uint32_t thr) {
     const bool side = e->opt_side_streams != 0;
-    hipStream_t s_long = side ? e->aux_stream : e->stream, s_giant = side ? e->giant_stream : e->stream;
+    hipStream_t s_long = side ? e->long_stream : e->stream, s_giant = side ? e->giant_stream : e->stream;
     if (side) {
         HIP_TRY(e, hipEventRecord(e->ev_fork, e->stream));
-        HIP_TRY(e, hipStreamWaitEvent(e->aux_stream, e->ev_fork, 0));
+        HIP_TRY(e, hipStreamWaitEvent(e->long_stream, e->ev_fork, 0));
     }
     // rows from this degree on go the giant way in this stage (hub_mode 1: every long row does)
     const uint32_t giant_from = e->stages[stage].f == 16 ? e->giant_f16() : e->giant_thresh;
@@ -306,7 +306,7 @@ int launch_side_rows(gnnvc_engine *e, const GraphDev &gv, int stage, uint32_t lo
     if ((e->n_giant < e->n_long || giant_from > e->giant_thresh) && long_from < giant_from)   // (equal: a plan or the giant kernels have every row in between)
         HIP_TRY(e, gnnvc::launch_long_stage(e->stages[stage], gv, e->ws, e->params.p, in, out, logits, lo, hi,
                                             e->long_list.p, e->n_long, thr, giant_from, s_long));
-    if (side) HIP_TRY(e, hipEventRecord(e->ev_join, e->aux_stream));
+    if (side) HIP_TRY(e, hipEventRecord(e->ev_long, e->long_stream));
     return GNNVC_OK;
 }
 
@@ -432,7 +432,7 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
     const bool longs = e->n_long > 0;
     GraphDev gv;   // (the check behind a pruned adjacency is queued before the fork to the side streams)
     gnnvc::SortedOrder so_p;
-    rc = gather_view(e, stage, lo, hi, in, c.sums == StageChoice::kGather, c.sorted.n != 0, gv, so_p);
+    rc = gather_view(e, stage, lo, hi, in, c.sums == StageChoice::kGather, c.sorted.n != 0, gv, so_p, c.mfma, c.long_thresh);
     if (rc) return rc;
     if (longs) {
         rc = launch_side_rows(e, gv, stage, lo, hi, in, out, logits, c.long_thresh);
@@ -441,7 +441,7 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
     rc = launch_main(e, c, gv, so_p, stage, lo, hi, in, out, logits);
     if (rc) return rc;
     if (longs && e->opt_side_streams) {   // join
-        HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
+        HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_long, 0));
         if (e->n_giant) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_giant, 0));
     }
     return GNNVC_OK;
@@ -610,6 +610,8 @@ void gnnvc_destroy(gnnvc_engine *e) {
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->aux_stream) { (void)hipStreamSynchronize(e->aux_stream); (void)hipStreamDestroy(e->aux_stream); }
+    if (e->ev_long) (void)hipEventDestroy(e->ev_long);
+    if (e->long_stream) { (void)hipStreamSynchronize(e->long_stream); (void)hipStreamDestroy(e->long_stream); }
     if (e->giant_stream) { (void)hipStreamSynchronize(e->giant_stream); (void)hipStreamDestroy(e->giant_stream); }
     if (e->ev_giant) (void)hipEventDestroy(e->ev_giant);
     for (auto v : e->ev) (void)hipEventDestroy(v);
@@ -635,6 +637,7 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream) {
 int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     if (!e || !key) return GNNVC_ERR_INVALID;
     const std::string k(key);
+    e->short_from = 0;   // (lists a filtered stage left go by the thresholds and variants of the call that wrote them)
     if (k == "blocked_stage0") e->opt_blocked = value < 0 ? 0 : (value > 2 ? 2 : (int)value);   // 2 = also on skewed graphs
     else if (k == "block_cols") e->opt_block_cols = value > 0 ? (uint32_t)value : 0;
     else if (k == "blocked_min_n") e->opt_blocked_min_n = value > 0 ? (uint32_t)value : 0;
@@ -659,6 +662,12 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "prune_heavy_entries") { e->opt_prune_heavy_entries = value > 0 ? (uint64_t)value : 0; for (auto &pp : e->prune) pp.tried = pp.ready = false; }
     else if (k == "prune_early_entries") e->opt_prune_early_nnz = value > 0 ? (uint64_t)value : 0;
     else if (k == "prune_giant_rows") e->opt_prune_giant = value != 0 ? 1 : 0;
+    else if (k == "long_rows_priority") e->opt_long_priority = value != 0 ? 1 : 0;
+    else if (k == "filter_zero_rows") e->opt_filter = value != 0 ? 1 : 0;
+    else if (k == "filter_keep_lists") e->opt_filter_keep = value != 0 ? 1 : 0;
+    else if (k == "filter_min_entries") e->opt_filter_min_nnz = value > 0 ? (uint64_t)value : 0;
+    else if (k == "filter_min_long_percent") e->opt_filter_min_long_pct = value < 0 ? 0u : (value > 100 ? 101u : (uint32_t)value);
+    else if (k == "filter_min_percent") e->opt_filter_min_pct = value < 0 ? 0u : (value > 100 ? 101u : (uint32_t)value);
     else if (k == "prune_min_entries") e->opt_prune_min_nnz = value > 0 ? (uint64_t)value : 0;
     else if (k == "prune_min_drop_percent") e->opt_prune_min_drop = value < 0 ? 0u : (value > 100 ? 100u : (uint32_t)value);
     else if (k == "compact_skewed") { e->opt_compact_skewed = value != 0 ? 1 : 0; e->c4_tried = false; e->c4_ready = false; }
@@ -697,6 +706,20 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
     else if (k == "compact_gather_rows_per_chunk") *value = e->c4_ready ? (long)e->c4_rows : 0;
     else if (k == "compact_gather_steps") *value = e->c4_ready ? (long)e->c4_steps_total : 0;
     else if (k == "pruned_stage1" || k == "pruned_stage2") *value = e->prune[k.back() - '0'].ready ? 1 : 0;
+    else if (k == "long_entries_percent") *value = e->n_long && e->g.nnz ? (long)(e->long_entries * 100ull / e->g.nnz) : 0;
+    else if (k == "filtered_stage1" || k == "filtered_stage2") *value = e->filtered[k.back() - '0'] ? 1 : 0;
+    else if (k == "short_lists_stage1" || k == "short_lists_stage2") *value = e->short_used[k.back() - '0'] ? 1 : 0;
+    else if (k == "filter_mass_percent_stage1" || k == "filter_mass_percent_stage2") {   // (diagnostic: reads the device's counters back)
+        const int st = k.back() - '0';
+        *value = -1;
+        if (e->filtered[st] && e->filter_info.p && e->g.nnz) {
+            unsigned long long info[2] = {0, 0};
+            if (hipStreamSynchronize(e->stream) != hipSuccess ||
+                hipMemcpy(info, e->filter_info.p + 4 * st, sizeof info, hipMemcpyDeviceToHost) != hipSuccess)
+                return GNNVC_ERR_DEVICE;
+            *value = (long)(info[0] * 100ull / e->g.nnz);
+        }
+    }
     else if (k == "pruned_bound_stage1" || k == "pruned_bound_stage2") *value = e->prune[k.back() - '0'].ready ? (long)e->prune[k.back() - '0'].bound : 0;
     else if (k == "pruned_observed_stage1" || k == "pruned_observed_stage2") *value = e->prune[k.back() - '0'].tried ? (long)e->prune[k.back() - '0'].observed : 0;
     else if (k == "pruned_vertices_stage1" || k == "pruned_vertices_stage2") *value = e->prune[k.back() - '0'].ready ? (long)e->prune[k.back() - '0'].members : 0;
@@ -1040,6 +1063,7 @@ static int attach_common(gnnvc_engine *e, const GraphDev &cand) {
     e->lt_ready = e->lt_tried = false;
     e->c4_ready = e->c4_tried = false;
     for (auto &pp : e->prune) pp.tried = pp.ready = pp.deferred = false;
+    e->short_from = 0;
     for (int s = 0; s < 4; ++s) { e->c4_stage_off[s] = false; e->c4_unfit_runs[s] = 0; e->fit_used[s] = false; }
     e->fit_pending = false;
     e->c4_range_mode = false;

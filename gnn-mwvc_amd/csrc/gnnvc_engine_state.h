@@ -223,6 +223,28 @@ struct gnnvc_engine {
     int opt_prune_giant = 1;         // option "prune_giant_rows" (A/B): 0 = the giant rows keep their full streams
     uint64_t opt_prune_min_nnz = 1u << 20;   // option "prune_min_entries": smaller graphs are not worth a plan
     uint32_t opt_prune_min_drop = 15;   // option "prune_min_drop_percent": build only if at least this share of the entries goes
+    // Filtered gather: while a skewed graph's 16-wide stage has no pruned adjacency (the graph's first forward: the reference's
+    // driver never comes back for a second), its kernels look every entry's target up in the bitmap of THIS input's all-zero
+    // rows, written just before them, and fetch the pad row instead (GraphDev::zero_bits; nothing to build, nothing to prove).
+    int opt_long_priority = 1;       // option "long_rows_priority" (A/B, before the first graph with long rows): 0 = the long rows' queue at the lowest priority
+    int opt_filter = 1;              // option "filter_zero_rows" (A/B): 0 = plain gathers until the plan is there
+    // which graphs (measured, scratch/experiments/first_ab2.sh + fuzz_large.py: first forward with / without): R-MAT from ~48 M
+    // entries on gains 0.5 - 1.6 ms (R-MAT-22 4.61 -> 3.98, R-MAT-24 19.3 -> 17.7, scale 21 x 16: 2.84 -> 2.30); smaller graphs
+    // lose 0.05 - 0.25 ms to the marks and look-ups, power-law graphs (41 - 58 % of the entries point to zero rows) 0.1 ms, nearly
+    // uniform graphs with a few hubs (1 - 20 %) 0.2 ms — those have 1 - 3 % of their entries in long rows, R-MAT 35 - 58 %
+    uint64_t opt_filter_min_nnz = 48u << 20;   // option "filter_min_entries"
+    uint32_t opt_filter_min_long_pct = 25;     // option "filter_min_long_percent": only graphs whose long rows hold this share of the entries
+    uint32_t opt_filter_min_pct = 50;   // option "filter_min_percent": the share of the entries that has to point into the set (decided on the device)
+    int opt_filter_keep = 1;         // option "filter_keep_lists" (A/B): 0 = every filtered stage walks the whole adjacency
+    DevBuf<uint32_t> filter_bits[4];
+    DevBuf<unsigned long long> filter_info;   // [4 * stage]: {degrees of the set's vertices, their number, verdict on an earlier stage's lists}
+    bool filtered[4] = {false, false, false, false};   // the last call of the stage was offered the bitmap
+    // ... and the targets a filtered stage found outside its set, left per row in prune[stage].pcol / .prp (the buffers of the
+    // plan that is not built yet), are the adjacency of the NEXT 16-wide stage of the same forward when the device finds that
+    // stage's input to keep the set all zero (GraphDev::keep_col / short_col): short_from = the stage that left them, 0 = none
+    int short_from = 0;
+    uint32_t short_min = 0, short_max = 0;   // the degrees [min, max) of the rows that have a list
+    bool short_used[4] = {false, false, false, false};   // the last call of the stage was offered an earlier stage's lists
     // Does the device keep finding a stage's input unfit for the plan (more than its tables' columns live: low-degree graphs)?
     // Whole forwards copy the verdicts out behind themselves; three misses in a row switch the plan off for that stage of this
     // graph — its counting, choosing and empty launches cost up to 17 % of a forward that then gathers anyway.
@@ -268,8 +290,14 @@ struct gnnvc_engine {
     bool opt_long_auto = true;        // no explicit threshold: 256 where few rows are that long, else 512
     uint32_t long_thresh = 0xFFFFFFFFu, n_long = 0;
     DevBuf<uint32_t> long_list, long_count;
+    uint64_t long_entries = 0;       // entries of the listed rows
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // the long rows' own queue, at the device's highest priority: a long row is a sequential chain, the stage's critical path
+    // when it has to wait for the tile kernel's workgroups to leave a CU (R-MAT-22's first forward: k_long_f16 0.42 ms alone,
+    // 1.0 ms beside the tile kernel at equal priority)
+    hipStream_t long_stream = nullptr;
+    hipEvent_t ev_long = nullptr;
     hipStream_t giant_stream = nullptr;  // giant rows: three dependent launches, the side work's long pole -> a high-priority stream of its own
     hipEvent_t ev_giant = nullptr;
     // giant rows (degree >= giant_thresh, a subset of the long rows): CSR-order sums evaluated in parallel (exact_sum.h)
@@ -381,7 +409,7 @@ gnnvc::CompactPlan compact_plan(const gnnvc_engine *e);
 int ensure_round_events(gnnvc_engine *e, size_t count);
 int ensure_events(gnnvc_engine *e, size_t count);
 int gather_view(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float *in, bool gathering, bool sorted_tiles,
-                GraphDev &gv, gnnvc::SortedOrder &so_p);
+                GraphDev &gv, gnnvc::SortedOrder &so_p, bool matrix_cores = true, uint32_t long_from = 0xFFFFFFFFu);
 int reserve_features(gnnvc_engine *e, uint32_t n);
 int reserve_multi_front(gnnvc_engine *e, uint32_t n);
 int prepare_plans(gnnvc_engine *e);                          // everything a forward needs that depends on the graph alone

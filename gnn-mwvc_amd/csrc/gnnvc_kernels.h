@@ -33,6 +33,20 @@ struct GraphDev {
     // number of entries it has LEFT (not by its degree) — except the giant rows, degree >= eff_giant, which stay with
     // their kernels.  The engine sets it when the tile order of the call was built from those numbers too.
     uint32_t prune_eff = 0, eff_giant = 0xFFFFFFFFu, eff_thresh = 0xFFFFFFFFu;   // eff_thresh: entries left from which a row is the long-row kernel's
+    // Filtered gather for ONE call of a 16-wide stage that has no pruned adjacency (yet): zero_bits = bit v set iff row v of this
+    // call's input is all zero (n + 1 bits, the pad row's is 0), zero_info = {degrees of those vertices, their number} — both
+    // written on the device from this very input (filter_mark) just before the stage's kernels, which redirect an entry whose
+    // target's bit is set to the pad row when the set is worth it (filter_worth below).  Null: every entry is gathered.
+    const uint32_t *zero_bits = nullptr;
+    const unsigned long long *zero_info = nullptr;
+    uint32_t zero_min_pct = 50;   // the set is worth a look-up per entry from this share of the entries pointing into it
+    // The LONG rows' lists under the filter (k_long_lists in front of k_long_f16): keep_col / keep_cnt = per long row of this call
+    // its targets outside the set, in stored order, IN PLACE — row u's at keep_col[rowptr[u] ...], keep_cnt[u] of them — written
+    // and walked within the call.  short_col / short_cnt = the lists an earlier stage of the same forward left, which the pass
+    // shortens further instead of the full rows iff *short_bad == 0: the set they were made with is all zero in this call's
+    // input too (k_filter_mark's verdict, on the device).  cnt pointers are biased like rowptr.
+    uint32_t *keep_col = nullptr, *keep_cnt = nullptr;
+    const uint32_t *short_col = nullptr, *short_cnt = nullptr, *short_bad = nullptr;
 #if defined(__HIPCC__)
     __host__ __device__
 #endif
@@ -229,6 +243,11 @@ hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_
 hipError_t prune_observe(const GraphDev &g, const float *feat, uint32_t *max_deg, hipStream_t stream);
 hipError_t prune_mark_degree(const GraphDev &g, uint32_t bound, uint32_t *heavy_bits, hipStream_t stream);
 hipError_t prune_mark_zero(const GraphDev &g, const float *feat, uint32_t *heavy_bits, hipStream_t stream);
+// filtered gather (GraphDev::zero_bits / zero_info): bits = n / 32 + 1 words, info = 3 words {degrees, members, verdict}, written
+// from feat (16 columns).  prev_bits / prev_info: an earlier stage's set of this forward — info[2] = 0 iff the lists that stage
+// left (GraphDev::keep_col) may stand for the adjacency with THIS input (GraphDev::short_bad points to info + 2).
+hipError_t filter_mark(const GraphDev &g, const float *feat, uint32_t *bits, unsigned long long *info, hipStream_t stream,
+                       const uint32_t *prev_bits = nullptr, const unsigned long long *prev_info = nullptr);
 // mass[0] = sum of the degrees of the set's vertices (whole graphs: the entries that point to them, if the adjacency is symmetric;
 // 0 on a slice), mass[1] = vertices in the set
 // (prev_bits: another set — mass[2] = its vertices outside this one; mass has room for 3 words)

@@ -34,10 +34,20 @@ constexpr int kWavesPerBlock = kBlock / kWave;
 // on the sink's stream is bracketed by two HIP events of the sink's pool (launches on the side streams are not).
 thread_local KernelTraceSink *t_sink = nullptr;
 
+// GNNVC_DEBUG_SYNC=1 in the environment: every launch is announced on stderr and waited for (which kernel a device fault
+// belongs to; nothing overlaps any more)
+static const bool g_debug_sync = getenv("GNNVC_DEBUG_SYNC") != nullptr;
+
 struct KernelTimer {
     KernelTraceSink::Rec *rec = nullptr;
     hipStream_t stream;
+    const char *dbg_name = nullptr;
     KernelTimer(hipStream_t s, const char *name) : stream(s) {
+        if (g_debug_sync) {
+            dbg_name = name;
+            fprintf(stderr, "[gnnvc] launch %s\n", name);
+            fflush(stderr);
+        }
         KernelTraceSink *k = t_sink;
         if (!k || k->stream != s) return;
         if (k->used == k->recs.size()) {
@@ -51,6 +61,11 @@ struct KernelTimer {
     }
     ~KernelTimer() {
         if (rec) (void)hipEventRecord(rec->b, stream);
+        if (dbg_name) {
+            const hipError_t rc = hipStreamSynchronize(stream);
+            fprintf(stderr, "[gnnvc] done   %s: %s\n", dbg_name, hipGetErrorName(rc));
+            fflush(stderr);
+        }
     }
 };
 #define GNNVC_LAUNCH(kernel_, grid_, block_, lds_, stream_, ...)              \
@@ -309,7 +324,20 @@ __device__ __forceinline__ void c4_emit(const float *trow, uint32_t nz, uint32_t
 // AGGONLY (compact-table plan): every row's aggregate arrives ready-made — four sums in acc4 for clean rows, the
 // full 16 in agg16 for dirty ones — and the kernel is only the dense layers; it leaves at once when the device
 // found the input unfit for the plan (c4desc[0] == 0), and the gathering variant leaves at once when it was fit.
-template <int N1, int N2, int N3, bool SIGMOID, int S, bool MFMA, bool SORTED, bool AGGONLY = false>
+// FILTER (round 3, a skewed graph's stages while they have no pruned adjacency yet — a graph's first forward, or an input its
+// plan does not fit): g.zero_bits says which vertices' rows are all zero in THIS call's input (k_prune_mark_zero of this very
+// input, a moment ago), and an entry that points to one of them gathers the pad row instead — an L1 hit, not a request to the
+// fabric, which on R-MAT-22 is what 73 - 86 % of the entries would otherwise be.  x + 0 == x: the same sums, bit for bit, with
+// nothing to build and nothing to prove (the set is this input's own).
+// is the set worth a look-up per entry?  (uniform; whole graphs: zero_min_pct of the entries point into it, if the adjacency is
+// symmetric; a slice knows only its own rows' degrees: one vertex in fifty is in it)
+__device__ __forceinline__ bool filter_worth_info(const GraphDev &g, const unsigned long long *info) {
+    const unsigned long long mass = info[0], members = info[1];
+    return g.sliced_dev() ? members * 50ull >= g.n : mass * 100ull >= g.nnz * (unsigned long long)g.zero_min_pct;
+}
+__device__ __forceinline__ bool filter_worth(const GraphDev &g) { return g.zero_bits != nullptr && filter_worth_info(g, g.zero_info); }
+
+template <int N1, int N2, int N3, bool SIGMOID, int S, bool MFMA, bool SORTED, bool AGGONLY = false, bool FILTER = false>
 __global__ __launch_bounds__(kBlock) void k_stage_f16(
         GraphDev g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
         float *__restrict__ logits, const float *__restrict__ P, uint32_t row_lo,
@@ -334,6 +362,7 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
     // with the pruned adjacency a row's class (tile kernel / long-row kernel) goes by the entries it has left, and the
     // sorted tiles come from the list built from those numbers (its meta holds the pruned ranges)
     const bool by_left = pruned && g.prune_eff != 0u;
+    const bool filt = FILTER && !pruned && filter_worth(g);
     if (SORTED && by_left) {
         srt_vertex = srt_vertex_p;
         srt_meta = srt_meta_p;
@@ -464,6 +493,18 @@ __global__ __launch_bounds__(kBlock) void k_stage_f16(
                 const uint32_t cv = staged ? stage[ee - sbase] : gcol[ee];
                 idx[p][s] = (ee < e[p]) ? cv : zrow;
             }
+        if (FILTER && filt) {
+            const uint32_t *__restrict__ zb = g.zero_bits;   // (n + 1 bits: the pad row's is 0)
+            uint32_t wd[4][S];
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int s = 0; s < S; ++s) wd[p][s] = zb[idx[p][s] >> 5];
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int s = 0; s < S; ++s) idx[p][s] = (wd[p][s] >> (idx[p][s] & 31u) & 1u) ? zrow : idx[p][s];
+        }
         float4 r[4][S];
 #pragma unroll
         for (int p = 0; p < 4; ++p)
@@ -794,9 +835,16 @@ __global__ __launch_bounds__(kBlock) void k_stage_f1(
 // kernel of the same stage (disjoint output rows).
 __global__ void k_find_long(GraphDev g, uint32_t thresh, uint32_t *__restrict__ list,
                             uint32_t *__restrict__ count) {
+    // count[0] = rows listed; count[2..3] (one 64-bit word) = their entries
     const uint32_t u = g.lo() + blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= g.hi()) return;
-    if (g.rowptr[u + 1] - g.rowptr[u] >= thresh) list[atomicAdd(count, 1u)] = u;
+    const uint32_t d = u < g.hi() ? g.rowptr[u + 1] - g.rowptr[u] : 0u;
+    const bool is_long = u < g.hi() && d >= thresh;
+    if (is_long) list[atomicAdd(count, 1u)] = u;
+    unsigned long long mine = is_long ? d : 0u;
+#pragma unroll
+    for (int off = 32; off; off >>= 1)
+        mine += ((unsigned long long)__shfl_xor((unsigned)(mine >> 32), off) << 32) | __shfl_xor((unsigned)mine, off);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(reinterpret_cast<unsigned long long *>(count + 2), mine);
 }
 
 // The dense layers of ONE row on one WAVE (round 3): lane j holds output j of a layer, input k arrives from lane k through
@@ -923,8 +971,66 @@ __device__ __forceinline__ void long_drain_round(const f32x4 (&rows)[kLongR], fl
     }
 }
 
-template <int N1, int N2, int N3, bool SIGMOID>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_long_f16(
+// Long rows under the filtered gather (see k_stage_f16<.., FILTER>): it is the add chain (~4 ns a neighbour) that paces a long
+// row, not its fetches, so redirecting the known-zero targets to the pad row inside k_long_f16 gains nothing (measured: 0.85 ->
+// 0.89 ms on R-MAT-22), and compacting them away inside it costs more registers and barriers than it saves (1.77 ms).  Instead a
+// pass of its own in front of it writes every long row's targets OUTSIDE the set, in stored order, IN PLACE (row u's at
+// keep_col[rowptr[u] ...], keep_cnt[u] of them): one workgroup per row, 1024 entries a trip, 4 ballots per wave and a 16-entry
+// exchange through LDS for the order — nothing sequential but the trips of one row — and k_long_f16<.., FILTER> then walks the
+// short list.  The pass reads the row's full list, or the list an EARLIER stage of this forward left (short_col / short_cnt) when
+// the device found this input to keep that stage's set all zero (*short_bad == 0, k_filter_mark).
+__global__ __launch_bounds__(256) void k_long_lists(GraphDev g, uint32_t row_lo, uint32_t row_hi, const uint32_t *__restrict__ list,
+                                                    uint32_t min_deg, uint32_t max_deg) {
+    __shared__ uint32_t rc[2][16];
+    const uint32_t u = list[blockIdx.x];
+    if (u < row_lo || u >= row_hi) return;   // block-uniform, and the same rows as k_long_f16 takes
+    const uint32_t rs = g.rowptr[u], deg = g.rowptr[u + 1] - rs;
+    if (deg >= max_deg || deg < min_deg || !filter_worth(g)) return;
+    const bool shortl = g.short_col != nullptr && *g.short_bad == 0u;
+    const uint32_t *__restrict__ src = (shortl ? g.short_col : g.col) + rs;
+    const uint32_t len = shortl ? min(g.short_cnt[u], deg) : deg;   // (min, and the clamp below: a list is never longer than its row, an id never beyond the pad row — whatever the words hold)
+    uint32_t *__restrict__ dst = g.keep_col + rs;
+    const uint32_t *__restrict__ zb = g.zero_bits;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t kept = 0;
+    for (uint32_t base = 0, trip = 0; base < len; base += 1024, ++trip) {   // entry base + 256 i + tid: run (i, wave) is the (4 i + wave)-th
+        uint32_t v[4], wd[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t k = base + 256 * i + tid;
+            v[i] = k < len ? min(src[k], g.n) : g.n;   // (past the end: the pad row, whose bit is 0 — masked below)
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wd[i] = zb[v[i] >> 5];
+        unsigned long long m[4];
+        uint32_t mycnt = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool take = base + 256 * i + tid < len && !(wd[i] >> (v[i] & 31u) & 1u);
+            m[i] = __ballot(take);
+            mycnt = (lane == i) ? (uint32_t)__popcll(m[i]) : mycnt;
+        }
+        uint32_t(&cnt)[16] = rc[trip & 1u];
+        if (lane < 4) cnt[4 * lane + w] = mycnt;
+        __syncthreads();   // (rc alternates: a wave writes cnt of trip t + 2 only after this barrier of trip t + 1, behind every read of trip t)
+        uint32_t before[4], run = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if ((r & 3) == w) before[r >> 2] = run;
+            run += cnt[r];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (m[i] >> lane & 1ull) dst[kept + before[i] + (uint32_t)__popcll(m[i] & below)] = v[i];
+        kept += run;
+    }
+    if (tid == 0) g.keep_cnt[u] = kept;
+}
+
+// FILTER: the row's list is the one k_long_lists wrote for this call (when the set was worth it: the same test there and here).
+template <int N1, int N2, int N3, bool SIGMOID, bool FILTER = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_long_f16(
         GraphDev g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
         float *__restrict__ logits, const float *__restrict__ P, uint32_t row_lo, uint32_t row_hi,
         const uint32_t *__restrict__ list, uint32_t min_deg, uint32_t max_deg) {
@@ -936,8 +1042,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     if (deg >= max_deg) return;              // a giant row: the k_giant_* kernels have it
     // the entries to gather: the row's whole list, or its pruned one (see k_prune_*; gdeg may be 0)
     const bool pruned = g.prune_bad != nullptr && *g.prune_bad == 0u;
-    const uint32_t *__restrict__ gcol = pruned ? g.pcol : g.col;
-    const uint32_t rs = pruned ? g.prp[u] : g.rowptr[u], re = pruned ? g.prp[u + 1] : g.rowptr[u + 1];
+    const bool lists = FILTER && !pruned && g.keep_col != nullptr && deg >= min_deg && filter_worth(g);
+    const uint32_t *__restrict__ gcol = pruned ? g.pcol : (lists ? g.keep_col : g.col);
+    const uint32_t rs = pruned ? g.prp[u] : g.rowptr[u];
+    const uint32_t re = pruned ? g.prp[u + 1] : (lists ? rs + min(g.keep_cnt[u], deg) : g.rowptr[u + 1]);
     const uint32_t gdeg = re - rs, last = gdeg ? re - 1 : rs;   // (col arrays are padded: [rs] is readable)
     // listed for another stage's threshold (or, classed by the entries it has left, short enough): a tile kernel has it here
     if ((pruned && g.prune_eff) ? gdeg < g.eff_thresh : deg < min_deg) return;
@@ -959,23 +1067,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #define GNNVC_FETCH_ROWS(dst_, rd_)                                       \
     _Pragma("unroll") for (int j = 0; j < R; ++j) {                        \
         const uint32_t e_ = rs + (rd_) * kRound + q + 64 * j;             \
-        dst_[j] = fv[(size_t)((e_ < re) ? idx[j] : zrow) * 4 + c];        \
+        dst_[j] = fv[(size_t)((e_ < re) ? (FILTER ? min(idx[j], zrow) : idx[j]) : zrow) * 4 + c]; \
     }
     float acc = 0.0f;   // threads 0..15: feature column tid
     // Every fetch below is unconditional (past the row's end the indices clamp to its last
     // entry and the rows to the zero row): only then can the compiler prove how many younger
     // loads are outstanding and wait for exactly the round being drained (vmcnt is in-order).
-    GNNVC_FETCH_IDX(0u)
-    GNNVC_FETCH_ROWS(ra, 0u)
-    GNNVC_FETCH_IDX(1u)
-    for (uint32_t rd = 0; rd < nrounds; rd += 2) {
-        GNNVC_FETCH_ROWS(rb, rd + 1)
-        GNNVC_FETCH_IDX(rd + 2)
-        long_drain_round(ra, slab, gdeg - rd * kRound, tid, q, c, acc);
-        if (rd + 1 >= nrounds) break;
-        GNNVC_FETCH_ROWS(ra, rd + 2)
-        GNNVC_FETCH_IDX(rd + 3)
-        long_drain_round(rb, slab, gdeg - (rd + 1) * kRound, tid, q, c, acc);
+    {
+        GNNVC_FETCH_IDX(0u)
+        GNNVC_FETCH_ROWS(ra, 0u)
+        GNNVC_FETCH_IDX(1u)
+        for (uint32_t rd = 0; rd < nrounds; rd += 2) {
+            GNNVC_FETCH_ROWS(rb, rd + 1)
+            GNNVC_FETCH_IDX(rd + 2)
+            long_drain_round(ra, slab, gdeg - rd * kRound, tid, q, c, acc);
+            if (rd + 1 >= nrounds) break;
+            GNNVC_FETCH_ROWS(ra, rd + 2)
+            GNNVC_FETCH_IDX(rd + 3)
+            long_drain_round(rb, slab, gdeg - (rd + 1) * kRound, tid, q, c, acc);
+        }
     }
 #undef GNNVC_FETCH_IDX
 #undef GNNVC_FETCH_ROWS
@@ -1108,6 +1218,13 @@ __global__ __launch_bounds__(256) void k_giant_gather16(GraphDev g, const float4
     for (int jj = 0; jj < 4; ++jj) {
         const uint32_t j = j0 + q + 64 * jj;
         idx[jj] = j < deg ? gcol[first + j] : g.n;     // past the row's end: the all-zero pad row
+    }
+    if (!pruned && filter_worth(g)) {                  // filtered gather (see k_stage_f16): known-zero rows are not fetched
+        uint32_t wd[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) wd[jj] = g.zero_bits[idx[jj] >> 5];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) idx[jj] = (wd[jj] >> (idx[jj] & 31u) & 1u) ? g.n : idx[jj];
     }
     f32x4 r[4];
 #pragma unroll
@@ -2691,6 +2808,63 @@ __global__ __launch_bounds__(256) void k_prune_mark_zero(const float4 *__restric
     if ((threadIdx.x & 63) == 1 && w0 + 1 < words) heavy_bits[w0 + 1] = (uint32_t)(m >> 32);
 }
 
+// Filtered gather (k_stage_f16<.., FILTER>, k_long_f16<.., FILTER>, k_giant_gather16): the bitmap of this input's all-zero rows
+// over n + 1 vertices (the pad row's bit is 0) and, in info (zeroed by the launcher), {the degrees of those vertices (rows this
+// engine holds), their number}.
+// prev_bits (may be null): the set an earlier stage of this forward filtered with (prev_info: its info) — info[2] becomes
+// non-zero unless that set was worth filtering with AND every vertex of it has an all-zero row in feat too: only then do the
+// lists that stage left (GraphDev::short_col) stand for the adjacency in this call.
+__global__ __launch_bounds__(256) void k_filter_mark(GraphDev g, const float4 *__restrict__ feat, uint32_t *__restrict__ bits,
+                                                     unsigned long long *__restrict__ info, const uint32_t *__restrict__ prev_bits,
+                                                     const unsigned long long *__restrict__ prev_info) {
+    // (a block walks groups of 256 rows with the grid's stride: two atomics per BLOCK at the end — one per group of 256 rows
+    // made 32 K atomics on two addresses of R-MAT-22's 4 M rows, 0.18 - 0.26 ms for a 0.05 ms pass)
+    const uint32_t words = g.n / 32 + 1, groups = (g.n + 1 + 255) / 256;
+    unsigned long long deg = 0;
+    uint32_t members = 0;
+    bool miss = false;
+    for (uint32_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const uint32_t u = grp * 256 + threadIdx.x;
+        bool zero = false;
+        if (u < g.n) {
+            const float4 a = feat[(size_t)u * 4], b = feat[(size_t)u * 4 + 1], c = feat[(size_t)u * 4 + 2], d = feat[(size_t)u * 4 + 3];
+            zero = !(a.x != 0.f || a.y != 0.f || a.z != 0.f || a.w != 0.f || b.x != 0.f || b.y != 0.f || b.z != 0.f || b.w != 0.f ||
+                     c.x != 0.f || c.y != 0.f || c.z != 0.f || c.w != 0.f || d.x != 0.f || d.y != 0.f || d.z != 0.f || d.w != 0.f);
+        }
+        const unsigned long long m = __ballot(zero);
+        const uint32_t w0 = (u & ~63u) >> 5;
+        if ((threadIdx.x & 63) == 0 && w0 < words) bits[w0] = (uint32_t)m;
+        if ((threadIdx.x & 63) == 1 && w0 + 1 < words) bits[w0 + 1] = (uint32_t)(m >> 32);
+        if (zero) {
+            ++members;
+            if (u >= g.lo() && u < g.hi()) deg += g.rowptr[u + 1] - g.rowptr[u];
+        } else if (prev_bits != nullptr && u < g.n && (prev_bits[u >> 5] >> (u & 31) & 1u)) {
+            miss = true;
+        }
+    }
+    if (prev_bits != nullptr) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && !filter_worth_info(g, prev_info)) miss = true;
+        if (__any(miss) && (threadIdx.x & 63) == 0) atomicOr(reinterpret_cast<unsigned int *>(info + 2), 1u);
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+        deg += ((unsigned long long)__shfl_xor((unsigned)(deg >> 32), off) << 32) | __shfl_xor((unsigned)deg, off);
+        members += __shfl_xor(members, off);
+    }
+    __shared__ unsigned long long part[4][2];
+    if ((threadIdx.x & 63) == 0) {
+        part[threadIdx.x >> 6][0] = deg;
+        part[threadIdx.x >> 6][1] = members;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long d = part[0][0] + part[1][0] + part[2][0] + part[3][0];
+        const unsigned long long c = part[0][1] + part[1][1] + part[2][1] + part[3][1];
+        if (d) atomicAdd(info, d);
+        if (c) atomicAdd(info + 1, c);
+    }
+}
+
 // mass[0] += the degrees of the set's vertices (on a symmetric adjacency: the entries that point to them; whole graphs only —
 // a slice does not hold the other rows' degrees), mass[1] += the number of vertices in the set
 __global__ __launch_bounds__(256) void k_prune_mass(GraphDev g, const uint32_t *__restrict__ heavy_bits, unsigned long long *__restrict__ mass,
@@ -3574,20 +3748,28 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
 #ifndef GNNVC_GATHER_S_SORTED
 #define GNNVC_GATHER_S_SORTED 3
 #endif
-#define GNNVC_LAUNCH_F16(N2_, N3_, SIG_, MF_, SRT_, S_, LG_)                                          \
-    GNNVC_LAUNCH((k_stage_f16<32, N2_, N3_, SIG_, S_, MF_, SRT_>), grid, block, 0, stream, g, ws, in4, out, \
-                       LG_, P, row_lo, row_hi, long_thresh, sorted ? so->vertex : nullptr,                \
-                       sorted ? so->meta : nullptr, sorted ? so->n : 0u, il,                              \
+#define GNNVC_F16_ARGS(SIG_, MF_, LG_)                                                                              \
+                       grid, block, 0, stream, g, ws, in4, out,                                                           \
+                       LG_, P, row_lo, row_hi, long_thresh, sorted ? so->vertex : nullptr,                                \
+                       sorted ? so->meta : nullptr, sorted ? so->n : 0u, il,                                              \
                        (const float4 *)nullptr, acc4 ? c4desc : nullptr, (const float4 *)nullptr,                         \
                        (MF_ || SIG_) ? nullptr : emit.spec, reinterpret_cast<c4row *>((MF_ || SIG_) ? nullptr : emit.table), \
                        (MF_ || SIG_) ? nullptr : emit.counts,                                                             \
-                       with_p ? so_pruned->vertex : nullptr, with_p ? so_pruned->meta : nullptr, n_p)
+                       with_p ? so_pruned->vertex : nullptr, with_p ? so_pruned->meta : nullptr, n_p
+#define GNNVC_LAUNCH_X(...) GNNVC_LAUNCH(__VA_ARGS__)   // (the argument list above is expanded on the way through)
+#define GNNVC_LAUNCH_F16(N2_, N3_, SIG_, MF_, SRT_, S_, LG_) \
+    GNNVC_LAUNCH_X((k_stage_f16<32, N2_, N3_, SIG_, S_, MF_, SRT_>), GNNVC_F16_ARGS(SIG_, MF_, LG_))
+#define GNNVC_LAUNCH_F16F(N2_, N3_, SIG_, MF_, SRT_, S_, LG_, FLT_) \
+    GNNVC_LAUNCH_X((k_stage_f16<32, N2_, N3_, SIG_, S_, MF_, SRT_, false, FLT_>), GNNVC_F16_ARGS(SIG_, MF_, LG_))
     case 2:
         if (sorted) GNNVC_LAUNCH_F16(32, 16, false, false, true, GNNVC_GATHER_S_SORTED, nullptr);
         else GNNVC_LAUNCH_F16(32, 16, false, false, false, GNNVC_GATHER_S, nullptr);
         break;
-    case 3:
-        if (sorted) GNNVC_LAUNCH_F16(32, 16, false, true, true, GNNVC_GATHER_S_SORTED, nullptr);
+    case 3:   // (the filtered gather comes with the matrix-core variants only: the default of the 16-wide stages)
+        if (g.zero_bits) {
+            if (sorted) GNNVC_LAUNCH_F16F(32, 16, false, true, true, GNNVC_GATHER_S_SORTED, nullptr, true);
+            else GNNVC_LAUNCH_F16F(32, 16, false, true, false, GNNVC_GATHER_S, nullptr, true);
+        } else if (sorted) GNNVC_LAUNCH_F16(32, 16, false, true, true, GNNVC_GATHER_S_SORTED, nullptr);
         else GNNVC_LAUNCH_F16(32, 16, false, true, false, GNNVC_GATHER_S, nullptr);
         break;
     case 4:
@@ -3595,10 +3777,16 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
         else GNNVC_LAUNCH_F16(16, 1, true, false, false, GNNVC_GATHER_S, logits);
         break;
     case 5:
-        if (sorted) GNNVC_LAUNCH_F16(16, 1, true, true, true, GNNVC_GATHER_S_SORTED, logits);
+        if (g.zero_bits) {
+            if (sorted) GNNVC_LAUNCH_F16F(16, 1, true, true, true, GNNVC_GATHER_S_SORTED, logits, true);
+            else GNNVC_LAUNCH_F16F(16, 1, true, true, false, GNNVC_GATHER_S, logits, true);
+        } else if (sorted) GNNVC_LAUNCH_F16(16, 1, true, true, true, GNNVC_GATHER_S_SORTED, logits);
         else GNNVC_LAUNCH_F16(16, 1, true, true, false, GNNVC_GATHER_S, logits);
         break;
 #undef GNNVC_LAUNCH_F16
+#undef GNNVC_LAUNCH_F16F
+#undef GNNVC_F16_ARGS
+#undef GNNVC_LAUNCH_X
     default:
         return hipErrorInvalidValue;
     }
@@ -3850,6 +4038,15 @@ hipError_t prune_mark_degree(const GraphDev &g, uint32_t bound, uint32_t *heavy_
     return hipGetLastError();
 }
 
+hipError_t filter_mark(const GraphDev &g, const float *feat, uint32_t *bits, unsigned long long *info, hipStream_t stream,
+                       const uint32_t *prev_bits, const unsigned long long *prev_info) {
+    hipError_t rc = hipMemsetAsync(info, 0, 3 * sizeof(unsigned long long), stream);
+    if (rc != hipSuccess || g.n == 0) return rc;
+    GNNVC_LAUNCH(k_filter_mark, dim3(std::min<size_t>(((size_t)g.n + 1 + 255) / 256, 1024)), dim3(256), 0, stream, g,
+                 reinterpret_cast<const float4 *>(feat), bits, info, prev_bits, prev_info);
+    return hipGetLastError();
+}
+
 hipError_t prune_mark_zero(const GraphDev &g, const float *feat, uint32_t *heavy_bits, hipStream_t stream) {
     if (g.n == 0) return hipSuccess;
     GNNVC_LAUNCH(k_prune_mark_zero, dim3((g.n + 255) / 256), dim3(256), 0, stream, reinterpret_cast<const float4 *>(feat), g.n, heavy_bits);
@@ -4077,7 +4274,7 @@ hipError_t degree_scatter(const GraphDev &g, uint32_t row_lo, uint32_t row_hi, u
 // ---- long rows --------------------------------------------------------------------------
 hipError_t find_long_rows(const GraphDev &g, uint32_t thresh, uint32_t *list, uint32_t *count,
                           hipStream_t stream) {
-    hipError_t rc = hipMemsetAsync(count, 0, sizeof(uint32_t), stream);
+    hipError_t rc = hipMemsetAsync(count, 0, 4 * sizeof(uint32_t), stream);   // (count: 4 words, see k_find_long)
     if (rc != hipSuccess || g.hi() <= g.lo()) return rc;
     GNNVC_LAUNCH(k_find_long, dim3((g.hi() - g.lo() + 255) / 256), dim3(256), 0, stream, g, thresh, list, count);
     return hipGetLastError();
@@ -4202,12 +4399,22 @@ hipError_t launch_long_stage(const StagePlan &sp, const GraphDev &g, float ws, c
                            min_deg, max_deg);
         break;
     case 1:
-        GNNVC_LAUNCH((k_long_f16<32, 32, 16, false>), grid, block, 0, stream, g, ws,
-                           reinterpret_cast<const float4 *>(in), out, nullptr, P, row_lo, row_hi, list, min_deg, max_deg);
+        if (g.zero_bits && g.keep_col) {
+            GNNVC_LAUNCH(k_long_lists, grid, block, 0, stream, g, row_lo, row_hi, list, min_deg, max_deg);
+            GNNVC_LAUNCH((k_long_f16<32, 32, 16, false, true>), grid, block, 0, stream, g, ws,
+                               reinterpret_cast<const float4 *>(in), out, nullptr, P, row_lo, row_hi, list, min_deg, max_deg);
+        } else
+            GNNVC_LAUNCH((k_long_f16<32, 32, 16, false>), grid, block, 0, stream, g, ws,
+                               reinterpret_cast<const float4 *>(in), out, nullptr, P, row_lo, row_hi, list, min_deg, max_deg);
         break;
     case 2:
-        GNNVC_LAUNCH((k_long_f16<32, 16, 1, true>), grid, block, 0, stream, g, ws,
-                           reinterpret_cast<const float4 *>(in), out, logits, P, row_lo, row_hi, list, min_deg, max_deg);
+        if (g.zero_bits && g.keep_col) {
+            GNNVC_LAUNCH(k_long_lists, grid, block, 0, stream, g, row_lo, row_hi, list, min_deg, max_deg);
+            GNNVC_LAUNCH((k_long_f16<32, 16, 1, true, true>), grid, block, 0, stream, g, ws,
+                               reinterpret_cast<const float4 *>(in), out, logits, P, row_lo, row_hi, list, min_deg, max_deg);
+        } else
+            GNNVC_LAUNCH((k_long_f16<32, 16, 1, true>), grid, block, 0, stream, g, ws,
+                               reinterpret_cast<const float4 *>(in), out, logits, P, row_lo, row_hi, list, min_deg, max_deg);
         break;
     default:
         return hipErrorInvalidValue;

@@ -130,8 +130,10 @@ int find_long(gnnvc_engine *e) {
     uint32_t thresh = e->opt_long_thresh;
     e->thresh_f16 = 0xFFFFFFFFu;
     HIP_TRY(e, e->long_list.reserve(ghi - glo));
-    HIP_TRY(e, e->long_count.reserve(1));
+    HIP_TRY(e, e->long_count.reserve(4));
     uint32_t cnt = 0;
+    uint32_t found[4] = {0, 0, 0, 0};   // {rows, -, their entries (64 bits)}
+    e->long_entries = 0;
     bool few_long = false;
     if (e->opt_long_auto) {
         // A row of d entries holds its tile for d / 3 gather trips (~1.2 us each): with only a few thousand rows above 256 the
@@ -139,22 +141,31 @@ int find_long(gnnvc_engine *e) {
         // workgroups of their own; where a hundred thousand rows sit there (R-MAT-22: 110 K) a workgroup each costs more than
         // the tiles (6.2 vs 3.0 ms) and the threshold stays at 512.
         HIP_TRY(e, gnnvc::find_long_rows(g, 256u, e->long_list.p, e->long_count.p, e->stream));
-        HIP_TRY(e, hipMemcpyAsync(&cnt, e->long_count.p, sizeof cnt, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(found, e->long_count.p, sizeof found, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(e, hipStreamSynchronize(e->stream));
+        cnt = found[0];
         if (cnt == 0) return GNNVC_OK;   // (no row of 256 entries: none of 512 either)
         few_long = cnt <= 16384u && (uint64_t)cnt * 64 <= (uint64_t)(ghi - glo);   // (few, and the exception among the rows: not a dense graph)
         if (few_long) thresh = 256u;
     }
     if (!few_long) {
         HIP_TRY(e, gnnvc::find_long_rows(g, thresh, e->long_list.p, e->long_count.p, e->stream));
-        HIP_TRY(e, hipMemcpyAsync(&cnt, e->long_count.p, sizeof cnt, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(found, e->long_count.p, sizeof found, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(e, hipStreamSynchronize(e->stream));
+        cnt = found[0];
     }
+    e->long_entries = (uint64_t)found[2] | ((uint64_t)found[3] << 32);
     if (cnt == 0) return GNNVC_OK;   // nothing long: the tile kernels keep every row
     if (!e->aux_stream) {
         HIP_TRY(e, hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking));
         HIP_TRY(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
         HIP_TRY(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    }
+    if (!e->long_stream) {
+        int lo_p = 0, hi_p = 0;   // (numerically lower = higher priority)
+        HIP_TRY(e, hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+        HIP_TRY(e, hipStreamCreateWithPriority(&e->long_stream, hipStreamNonBlocking, e->opt_long_priority ? hi_p : lo_p));
+        HIP_TRY(e, hipEventCreateWithFlags(&e->ev_long, hipEventDisableTiming));
     }
     e->n_long = cnt;
     e->long_thresh = thresh;
@@ -792,6 +803,10 @@ int reserve_prune(gnnvc_engine *e, int stage) {
     HIP_TRY(e, e->pin_info.reserve(64));
     HIP_TRY(e, e->dev_info.reserve(64));
     HIP_TRY(e, pp.heavy.reserve(((size_t)g.n + 31) / 32 + 1));
+    if (e->opt_filter) {
+        HIP_TRY(e, e->filter_bits[stage].reserve((size_t)g.n / 32 + 1));
+        HIP_TRY(e, e->filter_info.reserve(16));
+    }
     HIP_TRY(e, e->prune_mask.reserve(std::max<size_t>(chunks, 2)));
     HIP_TRY(e, e->prune_off.reserve(chunks + 1));
     HIP_TRY(e, e->prune_scratch.reserve(gnnvc::blocked_scan_scratch_elems(chunks + 1)));
@@ -908,7 +923,7 @@ int build_prune_impl(gnnvc_engine *e, int stage, const float *in, bool early) {
 // check of this very input is queued here, ahead of every kernel that reads its verdict).  so_p: the tile order that goes
 // with classing the rows by the entries they have left (natural tiles need none).
 int gather_view(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float *in, bool gathering, bool sorted_tiles,
-                GraphDev &gv, gnnvc::SortedOrder &so_p) {
+                GraphDev &gv, gnnvc::SortedOrder &so_p, bool matrix_cores, uint32_t long_from) {
     gv = e->g;
     so_p = gnnvc::SortedOrder();
     if (stage < 1 || stage > 3 || e->stages[stage].f != 16 || !e->opt_prune) return GNNVC_OK;
@@ -918,14 +933,65 @@ int gather_view(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const floa
     // long rows: that is where zero rows are found) already the first time its stage runs: the passes cost less than the
     // gathers they save there (first forward R-MAT-22 6.95 -> 6.16 ms, R-MAT-24 34.5 -> 25.9 ms; R-MAT-20 and the power-law
     // graph lose 0.3 - 0.5 ms to the fixed costs, hence the size bound).
-    const bool early = (e->sorted_wanted || e->n_long > 0) && e->opt_prune_early_nnz && e->g.nnz >= e->opt_prune_early_nnz;
+    // (round 3: that is the rule with "filter_zero_rows" off.  With it — the default — a skewed graph's first forward builds
+    // nothing: its kernels skip the zero rows by looking them up, see below, and the plan is built if the graph comes back.)
+    const bool skewed = e->sorted_wanted || e->n_long > 0;
+    // (the tile kernel's filtered instantiations are those of the matrix-core variants, the default of the 16-wide stages)
+    // ... on graphs whose LONG rows hold a good share of the entries (known since the hand-off): that is where the model zeroes
+    // most targets (R-MAT: 73 - 86 % of the entries point to zero rows; power-law graphs and uniform graphs with hubs, 1 - 55 %,
+    // lose 0.1 - 0.3 ms of their first forward to the look-ups)
+    const bool filter = e->opt_filter && matrix_cores && skewed && e->g.nnz >= e->opt_filter_min_nnz && e->g.nnz < (1ull << 32) &&
+                        e->n_long > 0 && e->long_entries * 100ull >= e->g.nnz * (uint64_t)e->opt_filter_min_long_pct;
+    const bool early = !filter && skewed && e->opt_prune_early_nnz && e->g.nnz >= e->opt_prune_early_nnz;
     const uint32_t uses_needed = (early && !pp.deferred) ? 1u : 2u;
+    e->filtered[stage] = e->short_used[stage] = false;
+    if (e->short_from >= stage) e->short_from = 0;   // (the stage that left the lists runs again: they are this call's to leave, or nobody's)
     if (!pp.tried && e->graph_uses >= uses_needed) {
         const bool first_forward = e->graph_uses < 2;
         int rc = timed_build(e, [&] { return build_prune_impl(e, stage, in, first_forward); });
         if (rc) return rc;
     }
-    if (!pp.ready) return GNNVC_OK;
+    if (!pp.ready) {
+        // no plan (yet, or the graph has too few zero rows for one): the bitmap of this input's zero rows for the kernels to
+        // look into — in a graph's first forward, and later only while a plan may still come (tried && !ready: it was found
+        // not worth it, and neither is a look-up per entry)
+        if (filter && !pp.tried) {
+            const GraphDev &g = e->g;
+            HIP_TRY(e, e->filter_bits[stage].reserve((size_t)g.n / 32 + 1));
+            HIP_TRY(e, e->filter_info.reserve(16));
+            // an earlier stage of this graph left its long rows' lists — of every row this call's long-row kernel will take?
+            const int from = e->short_from;
+            const uint32_t giant_from = e->giant_f16();
+            const bool consume = from >= 1 && from < stage && long_from >= e->short_min && giant_from <= e->short_max;
+            // (gv, not g: the verdict on the earlier stage's lists has to be reached with the bound that stage's kernels used)
+            gv.zero_min_pct = e->opt_filter_min_pct;
+            HIP_TRY(e, gnnvc::filter_mark(gv, in, e->filter_bits[stage].p, e->filter_info.p + 4 * stage, e->stream,
+                                          consume ? e->filter_bits[from].p : nullptr, consume ? e->filter_info.p + 4 * from : nullptr));
+            gv.zero_bits = e->filter_bits[stage].p;
+            gv.zero_info = e->filter_info.p + 4 * stage;
+            e->filtered[stage] = true;
+            if (e->opt_filter_keep && e->n_long > 0) {
+                // the long rows' short lists of this call go where the plan's entries will go once it is built
+                HIP_TRY(e, pp.pcol.reserve((size_t)g.nnz + GNNVC_COL_PAD));
+                HIP_TRY(e, pp.prp.reserve((size_t)(g.hi() - g.lo()) + 1));
+                gv.keep_col = pp.pcol.p;
+                gv.keep_cnt = pp.prp.p - g.lo();
+                if (consume) {
+                    gv.short_col = e->prune[from].pcol.p;
+                    gv.short_cnt = e->prune[from].prp.p - g.lo();
+                    gv.short_bad = reinterpret_cast<const uint32_t *>(e->filter_info.p + 4 * stage + 2);
+                    e->short_used[stage] = true;
+                }
+                // a call that sees every row the engine holds leaves them for the next 16-wide stage, if there is one
+                if (lo == g.lo() && hi == g.hi() && stage + 1 < (int)e->stages.size() && stage + 1 <= 3 && e->stages[stage + 1].f == 16) {
+                    e->short_from = stage;
+                    e->short_min = long_from;
+                    e->short_max = giant_from;
+                }
+            }
+        }
+        return GNNVC_OK;
+    }
     HIP_TRY(e, gnnvc::prune_check(e->g, in, pp.heavy.p, e->prune_flags.p + stage, e->stream));
     gv.prp = pp.prp.p - e->g.lo();   // (indexed by global row id, like rowptr)
     gv.pcol = pp.pcol.p;
@@ -1038,6 +1104,7 @@ void reset_graph_state(gnnvc_engine *e) {
     e->c4_ready = e->c4_tried = false;
     e->lt_pb.open = e->c4_pb.open = false;
     for (auto &pp : e->prune) pp.tried = pp.ready = pp.deferred = false;
+    e->short_from = 0;
     for (int s = 0; s < 4; ++s) { e->c4_stage_off[s] = false; e->c4_unfit_runs[s] = 0; e->fit_used[s] = false; }
     e->fit_pending = false;
     e->c4_range_mode = false;

@@ -12,7 +12,7 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 big = len(sys.argv) > 3 and sys.argv[3] == "big"   # 3 - 12 M vertices, up to ~250 M entries
 dev = torch.device("cuda", 0)
 from tools.panel_graphs import PLAIN, panel_graph
-INFO = ("tile_waste_x100", "lds_table_active", "lds_table_mapped", "compact_gather_active", "pruned_stage1", "pruned_stage2", "sorted_tiles_active", "long_rows",
+INFO = ("filter_mass_percent_stage1", "filter_mass_percent_stage2", "long_entries_percent", "tile_waste_x100", "lds_table_active", "lds_table_mapped", "compact_gather_active", "pruned_stage1", "pruned_stage2", "sorted_tiles_active", "long_rows",
         "long_row_threshold", "giant_rows", "giant_segments", "blocked_stage0_active")
 
 
@@ -31,13 +31,15 @@ def run(g, x, opts, reps):
         e.forward_device(x.data_ptr(), sc.data_ptr(), lg.data_ptr()); e.synchronize()
         if i == 0:
             first_ms = (time.perf_counter() - t) * 1e3
+            first_info = {k: e.get_info(k) for k in INFO[:2]}
         outs.append((sc.clone(), lg.clone()))
     t = time.perf_counter()
     for _ in range(5):
         e.forward_device(x.data_ptr(), sc.data_ptr(), lg.data_ptr())
     e.synchronize()
     ms = (time.perf_counter() - t) * 200.0
-    info = {k: e.get_info(k) for k in INFO}
+    info = {k: e.get_info(k) for k in INFO[2:]}
+    info.update({k: v for k, v in first_info.items() if v > 0})
     e.close()
     info["first_ms"] = round(first_ms, 3)
     return outs, {k: v for k, v in info.items() if v}, ms
@@ -58,7 +60,7 @@ for case in range(cases):
         alt = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in sys.argv[4].split(",")}
         got2, info2, ms2 = run(g, x, alt, 4)
         m2 = sum(int((r[1].view(torch.int32) != ref[0][1].view(torch.int32)).sum()) for r in got2)
-        extra = f" alt {ms2:.3f} ms ({m2} mismatches) alt/default {ms2 / ms:.2f};"
+        extra = f" alt {ms2:.3f} ms ({m2} mismatches) alt/default {ms2 / ms:.2f}; alt first {info2['first_ms']} ms;"
     miss = [int((r[1].view(torch.int32) != ref[0][1].view(torch.int32)).sum()) + int((r[0].view(torch.int32) != ref[0][0].view(torch.int32)).sum()) for r in got]
     f1, f0 = info["first_ms"], info_plain["first_ms"]
     tag = "MISMATCH" if any(miss) else "ok"

@@ -122,7 +122,7 @@ def test_every_logit_matches_the_oracle(big, oracle_model):
 
 def test_first_forward_of_a_fresh_graph_runs_with_the_plans(big):
     """Score-once callers (the reference's driver): a new engine, the graph handed over, ONE forward.  The plans that depend
-    on the graph alone were built at hand-off, the pruned adjacency of a large skewed graph inside that forward — and the
+    on the graph alone were built at hand-off, a large skewed graph's stages skip the zero rows without a plan — and the
     bits are those of every other path."""
     import torch
     import gnn_mwvc_amd as G
@@ -148,7 +148,18 @@ def test_first_forward_of_a_fresh_graph_runs_with_the_plans(big):
             assert e2.get_info("compact_gather_last_ok") == 1 and e2.get_info("compact_gather_last_dirty") > 0
             assert e2.get_info("compact_table_written_by_producer") == 1
         elif big["name"] in ("rmat22", "rmat24"):
+            # nothing is built inside a once-scored skewed graph's forward: its 16-wide stages skip the zero rows by looking
+            # them up (filtered gather), the long rows walk lists a pass in front of them shortened, the last stage's from the
+            # lists the stage before left
             assert e2.get_info("sorted_tiles_active") == 1
+            for st in (1, 2):
+                assert e2.get_info(f"filtered_stage{st}") == 1 and e2.get_info(f"pruned_stage{st}") == 0
+                assert e2.get_info(f"filter_mass_percent_stage{st}") >= 50
+            assert e2.get_info("short_lists_stage2") == 1
+            # ... and if the graph does come back, the pruned adjacency is built then
+            e2.forward_device(big["x"].data_ptr(), sc.data_ptr(), lg.data_ptr())
+            e2.synchronize()
+            assert torch.equal(lg.view(torch.int32), big["lg"].view(torch.int32))
             for st in (1, 2):
                 assert e2.get_info(f"pruned_stage{st}") == 1 and e2.get_info(f"pruned_last_ok_stage{st}") == 1
     finally:

@@ -844,6 +844,93 @@ def test_pruned_adjacency_is_bit_identical(model_text, oracle_model, maker, mode
         e.close()
 
 
+@pytest.mark.parametrize("min_percent", [1, 101])
+@pytest.mark.parametrize("maker", [
+    lambda: gg.rmat(14, 8, 3),
+    lambda: gg.hub_graph(30000, 200000, 3, 6000, seed=9),
+    lambda: gg.chung_lu_hubs(40000, 8.0, 2.2, 2, 3000, seed=4),
+])
+def test_filtered_first_forward_is_bit_identical(model_text, oracle_model, maker, min_percent):
+    """A skewed graph scored ONCE (what the reference's driver does) has no pruned adjacency: its 16-wide stages look every
+    entry's target up in the bitmap of THIS input's all-zero rows (k_filter_mark) and fetch the pad row instead, the long rows
+    walk lists shortened by a pass in front of them (k_long_lists), and the next stage shortens those lists further when the
+    device finds the earlier set still all zero in its input.  min_percent 1: the set always counts as worth it; 101: never —
+    the filtered instantiations run, nothing is written, nothing may be read.  Whole first forwards and single stages
+    (fitting inputs, inputs that break the earlier stage's set, row ranges) equal the oracle bit for bit."""
+    import torch
+    import gnn_mwvc_amd as G
+    g = maker()
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_option("blocked_min_n", 0)
+        e.set_option("long_row_threshold", 256)
+        e.set_option("sorted_long_row_threshold", 512)
+        e.set_option("giant_row_threshold", 4096)
+        e.set_option("filter_min_entries", 0)
+        e.set_option("filter_min_long_percent", 0)
+        e.set_option("filter_min_percent", min_percent)
+        e.set_weight_scale(g.ws)
+        oracle_model.set_weight_scale(g.ws)
+        want_logits = oracle_model.logits(g)
+        for _ in range(2):                                   # twice a FIRST forward: the graph handed over anew
+            e.upload_graph(g)
+            _, logits = e.forward(g.x())
+            assert e.get_info("graph_uses") == 1
+            assert e.get_info("filtered_stage1") == 1 and e.get_info("filtered_stage2") == 1
+            assert e.get_info("pruned_stage1") == 0 and e.get_info("pruned_stage2") == 0
+            assert e.get_info("long_rows") > 0 and e.get_info("short_lists_stage2") == 1
+            assert np.array_equal(bits(logits[:, 0]), bits(want_logits))
+        if min_percent == 1:
+            assert e.get_info("filter_mass_percent_stage1") >= 1
+        # single stages on the once-scored graph (still no plan: stage calls do not count as uses)
+        stage_in = {1: oracle_model.predict(g, g.x(), stop_after=6), 2: oracle_model.predict(g, g.x(), stop_after=13)}
+        zero1 = np.flatnonzero(~(stage_in[1] != 0).any(axis=1))
+        dev = torch.device("cuda:0")
+        rng = np.random.default_rng(11)
+
+        def stage(st, hs, lo, hi):
+            hin = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+            hin[: g.n] = torch.from_numpy(hs).to(dev)
+            out = torch.full((g.n + 1, 16 if st == 1 else 1), 7.0, dtype=torch.float32, device=dev)
+            lg = torch.full((g.n + 1,), 7.0, dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+            e.stage_forward_device(st, lo, hi, hin.data_ptr(), out.data_ptr(), lg.data_ptr() if st == 2 else 0)
+            e.synchronize()
+            got = out[lo:hi].cpu().numpy() if st == 1 else lg[lo:hi].cpu().numpy().reshape(-1, 1)
+            want = _oracle_stage(oracle_model, g, st, hs)
+            assert np.array_equal(bits(got), bits(want[lo:hi])), (st, lo, hi)
+
+        third = g.n // 3 // 64 * 64
+        for case in ("same_set", "bigger_set", "broken_set", "dense", "after_a_range"):
+            h1 = (rng.uniform(0.05, 2.0, (g.n, 16)) * (rng.random((g.n, 16)) < 0.5)).astype(np.float32)
+            h1[zero1] = 0.0                                  # stage 1's input: the model's own zero rows
+            h2 = (rng.uniform(0.05, 2.0, (g.n, 16)) * (rng.random((g.n, 16)) < 0.5)).astype(np.float32)
+            if case != "dense":
+                h2[zero1] = 0.0
+            if case == "bigger_set":
+                h2[rng.random(g.n) < 0.3] = 0.0
+                h2[zero1[::2], 5] = -0.0                     # a zero of either sign is a zero
+            if case == "broken_set" and len(zero1):
+                h2[zero1[len(zero1) // 2], 9] = 0.25         # the earlier stage's lists do not stand for this input
+            if case == "after_a_range":
+                stage(1, h1, third, 2 * third)               # a call that does not see every row leaves nothing behind
+            else:
+                stage(1, h1, 0, g.n)
+            for lo, hi in ((0, g.n), (third, 2 * third)):
+                stage(2, h2, lo, hi)
+                if min_percent == 1 and len(zero1) and case != "after_a_range":
+                    assert e.get_info("short_lists_stage2") == 1
+                if case == "after_a_range":
+                    assert e.get_info("short_lists_stage2") == 0
+        e.set_option("filter_zero_rows", 0)                  # and the same first forward without any of it
+        e.upload_graph(g)
+        _, logits = e.forward(g.x())
+        assert e.get_info("filtered_stage1") == 0 and e.get_info("filtered_stage2") == 0
+        assert np.array_equal(bits(logits[:, 0]), bits(want_logits))
+    finally:
+        e.close()
+
+
 def test_compact_gather_plan_steps_aside_for_good(model_text, oracle_model):
     """A graph whose stage inputs never fit the plan (low degrees: more than four live columns): after three forwards in a row
     that the device sent down the gathering kernels, the engine stops queuing the plan's counting, choosing and empty
