@@ -528,9 +528,10 @@ int gnnvc_create(gnnvc_engine **out, const char *model_text, size_t len, int dev
                 rc = fail(e, GNNVC_ERR_DEVICE, "hipStreamCreate failed");
             e->stream = e->own_stream;
         }
-        // (creating a stream takes ~6 ms on this stack: the second stream of the overlapped rounds / long rows is made here, once
-        // per engine, not inside the first forward that wants it)
+        // (creating a stream takes ~10 ms on this stack: the side queues are made here, once per engine, not inside the first
+        // hand-off or forward that wants them)
         if (rc == GNNVC_OK) rc = ensure_round_events(e, 0);
+        if (rc == GNNVC_OK) rc = ensure_side_streams(e);
         if (rc == GNNVC_OK) rc = upload_params(e);
     } catch (const std::bad_alloc &) {
         rc = GNNVC_ERR_NOMEM;
@@ -662,7 +663,6 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "prune_heavy_entries") { e->opt_prune_heavy_entries = value > 0 ? (uint64_t)value : 0; for (auto &pp : e->prune) pp.tried = pp.ready = false; }
     else if (k == "prune_early_entries") e->opt_prune_early_nnz = value > 0 ? (uint64_t)value : 0;
     else if (k == "prune_giant_rows") e->opt_prune_giant = value != 0 ? 1 : 0;
-    else if (k == "long_rows_priority") e->opt_long_priority = value != 0 ? 1 : 0;
     else if (k == "filter_zero_rows") e->opt_filter = value != 0 ? 1 : 0;
     else if (k == "filter_keep_lists") e->opt_filter_keep = value != 0 ? 1 : 0;
     else if (k == "filter_min_entries") e->opt_filter_min_nnz = value > 0 ? (uint64_t)value : 0;

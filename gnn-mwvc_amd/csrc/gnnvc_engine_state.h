@@ -226,7 +226,6 @@ struct gnnvc_engine {
     // Filtered gather: while a skewed graph's 16-wide stage has no pruned adjacency (the graph's first forward: the reference's
     // driver never comes back for a second), its kernels look every entry's target up in the bitmap of THIS input's all-zero
     // rows, written just before them, and fetch the pad row instead (GraphDev::zero_bits; nothing to build, nothing to prove).
-    int opt_long_priority = 1;       // option "long_rows_priority" (A/B, before the first graph with long rows): 0 = the long rows' queue at the lowest priority
     int opt_filter = 1;              // option "filter_zero_rows" (A/B): 0 = plain gathers until the plan is there
     // which graphs (measured, scratch/experiments/first_ab2.sh + fuzz_large.py: first forward with / without): R-MAT from ~48 M
     // entries on gains 0.5 - 1.6 ms (R-MAT-22 4.61 -> 3.98, R-MAT-24 19.3 -> 17.7, scale 21 x 16: 2.84 -> 2.30); smaller graphs
@@ -293,9 +292,7 @@ struct gnnvc_engine {
     uint64_t long_entries = 0;       // entries of the listed rows
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // the long rows' own queue, at the device's highest priority: a long row is a sequential chain, the stage's critical path
-    // when it has to wait for the tile kernel's workgroups to leave a CU (R-MAT-22's first forward: k_long_f16 0.42 ms alone,
-    // 1.0 ms beside the tile kernel at equal priority)
+    // the long rows' own queue (not the second queue of the overlapped rounds: its join event is its own)
     hipStream_t long_stream = nullptr;
     hipEvent_t ev_long = nullptr;
     hipStream_t giant_stream = nullptr;  // giant rows: three dependent launches, the side work's long pole -> a high-priority stream of its own
@@ -406,6 +403,7 @@ int c4_begin(gnnvc_engine *e, uint32_t base, uint32_t end, bool allow_mapped);
 int c4_advance(gnnvc_engine *e, uint32_t upto, hipStream_t stream);
 int c4_finish(gnnvc_engine *e);
 gnnvc::CompactPlan compact_plan(const gnnvc_engine *e);
+int ensure_side_streams(gnnvc_engine *e);
 int ensure_round_events(gnnvc_engine *e, size_t count);
 int ensure_events(gnnvc_engine *e, size_t count);
 int gather_view(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float *in, bool gathering, bool sorted_tiles,

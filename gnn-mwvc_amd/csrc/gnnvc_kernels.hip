@@ -338,7 +338,7 @@ __device__ __forceinline__ bool filter_worth_info(const GraphDev &g, const unsig
 __device__ __forceinline__ bool filter_worth(const GraphDev &g) { return g.zero_bits != nullptr && filter_worth_info(g, g.zero_info); }
 
 template <int N1, int N2, int N3, bool SIGMOID, int S, bool MFMA, bool SORTED, bool AGGONLY = false, bool FILTER = false>
-__global__ __launch_bounds__(kBlock) void k_stage_f16(
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void k_stage_f16(
         GraphDev g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
         float *__restrict__ logits, const float *__restrict__ P, uint32_t row_lo,
         uint32_t row_hi, uint32_t long_thresh, const uint32_t *__restrict__ srt_vertex,
@@ -3063,6 +3063,8 @@ __global__ __launch_bounds__(64) void k_deg_starts(uint32_t *__restrict__ hist, 
 
 // cursor[d] holds the next free slot of degree class d (classes laid out by DEscending degree,
 // so the heaviest tiles are dispatched first); entries carry what the tile kernel needs per vertex
+constexpr int kDegScatterRows = 8;   // rows per thread: the two sweeps over the class counters are per BLOCK (4096 counters
+                                     // for 256 rows made the pass 0.22 ms on R-MAT-22's 4 M rows)
 __global__ __launch_bounds__(256) void k_deg_scatter(GraphDev g, uint32_t row_lo, uint32_t row_hi, uint32_t long_thresh,
                                                      uint32_t bins, uint32_t *__restrict__ cursor,
                                                      uint32_t *__restrict__ vertex, uint4 *__restrict__ meta,
@@ -3072,26 +3074,35 @@ __global__ __launch_bounds__(256) void k_deg_scatter(GraphDev g, uint32_t row_lo
     __shared__ uint32_t local[4096];
     for (uint32_t i = threadIdx.x; i < bins; i += blockDim.x) local[i] = 0;
     __syncthreads();
-    const uint32_t u = row_lo + blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t rs = 0, re = 0, cls = 0xFFFFFFFFu, rank_in_block = 0;
-    if (u < row_hi) {
-        rs = g.rowptr[u];
-        re = g.rowptr[u + 1];
-        const uint32_t d = re - rs;
-        const bool skip = skip_rowptr && skip_rowptr[u + 1] - skip_rowptr[u] >= skip_from;
-        if (d < long_thresh && !skip) {
-            cls = deg_class(d, bins);
-            rank_in_block = atomicAdd(&local[cls], 1u);
+    const uint32_t u0 = row_lo + blockIdx.x * (blockDim.x * kDegScatterRows) + threadIdx.x;
+    uint32_t rs[kDegScatterRows], re[kDegScatterRows], cls[kDegScatterRows], rank_in_block[kDegScatterRows];
+#pragma unroll
+    for (int k = 0; k < kDegScatterRows; ++k) {
+        const uint32_t u = u0 + k * blockDim.x;
+        cls[k] = 0xFFFFFFFFu;
+        rs[k] = re[k] = rank_in_block[k] = 0;
+        if (u < row_hi) {
+            rs[k] = g.rowptr[u];
+            re[k] = g.rowptr[u + 1];
+            const uint32_t d = re[k] - rs[k];
+            const bool skip = skip_rowptr && skip_rowptr[u + 1] - skip_rowptr[u] >= skip_from;
+            if (d < long_thresh && !skip) {
+                cls[k] = deg_class(d, bins);
+                rank_in_block[k] = atomicAdd(&local[cls[k]], 1u);
+            }
         }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < bins; i += blockDim.x)
         if (local[i]) local[i] = atomicAdd(&cursor[i], local[i]);   // now the block's base slot of class i
     __syncthreads();
-    if (cls != 0xFFFFFFFFu) {
-        const uint32_t slot = local[cls] + rank_in_block;
-        vertex[slot] = u;
-        meta[slot] = make_uint4(rs, re, g.w[u], g.nw[u]);
+#pragma unroll
+    for (int k = 0; k < kDegScatterRows; ++k) {
+        if (cls[k] != 0xFFFFFFFFu) {
+            const uint32_t u = u0 + k * blockDim.x, slot = local[cls[k]] + rank_in_block[k];
+            vertex[slot] = u;
+            meta[slot] = make_uint4(rs[k], re[k], g.w[u], g.nw[u]);
+        }
     }
 }
 
@@ -4266,7 +4277,7 @@ hipError_t degree_scatter(const GraphDev &g, uint32_t row_lo, uint32_t row_hi, u
                           uint32_t bins, uint32_t *cursor, uint32_t *vertex, void *meta, hipStream_t stream,
                           const uint32_t *skip_rowptr, uint32_t skip_from) {
     if (row_hi <= row_lo) return hipSuccess;
-    GNNVC_LAUNCH(k_deg_scatter, dim3((row_hi - row_lo + 255) / 256), dim3(256), 0, stream, g, row_lo, row_hi,
+    GNNVC_LAUNCH(k_deg_scatter, dim3((row_hi - row_lo + 256 * kDegScatterRows - 1) / (256 * kDegScatterRows)), dim3(256), 0, stream, g, row_lo, row_hi,
                        long_thresh, bins, cursor, vertex, reinterpret_cast<uint4 *>(meta), skip_rowptr, skip_from);
     return hipGetLastError();
 }

@@ -57,11 +57,9 @@ int find_giant(gnnvc_engine *e) {
     }
     HIP_TRY(e, hipMemcpy(e->gi_meta.p, meta.data(), ((size_t)cnt + 1) * sizeof(uint4), hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(e->gi_off.p, off.data(), (size_t)cnt * sizeof(unsigned long long), hipMemcpyHostToDevice));
-    if (!e->giant_stream) {
-        int lo_p = 0, hi_p = 0;   // (numerically lower = higher priority)
-        HIP_TRY(e, hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
-        HIP_TRY(e, hipStreamCreateWithPriority(&e->giant_stream, hipStreamNonBlocking, hi_p));
-        HIP_TRY(e, hipEventCreateWithFlags(&e->ev_giant, hipEventDisableTiming));
+    {
+        int rc = ensure_side_streams(e);
+        if (rc) return rc;
     }
     e->n_giant = cnt;
     e->giant_blocks = (uint32_t)blocks;
@@ -161,11 +159,9 @@ int find_long(gnnvc_engine *e) {
         HIP_TRY(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
         HIP_TRY(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     }
-    if (!e->long_stream) {
-        int lo_p = 0, hi_p = 0;   // (numerically lower = higher priority)
-        HIP_TRY(e, hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
-        HIP_TRY(e, hipStreamCreateWithPriority(&e->long_stream, hipStreamNonBlocking, e->opt_long_priority ? hi_p : lo_p));
-        HIP_TRY(e, hipEventCreateWithFlags(&e->ev_long, hipEventDisableTiming));
+    {
+        int rc = ensure_side_streams(e);
+        if (rc) return rc;
     }
     e->n_long = cnt;
     e->long_thresh = thresh;
@@ -776,6 +772,25 @@ int build_blocked(gnnvc_engine *e) { return timed_build(e, [&] { return build_bl
 int build_lds_table(gnnvc_engine *e) { return timed_build(e, [&] { return build_lds_table_impl(e); }); }
 int build_compact(gnnvc_engine *e, uint32_t base, uint32_t end, bool allow_mapped) {
     return timed_build(e, [&] { return build_compact_impl(e, base, end, allow_mapped); });
+}
+
+// The queues of the long and the giant rows.  Made once per ENGINE (gnnvc_create): creating a stream takes ~10 ms on this
+// stack (scratch/experiments/stream_cost.py; 2.5 ms when the runtime has a destroyed one to reuse) — three of them inside the
+// first skewed graph's hand-off were most of what a fresh engine's attach took (R-MAT-22: 14 - 17 ms of which 1.7 ms are work).
+int ensure_side_streams(gnnvc_engine *e) {
+    if (!e->long_stream) {
+        // (the device's highest priority was tried for this queue — a long row is a chain, the stage's critical path when it
+        // waits for the tile kernel's workgroups to leave a CU — and changed nothing: 3.97 vs 3.99 ms, R-MAT-22's first forward)
+        HIP_TRY(e, hipStreamCreateWithFlags(&e->long_stream, hipStreamNonBlocking));
+        HIP_TRY(e, hipEventCreateWithFlags(&e->ev_long, hipEventDisableTiming));
+    }
+    if (!e->giant_stream) {
+        int lo_p = 0, hi_p = 0;   // (numerically lower = higher priority)
+        HIP_TRY(e, hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+        HIP_TRY(e, hipStreamCreateWithPriority(&e->giant_stream, hipStreamNonBlocking, hi_p));
+        HIP_TRY(e, hipEventCreateWithFlags(&e->ev_giant, hipEventDisableTiming));
+    }
+    return GNNVC_OK;
 }
 
 int ensure_round_events(gnnvc_engine *e, size_t count) {
