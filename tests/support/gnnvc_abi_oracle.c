@@ -59,6 +59,12 @@ int gnnvc_create_multi(gnnvc_engine **out, const char *text, size_t len, const i
     return gnnvc_create(out, text, len, devices[0]);
 }
 
+/* (the double has no plans to switch: every option is accepted and changes nothing) */
+int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
+    (void)value;
+    return (e && key) ? GNNVC_OK : GNNVC_ERR_INVALID;
+}
+
 static void drop_graph(gnnvc_engine *e) {
     free(e->rowptr); free(e->col); free(e->w); free(e->nw);
     e->rowptr = NULL; e->col = e->w = e->nw = NULL;
