@@ -101,6 +101,14 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *                         rows (default 65536, 0 = off) picks the next stage's table columns ahead of the real run, which
  *                         then writes the table on its way; the choice is re-made from the counts of all rows, so the pilot
  *                         changes time, never a result
+ *   "filter_zero_rows" 0|1  a large skewed graph's FIRST forward (the reference's driver never comes back for a second): its
+ *                         16-wide stages look every entry's target up in the bitmap of this input's all-zero rows and fetch the
+ *                         pad row instead, the long rows walk lists a pass in front of them shortened — nothing is built, the
+ *                         pruned adjacency ("prune_zero_rows") waits for a second forward (default 1; bit-identical either
+ *                         way).  "filter_min_entries" (default 48 Mi) / "filter_min_long_percent" (25: the share of the
+ *                         entries in long rows) say which graphs, "filter_min_percent" (50) from which share of the entries
+ *                         pointing to zero rows the device uses the bitmap, "filter_keep_lists" 0 = every stage shortens the
+ *                         full rows.  gnnvc_get_info: "filtered_stage1|2", "short_lists_stage2", "filter_mass_percent_stage1|2"
  *   "blocked_stage0" 0|1  column-blocked plan of the F = 1 stage (default 1; results are
  *                         bit-identical either way, it only changes memory traffic)
  *   "lds_table"      0|1|2  LDS-table plan of the F = 1 stage: when every weight fits a byte and the
