@@ -13,9 +13,15 @@ import csv, glob
 f = glob.glob("gpurun_out/ff_trace/**/*kernel_trace.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if "gnnvc" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# the forward = from the first stage kernel (k_zero_row / k_stage_f1) on
+# the forward = from its first kernel on: the pilot run of the F = 1 stage kernel (the hand-off's kernels — row classes, the two
+# plans' builders — come before it and are listed above the line)
 names = [r["Kernel_Name"] for r in rows]
-start = next(i for i, n in enumerate(names) if "k_stage_f1" in n or "k_zero_row" in n)
+start = next(i for i, n in enumerate(names) if "k_stage_f1<" in n)
+print("hand-off (attach) of a fresh engine, metric graph: kernel, start offset us from the forward's first kernel, duration us")
+t_f = int(rows[start]["Start_Timestamp"])
+for r in rows[:start]:
+    n = r["Kernel_Name"]
+    print(f"  {n[n.find('k_'):].split('(')[0][:60]:62s} {(int(r['Start_Timestamp']) - t_f) / 1e3:10.1f}  {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:9.1f}")
 t0 = int(rows[start]["Start_Timestamp"])
 print("one forward of a fresh engine, metric graph (ER 10 M / 100 M): kernel, queue, start offset us, duration us")
 queues = {}
