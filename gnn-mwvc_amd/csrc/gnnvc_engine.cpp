@@ -275,16 +275,24 @@ int choose_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const flo
 // fork: the long (and giant) rows of this stage beside the tile kernel
 int launch_side_rows(gnnvc_engine *e, const GraphDev &gv, int stage, uint32_t lo, uint32_t hi, const float *in, float *out,
                      float *logits, uint32_t thr) {
+    // One side queue beside the main one (ensure_side_streams).  The giant rows' walk is a latency chain on a few waves and
+    // always goes there; the long rows join it — unless that walk is what a stage waits for (find_giant: the power-law graph),
+    // then they run ahead of the tile kernel on the main queue instead: power-law 1 M 0.89 ms (long rows beside the giant
+    // walk: 1.15), R-MAT-22 2.62 ms (long rows on the main queue: 2.79).
     const bool side = e->opt_side_streams != 0;
-    hipStream_t s_long = side ? e->long_stream : e->stream, s_giant = side ? e->giant_stream : e->stream;
+    const bool long_on_main = side && (e->opt_long_on_main < 0 ? (e->n_giant != 0 && e->giant_walk_bound) : e->opt_long_on_main != 0);
+    const bool side_long = side && !long_on_main;
+    hipStream_t s_long = side_long ? e->long_stream : e->stream;
+    hipStream_t s_giant = !side ? e->stream : (long_on_main ? e->giant_stream : e->long_stream);
+    e->side_join = !side ? 0 : (long_on_main ? 2 : 1);
     if (side) {
         HIP_TRY(e, hipEventRecord(e->ev_fork, e->stream));
-        HIP_TRY(e, hipStreamWaitEvent(e->long_stream, e->ev_fork, 0));
+        if (side_long) HIP_TRY(e, hipStreamWaitEvent(e->long_stream, e->ev_fork, 0));
     }
     // rows from this degree on go the giant way in this stage (hub_mode 1: every long row does)
     const uint32_t giant_from = e->stages[stage].f == 16 ? e->giant_f16() : e->giant_thresh;
     if (e->n_giant) {   // the heaviest rows: beside the tile kernel AND beside the other long rows
-        if (side) HIP_TRY(e, hipStreamWaitEvent(e->giant_stream, e->ev_fork, 0));
+        if (long_on_main) HIP_TRY(e, hipStreamWaitEvent(e->giant_stream, e->ev_fork, 0));
         gnnvc::GiantRows gr;
         gr.n = e->n_giant;
         gr.blocks = e->giant_blocks;
@@ -299,14 +307,14 @@ int launch_side_rows(gnnvc_engine *e, const GraphDev &gv, int stage, uint32_t lo
         }
         HIP_TRY(e, gnnvc::launch_giant_stage(e->stages[stage], e->opt_prune_giant ? gv : e->g, e->ws, e->params.p, in, out, logits, lo, hi, gr,
                                              e->opt_hub_mode == 1, s_giant, giant_from));
-        if (side) HIP_TRY(e, hipEventRecord(e->ev_giant, e->giant_stream));
+        if (long_on_main) HIP_TRY(e, hipEventRecord(e->ev_giant, e->giant_stream));
     }
     // (with rows classed by the entries they have left, k_long_* takes rows from gv.eff_thresh entries on whatever their degree)
     const uint32_t long_from = gv.prune_eff ? std::min(thr, gv.eff_thresh) : thr;
     if ((e->n_giant < e->n_long || giant_from > e->giant_thresh) && long_from < giant_from)   // (equal: a plan or the giant kernels have every row in between)
         HIP_TRY(e, gnnvc::launch_long_stage(e->stages[stage], gv, e->ws, e->params.p, in, out, logits, lo, hi,
                                             e->long_list.p, e->n_long, thr, giant_from, s_long));
-    if (side) HIP_TRY(e, hipEventRecord(e->ev_long, e->long_stream));
+    if (side_long) HIP_TRY(e, hipEventRecord(e->ev_long, e->long_stream));
     return GNNVC_OK;
 }
 
@@ -440,9 +448,9 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
     }
     rc = launch_main(e, c, gv, so_p, stage, lo, hi, in, out, logits);
     if (rc) return rc;
-    if (longs && e->opt_side_streams) {   // join
-        HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_long, 0));
-        if (e->n_giant) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_giant, 0));
+    if (longs && e->side_join) {   // join: the side queue's last kernel of this stage
+        if (e->side_join == 1) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_long, 0));
+        else if (e->n_giant) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_giant, 0));
     }
     return GNNVC_OK;
 }
@@ -531,7 +539,6 @@ int gnnvc_create(gnnvc_engine **out, const char *model_text, size_t len, int dev
         // (creating a stream takes ~10 ms on this stack: the side queues are made here, once per engine, not inside the first
         // hand-off or forward that wants them)
         if (rc == GNNVC_OK) rc = ensure_round_events(e, 0);
-        if (rc == GNNVC_OK) rc = ensure_side_streams(e);
         if (rc == GNNVC_OK) rc = upload_params(e);
     } catch (const std::bad_alloc &) {
         rc = GNNVC_ERR_NOMEM;
@@ -596,6 +603,8 @@ void gnnvc_destroy(gnnvc_engine *e) {
     e->c4_agg16.release(); e->c4_dirty.release(); e->c4_emit_counts.release();
     for (auto &pp : e->prune) { pp.prp.release(); pp.pcol.release(); pp.heavy.release(); pp.svertex.release(); pp.smeta.release(); }
     e->prune_flags.release(); e->prune_scratch.release(); e->prune_off.release(); e->prune_mask.release();
+    for (auto &b : e->filter_bits) b.release();
+    e->filter_info.release();
     e->long_list.release(); e->long_count.release();
     e->gi_meta.release(); e->gi_off.release(); e->gi_slab.release(); e->gi_agg.release(); e->gi_segsum.release(); e->gi_segmap.release();
     e->rowptr2.release(); e->col2.release(); e->der_old_row.release(); e->der_new_of.release(); e->der_tail.release();
@@ -612,8 +621,8 @@ void gnnvc_destroy(gnnvc_engine *e) {
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->aux_stream) { (void)hipStreamSynchronize(e->aux_stream); (void)hipStreamDestroy(e->aux_stream); }
     if (e->ev_long) (void)hipEventDestroy(e->ev_long);
-    if (e->long_stream) { (void)hipStreamSynchronize(e->long_stream); (void)hipStreamDestroy(e->long_stream); }
-    if (e->giant_stream) { (void)hipStreamSynchronize(e->giant_stream); (void)hipStreamDestroy(e->giant_stream); }
+
+
     if (e->ev_giant) (void)hipEventDestroy(e->ev_giant);
     for (auto v : e->ev) (void)hipEventDestroy(v);
     for (auto v : e->round_ev) (void)hipEventDestroy(v);
@@ -663,6 +672,7 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "prune_heavy_entries") { e->opt_prune_heavy_entries = value > 0 ? (uint64_t)value : 0; for (auto &pp : e->prune) pp.tried = pp.ready = false; }
     else if (k == "prune_early_entries") e->opt_prune_early_nnz = value > 0 ? (uint64_t)value : 0;
     else if (k == "prune_giant_rows") e->opt_prune_giant = value != 0 ? 1 : 0;
+    else if (k == "long_rows_on_main") e->opt_long_on_main = value < 0 ? -1 : (value != 0 ? 1 : 0);
     else if (k == "filter_zero_rows") e->opt_filter = value != 0 ? 1 : 0;
     else if (k == "filter_keep_lists") e->opt_filter_keep = value != 0 ? 1 : 0;
     else if (k == "filter_min_entries") e->opt_filter_min_nnz = value > 0 ? (uint64_t)value : 0;
@@ -706,6 +716,8 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
     else if (k == "compact_gather_rows_per_chunk") *value = e->c4_ready ? (long)e->c4_rows : 0;
     else if (k == "compact_gather_steps") *value = e->c4_ready ? (long)e->c4_steps_total : 0;
     else if (k == "pruned_stage1" || k == "pruned_stage2") *value = e->prune[k.back() - '0'].ready ? 1 : 0;
+    else if (k == "side_queue_probes") *value = e->side_probes;
+    else if (k == "side_queue_runs_beside") *value = e->side_beside ? 1 : 0;
     else if (k == "long_entries_percent") *value = e->n_long && e->g.nnz ? (long)(e->long_entries * 100ull / e->g.nnz) : 0;
     else if (k == "filtered_stage1" || k == "filtered_stage2") *value = e->filtered[k.back() - '0'] ? 1 : 0;
     else if (k == "short_lists_stage1" || k == "short_lists_stage2") *value = e->short_used[k.back() - '0'] ? 1 : 0;

@@ -226,6 +226,8 @@ struct gnnvc_engine {
     // Filtered gather: while a skewed graph's 16-wide stage has no pruned adjacency (the graph's first forward: the reference's
     // driver never comes back for a second), its kernels look every entry's target up in the bitmap of THIS input's all-zero
     // rows, written just before them, and fetch the pad row instead (GraphDev::zero_bits; nothing to build, nothing to prove).
+    int opt_long_on_main = -1;       // option "long_rows_on_main": -1 = by the graph (launch_side_rows), 0 = beside the giant rows on the side queue, 1 = ahead of the tile kernel
+    int side_join = 0;               // what the stage at hand joins on: 0 nothing, 1 the long rows' queue, 2 the giant rows' queue
     int opt_filter = 1;              // option "filter_zero_rows" (A/B): 0 = plain gathers until the plan is there
     // which graphs (measured, scratch/experiments/first_ab2.sh + fuzz_large.py: first forward with / without): R-MAT from ~48 M
     // entries on gains 0.5 - 1.6 ms (R-MAT-22 4.61 -> 3.98, R-MAT-24 19.3 -> 17.7, scale 21 x 16: 2.84 -> 2.30); smaller graphs
@@ -292,9 +294,11 @@ struct gnnvc_engine {
     uint64_t long_entries = 0;       // entries of the listed rows
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // the long rows' own queue (not the second queue of the overlapped rounds: its join event is its own)
+    // (the long rows' and the giant rows' stream handles: the side queue again — ensure_side_streams — with join events of their own)
     hipStream_t long_stream = nullptr;
     hipEvent_t ev_long = nullptr;
+    int side_probes = 0;             // streams tried until one ran beside the main stream (info "side_queue_probes")
+    bool side_beside = false;        // ... and whether one did (info "side_queue_runs_beside")
     hipStream_t giant_stream = nullptr;  // giant rows: three dependent launches, the side work's long pole -> a high-priority stream of its own
     hipEvent_t ev_giant = nullptr;
     // giant rows (degree >= giant_thresh, a subset of the long rows): CSR-order sums evaluated in parallel (exact_sum.h)

@@ -344,6 +344,8 @@ hipError_t narrow_rowptr(const void *in_u64, uint32_t *out, size_t count, hipStr
 
 // this zero-fills
 // the pad row of a feature matrix: rows [n, n+1) of an (n+1) x width buffer.
+// *yes = kernels on b run beside kernels on a (the two streams sit on different hardware queues); ~0.3 ms
+hipError_t streams_run_side_by_side(hipStream_t a, hipStream_t b, bool *yes);
 hipError_t launch_zero_pad_row(float *buf, uint32_t n, uint32_t width, hipStream_t stream);
 
 }  // namespace gnnvc

@@ -3827,6 +3827,40 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
     return hipGetLastError();
 }
 
+// Do kernels on stream b run BESIDE kernels on stream a?  HIP streams are placed on a small pool of HSA queues by the runtime
+// (four per priority; a new stream takes the one with the fewest users, ties included — which can be the queue of the very
+// stream it is meant to run beside: then everything on the two is serialised, and nothing tells).  One wave spins ~300 us on
+// a, an empty kernel goes to b: if b's is done while a's still spins, they are on different queues.
+__global__ void k_spin(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();   // (100 MHz)
+    for (int i = 0; i < (1 << 22) && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(16);
+}
+__global__ void k_nothing() {}
+
+hipError_t streams_run_side_by_side(hipStream_t a, hipStream_t b, bool *yes) {
+    *yes = false;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    hipError_t rc = hipEventCreateWithFlags(&ea, hipEventDisableTiming);
+    if (rc == hipSuccess) rc = hipEventCreateWithFlags(&eb, hipEventDisableTiming);
+    if (rc == hipSuccess) {
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, 30000ull);
+        rc = hipEventRecord(ea, a);
+    }
+    if (rc == hipSuccess) {
+        hipLaunchKernelGGL(k_nothing, dim3(1), dim3(64), 0, b);
+        rc = hipEventRecord(eb, b);
+    }
+    if (rc == hipSuccess) rc = hipEventSynchronize(eb);
+    if (rc == hipSuccess) {
+        *yes = hipEventQuery(ea) == hipErrorNotReady;
+        rc = hipEventSynchronize(ea);
+    }
+    if (ea) (void)hipEventDestroy(ea);
+    if (eb) (void)hipEventDestroy(eb);
+    (void)hipGetLastError();   // (hipErrorNotReady is sticky for hipGetLastError)
+    return rc;
+}
+
 hipError_t launch_graph_layer(const GraphDev &g, float ws, uint32_t f, const float *in,
                               float *out, hipStream_t stream) {
     const size_t work = (size_t)g.n * (2 * f + 3);

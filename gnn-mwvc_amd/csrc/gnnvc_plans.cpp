@@ -154,11 +154,6 @@ int find_long(gnnvc_engine *e) {
     }
     e->long_entries = (uint64_t)found[2] | ((uint64_t)found[3] << 32);
     if (cnt == 0) return GNNVC_OK;   // nothing long: the tile kernels keep every row
-    if (!e->aux_stream) {
-        HIP_TRY(e, hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking));
-        HIP_TRY(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
-        HIP_TRY(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
-    }
     {
         int rc = ensure_side_streams(e);
         if (rc) return rc;
@@ -774,30 +769,44 @@ int build_compact(gnnvc_engine *e, uint32_t base, uint32_t end, bool allow_mappe
     return timed_build(e, [&] { return build_compact_impl(e, base, end, allow_mapped); });
 }
 
-// The queues of the long and the giant rows.  Made once per ENGINE (gnnvc_create): creating a stream takes ~10 ms on this
-// stack (scratch/experiments/stream_cost.py; 2.5 ms when the runtime has a destroyed one to reuse) — three of them inside the
-// first skewed graph's hand-off were most of what a fresh engine's attach took (R-MAT-22: 14 - 17 ms of which 1.7 ms are work).
+// The engine's SIDE queue, made once per engine (gnnvc_create): what runs beside the main stream's kernels — the dense part of a
+// round under the next round's sums, the long and giant rows beside the tile kernel, the plan builders of a hand-off beside the
+// copy.  ONE side queue, not one per purpose (round 3): with the long rows, the giant rows and the overlapped rounds each on a
+// stream of their own, where the runtime placed those streams decided the forward's time — power-law 1 M 0.91 or 1.49 ms, R-MAT-22
+// 2.66 or 2.85, R-MAT-20 0.80 or 1.05 - 1.5 — by how many other engines the process had alive
+// (scratch/experiments/queue_pressure.py; priorities did not stabilise it).  A HIP stream goes to the hardware queue with the
+// fewest users, ties included, which can be the main stream's own queue: then the two are serialised (R-MAT-22 3.44 ms) — so
+// the candidate is PROBED (streams_run_side_by_side, 0.3 ms) and replaced until one runs beside the main stream.  Creating a
+// stream costs ~10 ms on this stack (scratch/experiments/stream_cost.py): none is made inside a hand-off or a forward.
 int ensure_side_streams(gnnvc_engine *e) {
-    if (!e->long_stream) {
-        // (the device's highest priority was tried for this queue — a long row is a chain, the stage's critical path when it
-        // waits for the tile kernel's workgroups to leave a CU — and changed nothing: 3.97 vs 3.99 ms, R-MAT-22's first forward)
-        HIP_TRY(e, hipStreamCreateWithFlags(&e->long_stream, hipStreamNonBlocking));
-        HIP_TRY(e, hipEventCreateWithFlags(&e->ev_long, hipEventDisableTiming));
+    if (e->aux_stream) return GNNVC_OK;
+    hipStream_t tried[4] = {nullptr, nullptr, nullptr, nullptr};
+    int n = 0;
+    hipStream_t good = nullptr;
+    while (n < 4 && !good) {
+        HIP_TRY(e, hipStreamCreateWithFlags(&tried[n], hipStreamNonBlocking));
+        bool beside = false;
+        HIP_TRY(e, gnnvc::streams_run_side_by_side(e->stream, tried[n], &beside));
+        if (beside) good = tried[n];
+        ++n;
     }
-    if (!e->giant_stream) {
-        int lo_p = 0, hi_p = 0;   // (numerically lower = higher priority)
-        HIP_TRY(e, hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
-        HIP_TRY(e, hipStreamCreateWithPriority(&e->giant_stream, hipStreamNonBlocking, hi_p));
-        HIP_TRY(e, hipEventCreateWithFlags(&e->ev_giant, hipEventDisableTiming));
-    }
+    e->side_probes = n;
+    e->side_beside = good != nullptr;
+    if (!good) good = tried[n - 1];   // (none passed: a serialised side queue is slow, not wrong)
+    for (int i = 0; i < n; ++i)
+        if (tried[i] != good) (void)hipStreamDestroy(tried[i]);
+    e->aux_stream = e->long_stream = e->giant_stream = good;
+    HIP_TRY(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    HIP_TRY(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    HIP_TRY(e, hipEventCreateWithFlags(&e->ev_long, hipEventDisableTiming));
+    HIP_TRY(e, hipEventCreateWithFlags(&e->ev_giant, hipEventDisableTiming));
     return GNNVC_OK;
 }
 
 int ensure_round_events(gnnvc_engine *e, size_t count) {
-    if (!e->aux_stream) {
-        HIP_TRY(e, hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking));
-        HIP_TRY(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
-        HIP_TRY(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    {
+        int rc = ensure_side_streams(e);
+        if (rc) return rc;
     }
     while (e->round_ev.size() < count) {
         hipEvent_t v;
