@@ -109,6 +109,11 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *                         entries in long rows) say which graphs, "filter_min_percent" (50) from which share of the entries
  *                         pointing to zero rows the device uses the bitmap, "filter_keep_lists" 0 = every stage shortens the
  *                         full rows.  gnnvc_get_info: "filtered_stage1|2", "short_lists_stage2", "filter_mass_percent_stage1|2"
+ *   "long_rows_on_main" -1|0|1  where the long rows' kernels run: the engine has ONE side queue beside its main stream (probed at
+ *                         creation to sit on another hardware queue: gnnvc_get_info "side_queue_probes" / "side_queue_runs_beside");
+ *                         the giant rows always take it, the long rows join them there (0) or run ahead of the tile kernel on the
+ *                         main stream (1); -1 (default) = by the graph: on the main stream when the longest giant row's walk is
+ *                         what a stage waits for
  *   "blocked_stage0" 0|1  column-blocked plan of the F = 1 stage (default 1; results are
  *                         bit-identical either way, it only changes memory traffic)
  *   "lds_table"      0|1|2  LDS-table plan of the F = 1 stage: when every weight fits a byte and the
