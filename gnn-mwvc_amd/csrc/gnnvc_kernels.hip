@@ -329,11 +329,10 @@ __device__ __forceinline__ void c4_emit(const float *trow, uint32_t nz, uint32_t
 // input, a moment ago), and an entry that points to one of them gathers the pad row instead — an L1 hit, not a request to the
 // fabric, which on R-MAT-22 is what 73 - 86 % of the entries would otherwise be.  x + 0 == x: the same sums, bit for bit, with
 // nothing to build and nothing to prove (the set is this input's own).
-// is the set worth a look-up per entry?  (uniform; whole graphs: zero_min_pct of the entries point into it, if the adjacency is
-// symmetric; a slice knows only its own rows' degrees: one vertex in fifty is in it)
+// is the set worth a look-up per entry?  (uniform: zero_min_pct of the entries point into it, if the adjacency is symmetric — the
+// degrees of the set's vertices AMONG THE ROWS THIS ENGINE HOLDS against the entries it holds: a slice sees its own share of both)
 __device__ __forceinline__ bool filter_worth_info(const GraphDev &g, const unsigned long long *info) {
-    const unsigned long long mass = info[0], members = info[1];
-    return g.sliced_dev() ? members * 50ull >= g.n : mass * 100ull >= g.nnz * (unsigned long long)g.zero_min_pct;
+    return info[0] * 100ull >= g.nnz * (unsigned long long)g.zero_min_pct;
 }
 __device__ __forceinline__ bool filter_worth(const GraphDev &g) { return g.zero_bits != nullptr && filter_worth_info(g, g.zero_info); }
 

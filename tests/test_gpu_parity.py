@@ -929,6 +929,19 @@ def test_filtered_first_forward_is_bit_identical(model_text, oracle_model, maker
         assert np.array_equal(bits(logits[:, 0]), bits(want_logits))
     finally:
         e.close()
+    # the same once-scored graph cut into three parts behind one handle: every part filters with the whole input's bitmap and
+    # shortens the lists of the long rows IT holds
+    m = G.Engine(model_text, devices=[0, 0, 0])
+    try:
+        for k, v in (("blocked_min_n", 0), ("long_row_threshold", 256), ("sorted_long_row_threshold", 512), ("giant_row_threshold", 4096),
+                     ("filter_min_entries", 0), ("filter_min_long_percent", 0), ("filter_min_percent", min_percent)):
+            m.set_option(k, v)
+        m.set_weight_scale(g.ws)
+        m.upload_graph(g)
+        _, logits = m.forward(g.x())
+        assert np.array_equal(bits(logits[:, 0]), bits(want_logits))
+    finally:
+        m.close()
 
 
 def test_compact_gather_plan_steps_aside_for_good(model_text, oracle_model):
