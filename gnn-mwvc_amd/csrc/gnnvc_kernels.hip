@@ -917,7 +917,6 @@ constexpr int kLongChunk = 256;
 // quad: rows q + 64 j of the round) go through the LDS slab 256 at a time and threads
 // 0..15 add them, column by column, in CSR order.
 constexpr int kLongR = 16;
-constexpr uint32_t kLongRound = 64 * kLongR;
 // first-class vector type (HIP's float4 is a struct: arrays of it that live across loop
 // iterations are not promoted to registers)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -928,13 +927,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // over all 64 banks (260 % 64 = 4) and the four column groups of the writers over 16-bank strides.
 constexpr int kLongStride = kLongChunk + 4;
 
-__device__ __forceinline__ void long_drain_round(const f32x4 (&rows)[kLongR], float (&slab)[2][kLongStride * 16],
-                                                 uint32_t left_round, int tid, int q, int c, float &acc) {
+// (R: neighbours per quad and round / 64 — 16, or 4 in the filtered variant, whose rounds are one quarter; `qc` counts the quarters
+// drained so far: the slab buffers alternate with IT, not with the quarter's place in its round, which for R = 16 is the same)
+template <int R>
+__device__ __forceinline__ void long_drain_round(const f32x4 (&rows)[R], float (&slab)[2][kLongStride * 16],
+                                                 uint32_t left_round, int tid, int q, int c, float &acc, uint32_t &qc) {
 #pragma unroll
-    for (int sub = 0; sub < kLongR / 4; ++sub) {
+    for (int sub = 0; sub < R / 4; ++sub) {
         // slab entry k of this quarter = neighbour sub*256 + k of the round  <->  (j = 4 sub + k / 64, q = k % 64)
         if ((uint32_t)(sub * kLongChunk) < left_round) {   // block-uniform
-            float *buf = slab[sub & 1];
+            float *buf = slab[qc & 1u];
+            ++qc;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const f32x4 r = rows[4 * sub + jj];
@@ -964,7 +967,7 @@ __device__ __forceinline__ void long_drain_round(const f32x4 (&rows)[kLongR], fl
                 }
                 for (; k < cnt; ++k) acc += col[k];
             }
-            // slab[sub & 1] is rewritten two quarters later, after the barrier of the next
+            // this buffer is rewritten two quarters later, after the barrier of the next
             // quarter, which the adders reach only when these reads are done
         }
     }
@@ -1028,8 +1031,11 @@ __global__ __launch_bounds__(256) void k_long_lists(GraphDev g, uint32_t row_lo,
 }
 
 // FILTER: the row's list is the one k_long_lists wrote for this call (when the set was worth it: the same test there and here).
+// Most of those lists are short (R-MAT-22: 35 K rows, a few hundred targets left in most), and a workgroup's time on a short
+// list is its start-up — two dependent fetches, one quarter, the dense tail — so the filtered variant takes rounds of a QUARTER
+// (4 neighbour rows per quad in flight per set instead of 16): a third of the registers, twice the workgroups per CU.
 template <int N1, int N2, int N3, bool SIGMOID, bool FILTER = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_long_f16(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_long_f16(
         GraphDev g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
         float *__restrict__ logits, const float *__restrict__ P, uint32_t row_lo, uint32_t row_hi,
         const uint32_t *__restrict__ list, uint32_t min_deg, uint32_t max_deg) {
@@ -1052,10 +1058,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // Two register sets (A, B) alternate: while one round drains through the slab, the
     // 1024 row fetches of the next round and the column indices of the round after it are
     // in flight, so neither memory latency sits on the sequential add chain.
-    constexpr int R = kLongR;
-    constexpr uint32_t kRound = kLongRound;
+    constexpr int R = FILTER ? 4 : kLongR;
+    constexpr uint32_t kRound = 64u * R;
     const uint32_t nrounds = (gdeg + kRound - 1) / kRound;
-    uint32_t idx[R];
+    uint32_t idx[R], qc = 0;
     f32x4 ra[R], rb[R];
     const f32x4 *__restrict__ fv = reinterpret_cast<const f32x4 *>(fin);
 #define GNNVC_FETCH_IDX(rd_)                                              \
@@ -1079,11 +1085,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (uint32_t rd = 0; rd < nrounds; rd += 2) {
             GNNVC_FETCH_ROWS(rb, rd + 1)
             GNNVC_FETCH_IDX(rd + 2)
-            long_drain_round(ra, slab, gdeg - rd * kRound, tid, q, c, acc);
+            long_drain_round<R>(ra, slab, gdeg - rd * kRound, tid, q, c, acc, qc);
             if (rd + 1 >= nrounds) break;
             GNNVC_FETCH_ROWS(ra, rd + 2)
             GNNVC_FETCH_IDX(rd + 3)
-            long_drain_round(rb, slab, gdeg - (rd + 1) * kRound, tid, q, c, acc);
+            long_drain_round<R>(rb, slab, gdeg - (rd + 1) * kRound, tid, q, c, acc, qc);
         }
     }
 #undef GNNVC_FETCH_IDX
