@@ -913,10 +913,14 @@ __device__ __forceinline__ void wave_tail_f1(const GraphDev &g, float ws, const 
 
 constexpr int kLongChunk = 256;
 
-// One round of the long-row kernel: the 1024 rows a workgroup holds in registers (16 per
-// quad: rows q + 64 j of the round) go through the LDS slab 256 at a time and threads
-// 0..15 add them, column by column, in CSR order.
-constexpr int kLongR = 16;
+// One round of the long-row kernel: the 64 R neighbour rows a workgroup holds in registers (R per quad: rows q + 64 j of the
+// round) go through the LDS slab 256 at a time and threads 0..15 add them, column by column, in CSR order.  R was 16 (rounds of
+// 1024, 212 registers a wave, two workgroups per CU) until round 3: with the long rows on ONE side queue behind the giant rows
+// (see launch_side_rows) their kernel is on a stage's critical path, most of its rows are a few hundred to a few thousand
+// entries, and a workgroup's time on those is its start-up (two dependent fetches, a quarter, the dense tail) — with rounds
+// of a QUARTER (R = 4: 104 registers, four workgroups per CU) R-MAT-22 went 2.63 -> 2.46 ms, R-MAT-24 10.5 -> 9.5, power-law 1 M
+// 0.91 -> 0.86, R-MAT-20 0.94 -> 0.89 (R = 8: 2.52 / 9.85 / 0.87 / 0.91).
+constexpr int kLongR = 4;
 // first-class vector type (HIP's float4 is a struct: arrays of it that live across loop
 // iterations are not promoted to registers)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -927,8 +931,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // over all 64 banks (260 % 64 = 4) and the four column groups of the writers over 16-bank strides.
 constexpr int kLongStride = kLongChunk + 4;
 
-// (R: neighbours per quad and round / 64 — 16, or 4 in the filtered variant, whose rounds are one quarter; `qc` counts the quarters
-// drained so far: the slab buffers alternate with IT, not with the quarter's place in its round, which for R = 16 is the same)
+// (R: neighbour rows per quad and round; `qc` counts the quarters drained so far: the slab buffers alternate with IT, not with
+// the quarter's place in its round — a round of R = 4 is ONE quarter)
 template <int R>
 __device__ __forceinline__ void long_drain_round(const f32x4 (&rows)[R], float (&slab)[2][kLongStride * 16],
                                                  uint32_t left_round, int tid, int q, int c, float &acc, uint32_t &qc) {
@@ -1031,9 +1035,8 @@ __global__ __launch_bounds__(256) void k_long_lists(GraphDev g, uint32_t row_lo,
 }
 
 // FILTER: the row's list is the one k_long_lists wrote for this call (when the set was worth it: the same test there and here).
-// Most of those lists are short (R-MAT-22: 35 K rows, a few hundred targets left in most), and a workgroup's time on a short
-// list is its start-up — two dependent fetches, one quarter, the dense tail — so the filtered variant takes rounds of a QUARTER
-// (4 neighbour rows per quad in flight per set instead of 16): a third of the registers, twice the workgroups per CU.
+// (Most of those lists are short — R-MAT-22: 35 K rows, a few hundred targets left in most: the rounds of a quarter, kLongR,
+// were first measured here: first forward 4.03 -> 3.73 ms.)
 template <int N1, int N2, int N3, bool SIGMOID, bool FILTER = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_long_f16(
         GraphDev g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
@@ -1058,7 +1061,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     // Two register sets (A, B) alternate: while one round drains through the slab, the
     // 1024 row fetches of the next round and the column indices of the round after it are
     // in flight, so neither memory latency sits on the sequential add chain.
-    constexpr int R = FILTER ? 4 : kLongR;
+    constexpr int R = kLongR;
     constexpr uint32_t kRound = 64u * R;
     const uint32_t nrounds = (gdeg + kRound - 1) / kRound;
     uint32_t idx[R], qc = 0;
