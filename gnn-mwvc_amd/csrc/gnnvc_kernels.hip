@@ -1106,9 +1106,9 @@ __global__ __launch_bounds__(256) void k_long_f1(
         GraphDev g, float ws, const float *__restrict__ xin, float *__restrict__ fout,
         const float *__restrict__ P, uint32_t row_lo, uint32_t row_hi,
         const uint32_t *__restrict__ list, uint32_t min_deg, uint32_t max_deg) {
-    // a round = 2048 neighbours (8 per thread); values of round r + 1 and column indices of
+    // a round = 256 R neighbours (R per thread); values of round r + 1 and column indices of
     // round r + 2 are in flight while thread 0 adds round r from the LDS slab in CSR order
-    constexpr int R = 8;
+    constexpr int R = 4;   // (8 until round 3: rounds of 2048; 4: R-MAT-22 2.46 -> 2.44 ms, power-law 0.856 -> 0.834; 2: the same)
     constexpr uint32_t kRound = 256 * R;
     __shared__ __attribute__((aligned(16))) float slab[2][kRound];
     const uint32_t u = list[blockIdx.x];
