@@ -285,15 +285,11 @@ int launch_side_rows(gnnvc_engine *e, const GraphDev &gv, int stage, uint32_t lo
     hipStream_t s_long = side_long ? e->long_stream : e->stream;
     hipStream_t s_giant = !side ? e->stream : (long_on_main ? e->giant_stream : e->long_stream);
     e->side_join = !side ? 0 : (long_on_main ? 2 : 1);
-    if (side) {
-        HIP_TRY(e, hipEventRecord(e->ev_fork, e->stream));
-        if (side_long) HIP_TRY(e, hipStreamWaitEvent(e->long_stream, e->ev_fork, 0));
-    }
     // rows from this degree on go the giant way in this stage (hub_mode 1: every long row does)
     const uint32_t giant_from = e->stages[stage].f == 16 ? e->giant_f16() : e->giant_thresh;
-    if (e->n_giant) {   // the heaviest rows: beside the tile kernel AND beside the other long rows
-        if (long_on_main) HIP_TRY(e, hipStreamWaitEvent(e->giant_stream, e->ev_fork, 0));
-        gnnvc::GiantRows gr;
+    gnnvc::GiantRows gr;
+    bool gather_first = false;
+    if (e->n_giant) {
         gr.n = e->n_giant;
         gr.blocks = e->giant_blocks;
         gr.meta = e->gi_meta.p;
@@ -305,8 +301,24 @@ int launch_side_rows(gnnvc_engine *e, const GraphDev &gv, int stage, uint32_t lo
             gr.segmap = e->gi_segmap.p;
             gr.maxseg = e->gi_maxseg;
         }
+        // The giant rows' gather on the main queue, ahead of the fork (see launch_giant_stage) — where it is small (a throughput
+        // kernel that delays the tile kernel by what it takes alone: R-MAT-22's 7.5 M giant entries 0.03 - 0.05 ms, R-MAT-24's
+        // 64 M 0.3 - 0.6 ms) and the long rows are on the side queue behind the walk.  Measured: R-MAT-20 0.89 -> 0.83 ms
+        // (first forward 1.32 -> 1.20), R-MAT-22 first forward 3.75 -> 3.57 (steady the same); R-MAT-24 9.5 -> 10.8 and
+        // power-law 0.84 -> 0.87 the wrong way, hence the two conditions.
+        gather_first = side && (e->opt_giant_gather_first < 0 ? (!long_on_main && e->giant_entries <= (16ull << 20)) : e->opt_giant_gather_first != 0);
+        if (gather_first)
+            HIP_TRY(e, gnnvc::launch_giant_stage(e->stages[stage], e->opt_prune_giant ? gv : e->g, e->ws, e->params.p, in, out, logits, lo, hi,
+                                                 gr, e->opt_hub_mode == 1, e->stream, giant_from, /*part=*/1));
+    }
+    if (side) {
+        HIP_TRY(e, hipEventRecord(e->ev_fork, e->stream));
+        if (side_long) HIP_TRY(e, hipStreamWaitEvent(e->long_stream, e->ev_fork, 0));
+    }
+    if (e->n_giant) {   // the heaviest rows: beside the tile kernel
+        if (long_on_main) HIP_TRY(e, hipStreamWaitEvent(e->giant_stream, e->ev_fork, 0));
         HIP_TRY(e, gnnvc::launch_giant_stage(e->stages[stage], e->opt_prune_giant ? gv : e->g, e->ws, e->params.p, in, out, logits, lo, hi, gr,
-                                             e->opt_hub_mode == 1, s_giant, giant_from));
+                                             e->opt_hub_mode == 1, s_giant, giant_from, gather_first ? 2 : 0));
         if (long_on_main) HIP_TRY(e, hipEventRecord(e->ev_giant, e->giant_stream));
     }
     // (with rows classed by the entries they have left, k_long_* takes rows from gv.eff_thresh entries on whatever their degree)
@@ -672,6 +684,7 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "prune_heavy_entries") { e->opt_prune_heavy_entries = value > 0 ? (uint64_t)value : 0; for (auto &pp : e->prune) pp.tried = pp.ready = false; }
     else if (k == "prune_early_entries") e->opt_prune_early_nnz = value > 0 ? (uint64_t)value : 0;
     else if (k == "prune_giant_rows") e->opt_prune_giant = value != 0 ? 1 : 0;
+    else if (k == "giant_gather_first") e->opt_giant_gather_first = value < 0 ? -1 : (value != 0 ? 1 : 0);
     else if (k == "long_rows_on_main") e->opt_long_on_main = value < 0 ? -1 : (value != 0 ? 1 : 0);
     else if (k == "filter_zero_rows") e->opt_filter = value != 0 ? 1 : 0;
     else if (k == "filter_keep_lists") e->opt_filter_keep = value != 0 ? 1 : 0;

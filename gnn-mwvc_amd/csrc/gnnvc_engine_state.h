@@ -226,6 +226,7 @@ struct gnnvc_engine {
     // Filtered gather: while a skewed graph's 16-wide stage has no pruned adjacency (the graph's first forward: the reference's
     // driver never comes back for a second), its kernels look every entry's target up in the bitmap of THIS input's all-zero
     // rows, written just before them, and fetch the pad row instead (GraphDev::zero_bits; nothing to build, nothing to prove).
+    int opt_giant_gather_first = -1; // option "giant_gather_first": the giant rows' gather on the main queue ahead of the tile kernel (1), on the side queue with the rest of their chain (0), -1 = by the graph (launch_side_rows)
     int opt_long_on_main = -1;       // option "long_rows_on_main": -1 = by the graph (launch_side_rows), 0 = beside the giant rows on the side queue, 1 = ahead of the tile kernel
     int side_join = 0;               // what the stage at hand joins on: 0 nothing, 1 the long rows' queue, 2 the giant rows' queue
     int opt_filter = 1;              // option "filter_zero_rows" (A/B): 0 = plain gathers until the plan is there

@@ -168,7 +168,7 @@ hipError_t find_giant_rows(const GraphDev &g, const uint32_t *list, uint32_t n_l
                            hipStream_t stream);
 hipError_t launch_giant_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *in, float *out,
                               float *logits, uint32_t row_lo, uint32_t row_hi, const GiantRows &gr, bool fast, hipStream_t stream,
-                              uint32_t min_deg = 0 /* listed rows below this degree are another kernel's in this stage */);
+                              uint32_t min_deg = 0 /* listed rows below this degree are another kernel's in this stage */, int part = 0);
 hipError_t stream_sums(const float *streams_dev, uint32_t streams, uint32_t len, void *meta, unsigned long long *off, float *agg,
                        int mode /* 0 exact on several waves, 1 fast, 2 exact on one wave */, hipStream_t stream, float *segsum = nullptr,
                        void *segmap = nullptr);

@@ -4371,18 +4371,24 @@ uint32_t giant_window() { return kGiantWin; }
 uint32_t giant_block() { return kGiantBlk; }
 
 hipError_t launch_giant_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *in, float *out,
-                              float *logits, uint32_t row_lo, uint32_t row_hi, const GiantRows &gr, bool fast, hipStream_t stream, uint32_t min_deg) {
+                              float *logits, uint32_t row_lo, uint32_t row_hi, const GiantRows &gr, bool fast, hipStream_t stream, uint32_t min_deg,
+                              int part) {
+    // part: 0 = everything on `stream`, 1 = the gather only, 2 = everything behind the gather (the engine puts the gather — a
+    // throughput kernel, 0.03 ms alone — on the main queue AHEAD of the tile kernel and the walk on the side queue: queued
+    // beside the tile kernel it waited 0.2 - 0.3 ms for free slots at the head of the chain a stage waits for)
     if (gr.n == 0 || row_hi <= row_lo) return hipSuccess;
     const uint4 *meta = reinterpret_cast<const uint4 *>(gr.meta);
     const uint32_t F = sp.f == 16 ? 16u : 1u;
     const uint32_t *pr = sp.f == 16 ? g.prp : nullptr, *pb = sp.f == 16 ? g.prune_bad : nullptr;   // (pruned adjacency: 16-wide stages only)
-    if (sp.f == 16)
-        GNNVC_LAUNCH(k_giant_gather16, dim3(gr.blocks), dim3(256), 0, stream, g, reinterpret_cast<const float4 *>(in), gr.slab,
-                           meta, gr.off, gr.n, row_lo, row_hi, min_deg);
-    else if (sp.f == 1)
-        GNNVC_LAUNCH(k_giant_gather1, dim3(gr.blocks), dim3(256), 0, stream, g, in, gr.slab, meta, gr.off, gr.n, row_lo, row_hi);
-    else
-        return hipErrorInvalidValue;
+    if (sp.f != 16 && sp.f != 1) return hipErrorInvalidValue;
+    if (part != 2) {
+        if (sp.f == 16)
+            GNNVC_LAUNCH(k_giant_gather16, dim3(gr.blocks), dim3(256), 0, stream, g, reinterpret_cast<const float4 *>(in), gr.slab,
+                               meta, gr.off, gr.n, row_lo, row_hi, min_deg);
+        else
+            GNNVC_LAUNCH(k_giant_gather1, dim3(gr.blocks), dim3(256), 0, stream, g, in, gr.slab, meta, gr.off, gr.n, row_lo, row_hi);
+        if (part == 1) return hipGetLastError();
+    }
     if (fast) {
         GNNVC_LAUNCH(k_giant_sum<true>, dim3(gr.n * F), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.agg, row_lo, row_hi, pr, pb,
                      (const uint4 *)nullptr, 0u, min_deg);
