@@ -113,7 +113,9 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *                         creation to sit on another hardware queue: gnnvc_get_info "side_queue_probes" / "side_queue_runs_beside");
  *                         the giant rows always take it, the long rows join them there (0) or run ahead of the tile kernel on the
  *                         main stream (1); -1 (default) = by the graph: on the main stream when the longest giant row's walk is
- *                         what a stage waits for
+ *                         what a stage waits for.  "giant_gather_first" -1|0|1: the giant rows' gather on the main stream ahead
+ *                         of the tile kernel (1) or on the side queue with the rest of their chain (0); -1 (default) = on the
+ *                         main stream when it is small (at most 16 Mi giant entries) and the long rows are on the side queue
  *   "blocked_stage0" 0|1  column-blocked plan of the F = 1 stage (default 1; results are
  *                         bit-identical either way, it only changes memory traffic)
  *   "lds_table"      0|1|2  LDS-table plan of the F = 1 stage: when every weight fits a byte and the
