@@ -274,7 +274,7 @@ int choose_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const flo
 
 // fork: the long (and giant) rows of this stage beside the tile kernel
 int launch_side_rows(gnnvc_engine *e, const GraphDev &gv, int stage, uint32_t lo, uint32_t hi, const float *in, float *out,
-                     float *logits, uint32_t thr) {
+                     float *logits, uint32_t thr, bool plain_f1) {
     // One side queue beside the main one (ensure_side_streams).  The giant rows' walk is a latency chain on a few waves and
     // always goes there; the long rows join it — unless that walk is what a stage waits for (find_giant: the power-law graph),
     // then they run ahead of the tile kernel on the main queue instead: power-law 1 M 0.89 ms (long rows beside the giant
@@ -306,7 +306,11 @@ int launch_side_rows(gnnvc_engine *e, const GraphDev &gv, int stage, uint32_t lo
         // 64 M 0.3 - 0.6 ms) and the long rows are on the side queue behind the walk.  Measured: R-MAT-20 0.89 -> 0.83 ms
         // (first forward 1.32 -> 1.20), R-MAT-22 first forward 3.75 -> 3.57 (steady the same); R-MAT-24 9.5 -> 10.8 and
         // power-law 0.84 -> 0.87 the wrong way, hence the two conditions.
-        gather_first = side && (e->opt_giant_gather_first < 0 ? (!long_on_main && e->giant_entries <= (16ull << 20)) : e->opt_giant_gather_first != 0);
+        // ... or, however large, in an F = 1 stage that has no plan (a graph's first forward): every long row's chain is on the
+        // side queue there and the gather at its head waited for slots for as long as the tile kernel ran (R-MAT-24: 3.1 ms
+        // for a kernel that takes 0.6 alone; the stage 6.1 ms against the tile kernel's 3.3)
+        gather_first = side && (e->opt_giant_gather_first < 0 ? (!long_on_main && (e->giant_entries <= (16ull << 20) || plain_f1))
+                                                               : e->opt_giant_gather_first != 0);
         if (gather_first)
             HIP_TRY(e, gnnvc::launch_giant_stage(e->stages[stage], e->opt_prune_giant ? gv : e->g, e->ws, e->params.p, in, out, logits, lo, hi,
                                                  gr, e->opt_hub_mode == 1, e->stream, giant_from, /*part=*/1));
@@ -455,7 +459,8 @@ int run_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float 
     rc = gather_view(e, stage, lo, hi, in, c.sums == StageChoice::kGather, c.sorted.n != 0, gv, so_p, c.mfma, c.long_thresh);
     if (rc) return rc;
     if (longs) {
-        rc = launch_side_rows(e, gv, stage, lo, hi, in, out, logits, c.long_thresh);
+        rc = launch_side_rows(e, gv, stage, lo, hi, in, out, logits, c.long_thresh,
+                              /*plain_f1=*/e->stages[stage].f == 1 && c.sums == StageChoice::kGather);
         if (rc) return rc;
     }
     rc = launch_main(e, c, gv, so_p, stage, lo, hi, in, out, logits);
