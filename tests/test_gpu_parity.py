@@ -944,6 +944,24 @@ def test_filtered_first_forward_is_bit_identical(model_text, oracle_model, maker
         m.close()
 
 
+def test_side_queue_runs_beside_the_main_stream(model_text):
+    """HIP places a new stream on the hardware queue with the fewest users — ties included, which can be the queue of the
+    engine's own main stream: the two are then serialised and a forward with long rows takes 1.3 - 1.4 x as long.  Every engine
+    probes its side queue at creation and replaces it until a kernel on it finishes while the main stream is still busy
+    (gnnvc_get_info "side_queue_runs_beside" / "side_queue_probes"), whatever other engines the process has alive."""
+    import gnn_mwvc_amd as G
+    alive = []
+    try:
+        for k in range(6):
+            e = G.Engine(model_text, device=0)
+            alive.append(e)
+            assert 1 <= e.get_info("side_queue_probes") <= 4
+            assert e.get_info("side_queue_runs_beside") == 1, k
+    finally:
+        for e in alive:
+            e.close()
+
+
 def test_compact_gather_plan_steps_aside_for_good(model_text, oracle_model):
     """A graph whose stage inputs never fit the plan (low degrees: more than four live columns): after three forwards in a row
     that the device sent down the gathering kernels, the engine stops queuing the plan's counting, choosing and empty
