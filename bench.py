@@ -32,9 +32,10 @@ What the ONE JSON line on rank 0 says (contract in the project brief, read as VE
                         row-parallel aggregation its inert OpenMP pragma intended, and the parity checks: EVERY logit of
                         the timed graph, timed configuration, against the oracle (bitwise), every logit against the
                         stage-by-stage path, exact sampled rows.
-  workloads             the other single-GPU configs of BASELINE.json (er100k = configs[1], rmat22 = configs[2],
-                        powerlaw1m = configs[4]), each on a fresh engine: attach, first forward, steady state (K timed
-                        steps after W warm-ups), forward-level fraction, every logit against the oracle.
+  workloads             the other configs of BASELINE.json on one GPU (er100k = configs[1], rmat22 = configs[2], rmat24 =
+                        configs[3]'s graph unpartitioned, powerlaw1m = configs[4]) and er3m, each on a fresh engine: attach,
+                        first forward, steady state (K timed steps after W warm-ups), forward-level fraction, every logit
+                        of the steady state AND of a fresh engine's first forward against the oracle.
 """
 from __future__ import annotations
 
@@ -142,8 +143,8 @@ def main() -> int:
     ap.add_argument("--cpu-sample", default="",
                     help="CPU baseline on a bounded sample 'NxM' of the workload's family instead of the workload graph itself "
                          "(default: the graph itself — ~50 s of CPU work on the metric graph)")
-    ap.add_argument("--no-workloads", action="store_true", help="skip the `workloads` block (er100k, rmat22, powerlaw1m)")
-    ap.add_argument("--workloads", default="er100k,rmat22,powerlaw1m", help="comma-separated side workloads of the default run")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the `workloads` block (er100k, er3m, rmat22, rmat24, powerlaw1m)")
+    ap.add_argument("--workloads", default="er100k,er3m,rmat22,rmat24,powerlaw1m", help="comma-separated side workloads of the default run")
     ap.add_argument("--no-host-path", action="store_true", help="skip host_path_ms (PCIe-inclusive gnnvc_forward)")
     ap.add_argument("--no-blocked", action="store_true", help="disable the column-blocked F=1 stage (A/B)")
     ap.add_argument("--block-cols", type=int, default=0)
