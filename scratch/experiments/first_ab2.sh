@@ -25,19 +25,20 @@ def run(g, x, opts):
     steady = (time.perf_counter() - t) * 200
     e.close()
     return first, steady, info, lg.clone()
-cases = [("rmat", s, ef, 7 + s) for s in (18, 19, 20, 21, 22) for ef in (4, 8, 16)] + [("pl", 1_000_000, 16.0, 5), ("pl", 2_000_000, 10.0, 6)]
+cases = [("rmat", s, ef, 7 + s) for s in (19, 20, 21, 22) for ef in (4, 8, 16)] + [("pl", 1_000_000, 16.0, 5), ("pl", 2_000_000, 10.0, 6), ("pl", 4_000_000, 12.0, 7)]
 for c in cases:
     if c[0] == "rmat": g = ggt.rmat(c[1], c[2], c[3], dev)
     else: g = ggt.power_law_hubs(c[1], c[2], 2.1, 8, 65536, c[3], dev)
     x = g.x().contiguous()
-    run(g, x, {})
-    f1, s1, i1, l1 = run(g, x, {})
-    f1b, _, _, _ = run(g, x, {})
+    FORCE = {"filter_min_entries": 0}
+    run(g, x, FORCE)
+    f1, s1, i1, l1 = run(g, x, FORCE)
+    f1b, _, _, _ = run(g, x, FORCE)
     f0, s0, i0, l0 = run(g, x, {"filter_zero_rows": 0})
     f0b, _, _, _ = run(g, x, {"filter_zero_rows": 0})
-    f5, _, _, _ = run(g, x, {"filter_min_percent": 50})
+    f5, _, _, _ = run(g, x, {"filter_min_entries": 0, "filter_min_long_percent": 0})
     bad = int((l1.view(torch.int32) != l0.view(torch.int32)).sum())
-    print(f"{c} n {g.n} nnz {g.nnz}: first filter {min(f1, f1b):.3f} gate50 {f5:.3f} nofilter {min(f0, f0b):.3f} steady {s1:.3f}; {i1}; mismatches {bad}", flush=True)
+    print(f"{c} n {g.n} nnz {g.nnz}: first filter(any size) {min(f1, f1b):.3f} filter(any size, any long share) {f5:.3f} nofilter {min(f0, f0b):.3f} steady {s1:.3f}; {i1}; mismatches {bad}", flush=True)
     del g, x
     torch.cuda.empty_cache()
 PY
