@@ -48,6 +48,15 @@ for case in range(cases):
     opts["overlap_dense"] = int(rng.choice([0, 1]))
     if rng.random() < 0.3: opts["plan_chunk_rows"] = int(rng.choice([16, 48, 256, 4096]))
     if rng.random() < 0.5: opts["compact_first_forward_entries"] = 1   # the 16-wide stages' plan built inside the first forward
+    # round 3: the filtered gather of a graph's first forward, its bounds, where the long / giant rows' kernels are queued
+    opts["filter_zero_rows"] = int(rng.choice([0, 1, 1, 1]))
+    opts["filter_min_entries"] = 0
+    opts["filter_min_long_percent"] = int(rng.choice([0, 0, 25]))
+    opts["filter_min_percent"] = int(rng.choice([0, 1, 20, 50, 101]))
+    opts["filter_keep_lists"] = int(rng.choice([0, 1, 1]))
+    opts["long_rows_on_main"] = int(rng.choice([-1, 0, 1]))
+    opts["giant_gather_first"] = int(rng.choice([-1, 0, 1]))
+    opts["side_streams"] = int(rng.choice([0, 1, 1, 1]))
     e = G.Engine(G.default_model_text(), device=0)
     try:
         for k, v in opts.items():
