@@ -506,6 +506,10 @@ def main() -> int:
                    "exchange": "none" if not multi else "all-gather of the N feature rows (16 fp32, or only their live "
                                                           "columns) after each partitioned stage, N scores at the end"},
         "first_forward_ms": early_ms[0], "second_forward_ms": early_ms[1], "third_forward_ms": early_ms[2],
+        # a graph scored ONCE (the reference driver's call pattern, src/GNN_VC.cpp:171-192): edges/s of the first forward on
+        # the fresh graph, and its forward-level fraction
+        "score_once_value": n_edges / (early_ms[0] * 1e-3),
+        "first_forward_roofline_frac": fwd_bytes / (early_ms[0] * 1e-3) / 1e9 / world / HBM_PEAK_GBS,
         "plan_build_ms": plan_build_ms,
         "roofline": {"bound": "hbm",
                      "definition": "forward level (SURVEY.md 8d): (288 E + 300 N) algorithmic bytes / ms_per_step, per GPU",
@@ -567,6 +571,8 @@ def main() -> int:
             trials.append((a4, (time.perf_counter() - t4) * 1e3))
             e4.close()
             med = sorted(trials, key=lambda t: t[0] + t[1])[1]
+            out["score_once_value"] = n_edges / (med[1] * 1e-3)
+            out["first_forward_roofline_frac"] = fwd_bytes / (med[1] * 1e-3) / 1e9 / HBM_PEAK_GBS
             out["score_once"].update({"attach_ms": med[0], "first_forward_ms": med[1], "attach_plus_first_forward_ms": med[0] + med[1],
                                       "first_forward_over_steady": med[1] / ms_per_step,
                                       "trials_attach_first_ms": [[round(a, 3), round(f, 3)] for a, f in trials]})
@@ -849,6 +855,10 @@ def side_workload(name, args, dev, make_engine, ggt):
            "ms_per_step": ms, "value": g.n_edges / (ms * 1e-3), "unit": "edges/s",
            "attach_ms": attach_ms, "first_forward_ms": early[0], "attach_plus_first_forward_ms": attach_ms + early[0],
            "second_forward_ms": early[1], "third_forward_ms": early[2], "first_forward_over_steady": early[0] / ms,
+           # a graph scored ONCE — the reference driver's call pattern (src/GNN_VC.cpp:171-192): edges/s and the forward-level
+           # fraction of the FIRST forward on the fresh graph
+           "score_once_value": g.n_edges / (early[0] * 1e-3),
+           "first_forward_roofline_frac": fwd_bytes / (early[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "roofline_frac": fwd_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "forward_bytes": fwd_bytes,
            "plan": {"lds_table": bool(e.get_info("lds_table_active")), "compact_gather": bool(e.get_info("compact_gather_active")),
                     "pruned_stage1": bool(e.get_info("pruned_stage1")), "pruned_stage2": bool(e.get_info("pruned_stage2")),

@@ -945,7 +945,11 @@ int gnnvc_upload_graph(gnnvc_engine *e, uint32_t n, const uint64_t *rowptr, cons
     }
     e->early_open = e->early_declined = false;
     rc = handoff_early(e, n, nnz);   // (large graphs: classed now, plans begun — see handoff_early)
-    if (rc) return rc;
+    if (rc) {
+        e->early_open = false;
+        reset_graph_state(e);
+        return rc;
+    }
     if (e->early_open && (e->lt_pb.open || e->c4_pb.open)) {
         // the column array in pieces: while piece k + 1 crosses the bus the second stream regroups the slices piece k completed
         const uint64_t piece = 16ull << 20;
@@ -1028,9 +1032,15 @@ int gnnvc_staged_columns_ready(gnnvc_engine *e, uint64_t first, uint64_t count) 
         HIP_TRY(e, hipMemcpyAsync(e->w.p, e->pin_w.p, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
         HIP_TRY(e, hipMemcpyAsync(e->nw.p, e->pin_nw.p, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
         rc = handoff_early(e, n, e->staged_nnz);
-        if (rc) return rc;
     }
-    return handoff_progress(e, e->pin_rowptr.p, e->staged_n, e->staged_sent);
+    if (rc == GNNVC_OK) rc = handoff_progress(e, e->pin_rowptr.p, e->staged_n, e->staged_sent);
+    if (rc) {   // (e.g. row pointers the early builders must not see: the hand-off is over, the staging memory can be reused)
+        e->staging = false;
+        e->staged_sent = 0;
+        e->early_open = false;
+        reset_graph_state(e);
+    }
+    return rc;
 }
 
 int gnnvc_commit_staged_graph(gnnvc_engine *e) {
@@ -1090,19 +1100,10 @@ static int attach_common(gnnvc_engine *e, const GraphDev &cand) {
     e->der_open = false;
     int rc = reserve_features(e, cand.n);
     if (rc) return rc;
-    e->lt_ready = e->lt_tried = false;
-    e->c4_ready = e->c4_tried = false;
-    for (auto &pp : e->prune) pp.tried = pp.ready = pp.deferred = false;
-    e->short_from = 0;
-    for (int s = 0; s < 4; ++s) { e->c4_stage_off[s] = false; e->c4_unfit_runs[s] = 0; e->fit_used[s] = false; }
-    e->fit_pending = false;
-    e->c4_range_mode = false;
-    e->c4_prepared_stage = -1;
-    e->blocked_ready = false;   // the column-blocked index is built on the graph's SECOND forward:
-    e->blocked_tried = false;   // it costs about as much as it saves on one, and the reference's
-    e->graph_uses = 0;          // driver uses every graph exactly once (src/GNN_VC.cpp:171-192)
-    e->plan_build_ms = 0.0;
-    for (bool &b : e->c4_seeded) b = false;
+    // (a staged hand-off that opened the early builders may have been abandoned or refused before its commit: nothing of it —
+    // open plan builds with the OLD graph's geometry least of all — may reach prepare_plans with this graph)
+    reset_graph_state(e);
+    e->early_open = e->early_declined = false;
     rc = find_long(e);
     if (rc) return rc;
     return prepare_plans(e);   // ... which is why what depends on the graph alone is built here, not in a later forward

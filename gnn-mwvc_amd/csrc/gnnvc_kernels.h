@@ -340,6 +340,7 @@ hipError_t launch_reduction_flags(const GraphDev &g, uint32_t max_degree, uint8_
 // Device-side graph checks after an upload (*flags: bit0 column id out of range, bit1 bad
 // row pointers) and the uint64 -> uint32 row-pointer narrowing of the host ABI.
 hipError_t validate_graph(const GraphDev &g, uint32_t *flags, hipStream_t stream);
+hipError_t validate_rowptr(const GraphDev &g, uint32_t *flags, hipStream_t stream);   // row pointers only (bit1 as validate_graph)
 hipError_t narrow_rowptr(const void *in_u64, uint32_t *out, size_t count, hipStream_t stream);
 
 // this zero-fills

@@ -3684,10 +3684,24 @@ __global__ __launch_bounds__(256) void k_validate_graph(GraphDev g, uint32_t *__
     if (bad) atomicOr(flags, bad);
 }
 
-// uint64 row pointers (host ABI) -> uint32 (device layout)
+// the row pointers alone (a host hand-off has them on the device long before the column array: handoff_early classes the
+// graph and starts the flat plan builders from them, and those index the column and entry arrays with what they find here)
+__global__ __launch_bounds__(256) void k_validate_rowptr(GraphDev g, uint32_t *__restrict__ flags) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    uint32_t bad = 0;
+    const size_t r0 = g.lo(), r1 = g.hi();
+    for (size_t u = r0 + gid; u < r1; u += step)
+        if (g.rowptr[u] > g.rowptr[u + 1]) bad |= 2u;
+    if (gid == 0 && (g.rowptr[r0] != 0 || (uint64_t)g.rowptr[r1] != g.nnz)) bad |= 2u;
+    if (bad) atomicOr(flags, bad);
+}
+
+// uint64 row pointers (host ABI) -> uint32 (device layout); a value that does not fit saturates, so that the monotone /
+// "ends at nnz" checks see it instead of its low half
 __global__ void k_narrow_rowptr(const unsigned long long *__restrict__ in, uint32_t *__restrict__ out, size_t count) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) out[i] = (uint32_t)in[i];
+    if (i < count) out[i] = in[i] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)in[i];
 }
 
 __global__ void k_zero_row(float *buf, uint32_t n, uint32_t width) {
@@ -4562,6 +4576,13 @@ hipError_t validate_graph(const GraphDev &g, uint32_t *flags, hipStream_t stream
     hipError_t rc = hipMemsetAsync(flags, 0, sizeof(uint32_t), stream);
     if (rc != hipSuccess || g.n == 0) return rc;
     GNNVC_LAUNCH(k_validate_graph, dim3(2048), dim3(256), 0, stream, g, flags);
+    return hipGetLastError();
+}
+
+hipError_t validate_rowptr(const GraphDev &g, uint32_t *flags, hipStream_t stream) {
+    hipError_t rc = hipMemsetAsync(flags, 0, sizeof(uint32_t), stream);
+    if (rc != hipSuccess || g.n == 0) return rc;
+    GNNVC_LAUNCH(k_validate_rowptr, dim3(1024), dim3(256), 0, stream, g, flags);
     return hipGetLastError();
 }
 

@@ -1157,6 +1157,16 @@ int handoff_early(gnnvc_engine *e, uint32_t n, uint64_t nnz) {
     e->empty_slice = false;
     e->g = GraphDev{n, nnz, e->rowptr.p, e->col.p, e->w.p, e->nw.p};
     reset_graph_state(e);
+    {   // The flat builders read col[] and write the plans' entry arrays at offsets they take from the row pointers: those have
+        // to be known good BEFORE anything is classed or begun (the column ids are clamped where they index; the full check of
+        // the hand-off still runs at its end).  n + 1 words, and find_long waits for the row pointers anyway.
+        HIP_TRY(e, e->blk_flag.reserve(1));
+        HIP_TRY(e, gnnvc::validate_rowptr(e->g, e->blk_flag.p, e->stream));
+        uint32_t bad = 0;
+        HIP_TRY(e, hipMemcpyAsync(&bad, e->blk_flag.p, sizeof bad, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        if (bad) return fail(e, GNNVC_ERR_INVALID, "row pointers are not monotone from 0 to nnz");
+    }
     int rc = find_long(e);
     if (rc) return rc;
     const bool skewed = e->sorted_wanted || e->n_long > 0;

@@ -256,7 +256,10 @@ int gnnvc_attach_graph_slice(gnnvc_engine *e, uint32_t n_global, uint32_t row_lo
  *      (pieces must be announced in ascending order without gaps);
  *   4. gnnvc_commit_staged_graph(e) copies the rest, runs the same device-side checks as
  *      gnnvc_upload_graph and makes the graph current.
- * The pointers stay valid until the next gnnvc_graph_staging call with larger sizes. */
+ * The pointers stay valid until the next gnnvc_graph_staging call with larger sizes.
+ * An error from gnnvc_staged_columns_ready (e.g. GNNVC_ERR_INVALID for row pointers that are not monotone from 0 to nnz,
+ * which a large hand-off checks before it starts building from them) ends the hand-off: no graph is current, begin again
+ * at step 1. */
 int gnnvc_graph_staging(gnnvc_engine *e, uint32_t n, uint64_t nnz, uint32_t **rowptr, uint32_t **col,
                         uint32_t **w, uint32_t **nw);
 int gnnvc_staged_columns_ready(gnnvc_engine *e, uint64_t first, uint64_t count);

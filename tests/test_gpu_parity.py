@@ -305,6 +305,65 @@ def test_malformed_graphs_are_rejected(model_text):
         e.close()
 
 
+@pytest.mark.parametrize("route", ["upload", "staged"])
+def test_malformed_row_pointers_never_reach_the_early_builders(model_text, oracle_model, route):
+    """a large host hand-off classes the graph and starts the flat plan builders from the row pointers BEFORE the
+    full validation at its end; those builders read col[] and write the entry arrays at offsets taken from the row pointers.
+    With the early path forced onto a small graph, non-monotone / out-of-range inner row pointers must be refused before any
+    builder runs, leave no graph behind, and leave the engine usable (an attach after an abandoned staged hand-off included)."""
+    import gnn_mwvc_amd as G
+    import torch
+    g = gg.erdos_renyi(40000, 400000, 77)
+    oracle_model.set_weight_scale(g.ws)
+    want = oracle_model.logits(g)
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_option("blocked_min_n", 0)
+        e.set_option("plans_at_handoff", 2)
+        e.set_option("handoff_min_entries", 1)
+        e.set_weight_scale(g.ws)
+        for kind in ("descending", "beyond_nnz", "huge"):
+            rp = g.rowptr.copy()
+            if kind == "descending":
+                rp[20000] = rp[20002] + 5
+            elif kind == "beyond_nnz":
+                rp[30000:39000] = g.nnz + 12345          # monotone among themselves, but past the end (and back down after)
+            else:
+                rp[1000] = (1 << 33) + 7                 # does not fit 32 bits: must not pass as its low half
+            bad = gg.CsrGraph(g.n, rp, g.col, g.w, g.nw)
+            with pytest.raises(G.GnnvcError) as ei:
+                if route == "upload":
+                    e.upload_graph(bad)
+                elif kind == "huge":
+                    raise G.GnnvcError(-1, "(the staged arrays are 32-bit: not expressible)")
+                else:
+                    e.upload_graph_staged(bad, pieces=3)
+            assert ei.value.code == -1, kind
+            with pytest.raises(G.GnnvcError):           # no usable graph is left behind
+                e.forward(g.x())
+        # an attach right after the refused / abandoned hand-off gets plans of its OWN geometry (attach_common resets every
+        # open build)
+        from tools import graphgen_torch as ggt
+        g2 = gg.erdos_renyi(30000, 330000, 78)
+        dg = ggt.from_host(g2, torch.device("cuda:0"))
+        torch.cuda.synchronize()
+        e.set_weight_scale(g2.ws)
+        oracle_model.set_weight_scale(g2.ws)
+        e.attach_graph_device(dg.n, dg.nnz, dg.rowptr.data_ptr(), dg.col.data_ptr(), dg.w.data_ptr(), dg.nw.data_ptr(), keepalive=dg)
+        _, lg = e.forward(g2.x())
+        assert np.array_equal(bits(lg[:, 0]), bits(oracle_model.logits(g2)))
+        e.set_weight_scale(g.ws)
+        if route == "upload":
+            e.upload_graph(g)
+        else:
+            e.upload_graph_staged(g, pieces=3)
+        assert e.get_info("lds_table_active") == 1 and e.get_info("compact_gather_active") == 1
+        _, lg = e.forward(g.x())
+        assert np.array_equal(bits(lg[:, 0]), bits(want))
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("maker,pieces", [
     (lambda: gg.erdos_renyi(5000, 40000, 23), 1),
     (lambda: gg.erdos_renyi(5000, 40000, 23), 7),

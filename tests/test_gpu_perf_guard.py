@@ -48,6 +48,26 @@ def _run(G, torch, g, x, opts, dev):
         e.close()
 
 
+def _first_again(G, torch, g, x, opts, dev):
+    """One more fresh engine's first forward (hipMalloc on this stack now and then takes 100+ ms, and a single
+    wall-clock shot per configuration would trip on it now and then across 20 cases: the guard compares the better of two)."""
+    e = G.Engine(G.default_model_text(), device=0)
+    try:
+        for k, v in opts.items():
+            e.set_option(k, v)
+        e.set_weight_scale(g.ws)
+        e.attach_graph_device(g.n, g.nnz, g.rowptr.data_ptr(), g.col.data_ptr(), g.w.data_ptr(), g.nw.data_ptr(), keepalive=g)
+        sc = torch.zeros(g.n, device=dev)
+        lg = torch.zeros(g.n, device=dev)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        e.forward_device(x.data_ptr(), sc.data_ptr(), lg.data_ptr())
+        e.synchronize()
+        return (time.perf_counter() - t) * 1e3
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("case", CASES)
 def test_defaults_are_not_slower_than_the_plain_kernels(case):
     import torch
@@ -58,6 +78,8 @@ def test_defaults_are_not_slower_than_the_plain_kernels(case):
     x = g.x().contiguous()
     ref, ms_plain, first_plain = _run(G, torch, g, x, pg.PLAIN, dev)
     got, ms, first = _run(G, torch, g, x, {}, dev)
+    first_plain = min(first_plain, _first_again(G, torch, g, x, pg.PLAIN, dev))
+    first = min(first, _first_again(G, torch, g, x, {}, dev))
     for i, (sc, lg) in enumerate(got):
         assert torch.equal(lg.view(torch.int32), ref[0][1].view(torch.int32)), (case, kind, i)
         assert torch.equal(sc.view(torch.int32), ref[0][0].view(torch.int32)), (case, kind, i)
