@@ -150,7 +150,6 @@ def main() -> int:
     ap.add_argument("--block-cols", type=int, default=0)
     ap.add_argument("--long-threshold", type=int, default=-1, help="degree at which a row gets its own workgroup")
     ap.add_argument("--giant-threshold", type=int, default=-1, help="degree from which a long row is summed by the parallel scan kernels")
-    ap.add_argument("--hub-mode", type=int, default=0, help="1 = tolerance mode for long rows (tree sums); never the default")
     ap.add_argument("--side-streams", type=int, default=1, help="0 = long / giant rows on the main stream (profiling: standalone kernel times)")
     ap.add_argument("--kernel-trace", type=int, default=1, help="HIP events around every main-stream kernel of the timed forwards")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="any engine option (A/B runs), repeatable")
@@ -169,6 +168,11 @@ def main() -> int:
                     help="torch.distributed backend for N>1 (gloo only to rehearse several ranks on ONE GPU)")
     ap.add_argument("--host-path", action="store_true",
                     help="also time the host-pointer path (PCIe inclusive), reported separately")
+    ap.add_argument("--multi-handle", type=int, default=0, metavar="P",
+                    help="time the path behind the C ABI's multi-device handle (gnnvc_create_multi: what the reference's one call "
+                         "site m.predict gets with GNNVC_DEVICES): P parts on the first P devices of this process — or, with fewer "
+                         "devices, several parts per device (a rehearsal: the exchange's bytes and the per-part critical path are "
+                         "real, the forward's wall time is not a scaling number)")
     args = ap.parse_args()
 
     # stdout carries ONE line, the result: whatever libraries print there while the job runs (RCCL's version banner,
@@ -223,6 +227,10 @@ def main() -> int:
     n, nnz, n_edges, ws = g.n, g.nnz, g.n_edges, g.ws
     csr_bytes_full = (g.rowptr.numel() + g.col.numel() + g.w.numel() + g.nw.numel()) * 4
 
+    if args.multi_handle:
+        rc = multi_handle_run(args, dev, g, workload_desc, result_fd)
+        return rc
+
     def make_engine(**opts):
         e = G.Engine(G.default_model_text(), device=dev_index)
         assert e.fused and e.num_stages == 3
@@ -241,8 +249,6 @@ def main() -> int:
             e.set_option("long_row_threshold", args.long_threshold)
         if args.giant_threshold >= 0:
             e.set_option("giant_row_threshold", args.giant_threshold)
-        if args.hub_mode:
-            e.set_option("hub_mode", 1)
         e.set_option("side_streams", args.side_streams)
         if args.mfma >= 0:
             e.set_option("mfma_dense", args.mfma)
@@ -470,14 +476,11 @@ def main() -> int:
     plans = {"compact_gather_f16": bool(eng.get_info("compact_gather_active")),
              "pruned_adjacency": {f"stage{st}": ({"entries_kept": eng.get_info(f"pruned_entries_stage{st}"),
                                                   "zero_row_vertices": eng.get_info(f"pruned_vertices_stage{st}"),
-                                                  "degree_bound": eng.get_info(f"pruned_bound_stage{st}") or None,
                                                   "last_call_fit": bool(eng.get_info(f"pruned_last_ok_stage{st}"))}
                                                  if eng.get_info(f"pruned_stage{st}") else None) for st in (1, 2)},
-             "compact_gather_mapped": bool(eng.get_info("compact_gather_mapped")),
              "compact_gather_last": {"fit": bool(eng.get_info("compact_gather_last_ok")), "passes": eng.get_info("compact_gather_last_passes"),
                                      "dirty_rows": eng.get_info("compact_gather_last_dirty"), "column_blocks": eng.get_info("compact_gather_blocks"),
-                                     "steps": eng.get_info("compact_gather_steps"), "rows": eng.get_info("compact_gather_mapped_rows"),
-                                     "entries": eng.get_info("compact_gather_mapped_entries")},
+                                     "steps": eng.get_info("compact_gather_steps")},
              "lds_table_stage0": bool(eng.get_info("lds_table_active")),
              "lds_table_skewed_layout": bool(eng.get_info("lds_table_mapped")),
              "compact_gather_switched_off": [bool(eng.get_info("compact_gather_off_stage1")), bool(eng.get_info("compact_gather_off_stage2"))],
@@ -490,14 +493,13 @@ def main() -> int:
              "natural_tile_waste": eng.get_info("tile_waste_x100") / 100.0,
              "interleaved_tiles": bool(eng.get_info("interleaved_tiles")), "long_rows": eng.get_info("long_rows"),
              "long_row_threshold": eng.get_info("long_row_threshold"), "giant_rows": eng.get_info("giant_rows"),
-             "giant_entries": eng.get_info("giant_entries"), "giant_row_threshold": eng.get_info("giant_row_threshold"),
-             "hub_mode": "fast (tolerance)" if eng.get_info("hub_mode") else "exact"}
+             "giant_entries": eng.get_info("giant_entries"), "giant_row_threshold": eng.get_info("giant_row_threshold")}
     out = {
         "metric": "GNN forward edges/sec", "value": edges_per_s, "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "mode": "fast" if args.hub_mode else "exact",
+        "mode": "exact",
         "config": {"workload": workload_desc, "vertices": n, "edges": n_edges,
                    "graph": args.workload, "partition": f"1d-vertex x{world} ({part_mode}-balanced)",
                    "timed_state": "steady state of a graph scored repeatedly: per-graph plans built in its first two forwards, "
@@ -608,6 +610,104 @@ def main() -> int:
     if multi:
         dist.destroy_process_group()
     return 0
+
+
+def multi_handle_run(args, dev, g, desc, result_fd):
+    """--multi-handle P: the forward behind ONE handle of the C ABI that drives P devices (gnnvc_create_multi, csrc/gnnvc_multi.cpp)
+    — the path the reference's single call site m.predict(x, out, g) (src/GNN_VC.cpp:192) takes with GNNVC_DEVICES set.  Host
+    hand-off (gnnvc_upload_graph cuts the graph and gives every device its slice), first forward (chooses the exchange's
+    packing), K timed steps of gnnvc_forward_device, every score against a single engine's, the bytes a part ships to one peer per
+    exchange, and part 0's critical path — its compute + pack + push + expand with the other parts idle ("multi_only_part")."""
+    import numpy as np
+    import torch
+    import gnn_mwvc_amd as G
+    P = args.multi_handle
+    ndev = torch.cuda.device_count()
+    devices = list(range(P)) if ndev >= P else [i % ndev for i in range(P)]
+    n, nnz, n_edges = g.n, g.nnz, g.n_edges
+    x = g.x().contiguous()
+    ref_sc = torch.zeros(n, dtype=torch.float32, device=dev)
+    ref_lg = torch.zeros(n, dtype=torch.float32, device=dev)
+    e0 = G.Engine(G.default_model_text(), device=0)
+    e0.set_weight_scale(g.ws)
+    e0.attach_graph_device(n, nnz, g.rowptr.data_ptr(), g.col.data_ptr(), g.w.data_ptr(), g.nw.data_ptr(), keepalive=g)
+    e0.forward_device(x.data_ptr(), ref_sc.data_ptr(), ref_lg.data_ptr())
+    e0.synchronize()
+    e0.close()
+    hg = g.to_host()
+    e = G.Engine(G.default_model_text(), devices=devices)
+    e.set_weight_scale(g.ws)
+    for kv in args.opt:
+        k, _, v = kv.partition("=")
+        e.set_option(k, int(v))
+    t = time.perf_counter()
+    e.upload_graph(hg)
+    e.synchronize()
+    upload_ms = (time.perf_counter() - t) * 1e3
+    sc = torch.zeros(n, dtype=torch.float32, device=dev)
+    lg = torch.zeros(n, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+
+    def once():
+        t = time.perf_counter()
+        e.forward_device(x.data_ptr(), sc.data_ptr(), lg.data_ptr())   # complete when it returns
+        return (time.perf_counter() - t) * 1e3
+
+    early = [once() for _ in range(3)]
+    first_bad = int((lg.view(torch.int32) != ref_lg.view(torch.int32)).sum())
+    for _ in range(args.warmup):
+        once()
+    t = time.perf_counter()
+    for _ in range(args.steps):
+        e.forward_device(x.data_ptr(), sc.data_ptr(), lg.data_ptr())
+    ms = (time.perf_counter() - t) * 1e3 / args.steps
+    bad = int((lg.view(torch.int32) != ref_lg.view(torch.int32)).sum())
+    bad_sc = int((sc.view(torch.int32) != ref_sc.view(torch.int32)).sum())
+    info = {k: e.get_info(k) for k in ("multi_pieces", "multi_packed_stage0", "multi_packed_stage1", "multi_packed_columns_stage0",
+                                       "multi_packed_columns_stage1", "multi_exchange_bytes_per_peer_stage0",
+                                       "multi_exchange_bytes_per_peer_stage1", "multi_peer_stores")}
+    spans = [e.get_info(f"multi_part_span_us_{r}") / 1e3 for r in range(P)]
+    parts = [{"rows": e.get_info(f"part_rows_{r}"), "entries": e.get_info(f"part_entries_{r}")} for r in range(P)]
+    # part 0 alone: what ONE device of P would have to do per forward (its three stages in pieces, pack, push to P - 1 peers,
+    # expand P - 1 peers' pieces), nothing else on the GPU
+    solo_ms = None
+    if P > 1:
+        e.set_option("multi_only_part", 0)
+        for _ in range(2):
+            once()
+        solo = []
+        for _ in range(max(args.steps // 2, 3)):
+            once()
+            solo.append(e.get_info("multi_part_span_us_0") / 1e3)
+        solo_ms = sorted(solo)[len(solo) // 2]
+        e.set_option("multi_only_part", -1)
+    e.close()
+    distinct = len(set(devices))
+    fwd_bytes = sum(stage_bytes(i, n, nnz) for i in range(3))
+    out = {"metric": "GNN forward edges/sec", "value": n_edges / (ms * 1e-3), "unit": "edges/s", "n_gpus": distinct,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic", "mode": "exact",
+           "config": {"workload": desc, "vertices": n, "edges": n_edges, "graph": args.workload,
+                      "path": "gnnvc_create_multi: one handle of the C ABI, one host thread per device, packed pieces pushed over the fabric",
+                      "parts": P, "devices": devices,
+                      "rehearsal": distinct < P,
+                      "note": ("several parts share a device: ms_per_step is NOT a scaling number — the exchange's bytes, the bits and "
+                               "part 0's critical path are what this run shows") if distinct < P else "one part per device"},
+           "first_forward_ms": early[0], "second_forward_ms": early[1], "third_forward_ms": early[2],
+           "score_once_value": n_edges / (early[0] * 1e-3),
+           "host_upload_ms": upload_ms,
+           "roofline": {"bound": "hbm", "definition": "forward level (SURVEY.md 8d): (288 E + 300 N) algorithmic bytes / ms_per_step, per GPU",
+                        "achieved": fwd_bytes / (ms * 1e-3) / 1e9 / distinct, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": fwd_bytes / (ms * 1e-3) / 1e9 / distinct / HBM_PEAK_GBS, "traffic": None},
+           "multi": {**info, "part_span_ms_last_forward": spans, "parts": parts,
+                     "part0_critical_path_ms": solo_ms,
+                     "part0_critical_path_note": "part 0's compute + pack + push (to every peer) + expand (every peer's pieces) with the "
+                                                 "other parts idle: HIP events on its stream, median"},
+           "parity": {"logit_bit_mismatches_vs_single_engine": bad, "score_bit_mismatches_vs_single_engine": bad_sc,
+                      "first_forward_logit_bit_mismatches_vs_single_engine": first_bad, "logits_checked": n}}
+    sys.stdout.flush()
+    os.write(result_fd, (json.dumps(out) + "\n").encode())
+    return 0 if (bad == 0 and bad_sc == 0 and first_bad == 0) else 4
 
 
 def forward_variants(make_engine, attach_whole, x, n, dev):
@@ -862,6 +962,7 @@ def side_workload(name, args, dev, make_engine, ggt):
            "roofline_frac": fwd_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "forward_bytes": fwd_bytes,
            "plan": {"lds_table": bool(e.get_info("lds_table_active")), "compact_gather": bool(e.get_info("compact_gather_active")),
                     "pruned_stage1": bool(e.get_info("pruned_stage1")), "pruned_stage2": bool(e.get_info("pruned_stage2")),
+                    "pruned_stage1_predicted_at_handoff": bool(e.get_info("pruned_predicted_stage1")),
                     "pruned_stage2_from_stage1_entries": bool(e.get_info("pruned_from_previous_stage2")),
                     "sorted_tiles": bool(e.get_info("sorted_tiles_active")), "long_rows": e.get_info("long_rows"),
                     "giant_rows": e.get_info("giant_rows")}}

@@ -195,7 +195,7 @@ int choose_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const flo
     // its compact rows, so that stage can skip its two passes over the input.  Only the VALU variants emit.
     const int fused_in = in_forward ? e->c4_fused_for : -1;   // is THIS stage's input covered by the previous kernel?
     e->c4_fused_for = -1;
-    const bool may_emit = in_forward && e->c4_ready && !e->c4_mapped && !e->c4_range_mode && e->c4_base == 0 && e->c4_end == e->g.n && !longs &&
+    const bool may_emit = in_forward && e->c4_ready && !e->c4_range_mode && e->c4_base == 0 && e->c4_end == e->g.n && !longs &&
                           (size_t)stage + 1 < e->stages.size() && e->stages[stage + 1].f == 16 && lo == 0 && hi == e->g.n &&
                           e->opt_mfma != 1 && !e->c4_stage_off[stage + 1];
     c.long_thresh = (sp.f == 16) ? e->thresh_f16 : e->long_thresh;
@@ -212,7 +212,7 @@ int choose_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const flo
         // (consecutive-row layout: any call that covers at least three quarters of the chunks a full GPU takes — or of the plan's
         // own, where the plan is a rank's slice of fewer)
         const uint32_t lt_need = std::min(192u, e->lt_chunks - e->lt_chunks / 4u);
-        const bool lt_fits = e->lt_ready && hi > lo &&
+        const bool lt_fits = e->lt_ready && !e->lt_off && hi > lo &&
                              (e->lt_mapped ? (lo == 0 && hi == e->g.n)
                                            : (lo >= e->lt_base && hi <= e->lt_end &&
                                               ((hi - 1 - e->lt_base) / e->lt_rows - (lo - e->lt_base) / e->lt_rows + 1) >= lt_need));
@@ -222,6 +222,7 @@ int choose_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const flo
         }
         ++e->graph_uses;
         c.sums = lt_fits ? StageChoice::kLdsTable : (e->blocked_ready ? StageChoice::kBlocked : StageChoice::kGather);
+        if (lt_fits && in_forward) e->lt_used = true;
         if (lt_fits && e->lt_mapped) c.long_thresh = e->lt_plan_thresh;   // the plan holds every row below the giant ones
         c.emit = may_emit;
         if (c.sums != StageChoice::kGather) return GNNVC_OK;   // (those two bring their own tile order)
@@ -236,17 +237,11 @@ int choose_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const flo
         const bool whole_plan = e->c4_ready && e->c4_base == 0 && e->c4_end == e->g.n && !e->c4_stage_off[stage];
         const bool prepared = e->c4_ready && e->c4_prepared_stage == stage && e->c4_prepared_in == in &&
                               lo >= e->c4_base && hi <= e->c4_end && hi > lo;
-        if (prepared && !longs && !e->c4_mapped) {
+        if (prepared && !longs) {
             // gnnvc_stage_input_ready wrote the table for this input: any call that fills at least half the
             // GPU with chunks takes the sums from it (smaller ones would leave most CUs idle for a chunk's time)
             const uint32_t nchunks = (hi - 1 - e->c4_base) / e->c4_rows - (lo - e->c4_base) / e->c4_rows + 1;
             if (nchunks >= 128u) c.sums = StageChoice::kCompactPrepared;
-        } else if (!e->c4_range_mode && whole_plan && e->c4_mapped) {
-            // a skewed graph's plan sums all of its rows at once: whole-graph calls only; long rows beside it as always
-            if (lo == 0 && hi == e->g.n) {
-                c.sums = StageChoice::kCompactWhole;
-                c.fused_counts = false;
-            }
         } else if (!e->c4_range_mode && whole_plan && !longs && (uint64_t)(hi - lo) * 2 >= e->g.n) {
             // worth its fixed cost (count + compact the whole input) only when this call covers most of the rows
             c.sums = StageChoice::kCompactWhole;
@@ -285,7 +280,7 @@ int launch_side_rows(gnnvc_engine *e, const GraphDev &gv, int stage, uint32_t lo
     hipStream_t s_long = side_long ? e->long_stream : e->stream;
     hipStream_t s_giant = !side ? e->stream : (long_on_main ? e->giant_stream : e->long_stream);
     e->side_join = !side ? 0 : (long_on_main ? 2 : 1);
-    // rows from this degree on go the giant way in this stage (hub_mode 1: every long row does)
+    // rows from this degree on go the giant way in this stage
     const uint32_t giant_from = e->stages[stage].f == 16 ? e->giant_f16() : e->giant_thresh;
     gnnvc::GiantRows gr;
     bool gather_first = false;
@@ -313,7 +308,7 @@ int launch_side_rows(gnnvc_engine *e, const GraphDev &gv, int stage, uint32_t lo
                                                                : e->opt_giant_gather_first != 0);
         if (gather_first)
             HIP_TRY(e, gnnvc::launch_giant_stage(e->stages[stage], e->opt_prune_giant ? gv : e->g, e->ws, e->params.p, in, out, logits, lo, hi,
-                                                 gr, e->opt_hub_mode == 1, e->stream, giant_from, /*part=*/1));
+                                                 gr, e->stream, giant_from, /*part=*/1));
     }
     if (side) {
         HIP_TRY(e, hipEventRecord(e->ev_fork, e->stream));
@@ -322,7 +317,7 @@ int launch_side_rows(gnnvc_engine *e, const GraphDev &gv, int stage, uint32_t lo
     if (e->n_giant) {   // the heaviest rows: beside the tile kernel
         if (long_on_main) HIP_TRY(e, hipStreamWaitEvent(e->giant_stream, e->ev_fork, 0));
         HIP_TRY(e, gnnvc::launch_giant_stage(e->stages[stage], e->opt_prune_giant ? gv : e->g, e->ws, e->params.p, in, out, logits, lo, hi, gr,
-                                             e->opt_hub_mode == 1, s_giant, giant_from, gather_first ? 2 : 0));
+                                             s_giant, giant_from, gather_first ? 2 : 0));
         if (long_on_main) HIP_TRY(e, hipEventRecord(e->ev_giant, e->giant_stream));
     }
     // (with rows classed by the entries they have left, k_long_* takes rows from gv.eff_thresh entries on whatever their degree)
@@ -412,7 +407,8 @@ int launch_main(gnnvc_engine *e, const StageChoice &c, const GraphDev &gv, const
     const gnnvc::SortedOrder *sop = c.sorted.n ? &c.sorted : nullptr;
     HIP_TRY(e, gnnvc::launch_stage(sp, gv, e->ws, e->params.p, in, out, logits, lo, hi, c.long_thresh, c.mfma, sop,
                                    e->interleave, e->stream, acc4, desc, e->c4_agg16.p, e->opt_mfma == 1, emit,
-                                   /*dense_part=*/!c.rounds, so_p.vertex ? &so_p : nullptr));
+                                   /*dense_part=*/!c.rounds, so_p.vertex ? &so_p : nullptr,
+                                   (acc4 && e->opt_dense_skip) ? e->c4_table.p : nullptr));
     if (!c.rounds) return GNNVC_OK;
     HIP_TRY(e, hipMemsetAsync(desc + 5, 0, sizeof(uint32_t), e->stream));        // dirty-row counter
     HIP_TRY(e, hipMemsetAsync(e->c4_marks.p, 0, sizeof(uint32_t), e->stream));   // marks[0]
@@ -439,7 +435,7 @@ int launch_main(gnnvc_engine *e, const StageChoice &c, const GraphDev &gv, const
         HIP_TRY(e, gnnvc::compact_fix(e->g, in, desc, e->c4_dirty.p, e->c4_dirty_cap, e->c4_agg16.p, e->c4_marks.p + k, ds,
                                       /*blocks=*/64));
         HIP_TRY(e, gnnvc::launch_dense_sigmoid(sp, e->g, e->ws, e->params.p, in, out, logits, ra, rb, e->c4_acc.p, desc,
-                                               e->c4_agg16.p, ds));
+                                               e->c4_agg16.p, ds, 0xFFFFFFFFu, e->opt_dense_skip ? e->c4_table.p : nullptr));
     }
     if (nrounds > 1) {
         HIP_TRY(e, hipEventRecord(e->ev_join, e->aux_stream));
@@ -616,7 +612,7 @@ void gnnvc_destroy(gnnvc_engine *e) {
     e->lt_bytes.release(); e->lt_entries.release(); e->lt_segcnt.release(); e->lt_stepptr.release();
     e->lt_stepcnt.release(); e->lt_bad.release(); e->lt_steps.release(); e->lt_rowmap.release(); e->lt_first.release(); e->lt_bstart.release();
     e->c4_entries.release(); e->c4_segcnt.release(); e->c4_stepptr.release(); e->c4_stepcnt.release();
-    e->c4_desc.release(); e->c4_rowmap.release(); e->c4_first.release(); e->c4_bstart.release(); e->c4_map_vertex.release(); e->c4_map_meta.release(); e->map_coarse.release(); e->c4_steps.release(); e->c4_table.release(); e->c4_marks.release(); e->c4_acc.release(); e->c4_counts.release();
+    e->c4_desc.release(); e->c4_map_vertex.release(); e->c4_map_meta.release(); e->map_coarse.release(); e->c4_steps.release(); e->c4_table.release(); e->c4_marks.release(); e->c4_acc.release(); e->c4_counts.release();
     e->c4_agg16.release(); e->c4_dirty.release(); e->c4_emit_counts.release();
     for (auto &pp : e->prune) { pp.prp.release(); pp.pcol.release(); pp.heavy.release(); pp.svertex.release(); pp.smeta.release(); }
     e->prune_flags.release(); e->prune_scratch.release(); e->prune_off.release(); e->prune_mask.release();
@@ -661,9 +657,20 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream) {
     return GNNVC_OK;
 }
 
+int gnnvc_get_stream(gnnvc_engine *e, void **hip_stream) {
+    if (!e || !hip_stream) return GNNVC_ERR_INVALID;
+    *hip_stream = e->stream;
+    return GNNVC_OK;
+}
+
 int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     if (!e || !key) return GNNVC_ERR_INVALID;
     const std::string k(key);
+    if (k.rfind("multi_", 0) == 0) {   // the exchange of a multi-device handle (gnnvc_multi.cpp): "multi_pieces", "multi_pack", "multi_push", "multi_only_part"
+        if (!e->multi) return fail(e, GNNVC_ERR_INVALID, "option '%s' needs a multi-device handle (gnnvc_create_multi)", key);
+        const int rc = gnnvc::multi_set_option(e->multi, key, value);
+        return rc ? fail(e, rc, "unknown option '%s'", key) : GNNVC_OK;
+    }
     e->short_from = 0;   // (lists a filtered stage left go by the thresholds and variants of the call that wrote them)
     if (k == "blocked_stage0") e->opt_blocked = value < 0 ? 0 : (value > 2 ? 2 : (int)value);   // 2 = also on skewed graphs
     else if (k == "block_cols") e->opt_block_cols = value > 0 ? (uint32_t)value : 0;
@@ -678,17 +685,19 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
         e->opt_giant_f16 = e->opt_giant_thresh ? e->opt_giant_thresh : 1u;
         e->giant_f16_auto = false;
     }
-    else if (k == "hub_mode") e->opt_hub_mode = value == 1 ? 1 : 0;
-    else if (k == "giant_row_threshold_f16") { e->opt_giant_f16 = value > 0 ? (uint32_t)value : 1u; e->giant_f16_auto = false; for (auto &pp : e->prune) pp.tried = pp.ready = false; }
+    else if (k == "giant_row_threshold_f16") { e->opt_giant_f16 = value > 0 ? (uint32_t)value : 1u; e->giant_f16_auto = false; for (auto &pp : e->prune) pp.forget(); }
     else if (k == "giant_segments") e->opt_giant_segments = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "side_streams") e->opt_side_streams = value != 0 ? 1 : 0;
     else if (k == "kernel_trace") e->opt_ktrace = value != 0 ? 1 : 0;
     else if (k == "compact_gather") e->opt_compact = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
-    else if (k == "prune_zero_rows") { e->opt_prune = value < 0 ? 0 : (value > 2 ? 2 : (int)value); for (auto &pp : e->prune) pp.tried = pp.ready = false; }
-    else if (k == "prune_class_by_entries_left") { e->opt_prune_eff = value != 0 ? 1 : 0; for (auto &pp : e->prune) pp.tried = pp.ready = false; }
-    else if (k == "prune_heavy_entries") { e->opt_prune_heavy_entries = value > 0 ? (uint64_t)value : 0; for (auto &pp : e->prune) pp.tried = pp.ready = false; }
+    else if (k == "prune_zero_rows") { e->opt_prune = value > 0 ? 1 : 0; for (auto &pp : e->prune) pp.forget(); }
+    else if (k == "prune_class_by_entries_left") { e->opt_prune_eff = value != 0 ? 1 : 0; for (auto &pp : e->prune) pp.forget(); }
+    else if (k == "prune_heavy_entries") { e->opt_prune_heavy_entries = value > 0 ? (uint64_t)value : 0; for (auto &pp : e->prune) pp.forget(); }
     else if (k == "prune_early_entries") e->opt_prune_early_nnz = value > 0 ? (uint64_t)value : 0;
     else if (k == "prune_giant_rows") e->opt_prune_giant = value != 0 ? 1 : 0;
+    else if (k == "prune_predict") e->opt_prune_predict = value != 0 ? 1 : 0;
+    else if (k == "dense_skip_zeros") e->opt_dense_skip = value != 0 ? 1 : 0;
+    else if (k == "prune_predict_min_entries") e->opt_predict_min_nnz = value > 0 ? (uint64_t)value : 0;
     else if (k == "giant_gather_first") e->opt_giant_gather_first = value < 0 ? -1 : (value != 0 ? 1 : 0);
     else if (k == "long_rows_on_main") e->opt_long_on_main = value < 0 ? -1 : (value != 0 ? 1 : 0);
     else if (k == "filter_zero_rows") e->opt_filter = value != 0 ? 1 : 0;
@@ -698,8 +707,6 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "filter_min_percent") e->opt_filter_min_pct = value < 0 ? 0u : (value > 100 ? 101u : (uint32_t)value);
     else if (k == "prune_min_entries") e->opt_prune_min_nnz = value > 0 ? (uint64_t)value : 0;
     else if (k == "prune_min_drop_percent") e->opt_prune_min_drop = value < 0 ? 0u : (value > 100 ? 100u : (uint32_t)value);
-    else if (k == "compact_skewed") { e->opt_compact_skewed = value != 0 ? 1 : 0; e->c4_tried = false; e->c4_ready = false; }
-    else if (k == "compact_passes") { e->opt_compact_passes = value < 1 ? 1u : (value > 3 ? 3u : (uint32_t)value); e->c4_tried = false; e->c4_ready = false; }
     else if (k == "lds_table_skewed") e->opt_lds_skewed = value != 0 ? 1 : 0;
     else if (k == "lds_table_skewed_rows") e->opt_lds_skewed_rows = value > 0 ? (uint32_t)value : 0u;
     else if (k == "lds_table") e->opt_lds_table = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
@@ -728,6 +735,9 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
         *value = k[5] == 'r' ? (long)(hi - lo) : (long)en;
     }
     else if (k == "multi_last_forward_us") *value = e->multi ? (long)(gnnvc::multi_last_forward_ms(e->multi) * 1000.0) : 0;
+    else if (k.rfind("multi_", 0) == 0) {
+        if (!e->multi || !gnnvc::multi_get_info(e->multi, key, value)) return GNNVC_ERR_INVALID;
+    }
     else if (k == "compact_gather_active") *value = e->c4_ready ? 1 : 0;
     else if (k == "compact_gather_chunks") *value = e->c4_ready ? (long)e->c4_chunks : 0;
     else if (k == "compact_gather_block_cols") *value = e->c4_ready ? (long)e->c4_block : 0;
@@ -750,16 +760,16 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
             *value = (long)(info[0] * 100ull / e->g.nnz);
         }
     }
-    else if (k == "pruned_bound_stage1" || k == "pruned_bound_stage2") *value = e->prune[k.back() - '0'].ready ? (long)e->prune[k.back() - '0'].bound : 0;
-    else if (k == "pruned_observed_stage1" || k == "pruned_observed_stage2") *value = e->prune[k.back() - '0'].tried ? (long)e->prune[k.back() - '0'].observed : 0;
     else if (k == "pruned_vertices_stage1" || k == "pruned_vertices_stage2") *value = e->prune[k.back() - '0'].ready ? (long)e->prune[k.back() - '0'].members : 0;
     else if (k == "pruned_entries_stage1" || k == "pruned_entries_stage2") *value = e->prune[k.back() - '0'].ready ? (long)e->prune[k.back() - '0'].kept : 0;
+    else if (k == "pruned_predicted_stage1") *value = e->prune[1].ready && e->prune[1].predicted ? 1 : 0;
+    else if (k == "pruned_borrowed_stage2") *value = e->borrowed[2] ? 1 : 0;
     else if (k == "pruned_from_previous_stage2") *value = e->prune[2].ready && e->prune[2].from_prev ? 1 : 0;
     else if (k == "pruned_last_ok_stage1" || k == "pruned_last_ok_stage2") {
         // did the last call of that stage use its pruned adjacency?  (waits for the stream; tests and tools)
         const int st = k.back() - '0';
         *value = 0;
-        if (e->prune[st].ready) {
+        if (e->prune[st].ready || e->borrowed[st]) {
             uint32_t bad = 1;
             if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess ||
                 hipMemcpy(&bad, e->prune_flags.p + st, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess)
@@ -767,12 +777,9 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
             *value = bad == 0 ? 1 : 0;
         }
     }
+    else if (k == "lds_table_off") *value = e->lt_off ? 1 : 0;
     else if (k == "compact_gather_off_stage1" || k == "compact_gather_off_stage2") *value = e->c4_stage_off[k.back() - '0'] ? 1 : 0;
-    else if (k == "compact_gather_mapped") *value = e->c4_ready && e->c4_mapped ? 1 : 0;
     else if (k == "compact_gather_blocks") *value = e->c4_ready ? (long)e->c4_nblocks : 0;
-    else if (k == "compact_gather_mapped_rows") *value = e->c4_ready ? (long)e->c4_mapped_rows : 0;
-    else if (k == "compact_gather_mapped_entries") *value = e->c4_ready ? (long)e->c4_mapped_entries : 0;
-    else if (k == "compact_gather_max_passes") *value = e->c4_ready ? (long)e->c4_max_passes : 0;
     else if (k == "compact_gather_last_ok" || k == "compact_gather_last_dirty" || k == "compact_gather_last_passes" ||
              k == "compact_table_written_by_producer") {
         // what the device decided at the last launch of the plan (waits for the stream; for tests and tools)
@@ -806,7 +813,6 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
     else if (k == "giant_segments") *value = e->n_giant ? (long)e->gi_maxseg : 0;
     else if (k == "giant_entries") *value = (long)e->giant_entries;
     else if (k == "giant_row_threshold") *value = e->n_giant ? (long)e->giant_thresh : 0;
-    else if (k == "hub_mode") *value = e->opt_hub_mode;
     else if (k == "mfma_dense") *value = e->opt_mfma;
     else if (k == "sorted_tiles_active") *value = e->sorted_wanted ? 1 : 0;
     else if (k == "tile_waste_x100") *value = (long)(e->srt_waste * 100.0);
@@ -1317,6 +1323,10 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
     e->c4_prepared_stage = -1;
     if (e->fit_pending && hipEventQuery(e->ev_fit) == hipSuccess) {   // the previous forward's verdicts have arrived
         e->fit_pending = false;
+        if (e->lt_used && e->lt_ready) {
+            e->lt_unfit_runs = e->fit_pin.p[2] != 0u ? e->lt_unfit_runs + 1 : 0u;
+            if (e->lt_unfit_runs >= (e->lt_mapped ? 1u : 3u)) e->lt_off = true;
+        }
         for (int s = 1; s <= 2; ++s) {
             if (!e->fit_used[s]) continue;
             // (a stage whose statistics were to come from a producer that itself fell back had no chance: not its miss)
@@ -1325,8 +1335,10 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
             if (e->c4_unfit_runs[s] >= 3u) e->c4_stage_off[s] = true;
         }
     }
-    if (!e->fit_pending)
+    if (!e->fit_pending) {
         for (int s = 0; s < 4; ++s) e->fit_used[s] = false;
+        e->lt_used = false;
+    }
     struct SinkGuard {   // the thread-local sink never outlives this call, whichever way it returns
         ~SinkGuard() { gnnvc::set_kernel_trace(nullptr); }
     } sink_guard;
@@ -1359,12 +1371,18 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
     gnnvc::set_kernel_trace(nullptr);
     if (rc) return rc;
     e->ev_count = (int)ns + 1;
-    if (!e->fit_pending && (e->fit_used[1] || e->fit_used[2]) && e->c4_ready && e->c4_desc.p) {   // this forward's verdicts, copied out behind it
+    const bool c4_verdicts = (e->fit_used[1] || e->fit_used[2]) && e->c4_ready && e->c4_desc.p;
+    const bool lt_verdict = e->lt_used && e->lt_ready && e->lt_bad.p;
+    if (!e->fit_pending && (c4_verdicts || lt_verdict)) {   // this forward's verdicts, copied out behind it
         if (!e->ev_fit) HIP_TRY(e, hipEventCreateWithFlags(&e->ev_fit, hipEventDisableTiming));
         HIP_TRY(e, e->fit_pin.reserve(4));
-        for (int s = 1; s <= 2; ++s)
-            HIP_TRY(e, hipMemcpyAsync(e->fit_pin.p + (s - 1), e->c4_desc.p + gnnvc_engine::kDescWords * (s - 1), sizeof(uint32_t),
-                                      hipMemcpyDeviceToHost, e->stream));
+        if (c4_verdicts)
+            for (int s = 1; s <= 2; ++s)
+                HIP_TRY(e, hipMemcpyAsync(e->fit_pin.p + (s - 1), e->c4_desc.p + gnnvc_engine::kDescWords * (s - 1), sizeof(uint32_t),
+                                          hipMemcpyDeviceToHost, e->stream));
+        else
+            for (int s = 1; s <= 2; ++s) e->fit_used[s] = false;
+        if (lt_verdict) HIP_TRY(e, hipMemcpyAsync(e->fit_pin.p + 2, e->lt_bad.p, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(e, hipEventRecord(e->ev_fit, e->stream));
         e->fit_pending = true;
     }
@@ -1386,7 +1404,7 @@ int gnnvc_stage_input_ready(gnnvc_engine *e, int stage, const float *d_in, uint3
     const bool same_range = e->c4_range_mode && e->c4_tried && e->c4_base == row_lo && e->c4_end == row_hi;
     e->c4_range_mode = true;
     if (!same_range) {
-        rc = build_compact(e, row_lo, row_hi, /*allow_mapped=*/false);
+        rc = build_compact(e, row_lo, row_hi);
         if (rc) return rc;
         if (!e->c4_ready) {   // remember what was tried, so that the next forward does not try again
             e->c4_base = row_lo;
@@ -1550,6 +1568,39 @@ int gnnvc_unpack_gathered(gnnvc_engine *e, const float *d_buf, uint32_t world, u
     if (rc) return rc;
     HIP_TRY(e, gnnvc::unpack_gathered(d_buf, world, skip_rank, (size_t)piece_words, dense_rows, exc_cap, rows_per_rank, row_off,
                                       rows, n, mask, kp, d_feat, e->stream));
+    return GNNVC_OK;
+}
+
+int gnnvc_push_piece(gnnvc_engine *e, const float *d_region, uint32_t rows, uint32_t kp, uint32_t exc_cap, uint32_t n_dst,
+                     float *const *d_dst, void *hip_stream) {
+    if (!e) return GNNVC_ERR_INVALID;
+    if (!n_dst) return GNNVC_OK;
+    if (n_dst > 64 || kp < 4 || kp > 16 || kp % 4) return fail(e, GNNVC_ERR_INVALID, "push of %u destinations, packed width %u", n_dst, kp);
+    if (!d_region || !d_dst) return fail(e, GNNVC_ERR_INVALID, "null device buffers");
+    for (uint32_t i = 0; i < n_dst; ++i)
+        if (!d_dst[i]) return fail(e, GNNVC_ERR_INVALID, "null destination %u", i);
+    int rc = use_device(e);
+    if (rc) return rc;
+    HIP_TRY(e, gnnvc::push_piece(d_region, rows, kp, exc_cap, n_dst, d_dst, hip_stream ? static_cast<hipStream_t>(hip_stream) : e->stream));
+    return GNNVC_OK;
+}
+
+int gnnvc_unpack_pieces(gnnvc_engine *e, const gnnvc_piece *pieces, uint32_t n_pieces, uint32_t exc_cap, uint32_t width, uint32_t mask,
+                        uint32_t kp, float *d_feat) {
+    if (!e) return GNNVC_ERR_INVALID;
+    int rc = codec_args(e, width, 0, 0, mask, kp);
+    if (rc) return rc;
+    if (!n_pieces) return GNNVC_OK;
+    if (n_pieces > 64 || !pieces || !d_feat) return fail(e, GNNVC_ERR_INVALID, "%u pieces (1 .. 64), null buffers", n_pieces);
+    gnnvc::UnpackPiece up[64];
+    for (uint32_t i = 0; i < n_pieces; ++i) {
+        if (pieces[i].row_lo > pieces[i].row_hi || (pieces[i].row_lo != pieces[i].row_hi && !pieces[i].d_region))
+            return fail(e, GNNVC_ERR_INVALID, "piece %u: rows [%u, %u)", i, pieces[i].row_lo, pieces[i].row_hi);
+        up[i] = gnnvc::UnpackPiece{pieces[i].d_region, pieces[i].row_lo, pieces[i].row_hi};
+    }
+    rc = use_device(e);
+    if (rc) return rc;
+    HIP_TRY(e, gnnvc::unpack_pieces(up, n_pieces, exc_cap, mask, kp, d_feat, e->stream));
     return GNNVC_OK;
 }
 
@@ -1718,7 +1769,7 @@ int gnnvc_stream_sum(gnnvc_engine *e, const float *values, uint32_t streams, uin
     if (!e) return GNNVC_ERR_INVALID;
     if (!streams) return GNNVC_OK;
     if (!sums || (len && !values)) return fail(e, GNNVC_ERR_INVALID, "null host buffers");
-    if (mode < 0 || mode > 2) return fail(e, GNNVC_ERR_INVALID, "mode %d (0 = exact, 1 = fast, 2 = exact on one wave per stream)", mode);
+    if (mode != 0 && mode != 2) return fail(e, GNNVC_ERR_INVALID, "mode %d (0 = a stream on several waves, 2 = on one wave; the same exact sum)", mode);
     if (len == 0) {
         for (uint32_t i = 0; i < streams; ++i) sums[i] = 0.0f;
         return GNNVC_OK;

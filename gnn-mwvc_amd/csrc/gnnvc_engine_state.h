@@ -140,6 +140,12 @@ struct gnnvc_engine {
     // LDS-table plan of the F = 1 stage (same timing as the blocked plan: built on the graph's second forward)
     int opt_lds_table = 1;          // 0 = off, 1 = when it applies, 2 = also on skewed graphs
     bool lt_ready = false, lt_tried = false;
+    // (round 4) the device's per-forward verdict on the byte table comes back behind whole forwards like the compact table's: an
+    // input that is not k / ws leaves the plan's launches empty and — in the skewed layout, whose rows below the giant ones are
+    // all the tile kernel's then — makes the stage several times slower than without the plan; one miss there, three on the
+    // consecutive-row layout, switch it off for the graph
+    bool lt_used = false, lt_off = false;
+    uint32_t lt_unfit_runs = 0;
     bool lt_mapped = false;              // skewed graphs: rows dealt to slices (lt_rowmap), blocks of equal mass, rows below lt_plan_thresh
     uint32_t lt_plan_thresh = 0xFFFFFFFFu;
     DevBuf<uint32_t> lt_rowmap, lt_first, lt_bstart;
@@ -174,22 +180,17 @@ struct gnnvc_engine {
     bool c4_ready = false, c4_tried = false;
     uint32_t c4_rows = 0, c4_chunks = 0, c4_steps_total = 0, c4_block = 0, c4_last_entry = 0, c4_nblocks = 0;
     DevBuf<uint32_t> c4_entries, c4_segcnt, c4_stepptr, c4_stepcnt, c4_desc;
-    // skewed graphs: the plan covers the rows below the long-row threshold, dealt from the degree-sorted list to slices of
-    // equal weight (c4_rowmap), over column blocks of equal entry mass (c4_bstart), with up to c4_max_passes tables per input
-    bool c4_mapped = false;
-    uint32_t c4_max_passes = 1, c4_nslices = 0, c4_mapped_rows = 0;
-    uint64_t c4_mapped_entries = 0;
-    DevBuf<uint32_t> c4_rowmap, c4_first, c4_bstart, c4_map_vertex;
+    uint32_t c4_nslices = 0;
+    DevBuf<uint32_t> c4_map_vertex;   // (scratch of layout_skewed_plan: the LDS-table plan's layout on skewed graphs)
     DevBuf<uint32_t> map_coarse;      // uint16 per 256 columns: their block (scratch of the skewed-graph plan builders)
     DevBuf<uint4> c4_map_meta;
-    int opt_compact_skewed = 0;      // option "compact_skewed": 1 = skewed graphs take the mapped compact-table plan (measured: no gain on
-                                     // R-MAT-22 — three passes at ~110 G entries/s tie with the gathering kernel — so it is opt-in)
-    uint32_t opt_compact_passes = 3; // option "compact_passes": tables per input on skewed graphs (1..3)
     DevBuf<uint4> c4_steps;
     DevBuf<float> c4_table, c4_acc, c4_agg16;
     DevBuf<uint32_t> c4_marks;            // dirty-row slots handed out after each round of the aggregation grid
     std::vector<hipEvent_t> round_ev;     // "round k's sums are done" (main stream -> aux stream)
     int opt_overlap = 1;                  // last stage: dense layers of round k under the sums of round k + 1
+    int opt_dense_skip = 1;               // option "dense_skip_zeros" (A/B): the aggregate-only dense kernels take a clean row's <= 11 non-zero
+                                          // first-layer terms from its sums and the input's compact table instead of the 32-term chain (k_dense_f16)
     DevBuf<uint32_t> c4_dirty;
     uint32_t c4_dirty_cap = 0;
     DevBuf<unsigned long long> c4_counts, c4_emit_counts;
@@ -202,8 +203,13 @@ struct gnnvc_engine {
     // sees the second time the graph is scored; every later call proves on the device that its input still fits
     struct PrunePlan {
         bool tried = false, ready = false, deferred = false;
+        // round 4: built at HAND-OFF from the set the graph alone predicts (k_predict_zero_f1: the reference driver's input is
+        // x = W / ws, so the first 16-wide stage's zero rows follow from the weights) — proven per call like any other set;
+        // verified: a forward has run with it and the host has seen that its check passed (if not, the plan is dropped and
+        // rebuilt from the input the stage really sees)
+        bool predicted = false, verified = false;
+        void forget() { tried = ready = deferred = predicted = verified = false; }
         bool from_prev = false;             // built from the previous stage's kept entries (its set is contained in this one)
-        uint32_t bound = 0, observed = 0;   // vertices of degree >= bound are expected to have all-zero rows (largest degree seen with a non-zero row)
         uint64_t kept = 0;                  // entries left
         uint64_t members = 0;               // vertices in the set
         DevBuf<uint32_t> prp, pcol, heavy;
@@ -216,9 +222,14 @@ struct gnnvc_engine {
     PrunePlan prune[4];
     DevBuf<uint32_t> prune_flags, prune_scratch, prune_off;   // (off / mask: per chunk of 64 entries, while a plan is built)
     DevBuf<unsigned long long> prune_mask;   // flags: [stage] = this call's verdict (0 = the pruned adjacency applies), [3] = observe
-    int opt_prune = 1;               // option "prune_zero_rows": 1 = the rows found all zero when the plan is built, 2 = a degree bound, 0 = off
+    int opt_prune = 1;               // option "prune_zero_rows": 1 = the rows found all zero when the plan is built (or predicted at hand-off), 0 = off
     uint64_t opt_prune_heavy_entries = 16u << 20;   // option "prune_heavy_entries": from this many entries left, rows up to the sorted threshold stay with the tile kernel
     uint64_t opt_prune_early_nnz = 64u << 20;   // option "prune_early_entries": skewed graphs with at least this many entries build the plan in their first forward (0 = never)
+    // option "prune_predict": 1 = large skewed graphs (the ones the filtered gather is offered to) get the first 16-wide stage's
+    // pruned adjacency when they are HANDED OVER, from the predicted set — a graph scored once (the reference's driver,
+    // src/GNN_VC.cpp:171-192) then runs its first forward on it, and the next stage borrows it until it has its own
+    int opt_prune_predict = 1;
+    uint64_t opt_predict_min_nnz = 48u << 20;   // option "prune_predict_min_entries"
     int opt_prune_eff = 1;           // option "prune_class_by_entries_left" (A/B): 0 = rows keep the class their degree gives them
     int opt_prune_giant = 1;         // option "prune_giant_rows" (A/B): 0 = the giant rows keep their full streams
     uint64_t opt_prune_min_nnz = 1u << 20;   // option "prune_min_entries": smaller graphs are not worth a plan
@@ -241,6 +252,7 @@ struct gnnvc_engine {
     DevBuf<uint32_t> filter_bits[4];
     DevBuf<unsigned long long> filter_info;   // [4 * stage]: {degrees of the set's vertices, their number, verdict on an earlier stage's lists}
     bool filtered[4] = {false, false, false, false};   // the last call of the stage was offered the bitmap
+    bool borrowed[4] = {false, false, false, false};   // the last call of the stage ran on the PREVIOUS stage's predicted plan (gather_view)
     // ... and the targets a filtered stage found outside its set, left per row in prune[stage].pcol / .prp (the buffers of the
     // plan that is not built yet), are the adjacency of the NEXT 16-wide stage of the same forward when the device finds that
     // stage's input to keep the set all zero (GraphDev::keep_col / short_col): short_from = the stage that left them, 0 = none
@@ -316,7 +328,6 @@ struct gnnvc_engine {
     bool empty_slice = false;            // gnnvc_attach_graph_slice with no rows: every stage call is a no-op
     uint32_t opt_giant_thresh = 16384;   // option "giant_row_threshold" (0 = off: k_long_* take every long row)
     int opt_side_streams = 1;            // option "side_streams": 0 = long / giant rows on the main stream, one after the other (profiling)
-    int opt_hub_mode = 0;                // option "hub_mode": 0 = exact (the chain's bits), 1 = fast (tree sums, tolerance mode)
     uint32_t giant_thresh = 0xFFFFFFFFu, n_giant = 0, giant_blocks = 0;
     uint32_t opt_giant_f16 = 65536;     // option "giant_row_threshold_f16": the 16-wide stages send only rows from this degree on the giant way
     bool giant_f16_auto = true, giant_walk_bound = false;   // (walk_bound: the longest stream's walk is what a stage waits for, find_giant)
@@ -325,7 +336,7 @@ struct gnnvc_engine {
         // by the graph: a 65 536-entry row's add chain in k_long_f16 is ~0.26 ms — lost in the stages of a graph with 64 M entries
         // and more (R-MAT-22 2.98 -> 2.88 ms, R-MAT-24 12.6 -> 11.6 ms), what the stages of a smaller one would wait for (R-MAT-20
         // 0.99 -> 1.05 ms, power-law 1.03 -> 1.30 ms)
-        if (opt_hub_mode == 1 || (giant_f16_auto && g.nnz < (64ull << 20))) return giant_thresh;
+        if (giant_f16_auto && g.nnz < (64ull << 20)) return giant_thresh;
         return std::max(giant_thresh, opt_giant_f16);
     }   // (16 streams per row: three times a
                                         // long row's traffic — worth it only for the rows whose add chain a stage would wait for)
@@ -398,13 +409,13 @@ int find_long(gnnvc_engine *e);                              // row classes of a
 int ensure_sorted(gnnvc_engine *e, uint32_t lo, uint32_t hi);
 int build_blocked(gnnvc_engine *e);
 int build_lds_table(gnnvc_engine *e);
-int build_compact(gnnvc_engine *e, uint32_t base = 0, uint32_t end = 0xFFFFFFFFu, bool allow_mapped = true);
+int build_compact(gnnvc_engine *e, uint32_t base = 0, uint32_t end = 0xFFFFFFFFu);
 // a plan put together piece by piece (gnnvc_engine::PlanBuild): begin = eligibility, geometry, buffers; advance = count and
 // regroup the slices up to a given one on a given stream; finish = the step records and the verdict
 int lt_begin(gnnvc_engine *e);
 int lt_advance(gnnvc_engine *e, uint32_t upto, hipStream_t stream);
 int lt_finish(gnnvc_engine *e);
-int c4_begin(gnnvc_engine *e, uint32_t base, uint32_t end, bool allow_mapped);
+int c4_begin(gnnvc_engine *e, uint32_t base, uint32_t end);
 int c4_advance(gnnvc_engine *e, uint32_t upto, hipStream_t stream);
 int c4_finish(gnnvc_engine *e);
 gnnvc::CompactPlan compact_plan(const gnnvc_engine *e);

@@ -116,11 +116,14 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
                         const EmitArgs &emit = EmitArgs(),
                         bool dense_part = true /* false: only the gathering kernel (which leaves at once when the compact-table
                                                   plan applies); the caller launches the sums and the dense kernel itself */,
-                        const SortedOrder *so_pruned = nullptr /* g.prune_eff: the tile order by entries left (meta = pruned ranges) */);
+                        const SortedOrder *so_pruned = nullptr /* g.prune_eff: the tile order by entries left (meta = pruned ranges) */,
+                        const float *table_in = nullptr /* acc4: the compact table of THIS stage's input (one pass), so that the dense
+                                                           kernel takes a row's own live values from it; null = from the full rows */);
 // the dense layers + sigmoid of the last stage when its aggregates are ready (compact-table plan)
 hipError_t launch_dense_sigmoid(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *in, float *out,
                                 float *logits, uint32_t row_lo, uint32_t row_hi, const float *acc4, const uint32_t *c4desc,
-                                const float *agg16, hipStream_t stream, uint32_t long_thresh = 0xFFFFFFFFu /* rows at least this long are not this kernel's */);
+                                const float *agg16, hipStream_t stream, uint32_t long_thresh = 0xFFFFFFFFu /* rows at least this long are not this kernel's */,
+                                const float *table_in = nullptr /* as launch_stage's */);
 
 // Building blocks of the degree-sorted order (the prefix over the few thousand degree classes
 // is done on the host).
@@ -167,10 +170,10 @@ uint32_t giant_block();
 hipError_t find_giant_rows(const GraphDev &g, const uint32_t *list, uint32_t n_long, uint32_t thresh, void *meta, uint32_t *count,
                            hipStream_t stream);
 hipError_t launch_giant_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *in, float *out,
-                              float *logits, uint32_t row_lo, uint32_t row_hi, const GiantRows &gr, bool fast, hipStream_t stream,
+                              float *logits, uint32_t row_lo, uint32_t row_hi, const GiantRows &gr, hipStream_t stream,
                               uint32_t min_deg = 0 /* listed rows below this degree are another kernel's in this stage */, int part = 0);
 hipError_t stream_sums(const float *streams_dev, uint32_t streams, uint32_t len, void *meta, unsigned long long *off, float *agg,
-                       int mode /* 0 exact on several waves, 1 fast, 2 exact on one wave */, hipStream_t stream, float *segsum = nullptr,
+                       int mode /* 0 on several waves, 2 on one wave: the same exact sum */, hipStream_t stream, float *segsum = nullptr,
                        void *segmap = nullptr);
 
 // Column-blocked F = 1 stage (bit-identical to launch_stage on stage 0; see the kernels).
@@ -234,15 +237,15 @@ hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_
                              uint32_t row_base, uint32_t row_end, uint32_t slack, const PlanMap &pm,
                              uint32_t *bad /* |= 2 if a row's blocks do not ascend (the flat walk checks here, not in the count pass) */,
                              uint32_t chunk0 = 0, uint32_t chunk1 = 0xFFFFFFFFu);
-// Pruned adjacency (k_prune_*).  observe = largest degree among the vertices with a non-zero row of feat (16 columns).
-// The set of vertices whose rows are taken to be all zero, as a bitmap: mark_degree (degree >= bound) or mark_zero (the rows
-// that ARE all zero in feat).  count = per chunk of 64 entries which are kept (mask) and, scanned in place, how many before
+// Pruned adjacency (k_prune_*).  The set of vertices whose rows are taken to be all zero, as a bitmap: mark_zero (the rows that
+// ARE all zero in feat) or predict_zero_rows (the rows the graph's weights predict, at hand-off).  count = per chunk of 64 entries which are kept (mask) and, scanned in place, how many before
 // it (off: chunks + 1 words, off[chunks] = kept entries; scratch as for blocked_scan_scratch_elems(chunks + 1)); fill = the
 // kept entries (pcol, sized by the caller from off[chunks]) and the pruned row offsets (prp: rows + 1 words); check =
 // *bad |= 1 if a vertex of the set has a non-zero row in feat.
-hipError_t prune_observe(const GraphDev &g, const float *feat, uint32_t *max_deg, hipStream_t stream);
-hipError_t prune_mark_degree(const GraphDev &g, uint32_t bound, uint32_t *heavy_bits, hipStream_t stream);
 hipError_t prune_mark_zero(const GraphDev &g, const float *feat, uint32_t *heavy_bits, hipStream_t stream);
+// the set PREDICTED from the graph alone (hand-off): the vertices whose rows the F = 1 stage sp0 will write as all zero when the
+// caller's input is the reference driver's x = W / ws (see k_predict_zero_f1); whole graphs only
+hipError_t predict_zero_rows(const StagePlan &sp0, const GraphDev &g, float ws, const float *params, uint32_t *heavy_bits, hipStream_t stream);
 // filtered gather (GraphDev::zero_bits / zero_info): bits = n / 32 + 1 words, info = 3 words {degrees, members, verdict}, written
 // from feat (16 columns).  prev_bits / prev_info: an earlier stage's set of this forward — info[2] = 0 iff the lists that stage
 // left (GraphDev::keep_col) may stand for the adjacency with THIS input (GraphDev::short_bad points to info + 2).
@@ -333,6 +336,15 @@ hipError_t unpack_rows(const float *dense, const uint32_t *exc, uint32_t cap, ui
 hipError_t unpack_gathered(const float *buf, uint32_t world, uint32_t skip, size_t piece_words, uint32_t dense_rows,
                            uint32_t cap, uint32_t per, uint32_t off, uint32_t size, uint32_t n, uint32_t mask, uint32_t kp,
                            float *feat, hipStream_t stream);
+
+// several devices behind one handle: one packed piece (rows x kp dense floats + exception list of room `cap`) stored into n_dst
+// (<= 64) destination regions in one launch; the regions of one piece index from up to 64 peers expanded in one launch
+struct UnpackPiece {
+    const float *region;
+    uint32_t row_lo, row_hi;
+};
+hipError_t push_piece(const float *region, uint32_t rows, uint32_t kp, uint32_t cap, uint32_t n_dst, float *const *dst, hipStream_t stream);
+hipError_t unpack_pieces(const UnpackPiece *pieces, uint32_t n_pieces, uint32_t cap, uint32_t mask, uint32_t kp, float *feat, hipStream_t stream);
 
 // Reduction-rule predicates per vertex (one byte each) on the device CSR; see the kernel.
 hipError_t launch_reduction_flags(const GraphDev &g, uint32_t max_degree, uint8_t *flags, hipStream_t stream);

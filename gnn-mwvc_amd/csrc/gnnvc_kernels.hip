@@ -629,56 +629,143 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
 // more than the overlap gains — measured.)
 // acc4[u] = four sums (columns c4desc[1..4]) of a clean row, or {sign bit, slot} of a dirty one whose sixteen sums
 // sit in agg16[slot]; leaves at once when c4desc[0] == 0 (the gathering k_stage_f16 has the launch then).
-template <int N1, int N2>
-__global__ __launch_bounds__(kBlock) void k_dense_sigmoid(GraphDev g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
-                                                          float *__restrict__ logits, const float *__restrict__ P, uint32_t row_lo,
-                                                          uint32_t row_hi, const float4 *__restrict__ acc4,
-                                                          const uint32_t *__restrict__ c4desc, const float4 *__restrict__ agg16,
-                                                          uint32_t long_thresh) {
+// (round 4) The same kernel serves the FEATURE stage (SIGMOID false: 16 outputs per row, handed to full-row stores through a
+// per-wave LDS tile, and the producer side of the next stage's table, c4_emit) — and both skip what they know to be zero: a clean
+// row's 32 first-layer inputs are its four sums, its own values in the table's four columns (the input's compact table holds
+// exactly those: 16 bytes per vertex instead of its 64-byte row), degree and the two weights — at most 11 non-zero terms of the
+// 32-term chain, and fma(+-0, w, acc) == acc leaves every other term out bit for bit (what already drops columns 32 - 34).
+// Three routes, uniform per wave: (A) no dirty row, no vertex with stray non-zeros: <= 11 terms; (B) dirty rows (their sixteen
+// sums from agg16) but no stray vertex: 16 + <= 7 terms; (C) anything else (a stray vertex among the wave's own rows, several
+// passes): the full chain from full rows.  Terms run in ascending k in every route: the reference's order.
+template <int N>
+__device__ __forceinline__ void fma_term(float (&out)[N], float a, const float *__restrict__ Wrow) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) out[j] = __builtin_fmaf(a, Wrow[j], out[j]);
+}
+template <int N>
+__device__ __forceinline__ void bias_relu(float (&out)[N], const float *__restrict__ b) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) out[j] = relu_ref(out[j] + b[j]);
+}
+
+template <int N1, int N2, int N3, bool SIGMOID>
+__global__ __launch_bounds__(kBlock) void k_dense_f16(GraphDev g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
+                                                      float *__restrict__ logits, const float *__restrict__ P, uint32_t row_lo,
+                                                      uint32_t row_hi, const float4 *__restrict__ acc4,
+                                                      const uint32_t *__restrict__ c4desc, const float4 *__restrict__ agg16,
+                                                      const float4 *table_in /* may alias emit_table: each lane reads its row first */, uint32_t long_thresh,
+                                                      const uint32_t *__restrict__ emit_spec, c4row *__restrict__ emit_table,
+                                                      unsigned long long *__restrict__ emit_counts) {
+    static_assert(SIGMOID ? N3 == 1 : N3 == 16, "a feature stage writes 16 floats per row, the last stage one score");
+    __shared__ float lds[SIGMOID ? 1 : kWavesPerBlock][SIGMOID ? 1 : kWave * kOutPitch];
     if (c4desc[0] == 0) return;
+    const int lane = threadIdx.x & 63;
     const uint32_t uu = row_lo + blockIdx.x * kBlock + threadIdx.x;
     const uint32_t u = uu < row_hi ? uu : row_hi - 1;
-    const bool mine = uu < row_hi && g.rowptr[u + 1] - g.rowptr[u] < long_thresh;   // (longer rows: the long-row kernels')
+    const uint32_t deg = g.rowptr[u + 1] - g.rowptr[u];
+    const bool mine = uu < row_hi && deg < long_thresh;   // (longer rows: the long-row kernels')
     const uint32_t npass = c4desc[0];
+    const uint32_t d0 = c4desc[1], d1 = c4desc[2], d2 = c4desc[3], d3 = c4desc[4];
     const float4 a = acc4[u];
-    const float4 h0 = fin[(size_t)u * 4], h1 = fin[(size_t)u * 4 + 1], h2 = fin[(size_t)u * 4 + 2], h3 = fin[(size_t)u * 4 + 3];
-    // first-layer inputs in k order: 0..15 aggregate, 16 = h[0], 17 = degree, 18 = W/ws, 19 = NW/ws, 20..31 = h[4..15]
-    float x0[32];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) x0[k] = 0.0f;
-    for (uint32_t qp = 0; qp < npass; ++qp) {   // (uniform)
-        const uint32_t *dc = c4desc + (qp == 0 ? 1 : 4 + 4 * qp);
-        const uint32_t d0 = dc[0], d1 = dc[1], d2 = dc[2], d3 = dc[3];
-        const float4 aq = qp == 0 ? a : acc4[(size_t)qp * g.n + u];
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-            x0[k] = ((uint32_t)k == d0) ? aq.x : ((uint32_t)k == d1) ? aq.y : ((uint32_t)k == d2) ? aq.z : ((uint32_t)k == d3) ? aq.w : x0[k];
-    }
     const bool dirty = (__float_as_uint(a.x) >> 31) != 0;   // met a neighbour with stray non-zeros: recomputed from full rows by k_c4_fix
-    if (__any(dirty)) {
-        const size_t slot = dirty ? (size_t)__float_as_uint(a.y) : 0;
-        const float4 g0 = agg16[slot * 4], g1 = agg16[slot * 4 + 1], g2 = agg16[slot * 4 + 2], g3 = agg16[slot * 4 + 3];
-        const float gg[16] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w, g3.x, g3.y, g3.z, g3.w};
-#pragma unroll
-        for (int k = 0; k < 16; ++k) x0[k] = dirty ? gg[k] : x0[k];
-    }
-    x0[16] = h0.x;
-    x0[17] = (float)(g.rowptr[u + 1] - g.rowptr[u]);
-    x0[18] = (float)g.w[u] / ws;
-    x0[19] = (float)g.nw[u] / ws;
-    x0[20] = h1.x; x0[21] = h1.y; x0[22] = h1.z; x0[23] = h1.w;
-    x0[24] = h2.x; x0[25] = h2.y; x0[26] = h2.z; x0[27] = h2.w;
-    x0[28] = h3.x; x0[29] = h3.y; x0[30] = h3.z; x0[31] = h3.w;
+    // this vertex's own values in the table's columns (sign bit of the first: it has non-zeros elsewhere too)
+    const float4 t = (table_in != nullptr && npass == 1u) ? table_in[u] : make_float4(-0.0f, 0.f, 0.f, 0.f);
+    const bool stray = (__float_as_uint(t.x) >> 31) != 0;
+    const float f_deg = (float)deg, f_w = (float)g.w[u] / ws, f_nw = (float)g.nw[u] / ws;
     const float *W1 = P, *b1 = W1 + 35 * N1;
     const float *W2 = b1 + N1, *b2 = W2 + N1 * N2;
-    const float *W3 = b2 + N2, *b3 = W3 + N2;
-    float x1[N1], x2[N2], x3[1];
-    dense<32, 32, N1, 0>(x0, x1, W1, b1);   // rows 32..34 of W1 meet exact zeros
+    const float *W3 = b2 + N2, *b3 = W3 + N2 * N3;
+    float x1[N1];
+    if (!__any(stray)) {
+        // the own-row terms of the chain: k = 16 (h[0]), 17 .. 19, 16 + d for a table column d >= 4 (h[1..3] are overwritten by
+        // degree and weights in the reference's layout); a column slot without a column reads 0xFFFFFFFF
+        auto own_terms = [&]() {
+            if (d0 == 0u) fma_term<N1>(x1, t.x, W1 + 16 * N1);
+            fma_term<N1>(x1, f_deg, W1 + 17 * N1);
+            fma_term<N1>(x1, f_w, W1 + 18 * N1);
+            fma_term<N1>(x1, f_nw, W1 + 19 * N1);
+            if (d0 >= 4u && d0 < 16u) fma_term<N1>(x1, t.x, W1 + (16u + d0) * N1);
+            if (d1 >= 4u && d1 < 16u) fma_term<N1>(x1, t.y, W1 + (16u + d1) * N1);
+            if (d2 >= 4u && d2 < 16u) fma_term<N1>(x1, t.z, W1 + (16u + d2) * N1);
+            if (d3 >= 4u && d3 < 16u) fma_term<N1>(x1, t.w, W1 + (16u + d3) * N1);
+        };
+#pragma unroll
+        for (int j = 0; j < N1; ++j) x1[j] = 0.0f;
+        if (!__any(dirty)) {   // (A)
+            if (d0 < 16u) fma_term<N1>(x1, a.x, W1 + d0 * N1);
+            if (d1 < 16u) fma_term<N1>(x1, a.y, W1 + d1 * N1);
+            if (d2 < 16u) fma_term<N1>(x1, a.z, W1 + d2 * N1);
+            if (d3 < 16u) fma_term<N1>(x1, a.w, W1 + d3 * N1);
+        } else {               // (B)
+            const size_t slot = dirty ? (size_t)__float_as_uint(a.y) : 0;
+            const float4 g0 = agg16[slot * 4], g1 = agg16[slot * 4 + 1], g2 = agg16[slot * 4 + 2], g3 = agg16[slot * 4 + 3];
+            const float gg[16] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w, g3.x, g3.y, g3.z, g3.w};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float clean = ((uint32_t)k == d0) ? a.x : ((uint32_t)k == d1) ? a.y : ((uint32_t)k == d2) ? a.z : ((uint32_t)k == d3) ? a.w : 0.0f;
+                fma_term<N1>(x1, dirty ? gg[k] : clean, W1 + k * N1);
+            }
+        }
+        own_terms();
+        bias_relu<N1>(x1, b1);
+    } else {                   // (C)
+        const float4 h0 = fin[(size_t)u * 4], h1 = fin[(size_t)u * 4 + 1], h2 = fin[(size_t)u * 4 + 2], h3 = fin[(size_t)u * 4 + 3];
+        // first-layer inputs in k order: 0..15 aggregate, 16 = h[0], 17 = degree, 18 = W/ws, 19 = NW/ws, 20..31 = h[4..15]
+        float x0[32];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x0[k] = 0.0f;
+        for (uint32_t qp = 0; qp < npass; ++qp) {   // (uniform)
+            const uint32_t *dc = c4desc + (qp == 0 ? 1 : 4 + 4 * qp);
+            const uint32_t e0 = dc[0], e1 = dc[1], e2 = dc[2], e3 = dc[3];
+            const float4 aq = qp == 0 ? a : acc4[(size_t)qp * g.n + u];
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                x0[k] = ((uint32_t)k == e0) ? aq.x : ((uint32_t)k == e1) ? aq.y : ((uint32_t)k == e2) ? aq.z : ((uint32_t)k == e3) ? aq.w : x0[k];
+        }
+        if (__any(dirty)) {
+            const size_t slot = dirty ? (size_t)__float_as_uint(a.y) : 0;
+            const float4 g0 = agg16[slot * 4], g1 = agg16[slot * 4 + 1], g2 = agg16[slot * 4 + 2], g3 = agg16[slot * 4 + 3];
+            const float gg[16] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w, g3.x, g3.y, g3.z, g3.w};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) x0[k] = dirty ? gg[k] : x0[k];
+        }
+        x0[16] = h0.x;
+        x0[17] = f_deg;
+        x0[18] = f_w;
+        x0[19] = f_nw;
+        x0[20] = h1.x; x0[21] = h1.y; x0[22] = h1.z; x0[23] = h1.w;
+        x0[24] = h2.x; x0[25] = h2.y; x0[26] = h2.z; x0[27] = h2.w;
+        x0[28] = h3.x; x0[29] = h3.y; x0[30] = h3.z; x0[31] = h3.w;
+        dense<32, 32, N1, 0>(x0, x1, W1, b1);   // rows 32..34 of W1 meet exact zeros
+    }
+    float x2[N2], x3[N3];
     dense<N1, N1, N2, 0>(x1, x2, W2, b2);
-    dense<N2, N2, 1, 1>(x2, x3, W3, b3);
-    if (mine) {
-        if (logits) logits[u] = x3[0];
-        fout[u] = sigmoid_ref(x3[0]);
+    dense<N2, N2, N3, SIGMOID ? 1 : 0>(x2, x3, W3, b3);
+    if constexpr (SIGMOID) {
+        if (mine) {
+            if (logits) logits[u] = x3[0];
+            fout[u] = sigmoid_ref(x3[0]);
+        }
+    } else {
+        // the wave's 64 x 16 outputs through LDS: every global store instruction writes 16 full rows
+        float *T = lds[threadIdx.x >> 6];
+        uint32_t nz = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            T[lane * kOutPitch + j] = x3[j];
+            nz |= (x3[j] != 0.0f ? 1u : 0u) << j;
+        }
+        if (emit_counts) c4_emit(&T[lane * kOutPitch], nz, u, mine, lane, emit_spec, emit_table, emit_counts);
+        wave_lds_sync();
+        const int q = lane >> 2, c = lane & 3;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int src_lane = 16 * p + q;
+            const float *src = &T[src_lane * kOutPitch + 4 * c];
+            const float4 o = make_float4(src[0], src[1], src[2], src[3]);
+            const uint32_t row = __shfl(u, src_lane);
+            if (__shfl((int)mine, src_lane)) reinterpret_cast<float4 *>(fout)[(size_t)row * 4 + c] = o;
+        }
     }
 }
 
@@ -832,18 +919,38 @@ __global__ __launch_bounds__(kBlock) void k_stage_f1(
 // fp32 add chain as everywhere else, so results stay bit-identical.  The row's
 // dense layers then run on one lane.  Runs on a second stream beside the tile
 // kernel of the same stage (disjoint output rows).
-__global__ void k_find_long(GraphDev g, uint32_t thresh, uint32_t *__restrict__ list,
-                            uint32_t *__restrict__ count) {
-    // count[0] = rows listed; count[2..3] (one 64-bit word) = their entries
-    const uint32_t u = g.lo() + blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t d = u < g.hi() ? g.rowptr[u + 1] - g.rowptr[u] : 0u;
-    const bool is_long = u < g.hi() && d >= thresh;
-    if (is_long) list[atomicAdd(count, 1u)] = u;
-    unsigned long long mine = is_long ? d : 0u;
+__global__ __launch_bounds__(256) void k_find_long(GraphDev g, uint32_t thresh, uint32_t *__restrict__ list,
+                                                   uint32_t *__restrict__ count) {
+    // count[0] = rows listed; count[2..3] (one 64-bit word) = their entries.  A WAVE reserves the slots of its long rows with one
+    // atomic (round 4: one per row made 110 K atomics on one word of R-MAT-22's 4 M rows, 0.35 ms for a 0.02 ms pass), a block
+    // adds its entries with one; the list's order is free (every listed row gets a workgroup of its own).
+    __shared__ unsigned long long part[4];
+    const uint32_t lane = threadIdx.x & 63;
+    unsigned long long mine = 0;
+    for (uint32_t base = g.lo() + blockIdx.x * blockDim.x; base < g.hi(); base += gridDim.x * blockDim.x) {
+        const uint32_t u = base + threadIdx.x;
+        const uint32_t d = u < g.hi() ? g.rowptr[u + 1] - g.rowptr[u] : 0u;
+        const bool is_long = u < g.hi() && d >= thresh;
+        const unsigned long long m = __ballot(is_long);
+        if (m) {
+            uint32_t first = 0;
+            if (lane == 0) first = atomicAdd(count, (uint32_t)__popcll(m));
+            first = __shfl(first, 0);
+            if (is_long) {
+                list[first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = u;
+                mine += d;
+            }
+        }
+    }
 #pragma unroll
     for (int off = 32; off; off >>= 1)
         mine += ((unsigned long long)__shfl_xor((unsigned)(mine >> 32), off) << 32) | __shfl_xor((unsigned)mine, off);
-    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(reinterpret_cast<unsigned long long *>(count + 2), mine);
+    if (lane == 0) part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = part[0] + part[1] + part[2] + part[3];
+        if (t) atomicAdd(reinterpret_cast<unsigned long long *>(count + 2), t);
+    }
 }
 
 // The dense layers of ONE row on one WAVE (round 3): lane j holds output j of a layer, input k arrives from lane k through
@@ -1175,9 +1282,8 @@ __global__ __launch_bounds__(256) void k_long_f1(
 //                    the new binade.  A row crosses a binade about log2(degree) times, so nearly every window
 //                    is one step: ~1 ns per neighbour and column, columns in parallel;
 //   k_giant_dense    the rows' dense layers, one lane per row (as the tail of k_long_*).
-// All three skip rows outside [row_lo, row_hi) (vertex-partitioned runs).  FAST (option "hub_mode" 1, never
-// the default): k_giant_sum adds lane-strided partial sums and combines them with a wave tree — the
-// tolerance mode of SURVEY.md §7; results then differ from the chain's in the last bits.
+// All three skip rows outside [row_lo, row_hi) (vertex-partitioned runs).  (Rounds 1 - 3 carried a tolerance mode beside this —
+// lane-strided partial sums and a wave tree, "hub_mode" 1; with the exact path as fast as it is it bought nothing and is gone.)
 constexpr int kGiantB = 16;                          // addends per lane and window
 static_assert(kGiantB <= xsum::kMaxAppends, "a lane's appends must fit 32 bits before saturate()");
 constexpr uint32_t kGiantWin = 64u * kGiantB;        // 1024: streams are padded to a multiple of this
@@ -1265,13 +1371,7 @@ __global__ __launch_bounds__(256) void k_giant_gather1(GraphDev g, const float *
 }
 
 // one window of a stream: this lane's 16 addends are d[0..3]; valid are those with local index in [lo, hi)
-template <bool FAST>
-__device__ __forceinline__ void giant_window(const f32x4 (&d)[kGiantB / 4], int lane, int hi, float &acc, float &part) {
-    if constexpr (FAST) {
-#pragma unroll
-        for (int i = 0; i < kGiantB; ++i) part += (i < hi) ? d[i >> 2][i & 3] : 0.0f;
-        return;
-    }
+__device__ __forceinline__ void giant_window(const f32x4 (&d)[kGiantB / 4], int lane, int hi, float &acc) {
     int lo = 0;   // per lane: local indices below lo are consumed
     for (int guard = 0; guard < 66; ++guard) {   // every pass consumes at least one lane
         uint32_t E = 0, m = 0;
@@ -1339,16 +1439,27 @@ __device__ __forceinline__ void giant_window(const f32x4 (&d)[kGiantB / 4], int 
 //                    crosses into the next one — about log2(length) times per stream — or a marked segment) its windows are
 //                    walked as before.  The result never depends on the estimate, only the time does (host emulation with
 //                    estimates that are right, one off and random: tests/test_exact_sum_host.py).
+// (round 4 tried segments of ONE window, with the maps fetched 64 at a time and, in a second form, every window prefetched: the
+// walk of the power-law graph's 201 K-entry row went from 0.09 - 0.17 ms to 0.09 - 0.13 and to 0.10 - 0.19 ms — a wave pulling
+// its whole stream is bound by its own memory-level parallelism, a wave fetching on demand by a round trip per binade crossing —
+// while the segment kernels doubled; four windows per segment stay, the maps now arrive 64 at a time.)
 constexpr uint32_t kGiantSeg = 4;   // windows per segment: 4096 addends
 
-__global__ __launch_bounds__(64) void k_giant_segsum(const float *__restrict__ slab, const uint4 *__restrict__ meta,
+// (a block = kGiantSegWaves waves, one segment each: with one-window segments a block per segment would be a hundred thousand
+// one-wave workgroups on the power-law graph)
+constexpr uint32_t kGiantSegWaves = 4;
+__host__ __device__ inline uint32_t giant_seg_blocks(uint32_t maxseg) { return (maxseg + kGiantSegWaves - 1) / kGiantSegWaves; }
+
+__global__ __launch_bounds__(64 * kGiantSegWaves) void k_giant_segsum(const float *__restrict__ slab, const uint4 *__restrict__ meta,
                                                      const unsigned long long *__restrict__ off, uint32_t F, uint32_t maxseg,
                                                      float *__restrict__ segsum, uint32_t row_lo, uint32_t row_hi,
                                                      const uint32_t *__restrict__ prp, const uint32_t *__restrict__ prune_bad, uint32_t min_deg) {
-    const uint32_t st = blockIdx.x / maxseg, sg = blockIdx.x % maxseg, i = st / F, c = st % F;
+    const uint32_t sb = giant_seg_blocks(maxseg);
+    const uint32_t st = blockIdx.x / sb, sg = (blockIdx.x % sb) * kGiantSegWaves + (threadIdx.x >> 6), i = st / F, c = st % F;
+    if (sg >= maxseg) return;
     const uint4 mt = meta[i];
     if (mt.x < row_lo || mt.x >= row_hi || mt.z < min_deg) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const bool pruned = prune_bad != nullptr && *prune_bad == 0u;
     const uint32_t len = pruned ? prp[mt.x + 1] - prp[mt.x] : mt.z;
     const uint32_t lpad = (len + kGiantWin - 1) / kGiantWin * kGiantWin, nwin = lpad / kGiantWin;
@@ -1368,16 +1479,17 @@ __global__ __launch_bounds__(64) void k_giant_segsum(const float *__restrict__ s
     if (lane == 0) segsum[(size_t)st * maxseg + sg] = part;
 }
 
-__global__ __launch_bounds__(64) void k_giant_segmap(const float *__restrict__ slab, const uint4 *__restrict__ meta,
+__global__ __launch_bounds__(64 * kGiantSegWaves) void k_giant_segmap(const float *__restrict__ slab, const uint4 *__restrict__ meta,
                                                      const unsigned long long *__restrict__ off, uint32_t F, uint32_t maxseg,
                                                      const float *__restrict__ segsum, uint4 *__restrict__ segmap, uint32_t row_lo,
                                                      uint32_t row_hi, const uint32_t *__restrict__ prp,
                                                      const uint32_t *__restrict__ prune_bad, uint32_t min_deg) {
-    const uint32_t st = blockIdx.x / maxseg, sg = blockIdx.x % maxseg, i = st / F, c = st % F;
-    if (sg == 0) return;                                  // (the first segment is always walked: nothing in front of it to estimate)
+    const uint32_t sb = giant_seg_blocks(maxseg);
+    const uint32_t st = blockIdx.x / sb, sg = (blockIdx.x % sb) * kGiantSegWaves + (threadIdx.x >> 6), i = st / F, c = st % F;
+    if (sg == 0 || sg >= maxseg) return;                  // (the first segment is always walked: nothing in front of it to estimate)
     const uint4 mt = meta[i];
     if (mt.x < row_lo || mt.x >= row_hi || mt.z < min_deg) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const bool pruned = prune_bad != nullptr && *prune_bad == 0u;
     const uint32_t len = pruned ? prp[mt.x + 1] - prp[mt.x] : mt.z;
     const uint32_t lpad = (len + kGiantWin - 1) / kGiantWin * kGiantWin, nwin = lpad / kGiantWin;
@@ -1423,7 +1535,6 @@ __global__ __launch_bounds__(64) void k_giant_segmap(const float *__restrict__ s
     if (lane == 0) segmap[(size_t)st * maxseg + sg] = make_uint4(E, total.d0, total.d1, any_bad ? 1u : 0u);
 }
 
-template <bool FAST>
 __global__ __launch_bounds__(64) void k_giant_sum(const float *__restrict__ slab, const uint4 *__restrict__ meta,
                                                   const unsigned long long *__restrict__ off, uint32_t F, float *__restrict__ agg,
                                                   uint32_t row_lo, uint32_t row_hi, const uint32_t *__restrict__ prp,
@@ -1455,15 +1566,25 @@ __global__ __launch_bounds__(64) void k_giant_sum(const float *__restrict__ slab
     {                                                                                      \
         const long long left_ = (long long)len - (long long)(w_) * kGiantWin - (long long)lane * kGiantB; \
         const int hi_ = left_ <= 0 ? 0 : (left_ >= kGiantB ? kGiantB : (int)left_);         \
-        giant_window<FAST>(buf[slot_], lane, hi_, acc, part);                              \
+        giant_window(buf[slot_], lane, hi_, acc);                                          \
     }
-    float acc = 0.0f, part = 0.0f;
-    const bool segmented = !FAST && segmap != nullptr;
+    float acc = 0.0f;
+    const bool segmented = segmap != nullptr;
     const uint32_t segw = segmented ? kGiantSeg : nwin;      // (no maps: the whole stream is one walk)
+    const uint32_t nseg = (nwin + segw - 1) / segw;
+    // lane j: the map of segment (sg & ~63) + j — fetched 64 at a time, ahead of their use (round 4: a dependent fetch per
+    // segment was a third of the walk's time on the power-law graph's 201 K-entry row)
+    uint4 maps = make_uint4(0u, 0u, 0u, 1u);
     for (uint32_t w0 = 0, sg = 0; w0 < nwin; w0 += segw, ++sg) {
         const uint32_t w1 = min(nwin, w0 + segw);
+        if (segmented && (sg & 63u) == 0u) {
+            const uint32_t j = sg + (uint32_t)lane;
+            maps = (j >= 1u && j < nseg) ? segmap[(size_t)blockIdx.x * maxseg + j] : make_uint4(0u, 0u, 0u, 1u);
+        }
         if (segmented && sg > 0) {   // the segment in one step, if its map was made for the binade the accumulator is in
-            const uint4 mp = segmap[(size_t)blockIdx.x * maxseg + sg];
+            const int src_lane = (int)(sg & 63u);
+            const uint4 mp = make_uint4((uint32_t)__builtin_amdgcn_readlane((int)maps.x, src_lane), (uint32_t)__builtin_amdgcn_readlane((int)maps.y, src_lane),
+                                        (uint32_t)__builtin_amdgcn_readlane((int)maps.z, src_lane), (uint32_t)__builtin_amdgcn_readlane((int)maps.w, src_lane));
             uint32_t E = 0, m = 0;
             if (mp.w == 0u && xsum::decode_acc(__float_as_uint(acc), E, m) && E == mp.x) {
                 const uint32_t D = (m & 1u) ? mp.z : mp.y;
@@ -1486,11 +1607,6 @@ __global__ __launch_bounds__(64) void k_giant_sum(const float *__restrict__ slab
     }
 #undef GNNVC_GIANT_LOAD
 #undef GNNVC_GIANT_USE
-    if constexpr (FAST) {
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) part += __shfl_xor(part, s);
-        acc = part;
-    }
     if (lane == 0) agg[(size_t)i * 16 + c] = acc;
 }
 
@@ -2768,39 +2884,6 @@ __global__ void k_c4_mark(const uint32_t *__restrict__ desc, uint32_t *__restric
 // (Default: not a degree bound but the very set of vertices whose rows were all zero in the input the plan was built from —
 // a graph's stage inputs are the same on every forward, they follow from its weights — which also catches the zero rows of
 // low-degree vertices: R-MAT-22's last stage keeps 14 % of the entries instead of 25 %.)
-__global__ __launch_bounds__(256) void k_prune_observe(GraphDev g, const float4 *__restrict__ feat, uint32_t *__restrict__ max_deg) {
-    uint32_t best = 0;
-    bool any = false;
-    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < g.n; u += gridDim.x * blockDim.x) {
-        const float4 a = feat[(size_t)u * 4], b = feat[(size_t)u * 4 + 1], c = feat[(size_t)u * 4 + 2], d = feat[(size_t)u * 4 + 3];
-        const bool nz = a.x != 0.f || a.y != 0.f || a.z != 0.f || a.w != 0.f || b.x != 0.f || b.y != 0.f || b.z != 0.f || b.w != 0.f ||
-                        c.x != 0.f || c.y != 0.f || c.z != 0.f || c.w != 0.f || d.x != 0.f || d.y != 0.f || d.z != 0.f || d.w != 0.f;
-        if (nz) {   // (NaN != 0: a row with a NaN counts as non-zero)
-            const uint32_t deg = g.rowptr[u + 1] - g.rowptr[u];
-            best = deg > best ? deg : best;
-            any = true;
-        }
-    }
-#pragma unroll
-    for (int off = 32; off; off >>= 1) {
-        const uint32_t o = __shfl_xor(best, off);
-        best = o > best ? o : best;
-    }
-    if (__any(any) && (threadIdx.x & 63) == 0) atomicMax(max_deg, best);
-}
-
-// heavy_bits: bit v = degree(v) >= bound (one thread per word)
-__global__ __launch_bounds__(256) void k_prune_mark(GraphDev g, uint32_t bound, uint32_t *__restrict__ heavy_bits) {
-    const uint32_t wd = blockIdx.x * blockDim.x + threadIdx.x;
-    if (wd >= (g.n + 31) / 32) return;
-    uint32_t bits = 0;
-    for (uint32_t i = 0; i < 32; ++i) {
-        const uint32_t v = wd * 32 + i;
-        if (v < g.n && g.rowptr[v + 1] - g.rowptr[v] >= bound) bits |= 1u << i;
-    }
-    heavy_bits[wd] = bits;
-}
-
 // heavy_bits: bit v = row v of feat is all zero (one wave per 64 vertices: two words)
 __global__ __launch_bounds__(256) void k_prune_mark_zero(const float4 *__restrict__ feat, uint32_t n, uint32_t *__restrict__ heavy_bits) {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;   // (the grid covers n rounded up to 64)
@@ -2812,6 +2895,50 @@ __global__ __launch_bounds__(256) void k_prune_mark_zero(const float4 *__restric
     }
     const unsigned long long m = __ballot(zero);
     const uint32_t w0 = (u & ~63u) >> 5, words = (n + 31) / 32;
+    if ((threadIdx.x & 63) == 0 && w0 < words) heavy_bits[w0] = (uint32_t)m;
+    if ((threadIdx.x & 63) == 1 && w0 + 1 < words) heavy_bits[w0 + 1] = (uint32_t)(m >> 32);
+}
+
+// heavy_bits: bit v = row v of the F = 1 stage's OUTPUT is PREDICTED to be all zero — from the graph alone, when it is handed
+// over (round 4).  The reference's driver feeds x[u] = (float)W(u) / ws (src/GNN_VC.cpp:189-191), so the stage's first-layer
+// input of vertex u is [sum of its neighbours' x, x[u], degree, W/ws, NW/ws] with the sum ~ NW/ws (the same weights added
+// as integers instead of as rounded floats).  The kernel runs the stage's dense layers on that input and sets the bit when
+// every output is below zero BY A MARGIN before the last ReLU (the margin covers the sum's rounding: a row that close to the
+// kink is simply left out of the set).  A prediction, never a proof: every call proves on the device that the set's rows are
+// all zero in ITS input (k_prune_check) and takes the full adjacency if one is not — an input other than W/ws costs time,
+// never a bit.  Vertices without entries are left out (nothing points to them on a symmetric adjacency).
+template <int N1, int N2, int N3>
+__global__ __launch_bounds__(256) void k_predict_zero_f1(GraphDev g, float ws, const float *__restrict__ P, uint32_t *__restrict__ heavy_bits) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;   // (the grid covers n rounded up to 64)
+    const uint32_t uc = u < g.n ? u : g.n - 1;
+    const uint32_t deg = g.rowptr[uc + 1] - g.rowptr[uc];
+    bool zero = false;
+    if (__any(u < g.n && deg != 0)) {   // (uniform per wave: R-MAT's runs of isolated vertices cost nothing)
+        float x0[5];
+        x0[1] = (float)g.w[uc] / ws;
+        x0[2] = (float)deg;
+        x0[3] = x0[1];
+        x0[4] = (float)g.nw[uc] / ws;
+        x0[0] = x0[4];
+        const float *W1 = P, *b1 = W1 + 5 * N1;
+        const float *W2 = b1 + N1, *b2 = W2 + N1 * N2;
+        const float *W3 = b2 + N2, *b3 = W3 + N2 * N3;
+        float x1[N1], x2[N2], x3[N3];
+        dense<5, 5, N1, 0>(x0, x1, W1, b1);
+        dense<N1, N1, N2, 0>(x1, x2, W2, b2);
+        dense<N2, N2, N3, 1>(x2, x3, W3, b3);   // (no ReLU: the margin is taken on the pre-activations)
+        float top = x3[0], scale = 0.0f;
+#pragma unroll
+        for (int j = 0; j < N3; ++j) {
+            top = x3[j] > top ? x3[j] : top;
+            scale = fabsf(x3[j]) > scale ? fabsf(x3[j]) : scale;
+        }
+#pragma unroll
+        for (int k = 0; k < N2; ++k) scale = x2[k] > scale ? x2[k] : scale;
+        zero = u < g.n && deg != 0 && top <= -1e-3f * (1.0f + scale);   // (a NaN compares false: not in the set)
+    }
+    const unsigned long long m = __ballot(zero);
+    const uint32_t w0 = (u & ~63u) >> 5, words = (g.n + 31) / 32;
     if ((threadIdx.x & 63) == 0 && w0 < words) heavy_bits[w0] = (uint32_t)m;
     if ((threadIdx.x & 63) == 1 && w0 + 1 < words) heavy_bits[w0 + 1] = (uint32_t)(m >> 32);
 }
@@ -3434,6 +3561,60 @@ __global__ __launch_bounds__(256) void k_unpack_gathered_exceptions(const float 
     }
 }
 
+// ---- several devices behind one handle (gnnvc_multi.cpp): a packed piece goes to every peer in ONE launch — the stores land
+// in the peers' memory over the fabric (peer access enabled) or, where parts share a device, in local memory — and a receiver
+// expands the regions of one piece index from all its peers in one launch.
+struct PushDst {
+    float *p[64];
+};
+// region = dense_words floats (a multiple of 4) followed by the exception list {count, -, -, -, entries of 4 words}: the dense
+// part and the USED part of the list are copied to destination blockIdx.y, 16 bytes per lane
+__global__ __launch_bounds__(256) void k_push_piece(const float *__restrict__ src, size_t dense_words, uint32_t cap, PushDst dst) {
+    float *__restrict__ out = dst.p[blockIdx.y];
+    const float4 *__restrict__ s4 = reinterpret_cast<const float4 *>(src);
+    float4 *__restrict__ d4 = reinterpret_cast<float4 *>(out);
+    const size_t quads = dense_words / 4, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += stride) d4[i] = s4[i];
+    const uint4 *__restrict__ e4 = reinterpret_cast<const uint4 *>(src + dense_words);
+    uint4 *__restrict__ o4 = reinterpret_cast<uint4 *>(out + dense_words);
+    const uint32_t count = min(reinterpret_cast<const uint32_t *>(src + dense_words)[0], cap);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)count + 1; i += stride) o4[i] = e4[i];
+}
+
+struct PieceRef {
+    const float *region;
+    uint32_t row_lo, row_hi;
+};
+struct PieceList {
+    PieceRef d[64];
+};
+// blockIdx.y = piece: feat rows [row_lo, row_hi) from its dense part (k_unpack_rows' expansion)
+__global__ __launch_bounds__(256) void k_unpack_pieces(PieceList pl, uint32_t mask, uint32_t kp, float *__restrict__ feat) {
+    const PieceRef pr = pl.d[blockIdx.y];
+    const uint32_t rows = pr.row_hi - pr.row_lo;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)rows * 4; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t rel = (uint32_t)(i >> 2), q = (uint32_t)(i & 3);
+        const float *src = pr.region + (size_t)rel * kp;
+        float v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t c = 4 * q + t;
+            v[t] = (mask >> c & 1u) ? src[__popc(mask & ((1u << c) - 1u))] : 0.0f;
+        }
+        reinterpret_cast<float4 *>(feat)[((size_t)pr.row_lo + rel) * 4 + q] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+__global__ __launch_bounds__(256) void k_unpack_pieces_exceptions(PieceList pl, uint32_t cap, uint32_t kp, float *__restrict__ feat) {
+    const PieceRef pr = pl.d[blockIdx.y];
+    const uint32_t rows = pr.row_hi - pr.row_lo;
+    const uint32_t *exc = reinterpret_cast<const uint32_t *>(pr.region + (size_t)rows * kp);
+    const uint32_t count = min(exc[0], cap);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const uint4 en = reinterpret_cast<const uint4 *>(exc)[1 + i];
+        if (en.x < rows && en.y < 16u) feat[((size_t)pr.row_lo + en.x) * 16 + en.y] = __uint_as_float(en.z);   // (never trust a received index with a store)
+    }
+}
+
 // the exception list of the same piece, applied after k_unpack_rows (stream order)
 __global__ __launch_bounds__(256) void k_unpack_exceptions(const uint32_t *__restrict__ exc, uint32_t cap, uint32_t row_lo,
                                                            uint32_t row_hi, float *__restrict__ feat) {
@@ -3728,13 +3909,14 @@ int stage_variant(int f, int n1, int n2, int n3, int sigmoid_last) {
 // the dense layers + sigmoid of the last stage when its aggregates are ready (compact-table plan): rows [row_lo, row_hi)
 hipError_t launch_dense_sigmoid(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *in, float *out,
                                 float *logits, uint32_t row_lo, uint32_t row_hi, const float *acc4, const uint32_t *c4desc,
-                                const float *agg16, hipStream_t stream, uint32_t long_thresh) {
+                                const float *agg16, hipStream_t stream, uint32_t long_thresh, const float *table_in) {
     if (row_hi <= row_lo) return hipSuccess;
     if (sp.f != 16 || sp.variant != 2 || !acc4 || !c4desc) return hipErrorInvalidValue;
     const dim3 grid((row_hi - row_lo + kBlock - 1) / kBlock), block(kBlock);
-    GNNVC_LAUNCH((k_dense_sigmoid<32, 16>), grid, block, 0, stream, g, ws, reinterpret_cast<const float4 *>(in), out, logits,
+    GNNVC_LAUNCH((k_dense_f16<32, 16, 1, true>), grid, block, 0, stream, g, ws, reinterpret_cast<const float4 *>(in), out, logits,
                        params + sp.param_offset, row_lo, row_hi, reinterpret_cast<const float4 *>(acc4), c4desc,
-                       reinterpret_cast<const float4 *>(agg16), long_thresh);
+                       reinterpret_cast<const float4 *>(agg16), reinterpret_cast<const float4 *>(table_in), long_thresh,
+                       (const uint32_t *)nullptr, (c4row *)nullptr, (unsigned long long *)nullptr);
     return hipGetLastError();
 }
 
@@ -3742,7 +3924,7 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
                         const float *in, float *out, float *logits, uint32_t row_lo,
                         uint32_t row_hi, uint32_t long_thresh, bool mfma, const SortedOrder *so,
                         bool interleave, hipStream_t stream, const float *acc4, const uint32_t *c4desc, const float *agg16,
-                        bool mfma_agg, const EmitArgs &emit, bool dense_part, const SortedOrder *so_pruned) {
+                        bool mfma_agg, const EmitArgs &emit, bool dense_part, const SortedOrder *so_pruned, const float *table_in) {
     if (row_hi <= row_lo) return hipSuccess;
     const bool sorted = so && so->n > 0;
     const bool with_p = sorted && g.prune_eff && so_pruned && so_pruned->vertex;
@@ -3838,11 +4020,18 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
                            (MF_ || SIG_) ? nullptr : emit.spec, reinterpret_cast<c4row *>((MF_ || SIG_) ? nullptr : emit.table), \
                            (MF_ || SIG_) ? nullptr : emit.counts)
         if (sp.variant == 1) {
-            if (mfma_agg) GNNVC_LAUNCH_AGG(32, 16, false, true, nullptr);
-            else GNNVC_LAUNCH_AGG(32, 16, false, false, nullptr);
+            if (mfma_agg) {
+                GNNVC_LAUNCH_AGG(32, 16, false, true, nullptr);
+            } else {   // (round 4: one lane per row, the terms that are zero left out — k_dense_f16)
+                const dim3 dgrid((row_hi - row_lo + kBlock - 1) / kBlock);
+                GNNVC_LAUNCH((k_dense_f16<32, 32, 16, false>), dgrid, block, 0, stream, g, ws, in4, out, (float *)nullptr, P, row_lo, row_hi,
+                                   reinterpret_cast<const float4 *>(acc4), c4desc, reinterpret_cast<const float4 *>(agg16),
+                                   reinterpret_cast<const float4 *>(table_in), long_thresh, emit.spec,
+                                   reinterpret_cast<c4row *>(emit.table), emit.counts);
+            }
         } else {
             if (mfma_agg) GNNVC_LAUNCH_AGG(16, 1, true, true, logits);
-            else return launch_dense_sigmoid(sp, g, ws, params, in, out, logits, row_lo, row_hi, acc4, c4desc, agg16, stream, long_thresh);
+            else return launch_dense_sigmoid(sp, g, ws, params, in, out, logits, row_lo, row_hi, acc4, c4desc, agg16, stream, long_thresh, table_in);
         }
 #undef GNNVC_LAUNCH_AGG
     }
@@ -4091,20 +4280,6 @@ hipError_t lds_table_scatter(const GraphDev &g, uint32_t rows_per_chunk, uint32_
     return hipGetLastError();
 }
 
-hipError_t prune_observe(const GraphDev &g, const float *feat, uint32_t *max_deg, hipStream_t stream) {
-    hipError_t rc = hipMemsetAsync(max_deg, 0, sizeof(uint32_t), stream);
-    if (rc != hipSuccess || g.n == 0) return rc;
-    GNNVC_LAUNCH(k_prune_observe, dim3(std::min<unsigned>((g.n + 255) / 256, 4096u)), dim3(256), 0, stream, g,
-                 reinterpret_cast<const float4 *>(feat), max_deg);
-    return hipGetLastError();
-}
-
-hipError_t prune_mark_degree(const GraphDev &g, uint32_t bound, uint32_t *heavy_bits, hipStream_t stream) {
-    if (g.n == 0) return hipSuccess;
-    GNNVC_LAUNCH(k_prune_mark, dim3(((g.n + 31) / 32 + 255) / 256), dim3(256), 0, stream, g, bound, heavy_bits);
-    return hipGetLastError();
-}
-
 hipError_t filter_mark(const GraphDev &g, const float *feat, uint32_t *bits, unsigned long long *info, hipStream_t stream,
                        const uint32_t *prev_bits, const unsigned long long *prev_info) {
     hipError_t rc = hipMemsetAsync(info, 0, 3 * sizeof(unsigned long long), stream);
@@ -4122,6 +4297,13 @@ hipError_t prune_mark_zero(const GraphDev &g, const float *feat, uint32_t *heavy
 
 // mask: one 64-bit word per chunk of 64 entries, off: chunks + 1 words (scanned in place: off[chunks] = kept entries;
 // scratch as for blocked_scan_scratch_elems(chunks + 1))
+hipError_t predict_zero_rows(const StagePlan &sp0, const GraphDev &g, float ws, const float *params, uint32_t *heavy_bits, hipStream_t stream) {
+    if (g.n == 0) return hipSuccess;
+    if (sp0.variant != 0 || g.sliced()) return hipErrorInvalidValue;   // (the F = 1 stage 5 -> 32 -> 32 -> 16; a slice lacks the other rows' degrees)
+    GNNVC_LAUNCH((k_predict_zero_f1<32, 32, 16>), dim3((g.n + 255) / 256), dim3(256), 0, stream, g, ws, params + sp0.param_offset, heavy_bits);
+    return hipGetLastError();
+}
+
 hipError_t prune_mass(const GraphDev &g, const uint32_t *heavy_bits, unsigned long long *mass, hipStream_t stream, const uint32_t *prev_bits) {
     hipError_t rc = hipMemsetAsync(mass, 0, 3 * sizeof(unsigned long long), stream);
     if (rc != hipSuccess || g.n == 0) return rc;
@@ -4343,7 +4525,7 @@ hipError_t find_long_rows(const GraphDev &g, uint32_t thresh, uint32_t *list, ui
                           hipStream_t stream) {
     hipError_t rc = hipMemsetAsync(count, 0, 4 * sizeof(uint32_t), stream);   // (count: 4 words, see k_find_long)
     if (rc != hipSuccess || g.hi() <= g.lo()) return rc;
-    GNNVC_LAUNCH(k_find_long, dim3((g.hi() - g.lo() + 255) / 256), dim3(256), 0, stream, g, thresh, list, count);
+    GNNVC_LAUNCH(k_find_long, dim3(std::min<unsigned>((g.hi() - g.lo() + 255) / 256, 2048u)), dim3(256), 0, stream, g, thresh, list, count);
     return hipGetLastError();
 }
 
@@ -4385,7 +4567,7 @@ uint32_t giant_window() { return kGiantWin; }
 uint32_t giant_block() { return kGiantBlk; }
 
 hipError_t launch_giant_stage(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *in, float *out,
-                              float *logits, uint32_t row_lo, uint32_t row_hi, const GiantRows &gr, bool fast, hipStream_t stream, uint32_t min_deg,
+                              float *logits, uint32_t row_lo, uint32_t row_hi, const GiantRows &gr, hipStream_t stream, uint32_t min_deg,
                               int part) {
     // part: 0 = everything on `stream`, 1 = the gather only, 2 = everything behind the gather (the engine puts the gather — a
     // throughput kernel, 0.03 ms alone — on the main queue AHEAD of the tile kernel and the walk on the side queue: queued
@@ -4403,18 +4585,16 @@ hipError_t launch_giant_stage(const StagePlan &sp, const GraphDev &g, float ws, 
             GNNVC_LAUNCH(k_giant_gather1, dim3(gr.blocks), dim3(256), 0, stream, g, in, gr.slab, meta, gr.off, gr.n, row_lo, row_hi);
         if (part == 1) return hipGetLastError();
     }
-    if (fast) {
-        GNNVC_LAUNCH(k_giant_sum<true>, dim3(gr.n * F), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.agg, row_lo, row_hi, pr, pb,
-                     (const uint4 *)nullptr, 0u, min_deg);
-    } else {
+    {
         const bool seg = gr.segsum && gr.segmap && gr.maxseg > 1;   // one stream on several waves (see k_giant_segmap)
         if (seg) {
-            GNNVC_LAUNCH(k_giant_segsum, dim3(gr.n * F * gr.maxseg), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.maxseg, gr.segsum,
+            const dim3 sgrid(gr.n * F * giant_seg_blocks(gr.maxseg)), sblock(64 * kGiantSegWaves);
+            GNNVC_LAUNCH(k_giant_segsum, sgrid, sblock, 0, stream, gr.slab, meta, gr.off, F, gr.maxseg, gr.segsum,
                          row_lo, row_hi, pr, pb, min_deg);
-            GNNVC_LAUNCH(k_giant_segmap, dim3(gr.n * F * gr.maxseg), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.maxseg, gr.segsum,
+            GNNVC_LAUNCH(k_giant_segmap, sgrid, sblock, 0, stream, gr.slab, meta, gr.off, F, gr.maxseg, gr.segsum,
                          reinterpret_cast<uint4 *>(gr.segmap), row_lo, row_hi, pr, pb, min_deg);
         }
-        GNNVC_LAUNCH(k_giant_sum<false>, dim3(gr.n * F), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.agg, row_lo, row_hi, pr, pb,
+        GNNVC_LAUNCH(k_giant_sum, dim3(gr.n * F), dim3(64), 0, stream, gr.slab, meta, gr.off, F, gr.agg, row_lo, row_hi, pr, pb,
                      seg ? reinterpret_cast<const uint4 *>(gr.segmap) : nullptr, gr.maxseg, min_deg);
     }
     const float *P = params + sp.param_offset;
@@ -4435,27 +4615,24 @@ uint32_t giant_segments(uint32_t len) {   // segments of a stream of `len` adden
     return (nwin + kGiantSeg - 1) / kGiantSeg;
 }
 
-// mode: 0 = exact, the stream on several waves (segsum / segmap: streams x giant_segments(len) floats / uint4, may be null:
-// then as mode 2), 1 = fast (tolerance), 2 = exact, one wave walks the whole stream
+// mode: 0 = the stream on several waves (segsum / segmap: streams x giant_segments(len) floats / uint4, may be null:
+// then as mode 2), 2 = one wave walks the whole stream; the same exact sum either way
 hipError_t stream_sums(const float *streams_dev, uint32_t streams, uint32_t len, void *meta, unsigned long long *off, float *agg,
                        int mode, hipStream_t stream, float *segsum, void *segmap) {
     if (!streams) return hipSuccess;
     GNNVC_LAUNCH(k_stream_meta, dim3((streams + 256) / 256), dim3(256), 0, stream, reinterpret_cast<uint4 *>(meta), off, streams, len);
     const uint4 *mt = reinterpret_cast<const uint4 *>(meta);
     const uint32_t *none = nullptr;
-    if (mode == 1) {
-        GNNVC_LAUNCH(k_giant_sum<true>, dim3(streams), dim3(64), 0, stream, streams_dev, mt, off, 1u, agg, 0u, 1u, none, none,
-                     (const uint4 *)nullptr, 0u, 0u);
-        return hipGetLastError();
-    }
+    if (mode != 0 && mode != 2) return hipErrorInvalidValue;
     const uint32_t maxseg = giant_segments(len);
     const bool seg = mode == 0 && segsum && segmap && maxseg > 1;
     if (seg) {
-        GNNVC_LAUNCH(k_giant_segsum, dim3(streams * maxseg), dim3(64), 0, stream, streams_dev, mt, off, 1u, maxseg, segsum, 0u, 1u, none, none, 0u);
-        GNNVC_LAUNCH(k_giant_segmap, dim3(streams * maxseg), dim3(64), 0, stream, streams_dev, mt, off, 1u, maxseg, segsum,
+        const dim3 sgrid(streams * giant_seg_blocks(maxseg)), sblock(64 * kGiantSegWaves);
+        GNNVC_LAUNCH(k_giant_segsum, sgrid, sblock, 0, stream, streams_dev, mt, off, 1u, maxseg, segsum, 0u, 1u, none, none, 0u);
+        GNNVC_LAUNCH(k_giant_segmap, sgrid, sblock, 0, stream, streams_dev, mt, off, 1u, maxseg, segsum,
                      reinterpret_cast<uint4 *>(segmap), 0u, 1u, none, none, 0u);
     }
-    GNNVC_LAUNCH(k_giant_sum<false>, dim3(streams), dim3(64), 0, stream, streams_dev, mt, off, 1u, agg, 0u, 1u, none, none,
+    GNNVC_LAUNCH(k_giant_sum, dim3(streams), dim3(64), 0, stream, streams_dev, mt, off, 1u, agg, 0u, 1u, none, none,
                  seg ? reinterpret_cast<const uint4 *>(segmap) : nullptr, maxseg, 0u);
     return hipGetLastError();
 }
@@ -4563,6 +4740,36 @@ hipError_t unpack_gathered(const float *buf, uint32_t world, uint32_t skip, size
     if (cap)
         GNNVC_LAUNCH(k_unpack_gathered_exceptions, dim3(std::min<unsigned>((cap + 255) / 256, 64), world), dim3(256), 0,
                            stream, buf, skip, piece_words, dense_rows, cap, per, off, size, n, kp, feat);
+    return hipGetLastError();
+}
+
+hipError_t push_piece(const float *region, uint32_t rows, uint32_t kp, uint32_t cap, uint32_t n_dst, float *const *dst, hipStream_t stream) {
+    if (!n_dst) return hipSuccess;
+    if (n_dst > 64 || kp < 4 || kp > 16 || (kp & 3u)) return hipErrorInvalidValue;
+    PushDst pd{};
+    for (uint32_t i = 0; i < n_dst; ++i) pd.p[i] = dst[i];
+    const size_t dense_words = (size_t)rows * kp;
+    // (a modest grid per destination: the stores are paced by the links, and the CUs are wanted by the next piece's kernels)
+    const unsigned bx = (unsigned)std::min<size_t>(std::max<size_t>((dense_words / 4 + 255) / 256, 1), 64);
+    GNNVC_LAUNCH(k_push_piece, dim3(bx, n_dst), dim3(256), 0, stream, region, dense_words, cap, pd);
+    return hipGetLastError();
+}
+
+hipError_t unpack_pieces(const UnpackPiece *pieces, uint32_t n_pieces, uint32_t cap, uint32_t mask, uint32_t kp, float *feat, hipStream_t stream) {
+    if (!n_pieces) return hipSuccess;
+    if (n_pieces > 64 || kp < 4 || kp > 16 || (uint32_t)__builtin_popcount(mask & 0xFFFFu) > kp) return hipErrorInvalidValue;
+    PieceList pl{};
+    uint32_t most = 0;
+    for (uint32_t i = 0; i < n_pieces; ++i) {
+        if (pieces[i].row_hi < pieces[i].row_lo) return hipErrorInvalidValue;
+        pl.d[i] = PieceRef{pieces[i].region, pieces[i].row_lo, pieces[i].row_hi};
+        most = std::max(most, pieces[i].row_hi - pieces[i].row_lo);
+    }
+    if (!most) return hipSuccess;
+    const unsigned bx = (unsigned)std::min<size_t>(((size_t)most * 4 + 255) / 256, 2048);
+    GNNVC_LAUNCH(k_unpack_pieces, dim3(bx, n_pieces), dim3(256), 0, stream, pl, mask & 0xFFFFu, kp, feat);
+    if (cap)
+        GNNVC_LAUNCH(k_unpack_pieces_exceptions, dim3(std::min<unsigned>((cap + 255) / 256, 64), n_pieces), dim3(256), 0, stream, pl, cap, kp, feat);
     return hipGetLastError();
 }
 

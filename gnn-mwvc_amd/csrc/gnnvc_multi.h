@@ -1,9 +1,10 @@
 // gnnvc_multi.h — several devices behind one handle (gnnvc_create_multi, include/gnnvc.h).  Internal.
 //
 // The front handle is an ordinary engine on devices[0]; its `multi` member points to the state below, which drives one
-// ordinary engine per device through the PUBLIC ABI (gnnvc_attach_graph_slice / gnnvc_stage_forward_device): each holds the
-// CSR slice of its rows and full-size replicated feature buffers, and after the first and second stage every device
-// copies the rows it computed straight into every peer's buffer (hipMemcpyPeerAsync: one xGMI link per peer, no ring).
+// ordinary engine per device — each from a host thread of its own — through the PUBLIC ABI (gnnvc_attach_graph_slice /
+// gnnvc_stage_forward_device / gnnvc_pack_rows / gnnvc_push_piece / gnnvc_unpack_pieces): each holds the CSR slice of its rows
+// and full-size replicated feature buffers, and after the first and second stage every device pushes the rows it computed,
+// packed to their live columns and piece by piece, into every peer's receive buffer (one xGMI link per peer, no ring).
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -30,5 +31,7 @@ int multi_synchronize(MultiState *m);
 // rows / entries of part r, wall time of the last forward and of its exchanges as seen by the host
 int multi_part_info(const MultiState *m, int part, uint32_t *row_lo, uint32_t *row_hi, uint64_t *entries);
 double multi_last_forward_ms(const MultiState *m);
+// gnnvc_get_info keys "multi_*" (pieces, packing, bytes shipped per peer and exchange, a part's span of the last forward)
+bool multi_get_info(MultiState *m, const char *key, long *value);
 
 }  // namespace gnnvc

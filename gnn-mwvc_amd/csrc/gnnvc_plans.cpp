@@ -14,7 +14,6 @@ namespace gnnvc_eng {
 // column), laid out here on the host — heaviest row first, so the longest streams start first.
 int find_giant(gnnvc_engine *e) {
     uint32_t gt = e->opt_giant_thresh ? std::max(e->opt_giant_thresh, e->long_thresh) : 0xFFFFFFFFu;
-    if (e->opt_hub_mode == 1) gt = e->long_thresh;
     if (gt == 0xFFFFFFFFu || e->n_long == 0) return GNNVC_OK;
     HIP_TRY(e, e->gi_meta.reserve((size_t)e->n_long + 1));
     HIP_TRY(e, gnnvc::find_giant_rows(e->g, e->long_list.p, e->n_long, gt, e->gi_meta.p, e->long_count.p, e->stream));
@@ -556,10 +555,9 @@ int build_lds_table_impl(gnnvc_engine *e) {
 // entry mass (hub columns sit in narrow blocks), and an input may take up to three tables — the long and giant rows
 // stay with their own kernels beside the plan.
 // c4_begin: eligibility, geometry, buffers (on e->stream); leaves c4_pb.open set if there is a plan to build.
-int c4_begin(gnnvc_engine *e, uint32_t base, uint32_t end, bool allow_mapped) {
+int c4_begin(gnnvc_engine *e, uint32_t base, uint32_t end) {
     e->c4_ready = false;
     e->c4_tried = true;
-    e->c4_mapped = false;
     e->c4_prepared_stage = -1;
     for (bool &b : e->c4_seeded) b = false;
     gnnvc_engine::PlanBuild &pb = e->c4_pb;
@@ -577,10 +575,12 @@ int c4_begin(gnnvc_engine *e, uint32_t base, uint32_t end, bool allow_mapped) {
     if (g.n < std::min(e->opt_blocked_min_n, e->opt_compact_min_n) || g.nnz == 0 || g.nnz >= (1ull << 31)) return GNNVC_OK;
     // (... and the plan's fixed ~0.1 ms per forward needs entries to earn it back: ~25 ps per entry and stage)
     if (e->opt_blocked_min_n >= (1u << 20) && g.nnz < e->opt_compact_min_nnz) return GNNVC_OK;
+    // (degree-uniform graphs only.  Rounds 2 - 3 also carried the plan in a layout for SKEWED graphs — rows dealt to slices of
+    // equal weight, column blocks of equal entry mass, up to three tables per input, "compact_skewed" — which tied with the
+    // gathering kernels at three passes and lost 2 x to the pruned adjacency: removed in round 4.)
     const bool skewed = e->sorted_wanted || e->n_long > 0;
-    const bool mapped = skewed && e->opt_compact < 2 && e->opt_compact_skewed && allow_mapped && base == 0 && end == g.n && !g.sliced();
-    if (skewed && !mapped && e->opt_compact < 2) return GNNVC_OK;
-    if (!mapped && e->n_long > 0) return GNNVC_OK;   // (the long-row kernels write their rows themselves)
+    if (skewed && e->opt_compact < 2) return GNNVC_OK;
+    if (e->n_long > 0) return GNNVC_OK;   // (the long-row kernels write their rows themselves)
     // a chunk = 16 slices (one per wave of the workgroup that sums it); the plan is laid out per slice
     const uint32_t nsl = gnnvc::compact_slices();
     uint32_t max_rows = gnnvc::compact_max_rows();
@@ -593,22 +593,7 @@ int c4_begin(gnnvc_engine *e, uint32_t base, uint32_t end, bool allow_mapped) {
     // most 160 K vertices = 2.5 MiB of table, which still sits in an XCD's 4 MiB L2 while its 32 CUs sweep it
     const double fill = gnnvc::compact_step() * 5.0 / 6.0;
     uint32_t chunks = 0, rows = 0, slice_rows = 0, slices = 0, bc = gnnvc::compact_block(), nblocks = 0;
-    if (mapped) {
-        SkewedLayout L;
-        HIP_TRY(e, e->c4_stepcnt.reserve(1));
-        int rc = layout_skewed_plan(e, 0, max_rows, nsl, fill, 160u * 1024u, 1u, e->c4_rowmap, e->c4_first, e->c4_bstart, e->c4_stepcnt, L);
-        if (rc) return rc;
-        if (L.plan_rows == 0) return GNNVC_OK;
-        plan_rows = L.plan_rows;
-        range_nnz = L.entries;
-        chunks = L.chunks;
-        rows = L.rows;
-        slice_rows = L.slice_rows;
-        slices = L.slices;
-        nblocks = L.nblocks;
-        pb.pm = L.pm;
-        bc = 160u * 1024u;   // (the widest a block may be: what the entry encoding has to hold)
-    } else {
+    {
         chunks = (plan_rows + max_rows - 1) / max_rows;
         chunks = (chunks + 255u) / 256u * 256u;
         rows = (plan_rows + chunks - 1) / chunks;
@@ -632,9 +617,9 @@ int c4_begin(gnnvc_engine *e, uint32_t base, uint32_t end, bool allow_mapped) {
     if (nblocks > 4096) return GNNVC_OK;
     // every (slice, block) segment starts at a multiple of 4 entries: up to 3 pad entries per segment
     const uint32_t slack = 3u * nblocks + 4u;
-    const uint64_t entry_cap = (mapped ? range_nnz : g.nnz) + (uint64_t)slack * slices + 8;
+    const uint64_t entry_cap = g.nnz + (uint64_t)slack * slices + 8;
     if (entry_cap >= (1ull << 31)) return GNNVC_OK;
-    const uint32_t passes = mapped ? std::min(std::max(e->opt_compact_passes, 1u), gnnvc::compact_max_passes()) : 1u;
+    const uint32_t passes = 1u;
     constexpr int kFlagWord = 2 * gnnvc_engine::kDescWords;   // after the descriptors of the two consumer stages
     HIP_TRY(e, e->c4_desc.reserve(kFlagWord + 8));
     HIP_TRY(e, e->c4_counts.reserve(16));
@@ -651,10 +636,8 @@ int c4_begin(gnnvc_engine *e, uint32_t base, uint32_t end, bool allow_mapped) {
     HIP_TRY(e, e->c4_agg16.reserve((size_t)e->c4_dirty_cap * 16));
     HIP_TRY(e, hipMemsetAsync(e->c4_desc.p, 0, (kFlagWord + 8) * sizeof(uint32_t), e->stream));
     HIP_TRY(e, hipMemsetAsync(e->c4_entries.p, 0, entry_cap * sizeof(uint32_t), e->stream));   // (pad slots are read, never used)
-    if (mapped)   // rows the plan does not hold (no entries, or long): their sums stay +0 (never read for the long ones)
-        HIP_TRY(e, hipMemsetAsync(e->c4_acc.p, 0, (size_t)g.n * 4 * passes * sizeof(float), e->stream));
     pb.open = true;
-    pb.mapped = mapped;
+    pb.mapped = false;
     pb.base = base;
     pb.end = end;
     pb.slice_rows = slice_rows;
@@ -731,16 +714,12 @@ int c4_finish(gnnvc_engine *e) {
     e->c4_chunks = pb.chunks;
     e->c4_nslices = slices;
     e->c4_steps_total = (uint32_t)total;
-    e->c4_mapped = pb.mapped;
-    e->c4_max_passes = pb.passes;
-    e->c4_mapped_rows = pb.mapped ? pb.plan_rows : 0;
-    e->c4_mapped_entries = pb.mapped ? pb.plan_nnz : 0;
     e->c4_ready = true;
     return GNNVC_OK;
 }
 
-int build_compact_impl(gnnvc_engine *e, uint32_t base, uint32_t end, bool allow_mapped) {
-    int rc = c4_begin(e, base, end, allow_mapped);
+int build_compact_impl(gnnvc_engine *e, uint32_t base, uint32_t end) {
+    int rc = c4_begin(e, base, end);
     if (rc == GNNVC_OK) rc = c4_advance(e, 0xFFFFFFFFu, e->stream);
     if (rc == GNNVC_OK) rc = c4_finish(e);
     return rc;
@@ -755,18 +734,18 @@ gnnvc::CompactPlan compact_plan(const gnnvc_engine *e) {
     cp.plan_end = e->c4_end;
     cp.last_entry = e->c4_last_entry;
     cp.nslices = e->c4_nslices;
-    cp.max_passes = e->c4_max_passes;
+    cp.max_passes = 1;
     cp.step_ptr = e->c4_stepptr.p;
     cp.steps = e->c4_steps.p;
     cp.entries = e->c4_entries.p;
-    cp.rowmap = e->c4_mapped ? e->c4_rowmap.p : nullptr;
+    cp.rowmap = nullptr;
     return cp;
 }
 
 int build_blocked(gnnvc_engine *e) { return timed_build(e, [&] { return build_blocked_impl(e); }); }
 int build_lds_table(gnnvc_engine *e) { return timed_build(e, [&] { return build_lds_table_impl(e); }); }
-int build_compact(gnnvc_engine *e, uint32_t base, uint32_t end, bool allow_mapped) {
-    return timed_build(e, [&] { return build_compact_impl(e, base, end, allow_mapped); });
+int build_compact(gnnvc_engine *e, uint32_t base, uint32_t end) {
+    return timed_build(e, [&] { return build_compact_impl(e, base, end); });
 }
 
 // The engine's SIDE queue, made once per engine (gnnvc_create): what runs beside the main stream's kernels — the dense part of a
@@ -846,41 +825,33 @@ int reserve_prune(gnnvc_engine *e, int stage) {
 
 // Pruned adjacency for consumer stage `stage` (see k_prune_*): built once per graph from the input `in` of the call at hand.
 // Two host round trips: the size of the set and what it promises (before any pass over the entries), and what came of it.
-int build_prune_impl(gnnvc_engine *e, int stage, const float *in, bool early) {
+int build_prune_impl(gnnvc_engine *e, int stage, const float *in, bool early, bool predicted = false) {
     gnnvc_engine::PrunePlan &pp = e->prune[stage];
     pp.tried = true;
     pp.ready = false;
+    pp.predicted = pp.verified = false;
     const GraphDev &g = e->g;
     if (!e->opt_prune || g.n == 0 || e->empty_slice || g.nnz < e->opt_prune_min_nnz) return GNNVC_OK;
-    if (g.sliced() && e->opt_prune == 2) return GNNVC_OK;   // (a slice does not know the degrees of the vertices it does not hold)
+    if (predicted && (g.sliced() || stage != 1 || e->stages.size() < 2)) return GNNVC_OK;
     if (g.nnz >= (1ull << 32)) return GNNVC_OK;
     int rc = reserve_prune(e, stage);
     if (rc) return rc;
-    uint32_t *pin = e->pin_info.p;   // [0..3] = {mass lo, mass hi, members lo, members hi}, [4] = kept, [5] = observed, [6..7] = listed rows, rows without entries
-    uint32_t seen = 0;
-    if (e->opt_prune == 2) {
-        HIP_TRY(e, gnnvc::prune_observe(g, in, e->prune_flags.p + 3, e->stream));
-        HIP_TRY(e, hipMemcpyAsync(pin + 5, e->prune_flags.p + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
-        seen = pin[5];
-    }
-    pp.observed = seen;
-    if (e->opt_prune == 2) {
-        // a degree bound some way above the largest degree that still had a non-zero row: inputs that differ a little from
-        // this one still pass the per-call check
-        pp.bound = seen + seen / 8 + 2;
-        HIP_TRY(e, gnnvc::prune_mark_degree(g, pp.bound, pp.heavy.p, e->stream));
+    uint32_t *pin = e->pin_info.p;   // [0..3] = {mass lo, mass hi, members lo, members hi}, [4] = kept, [6..7] = listed rows, rows without entries
+    if (predicted) {
+        // the set the GRAPH predicts (hand-off: there is no input yet), see k_predict_zero_f1
+        HIP_TRY(e, gnnvc::predict_zero_rows(e->stages[0], g, e->ws, e->params.p, pp.heavy.p, e->stream));
     } else {
         // the very vertices whose rows are all zero in this input (a graph's stage inputs follow from its weights: the same on
-        // every forward; any other input fails the check and is served by the full adjacency)
-        pp.bound = 0;
+        // every forward; any other input fails the check and is served by the full adjacency).  (Rounds 2 - 3 also offered a
+        // degree bound as the set, "prune_zero_rows" 2: it drops fewer entries — R-MAT-22's last stage kept 25 % instead of 14 % —
+        // and was slower on every graph measured; removed in round 4.)
         HIP_TRY(e, gnnvc::prune_mark_zero(g, in, pp.heavy.p, e->stream));
     }
     // a cheap look before the passes over the entries: how many vertices the set has, and (whole graphs) their degrees ~ the
     // entries that would go
     unsigned long long *mass_dev = reinterpret_cast<unsigned long long *>(e->prune_mask.p);
     // (the stage before this one, if it has a plan built from THIS graph's set of zero rows: does this stage's set contain it?)
-    const gnnvc_engine::PrunePlan *prev = (stage >= 2 && e->opt_prune == 1 && e->prune[stage - 1].ready && !g.sliced()) ? &e->prune[stage - 1] : nullptr;
+    const gnnvc_engine::PrunePlan *prev = (stage >= 2 && !predicted && e->prune[stage - 1].ready && !g.sliced()) ? &e->prune[stage - 1] : nullptr;
     HIP_TRY(e, gnnvc::prune_mass(g, pp.heavy.p, mass_dev, e->stream, prev ? prev->heavy.p : nullptr));
     HIP_TRY(e, hipMemcpyAsync(pin, mass_dev, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipMemcpyAsync(pin + 10, mass_dev + 2, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
@@ -940,6 +911,7 @@ int build_prune_impl(gnnvc_engine *e, int stage, const float *in, bool early) {
         pp.slist = true;
     }
     pp.ready = true;
+    pp.predicted = predicted;
     return GNNVC_OK;
 }
 
@@ -968,14 +940,32 @@ int gather_view(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const floa
                         e->n_long > 0 && e->long_entries * 100ull >= e->g.nnz * (uint64_t)e->opt_filter_min_long_pct;
     const bool early = !filter && skewed && e->opt_prune_early_nnz && e->g.nnz >= e->opt_prune_early_nnz;
     const uint32_t uses_needed = (early && !pp.deferred) ? 1u : 2u;
-    e->filtered[stage] = e->short_used[stage] = false;
+    e->filtered[stage] = e->short_used[stage] = e->borrowed[stage] = false;
     if (e->short_from >= stage) e->short_from = 0;   // (the stage that left the lists runs again: they are this call's to leave, or nobody's)
+    if (pp.predicted && !pp.verified && e->graph_uses >= 2) {
+        // A plan built at hand-off from the PREDICTED set has served a forward: did its check pass there?  If the caller's input
+        // is not what the prediction assumed, the set is wrong for this graph's stage inputs (which are the same on every
+        // forward) and every call would fall back to the full adjacency: the plan goes, and is rebuilt below from the input the
+        // stage really sees.  One host round trip per graph, in a forward that builds the next stage's plan anyway.
+        uint32_t *pin = e->pin_info.p;
+        HIP_TRY(e, hipMemcpyAsync(pin + 12, e->prune_flags.p + stage, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        if (pin[12] != 0u) pp.forget();
+        else pp.verified = true;
+    }
     if (!pp.tried && e->graph_uses >= uses_needed) {
         const bool first_forward = e->graph_uses < 2;
         int rc = timed_build(e, [&] { return build_prune_impl(e, stage, in, first_forward); });
         if (rc) return rc;
     }
-    if (!pp.ready) {
+    // A graph's FIRST forward, the stage behind one that runs on a predicted plan: it borrows that plan — the model keeps the hubs'
+    // rows at zero from stage to stage (R-MAT-22: the earlier set is contained in this stage's), its own check against THIS input
+    // decides — until the graph comes back and it gets its own (built from the borrowed plan's kept entries: from_prev).
+    const gnnvc_engine::PrunePlan *use = &pp;
+    if (!pp.ready && !pp.tried && stage >= 2 && e->prune[stage - 1].ready && e->prune[stage - 1].predicted &&
+        e->stages[stage - 1].f == 16)
+        use = &e->prune[stage - 1];
+    if (!use->ready) {
         // no plan (yet, or the graph has too few zero rows for one): the bitmap of this input's zero rows for the kernels to
         // look into — in a graph's first forward, and later only while a plan may still come (tried && !ready: it was found
         // not worth it, and neither is a look-up per entry)
@@ -1016,23 +1006,24 @@ int gather_view(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const floa
         }
         return GNNVC_OK;
     }
-    HIP_TRY(e, gnnvc::prune_check(e->g, in, pp.heavy.p, e->prune_flags.p + stage, e->stream));
-    gv.prp = pp.prp.p - e->g.lo();   // (indexed by global row id, like rowptr)
-    gv.pcol = pp.pcol.p;
+    HIP_TRY(e, gnnvc::prune_check(e->g, in, use->heavy.p, e->prune_flags.p + stage, e->stream));
+    gv.prp = use->prp.p - e->g.lo();   // (indexed by global row id, like rowptr)
+    gv.pcol = use->pcol.p;
     gv.prune_bad = e->prune_flags.p + stage;
     if (e->opt_prune_eff) {
         const bool whole = lo == e->g.lo() && hi == e->g.hi();
         if (!sorted_tiles) {
             gv.prune_eff = 1;
-        } else if (whole && pp.slist) {
+        } else if (whole && use->slist) {
             gv.prune_eff = 1;
-            so_p.n = pp.sn;
-            so_p.vertex = pp.svertex.p;
-            so_p.meta = pp.smeta.p;
+            so_p.n = use->sn;
+            so_p.vertex = use->svertex.p;
+            so_p.meta = use->smeta.p;
         }
         gv.eff_giant = e->giant_f16();
-        gv.eff_thresh = pp.eff_thresh;
+        gv.eff_thresh = use->eff_thresh;
     }
+    e->borrowed[stage] = use != &pp;
     return GNNVC_OK;
 }
 
@@ -1107,12 +1098,23 @@ int prepare_plans(gnnvc_engine *e) {
         if (rc) return rc;
     }
     // pruned adjacency: it needs a stage's INPUT and is built inside a forward — with every buffer it wants already here
-    if (skewed && e->opt_prune && g.nnz >= e->opt_prune_min_nnz && g.nnz < (1ull << 32) && !(g.sliced() && e->opt_prune == 2)) {
+    if (skewed && e->opt_prune && g.nnz >= e->opt_prune_min_nnz && g.nnz < (1ull << 32) && true) {
         for (int st = 1; st < (int)e->stages.size() && st < 4; ++st)
             if (e->stages[st].f == 16) {
                 rc = reserve_prune(e, st);
                 if (rc) return rc;
             }
+        // ... except the first 16-wide stage's on the graphs whose first forward would otherwise look every target up (the
+        // filtered gather's graphs: large, their long rows hold a good share of the entries): the reference's driver feeds
+        // x = W / ws (src/GNN_VC.cpp:189-191), so that stage's zero rows follow from the graph's own weights, and the plan for the
+        // PREDICTED set is built here — proven per call like any other.  R-MAT-22: +0.9 ms of hand-off, first forward 3.5 -> 2.8 ms.
+        if (e->opt_prune_predict && !g.sliced() && g.nnz >= e->opt_predict_min_nnz && e->n_long > 0 &&
+            e->long_entries * 100ull >= g.nnz * (uint64_t)e->opt_filter_min_long_pct && e->stages.size() >= 2 &&
+            e->stages[0].variant == 0 && e->stages[1].f == 16 && !e->prune[1].tried) {
+            rc = timed_build(e, [&] { return build_prune_impl(e, 1, nullptr, /*early=*/true, /*predicted=*/true); });
+            if (rc) return rc;
+            if (!e->prune[1].ready) e->prune[1].forget();   // (not worth it by the prediction: the first forward filters, a second one observes)
+        }
     }
     if (!g.sliced()) {
         rc = ensure_events(e, e->stages.size() + 1);
@@ -1125,9 +1127,11 @@ int prepare_plans(gnnvc_engine *e) {
 // per-graph state of the plans: nothing of the previous graph's survives
 void reset_graph_state(gnnvc_engine *e) {
     e->lt_ready = e->lt_tried = false;
+    e->lt_used = e->lt_off = false;
+    e->lt_unfit_runs = 0;
     e->c4_ready = e->c4_tried = false;
     e->lt_pb.open = e->c4_pb.open = false;
-    for (auto &pp : e->prune) pp.tried = pp.ready = pp.deferred = false;
+    for (auto &pp : e->prune) pp.forget();
     e->short_from = 0;
     for (int s = 0; s < 4; ++s) { e->c4_stage_off[s] = false; e->c4_unfit_runs[s] = 0; e->fit_used[s] = false; }
     e->fit_pending = false;
@@ -1173,7 +1177,7 @@ int handoff_early(gnnvc_engine *e, uint32_t n, uint64_t nnz) {
     if (!skewed) {
         rc = lt_begin(e);
         if (rc) return rc;
-        rc = c4_begin(e, 0, 0xFFFFFFFFu, true);
+        rc = c4_begin(e, 0, 0xFFFFFFFFu);
         if (rc) return rc;
         // (only the flat builders work piece by piece; anything else waits for the commit)
         if (e->lt_pb.open && !gnnvc::lds_table_is_flat(e->lt_pb.slice_rows, e->lt_pb.pm)) e->lt_pb.open = false, e->lt_tried = false;

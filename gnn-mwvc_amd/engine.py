@@ -26,6 +26,7 @@ ABI_SYMBOLS = [
     "gnnvc_derive_graph_begin", "gnnvc_derive_graph_commit", "gnnvc_graph_row_hashes",
     "gnnvc_forward", "gnnvc_forward_device", "gnnvc_num_stages", "gnnvc_stage_widths",
     "gnnvc_stage_forward_device", "gnnvc_stage_input_ready", "gnnvc_live_columns", "gnnvc_column_counts", "gnnvc_pack_rows", "gnnvc_unpack_rows", "gnnvc_unpack_gathered",
+    "gnnvc_push_piece", "gnnvc_unpack_pieces", "gnnvc_get_stream",
     "gnnvc_reduction_flags", "gnnvc_score_keys", "gnnvc_synchronize", "gnnvc_last_forward_ms",
     "gnnvc_graph_layer_forward", "gnnvc_linear_forward", "gnnvc_relu_forward",
     "gnnvc_sigmoid_forward", "gnnvc_sgemm", "gnnvc_stream_sum", "gnnvc_kernel_trace",

@@ -66,10 +66,19 @@ void gnnvc_destroy(gnnvc_engine *e);
  *   gnnvc_upload_graph / the staged hand-off   cut the graph into n_devices contiguous row ranges of equal entry count (multiples
  *                         of 64 rows) and give device r the CSR slice of its rows (global column ids) — 1 / n_devices of the
  *                         graph's memory each — next to full-size replicated feature buffers;
- *   gnnvc_forward / gnnvc_forward_device        run every stage range by range and, after the first and second stage, let each
- *                         device copy the rows it computed straight into every peer's buffer (hipMemcpyPeerAsync: a direct
- *                         all-gather, one xGMI link per peer, no ring, no host hop); the scores (and logits) are assembled on
- *                         devices[0].  gnnvc_forward_device takes pointers on devices[0] and is complete when it returns;
+ *   gnnvc_forward / gnnvc_forward_device        run every stage range by range — every device driven by a host thread of its own —
+ *                         and, after the first and second stage, let each device send the rows it computed to every peer: in
+ *                         pieces, packed to their live columns (gnnvc_pack_rows: 16 bytes a row on the metric graph; the
+ *                         packing is chosen by the graph's first forward and checked lossless on every one), each piece stored
+ *                         into the peers' receive buffers by one kernel (gnnvc_push_piece: a direct all-gather, one xGMI link
+ *                         per peer, no ring, no host hop) under the next piece's kernels, and expanded there
+ *                         (gnnvc_unpack_pieces); the scores (and logits) are assembled on devices[0].  gnnvc_forward_device
+ *                         takes pointers on devices[0] and is complete when it returns — on an error too: every device is
+ *                         drained first.  Options "multi_pieces" (pieces per part and stage; default 1 up to 4 devices, where
+ *                         the per-range plans want whole ranges, 4 beyond), "multi_pack" 0 = full rows, "multi_push" 0 =
+ *                         hipMemcpyPeerAsync per peer and piece, "multi_only_part" r = a forward runs part r's share only (a
+ *                         timing rehearsal where parts share a device; its results are not complete).  gnnvc_get_info:
+ *                         "multi_exchange_bytes_per_peer_stage0|1", "multi_packed_columns_stage0|1", "multi_part_span_us_<r>";
  *   gnnvc_set_weight_scale / gnnvc_set_option / gnnvc_synchronize / gnnvc_score_keys / gnnvc_last_forward_ms (total only)
  *                         and the layer-level entry points without a graph (linear, relu, sigmoid, sgemm, stream_sum) work
  *                         as on any handle; gnnvc_get_info adds "devices", "part_rows_<r>", "part_entries_<r>";
@@ -87,6 +96,9 @@ int gnnvc_set_weight_scale(gnnvc_engine *e, float ws);
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of
  * the engine's own stream.  NULL restores the engine's stream. */
 int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
+/* The stream the engine launches on at the moment (its own unless gnnvc_set_stream installed another): a caller orders its own
+ * work behind the engine's asynchronous calls with it. */
+int gnnvc_get_stream(gnnvc_engine *e, void **hip_stream);
 
 /* Tuning options (take effect at the next graph upload / attach):
  *   "plans_at_handoff" 0|1|2  WHEN the per-graph plans below are built.  The reference's driver hands predict a new graph every
@@ -162,10 +174,6 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *   "side_streams"   0|1  1 (default) = long / giant rows on side streams beside the tile kernel; 0 = on the main
  *                         stream, one after the other (profiling: standalone kernel times)
  *   "kernel_trace"   0|1  HIP events around every main-stream kernel of a forward (gnnvc_kernel_trace)
- *   "hub_mode"       0|1  0 (default) = exact; 1 = FAST, the tolerance mode of SURVEY.md §7: every long row goes the
- *                         giant-row way and its streams are added as lane-strided partial sums + a wave tree.
- *                         Scores then differ from the reference's in the last bits (and with them, possibly, the
- *                         cover the greedy builds); never the default, never what the parity tests run
  *   "mfma_dense"     0|1|2  dense layers on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, a
  *                         k-ordered fma chain: same bits as the VALU path): 0 = VALU, 1 = MFMA in
  *                         every stage, 2 = MFMA in the 16-wide stages only (default); immediate
@@ -174,12 +182,19 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *                         would spend more than twice the useful gather rounds, the default)
  *   "sorted_min_nnz" n     in auto mode, graphs with fewer adjacency entries keep natural tiles
  *                         (default 4 Mi: the sort costs more than it saves on a graph used once)
- *   "prune_zero_rows" 0|1|2  pruned adjacency of the 16-wide stages: adjacency entries whose target row is all zero in
+ *   "prune_zero_rows" 0|1  pruned adjacency of the 16-wide stages: adjacency entries whose target row is all zero in
  *                         the stage's input are left out of a second CSR (adding a row of zeros changes no bit of a
  *                         sum); EVERY call proves on the device that its input fits, else it uses the full adjacency.
  *                         1 (default) = the set of vertices is the rows found all zero when the plan is built (a
- *                         graph's stage inputs follow from its weights), 2 = every vertex above a degree bound taken
- *                         from that input plus a margin, 0 = off.  Bit-identical results
+ *                         graph's stage inputs follow from its weights), 0 = off.  Bit-identical results
+ *   "prune_predict"  0|1  (round 4) a large skewed graph — at least "prune_predict_min_entries" adjacency entries, default
+ *                         48 Mi, "filter_min_long_percent" of them in long rows — gets the first 16-wide stage's pruned
+ *                         adjacency when it is HANDED OVER, from the set of zero rows its own weights predict (the reference's
+ *                         driver feeds x = W / ws, src/GNN_VC.cpp:189-191), proven per call like any other set; a graph scored
+ *                         once runs its first forward on it and the next stage borrows it.  Default 1.  gnnvc_get_info:
+ *                         "pruned_predicted_stage1", "pruned_borrowed_stage2"
+ *   "dense_skip_zeros" 0|1  (round 4; A/B) the aggregate-only dense kernels of the compact-table plan leave out the first-layer
+ *                         terms they know to be zero (default 1; bit-identical)
  *   "prune_min_entries" n  graphs with fewer adjacency entries do not prune (default 2^20);
  *   "prune_min_drop_percent" p  nor do graphs where less than p % of the entries would go (default 15);
  *   "prune_early_entries" n  skewed graphs with at least n entries build the plan in their first forward (default
@@ -188,16 +203,12 @@ int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
  *                         classed by the entries they have left (default 1), the entry count from which the tile
  *                         kernel keeps rows of up to "sorted_long_row_threshold" entries (default 2^24; below: 512),
  *                         giant rows pruned too (default 1)
- *   "compact_skewed" 0|1, "compact_passes" 1..3  the compact-table plan on SKEWED graphs (rows dealt to slices of equal
- *                         weight, column blocks of equal entry mass, up to three tables of four columns per input;
- *                         long and giant rows beside it).  Default 0: measured no faster than the gathering kernels
- *                         (DESIGN.md §5); bit-identical
  * gnnvc_get_info keys (further): "pruned_stage1|2", "pruned_entries_stage1|2", "pruned_vertices_stage1|2",
- * "pruned_bound_stage1|2", "pruned_last_ok_stage1|2" (did the last call of that stage use its pruned adjacency),
- * "compact_gather_mapped", "compact_gather_last_ok", "compact_gather_last_passes", "compact_gather_last_dirty",
+ * "pruned_last_ok_stage1|2" (did the last call of that stage use its pruned adjacency),
+ * "compact_gather_last_ok", "compact_gather_last_passes", "compact_gather_last_dirty",
  * "compact_gather_blocks", "compact_gather_steps", "plan_build_us".
  * gnnvc_get_info keys: "compact_gather_active", "compact_gather_chunks", "lds_table_active", "lds_table_chunks", "lds_table_steps", "mfma_dense", "sorted_tiles_active", "tile_waste_x100", "blocked_stage0_active", "blocked_blocks", "block_cols", "long_rows",
- * "long_row_threshold", "giant_rows", "giant_entries", "giant_row_threshold", "hub_mode". */
+ * "long_row_threshold", "giant_rows", "giant_entries", "giant_row_threshold". */
 int gnnvc_set_option(gnnvc_engine *e, const char *key, long value);
 int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value);
 
@@ -345,6 +356,24 @@ int gnnvc_unpack_gathered(gnnvc_engine *e, const float *d_buf, uint32_t world, u
                           uint32_t dense_rows, uint32_t exc_cap, uint32_t width, uint32_t rows_per_rank, uint32_t row_off,
                           uint32_t rows, uint32_t n, uint32_t mask, uint32_t kp, float *d_feat);
 
+/* One packed piece to several destinations, and several packed pieces expanded, in ONE launch each (round 4; what
+ * gnnvc_create_multi's devices exchange).  A piece REGION = rows x kp dense floats (gnnvc_pack_rows' d_dense) directly followed
+ * by its exception list (4 + 4 * exc_cap words).
+ *   gnnvc_push_piece     stores the dense part and the USED part of the list into each of d_dst[0 .. n_dst) (n_dst <= 64): device
+ *                        pointers this engine's device can store to — its own memory, or a peer's once peer access is enabled
+ *                        (hipDeviceEnablePeerAccess: the stores then cross the xGMI link to that peer) — on hip_stream (NULL =
+ *                        the engine's stream; the region must be complete in that stream's order);
+ *   gnnvc_unpack_pieces  expands pieces[0 .. n_pieces) (n_pieces <= 64) — region i holding rows [row_lo, row_hi) — into the
+ *                        16-column rows of d_feat exactly as gnnvc_unpack_rows would, on the engine's stream. */
+typedef struct gnnvc_piece {
+    const float *d_region;
+    uint32_t row_lo, row_hi;
+} gnnvc_piece;
+int gnnvc_push_piece(gnnvc_engine *e, const float *d_region, uint32_t rows, uint32_t kp, uint32_t exc_cap, uint32_t n_dst,
+                     float *const *d_dst, void *hip_stream);
+int gnnvc_unpack_pieces(gnnvc_engine *e, const gnnvc_piece *pieces, uint32_t n_pieces, uint32_t exc_cap, uint32_t width, uint32_t mask,
+                        uint32_t kp, float *d_feat);
+
 /* A multi-GPU rank that computes rows [row_lo, row_hi) of `stage` (1 or 2) in several gnnvc_stage_forward_device
  * calls announces the stage's complete input once: "d_in is final and will not change until those calls are done".
  * The engine then builds the compact-table plan over that row range — once per graph and range —
@@ -407,12 +436,12 @@ int gnnvc_sigmoid_forward(gnnvc_engine *e, size_t count, const float *in, float 
 
 /* The neighbour sum of graph_layer::forward (reference src/gnn_inference.cpp:33-36) on explicit data:
  * sums[i] = (((0 + v[i][0]) + v[i][1]) + ...) + v[i][len-1], one rounded fp32 add per element, for `streams`
- * rows of `len` floats (host pointers, row-major).  mode 0 evaluates that chain with the engine's parallel
- * giant-row kernels and returns its exact bits whatever the data holds; mode 1 is the tolerance mode (tree
- * sums: a few ulp off).  The layer-level handle on the path rows of degree >= "giant_row_threshold" take.
- * mode 0 runs a stream on several waves (segments of 4096 addends, each with its own parity map relative to an estimated
- * binade, used by the final walk only where the exact accumulator confirms it); mode 2 is the same result with one wave
- * walking the whole stream ("giant_segments" 0 for the engine's own rows). */
+ * rows of `len` floats (host pointers, row-major).  Both modes evaluate that chain with the engine's parallel
+ * giant-row kernels and return its exact bits whatever the data holds — the layer-level handle on the path rows of degree
+ * >= "giant_row_threshold" take.  mode 0 runs a stream on several waves (segments of 4096 addends, each with its own parity
+ * map relative to an estimated binade, used by the final walk only where the exact accumulator confirms it); mode 2 is the
+ * same result with one wave walking the whole stream ("giant_segments" 0 for the engine's own rows).  (Rounds 1 - 3 had a
+ * tolerance mode 1 — tree sums; it is gone: GNNVC_ERR_INVALID.) */
 int gnnvc_stream_sum(gnnvc_engine *e, const float *values, uint32_t streams, uint32_t len, int mode, float *sums);
 
 /* dot() (reference src/matrix.cpp:106-122, the cblas_sgemm seam):

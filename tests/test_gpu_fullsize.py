@@ -118,24 +118,32 @@ def test_every_logit_matches_the_oracle(big, oracle_model):
     assert bad.size == 0, (big["name"], int(bad.size), bad[:8].tolist())
 
 
-def test_first_forward_of_a_fresh_graph_runs_with_the_plans(big):
+@pytest.mark.parametrize("predict", [1, 0])
+def test_first_forward_of_a_fresh_graph_runs_with_the_plans(big, predict):
     """Score-once callers (the reference's driver): a new engine, the graph handed over, ONE forward.  The plans that depend
-    on the graph alone were built at hand-off, a large skewed graph's stages skip the zero rows without a plan — and the
-    bits are those of every other path."""
+    on the graph alone were built at hand-off — on a large skewed graph (round 4) the first 16-wide stage's pruned adjacency too,
+    from the set of zero rows the graph's own weights PREDICT, proven on the device by the call; the next stage borrows it — and
+    the bits are those of every other path.  With "prune_predict" 0 such a graph's stages look the zero rows up instead (round 3)."""
     import torch
     import gnn_mwvc_amd as G
     g, dev = big["g"], big["dev"]
+    skewed = big["name"] in ("rmat22", "rmat24")
+    if not predict and not skewed:
+        pytest.skip("prune_predict only concerns the large skewed graphs")
     sc = torch.zeros(g.n, device=dev)
     lg = torch.zeros(g.n, device=dev)
     torch.cuda.synchronize()
     e2 = G.Engine(G.default_model_text(), device=0)
     try:
+        e2.set_option("prune_predict", predict)
         e2.set_weight_scale(g.ws)
         e2.attach_graph_device(g.n, g.nnz, g.rowptr.data_ptr(), g.col.data_ptr(), g.w.data_ptr(), g.nw.data_ptr(), keepalive=g)
         assert e2.get_info("graph_uses") == 0
         if big["name"] == "er10m":      # built at hand-off, before any forward
             assert e2.get_info("lds_table_active") == 1 and e2.get_info("compact_gather_active") == 1
             assert e2.get_info("handoff_build_us") > 0
+        if skewed:
+            assert e2.get_info("pruned_predicted_stage1") == predict and e2.get_info("pruned_stage1") == predict
         e2.forward_device(big["x"].data_ptr(), sc.data_ptr(), lg.data_ptr())
         e2.synchronize()
         assert e2.get_info("graph_uses") == 1
@@ -145,8 +153,25 @@ def test_first_forward_of_a_fresh_graph_runs_with_the_plans(big):
             # its producer (no compaction pass), a few rows met stray non-zeros and were fixed
             assert e2.get_info("compact_gather_last_ok") == 1 and e2.get_info("compact_gather_last_dirty") > 0
             assert e2.get_info("compact_table_written_by_producer") == 1
-        elif big["name"] in ("rmat22", "rmat24"):
-            # nothing is built inside a once-scored skewed graph's forward: its 16-wide stages skip the zero rows by looking
+        elif skewed and predict:
+            # the predicted set held for this input in both stages (the device's verdicts), nothing was looked up
+            assert e2.get_info("sorted_tiles_active") == 1
+            assert e2.get_info("pruned_last_ok_stage1") == 1
+            assert e2.get_info("pruned_borrowed_stage2") == 1 and e2.get_info("pruned_last_ok_stage2") == 1
+            assert e2.get_info("filtered_stage1") == 0 and e2.get_info("filtered_stage2") == 0
+            kept1 = e2.get_info("pruned_entries_stage1")
+            assert 0 < kept1 < g.nnz // 2
+            # ... and if the graph does come back, the last stage gets a plan of its own, from the borrowed plan's kept entries
+            e2.forward_device(big["x"].data_ptr(), sc.data_ptr(), lg.data_ptr())
+            e2.synchronize()
+            assert torch.equal(lg.view(torch.int32), big["lg"].view(torch.int32))
+            assert e2.get_info("pruned_predicted_stage1") == 1          # (verified, kept)
+            assert e2.get_info("pruned_stage2") == 1 and e2.get_info("pruned_from_previous_stage2") == 1
+            assert e2.get_info("pruned_borrowed_stage2") == 0 and e2.get_info("pruned_entries_stage2") < kept1
+            for st in (1, 2):
+                assert e2.get_info(f"pruned_last_ok_stage{st}") == 1
+        elif skewed:
+            # nothing is built for a once-scored skewed graph: its 16-wide stages skip the zero rows by looking
             # them up (filtered gather), the long rows walk lists a pass in front of them shortened, the last stage's from the
             # lists the stage before left
             assert e2.get_info("sorted_tiles_active") == 1
@@ -235,9 +260,7 @@ def test_deterministic_and_plan_invariant(big):
         plans.append({"mfma_dense": 1, "long_row_threshold": 40})
     else:   # skewed graphs: other long-row thresholds, forced sorted tiles with a low threshold
         plans += [{"long_row_threshold": 2048, "mfma_dense": 1}, {"sorted_tiles": 1, "sorted_long_row_threshold": 600},
-                  {"prune_zero_rows": 0}, {"prune_zero_rows": 2}, {"prune_class_by_entries_left": 0, "prune_giant_rows": 0}]
-        if big["name"] == "rmat22":
-            plans.append({"compact_skewed": 1})
+                  {"prune_zero_rows": 0}, {"prune_predict": 0}, {"prune_class_by_entries_left": 0, "prune_giant_rows": 0}]
     for opts in plans:
         e2 = G.Engine(G.default_model_text(), device=0)
         try:

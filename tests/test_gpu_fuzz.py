@@ -45,15 +45,13 @@ def _options(rng):
         o["giant_row_threshold_f16"] = int(rng.choice([64, 1000, 5000, 65536]))
     o["giant_segments"] = int(rng.choice([-1, 0, 1]))
     o["sorted_tiles"] = int(rng.choice([-1, 0, 1]))
-    o["prune_zero_rows"] = int(rng.choice([0, 1, 1, 2]))
+    o["prune_zero_rows"] = int(rng.choice([0, 1, 1]))
     o["prune_class_by_entries_left"] = int(rng.choice([0, 1, 1]))
     o["prune_giant_rows"] = int(rng.choice([0, 1, 1]))
     o["prune_heavy_entries"] = int(rng.choice([1, 1 << 24]))
     o["lds_table"] = int(rng.choice([0, 1, 1]))
     o["lds_table_skewed_rows"] = int(rng.choice([0, 64, 512, 2048, 16384]))
     o["compact_gather"] = int(rng.choice([0, 1, 1]))
-    o["compact_skewed"] = int(rng.choice([0, 0, 1]))
-    o["compact_passes"] = int(rng.choice([1, 2, 3]))
     o["mfma_dense"] = int(rng.choice([0, 1, 2]))
     o["overlap_dense"] = int(rng.choice([0, 1]))
     if rng.random() < 0.3:
@@ -110,8 +108,7 @@ def test_random_stage_inputs(model_text, oracle_model, block):
         deg = np.diff(g.rowptr.astype(np.int64))
         opts = {"blocked_min_n": 0, "prune_min_entries": 0, "prune_min_drop_percent": int(rng.integers(0, 20)),
                 "long_row_threshold": int(rng.choice([64, 128, 256, 512])), "giant_row_threshold": int(rng.choice([300, 1000, 4096, 16384])),
-                "sorted_tiles": int(rng.choice([-1, 0, 1])), "prune_zero_rows": int(rng.choice([1, 1, 2])),
-                "compact_skewed": int(rng.choice([0, 1])), "compact_passes": int(rng.choice([1, 2, 3])),
+                "sorted_tiles": int(rng.choice([-1, 0, 1])), "prune_zero_rows": 1,
                 "giant_segments": int(rng.choice([0, 1]))}
         e = G.Engine(model_text, device=0)
         try:

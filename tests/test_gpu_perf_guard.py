@@ -5,8 +5,9 @@ notice a rule change that makes the DEFAULTS slower than the plain kernels on so
 hubs; 0.3 - 4 M vertices), for each the steady state with default options against the same graph with every plan off —
   * logits and scores bit-identical, forward after forward (the first one included);
   * engine defaults <= 1.10 x "all plans off" (+ 25 us of timer slack on forwards of a fraction of a millisecond);
-  * a fresh graph's first forward with the defaults <= 1.35 x the plain first forward (plans built at hand-off are outside it,
-    the pruned adjacency of a large skewed graph is built inside it and has to pay there).
+  * a fresh graph's first forward with the defaults <= 1.15 x the plain first forward (round 4; it was 1.35: plans built at
+    hand-off are outside it — a large skewed graph's predicted pruned adjacency among them — and what a first forward still
+    does inside itself, the filter's marks and look-ups on mid-size skewed graphs, has to pay there).
 """
 import time
 
@@ -84,6 +85,6 @@ def test_defaults_are_not_slower_than_the_plain_kernels(case):
         assert torch.equal(lg.view(torch.int32), ref[0][1].view(torch.int32)), (case, kind, i)
         assert torch.equal(sc.view(torch.int32), ref[0][0].view(torch.int32)), (case, kind, i)
     assert ms <= 1.10 * ms_plain + 0.025, f"case {case} ({kind}, n {g.n}, nnz {g.nnz}): defaults {ms:.3f} ms vs plans off {ms_plain:.3f} ms"
-    assert first <= 1.35 * first_plain + 0.05, f"case {case} ({kind}, n {g.n}, nnz {g.nnz}): first forward {first:.3f} ms vs plain {first_plain:.3f} ms"
+    assert first <= 1.15 * first_plain + 0.05, f"case {case} ({kind}, n {g.n}, nnz {g.nnz}): first forward {first:.3f} ms vs plain {first_plain:.3f} ms"
     del g, x, ref, got
     torch.cuda.empty_cache()
