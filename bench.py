@@ -164,6 +164,9 @@ def main() -> int:
     ap.add_argument("--partition", default="auto", choices=["auto", "rows", "nnz"])
     ap.add_argument("--compress-exchange", type=int, default=1,
                     help="N>1: 1 = ship only the live feature columns between stages (lossless, verified), 0 = full rows")
+    ap.add_argument("--halo", type=int, default=-1,
+                    help="N>1: 1 = ship only the rows the receiving rank's slice references (halo exchange), 0 = every row to every "
+                         "rank, -1 (default) = halo when the busiest rank would receive at most half of the all-gather's rows")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1 (gloo only to rehearse several ranks on ONE GPU)")
     ap.add_argument("--host-path", action="store_true",
@@ -272,6 +275,7 @@ def main() -> int:
     lo, hi = bounds[rank]
 
     eng = make_engine()
+    halo_plan = None
     ref_scores = None
     csr_bytes_rank = csr_bytes_full
     t0 = time.time()
@@ -293,6 +297,9 @@ def main() -> int:
         t0 = time.time()
         eng.attach_graph_slice(n, lo, hi, sl.nnz, sl.rowptr.data_ptr(), sl.col.data_ptr(), sl.w.data_ptr(), sl.nw.data_ptr(),
                                keepalive=sl)
+        if args.halo != 0:
+            # which rows of the other shards this rank's slice references at all (once per graph; setup)
+            halo_plan = D.build_halo_plan(sl.col.to(torch.int64), sl.nnz, bounds, rank, n, max_fraction=0.5 if args.halo < 0 else 2.0)
     else:
         attach_whole(eng)
     eng.synchronize()
@@ -356,7 +363,7 @@ def main() -> int:
         # verify=False: the dead-column check of the compressed exchange is read once, after the loop
         D.partitioned_forward(stage_fn, 3, x, bufs, bounds, rank, on_stage=hook, gather_logits=False,
                               replicate=set(), pipeline_chunks=chunks, codec=codec, verify=False, prepare_fn=prepare_fn,
-                              piece_rows=piece_rows[0])
+                              piece_rows=piece_rows[0], halo=halo_plan)
 
     trace = bool(os.environ.get("GNNVC_BENCH_TRACE"))
     t_start = time.time()
@@ -538,6 +545,9 @@ def main() -> int:
         out["config"]["pipeline_chunks"] = chunks
         out["config"]["piece_rows"] = piece_rows[0]
         out["config"]["compact_table_over_rank_rows"] = bool(use_prepare and eng.get_info("compact_gather_active"))
+        out["config"]["halo_exchange"] = None if halo_plan is None else {
+            "in_use": bool(halo_plan.use_halo), "rows_received_per_exchange": halo_plan.halo_rows_in,
+            "rows_an_all_gather_delivers": halo_plan.full_rows_in, "rows_sent_per_exchange": halo_plan.halo_rows_out}
         out["config"]["compressed_exchange"] = None if codec is None else {
             "verified_lossless": bool(exchange_ok),
             "bytes_per_row_shipped_of_64": {str(st): (round(pk.bytes_per_row, 2) if pk is not None else 64)
@@ -758,12 +768,10 @@ def forward_variants(make_engine, attach_whole, x, n, dev):
 
 def measured_traffic(workload: str):
     """Measured memory traffic of one steady-state forward, from the newest committed PMC summary (rocprofv3 --pmc passes of
-    tools/pmc_probe.py on the metric graph: L2->fabric read requests x 128 B, calibrated on a 1 GiB copy in the same
+    tools/pmc_probe.py on that workload: L2->fabric read requests x 128 B, calibrated on a 1 GiB copy in the same
     run, + WRITE_SIZE) — only if that summary was taken from the kernels as they are now (it records a hash of the
     kernel sources); otherwise null: a stale number would not describe what was just timed."""
-    if workload != "er10m":
-        return None, None
-    prof = sorted((ROOT / "profiles").glob("r*/pmc_summary.json"))
+    prof = sorted((ROOT / "profiles").glob("r*/pmc_summary.json" if workload == "er10m" else f"r*/pmc_summary_{workload}.json"))
     if not prof:
         return None, None
     data = json.loads(prof[-1].read_text())
@@ -951,6 +959,8 @@ def side_workload(name, args, dev, make_engine, ggt):
     e.synchronize()
     ms = (time.perf_counter() - t) * 1e3 / args.steps
     fwd_bytes = sum(stage_bytes(i, n, nnz) for i in range(3))
+    traffic, traffic_src = measured_traffic(name)
+    traffic1, _ = measured_traffic(name + "_first")
     res = {"workload": desc, "vertices": n, "edges": g.n_edges, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": ms, "value": g.n_edges / (ms * 1e-3), "unit": "edges/s",
            "attach_ms": attach_ms, "first_forward_ms": early[0], "attach_plus_first_forward_ms": attach_ms + early[0],
@@ -960,6 +970,11 @@ def side_workload(name, args, dev, make_engine, ggt):
            "score_once_value": g.n_edges / (early[0] * 1e-3),
            "first_forward_roofline_frac": fwd_bytes / (early[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "roofline_frac": fwd_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "forward_bytes": fwd_bytes,
+           # measured bytes of one steady-state forward (profiles/r*/pmc_summary_<workload>.json, only if taken from these sources)
+           "traffic": traffic, "traffic_source": traffic_src,
+           "traffic_frac": (traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+           "first_forward_traffic": traffic1,
+           "first_forward_traffic_frac": (traffic1 / (early[0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic1 else None,
            "plan": {"lds_table": bool(e.get_info("lds_table_active")), "compact_gather": bool(e.get_info("compact_gather_active")),
                     "pruned_stage1": bool(e.get_info("pruned_stage1")), "pruned_stage2": bool(e.get_info("pruned_stage2")),
                     "pruned_stage1_predicted_at_handoff": bool(e.get_info("pruned_predicted_stage1")),

@@ -376,7 +376,7 @@ int launch_main(gnnvc_engine *e, const StageChoice &c, const GraphDev &gv, const
                                                         e->lt_steps.p, e->lt_entries.p, e->lt_bytes.p, e->blk_acc.p, e->lt_bad.p,
                                                         c.long_thresh, e->opt_mfma == 1, e->interleave, e->stream, emit,
                                                         e->lt_last_entry, e->lt_mapped ? e->lt_rowmap.p : nullptr,
-                                                        e->lt_mapped ? e->lt_chunks : 0u, e->lt_base, e->lt_end));
+                                                        e->lt_mapped ? e->lt_chunks : 0u, e->lt_base, e->lt_end, e->lt_bits));
     if (c.sums == StageChoice::kBlocked)
         return hip_rc(e, gnnvc::launch_stage0_blocked(sp, e->g, e->ws, e->params.p, in, out, lo, hi, e->blk_count, e->blk_ptr.p,
                                                       e->blk_col.p, e->blk_acc.p, e->long_thresh, e->opt_mfma == 1, e->interleave,
@@ -711,6 +711,7 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "lds_table_skewed_rows") e->opt_lds_skewed_rows = value > 0 ? (uint32_t)value : 0u;
     else if (k == "lds_table") e->opt_lds_table = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else if (k == "lds_table_min_chunks") e->opt_lt_min_chunks = value > 0 ? (uint32_t)value : 1u;
+    else if (k == "lds_table_bits") e->opt_lt_bits = (value == 8 || value == 10 || value == 16) ? (int)value : 0;
     else if (k == "plans_at_handoff") e->opt_handoff = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else if (k == "handoff_min_entries") e->opt_handoff_min_nnz = value > 0 ? (uint64_t)value : 0;
     else if (k == "pilot_rows") e->opt_pilot_rows = value > 0 ? (uint32_t)value : 0u;
@@ -778,6 +779,7 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
         }
     }
     else if (k == "lds_table_off") *value = e->lt_off ? 1 : 0;
+    else if (k == "lds_table_bits") *value = e->lt_ready ? (long)e->lt_bits : 0;
     else if (k == "compact_gather_off_stage1" || k == "compact_gather_off_stage2") *value = e->c4_stage_off[k.back() - '0'] ? 1 : 0;
     else if (k == "compact_gather_blocks") *value = e->c4_ready ? (long)e->c4_nblocks : 0;
     else if (k == "compact_gather_last_ok" || k == "compact_gather_last_dirty" || k == "compact_gather_last_passes" ||
@@ -794,6 +796,16 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
         }
     }
     else if (k == "lds_table_active") *value = e->lt_ready ? 1 : 0;
+    else if (k == "lds_table_last_ok") {   // did the last forward's input fit the table?  (waits for the stream; tests and tools)
+        *value = 0;
+        if (e->lt_ready && e->lt_bad.p) {
+            uint32_t bad = 1;
+            if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess ||
+                hipMemcpy(&bad, e->lt_bad.p, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess)
+                return GNNVC_ERR_DEVICE;
+            *value = bad == 0 ? 1 : 0;
+        }
+    }
     else if (k == "lds_table_mapped") *value = e->lt_ready && e->lt_mapped ? 1 : 0;
     else if (k == "lds_table_blocks") *value = e->lt_ready ? (long)e->lt_blocks : 0;
     else if (k == "lds_table_chunks") *value = e->lt_ready ? (long)e->lt_chunks : 0;

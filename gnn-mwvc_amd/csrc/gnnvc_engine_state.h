@@ -144,6 +144,8 @@ struct gnnvc_engine {
     // input that is not k / ws leaves the plan's launches empty and — in the skewed layout, whose rows below the giant ones are
     // all the tile kernel's then — makes the stage several times slower than without the plan; one miss there, three on the
     // consecutive-row layout, switch it off for the graph
+    uint32_t lt_bits = 8;           // width of the plan's table entries: 8, 10 or 16 bits per vertex (by the graph's largest weight)
+    int opt_lt_bits = 0;            // option "lds_table_bits" (tests, A/B): force a width (0 = by the graph)
     bool lt_used = false, lt_off = false;
     uint32_t lt_unfit_runs = 0;
     bool lt_mapped = false;              // skewed graphs: rows dealt to slices (lt_rowmap), blocks of equal mass, rows below lt_plan_thresh

@@ -202,7 +202,11 @@ hipError_t launch_sgemm(int ta, int tb, uint32_t m, uint32_t n, uint32_t k, cons
                         uint32_t ldc, hipStream_t stream);
 
 // LDS-table plan of the F = 1 stage (see the kernels): build steps, then the per-forward launch
-uint32_t lds_table_max_rows();
+// (bits = the width of a table entry: 8, 10 or 16 — lds_table_bits_for(largest k); 0 = too wide for the plan)
+uint32_t lds_table_max_rows(uint32_t bits = 8);
+uint32_t lds_table_bits_for(uint32_t kmax);
+size_t lds_table_bytes_for(uint32_t bits, size_t n);   // bytes of a table over n vertices (padding included)
+hipError_t lds_table_wmax(const uint32_t *w, uint32_t n, uint32_t *wmax, hipStream_t stream);   // *wmax = max of w[0 .. n)
 // A plan over rows that are not consecutive (skewed graphs, compact-table plan): chunk c holds the rows
 // rowmap[c * rows_per_chunk ..] (0xFFFFFFFF = empty slot), its regrouped entries start at first[c] (+ the padding
 // slack), and column blocks may have any widths: block b = columns [bstart[b], bstart[b + 1]).  All null (the
@@ -211,14 +215,14 @@ struct PlanMap {
     const uint32_t *rowmap = nullptr, *first = nullptr, *bstart = nullptr;
     const uint16_t *coarse = nullptr;   // with bstart: the block of column 256 k, for every k (a column's block is that one or, rarely, a later one)
 };
-uint32_t lds_table_block();
+uint32_t lds_table_block(uint32_t bits = 8);
 uint32_t lds_table_step();
 uint32_t lds_table_record_words();
 // workgroup steps of the F = 1 plan: one record per (chunk, block, up to 256 entries per slice); a chunk = 16 slices
 hipError_t lds_table_wsteps(const GraphDev &g, uint32_t slice_rows, uint32_t nchunks, uint32_t nblocks, const uint32_t *seg_cnt,
                             const uint32_t *step_ptr, uint32_t *step_count, uint32_t *recs, bool write, uint32_t slack,
-                            hipStream_t stream, const PlanMap &pm = PlanMap(), uint32_t row_base = 0, uint32_t row_end = 0xFFFFFFFFu);
-hipError_t lds_table_bytes(const uint32_t *w, uint32_t n, uint8_t *wb, uint32_t *bad, hipStream_t stream);
+                            hipStream_t stream, const PlanMap &pm = PlanMap(), uint32_t row_base = 0, uint32_t row_end = 0xFFFFFFFFu,
+                            uint32_t bits = 8);
 // (chunk0 / chunk1: only chunks [chunk0, chunk1) of the plan — the flat builders, lds_table_is_flat(), work piece by piece, so a
 // hand-off can regroup the rows whose column entries have arrived while the rest is still on its way; the steps come last)
 bool lds_table_is_flat(uint32_t rows_per_chunk, const PlanMap &pm = PlanMap());
@@ -270,12 +274,13 @@ hipError_t mass_bounds(const GraphDev &g, unsigned long long target, uint32_t co
 hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *x,
                                    float *out, uint32_t row_lo, uint32_t row_hi, uint32_t rows_per_chunk,
                                    const uint32_t *step_ptr, const void *steps, const uint32_t *entries,
-                                   uint8_t *wbyte /* n + 64 bytes, pad zeroed: rewritten from x by every launch */,
+                                   uint8_t *wbyte /* lds_table_bytes_for(bits, n) bytes: rewritten from x by every launch */,
                                    float *acc, uint32_t *bad, uint32_t long_thresh, bool mfma, bool interleave,
                                    hipStream_t stream, const EmitArgs &emit, uint32_t last_entry,
                                    const uint32_t *rowmap = nullptr /* skewed graphs: the plan's rows, slice by slice */,
                                    uint32_t mapped_chunks = 0,
-                                   uint32_t plan_base = 0, uint32_t plan_end = 0xFFFFFFFFu /* the plan's row range (a rank's rows) */);
+                                   uint32_t plan_base = 0, uint32_t plan_end = 0xFFFFFFFFu /* the plan's row range (a rank's rows) */,
+                                   uint32_t bits = 8 /* width of the table's entries (the plan's blocks were laid out for it) */);
 
 // compact-table plan of the 16-wide stages (see the k_c4_* kernels); the step layout is built with the
 // lds_table_* functions per SLICE (rows_per_chunk / compact_slices() rows), compact_step() entries per step,

@@ -1714,48 +1714,73 @@ __global__ void k_row_hashes(GraphDev g, unsigned long long *__restrict__ out) {
 // streams the whole byte table once per chunk (512 chunks x 10 MB on the metric graph) from L2 into LDS.
 constexpr uint32_t kLtStep = 2048;        // default entries per step of the plan builder
 
-// The byte table of THIS forward, made from its input alone: wb[v] = k with x[v] == (float)k / ws bit for bit, k <= 255 — the
-// expression the kernel's look-up table is made of; bad |= 1 if some x[v] is no such value (the plan then steps aside for this
+// The table of THIS forward, made from its input alone: entry v = the integer k with x[v] == (float)k / ws bit for bit — the
+// expression the kernel's values are made of; bad |= 1 if some x[v] is no such value (the plan then steps aside for this
 // forward).  For the reference's driver x[v] = (float)W(v) / ws (src/GNN_VC.cpp:189-191): k = W(v).  Needs no vertex weights,
 // so a rank that holds a SLICE of the graph (and the replicated x) can use the plan too.
+// BITS (round 4): how wide an entry is — 8 (k <= 255: a byte per vertex), 10 (k <= 1023: three to a 32-bit word) or 16
+// (k <= 65535) — chosen per graph from its largest weight, so that weights beyond a byte (WEIGHT_SCALE is any u32,
+// include/gnn_inference.hpp:25; folds create new ones, include/reduction_graph.hpp:394-396) keep a table instead of falling
+// back to the column-blocked plan.  The 81 920 bytes of LDS a column block takes then hold 81 920 / 61 440 / 40 960 vertices.
+__host__ __device__ constexpr uint32_t lt_block_cols(uint32_t bits) { return bits == 8 ? 81920u : (bits == 10 ? 61440u : 40960u); }
+__host__ __device__ constexpr uint32_t lt_piece_cols(uint32_t bits) { return bits == 8 ? 16u : (bits == 10 ? 12u : 8u); }   // vertices per 16 bytes
+__host__ __device__ constexpr uint32_t lt_kmax(uint32_t bits) { return bits == 8 ? 255u : (bits == 10 ? 1023u : 65535u); }
+__host__ __device__ inline size_t lt_table_bytes(uint32_t bits, size_t n) { return (n + lt_piece_cols(bits) - 1) / lt_piece_cols(bits) * 16 + 64; }
+
+// x -> k (0 and a miss if x is no k / ws with k <= KMAX).  t = x * ws = k (1 + eps), |eps| <= 2^-23: rounds to k for k <= 65535
+template <uint32_t KMAX>
+__device__ __forceinline__ uint32_t lt_k_of(float xv, float ws, bool &miss) {
+    const float t = xv * ws;
+    const uint32_t k = (t >= 0.0f && t < (float)KMAX + 0.5f) ? (uint32_t)(t + 0.5f) : 0u;
+    miss |= __float_as_uint((float)k / ws) != __float_as_uint(xv);
+    return k;
+}
+
+template <int BITS>
 __global__ __launch_bounds__(256) void k_lt_bytes_x(const float *__restrict__ x, float ws, uint32_t n, uint8_t *__restrict__ wb,
                                                     uint32_t *bad) {
     bool miss = false;
-    // four vertices per thread: one 16-byte load, one 4-byte store (an x that is not 16-byte aligned: one vertex per thread)
-    const uint32_t quads = (reinterpret_cast<uintptr_t>(x) & 15u) ? 0u : n / 4u;
-    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += gridDim.x * blockDim.x) {
-        const float4 v = reinterpret_cast<const float4 *>(x)[q];
-        const float f[4] = {v.x, v.y, v.z, v.w};
-        uint32_t packed = 0;
+    constexpr uint32_t KMAX = lt_kmax(BITS);
+    if constexpr (BITS == 8) {
+        // four vertices per thread: one 16-byte load, one 4-byte store (an x that is not 16-byte aligned: one vertex per thread)
+        const uint32_t quads = (reinterpret_cast<uintptr_t>(x) & 15u) ? 0u : n / 4u;
+        for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += gridDim.x * blockDim.x) {
+            const float4 v = reinterpret_cast<const float4 *>(x)[q];
+            const float f[4] = {v.x, v.y, v.z, v.w};
+            uint32_t packed = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float t = f[i] * ws;                       // k (1 + eps), eps <= 2^-23: rounds to k for k <= 255
-            uint32_t k = (t >= 0.0f && t < 255.5f) ? (uint32_t)(t + 0.5f) : 0u;
-            miss |= __float_as_uint((float)k / ws) != __float_as_uint(f[i]);
-            packed |= k << (8 * i);
+            for (int i = 0; i < 4; ++i) packed |= lt_k_of<KMAX>(f[i], ws, miss) << (8 * i);
+            reinterpret_cast<uint32_t *>(wb)[q] = packed;
         }
-        reinterpret_cast<uint32_t *>(wb)[q] = packed;
-    }
-    for (uint32_t v = quads * 4u + blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {   // the tail (or all of it)
-        const float t = x[v] * ws;
-        const uint32_t k = (t >= 0.0f && t < 255.5f) ? (uint32_t)(t + 0.5f) : 0u;
-        miss |= __float_as_uint((float)k / ws) != __float_as_uint(x[v]);
-        wb[v] = (uint8_t)k;
+        for (uint32_t v = quads * 4u + blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x)   // the tail (or all of it)
+            wb[v] = (uint8_t)lt_k_of<KMAX>(x[v], ws, miss);
+    } else if constexpr (BITS == 16) {
+        const uint32_t pairs = (n + 1u) / 2u;   // one 32-bit word = two vertices
+        for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < pairs; q += gridDim.x * blockDim.x) {
+            const uint32_t k0 = lt_k_of<KMAX>(x[2 * q], ws, miss);
+            const uint32_t k1 = 2 * q + 1 < n ? lt_k_of<KMAX>(x[2 * q + 1], ws, miss) : 0u;
+            reinterpret_cast<uint32_t *>(wb)[q] = k0 | (k1 << 16);
+        }
+    } else {
+        const uint32_t words = (n + 2u) / 3u;   // one 32-bit word = three vertices of ten bits
+        for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < words; q += gridDim.x * blockDim.x) {
+            uint32_t packed = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 3; ++i)
+                if (3 * q + i < n) packed |= lt_k_of<KMAX>(x[3 * q + i], ws, miss) << (10 * i);
+            reinterpret_cast<uint32_t *>(wb)[q] = packed;
+        }
     }
     if (__any(miss) && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
 }
 
-// wb[v] = (uint8) w[v]; bad |= 1 if some weight does not fit a byte
-__global__ __launch_bounds__(256) void k_lt_bytes(const uint32_t *__restrict__ w, uint32_t n, uint8_t *__restrict__ wb,
-                                                  uint32_t *bad) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool big = false;
-    if (i < n) {
-        const uint32_t v = w[i];
-        big = v > 255u;
-        wb[i] = (uint8_t)v;
-    }
-    if (__any(big) && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
+// *wmax = the largest of w[0 .. n) (how wide the plan's table entries have to be)
+__global__ __launch_bounds__(256) void k_lt_wmax(const uint32_t *__restrict__ w, uint32_t n, uint32_t *__restrict__ wmax) {
+    uint32_t m = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = max(m, w[i]);
+#pragma unroll
+    for (int off = 32; off; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(wmax, m);
 }
 
 // A plan over rows that are NOT consecutive (skewed graphs, compact-table plan): chunk c holds the rows
@@ -2267,8 +2292,10 @@ __global__ __launch_bounds__(64) void k_ltw_steps(GraphDev g, uint32_t slice_row
                                                   const uint32_t *__restrict__ seg_cnt, const uint32_t *__restrict__ step_ptr,
                                                   uint32_t *__restrict__ step_count, uint32_t *__restrict__ recs, int write,
                                                   uint32_t cap, uint32_t slack, uint32_t block_cols, PlanMap pm, uint32_t row_base,
-                                                  uint32_t row_end) {
-    // record words [1] = the block's first column, [34] = the 16-byte piece of the byte table its last column sits in
+                                                  uint32_t row_end, uint32_t piece_cols) {
+    // record words [1] = the block's first column, [34] = the 16-byte piece of the table its last column sits in (piece_cols =
+    // vertices per 16 bytes of table: 16 for the byte table; 0 = the compact-table plan, which does not use the word)
+    if (piece_cols == 0) piece_cols = 16;
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
     uint32_t first[16];
@@ -2293,7 +2320,7 @@ __global__ __launch_bounds__(64) void k_ltw_steps(GraphDev g, uint32_t slice_row
                     rec[2 + w] = first[w] + t * cap;
                     rec[18 + w] = cnt[w] > t * cap ? min(cap, cnt[w] - t * cap) : 0u;
                 }
-                rec[34] = (min(lt_block_start(pm, b + 1, block_cols), g.n) + 15u) / 16u;
+                rec[34] = (min(lt_block_start(pm, b + 1, block_cols), g.n) + piece_cols - 1u) / piece_cols;
                 rec[35] = 0;
             }
             ++made;
@@ -2312,7 +2339,7 @@ __global__ __launch_bounds__(64) void k_ltw_steps(GraphDev g, uint32_t slice_row
             for (uint32_t i = 0; i < kLtwRec; ++i) rec[i] = 0;
             rec[0] = last_block;
             rec[1] = lt_block_start(pm, last_block, block_cols);
-            rec[34] = (min(lt_block_start(pm, last_block + 1, block_cols), g.n) + 15u) / 16u;
+            rec[34] = (min(lt_block_start(pm, last_block + 1, block_cols), g.n) + piece_cols - 1u) / piece_cols;
         }
     else
         step_count[c] = padded;
@@ -2325,8 +2352,13 @@ __global__ __launch_bounds__(64) void k_ltw_steps(GraphDev g, uint32_t slice_row
 // lane's last entry continuing with the next lane's entries (whole-wave DPP shift) — see k_c4_agg, which does
 // the same with four floats per row.  Two barriers per step: everyone is done with the slice / the next one
 // is in place (it was loaded into registers before the step's sums).
-constexpr uint32_t kLtwBlock = 81920;       // vertices per column block = bytes of the LDS slice
+constexpr uint32_t kLtwBlock = 81920;       // bytes of the LDS slice = vertices per column block of the BYTE table (lt_block_cols)
 constexpr uint32_t kLtwSliceRows = 1221;    // rows per slice: 16 x 4 B x rows + 1 KiB + 80 KiB <= 160 KiB
+// (only the byte table has a look-up table of its 256 values; the wider forms divide — (float)k / ws, the IEEE division that made
+// x — which hides under the slice's streaming.  A 1024-entry table for the 10-bit form was measured: its 4 KiB cost 48 rows per
+// slice, the metric graph's 512 chunks became 768 and stage 0 took 1.56 ms instead of 1.3.)
+__host__ __device__ constexpr uint32_t lt_lut_floats(uint32_t bits) { return bits == 8 ? 256u : 0u; }
+__host__ __device__ constexpr uint32_t lt_slice_rows_max(uint32_t) { return kLtwSliceRows; }
 constexpr uint32_t kLtwStep = 256;          // entries per slice and step
 constexpr uint32_t kLtwShift = 17;
 constexpr uint32_t kLtwNoRow = (1u << (32 - kLtwShift)) - 1u;
@@ -2335,6 +2367,7 @@ static_assert(kLtwBlock % (16 * 1024) == 0, "slice pieces per thread");
 
 __device__ __forceinline__ float ltw_sel(bool c, float v) { return c ? v : 0.0f; }   // values >= +0: x + 0 == x
 
+template <int BITS>
 __global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ step_ptr, const uint32_t *__restrict__ recs,
                                                  const uint32_t *__restrict__ entries, const uint8_t *__restrict__ wbyte, float ws,
                                                  float *__restrict__ agg, uint32_t n, uint32_t slice_rows, uint32_t chunk0,
@@ -2348,15 +2381,16 @@ __global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ st
     if (*bad) return;                                                   // block-uniform
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float *A = reinterpret_cast<float *>(lt_smem) + wave * slice_rows;  // this wave's sums
-    float *lut = reinterpret_cast<float *>(lt_smem) + 16 * slice_rows;  // 256 floats
-    uint8_t *slice = reinterpret_cast<uint8_t *>(lut + 256);            // kLtwBlock bytes (16-byte aligned: slice_rows * 64 is)
+    float *lut = reinterpret_cast<float *>(lt_smem) + 16 * slice_rows;  // 256 / 1024 / 0 floats
+    uint8_t *slice = reinterpret_cast<uint8_t *>(lut + lt_lut_floats(BITS));   // kLtwBlock bytes (16-byte aligned: slice_rows * 64 is)
+    constexpr uint32_t kPiece = lt_piece_cols(BITS);                    // vertices per 16-byte piece of the table
     const uint32_t chunk = chunk0 + blockIdx.x;
     const uint32_t row0 = row_base + (chunk * 16 + wave) * slice_rows;
     for (uint32_t i = lane; i < slice_rows; i += 64) A[i] = 0.0f;
-    if (tid < 256) lut[tid] = (float)tid / ws;                          // the very expression that makes x (checked per forward)
+    if (tid < lt_lut_floats(BITS)) lut[tid] = (float)tid / ws;          // the very expression that makes x (checked per forward)
     const uint32_t st0 = __builtin_amdgcn_readfirstlane(step_ptr[chunk]);
     const int nsteps = (int)(__builtin_amdgcn_readfirstlane(step_ptr[chunk + 1]) - st0);   // a multiple of 4; 8 more records are readable
-    const uint32_t last_piece = (n + 15u) / 16u;                        // the byte table is padded beyond this
+    const uint32_t last_piece = (n + kPiece - 1u) / kPiece;             // the table is padded beyond this
     constexpr int SW = kLtwBlock / 16 / 1024;
     uint4 e[4];                              // entries of step s in slot s & 3
     uint32_t cnt[4], bk[4];
@@ -2368,7 +2402,7 @@ __global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ st
     }
     u32x4 sr[SW];
     // descriptor of the step whose entries are loaded next: block, this wave's first entry and count
-    uint32_t d_blk = recs[(size_t)st0 * kLtwRec + 1] / 16u, d_first = recs[(size_t)st0 * kLtwRec + 2 + wave], d_cnt = recs[(size_t)st0 * kLtwRec + 18 + wave];
+    uint32_t d_blk = recs[(size_t)st0 * kLtwRec + 1] / kPiece, d_first = recs[(size_t)st0 * kLtwRec + 2 + wave], d_cnt = recs[(size_t)st0 * kLtwRec + 18 + wave];
     uint32_t d_end = recs[(size_t)st0 * kLtwRec + 34];   // (d_blk: the first 16-byte piece of the block's bytes, d_end: its last)
     uint32_t be[4] = {0, 0, 0, 0};
     int d_step = 0;
@@ -2389,7 +2423,7 @@ __global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ st
                 const int nx = se + 1;
                 const uint32_t nxc = (uint32_t)(nx < 0 ? 0 : (nx < nsteps ? nx : nsteps - 1));
                 const uint32_t *rec = recs + (size_t)(st0 + nxc) * kLtwRec;
-                d_blk = rec[1] / 16u;        // (wave-uniform values, left in vector registers: nothing waits for
+                d_blk = rec[1] / kPiece;     // (wave-uniform values, left in vector registers: nothing waits for
                 d_first = rec[2 + wave];     //  them before the next trip)
                 d_cnt = rec[18 + wave];
                 d_end = rec[34];
@@ -2413,7 +2447,15 @@ __global__ __launch_bounds__(1024) void k_lt_agg(const uint32_t *__restrict__ st
                 for (int k = 0; k < 4; ++k) {
                     const bool in = 4u * lane + k < cnt[slot];
                     r[k] = in ? (w[k] >> kLtwShift) : kLtwNoRow;
-                    val[k] = lut[slice[in ? (w[k] & ((1u << kLtwShift) - 1u)) : 0u]];
+                    const uint32_t cl = in ? (w[k] & ((1u << kLtwShift) - 1u)) : 0u;   // column within the block
+                    if constexpr (BITS == 8) {
+                        val[k] = lut[slice[cl]];
+                    } else if constexpr (BITS == 10) {
+                        const uint32_t wd = cl / 3u;
+                        val[k] = (float)((reinterpret_cast<const uint32_t *>(slice)[wd] >> (10u * (cl - 3u * wd))) & 1023u) / ws;
+                    } else {   // (no table of 65 536 values: the division itself, IEEE like the one that made x)
+                        val[k] = (float)reinterpret_cast<const uint16_t *>(slice)[cl] / ws;
+                    }
                     a[k] = A[r[k] < slice_rows ? r[k] : 0];
                 }
                 uint32_t prev3 = lane_prev(r[3]);
@@ -4195,24 +4237,29 @@ static uint32_t lt_flat_threads() {
     return 256u;
 }
 
-uint32_t lds_table_max_rows() { return 16u * kLtwSliceRows; }
-uint32_t lds_table_block() { return kLtwBlock; }
+uint32_t lds_table_max_rows(uint32_t bits) { return 16u * lt_slice_rows_max(bits); }
+uint32_t lds_table_block(uint32_t bits) { return lt_block_cols(bits); }
+uint32_t lds_table_bits_for(uint32_t kmax) { return kmax <= 255u ? 8u : (kmax <= 1023u ? 10u : (kmax <= 65535u ? 16u : 0u)); }
+size_t lds_table_bytes_for(uint32_t bits, size_t n) { return lt_table_bytes(bits, n); }
 uint32_t lds_table_step() { return kLtwStep; }
 uint32_t lds_table_record_words() { return kLtwRec; }
 
 hipError_t lds_table_wsteps(const GraphDev &g, uint32_t slice_rows, uint32_t nchunks, uint32_t nblocks, const uint32_t *seg_cnt,
                             const uint32_t *step_ptr, uint32_t *step_count, uint32_t *recs, bool write, uint32_t slack,
-                            hipStream_t stream, const PlanMap &pm, uint32_t row_base, uint32_t row_end) {
+                            hipStream_t stream, const PlanMap &pm, uint32_t row_base, uint32_t row_end, uint32_t bits) {
     if (slack < 3u * nblocks + 4u) return hipErrorInvalidValue;
+    if (bits != 8 && bits != 10 && bits != 16) return hipErrorInvalidValue;
     if (row_end > g.n) row_end = g.n;
     GNNVC_LAUNCH(k_ltw_steps, dim3((nchunks + 63) / 64), dim3(64), 0, stream, g, slice_rows, nchunks, nblocks, seg_cnt,
-                       step_ptr, step_count, recs, write ? 1 : 0, kLtwStep, slack, kLtwBlock, pm, row_base, row_end);
+                       step_ptr, step_count, recs, write ? 1 : 0, kLtwStep, slack, lt_block_cols(bits), pm, row_base, row_end,
+                       lt_piece_cols(bits));
     return hipGetLastError();
 }
 
-hipError_t lds_table_bytes(const uint32_t *w, uint32_t n, uint8_t *wb, uint32_t *bad, hipStream_t stream) {
-    if (!n) return hipSuccess;
-    GNNVC_LAUNCH(k_lt_bytes, dim3((n + 255) / 256), dim3(256), 0, stream, w, n, wb, bad);
+hipError_t lds_table_wmax(const uint32_t *w, uint32_t n, uint32_t *wmax, hipStream_t stream) {
+    hipError_t rc = hipMemsetAsync(wmax, 0, sizeof(uint32_t), stream);
+    if (rc != hipSuccess || !n) return rc;
+    GNNVC_LAUNCH(k_lt_wmax, dim3(std::min<unsigned>((n + 255) / 256, 1024u)), dim3(256), 0, stream, w, n, wmax);
     return hipGetLastError();
 }
 
@@ -4357,28 +4404,38 @@ hipError_t launch_stage0_lds_table(const StagePlan &sp, const GraphDev &g, float
                                    const uint32_t *step_ptr, const void *steps, const uint32_t *entries, uint8_t *wbyte,
                                    float *acc, uint32_t *bad, uint32_t long_thresh, bool mfma, bool interleave,
                                    hipStream_t stream, const EmitArgs &emit, uint32_t last_entry, const uint32_t *rowmap,
-                                   uint32_t mapped_chunks, uint32_t plan_base, uint32_t plan_end) {
+                                   uint32_t mapped_chunks, uint32_t plan_base, uint32_t plan_end, uint32_t bits) {
     if (row_hi <= row_lo) return hipSuccess;
+    if (bits != 8 && bits != 10 && bits != 16) return hipErrorInvalidValue;
+    if (rowmap && bits != 8) return hipErrorInvalidValue;   // (the skewed layout's block starts are multiples of 256 columns, not of a 10-bit piece)
     if (plan_end > g.n) plan_end = g.n;
     if (row_lo < plan_base || row_hi > plan_end) return hipErrorInvalidValue;
     if (rowmap && (row_lo != 0 || row_hi != g.n || mapped_chunks == 0)) return hipErrorInvalidValue;   // (a mapped plan sums all of its rows)
-    if (sp.variant != 0 || rows_per_chunk == 0 || rows_per_chunk > 16u * kLtwSliceRows || rows_per_chunk % 16u || g.nnz == 0)
+    if (sp.variant != 0 || rows_per_chunk == 0 || rows_per_chunk > 16u * lt_slice_rows_max(bits) || rows_per_chunk % 16u || g.nnz == 0)
         return hipErrorInvalidValue;
     // does this forward's input match the table?  decided on the device: no host round trip
     hipError_t rc = hipMemsetAsync(bad, 0, sizeof(uint32_t), stream);
     if (rc != hipSuccess) return rc;
-    GNNVC_LAUNCH(k_lt_bytes_x, dim3(std::min<unsigned>((g.n / 4 + 255) / 256 + 1, 4096u)), dim3(256), 0, stream, x, ws, g.n,
-                 wbyte, bad);
+    const dim3 tgrid(std::min<unsigned>((g.n / 4 + 255) / 256 + 1, 4096u));
     const uint32_t c0 = rowmap ? 0u : (row_lo - plan_base) / rows_per_chunk, c1 = rowmap ? mapped_chunks - 1 : (row_hi - 1 - plan_base) / rows_per_chunk;
     const uint32_t slice_rows = rows_per_chunk / 16u;
     constexpr size_t lds_max = (size_t)16 * kLtwSliceRows * 4 + 1024 + kLtwBlock;
     static_assert(lds_max <= 160 * 1024, "LDS budget of k_lt_agg");
-    const size_t lds = (size_t)16 * slice_rows * 4 + 1024 + kLtwBlock;
-    static std::atomic<uint64_t> lds_ok{0};
-    rc = allow_dynamic_lds(reinterpret_cast<const void *>(k_lt_agg), (int)lds_max, lds_ok);
-    if (rc != hipSuccess) return rc;
-    GNNVC_LAUNCH(k_lt_agg, dim3(c1 - c0 + 1), dim3(1024), lds, stream, step_ptr, reinterpret_cast<const uint32_t *>(steps),
-                       entries, wbyte, ws, acc, g.n, slice_rows, c0, last_entry, bad, rowmap, rowmap ? 0u : plan_base, rowmap ? g.n : plan_end);
+    const size_t lds = (size_t)16 * slice_rows * 4 + lt_lut_floats(bits) * 4 + kLtwBlock;
+#define GNNVC_LT_AGG(B_)                                                                                                          \
+    {                                                                                                                             \
+        GNNVC_LAUNCH(k_lt_bytes_x<B_>, tgrid, dim3(256), 0, stream, x, ws, g.n, wbyte, bad);                                      \
+        static std::atomic<uint64_t> lds_ok{0};                                                                                   \
+        rc = allow_dynamic_lds(reinterpret_cast<const void *>(k_lt_agg<B_>), (int)lds_max, lds_ok);                               \
+        if (rc != hipSuccess) return rc;                                                                                          \
+        GNNVC_LAUNCH(k_lt_agg<B_>, dim3(c1 - c0 + 1), dim3(1024), lds, stream, step_ptr, reinterpret_cast<const uint32_t *>(steps), \
+                     entries, wbyte, ws, acc, g.n, slice_rows, c0, last_entry, bad, rowmap, rowmap ? 0u : plan_base,               \
+                     rowmap ? g.n : plan_end);                                                                                    \
+    }
+    if (bits == 8) GNNVC_LT_AGG(8)
+    else if (bits == 10) GNNVC_LT_AGG(10)
+    else GNNVC_LT_AGG(16)
+#undef GNNVC_LT_AGG
     const uint32_t ntiles = (row_hi - row_lo + kWave - 1) / kWave;
     const uint32_t per_xcd = (ntiles + 7) / 8;
     const uint32_t blocks_per_xcd = (per_xcd + kWavesPerBlock - 1) / kWavesPerBlock;

@@ -399,8 +399,25 @@ int lt_begin(gnnvc_engine *e) {
     const uint32_t skewed_min_n = e->opt_blocked_min_n < (1u << 20) ? e->opt_blocked_min_n : e->opt_lds_skewed_min_n;
     const bool mapped = skewed && e->opt_lds_table < 2 && e->opt_lds_skewed && g.n >= skewed_min_n && !g.sliced();   // (the skewed layout deals whole graphs)
     if (skewed && !mapped && e->opt_lds_table < 2) return GNNVC_OK;   // long runs would serialise in one thread
-    const uint32_t bc = gnnvc::lds_table_block();
-    uint32_t max_rows = gnnvc::lds_table_max_rows();
+    // How wide a table entry has to be (round 4): the largest k = W(v) among the rows held here and the weight scale (the
+    // original graph's largest weight, src/GNN_VC.cpp:272-278) decide between a byte, ten bits (three to a word) and sixteen bits
+    // per vertex — and with it how many vertices a column block's 80 KiB of LDS hold.  Weights beyond 65 535: no table.  (One
+    // host round trip, in a hand-off that has several; the skewed layout's blocks are cut for the byte table only.)
+    uint32_t bits = 8;
+    {
+        HIP_TRY(e, e->lt_bad.reserve(2));
+        HIP_TRY(e, e->pin_info.reserve(64));
+        HIP_TRY(e, gnnvc::lds_table_wmax(g.w + base, held, e->lt_bad.p + 1, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(e->pin_info.p + 13, e->lt_bad.p + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        const uint32_t wmax = e->pin_info.p[13];
+        const double scale = (e->ws >= 1.0f && e->ws < 4.0e9f) ? (double)e->ws : 0.0;
+        bits = e->opt_lt_bits ? (uint32_t)e->opt_lt_bits : gnnvc::lds_table_bits_for(std::max<uint32_t>(wmax, (uint32_t)scale));
+        if (bits == 0 || gnnvc::lds_table_bits_for(wmax) == 0 || gnnvc::lds_table_bits_for(wmax) > bits) return GNNVC_OK;
+        if (mapped && bits != 8) return GNNVC_OK;
+    }
+    const uint32_t bc = gnnvc::lds_table_block(bits);
+    uint32_t max_rows = gnnvc::lds_table_max_rows(bits);
     if (e->opt_plan_chunk_rows) max_rows = std::min(max_rows, std::max(16u, e->opt_plan_chunk_rows / 16u * 16u));
     uint32_t nblocks = (g.n + bc - 1) / bc, chunks = 0, rows = 0, slice_rows = 0, slices = 0;
     uint64_t plan_nnz = g.nnz;
@@ -442,8 +459,8 @@ int lt_begin(gnnvc_engine *e) {
     const uint32_t slack = 3u * nblocks + 4u;   // every (slice, block) segment starts at a multiple of 4 entries
     const uint64_t entry_cap = plan_nnz + (uint64_t)slack * slices + 8;
     if (entry_cap >= (1ull << 31)) return GNNVC_OK;
-    HIP_TRY(e, e->lt_bad.reserve(2));
-    HIP_TRY(e, e->lt_bytes.reserve((size_t)g.n + 64));
+    const size_t table_bytes = gnnvc::lds_table_bytes_for(bits, g.n);
+    HIP_TRY(e, e->lt_bytes.reserve(table_bytes));
     HIP_TRY(e, e->lt_segcnt.reserve((size_t)slices * nblocks));
     HIP_TRY(e, e->lt_stepcnt.reserve(std::max(chunks, slices)));
     HIP_TRY(e, e->lt_stepptr.reserve((size_t)chunks + 1));
@@ -451,13 +468,12 @@ int lt_begin(gnnvc_engine *e) {
     HIP_TRY(e, e->blk_acc.reserve(g.n));
     uint32_t *flag = e->lt_bad.p + 1;   // word 0 is the per-forward flag
     HIP_TRY(e, hipMemsetAsync(flag, 0, sizeof(uint32_t), e->stream));
-    HIP_TRY(e, hipMemsetAsync(e->lt_bytes.p + g.n, 0, 64, e->stream));
+    HIP_TRY(e, hipMemsetAsync(e->lt_bytes.p + table_bytes - 80, 0, 80, e->stream));   // (the pad and the last piece: every forward rewrites the entries in front)
     HIP_TRY(e, hipMemsetAsync(e->lt_entries.p, 0, entry_cap * sizeof(uint32_t), e->stream));   // (pad slots are read, never used)
     if (mapped)   // rows outside the plan (no entries, or giant): their sums stay +0 (never read for the giant ones)
         HIP_TRY(e, hipMemsetAsync(e->blk_acc.p, 0, (size_t)g.n * sizeof(float), e->stream));
-    // (the table itself is rewritten from x by every forward; this pass only says whether the weights of the rows held here fit a
-    // byte at all — if not, x = W / ws never will, and the plan is not worth building)
-    HIP_TRY(e, gnnvc::lds_table_bytes(g.w + base, held, e->lt_bytes.p + base, flag, e->stream));
+    // (the table itself is rewritten from x by every forward)
+    e->lt_bits = bits;
     pb.open = true;
     pb.mapped = mapped;
     pb.base = base;
@@ -500,7 +516,7 @@ int lt_finish(gnnvc_engine *e) {
     const uint32_t chunks = pb.chunks;
     HIP_TRY(e, e->pin_small.reserve((size_t)chunks + 2));
     HIP_TRY(e, gnnvc::lds_table_wsteps(g, pb.slice_rows, chunks, pb.nblocks, e->lt_segcnt.p, nullptr, e->lt_stepcnt.p, nullptr, false, pb.slack,
-                                       e->stream, pb.pm, pb.base, pb.end));
+                                       e->stream, pb.pm, pb.base, pb.end, e->lt_bits));
     HIP_TRY(e, hipMemcpyAsync(e->pin_small.p, e->lt_stepcnt.p, chunks * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipMemcpyAsync(e->pin_small.p + chunks, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -522,7 +538,7 @@ int lt_finish(gnnvc_engine *e) {
     HIP_TRY(e, hipMemcpyAsync(e->lt_stepptr.p, e->pin_small.p, ptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipMemsetAsync(e->lt_steps.p, 0, rec_quads * sizeof(uint4), e->stream));
     HIP_TRY(e, gnnvc::lds_table_wsteps(g, pb.slice_rows, chunks, pb.nblocks, e->lt_segcnt.p, e->lt_stepptr.p, nullptr,
-                                       reinterpret_cast<uint32_t *>(e->lt_steps.p), true, pb.slack, e->stream, pb.pm, pb.base, pb.end));
+                                       reinterpret_cast<uint32_t *>(e->lt_steps.p), true, pb.slack, e->stream, pb.pm, pb.base, pb.end, e->lt_bits));
     HIP_TRY(e, hipStreamSynchronize(e->stream));   // pin_small is reused by others
     e->c4_map_meta.release();     // (only the dealing needed the list)
     e->c4_map_vertex.release();

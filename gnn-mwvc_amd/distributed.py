@@ -250,6 +250,95 @@ def exchange_rows(buf: torch.Tensor, bounds: Sequence[Tuple[int, int]], rank: in
             w.wait()
 
 
+@dataclasses.dataclass
+class HaloPlan:
+    """Which rows cross between which ranks when only REFERENCED rows travel (north_star: "boundary-vertex feature rows").
+    Rank r's slice references a set of rows (the column ids of its entries); of a peer's shard it needs exactly the referenced
+    ones.  send_idx[q] = the rows of MY shard that peer q's slice references, recv_idx[q] = the rows of q's shard mine does
+    (global row ids, ascending, on the buffers' device).  On an Erdős–Rényi graph a rank references ~92 % of all rows and the
+    all-gather stays (use_halo False); on a graph with locality (a banded / mesh-like graph cut into contiguous ranges) the
+    halo is a sliver of the shards and the exchange's bytes go with it."""
+    send_idx: List[torch.Tensor]
+    recv_idx: List[torch.Tensor]
+    halo_rows_in: int          # rows this rank receives per exchange
+    halo_rows_out: int         # rows it sends (summed over peers)
+    full_rows_in: int          # what the all-gather would deliver to it: every row of every other shard
+    use_halo: bool
+
+    def bytes_in(self, row_bytes: int = 64) -> int:
+        return self.halo_rows_in * row_bytes
+
+
+def build_halo_plan(col: torch.Tensor, nnz: int, bounds: Sequence[Tuple[int, int]], rank: int, n: int, group=None,
+                    max_fraction: float = 0.5) -> HaloPlan:
+    """Once per graph: every rank finds the rows its slice references (col = its slice's GLOBAL column ids, first nnz entries),
+    tells every peer which of that peer's rows it needs, and learns what the peers need of its own.  use_halo = the busiest
+    rank would receive at most `max_fraction` of what the all-gather delivers (every rank reaches the same verdict)."""
+    world = len(bounds)
+    dev = col.device
+    empty = torch.zeros(0, dtype=torch.int64, device=dev)
+    if world == 1:
+        return HaloPlan([empty], [empty], 0, 0, 0, False)
+    need = torch.unique(col[:nnz].to(torch.int64)) if nnz else empty
+    recv_idx = []
+    for q, (plo, phi) in enumerate(bounds):
+        recv_idx.append(empty if q == rank else need[(need >= plo) & (need < phi)].contiguous())
+    counts = torch.tensor([int(t.numel()) for t in recv_idx], dtype=torch.int64, device=dev)
+    table = torch.zeros(world * world, dtype=torch.int64, device=dev)      # table[r * world + q] = rows r needs from q
+    _before_comm(counts, group)
+    dist.all_gather_into_tensor(table, counts, group=group)
+    table = table.view(world, world).cpu()
+    send_idx = [empty if q == rank else torch.zeros(int(table[q, rank]), dtype=torch.int64, device=dev) for q in range(world)]
+    ops = []
+    for q in range(world):
+        if q == rank:
+            continue
+        if recv_idx[q].numel():
+            ops.append(dist.P2POp(dist.isend, recv_idx[q], q, group))
+        if send_idx[q].numel():
+            ops.append(dist.P2POp(dist.irecv, send_idx[q], q, group))
+    if ops:
+        _before_comm(counts, group)
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    lo, hi = bounds[rank]
+    for q in range(world):      # never trust a received index with a gather: it has to name one of MY rows
+        if q != rank and send_idx[q].numel() and (int(send_idx[q].min()) < lo or int(send_idx[q].max()) >= hi):
+            raise ValueError(f"rank {q} asked rank {rank} for rows outside [{lo}, {hi})")
+    rows_in = table.sum(dim=1)                                              # per rank: what it receives
+    full_in = torch.tensor([n - (phi - plo) for plo, phi in bounds], dtype=torch.int64)
+    worst = float((rows_in.to(torch.float64) / full_in.clamp(min=1).to(torch.float64)).max())
+    return HaloPlan(send_idx, recv_idx, int(rows_in[rank]), int(table[:, rank].sum()), int(full_in[rank]), worst <= max_fraction)
+
+
+def exchange_rows_halo(buf: torch.Tensor, plan: HaloPlan, rank: int, group=None) -> int:
+    """exchange_rows for callers that only need the rows their slice references: every rank sends each peer the rows of its
+    shard that peer references (gathered into one contiguous message per peer) and scatters what it receives into `buf`.
+    Rows nobody here references keep whatever they held — no kernel of this rank reads them.  Returns the bytes received."""
+    world = len(plan.send_idx)
+    if world == 1:
+        return 0
+    outs = [buf.index_select(0, plan.send_idx[q]) if (q != rank and plan.send_idx[q].numel()) else None for q in range(world)]
+    ins = [torch.empty((int(plan.recv_idx[q].numel()),) + tuple(buf.shape[1:]), dtype=buf.dtype, device=buf.device)
+           if (q != rank and plan.recv_idx[q].numel()) else None for q in range(world)]
+    ops = []
+    for q in range(world):
+        if outs[q] is not None:
+            ops.append(dist.P2POp(dist.isend, outs[q], q, group))
+        if ins[q] is not None:
+            ops.append(dist.P2POp(dist.irecv, ins[q], q, group))
+    got = 0
+    if ops:
+        _before_comm(buf, group)
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    for q in range(world):
+        if ins[q] is not None:
+            buf.index_copy_(0, plan.recv_idx[q], ins[q])
+            got += ins[q].numel() * ins[q].element_size()
+    return got
+
+
 def _piece_step(per: int, chunks: int, piece_rows: int) -> int:
     """Rows per piece: `piece_rows` when the caller knows a natural size (a multiple of ALIGN — e.g. 256 chunks of
     the engine's compact-table plan, so that no piece ends inside a chunk), else the shard cut into `chunks`."""
@@ -420,7 +509,8 @@ def partitioned_forward(stage_fn: StageFn, num_stages: int, x: torch.Tensor, buf
                         codec: "RowCodec | None" = None,
                         verify: bool = True,
                         prepare_fn=None,
-                        piece_rows: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+                        piece_rows: int = 0,
+                        halo: "HaloPlan | None" = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Run every fused stage on this rank's rows and exchange between stages.
 
     stage_fn(stage, lo, hi, src, dst, logits_or_None) computes rows [lo, hi) of `dst`
@@ -436,6 +526,9 @@ def partitioned_forward(stage_fn: StageFn, num_stages: int, x: torch.Tensor, buf
     settles each stage's Packing in bufs.live from its per-column non-zero counts; later forwards
     ship packed rows.  With verify=True (default) the forward ends with exchange_verified(): if any
     rank's exception list overflowed, every rank goes back to full rows and the forward is repeated.
+    halo: a HaloPlan with use_halo set (build_halo_plan) — the feature exchanges then ship only the rows the receiving rank's
+    slice references (full rows, one message per peer; no packing, no pieces: graphs with locality move little anyway).  The
+    scores still go to every rank.
     prepare_fn(stage, src, lo, hi): optional hint called once before a partitioned stage >= 1 — "src is this
     stage's complete input and stays as it is while rows [lo, hi) are computed from it, possibly in pieces"
     (Engine.stage_input_ready: the engine writes its compact table once instead of gathering full rows per piece).  Callers that pass verify=False (a timed loop) must call
@@ -472,10 +565,16 @@ def partitioned_forward(stage_fn: StageFn, num_stages: int, x: torch.Tensor, buf
         elif not last:
             if prepare_fn is not None and st >= 1:
                 prepare_fn(st, src, lo, hi)
-            pk = bufs.live.get(st) if (codec is not None and world > 1) else None
+            use_halo = halo is not None and halo.use_halo and world > 1
+            pk = bufs.live.get(st) if (codec is not None and world > 1 and not use_halo) else None
             pack = pk is not None
             used_codec = used_codec or pack
-            if can_pipeline:
+            if use_halo:
+                stage_fn(st, lo, hi, src, dst, None)
+                if on_stage:
+                    on_stage(st, "computed")
+                exchange_rows_halo(dst, halo, rank, group)
+            elif can_pipeline:
                 if pack:
                     exchange_rows_pipelined_packed(codec, stage_fn, st, src, dst, bufs, pk, bounds, rank,
                                                    pipeline_chunks, group, piece_rows)
@@ -492,7 +591,7 @@ def partitioned_forward(stage_fn: StageFn, num_stages: int, x: torch.Tensor, buf
                     exchange_rows_packed(codec, bufs, dst, pk, bounds, rank, group, exchange)
                 else:
                     exchange_rows(dst, bounds, rank, bufs.n, group, exchange)
-            if codec is not None and world > 1 and st not in bufs.live:
+            if codec is not None and world > 1 and st not in bufs.live and not use_halo:
                 # every rank now holds the complete, identical dst: count its non-zeros per column
                 # (synchronises; first forward on a graph only) and settle how it travels from now on
                 bufs.live[st] = choose_packing(codec.column_counts(dst, bufs.n), bufs.n, pieces)
@@ -511,7 +610,7 @@ def partitioned_forward(stage_fn: StageFn, num_stages: int, x: torch.Tensor, buf
     if used_codec and verify and not exchange_verified(bufs, group):
         return partitioned_forward(stage_fn, num_stages, x, bufs, bounds, rank, group, exchange, on_stage,
                                    gather_logits, replicate_stage0, pipeline_chunks, replicate, codec, verify, prepare_fn,
-                                   piece_rows)
+                                   piece_rows, halo)
     return bufs.scores[: bufs.n], bufs.logits[: bufs.n]
 
 

@@ -130,11 +130,13 @@ int gnnvc_get_stream(gnnvc_engine *e, void **hip_stream);
  *                         main stream when it is small (at most 16 Mi giant entries) and the long rows are on the side queue
  *   "blocked_stage0" 0|1  column-blocked plan of the F = 1 stage (default 1; results are
  *                         bit-identical either way, it only changes memory traffic)
- *   "lds_table"      0|1|2  LDS-table plan of the F = 1 stage: when every weight fits a byte and the
- *                         input is x[v] = (float)W(v)/ws (checked on the device at every forward), the
- *                         neighbour values are read from byte slices held in LDS instead of gathered from
- *                         memory (default 1 = large graphs, skewed ones in their own layout; 2 = the consecutive-row
- *                         layout on any large graph; 0 = off).
+ *   "lds_table"      0|1|2  LDS-table plan of the F = 1 stage: when the input is x[v] = (float)W(v)/ws with integer
+ *                         W(v) <= 65 535 (checked on the device at every forward), the neighbour values are read from a
+ *                         table held slice by slice in LDS instead of gathered from memory — a byte per vertex for weights up
+ *                         to 255, ten bits (three to a word) up to 1023, sixteen bits beyond (round 4; chosen per graph from
+ *                         its largest weight and the weight scale: gnnvc_get_info "lds_table_bits"; "lds_table_bits" 8|10|16
+ *                         forces a width, 0 = by the graph).  Default 1 = large graphs, skewed ones in their own layout
+ *                         (byte table only); 2 = the consecutive-row layout on any large graph; 0 = off.
  *                         Takes precedence over "blocked_stage0"; bit-identical results
  *   "compact_gather" 0|1|2  compact-table plan of the 16-wide stages: when at most four feature columns carry
  *                         (nearly) all non-zeros of a stage's input — decided on the device at every forward —

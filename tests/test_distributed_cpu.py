@@ -297,6 +297,68 @@ def test_partitioned_forward_matches_single_process(world, mode, exchange, graph
         assert all(lo % D.ALIGN == 0 or lo == g.n for lo, _ in bounds)   # (an empty last shard starts at n)
 
 
+def _banded_graph(n, band, seed):
+    """vertex u is adjacent to u +- 1 .. band (a graph with locality: a contiguous range references a sliver of its neighbours')"""
+    edges = [(u, u + d) for u in range(n) for d in range(1, band + 1) if u + d < n]
+    rng = np.random.default_rng(seed)
+    return gg.from_edge_list(n, edges, rng.integers(20, 121, n).tolist())
+
+
+def _halo_worker(rank, world, port, kind, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pathlib
+        text = (pathlib.Path(__file__).resolve().parent.parent / "gnn-mwvc_amd" / "data" / "mwvc_model.txt").read_text()
+        g = _banded_graph(4000, 3, 5) if kind == "banded" else gg.erdos_renyi(3000, 30000, 4)
+        bounds = D.partition_bounds(g.n, world, g.rowptr, "rows")
+        lo, hi = bounds[rank]
+        sl = D.slice_csr(g.n, torch.from_numpy(g.rowptr.astype(np.int64)), torch.from_numpy(g.col.astype(np.int64)),
+                         torch.from_numpy(g.w.astype(np.int64)), torch.from_numpy(g.nw.astype(np.int64)), lo, hi)
+        plan = D.build_halo_plan(sl.col, sl.nnz, bounds, rank, g.n)
+        bufs = D.ForwardBuffers.allocate(g.n, bounds, "cpu")
+        for f in bufs.feat:          # rows nobody sends this rank must never be read: poison them
+            f[: g.n] = float("nan")
+        fn = _sliced_oracle_stage_fn(sl, g.ws, text)
+        x = torch.from_numpy(g.x())
+        scores, logits = D.partitioned_forward(fn, 3, x, bufs, bounds, rank, replicate=set(), halo=plan)
+        q.put((rank, scores.numpy().copy(), logits.numpy().copy(), plan.use_halo, plan.halo_rows_in, plan.full_rows_in,
+               plan.halo_rows_out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kind", [(2, "banded"), (3, "banded"), (2, "er")])
+def test_halo_exchange_ships_only_referenced_rows(world, kind, oracle_model):
+    """north_star: "boundary-vertex feature rows exchanged".  On a graph with locality (a banded graph cut into contiguous
+    ranges) a rank needs a few rows of its neighbours' shards: the halo exchange ships exactly the rows the receiving slice
+    references — bytes proportional to the halo, not to N — every other remote row stays poisoned (NaN) here and the scores
+    are still the oracle's, bit for bit.  On an Erdős–Rényi graph a rank references nearly every row: the plan says so
+    (use_halo False) and the all-gather stays."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, kind, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = _banded_graph(4000, 3, 5) if kind == "banded" else gg.erdos_renyi(3000, 30000, 4)
+    oracle_model.set_weight_scale(g.ws)
+    want_s, want_l = oracle_model.scores(g), oracle_model.logits(g)
+    for rank, s, l, use_halo, rows_in, full_in, rows_out in results:
+        assert np.array_equal(s.view(np.uint32), want_s.view(np.uint32)), f"rank {rank}"
+        assert np.array_equal(l.view(np.uint32), want_l.view(np.uint32)), f"rank {rank}"
+        if kind == "banded":
+            # a rank borders at most two neighbours, 3 rows deep each way
+            assert use_halo and 0 < rows_in <= 6 and 0 < rows_out <= 6 and full_in > 1000
+        else:
+            assert not use_halo and rows_in > 0.8 * full_in
+
+
 def test_replication_rule():
     assert D.replicated_stages(1) == set()
     assert D.replicated_stages(2) == {0, 1}

@@ -601,15 +601,73 @@ def test_lds_table_plan_is_bit_identical(model_text, oracle_model, maker, force)
         e.close()
 
 
+@pytest.mark.parametrize("scale,want_bits", [(1, 8), (3, 10), (8, 10), (9, 16), (500, 16), (700, 0)])
+def test_lds_table_entry_width_follows_the_weights(model_text, oracle_model, scale, want_bits):
+    """Round 4: the LDS-table plan's entries are 8, 10 or 16 bits wide by the graph's largest weight — weights
+    beyond a byte (WEIGHT_SCALE is any u32; folds create new weights) keep a table instead of dropping to the column-blocked
+    plan; beyond 65 535 the plan steps aside.  Several column blocks of every width, the byte / 10-bit / 16-bit packing of
+    odd vertex counts, one fold-like weight above the rest, an input that is no k / ws, forced widths: the oracle's bits."""
+    import gnn_mwvc_amd as G
+    g0 = gg.erdos_renyi(200003, 2400000, 66)            # 5 / 4 / 3 column blocks at 16 / 10 / 8 bits
+    w = (g0.w.astype(np.int64) * scale).astype(np.uint32)
+    g = gg.CsrGraph(g0.n, g0.rowptr, g0.col, w, gg.neighbourhood_weights(g0.rowptr, g0.col, w))
+    assert int(w.max()) == 120 * scale
+    oracle_model.set_weight_scale(g.ws)
+    want = oracle_model.logits(g)
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_option("blocked_min_n", 0)
+        e.set_option("blocked_stage0", 0)
+        e.set_option("handoff_min_entries", 1)           # the plan at hand-off: the first forward runs on it
+        e.set_weight_scale(g.ws)
+        e.upload_graph(g)
+        assert e.get_info("lds_table_active") == (1 if want_bits else 0)
+        assert e.get_info("lds_table_bits") == want_bits
+        for rep in range(3):
+            _, lg = e.forward(g.x())
+            assert np.array_equal(bits(lg[:, 0]), bits(want)), rep
+        if want_bits:
+            assert e.get_info("lds_table_last_ok") == 1
+            # an input that is no k / ws: the device notices, the tile kernel gathers, the bits are still the oracle's
+            x2 = (g.x() * np.float32(0.999)).astype(np.float32)
+            _, lg = e.forward(x2)
+            assert e.get_info("lds_table_last_ok") == 0
+            assert np.array_equal(bits(lg[:, 0]), bits(oracle_model.predict(g, x2, stop_after=oracle_model.n_layers - 2)[:, 0]))
+        # a wider table than the weights need gives the same bits (forced widths)
+        for forced in (10, 16):
+            if want_bits and forced > want_bits:
+                e.set_option("lds_table_bits", forced)
+                e.upload_graph(g)
+                assert e.get_info("lds_table_bits") == forced
+                _, lg = e.forward(g.x())
+                assert e.get_info("lds_table_last_ok") == 1
+                assert np.array_equal(bits(lg[:, 0]), bits(want)), forced
+        e.set_option("lds_table_bits", 0)
+        if want_bits == 8:
+            # one vertex heavier than a byte (what a fold leaves behind, include/reduction_graph.hpp:394-396): ten bits
+            w2 = w.copy()
+            w2[12345] = 300
+            g2 = gg.CsrGraph(g.n, g.rowptr, g.col, w2, gg.neighbourhood_weights(g.rowptr, g.col, w2))
+            oracle_model.set_weight_scale(g.ws)          # (the scale stays the ORIGINAL graph's largest weight: x > 1 there)
+            e.upload_graph(g2)
+            assert e.get_info("lds_table_bits") == 10
+            _, lg = e.forward(w2.astype(np.float32) / np.float32(g.ws))
+            assert e.get_info("lds_table_last_ok") == 1
+            want2 = oracle_model.predict(g2, w2.astype(np.float32) / np.float32(g.ws), stop_after=oracle_model.n_layers - 2)[:, 0]
+            assert np.array_equal(bits(lg[:, 0]), bits(want2))
+    finally:
+        e.close()
+
+
 def test_lds_table_plan_steps_aside(model_text, oracle_model):
-    """Weights above 255, descending adjacency lists, long rows: the plan must not be used."""
+    """Weights above 65 535, descending adjacency lists, long rows: the plan must not be used."""
     import gnn_mwvc_amd as G
     e = G.Engine(model_text, device=0)
     try:
         e.set_option("blocked_min_n", 0)
         e.set_option("blocked_stage0", 0)
         g = gg.erdos_renyi(6000, 40000, 64)
-        big_w = gg.CsrGraph(g.n, g.rowptr, g.col, g.w * 3, gg.neighbourhood_weights(g.rowptr, g.col, g.w * 3))
+        big_w = gg.CsrGraph(g.n, g.rowptr, g.col, g.w * 700, gg.neighbourhood_weights(g.rowptr, g.col, g.w * 700))
         g7 = gg.erdos_renyi(200000, 800000, 65)         # three column blocks: descending lists visit them backwards
         rp = g7.rowptr.astype(np.int64)
         col = g7.col.copy()

@@ -19,13 +19,24 @@ def main():
     ap.add_argument("--n", type=int, default=10_000_000)
     ap.add_argument("--m", type=int, default=100_000_000)
     ap.add_argument("--forwards", type=int, default=5)   # the plans are built on the second forward; the last one is steady state
+    ap.add_argument("--workload", default="", help="one of bench.py's workloads instead of --n / --m (er10m = the default graph)")
+    ap.add_argument("--plain", type=int, default=0, help="1 = every per-graph plan off (the plain kernels' traffic)")
+    ap.add_argument("--first", type=int, default=0, help="1 = mark the FIRST forward of a fresh engine instead of the last (score-once traffic)")
     a = ap.parse_args()
     import torch
     import gnn_mwvc_amd as G
     from tools import graphgen_torch as ggt
     dev = torch.device("cuda", 0)
-    g = ggt.erdos_renyi(a.n, a.m, 10, dev)
+    if a.workload:
+        import bench
+        g, _ = bench.build_workload(a.workload, ggt, dev)
+    else:
+        g = ggt.erdos_renyi(a.n, a.m, 10, dev)
     eng = G.Engine(G.default_model_text(), device=0)
+    if a.plain:
+        from tools import panel_graphs
+        for k, v in panel_graphs.PLAIN.items():
+            eng.set_option(k, v)
     eng.set_weight_scale(g.ws)
     eng.attach_graph_device(g.n, g.nnz, g.rowptr.data_ptr(), g.col.data_ptr(), g.w.data_ptr(),
                             g.nw.data_ptr(), keepalive=g)
@@ -38,9 +49,17 @@ def main():
     torch.cuda.synchronize()
     torch.add(src, 1.0, out=dst)   # the only 'CUDAFunctorOnSelf_add<float>' kernel of the run
     torch.cuda.synchronize()
-    for _ in range(a.forwards):
+    # the marker: the only 'add<double>' kernel of the run sits right in front of the forward the summary takes (its last, the
+    # steady state — or its first with --first 1)
+    mark = torch.zeros(64, dtype=torch.float64, device=dev)
+    for i in range(a.forwards):
+        if (a.first and i == 0) or (not a.first and i == a.forwards - 1):
+            torch.add(mark, 1.0, out=mark)
+            torch.cuda.synchronize()
         eng.forward_device(x.data_ptr(), sc.data_ptr(), lg.data_ptr())
         eng.synchronize()
+        if a.first and i == 0:
+            break
     print("probe done", g.n, g.nnz)
     eng.close()
 
