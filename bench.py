@@ -497,6 +497,7 @@ def main() -> int:
              "column_blocks": eng.get_info("blocked_blocks"), "block_cols": eng.get_info("block_cols"),
              "mfma_dense": eng.get_info("mfma_dense"),
              "sorted_tiles": bool(eng.get_info("sorted_tiles_active")),
+             "side_queue_runs_beside": bool(eng.get_info("side_queue_runs_beside")) if eng.get_info("long_rows") else None,
              "natural_tile_waste": eng.get_info("tile_waste_x100") / 100.0,
              "interleaved_tiles": bool(eng.get_info("interleaved_tiles")), "long_rows": eng.get_info("long_rows"),
              "long_row_threshold": eng.get_info("long_row_threshold"), "giant_rows": eng.get_info("giant_rows"),
@@ -613,6 +614,8 @@ def main() -> int:
             for name, chk in checks:
                 out["workloads"][name].update(chk())
 
+    if rank == 0 and plans.get("side_queue_runs_beside") is False:
+        out["warning"] = "no side queue beside the main stream was found: the long / giant rows ran serialised with the tile kernels"
     if rank == 0:
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
@@ -980,7 +983,12 @@ def side_workload(name, args, dev, make_engine, ggt):
                     "pruned_stage1_predicted_at_handoff": bool(e.get_info("pruned_predicted_stage1")),
                     "pruned_stage2_from_stage1_entries": bool(e.get_info("pruned_from_previous_stage2")),
                     "sorted_tiles": bool(e.get_info("sorted_tiles_active")), "long_rows": e.get_info("long_rows"),
-                    "giant_rows": e.get_info("giant_rows")}}
+                    "giant_rows": e.get_info("giant_rows"),
+                    # (skewed graphs: the long / giant rows' kernels have to run BESIDE the tile kernel — a side queue that shares the
+                    # main stream's hardware queue serialises them and nothing else would say so)
+                    "side_queue_runs_beside": bool(e.get_info("side_queue_runs_beside")) if e.get_info("long_rows") else None}}
+    if res["plan"]["side_queue_runs_beside"] is False:
+        res["warning"] = "no side queue beside the main stream was found: this workload's long / giant rows ran serialised"
     # a fresh engine's first-forward logits too (what a score-once caller reads)
     e2 = make_engine()
     e2.set_weight_scale(g.ws)

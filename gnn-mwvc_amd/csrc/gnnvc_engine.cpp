@@ -653,8 +653,13 @@ int gnnvc_set_weight_scale(gnnvc_engine *e, float ws) {
 
 int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream) {
     if (!e) return GNNVC_ERR_INVALID;
-    e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
-    return GNNVC_OK;
+    hipStream_t want = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+    if (want == e->stream) return GNNVC_OK;
+    e->stream = want;
+    if (e->multi) return GNNVC_OK;
+    int rc = use_device(e);
+    if (rc) return rc;
+    return reprobe_side_streams(e);   // (the side queue has to sit on another hardware queue than THIS stream)
 }
 
 int gnnvc_get_stream(gnnvc_engine *e, void **hip_stream) {

@@ -422,6 +422,7 @@ int c4_advance(gnnvc_engine *e, uint32_t upto, hipStream_t stream);
 int c4_finish(gnnvc_engine *e);
 gnnvc::CompactPlan compact_plan(const gnnvc_engine *e);
 int ensure_side_streams(gnnvc_engine *e);
+int reprobe_side_streams(gnnvc_engine *e);
 int ensure_round_events(gnnvc_engine *e, size_t count);
 int ensure_events(gnnvc_engine *e, size_t count);
 int gather_view(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float *in, bool gathering, bool sorted_tiles,

@@ -105,6 +105,7 @@ struct MultiState {
     int opt_pack = 1;            // 0 = full rows always
     int opt_push = 1;            // 0 = hipMemcpyPeerAsync per peer instead of the push kernel
     int opt_only_part = -1;      // >= 0: a forward runs THIS part's share only (timing rehearsal on one device; results are not complete)
+    int opt_announce = -1;       // a part announces a 16-wide stage's complete input (compact table over its rows): -1 = up to 4 parts, 0 / 1
     Packing pk[2];
     std::vector<uint64_t> region_words[2];   // [r * kMaxPieces + k]: words of part r's piece k of stage s (dense + list)
     std::vector<uint64_t> region_pre[2];     // prefix over (r, k) in that order
@@ -372,7 +373,7 @@ int forward_part(MultiState *m, Part &me, std::string &err) {
                 if (nl) PTRY(me, gnnvc_unpack_pieces(me.eng, list, nl, pk.cap, 16, pk.mask, pk.kp, me.h[(s - 1) & 1].p), "gnnvc_unpack_pieces");
             }
         }
-        if (me.hi > me.lo && s >= 1 && P <= 4 && me.pieces == 1)
+        if (me.hi > me.lo && s >= 1 && me.pieces == 1 && (m->opt_announce < 0 ? P <= 4 : m->opt_announce != 0))
             PTRY(me, gnnvc_stage_input_ready(me.eng, s, in, me.lo, me.hi), "gnnvc_stage_input_ready");
         const bool choose = s < 2 && P > 1 && !m->pk[s].known;
         for (int k = 0; k < me.pieces; ++k) {
@@ -692,6 +693,7 @@ int multi_set_option(MultiState *m, const char *key, long value) {
         else if (k == "multi_pack") m->opt_pack = value != 0 ? 1 : 0;
         else if (k == "multi_push") m->opt_push = value != 0 ? 1 : 0;
         else if (k == "multi_only_part") m->opt_only_part = (value >= 0 && value < (long)m->parts.size()) ? (int)value : -1;
+        else if (k == "multi_announce") m->opt_announce = value < 0 ? -1 : (value != 0 ? 1 : 0);
         else return GNNVC_ERR_INVALID;
         if (k == "multi_pieces" || k == "multi_pack") {   // (they shape the pieces and the receive buffers: decided again on the next graph / forward)
             m->pk[0] = m->pk[1] = Packing();

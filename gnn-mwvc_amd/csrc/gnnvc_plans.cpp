@@ -798,6 +798,41 @@ int ensure_side_streams(gnnvc_engine *e) {
     return GNNVC_OK;
 }
 
+// The caller installed another main stream (gnnvc_set_stream): the side queue was probed against the engine's own.  The runtime
+// may have put the caller's stream on the side queue's hardware queue — the two would then run one after the other and nothing
+// would say so — so the pair is probed again, and the side queue replaced (up to four candidates) if it fails.
+// Streams the forward's events refer to are only swapped while nothing of a forward is in flight (the caller's contract for
+// gnnvc_set_stream: between forwards).
+int reprobe_side_streams(gnnvc_engine *e) {
+    if (!e->aux_stream) return GNNVC_OK;   // (no side queue yet: ensure_side_streams will probe against the stream in force)
+    bool beside = false;
+    HIP_TRY(e, gnnvc::streams_run_side_by_side(e->stream, e->aux_stream, &beside));
+    e->side_probes = 1;
+    if (!beside) {
+        hipStream_t tried[4] = {nullptr, nullptr, nullptr, nullptr};
+        int n = 0;
+        hipStream_t good = nullptr;
+        while (n < 4 && !good) {
+            HIP_TRY(e, hipStreamCreateWithFlags(&tried[n], hipStreamNonBlocking));
+            bool ok = false;
+            HIP_TRY(e, gnnvc::streams_run_side_by_side(e->stream, tried[n], &ok));
+            if (ok) good = tried[n];
+            ++n;
+        }
+        e->side_probes += n;
+        for (int i = 0; i < n; ++i)
+            if (tried[i] != good) (void)hipStreamDestroy(tried[i]);
+        if (good) {
+            (void)hipStreamSynchronize(e->aux_stream);
+            (void)hipStreamDestroy(e->aux_stream);
+            e->aux_stream = e->long_stream = e->giant_stream = good;
+            beside = true;
+        }
+    }
+    e->side_beside = beside;
+    return GNNVC_OK;
+}
+
 int ensure_round_events(gnnvc_engine *e, size_t count) {
     {
         int rc = ensure_side_streams(e);

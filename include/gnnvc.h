@@ -94,7 +94,10 @@ int gnnvc_create_multi(gnnvc_engine **out, const char *model_text, size_t len, c
 int gnnvc_set_weight_scale(gnnvc_engine *e, float ws);
 
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of
- * the engine's own stream.  NULL restores the engine's stream. */
+ * the engine's own stream.  NULL restores the engine's stream.  Call it between forwards.  The engine's side queue (long and
+ * giant rows, plan builders) has to sit on another hardware queue than the main stream; it is probed against the new one
+ * (~0.3 ms) and replaced if the runtime put the two on the same queue: gnnvc_get_info "side_queue_runs_beside" says whether a
+ * queue beside the main stream was found (0: skewed graphs' side work runs serialised — slower, never wrong). */
 int gnnvc_set_stream(gnnvc_engine *e, void *hip_stream);
 /* The stream the engine launches on at the moment (its own unless gnnvc_set_stream installed another): a caller orders its own
  * work behind the engine's asynchronous calls with it. */

@@ -1134,6 +1134,34 @@ def test_side_queue_runs_beside_the_main_stream(model_text):
             e.close()
 
 
+def test_side_queue_is_probed_again_for_a_callers_stream(model_text, oracle_model):
+    """the probe pairs the side queue with the engine's OWN main stream; a caller's stream (gnnvc_set_stream) may
+    share the side queue's hardware queue.  Installing one probes the pair again (and replaces the side queue if they are
+    serialised); going back to the engine's stream does too.  Logits unchanged on a graph with long rows."""
+    import gnn_mwvc_amd as G
+    import torch
+    g = gg.hub_graph(30000, 300000, 6, 9000, seed=5)   # long rows: the side queue has work
+    oracle_model.set_weight_scale(g.ws)
+    want = oracle_model.logits(g)
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_weight_scale(g.ws)
+        e.upload_graph(g)
+        for k in range(4):
+            mine = torch.cuda.Stream()
+            e.set_stream(mine.cuda_stream)
+            try:
+                assert e.get_info("side_queue_runs_beside") == 1, k
+                assert 1 <= e.get_info("side_queue_probes") <= 5
+                _, logits = e.forward(g.x())
+                assert np.array_equal(bits(logits[:, 0]), bits(want))
+            finally:
+                e.set_stream(None)
+            assert e.get_info("side_queue_runs_beside") == 1
+    finally:
+        e.close()
+
+
 def test_compact_gather_plan_steps_aside_for_good(model_text, oracle_model):
     """A graph whose stage inputs never fit the plan (low degrees: more than four live columns): after three forwards in a row
     that the device sent down the gathering kernels, the engine stops queuing the plan's counting, choosing and empty
