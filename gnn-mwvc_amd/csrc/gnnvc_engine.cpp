@@ -172,12 +172,15 @@ struct StageChoice {
         kLdsTable,          // F = 1: byte table in LDS (k_lt_agg), the tile kernel only runs the dense layers
         kBlocked,           // F = 1: column-blocked partial sums (k_blk_accumulate)
         kCompactPrepared,   // F = 16: compact table written by gnnvc_stage_input_ready for exactly this input
-        kCompactWhole       // F = 16: compact table over the whole graph, decided per forward on the device
+        kCompactWhole,      // F = 16: compact table over the whole graph, decided per forward on the device
+        kTableTiles         // F = 16, mid-size graphs: the tile kernel gathers the input's L2-resident compact table (k_stage_t4), or — decided
+                            // on the device — leaves the launch to the gathering kernel behind it
     } sums = kGather;
     bool mfma = false;          // dense layers of the gathering kernel on the matrix cores
     bool fused_counts = false;  // kCompactWhole: the producing stage kernel of this forward left counts (and perhaps the table)
     bool rounds = false;        // kCompactWhole, last stage: sums one round at a time, dense kernel of round k under round k + 1
     bool emit = false;          // this stage's VALU epilogue counts / compacts its output rows for stage `stage + 1`
+    bool emit_t4 = false;       // ... for the table tiles of stage `stage + 1` (k_stage_t4)
     uint32_t long_thresh = 0xFFFFFFFFu;   // rows of at least this degree belong to the side streams
     gnnvc::SortedOrder sorted;  // n != 0: tiles from the degree-sorted list of this row range
 };
@@ -200,6 +203,8 @@ int choose_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const flo
                           e->opt_mfma != 1 && !e->c4_stage_off[stage + 1];
     c.long_thresh = (sp.f == 16) ? e->thresh_f16 : e->long_thresh;
     c.mfma = e->opt_mfma == 1 || (e->opt_mfma == 2 && sp.f == 16);
+    const bool t4 = in_forward && e->t4_ok && lo == 0 && hi == e->g.n;   // table tiles: whole forwards on a graph that qualifies
+    c.emit_t4 = t4 && (size_t)stage + 1 < e->stages.size();
     if (stage == 0) {
         // The LDS-table plan works in chunks of ~19.5 K rows, one workgroup each: a call that covers fewer than
         // three quarters of a GPU's worth of chunks (the pieces of a pipelined multi-GPU run) would leave most CUs
@@ -226,6 +231,8 @@ int choose_stage(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const flo
         if (lt_fits && e->lt_mapped) c.long_thresh = e->lt_plan_thresh;   // the plan holds every row below the giant ones
         c.emit = may_emit;
         if (c.sums != StageChoice::kGather) return GNNVC_OK;   // (those two bring their own tile order)
+    } else if (sp.f == 16 && t4) {
+        c.sums = StageChoice::kTableTiles;
     } else if (sp.f == 16) {
         // (the second forward on a graph builds the plan; a graph whose plain 16-wide stages cost well above the build — the
         // option's bound — builds it in its first, which is all a score-once caller ever runs)
@@ -365,6 +372,24 @@ int launch_main(gnnvc_engine *e, const StageChoice &c, const GraphDev &gv, const
         HIP_TRY(e, gnnvc::compact_choose(e->c4_emit_counts.p, 64, rows, cons, 1u, e->stream));
         return GNNVC_OK;
     };
+    if (c.emit_t4) {   // this stage's epilogue counts its output's columns and writes the next stage's table (for that stage's last choice)
+        const int cons = stage + 1;
+        emit.spec = e->t4_desc_of(cons, e->t4_parity);
+        emit.table = e->t4_table[cons - 1].p;
+        emit.counts = e->t4_counts_of(cons, e->t4_parity);   // (cleared by the consumer's launch of the previous forward: k_stage_t4)
+    }
+    if (c.sums == StageChoice::kTableTiles) {
+        uint32_t *d_in = e->t4_desc_of(stage, e->t4_parity), *d_out = e->t4_desc_of(stage, e->t4_parity ^ 1u);
+        const bool solo = e->t4_fit_seen[stage] && e->opt_t4_solo;
+        HIP_TRY(e, gnnvc::launch_stage_t4(sp, e->g, e->ws, e->params.p, in, out, logits, lo, hi, e->interleave, e->stream,
+                                          e->t4_table[stage - 1].p, e->t4_counts_of(stage, e->t4_parity),
+                                          e->t4_counts_of(stage, e->t4_parity ^ 1u), d_in, d_out, emit, solo));
+        if (solo) return GNNVC_OK;
+        // ... and the gathering kernel, which leaves at once when the table tiles did the rows (d_out[8]: decided on the device)
+        return hip_rc(e, gnnvc::launch_stage(sp, gv, e->ws, e->params.p, in, out, logits, lo, hi, c.long_thresh, c.mfma, nullptr,
+                                             e->interleave, e->stream, nullptr, nullptr, nullptr, false, gnnvc::EmitArgs(), true, nullptr,
+                                             nullptr, d_out + 8));
+    }
     if (c.sums == StageChoice::kLdsTable || c.sums == StageChoice::kBlocked) {
         int rc = pilot();
         if (rc) return rc;
@@ -612,6 +637,9 @@ void gnnvc_destroy(gnnvc_engine *e) {
     e->lt_bytes.release(); e->lt_entries.release(); e->lt_segcnt.release(); e->lt_stepptr.release();
     e->lt_stepcnt.release(); e->lt_bad.release(); e->lt_steps.release(); e->lt_rowmap.release(); e->lt_first.release(); e->lt_bstart.release();
     e->c4_entries.release(); e->c4_segcnt.release(); e->c4_stepptr.release(); e->c4_stepcnt.release();
+    for (auto &t : e->t4_table) t.release();
+    for (auto &t : e->t4_counts) t.release();
+    e->t4_desc.release();
     e->c4_desc.release(); e->c4_map_vertex.release(); e->c4_map_meta.release(); e->map_coarse.release(); e->c4_steps.release(); e->c4_table.release(); e->c4_marks.release(); e->c4_acc.release(); e->c4_counts.release();
     e->c4_agg16.release(); e->c4_dirty.release(); e->c4_emit_counts.release();
     for (auto &pp : e->prune) { pp.prp.release(); pp.pcol.release(); pp.heavy.release(); pp.svertex.release(); pp.smeta.release(); }
@@ -702,6 +730,10 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "prune_giant_rows") e->opt_prune_giant = value != 0 ? 1 : 0;
     else if (k == "prune_predict") e->opt_prune_predict = value != 0 ? 1 : 0;
     else if (k == "dense_skip_zeros") e->opt_dense_skip = value != 0 ? 1 : 0;
+    else if (k == "table_tiles") e->opt_t4 = value != 0 ? 1 : 0;
+    else if (k == "table_tiles_solo") e->opt_t4_solo = value != 0 ? 1 : 0;
+    else if (k == "table_tiles_min_n") e->opt_t4_min_n = value > 0 ? (uint32_t)value : 0u;
+    else if (k == "table_tiles_max_bytes") e->opt_t4_max_bytes = value > 0 ? (uint64_t)value : 0ull;
     else if (k == "prune_predict_min_entries") e->opt_predict_min_nnz = value > 0 ? (uint64_t)value : 0;
     else if (k == "giant_gather_first") e->opt_giant_gather_first = value < 0 ? -1 : (value != 0 ? 1 : 0);
     else if (k == "long_rows_on_main") e->opt_long_on_main = value < 0 ? -1 : (value != 0 ? 1 : 0);
@@ -781,6 +813,18 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
                 hipMemcpy(&bad, e->prune_flags.p + st, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess)
                 return GNNVC_ERR_DEVICE;
             *value = bad == 0 ? 1 : 0;
+        }
+    }
+    else if (k == "table_tiles_active") *value = e->t4_ok ? 1 : 0;
+    else if (k == "table_tiles_fit_stage1" || k == "table_tiles_fit_stage2") {   // did the last forward's stage run on the table?  (waits for the stream)
+        *value = 0;
+        if (e->t4_ok && e->t4_desc.p) {
+            uint32_t fit = 0;
+            gnnvc_engine *m = const_cast<gnnvc_engine *>(e);
+            if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess ||
+                hipMemcpy(&fit, m->t4_desc_of(k.back() - '0', e->t4_parity) + 8, sizeof fit, hipMemcpyDeviceToHost) != hipSuccess)
+                return GNNVC_ERR_DEVICE;
+            *value = (long)fit;
         }
     }
     else if (k == "lds_table_off") *value = e->lt_off ? 1 : 0;
@@ -1344,6 +1388,17 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
             e->lt_unfit_runs = e->fit_pin.p[2] != 0u ? e->lt_unfit_runs + 1 : 0u;
             if (e->lt_unfit_runs >= (e->lt_mapped ? 1u : 3u)) e->lt_off = true;
         }
+        if (e->t4_used && e->t4_ok) {
+            // table tiles: a graph whose first 16-wide stage keeps missing (more than four live columns: sparse graphs) stops paying
+            // for the counters, the choice and the launches that leave at once — the first forward on a graph always misses (nobody
+            // has chosen columns yet), hence four in a row
+            e->t4_unfit_runs = e->fit_pin.p[3] == 0u ? e->t4_unfit_runs + 1 : 0u;
+            if (e->t4_unfit_runs >= 4u) e->t4_ok = false;
+            // a stage whose table fit the last forward seen gets no gathering kernel behind it (k_stage_t4's solo mode copes with
+            // the rare forward that does not fit after all)
+            e->t4_fit_seen[1] = e->fit_pin.p[3] != 0u;
+            e->t4_fit_seen[2] = e->fit_pin.p[4] != 0u;
+        }
         for (int s = 1; s <= 2; ++s) {
             if (!e->fit_used[s]) continue;
             // (a stage whose statistics were to come from a producer that itself fell back had no chance: not its miss)
@@ -1355,6 +1410,7 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
     if (!e->fit_pending) {
         for (int s = 0; s < 4; ++s) e->fit_used[s] = false;
         e->lt_used = false;
+        e->t4_used = false;
     }
     struct SinkGuard {   // the thread-local sink never outlives this call, whichever way it returns
         ~SinkGuard() { gnnvc::set_kernel_trace(nullptr); }
@@ -1387,12 +1443,18 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
     }
     gnnvc::set_kernel_trace(nullptr);
     if (rc) return rc;
+    if (e->t4_ok) {   // (the descriptors this forward's table tiles wrote are the next forward's specs)
+        e->t4_parity ^= 1u;
+        e->t4_choice_live = true;
+    }
     e->ev_count = (int)ns + 1;
     const bool c4_verdicts = (e->fit_used[1] || e->fit_used[2]) && e->c4_ready && e->c4_desc.p;
     const bool lt_verdict = e->lt_used && e->lt_ready && e->lt_bad.p;
-    if (!e->fit_pending && (c4_verdicts || lt_verdict)) {   // this forward's verdicts, copied out behind it
+    const bool t4_verdict = e->t4_ok && e->t4_desc.p;
+    if (t4_verdict && !e->fit_pending) e->t4_used = true;
+    if (!e->fit_pending && (c4_verdicts || lt_verdict || t4_verdict)) {   // this forward's verdicts, copied out behind it
         if (!e->ev_fit) HIP_TRY(e, hipEventCreateWithFlags(&e->ev_fit, hipEventDisableTiming));
-        HIP_TRY(e, e->fit_pin.reserve(4));
+        HIP_TRY(e, e->fit_pin.reserve(8));
         if (c4_verdicts)
             for (int s = 1; s <= 2; ++s)
                 HIP_TRY(e, hipMemcpyAsync(e->fit_pin.p + (s - 1), e->c4_desc.p + gnnvc_engine::kDescWords * (s - 1), sizeof(uint32_t),
@@ -1400,6 +1462,9 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
         else
             for (int s = 1; s <= 2; ++s) e->fit_used[s] = false;
         if (lt_verdict) HIP_TRY(e, hipMemcpyAsync(e->fit_pin.p + 2, e->lt_bad.p, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+        if (t4_verdict)   // (the parity has flipped: the descriptors this forward wrote are the current ones)
+            for (int s = 1; s <= 2; ++s)
+                HIP_TRY(e, hipMemcpyAsync(e->fit_pin.p + 2 + s, e->t4_desc_of(s, e->t4_parity) + 8, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(e, hipEventRecord(e->ev_fit, e->stream));
         e->fit_pending = true;
     }

@@ -271,6 +271,25 @@ struct gnnvc_engine {
     int c4_last_desc = 0;           // word offset in c4_desc of the plan's last launch (tests / tools)
     static constexpr int kDescWords = 16;   // per consumer stage (see k_c4_choose); the build flag follows the last stage's
 
+    // Table tiles (round 4; k_stage_t4): graphs too small for the compact-table plan and too large for their feature rows to sit in
+    // an L2 (50 - 400 K vertices: BASELINE configs[1]) gather the 16-wide stages' neighbours from the 16-byte compact table of the
+    // input — written by the kernel that produces the input, for the columns the previous forward chose — inside whole forwards.
+    int opt_t4 = 1;                          // option "table_tiles"
+    uint32_t opt_t4_min_n = 49152;           // option "table_tiles_min_n": below, the 64-byte rows fit an XCD's L2 anyway
+    uint64_t opt_t4_max_bytes = 6ull << 20;  // option "table_tiles_max_bytes": the table has to (mostly) sit in a 4 MiB L2
+    bool t4_ok = false;                      // the current graph qualifies
+    bool t4_used = false;                    // the forward whose verdicts are on their way ran with the table tiles offered
+    bool t4_fit_seen[4] = {false, false, false, false};   // the stage's table fit in the last forward whose verdict has arrived
+    int opt_t4_solo = 1;                     // option "table_tiles_solo" (A/B): 0 = always launch the gathering kernel behind the tiles
+    uint32_t t4_unfit_runs = 0;              // forwards in a row whose first 16-wide stage left the launch to the gathering kernel
+    bool t4_choice_live = false;             // a forward with table tiles has run on this engine: the descriptors hold a choice (kept across graphs)
+    uint32_t t4_parity = 0;                  // which of a stage's two descriptors the producers read in the forward at hand
+    DevBuf<float> t4_table[2];               // [0]: the table of stage 1's input, [1]: of stage 2's (a stage gathers from one while emitting the other)
+    DevBuf<uint32_t> t4_desc;                // [stage - 1][parity][16 words]
+    DevBuf<unsigned long long> t4_counts[2]; // the producers' per-column counters: [stage - 1], two sets of kEmitCounters each (by parity, like the descriptors)
+    unsigned long long *t4_counts_of(int stage, uint32_t parity) { return t4_counts[stage - 1].p + (size_t)parity * gnnvc::kEmitCounters; }
+    uint32_t *t4_desc_of(int stage, uint32_t parity) { return t4_desc.p + ((size_t)(stage - 1) * 2 + parity) * 16; }
+
     // option "mfma_dense": dense layers on the matrix cores (bit-identical to the VALU path).
     // 0 = VALU everywhere, 1 = MFMA everywhere, 2 = MFMA in the F = 16 stages only (default:
     // the F = 1 stage's first layer has K = 5 and stays on the VALU, and sending its 32
@@ -430,6 +449,7 @@ int gather_view(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const floa
 int reserve_features(gnnvc_engine *e, uint32_t n);
 int reserve_multi_front(gnnvc_engine *e, uint32_t n);
 int prepare_plans(gnnvc_engine *e);                          // everything a forward needs that depends on the graph alone
+int prepare_table_tiles(gnnvc_engine *e);                    // does the graph qualify for k_stage_t4, and its buffers
 void reset_graph_state(gnnvc_engine *e);
 int handoff_early(gnnvc_engine *e, uint32_t n, uint64_t nnz);
 // host wall time of a plan build, added to plan_build_ms (what was queued before is drained first: not the plan's cost)

@@ -118,7 +118,17 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
                                                   plan applies); the caller launches the sums and the dense kernel itself */,
                         const SortedOrder *so_pruned = nullptr /* g.prune_eff: the tile order by entries left (meta = pruned ranges) */,
                         const float *table_in = nullptr /* acc4: the compact table of THIS stage's input (one pass), so that the dense
-                                                           kernel takes a row's own live values from it; null = from the full rows */);
+                                                           kernel takes a row's own live values from it; null = from the full rows */,
+                        const uint32_t *skip_flag = nullptr /* (no acc4) a device word: != 0 = another kernel has done this launch's rows */);
+// a 16-wide stage (variant 1 or 2) from the L2-resident compact table of its input (k_stage_t4: graphs of 50 - 400 K vertices, whole
+// forwards): table_in = (n + 1) rows of 16 bytes written by the producer of the input (EmitArgs) for the columns in desc_in,
+// counts_in = that producer's kEmitCounters; desc_out (another 16 words) receives this forward's choice — the next forward's
+// spec — and desc_out[8] = 1 iff the kernel did the rows (the gathering kernel launched behind it takes desc_out + 8 as skip_flag)
+hipError_t launch_stage_t4(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *in, float *out, float *logits,
+                           uint32_t row_lo, uint32_t row_hi, bool interleave, hipStream_t stream, const float *table_in,
+                           const unsigned long long *counts_in, unsigned long long *counts_zero /* the other parity's set, cleared here */,
+                           const uint32_t *desc_in, uint32_t *desc_out, const EmitArgs &emit,
+                           bool solo = false /* no gathering kernel follows: a table that does not fit is handled inside, the slow way */);
 // the dense layers + sigmoid of the last stage when its aggregates are ready (compact-table plan)
 hipError_t launch_dense_sigmoid(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *in, float *out,
                                 float *logits, uint32_t row_lo, uint32_t row_hi, const float *acc4, const uint32_t *c4desc,

@@ -26,6 +26,22 @@ namespace gnnvc {
 
 namespace {
 
+#ifndef GNNVC_PHASE_PROBE
+#define GNNVC_PHASE_PROBE 0
+#endif
+#if GNNVC_PHASE_PROBE
+// (experiment builds only: scratch/experiments/phase_probe.py) a wave's first lane stamps the 100 MHz wall clock at the phases of a tile
+__device__ unsigned long long *gnnvc_probe_buf = nullptr;
+__device__ int gnnvc_probe_kind = 0;
+__device__ __forceinline__ void probe_mark(int kind, int phase) {
+    if (gnnvc_probe_buf && gnnvc_probe_kind == kind && (threadIdx.x & 63) == 0)
+        gnnvc_probe_buf[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + phase] = wall_clock64();
+}
+#define GNNVC_PROBE(kind, phase) probe_mark(kind, phase)
+#else
+#define GNNVC_PROBE(kind, phase) ((void)0)
+#endif
+
 constexpr int kWave = 64;
 constexpr int kBlock = 256;              // 4 waves, each wave owns one 64-vertex tile
 constexpr int kWavesPerBlock = kBlock / kWave;
@@ -299,9 +315,11 @@ __device__ __forceinline__ void mfma_tail(f32x16 (&d)[2], const float *__restric
 typedef float c4row __attribute__((ext_vector_type(4)));
 constexpr int kEmitSlots = 64, kEmitStride = 17;
 
-__device__ __forceinline__ void c4_emit(const float *trow, uint32_t nz, uint32_t u, bool mine, int lane,
-                                        const uint32_t *__restrict__ spec, c4row *__restrict__ table,
-                                        unsigned long long *__restrict__ counts) {
+// (the spec words as values: a kernel that loads them when it starts has them in scalar registers by the time its epilogue runs —
+// read there, behind the dense layers, the two dependent scalar loads are a microsecond or two on every wave's critical path)
+__device__ __forceinline__ void c4_emit_with(const float *trow, uint32_t nz, uint32_t u, bool mine, int lane, uint32_t spec_ok,
+                                             uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3, c4row *__restrict__ table,
+                                             unsigned long long *__restrict__ counts) {
     uint32_t my = 0;
 #pragma unroll
     for (int cidx = 0; cidx < 16; ++cidx) {
@@ -311,14 +329,25 @@ __device__ __forceinline__ void c4_emit(const float *trow, uint32_t nz, uint32_t
     const uint32_t rows = (uint32_t)__popcll(__ballot(mine));
     if (lane == 16) my = rows;
     if (lane <= 16 && my) atomicAdd(&counts[(blockIdx.x & (kEmitSlots - 1)) * kEmitStride + lane], (unsigned long long)my);
-    if (spec[0] == 1u && mine) {   // (a plan of several passes writes its tables in k_c4_compact)
-        const uint32_t s0 = spec[1], s1 = spec[2], s2 = spec[3], s3 = spec[4];
+    if (spec_ok == 1u && mine) {   // (a plan of several passes writes its tables in k_c4_compact)
         const float a = trow[s0], b = trow[s1], c = trow[s2], d = trow[s3];
         c4row out = {a == 0.0f ? 0.0f : a, b == 0.0f ? 0.0f : b, c == 0.0f ? 0.0f : c, d == 0.0f ? 0.0f : d};
-        if (nz & ~((1u << s0) | (1u << s1) | (1u << s2) | (1u << s3)))
+        // (a value that is not >= 0 — a NaN, or a negative one if the producer ever ends in something else than a ReLU — cannot lend
+        // its sign bit: the vertex is flagged in BOTH of the first two values, and a consumer that wants a flagged vertex's table
+        // values — k_stage_t4 — takes such a row's neighbours from the full rows)
+        const bool odd = !(a >= 0.0f) || !(b >= 0.0f) || !(c >= 0.0f) || !(d >= 0.0f);
+        if (odd || (nz & ~((1u << s0) | (1u << s1) | (1u << s2) | (1u << s3))))
             out[0] = __uint_as_float(__float_as_uint(out[0]) | 0x80000000u);   // stray non-zeros: flag the vertex
+        if (odd) out[1] = __uint_as_float(__float_as_uint(out[1]) | 0x80000000u);
         table[u] = out;
     }
+}
+__device__ __forceinline__ void c4_emit(const float *trow, uint32_t nz, uint32_t u, bool mine, int lane,
+                                        const uint32_t *__restrict__ spec, c4row *__restrict__ table,
+                                        unsigned long long *__restrict__ counts) {
+    const uint32_t ok = spec[0];
+    c4_emit_with(trow, nz, u, mine, lane, ok, ok == 1u ? spec[1] : 0u, ok == 1u ? spec[2] : 0u, ok == 1u ? spec[3] : 0u,
+                 ok == 1u ? spec[4] : 0u, table, counts);
 }
 
 // AGGONLY (compact-table plan): every row's aggregate arrives ready-made — four sums in acc4 for clean rows, the
@@ -347,6 +376,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
         const uint32_t *__restrict__ srt_vertex_p = nullptr, const uint4 *__restrict__ srt_meta_p = nullptr, uint32_t n_sorted_p = 0) {
     __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kRegionFloats];
     const int lane = threadIdx.x & 63;
+    GNNVC_PROBE((SIGMOID ? 2 : 1), 0);
     float *T = lds[threadIdx.x >> 6];
     uint32_t *stage = reinterpret_cast<uint32_t *>(T);
     if constexpr (AGGONLY) {
@@ -478,6 +508,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
                 acc[p] = agg16[(size_t)__float_as_uint(a0[p].y) * 4 + c];
     }
     wave_lds_sync();            // staged indices visible to the whole wave
+    GNNVC_PROBE((SIGMOID ? 2 : 1), 2);
 
     // ---- gather: neighbour rows summed in CSR order, S rows per vertex in flight
     if constexpr (!AGGONLY) {
@@ -524,6 +555,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     }
     }
 
+    GNNVC_PROBE((SIGMOID ? 2 : 1), 3);
     // ---- hand over through the LDS tile: 64 rows x 32 inputs in k order
     wave_lds_sync();  // every lane is done with the index stage before it is overwritten
 #pragma unroll
@@ -605,6 +637,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
         }
     }
 
+    GNNVC_PROBE((SIGMOID ? 2 : 1), 6);
     if constexpr (!SIGMOID) {
         static_assert(N3 == 16, "feature stages emit 16 floats per vertex");
         // the 64 x 16 output tile sits in LDS: every global store instruction writes 16 full rows
@@ -616,6 +649,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
             if (okrow[p]) reinterpret_cast<float4 *>(fout)[(size_t)urow[p] * 4 + c] = o;
         }
     }
+    GNNVC_PROBE((SIGMOID ? 2 : 1), 7);
 }
 
 // ------------------------------------------------------------------ dense-only sigmoid stage (no LDS)
@@ -767,6 +801,361 @@ __global__ __launch_bounds__(kBlock) void k_dense_f16(GraphDev g, float ws, cons
             if (__shfl((int)mine, src_lane)) reinterpret_cast<float4 *>(fout)[(size_t)row * 4 + c] = o;
         }
     }
+}
+
+// ------------------------------------------------------------------ 16-wide stage from an L2-resident compact table
+// (round 4; VERDICT r3 #3 — BASELINE configs[1], Erdős–Rényi 100 K / 1 M.)  A graph of 50 - 400 K vertices is too small for
+// the compact-table PLAN (its regrouped entries and block sweeps pay from 2^18 vertices and 8 Mi entries on) and too large for
+// its 64-byte feature rows to sit in an XCD's 4 MiB L2 (100 K vertices: 6.4 MB): the gathering tile kernel runs at the fabric's
+// rate of line requests (2 M entries a stage at ~60 G/s: 31 of the forward's 93 us per 16-wide stage).  The compact table of
+// such a graph — the four live columns, 16 bytes a vertex: 1.6 MB — DOES fit every L2, so a tile kernel that gathers table rows
+// instead of feature rows is served by L2 hits, with no plan at all: one lane per vertex, S neighbours' 16-byte rows in flight,
+// their four values added in stored order (the plain gather's order, column by column); a neighbour whose table row carries the
+// flag "has non-zeros in other columns" makes the row DIRTY and the lane re-gathers that row's full 64-byte rows (rare); the
+// dense layers as in k_dense_f16 (routes A / B / C).  Who writes the table: the kernel that PRODUCES the stage's input (c4_emit:
+// the F = 1 stage's VALU epilogue, or this kernel's own epilogue for the next stage — into a SECOND table, since its other
+// workgroups are still gathering from the first), for the columns the previous forward chose; every workgroup re-derives this
+// forward's choice from the producer's counters (the arithmetic of k_c4_choose, one table) and runs only if the table in place
+// was written for exactly those columns — otherwise it leaves at once and the gathering kernel launched behind it (which
+// leaves at once when this one ran: *fit) does the stage.  A graph's first forward therefore gathers the plain way (nobody has
+// chosen columns yet) and the steady state takes the table: this is for graphs that are scored again and again.
+// desc_in = this stage's descriptor as the producer saw it ([0] = 1: a table was written for columns [1..4]); desc_out (another
+// buffer: nobody may still be reading what block 0 writes) = this forward's choice, the next forward's spec; desc_out[8] = fit.
+struct T4Choice {
+    uint32_t fit, d0, d1, d2, d3;
+};
+__device__ __forceinline__ T4Choice t4_choose(const unsigned long long *__restrict__ counts, uint32_t n, const uint32_t *__restrict__ desc_in,
+                                              uint32_t *__restrict__ desc_out, int lane, bool write) {
+    // lane i < 17 ends up with the total of counter i (16 columns + the rows seen), as in k_c4_choose
+    unsigned long long part[kEmitStride], mine = 0;
+#pragma unroll
+    for (int t = 0; t < kEmitStride; ++t) part[t] = counts[t * 64 + lane];
+    for (int c = 0; c < kEmitStride; ++c) {
+        unsigned long long v = 0;
+#pragma unroll
+        for (int t = 0; t < kEmitStride; ++t) v += ((t * 64 + lane) % kEmitStride == c) ? part[t] : 0ull;
+#pragma unroll
+        for (int off = 32; off; off >>= 1)
+            v += ((unsigned long long)__shfl_xor((unsigned)(v >> 32), off) << 32) | __shfl_xor((unsigned)v, off);
+        if (lane == c) mine = v;
+    }
+    const unsigned long long rows = ((unsigned long long)__shfl((unsigned)(mine >> 32), 16) << 32) | __shfl((unsigned)mine, 16);
+    const bool prev_ok = desc_in[0] == 1u && rows == n;   // (the tiles' own test)
+    const uint32_t p1 = desc_in[1], p2 = desc_in[2], p3 = desc_in[3], p4 = desc_in[4];
+    T4Choice r = {0u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    uint32_t np = 0;
+    if (rows == n) {
+        const unsigned long long c = lane < 16 ? mine : 0ull;
+        uint32_t rank = 0;   // how many columns are fuller than column `lane` (ties: lowest index first)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const unsigned long long ck = ((unsigned long long)__shfl((unsigned)(c >> 32), k) << 32) | __shfl((unsigned)c, k);
+            rank += (ck > c || (ck == c && k < lane)) ? 1u : 0u;
+        }
+        unsigned long long rest = (lane < 16 && rank >= 4u) ? c : 0ull;
+#pragma unroll
+        for (int off = 8; off; off >>= 1)
+            rest += ((unsigned long long)__shfl_xor((unsigned)(rest >> 32), off) << 32) | __shfl_xor((unsigned)rest, off);
+        rest = ((unsigned long long)__shfl((unsigned)(rest >> 32), 0) << 32) | __shfl((unsigned)rest, 0);
+        if (rest <= (unsigned long long)n / 512) np = 1;
+        const unsigned long long cm = np ? __ballot(lane < 16 && rank < 4u) : 0ull;
+        const uint32_t m0 = (uint32_t)cm, m1 = m0 & (m0 - 1), m2 = m1 & (m1 - 1), m3 = m2 & (m2 - 1);
+        r.d0 = m0 ? (uint32_t)__builtin_ctz(m0) : 0xFFFFFFFFu;
+        r.d1 = m1 ? (uint32_t)__builtin_ctz(m1) : 0xFFFFFFFFu;
+        r.d2 = m2 ? (uint32_t)__builtin_ctz(m2) : 0xFFFFFFFFu;
+        r.d3 = m3 ? (uint32_t)__builtin_ctz(m3) : 0xFFFFFFFFu;
+        r.fit = (np == 1u && prev_ok && p1 == r.d0 && p2 == r.d1 && p3 == r.d2 && p4 == r.d3) ? 1u : 0u;
+    }
+    if (write && lane == 0) {
+        desc_out[0] = np;
+        desc_out[1] = r.d0; desc_out[2] = r.d1; desc_out[3] = r.d2; desc_out[4] = r.d3;
+        desc_out[5] = 0; desc_out[6] = 0; desc_out[7] = 0;
+        desc_out[8] = prev_ok ? 1u : 0u;   // what this launch's tiles did (the gathering kernel behind a non-solo launch skips on it)
+    }
+    return r;
+}
+
+template <int N1, int N2, int N3, bool SIGMOID, int S>
+__global__ __launch_bounds__(kBlock) void k_stage_t4(GraphDev g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
+                                                     float *__restrict__ logits, const float *__restrict__ P, uint32_t row_lo,
+                                                     uint32_t row_hi, int interleave, const float4 *__restrict__ table_in,
+                                                     const unsigned long long *__restrict__ counts_in,
+                                                     unsigned long long *__restrict__ counts_zero,
+                                                     const uint32_t *__restrict__ desc_in, uint32_t *__restrict__ desc_out,
+                                                     const uint32_t *__restrict__ emit_spec, c4row *__restrict__ emit_table,
+                                                     unsigned long long *__restrict__ emit_counts, int solo) {
+    // solo: no gathering kernel was launched behind this one (the host saw the previous forward fit and saves the ~6 us an
+    // empty launch of that grid costs): if the table does NOT fit this forward after all, every row goes the way dirty rows and
+    // stray vertices go — full rows, lane by lane: slow, rare, and the same bits
+    static_assert(SIGMOID ? N3 == 1 : N3 == 16, "a feature stage writes 16 floats per row, the last stage one score");
+    // (Half tiles — 32 vertices a wave, twice the waves — were built and measured: the gather phase takes the same 9 us, it is bound by
+    // the CU's L2 -> L1 line fills, not by a wave's chain; ER-100K 87 us against 81.)
+    __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kRegionFloats];
+    const int lane = threadIdx.x & 63;
+    GNNVC_PROBE((SIGMOID ? 12 : 11), 0);
+    if (blockIdx.x + 1u == gridDim.x) {
+        // the launch's LAST workgroup has no tile: it makes this input's choice of columns — what the producers of the NEXT forward
+        // write their tables for — while the others work.  (Every workgroup used to re-derive the choice first and run only if
+        // the table in place was written for exactly those columns: 8 of a tile's 28 us on ER-100K, scratch/experiments/
+        // phase_probe.py.  Nothing needs that: whatever columns the table holds, a vertex with non-zeros elsewhere is flagged and
+        // a row that meets one is summed from full rows — the choice only decides how FEW such rows there are.)
+        if (threadIdx.x < 64) t4_choose(counts_in, g.n, desc_in, desc_out, lane, true);
+        // ... and clears the counters the NEXT forward's producer of this stage's input adds to (the set this forward's producer
+        // used is still being read by the other workgroups; the two alternate with the descriptors — no memset between kernels,
+        // which cost 5 us of stream time apiece)
+        for (int i = threadIdx.x; i < kEmitSlots * kEmitStride; i += kBlock) counts_zero[i] = 0ull;
+        return;
+    }
+    // The stage's parameters (2 736 floats) go through LDS, fetched once per workgroup with coalesced loads while the tiles'
+    // prologues run: a mid-size graph has a wave or two per SIMD, a tile's chain of latencies IS the kernel, and 88 strided
+    // 4-byte loads per lane for the matrix cores' A operands and biases were 2.5 us of it wherever they were put (in front of
+    // their layers, or first of all — in front of everything else in the in-order load queue).
+    static_assert(N1 == 32, "layer-2 input is a full 32-feature tile");
+    constexpr int kParams = 35 * N1 + N1 + N1 * N2 + N2 + N2 * N3 + N3;
+    constexpr int kParamLoads = (kParams + kBlock - 1) / kBlock;
+    __shared__ float wl[kParams];
+    float pw[kParamLoads];
+#pragma unroll
+    for (int i = 0; i < kParamLoads; ++i) {
+        const int at = i * kBlock + (int)threadIdx.x;
+        pw[i] = at < kParams ? P[at] : 0.0f;
+    }
+    const float *W1 = wl, *b1 = W1 + 35 * N1;
+    const float *W2 = b1 + N1, *b2 = W2 + N1 * N2;
+    const float *W3 = b2 + N2, *b3 = W3 + N2 * N3;
+    const int mv = lane & 31, mh = lane >> 5;
+    // the table in place is this input's: the producer was told to write it (for columns desc_in[1..4]) AND its counters say that
+    // it has written all n rows (a producing kernel that does not emit leaves them short: the stage then gathers the plain way)
+    uint32_t seen = (uint32_t)counts_in[lane * kEmitStride + 16];
+#pragma unroll
+    for (int off = 32; off; off >>= 1) seen += __shfl_xor(seen, off);
+    const bool fit = desc_in[0] == 1u && seen == g.n;
+    GNNVC_PROBE((SIGMOID ? 12 : 11), 1);
+    if (!fit && !solo) return;     // uniform: the gathering kernel behind this one has the launch
+    const uint32_t d0 = desc_in[1], d1 = desc_in[2], d2 = desc_in[3], d3 = desc_in[4];
+    uint32_t es_ok = 0, es0 = 0, es1 = 0, es2 = 0, es3 = 0;   // what THIS kernel's epilogue writes for the next stage (loaded now: c4_emit_with)
+    if (!SIGMOID && emit_counts) {
+        es_ok = emit_spec[0];
+        if (es_ok == 1u) { es0 = emit_spec[1]; es1 = emit_spec[2]; es2 = emit_spec[3]; es3 = emit_spec[4]; }
+    }
+    float *T = lds[threadIdx.x >> 6];
+    uint32_t *stage = reinterpret_cast<uint32_t *>(T);
+    const uint32_t ntiles = (row_hi - row_lo + kWave - 1) / kWave;
+    const uint32_t tile_w = tile_for_wave(ntiles, interleave != 0);
+    const bool has_tile = tile_w < ntiles;            // (a wave without one still brings its share of the parameters)
+    const uint32_t tile = has_tile ? tile_w : 0u;
+    const uint32_t v0 = row_lo + tile * kWave;
+    const uint32_t uu = v0 + lane;
+    const bool mine = has_tile && uu < row_hi;
+    const uint32_t u = mine ? uu : row_hi - 1;
+    const uint32_t rs = g.rowptr[u], re = mine ? g.rowptr[u + 1] : rs;
+    const uint32_t deg = g.rowptr[u + 1] - g.rowptr[u];
+    // the tile's slice of col, staged in LDS with full-line loads (as the gathering tile kernels do)
+    const uint32_t c0 = __builtin_amdgcn_readfirstlane(g.rowptr[v0]);
+    const uint32_t vend = (v0 + kWave < row_hi) ? v0 + kWave : row_hi;
+    const uint32_t c1 = g.rowptr[vend];
+    const bool staged = (c1 - c0) <= kStageCap;
+    uint32_t sbase = 0;
+    if (staged) sbase = stage_cols(g.col, c0, c1, stage, lane);
+#pragma unroll
+    for (int i = 0; i < kParamLoads; ++i) {
+        const int at = i * kBlock + (int)threadIdx.x;
+        if (at < kParams) wl[at] = pw[i];
+    }
+    __syncthreads();
+    if (!has_tile) return;
+    const float4 t = fit ? table_in[u] : make_float4(-0.0f, 0.f, 0.f, 0.f);   // this vertex's own values in the table's columns
+    const bool stray = (__float_as_uint(t.x) >> 31) != 0;      // ... and whether it has non-zeros elsewhere (no table: as if)
+    const float f_deg = (float)deg, f_w = (float)g.w[u] / ws, f_nw = (float)g.nw[u] / ws;
+    wave_lds_sync();
+    GNNVC_PROBE((SIGMOID ? 12 : 11), 2);
+    const uint32_t zrow = g.n;                                 // table row n: zeros
+    c4row acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    // A neighbour whose table row is FLAGGED has non-zeros outside the table's columns.  Its four table values are still exact
+    // (they are >= 0: the flag sits in the first one's sign bit and is stripped before the add), so the row's four table sums
+    // stand; what is missing are its sums in the OTHER columns, and only flagged neighbours contribute to those — x + (+-0) == x
+    // and the sums start at +0: leaving the others out changes no bit.  So a lane notes the (up to two) flagged neighbours it met
+    // and afterwards adds their full rows' other columns, in stored order: one round of loads for the one row in three hundred
+    // that meets one, instead of the row's whole plain gather (which held one wave in five for 6 us at the end of the launch).
+    // A row that met three or more, or a neighbour flagged in its SECOND value too (a value that cannot lend its sign bit, see
+    // c4_emit_with), is summed from the full rows by the whole wave as before.
+    uint32_t nflag = 0, f1st = zrow, f2nd = zrow;
+    bool full = false;
+    for (uint32_t eb = rs; fit && eb < re; eb += S) {
+        c4row tv[S];
+        uint32_t id[S];
+#pragma unroll
+        for (int s2 = 0; s2 < S; ++s2) {
+            const uint32_t ee = eb + s2;
+            const uint32_t cv = staged ? stage[ee - sbase] : g.col[ee];
+            id[s2] = (ee < re) ? cv : zrow;
+            tv[s2] = reinterpret_cast<const c4row *>(table_in)[id[s2]];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < S; ++s2) {
+            const bool fl = (__float_as_uint(tv[s2][0]) >> 31) != 0;
+            full |= (__float_as_uint(tv[s2][1]) >> 31) != 0;
+            if (fl) {
+                f2nd = nflag == 1u ? id[s2] : f2nd;
+                f1st = nflag == 0u ? id[s2] : f1st;
+                ++nflag;
+            }
+            acc[0] += __builtin_fabsf(tv[s2][0]);
+            acc[1] += tv[s2][1];
+            acc[2] += tv[s2][2];
+            acc[3] += tv[s2][3];
+        }
+    }
+    full |= nflag > 2u;
+    const bool part = !full && nflag != 0u;
+    GNNVC_PROBE((SIGMOID ? 12 : 11), 3);
+    float gg[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) gg[k] = 0.0f;
+    if (!fit) {
+        // (uniform) a solo launch whose table is not there after all — the input changed character since the verdict the host
+        // went by: every lane sums its own row from the full rows, neighbour by neighbour.  Slow (a tile takes as long as its
+        // longest row's chain of 64-byte fetches), correct, and over as soon as the host sees this forward's verdict.
+        for (uint32_t e2 = rs; e2 < re; ++e2) {
+            const uint32_t cv = staged ? stage[e2 - sbase] : g.col[e2];
+            const float4 r0 = fin[(size_t)cv * 4], r1 = fin[(size_t)cv * 4 + 1], r2 = fin[(size_t)cv * 4 + 2], r3 = fin[(size_t)cv * 4 + 3];
+            gg[0] += r0.x; gg[1] += r0.y; gg[2] += r0.z; gg[3] += r0.w;
+            gg[4] += r1.x; gg[5] += r1.y; gg[6] += r1.z; gg[7] += r1.w;
+            gg[8] += r2.x; gg[9] += r2.y; gg[10] += r2.z; gg[11] += r2.w;
+            gg[12] += r3.x; gg[13] += r3.y; gg[14] += r3.z; gg[15] += r3.w;
+        }
+    }
+    if (part) {   // (divergent: the few lanes with such a row)
+        const float4 *r1 = fin + (size_t)f1st * 4, *r2 = fin + (size_t)f2nd * 4;   // (f2nd = the zero row when there is no second)
+        const float4 p0 = r1[0], p1 = r1[1], p2 = r1[2], p3 = r1[3], q0 = r2[0], q1 = r2[1], q2 = r2[2], q3 = r2[3];
+        const float pa[16] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w, p3.x, p3.y, p3.z, p3.w};
+        const float qa[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) gg[k] = (0.0f + pa[k]) + qa[k];   // (the table's own columns are overwritten with acc below)
+    }
+    // a row for the full way: its sixteen sums from the full rows, in stored order (the plain gather of that row), by the WAVE:
+    // lane 16 j + c fetches column c of the row's neighbours e + j, e + 4 + j, ... — 32 neighbours' rows in flight — and lane c
+    // adds them in stored order
+    for (unsigned long long left = __ballot(full); left; left &= left - 1) {
+        const int L = __ffsll((long long)left) - 1;
+        const uint32_t drs = (uint32_t)__shfl((int)rs, L), dre = (uint32_t)__shfl((int)re, L);
+        const int j = lane >> 4, cc = lane & 15;
+        const float *__restrict__ fsc = reinterpret_cast<const float *>(fin);
+        float a = 0.0f;
+        for (uint32_t e0 = drs; e0 < dre; e0 += 32) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t ea = e0 + 4 * k + j;
+                const uint32_t cv = ea < dre ? (staged ? stage[ea - sbase] : g.col[ea]) : zrow;   // (row n of the features: zeros)
+                v[k] = fsc[(size_t)cv * 16 + cc];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) a += __shfl(v[k], 16 * jj + cc);   // (lanes 0..15 hold the row's sums; a slot past the end adds +0)
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float sk = __shfl(a, k);
+            if (lane == L) gg[k] = sk;
+        }
+    }
+    GNNVC_PROBE((SIGMOID ? 12 : 11), 4);
+    // ---- the first layer's 32 inputs of this lane's vertex, in k order, into the wave's LDS tile: 0..15 the sums (four table
+    // columns, or a dirty row's sixteen), 16 = h[0], 17 = degree, 18 = W/ws, 19 = NW/ws, 20..31 = h[4..15].  The vertex's own
+    // values come from its table row — a vertex that is not flagged has nothing outside the table's columns — or, flagged (or no
+    // table), from its full row.
+    float4 h0 = make_float4(0.f, 0.f, 0.f, 0.f), h1 = h0, h2 = h0, h3 = h0;
+    if (stray) {
+        h0 = fin[(size_t)u * 4]; h1 = fin[(size_t)u * 4 + 1]; h2 = fin[(size_t)u * 4 + 2]; h3 = fin[(size_t)u * 4 + 3];
+    }
+    const float own_t[4] = {__uint_as_float(__float_as_uint(t.x) & 0x7FFFFFFFu), t.y, t.z, t.w};
+    const float own_f[16] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z, h2.w, h3.x, h3.y, h3.z, h3.w};
+    wave_lds_sync();       // the index stage is dead: the region becomes the input tile (row = vertex, column = k)
+    {
+        float *row = &T[lane * kInPitch];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            // a table column's sum from acc (unless the row went the full way), any other column's from the flagged neighbours (+0 if none)
+            const float v = ((uint32_t)k == d0) ? acc[0] : ((uint32_t)k == d1) ? acc[1] : ((uint32_t)k == d2) ? acc[2] : ((uint32_t)k == d3) ? acc[3] : gg[k];
+            row[k] = (full || !fit) ? gg[k] : v;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (k >= 1 && k <= 3) continue;   // h[1..3]: overwritten by degree / weights in the reference's layout
+            const float tab = ((uint32_t)k == d0) ? own_t[0] : ((uint32_t)k == d1) ? own_t[1] : ((uint32_t)k == d2) ? own_t[2] : ((uint32_t)k == d3) ? own_t[3] : 0.0f;
+            row[16 + k] = stray ? own_f[k] : tab;
+        }
+        row[17] = f_deg; row[18] = f_w; row[19] = f_nw;
+    }
+    wave_lds_sync();
+    GNNVC_PROBE((SIGMOID ? 12 : 11), 5);
+    // ---- the dense layers on the matrix cores (k-ordered fma chains: the VALU's bits), A operands fetched before the gather
+    f32x16 d[2];
+    {
+        float a1[16];
+        mfma_load_a<N1, 16>(W1, mv, mh, a1);   // rows 0..31 of W1; rows 32..34 meet exact zeros
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt) {
+            d[vt] = mfma_layer_lds(T, vt, mv, mh, a1);
+            mfma_bias_act<N1, 0>(d[vt], b1, mh);
+        }
+    }
+    {
+        float a2[16];
+        mfma_load_a<N2, 16>(W2, mv, mh, a2);
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt) {
+            d[vt] = mfma_layer_acc<32>(d[vt], a2);
+            mfma_bias_act<N2, 0>(d[vt], b2, mh);
+        }
+    }
+    GNNVC_PROBE((SIGMOID ? 12 : 11), 6);
+    if constexpr (SIGMOID) {
+        static_assert(N2 == 16 && N3 == 1, "sigmoid tail is 16 -> 1");
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt) {
+            const float logit = mfma_tail_16to1(d[vt], W3, mh) + b3[0];   // (valid on the high half lane of vertex 32 vt + v)
+            const uint32_t uv = __shfl(u, 32 * vt + mv);
+            const int keep = __shfl((int)mine, 32 * vt + mv);
+            if (mh == 1 && keep) {
+                if (logits) logits[uv] = logit;
+                fout[uv] = sigmoid_ref(logit);
+            }
+        }
+    } else {
+        float a3[16];
+        mfma_load_a<N3, N2 / 2>(W3, mv, mh, a3);
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt) {
+            d[vt] = mfma_layer_acc<N2>(d[vt], a3);
+            mfma_bias_act<N3, 0>(d[vt], b3, mh);
+        }
+        GNNVC_PROBE((SIGMOID ? 12 : 11), 8);
+        wave_lds_sync();   // the input tile is consumed: the region becomes the output tile
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) T[(32 * vt + mv) * kOutPitch + mfma_feat(r, mh)] = d[vt][r];
+        wave_lds_sync();
+        uint32_t nz = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) nz |= (T[lane * kOutPitch + j] != 0.0f ? 1u : 0u) << j;
+        GNNVC_PROBE((SIGMOID ? 12 : 11), 9);
+        if (emit_counts) c4_emit_with(&T[lane * kOutPitch], nz, u, mine, lane, es_ok, es0, es1, es2, es3, emit_table, emit_counts);
+        GNNVC_PROBE((SIGMOID ? 12 : 11), 10);
+        const int q = lane >> 2, c = lane & 3;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int src_lane = 16 * p + q;
+            const float *src = &T[src_lane * kOutPitch + 4 * c];
+            const float4 o = make_float4(src[0], src[1], src[2], src[3]);
+            const uint32_t row = __shfl(u, src_lane);
+            if (__shfl((int)mine, src_lane)) reinterpret_cast<float4 *>(fout)[(size_t)row * 4 + c] = o;
+        }
+    }
+    GNNVC_PROBE((SIGMOID ? 12 : 11), 11);
 }
 
 // ------------------------------------------------------------------ stage, F = 1
@@ -3948,6 +4337,35 @@ int stage_variant(int f, int n1, int n2, int n3, int sigmoid_last) {
     return -1;
 }
 
+// a 16-wide stage from the L2-resident compact table (k_stage_t4); it leaves at once unless the table in place fits this input
+#ifndef GNNVC_T4_S
+#define GNNVC_T4_S 4   // neighbours' table rows in flight per vertex
+#endif
+hipError_t launch_stage_t4(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *in, float *out, float *logits,
+                           uint32_t row_lo, uint32_t row_hi, bool interleave, hipStream_t stream, const float *table_in,
+                           const unsigned long long *counts_in, unsigned long long *counts_zero, const uint32_t *desc_in, uint32_t *desc_out,
+                           const EmitArgs &emit, bool solo) {
+    if (row_hi <= row_lo) return hipSuccess;
+    if (sp.f != 16 || (sp.variant != 1 && sp.variant != 2) || !table_in || !counts_in || !counts_zero || counts_zero == counts_in || !desc_in ||
+        !desc_out || desc_in == desc_out)
+        return hipErrorInvalidValue;
+    const uint32_t ntiles = (row_hi - row_lo + kWave - 1) / kWave;
+    const uint32_t per_xcd = (ntiles + 7) / 8;
+    const uint32_t blocks_per_xcd = (per_xcd + kWavesPerBlock - 1) / kWavesPerBlock;
+    const dim3 grid(blocks_per_xcd * 8 + 1), block(kBlock);   // (+ 1: the workgroup that chooses)
+    const float *P = params + sp.param_offset;
+    const float4 *in4 = reinterpret_cast<const float4 *>(in), *tab = reinterpret_cast<const float4 *>(table_in);
+    if (sp.variant == 1)
+        GNNVC_LAUNCH((k_stage_t4<32, 32, 16, false, GNNVC_T4_S>), grid, block, 0, stream, g, ws, in4, out, (float *)nullptr, P, row_lo, row_hi,
+                     interleave ? 1 : 0, tab, counts_in, counts_zero, desc_in, desc_out, emit.spec, reinterpret_cast<c4row *>(emit.table),
+                     emit.counts, solo ? 1 : 0);
+    else
+        GNNVC_LAUNCH((k_stage_t4<32, 16, 1, true, GNNVC_T4_S>), grid, block, 0, stream, g, ws, in4, out, logits, P, row_lo, row_hi,
+                     interleave ? 1 : 0, tab, counts_in, counts_zero, desc_in, desc_out, (const uint32_t *)nullptr, (c4row *)nullptr,
+                     (unsigned long long *)nullptr, solo ? 1 : 0);
+    return hipGetLastError();
+}
+
 // the dense layers + sigmoid of the last stage when its aggregates are ready (compact-table plan): rows [row_lo, row_hi)
 hipError_t launch_dense_sigmoid(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *in, float *out,
                                 float *logits, uint32_t row_lo, uint32_t row_hi, const float *acc4, const uint32_t *c4desc,
@@ -3966,7 +4384,8 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
                         const float *in, float *out, float *logits, uint32_t row_lo,
                         uint32_t row_hi, uint32_t long_thresh, bool mfma, const SortedOrder *so,
                         bool interleave, hipStream_t stream, const float *acc4, const uint32_t *c4desc, const float *agg16,
-                        bool mfma_agg, const EmitArgs &emit, bool dense_part, const SortedOrder *so_pruned, const float *table_in) {
+                        bool mfma_agg, const EmitArgs &emit, bool dense_part, const SortedOrder *so_pruned, const float *table_in,
+                        const uint32_t *skip_flag) {
     if (row_hi <= row_lo) return hipSuccess;
     const bool sorted = so && so->n > 0;
     const bool with_p = sorted && g.prune_eff && so_pruned && so_pruned->vertex;
@@ -4009,7 +4428,7 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
                        grid, block, 0, stream, g, ws, in4, out,                                                           \
                        LG_, P, row_lo, row_hi, long_thresh, sorted ? so->vertex : nullptr,                                \
                        sorted ? so->meta : nullptr, sorted ? so->n : 0u, il,                                              \
-                       (const float4 *)nullptr, acc4 ? c4desc : nullptr, (const float4 *)nullptr,                         \
+                       (const float4 *)nullptr, acc4 ? c4desc : skip_flag, (const float4 *)nullptr,                       \
                        (MF_ || SIG_) ? nullptr : emit.spec, reinterpret_cast<c4row *>((MF_ || SIG_) ? nullptr : emit.table), \
                        (MF_ || SIG_) ? nullptr : emit.counts,                                                             \
                        with_p ? so_pruned->vertex : nullptr, with_p ? so_pruned->meta : nullptr, n_p
@@ -4863,3 +5282,11 @@ hipError_t launch_zero_pad_row(float *buf, uint32_t n, uint32_t width, hipStream
 }
 
 }  // namespace gnnvc
+
+#if GNNVC_PHASE_PROBE
+extern "C" int gnnvc_debug_probe(void *buf, int kind) {
+    if (hipMemcpyToSymbol(HIP_SYMBOL(gnnvc::gnnvc_probe_buf), &buf, sizeof buf) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(gnnvc::gnnvc_probe_kind), &kind, sizeof kind) != hipSuccess) return -2;
+    return 0;
+}
+#endif

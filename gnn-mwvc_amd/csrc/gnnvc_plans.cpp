@@ -1115,8 +1115,49 @@ int ensure_events(gnnvc_engine *e, size_t count) {
 // What a forward needs that depends on the GRAPH alone, made when the graph is handed over (round 3): the
 // reference's driver scores every graph once (src/GNN_VC.cpp:171-192), and a plan built inside a later forward never
 // serves such a caller.  Runs behind find_long (which classed the graph) on the engine's stream; complete when it returns.
+// Table tiles (k_stage_t4): which graphs, and their buffers.  Nothing is built: the tables are written by the forwards' own
+// kernels; the graph only has to be of the size where a 16-byte-per-vertex table fits an L2 and 64-byte rows do not, degree-uniform
+// (no long rows, natural tiles) and outside the compact-table plan's range.
+int prepare_table_tiles(gnnvc_engine *e) {
+    e->t4_ok = false;
+    e->t4_unfit_runs = 0;
+    e->t4_used = false;
+    for (bool &b : e->t4_fit_seen) b = false;
+    const GraphDev &g = e->g;
+    if (!e->opt_t4 || !e->opt_compact || e->opt_mfma == 1 || e->stages.size() != 3 || g.n == 0 || e->empty_slice || g.sliced()) return GNNVC_OK;
+    if (e->stages[0].variant != 0 || e->stages[1].variant != 1 || e->stages[2].variant != 2) return GNNVC_OK;
+    if (e->n_long > 0 || e->sorted_wanted || g.nnz == 0) return GNNVC_OK;
+    if (g.n < e->opt_t4_min_n || ((uint64_t)g.n + 1) * 16 > e->opt_t4_max_bytes) return GNNVC_OK;
+    const bool plan_range = g.n >= std::min(e->opt_blocked_min_n, e->opt_compact_min_n) &&
+                            (e->opt_blocked_min_n < (1u << 20) || g.nnz >= e->opt_compact_min_nnz);
+    if (plan_range) return GNNVC_OK;   // (the compact-table plan has these graphs)
+    for (auto &t : e->t4_table) {
+        HIP_TRY(e, t.reserve(((size_t)g.n + 1) * 4));
+        HIP_TRY(e, hipMemsetAsync(t.p, 0, ((size_t)g.n + 1) * 4 * sizeof(float), e->stream));   // (row n: the zero row padded slots read)
+    }
+    for (auto &c : e->t4_counts) {
+        HIP_TRY(e, c.reserve(2 * gnnvc::kEmitCounters));
+        HIP_TRY(e, hipMemsetAsync(c.p, 0, 2 * gnnvc::kEmitCounters * sizeof(unsigned long long), e->stream));
+    }
+    // The CHOICE of columns survives a change of graph: the reference's driver scores every graph once (src/GNN_VC.cpp:171-192), its
+    // graphs are shrinking versions of one another and which columns the trained model leaves live hardly depends on the graph —
+    // so the producers of the new graph's FIRST forward write their tables for the previous graph's last choice (any choice gives
+    // the same bits: it only decides how few rows meet a flagged neighbour).  An engine's first qualifying graph starts without.
+    if (!e->t4_choice_live) {
+        HIP_TRY(e, e->t4_desc.reserve(2 * 2 * 16));
+        HIP_TRY(e, hipMemsetAsync(e->t4_desc.p, 0, 2 * 2 * 16 * sizeof(uint32_t), e->stream));
+        e->t4_parity = 0;
+    }
+    e->t4_ok = true;
+    return GNNVC_OK;
+}
+
 int prepare_plans(gnnvc_engine *e) {
     e->handoff_build_ms = 0.0;
+    {
+        const int rc = prepare_table_tiles(e);
+        if (rc) return rc;
+    }
     if (!e->opt_handoff || e->stages.empty() || e->g.n == 0 || e->empty_slice) return GNNVC_OK;
     const GraphDev &g = e->g;
     const double before = e->plan_build_ms;

@@ -1,4 +1,4 @@
-"""Randomised plan fuzz (GPU box): random small graphs x random thresholds / plan options, three forwards each, logits
+"""Randomised plan fuzz (GPU box): random small graphs x random thresholds / plan options, four forwards each, logits
 against the oracle bit for bit.  python scratch/experiments/fuzz_plans.py [cases=150] [seed0=0]"""
 import sys, pathlib, time
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
@@ -35,15 +35,13 @@ for case in range(cases):
     if rng.random() < 0.4: opts["giant_row_threshold_f16"] = int(rng.choice([64, 1000, 5000, 65536]))
     opts["giant_segments"] = int(rng.choice([-1, 0, 1]))
     opts["sorted_tiles"] = int(rng.choice([-1, 0, 1]))
-    opts["prune_zero_rows"] = int(rng.choice([0, 1, 1, 2]))
+    opts["prune_zero_rows"] = int(rng.choice([0, 1, 1]))
     opts["prune_class_by_entries_left"] = int(rng.choice([0, 1, 1]))
     opts["prune_giant_rows"] = int(rng.choice([0, 1, 1]))
     opts["prune_heavy_entries"] = int(rng.choice([1, 1 << 24]))
     opts["lds_table"] = int(rng.choice([0, 1, 1]))
     opts["lds_table_skewed_rows"] = int(rng.choice([0, 64, 512, 2048, 16384]))
     opts["compact_gather"] = int(rng.choice([0, 1, 1]))
-    opts["compact_skewed"] = int(rng.choice([0, 0, 1]))
-    opts["compact_passes"] = int(rng.choice([1, 2, 3]))
     opts["mfma_dense"] = int(rng.choice([0, 1, 2]))
     opts["overlap_dense"] = int(rng.choice([0, 1]))
     if rng.random() < 0.3: opts["plan_chunk_rows"] = int(rng.choice([16, 48, 256, 4096]))
@@ -57,6 +55,14 @@ for case in range(cases):
     opts["long_rows_on_main"] = int(rng.choice([-1, 0, 1]))
     opts["giant_gather_first"] = int(rng.choice([-1, 0, 1]))
     opts["side_streams"] = int(rng.choice([0, 1, 1, 1]))
+    # round 4: the pruned adjacency predicted at hand-off, dense layers that skip zero terms, the LDS table's entry widths, table tiles
+    opts["prune_predict"] = int(rng.choice([0, 1, 1]))
+    opts["prune_predict_min_entries"] = 0
+    opts["dense_skip_zeros"] = int(rng.choice([0, 1, 1]))
+    opts["lds_table_bits"] = int(rng.choice([0, 0, 8, 10, 16]))
+    opts["table_tiles"] = int(rng.choice([0, 1, 1]))
+    opts["table_tiles_min_n"] = int(rng.choice([0, 0, 49152]))
+    opts["table_tiles_solo"] = int(rng.choice([0, 1]))
     e = G.Engine(G.default_model_text(), device=0)
     try:
         for k, v in opts.items():
@@ -64,7 +70,7 @@ for case in range(cases):
         e.set_weight_scale(g.ws); om.set_weight_scale(g.ws)
         e.upload_graph(g)
         want = om.logits(g)
-        for rep in range(3):
+        for rep in range(4):
             _, lg = e.forward(g.x())
             if not np.array_equal(bits(lg[:, 0]), bits(want)):
                 bad += 1

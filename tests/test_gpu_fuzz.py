@@ -56,6 +56,9 @@ def _options(rng):
     o["overlap_dense"] = int(rng.choice([0, 1]))
     if rng.random() < 0.3:
         o["plan_chunk_rows"] = int(rng.choice([16, 48, 256, 4096]))
+    o["table_tiles"] = int(rng.choice([0, 1, 1]))
+    o["table_tiles_min_n"] = int(rng.choice([0, 0, 49152]))   # (0: the table tiles on these small graphs too)
+    o["table_tiles_solo"] = int(rng.choice([0, 1]))
     return o
 
 
@@ -73,7 +76,7 @@ def test_random_graphs_and_plan_options(model_text, oracle_model, block):
             oracle_model.set_weight_scale(g.ws)
             e.upload_graph(g)
             want = oracle_model.logits(g)
-            for rep in range(3):
+            for rep in range(4):
                 _, lg = e.forward(g.x())
                 assert np.array_equal(bits(lg[:, 0]), bits(want)), (case, rep, g.n, g.nnz, opts)
         finally:

@@ -1436,6 +1436,109 @@ def test_compact_gather_plan_rejects_unsorted_lists(model_text, oracle_model):
         e.close()
 
 
+@pytest.mark.parametrize("maker,fits", [
+    (lambda: gg.erdos_renyi(100000, 1000000, 1), True),        # BASELINE configs[1]: four live columns
+    (lambda: gg.erdos_renyi(60000, 900000, 81), True),         # 30 entries a row
+    (lambda: gg.erdos_renyi(65537, 700000, 82), True),         # a ragged last tile
+    (lambda: gg.erdos_renyi(80000, 240000, 83), False),        # 6 entries a row: more live columns than a table holds
+])
+def test_table_tiles_are_bit_identical(model_text, oracle_model, maker, fits):
+    """Round 4: on graphs of 50 - 400 K vertices the 16-wide stages of a whole forward gather their neighbours
+    from the 16-byte-per-vertex compact table of the input (k_stage_t4: the table sits in every L2, the 64-byte rows do not),
+    written by the kernel that produced the input for the columns the previous forward chose; the device decides per forward
+    and stage whether the table in place fits (else the gathering kernel behind it runs).  Forward after forward — the first
+    ones, which cannot fit yet, included — the logits are the oracle's; an input with other live columns refits or steps
+    aside; a graph that never fits stops being offered the tiles."""
+    import gnn_mwvc_amd as G
+    g = maker()
+    oracle_model.set_weight_scale(g.ws)
+    want = oracle_model.logits(g)
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_weight_scale(g.ws)
+        e.upload_graph(g)
+        assert e.get_info("table_tiles_active") == 1 and e.get_info("compact_gather_active") == 0
+        seen = []
+        for rep in range(8):
+            _, lg = e.forward(g.x())
+            assert np.array_equal(bits(lg[:, 0]), bits(want)), rep
+            seen.append((e.get_info("table_tiles_fit_stage1"), e.get_info("table_tiles_fit_stage2")))
+        if fits:
+            assert seen[0] == (0, 0)                        # nobody has chosen columns yet
+            assert seen[-1] == (1, 1) and seen[3] == (1, 1), seen
+            # another input on the same graph: whatever it makes live, the bits hold (and the tiles come back for the old one)
+            rng = np.random.default_rng(9)
+            for x2 in ((g.x() * np.float32(0.25)).astype(np.float32), rng.uniform(0.0, 2.0, g.n).astype(np.float32)):
+                w2 = oracle_model.predict(g, x2, stop_after=oracle_model.n_layers - 2)[:, 0]
+                for rep in range(4):
+                    _, lg = e.forward(x2)
+                    assert np.array_equal(bits(lg[:, 0]), bits(w2)), rep
+            for rep in range(4):
+                _, lg = e.forward(g.x())
+                assert np.array_equal(bits(lg[:, 0]), bits(want)), rep
+            # values that cannot lend the table their sign bit (NaN: every column of such a vertex's rows) and infinities: the
+            # vertices around them take their neighbours from the full rows, everything else stays on the table
+            x3 = g.x().copy()
+            x3[5] = np.nan; x3[77] = np.inf; x3[1234] = -np.inf; x3[4321] = -3.0; x3[999] = 3.0e38; x3[g.n - 1] = np.nan
+            w3 = oracle_model.predict(g, x3, stop_after=oracle_model.n_layers - 2)[:, 0]
+            assert np.isnan(w3).sum() > 100
+            for rep in range(3):
+                _, lg = e.forward(x3)
+                got = lg[:, 0]
+                same = (bits(got) == bits(w3)) | (np.isnan(got) & np.isnan(w3))
+                assert same.all(), (rep, int((~same).sum()))
+            for rep in range(3):
+                _, lg = e.forward(g.x())
+                assert np.array_equal(bits(lg[:, 0]), bits(want)), rep
+            # (the noise input missed four times in a row: the tiles may have been switched off for this graph by now)
+            assert e.get_info("table_tiles_active") == 0 or e.get_info("table_tiles_fit_stage1") == 1
+            # another graph on the same engine: its FIRST forward already takes the tiles wherever the last forward with tiles on
+            # the previous graph left a choice (here: whatever the inputs above left behind — any choice gives the same bits)
+            g2 = gg.erdos_renyi(70000, 800000, 91)
+            oracle_model.set_weight_scale(g2.ws)
+            want2 = oracle_model.logits(g2)
+            e.set_weight_scale(g2.ws)
+            e.upload_graph(g2)
+            assert e.get_info("table_tiles_active") == 1
+            first = None
+            for rep in range(4):
+                _, lg = e.forward(g2.x())
+                assert np.array_equal(bits(lg[:, 0]), bits(want2)), rep
+                fit = (e.get_info("table_tiles_fit_stage1"), e.get_info("table_tiles_fit_stage2"))
+                first = fit if first is None else first
+            assert fit == (1, 1) and first != (0, 0), (first, fit)
+            # ... and a third graph straight after: both stages of its first forward
+            g3 = gg.erdos_renyi(90000, 1100000, 92)
+            oracle_model.set_weight_scale(g3.ws)
+            e.set_weight_scale(g3.ws)
+            e.upload_graph(g3)
+            _, lg = e.forward(g3.x())
+            assert np.array_equal(bits(lg[:, 0]), bits(oracle_model.logits(g3)))
+            assert (e.get_info("table_tiles_fit_stage1"), e.get_info("table_tiles_fit_stage2")) == (1, 1)
+            oracle_model.set_weight_scale(g.ws)
+            e.set_weight_scale(g.ws)
+            e.upload_graph(g)
+            # the same with the gathering kernel always launched behind the tiles (no solo mode)
+            e.set_option("table_tiles_solo", 0)
+            e.upload_graph(g)
+            for rep in range(5):
+                _, lg = e.forward(g.x())
+                assert np.array_equal(bits(lg[:, 0]), bits(want)), rep
+            assert e.get_info("table_tiles_fit_stage1") == 1 and e.get_info("table_tiles_fit_stage2") == 1
+            e.set_option("table_tiles_solo", 1)
+        else:
+            assert all(f == (0, 0) for f in seen)
+            assert e.get_info("table_tiles_active") == 0     # four misses in a row: no longer offered
+        # stage calls outside a forward never take the tiles (nothing of theirs may be read or written there)
+        e.set_option("table_tiles", 0)
+        e.upload_graph(g)
+        assert e.get_info("table_tiles_active") == 0
+        _, lg = e.forward(g.x())
+        assert np.array_equal(bits(lg[:, 0]), bits(want))
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("chunk_rows,overlap,maker", [
     (16, 1, lambda: gg.erdos_renyi(20000, 200000, 72)),     # one row per wave slice: 1250 chunks, five rounds of the grid
     (16, 0, lambda: gg.erdos_renyi(20000, 200000, 72)),     # the same with the last stage's dense layers after, not under, the sums
