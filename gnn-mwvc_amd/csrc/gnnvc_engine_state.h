@@ -282,6 +282,7 @@ struct gnnvc_engine {
     bool t4_fit_seen[4] = {false, false, false, false};   // the stage's table fit in the last forward whose verdict has arrived
     int opt_t4_solo = 1;                     // option "table_tiles_solo" (A/B): 0 = always launch the gathering kernel behind the tiles
     uint32_t t4_unfit_runs = 0;              // forwards in a row whose first 16-wide stage left the launch to the gathering kernel
+    bool t4_now = false;                     // the forward at hand runs with the table tiles offered
     bool t4_choice_live = false;             // a forward with table tiles has run on this engine: the descriptors hold a choice (kept across graphs)
     uint32_t t4_parity = 0;                  // which of a stage's two descriptors the producers read in the forward at hand
     DevBuf<float> t4_table[2];               // [0]: the table of stage 1's input, [1]: of stage 2's (a stage gathers from one while emitting the other)

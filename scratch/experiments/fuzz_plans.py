@@ -1,4 +1,4 @@
-"""Randomised plan fuzz (GPU box): random small graphs x random thresholds / plan options, four forwards each, logits
+"""Randomised plan fuzz (GPU box): random small graphs x random thresholds / plan options, five forwards each, logits
 against the oracle bit for bit.  python scratch/experiments/fuzz_plans.py [cases=150] [seed0=0]"""
 import sys, pathlib, time
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
@@ -70,7 +70,7 @@ for case in range(cases):
         e.set_weight_scale(g.ws); om.set_weight_scale(g.ws)
         e.upload_graph(g)
         want = om.logits(g)
-        for rep in range(4):
+        for rep in range(5):
             _, lg = e.forward(g.x())
             if not np.array_equal(bits(lg[:, 0]), bits(want)):
                 bad += 1

@@ -76,7 +76,7 @@ def test_random_graphs_and_plan_options(model_text, oracle_model, block):
             oracle_model.set_weight_scale(g.ws)
             e.upload_graph(g)
             want = oracle_model.logits(g)
-            for rep in range(4):
+            for rep in range(5):
                 _, lg = e.forward(g.x())
                 assert np.array_equal(bits(lg[:, 0]), bits(want)), (case, rep, g.n, g.nnz, opts)
         finally:
