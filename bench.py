@@ -497,6 +497,8 @@ def main() -> int:
              "column_blocks": eng.get_info("blocked_blocks"), "block_cols": eng.get_info("block_cols"),
              "mfma_dense": eng.get_info("mfma_dense"),
              "sorted_tiles": bool(eng.get_info("sorted_tiles_active")),
+             "table_tiles": [bool(eng.get_info("table_tiles_fit_stage1")), bool(eng.get_info("table_tiles_fit_stage2"))]
+             if eng.get_info("table_tiles_active") else None,
              "side_queue_runs_beside": bool(eng.get_info("side_queue_runs_beside")) if eng.get_info("long_rows") else None,
              "natural_tile_waste": eng.get_info("tile_waste_x100") / 100.0,
              "interleaved_tiles": bool(eng.get_info("interleaved_tiles")), "long_rows": eng.get_info("long_rows"),
@@ -984,6 +986,9 @@ def side_workload(name, args, dev, make_engine, ggt):
                     "pruned_stage2_from_stage1_entries": bool(e.get_info("pruned_from_previous_stage2")),
                     "sorted_tiles": bool(e.get_info("sorted_tiles_active")), "long_rows": e.get_info("long_rows"),
                     "giant_rows": e.get_info("giant_rows"),
+                    # (graphs of 50 - 400 K vertices: the 16-wide stages gather an L2-resident table, DESIGN.md 5 "Table tiles")
+                    "table_tiles": [bool(e.get_info("table_tiles_fit_stage1")), bool(e.get_info("table_tiles_fit_stage2"))]
+                    if e.get_info("table_tiles_active") else None,
                     # (skewed graphs: the long / giant rows' kernels have to run BESIDE the tile kernel — a side queue that shares the
                     # main stream's hardware queue serialises them and nothing else would say so)
                     "side_queue_runs_beside": bool(e.get_info("side_queue_runs_beside")) if e.get_info("long_rows") else None}}
