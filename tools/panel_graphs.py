@@ -33,5 +33,5 @@ def panel_graph(case: int, dev, big: bool = False):
 
 
 # every per-graph plan off, fixed thresholds: the plain kernels
-PLAIN = {"lds_table": 0, "compact_gather": 0, "blocked_stage0": 0, "prune_zero_rows": 0, "giant_segments": 0, "sorted_tiles": 0,
+PLAIN = {"lds_table": 0, "compact_gather": 0, "blocked_stage0": 0, "prune_zero_rows": 0, "giant_segments": 0, "sorted_tiles": 0, "table_tiles": 0,
          "long_row_threshold": 512, "giant_row_threshold": 16384}

@@ -18,7 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=10_000_000)
     ap.add_argument("--m", type=int, default=100_000_000)
-    ap.add_argument("--forwards", type=int, default=5)   # the plans are built on the second forward; the last one is steady state
+    ap.add_argument("--forwards", type=int, default=6)   # plans are built by the second forward, table tiles fit from the fourth; the last one is steady state
     ap.add_argument("--workload", default="", help="one of bench.py's workloads instead of --n / --m (er10m = the default graph)")
     ap.add_argument("--plain", type=int, default=0, help="1 = every per-graph plan off (the plain kernels' traffic)")
     ap.add_argument("--first", type=int, default=0, help="1 = mark the FIRST forward of a fresh engine instead of the last (score-once traffic)")

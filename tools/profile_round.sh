@@ -18,6 +18,12 @@ if has trace; then
   rm -rf "$OUT/trace"
   timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --no-cpu-baseline --no-variants --no-workloads --no-host-path > "$OUT/bench_under_rocprof.log" 2>&1
 fi
+for w in er100k rmat22 powerlaw1m; do   # kernel stats of the other workloads' steady state (the same bench command, one workload)
+  if has trace_$w || has trace; then
+    rm -rf "$OUT/trace_$w"
+    timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$w" -- python3 bench.py --workload $w --steps 50 --no-cpu-baseline --no-variants --no-workloads --no-host-path > "$OUT/bench_under_rocprof_$w.log" 2>&1
+  fi
+done
 if has er10m; then
   pass er10m p_rd   "" TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum
   pass er10m p_wr   "" WRITE_SIZE TCC_REQ_sum
