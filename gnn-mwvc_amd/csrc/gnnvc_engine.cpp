@@ -430,6 +430,13 @@ int launch_main(gnnvc_engine *e, const StageChoice &c, const GraphDev &gv, const
         if (rc) return rc;
     }
     const gnnvc::SortedOrder *sop = c.sorted.n ? &c.sorted : nullptr;
+    // Wide tiles (k_stage_w*): a graph with fewer tiles than the chip has SIMDs — the reference CLI's later predict calls — and
+    // nothing but the plain gather to run (no plan, no long rows, no pruned adjacency, nothing to emit): a workgroup per tile
+    if (c.sums == StageChoice::kGather && e->opt_wide && e->g.n <= (sp.f == 16 ? e->opt_wide_max_n16 : e->opt_wide_max_n) && !e->g.sliced() && e->n_long == 0 && !sop &&
+        !acc4 && !emit.counts && gv.prune_bad == nullptr && gv.zero_bits == nullptr && sp.variant >= 0 && sp.variant <= 2) {
+        e->wide_used = true;
+        return hip_rc(e, gnnvc::launch_stage_wide(sp, e->g, e->ws, e->params.p, in, out, logits, lo, hi, e->stream));
+    }
     HIP_TRY(e, gnnvc::launch_stage(sp, gv, e->ws, e->params.p, in, out, logits, lo, hi, c.long_thresh, c.mfma, sop,
                                    e->interleave, e->stream, acc4, desc, e->c4_agg16.p, e->opt_mfma == 1, emit,
                                    /*dense_part=*/!c.rounds, so_p.vertex ? &so_p : nullptr,
@@ -729,6 +736,9 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
     else if (k == "prune_early_entries") e->opt_prune_early_nnz = value > 0 ? (uint64_t)value : 0;
     else if (k == "prune_giant_rows") e->opt_prune_giant = value != 0 ? 1 : 0;
     else if (k == "prune_predict") e->opt_prune_predict = value != 0 ? 1 : 0;
+    else if (k == "wide_tiles") e->opt_wide = value != 0 ? 1 : 0;
+    else if (k == "wide_tiles_max_n") e->opt_wide_max_n = value > 0 ? (uint32_t)value : 0u;
+    else if (k == "wide_tiles_max_n_f16") e->opt_wide_max_n16 = value > 0 ? (uint32_t)value : 0u;
     else if (k == "dense_skip_zeros") e->opt_dense_skip = value != 0 ? 1 : 0;
     else if (k == "table_tiles") e->opt_t4 = value != 0 ? 1 : 0;
     else if (k == "table_tiles_solo") e->opt_t4_solo = value != 0 ? 1 : 0;
@@ -815,6 +825,7 @@ int gnnvc_get_info(const gnnvc_engine *e, const char *key, long *value) {
             *value = bad == 0 ? 1 : 0;
         }
     }
+    else if (k == "wide_tiles_used") *value = e->wide_used ? 1 : 0;   // (did any stage since the graph was handed over run on wide tiles)
     else if (k == "table_tiles_active") *value = e->t4_ok ? 1 : 0;
     else if (k == "table_tiles_fit_stage1" || k == "table_tiles_fit_stage2") {   // did the last forward's stage run on the table?  (waits for the stream)
         *value = 0;

@@ -282,6 +282,10 @@ struct gnnvc_engine {
     bool t4_fit_seen[4] = {false, false, false, false};   // the stage's table fit in the last forward whose verdict has arrived
     int opt_t4_solo = 1;                     // option "table_tiles_solo" (A/B): 0 = always launch the gathering kernel behind the tiles
     uint32_t t4_unfit_runs = 0;              // forwards in a row whose first 16-wide stage left the launch to the gathering kernel
+    int opt_wide = 1;                        // option "wide_tiles": graphs of up to "wide_tiles_max_n" vertices run their plain stages a workgroup per tile
+    uint32_t opt_wide_max_n = 49152;         // the F = 1 stage ("wide_tiles_max_n": where the table tiles start — feeding them from wide tiles was measured slower) ...
+    uint32_t opt_wide_max_n16 = 131072;      // ... and the 16-wide stages ("wide_tiles_max_n_f16") up to these many vertices (measured: small_sizes.py)
+    bool wide_used = false;
     bool t4_now = false;                     // the forward at hand runs with the table tiles offered
     bool t4_choice_live = false;             // a forward with table tiles has run on this engine: the descriptors hold a choice (kept across graphs)
     uint32_t t4_parity = 0;                  // which of a stage's two descriptors the producers read in the forward at hand

@@ -120,6 +120,10 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
                         const float *table_in = nullptr /* acc4: the compact table of THIS stage's input (one pass), so that the dense
                                                            kernel takes a row's own live values from it; null = from the full rows */,
                         const uint32_t *skip_flag = nullptr /* (no acc4) a device word: != 0 = another kernel has done this launch's rows */);
+// a whole stage (variants 0, 1, 2) on WIDE tiles — a workgroup per 64-vertex tile, the tile's gather and each dense layer's outputs
+// split over its four waves (k_stage_w1 / k_stage_w16): graphs with fewer tiles than the chip has SIMDs, no long rows
+hipError_t launch_stage_wide(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *in, float *out,
+                             float *logits, uint32_t row_lo, uint32_t row_hi, hipStream_t stream);
 // a 16-wide stage (variant 1 or 2) from the L2-resident compact table of its input (k_stage_t4: graphs of 50 - 400 K vertices, whole
 // forwards): table_in = (n + 1) rows of 16 bytes written by the producer of the input (EmitArgs) for the columns in desc_in,
 // counts_in = that producer's kEmitCounters; desc_out (another 16 words) receives this forward's choice — the next forward's

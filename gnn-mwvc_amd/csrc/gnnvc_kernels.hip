@@ -934,9 +934,8 @@ __global__ __launch_bounds__(kBlock) void k_stage_t4(GraphDev g, float ws, const
     if (!fit && !solo) return;     // uniform: the gathering kernel behind this one has the launch
     const uint32_t d0 = desc_in[1], d1 = desc_in[2], d2 = desc_in[3], d3 = desc_in[4];
     uint32_t es_ok = 0, es0 = 0, es1 = 0, es2 = 0, es3 = 0;   // what THIS kernel's epilogue writes for the next stage (loaded now: c4_emit_with)
-    if (!SIGMOID && emit_counts) {
-        es_ok = emit_spec[0];
-        if (es_ok == 1u) { es0 = emit_spec[1]; es1 = emit_spec[2]; es2 = emit_spec[3]; es3 = emit_spec[4]; }
+    if (!SIGMOID && emit_counts) {   // (one go, unconditionally: nothing waits for these before the epilogue)
+        es_ok = emit_spec[0]; es0 = emit_spec[1] & 15u; es1 = emit_spec[2] & 15u; es2 = emit_spec[3] & 15u; es3 = emit_spec[4] & 15u;
     }
     float *T = lds[threadIdx.x >> 6];
     uint32_t *stage = reinterpret_cast<uint32_t *>(T);
@@ -1156,6 +1155,197 @@ __global__ __launch_bounds__(kBlock) void k_stage_t4(GraphDev g, float ws, const
         }
     }
     GNNVC_PROBE((SIGMOID ? 12 : 11), 11);
+}
+
+// ------------------------------------------------------------------ wide tiles: a tile on FOUR waves (small graphs)
+// (round 4; VERDICT r3: the reference CLI's predict calls 2..n score graphs of 41 423, 19 675, 7 375, 1 933 vertices,
+// src/GNN_VC.cpp:171-192.)  Below ~25 K vertices the chip has fewer tiles than SIMDs and a kernel takes as long as ONE tile's
+// chain on ONE wave — phase stamps (scratch/experiments/phase_probe.py): column ids 2 us, gather 3 us, dense layers 6 - 7 us (96
+// dependent 32x32x2 MFMAs, or as many VALU cycles), stores 0.5 us, + ~4 us to launch: 15 us a kernel for 2 000 vertices as for
+// 20 000.  Here a WORKGROUP owns the 64-vertex tile: in the gather a quad of lanes owns a vertex (wave q: vertices 16 q .. 16 q +
+// 15; four neighbour rows in flight per vertex — a quarter of the rows and half the rounds per wave), and in the dense layers
+// lane L of wave q computes a QUARTER of every layer's outputs of vertex L (outputs [PER q, PER q + PER)) with the layers'
+// activations exchanged through LDS: every output is still one k-ordered fma chain from +0.0f, then the separately rounded bias
+// add — the bits of dense<>().  No long rows, no sorted tiles, no pruned adjacency, no emit: graphs that small have none of it.
+template <int K, int KUSED, int N, int PER, int ACT>
+__device__ __forceinline__ void dense_cols(const float (&in)[K], float (&out)[PER], const float *__restrict__ W,
+                                           const float *__restrict__ b, int col0 /* wave-uniform */) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) out[j] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KUSED; ++k) {
+        const float a = in[k];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) out[j] = __builtin_fmaf(a, W[k * N + col0 + j], out[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const float t = out[j] + b[col0 + j];
+        out[j] = (ACT == 0) ? relu_ref(t) : t;
+    }
+}
+
+constexpr int kWidePitch = 33;
+
+// layers 2 and 3 of a wide tile (layer-1 outputs of this lane's vertex, PER1 of them, in o1): shared by both stage kinds
+template <int N1, int N2, int N3, bool SIGMOID>
+__device__ __forceinline__ void wide_tail(const float (&o1)[N1 / 4], float *A, float *B, const float *__restrict__ W2,
+                                          const float *__restrict__ b2, const float *__restrict__ W3, const float *__restrict__ b3,
+                                          int lane, int q, uint32_t v0, uint32_t row_hi, float *__restrict__ fout,
+                                          float *__restrict__ logits) {
+    static_assert(N1 % 4 == 0 && N2 % 4 == 0, "a quarter of a layer's outputs per wave");
+    constexpr int P1 = N1 / 4, P2 = N2 / 4;
+#pragma unroll
+    for (int j = 0; j < P1; ++j) B[lane * kWidePitch + P1 * q + j] = o1[j];
+    __syncthreads();
+    float x1[N1];
+#pragma unroll
+    for (int k = 0; k < N1; ++k) x1[k] = B[lane * kWidePitch + k];
+    float o2[P2];
+    dense_cols<N1, N1, N2, P2, 0>(x1, o2, W2, b2, P2 * q);
+#pragma unroll
+    for (int j = 0; j < P2; ++j) A[lane * kWidePitch + P2 * q + j] = o2[j];   // (A's inputs were consumed before the barrier above)
+    __syncthreads();
+    float x2[N2];
+#pragma unroll
+    for (int k = 0; k < N2; ++k) x2[k] = A[lane * kWidePitch + k];
+    if constexpr (SIGMOID) {
+        static_assert(N3 == 1, "sigmoid stage ends in one output");
+        if (q == 0) {   // (wave-uniform)
+            float o3[1];
+            dense_cols<N2, N2, 1, 1, 1>(x2, o3, W3, b3, 0);
+            const uint32_t u = v0 + lane;
+            if (u < row_hi) {
+                if (logits) logits[u] = o3[0];
+                fout[u] = sigmoid_ref(o3[0]);
+            }
+        }
+    } else {
+        static_assert(N3 == 16, "feature stages emit 16 floats per vertex");
+        constexpr int P3 = N3 / 4;
+        float o3[P3];
+        dense_cols<N2, N2, N3, P3, 0>(x2, o3, W3, b3, P3 * q);
+#pragma unroll
+        for (int j = 0; j < P3; ++j) B[lane * kOutPitch + P3 * q + j] = o3[j];   // (B's layer-1 outputs were consumed before the second barrier)
+        __syncthreads();
+        const int row = threadIdx.x >> 2, c = threadIdx.x & 3;   // 256 threads: 64 rows x four 16-byte pieces
+        const float *src = &B[row * kOutPitch + 4 * c];
+        if (v0 + row < row_hi) reinterpret_cast<float4 *>(fout)[(size_t)(v0 + row) * 4 + c] = make_float4(src[0], src[1], src[2], src[3]);
+    }
+}
+
+template <int N1, int N2, int N3, bool SIGMOID>
+__global__ __launch_bounds__(kBlock) void k_stage_w16(GraphDev g, float ws, const float4 *__restrict__ fin, float *__restrict__ fout,
+                                                      float *__restrict__ logits, const float *__restrict__ P, uint32_t row_lo,
+                                                      uint32_t row_hi) {
+    __shared__ float A[kWave * kWidePitch], B[kWave * kWidePitch];
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t v0 = row_lo + blockIdx.x * kWave;
+    {   // ---- gather: a quad of lanes per vertex, lane c holds floats 4c .. 4c + 3 of a 64-byte row
+        const int vq = 16 * q + (lane >> 2), c = lane & 3;
+        const uint32_t uu = v0 + vq;
+        const bool valid = uu < row_hi;
+        const uint32_t u = valid ? uu : row_hi - 1;
+        const uint32_t rs = g.rowptr[u], re_full = g.rowptr[u + 1];
+        const uint32_t re = valid ? re_full : rs;
+        const float4 self = fin[(size_t)u * 4 + c];
+        const float f_w = (float)g.w[u] / ws, f_nw = (float)g.nw[u] / ws;
+        const uint32_t zrow = g.n;   // all-zero pad row: x + 0.0f == x exactly
+        constexpr int S = 4;
+        c4row acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        const c4row *__restrict__ fv = reinterpret_cast<const c4row *>(fin);
+        uint32_t nxt[S];
+#pragma unroll
+        for (int s2 = 0; s2 < S; ++s2) nxt[s2] = g.col[rs + s2];   // (col is padded past nnz: readable; masked below)
+        for (uint32_t e = rs; e < re; e += S) {
+            c4row r[S];
+#pragma unroll
+            for (int s2 = 0; s2 < S; ++s2) r[s2] = fv[(size_t)((e + s2 < re) ? nxt[s2] : zrow) * 4 + c];
+#pragma unroll
+            for (int s2 = 0; s2 < S; ++s2) nxt[s2] = g.col[e + S + s2];   // the next round's ids fly with this round's rows
+#pragma unroll
+            for (int s2 = 0; s2 < S; ++s2) acc += r[s2];                  // stored order, one rounded add per neighbour and column
+        }
+        float *row = &A[vq * kWidePitch];
+        row[4 * c + 0] = acc[0]; row[4 * c + 1] = acc[1]; row[4 * c + 2] = acc[2]; row[4 * c + 3] = acc[3];
+        if (c == 0) {
+            row[16] = self.x;                    // h[0]; h[1..3] are overwritten by degree / weights in the reference's layout
+            row[17] = (float)(re_full - rs);
+            row[18] = f_w;
+            row[19] = f_nw;
+        } else {
+            float *d = &row[20 + 4 * (c - 1)];   // h[4..15]
+            d[0] = self.x; d[1] = self.y; d[2] = self.z; d[3] = self.w;
+        }
+    }
+    __syncthreads();
+    const float *W1 = P, *b1 = W1 + 35 * N1;
+    const float *W2 = b1 + N1, *b2 = W2 + N1 * N2;
+    const float *W3 = b2 + N2, *b3 = W3 + N2 * N3;
+    float x0[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) x0[k] = A[lane * kWidePitch + k];
+    float o1[N1 / 4];
+    dense_cols<32, 32, N1, N1 / 4, 0>(x0, o1, W1, b1, (N1 / 4) * q);   // rows 32..34 of W1 meet exact zeros
+    wide_tail<N1, N2, N3, SIGMOID>(o1, A, B, W2, b2, W3, b3, lane, q, v0, row_hi, fout, logits);
+}
+
+template <int N1, int N2, int N3>
+__global__ __launch_bounds__(kBlock) void k_stage_w1(GraphDev g, float ws, const float *__restrict__ xin, float *__restrict__ fout,
+                                                     const float *__restrict__ P, uint32_t row_lo, uint32_t row_hi) {
+    __shared__ float A[kWave * kWidePitch], B[kWave * kWidePitch];
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t v0 = row_lo + blockIdx.x * kWave;
+    {   // ---- gather: wave q sums vertices 16 q .. 16 q + 15, a QUAD of lanes per vertex: lane j of the quad fetches neighbours e + j and
+        // e + 4 + j of a round of eight, and every lane of the quad adds the eight values in stored order (quad broadcasts): the
+        // chain of one lane per vertex with four times its loads in flight
+        const int vq = 16 * q + (lane >> 2), j = lane & 3;
+        const uint32_t uu = v0 + vq;
+        const bool valid = uu < row_hi;
+        const uint32_t u = valid ? uu : row_hi - 1;
+        const uint32_t rs = g.rowptr[u], re_full = g.rowptr[u + 1];
+        const uint32_t re = valid ? re_full : rs;
+        const float xself = xin[u];
+        float agg = 0.0f;
+        uint32_t n0 = g.col[rs + j], n1 = g.col[rs + 4 + j];   // (col is padded past nnz: readable; masked below)
+        for (uint32_t e = rs; e < re; e += 8) {
+            const bool in0 = e + j < re, in1 = e + 4 + j < re;
+            const float r0 = xin[in0 ? n0 : u], r1 = xin[in1 ? n1 : u];
+            n0 = g.col[e + 8 + j];
+            n1 = g.col[e + 12 + j];
+            const float a0 = in0 ? r0 : 0.0f, a1 = in1 ? r1 : 0.0f;   // agg is never -0.0f, so + 0.0f is exact
+#define GNNVC_QUAD_BCAST(x_, t_) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x_), (t_) * 0x55, 0xf, 0xf, false))
+            agg += GNNVC_QUAD_BCAST(a0, 0);
+            agg += GNNVC_QUAD_BCAST(a0, 1);
+            agg += GNNVC_QUAD_BCAST(a0, 2);
+            agg += GNNVC_QUAD_BCAST(a0, 3);
+            agg += GNNVC_QUAD_BCAST(a1, 0);
+            agg += GNNVC_QUAD_BCAST(a1, 1);
+            agg += GNNVC_QUAD_BCAST(a1, 2);
+            agg += GNNVC_QUAD_BCAST(a1, 3);
+#undef GNNVC_QUAD_BCAST
+        }
+        if (j == 0) {
+            float *row = &A[vq * kWidePitch];
+            row[0] = agg;
+            row[1] = xself;
+            row[2] = (float)(re_full - rs);
+            row[3] = (float)g.w[u] / ws;
+            row[4] = (float)g.nw[u] / ws;
+        }
+    }
+    __syncthreads();
+    const float *W1 = P, *b1 = W1 + 5 * N1;
+    const float *W2 = b1 + N1, *b2 = W2 + N1 * N2;
+    const float *W3 = b2 + N2, *b3 = W3 + N2 * N3;
+    float x0[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) x0[k] = A[lane * kWidePitch + k];
+    float o1[N1 / 4];
+    dense_cols<5, 5, N1, N1 / 4, 0>(x0, o1, W1, b1, (N1 / 4) * q);
+    wide_tail<N1, N2, N3, false>(o1, A, B, W2, b2, W3, b3, lane, q, v0, row_hi, fout, nullptr);
 }
 
 // ------------------------------------------------------------------ stage, F = 1
@@ -4338,6 +4528,30 @@ int stage_variant(int f, int n1, int n2, int n3, int sigmoid_last) {
 }
 
 // a 16-wide stage from the L2-resident compact table (k_stage_t4); it leaves at once unless the table in place fits this input
+// a stage on wide tiles (k_stage_w1 / k_stage_w16: a workgroup per 64-vertex tile; small graphs without long rows)
+hipError_t launch_stage_wide(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *in, float *out,
+                             float *logits, uint32_t row_lo, uint32_t row_hi, hipStream_t stream) {
+    if (row_hi <= row_lo) return hipSuccess;
+    const dim3 grid((row_hi - row_lo + kWave - 1) / kWave), block(kBlock);
+    const float *P = params + sp.param_offset;
+    switch (sp.variant) {
+    case 0:
+        GNNVC_LAUNCH((k_stage_w1<32, 32, 16>), grid, block, 0, stream, g, ws, in, out, P, row_lo, row_hi);
+        break;
+    case 1:
+        GNNVC_LAUNCH((k_stage_w16<32, 32, 16, false>), grid, block, 0, stream, g, ws, reinterpret_cast<const float4 *>(in), out,
+                     (float *)nullptr, P, row_lo, row_hi);
+        break;
+    case 2:
+        GNNVC_LAUNCH((k_stage_w16<32, 16, 1, true>), grid, block, 0, stream, g, ws, reinterpret_cast<const float4 *>(in), out, logits, P,
+                     row_lo, row_hi);
+        break;
+    default:
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 #ifndef GNNVC_T4_S
 #define GNNVC_T4_S 4   // neighbours' table rows in flight per vertex
 #endif

@@ -1218,6 +1218,7 @@ int prepare_plans(gnnvc_engine *e) {
 
 // per-graph state of the plans: nothing of the previous graph's survives
 void reset_graph_state(gnnvc_engine *e) {
+    e->wide_used = false;
     e->lt_ready = e->lt_tried = false;
     e->lt_used = e->lt_off = false;
     e->lt_unfit_runs = 0;

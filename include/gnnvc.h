@@ -200,6 +200,16 @@ int gnnvc_get_stream(gnnvc_engine *e, void **hip_stream);
  *                         "pruned_predicted_stage1", "pruned_borrowed_stage2"
  *   "dense_skip_zeros" 0|1  (round 4; A/B) the aggregate-only dense kernels of the compact-table plan leave out the first-layer
  *                         terms they know to be zero (default 1; bit-identical)
+ *   "table_tiles"    0|1  (round 4) graphs of "table_tiles_min_n" (default 49 152) vertices and more whose 16-byte-per-vertex
+ *                         table fits "table_tiles_max_bytes" (default 6 MiB: n <= 393 K) and that are outside the compact-table
+ *                         plan's range, without long rows: whole forwards gather the 16-wide stages' neighbours from an
+ *                         L2-resident table of the input's four live columns, written by the kernel that produced the input
+ *                         for the columns the previous forward chose (kept across graphs of one engine); vertices with
+ *                         non-zeros elsewhere are flagged and their neighbours fetch those columns from the full rows —
+ *                         bit-identical for any input.  Offered from a graph's second forward on, or its first when the
+ *                         engine carries a choice over from its previous graph.  Default 1.  "table_tiles_solo" 0|1 (A/B):
+ *                         0 = the gathering kernel is always launched behind the tiles.  gnnvc_get_info:
+ *                         "table_tiles_active", "table_tiles_fit_stage1|2" (did the last forward's stage run on its table)
  *   "prune_min_entries" n  graphs with fewer adjacency entries do not prune (default 2^20);
  *   "prune_min_drop_percent" p  nor do graphs where less than p % of the entries would go (default 15);
  *   "prune_early_entries" n  skewed graphs with at least n entries build the plan in their first forward (default

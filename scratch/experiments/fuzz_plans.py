@@ -63,6 +63,7 @@ for case in range(cases):
     opts["table_tiles"] = int(rng.choice([0, 1, 1]))
     opts["table_tiles_min_n"] = int(rng.choice([0, 0, 49152]))
     opts["table_tiles_solo"] = int(rng.choice([0, 1]))
+    opts["wide_tiles"] = int(rng.choice([0, 1, 1]))
     e = G.Engine(G.default_model_text(), device=0)
     try:
         for k, v in opts.items():

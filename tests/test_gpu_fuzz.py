@@ -59,6 +59,7 @@ def _options(rng):
     o["table_tiles"] = int(rng.choice([0, 1, 1]))
     o["table_tiles_min_n"] = int(rng.choice([0, 0, 49152]))   # (0: the table tiles on these small graphs too)
     o["table_tiles_solo"] = int(rng.choice([0, 1]))
+    o["wide_tiles"] = int(rng.choice([0, 1, 1]))
     return o
 
 

@@ -1436,6 +1436,63 @@ def test_compact_gather_plan_rejects_unsorted_lists(model_text, oracle_model):
         e.close()
 
 
+@pytest.mark.parametrize("maker", [
+    lambda: gg.erdos_renyi(1933, 7000, 61),          # the reference CLI's later predict calls on ER-100K: 1 933 ...
+    lambda: gg.erdos_renyi(7375, 30000, 62),         # ... 7 375 ...
+    lambda: gg.erdos_renyi(19675, 90000, 63),        # ... 19 675 vertices
+    lambda: gg.erdos_renyi(65, 200, 64),             # a second tile of one vertex
+    lambda: gg.erdos_renyi(3, 2, 65),                # fewer vertices than a quad row
+    lambda: gg.erdos_renyi(5000, 400000, 66),        # 160 entries a row: forty rounds of four
+    lambda: gg.from_edge_list(300, [(0, 1), (5, 299)], [30, 40, 50] * 100),   # nearly every row empty
+])
+def test_wide_tiles_are_bit_identical(model_text, oracle_model, maker):
+    """Round 4: graphs with fewer 64-vertex tiles than the chip has SIMDs (the reference CLI's predict calls 2..n,
+    src/GNN_VC.cpp:171-192) run every stage a WORKGROUP per tile — the gather on quads of lanes over four waves, each dense layer's
+    outputs a quarter per wave (k_stage_w1 / k_stage_w16).  Same fma chains, same bits: whole forwards, arbitrary inputs, stage
+    calls over row ranges, and the option off."""
+    import torch
+    import gnn_mwvc_amd as G
+    g = maker()
+    oracle_model.set_weight_scale(g.ws)
+    want = oracle_model.logits(g)
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_weight_scale(g.ws)
+        e.upload_graph(g)
+        for rep in range(2):
+            sc, lg = e.forward(g.x())
+            assert np.array_equal(bits(lg[:, 0]), bits(want)), rep
+        assert e.get_info("wide_tiles_used") == 1
+        rng = np.random.default_rng(3)
+        x2 = rng.normal(size=g.n).astype(np.float32)
+        x2[rng.integers(0, g.n, 3)] = np.array([np.inf, -0.0, 1e30], dtype=np.float32)
+        w2 = oracle_model.logits(g, x2)
+        _, lg = e.forward(x2)
+        same = (bits(lg[:, 0]) == bits(w2)) | (np.isnan(lg[:, 0]) & np.isnan(w2))
+        assert same.all()
+        # stage by stage over row ranges on device buffers
+        dev = torch.device("cuda:0")
+        x = torch.from_numpy(g.x()).to(dev)
+        h1 = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+        h2 = torch.zeros((g.n + 1, 16), dtype=torch.float32, device=dev)
+        sc = torch.zeros(g.n, dtype=torch.float32, device=dev)
+        lgd = torch.zeros(g.n, dtype=torch.float32, device=dev)
+        cuts = sorted({0, min(1, g.n), min(64, g.n), g.n // 3, (2 * g.n) // 3 + 1 if g.n > 3 else g.n, g.n})
+        for st, (src, dst) in enumerate(((x, h1), (h1, h2), (h2, sc))):
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                e.stage_forward_device(st, lo, hi, src.data_ptr(), dst.data_ptr(), lgd.data_ptr() if st == 2 else 0)
+        e.synchronize()
+        assert np.array_equal(bits(lgd.cpu().numpy()), bits(want))
+        assert float(h1[-1].abs().sum()) == 0.0 and float(h2[-1].abs().sum()) == 0.0   # pad rows untouched
+        e.set_option("wide_tiles", 0)
+        e.upload_graph(g)
+        _, lg = e.forward(g.x())
+        assert np.array_equal(bits(lg[:, 0]), bits(want))
+        assert e.get_info("wide_tiles_used") == 0
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("maker,fits", [
     (lambda: gg.erdos_renyi(100000, 1000000, 1), True),        # BASELINE configs[1]: four live columns
     (lambda: gg.erdos_renyi(60000, 900000, 81), True),         # 30 entries a row
