@@ -58,6 +58,7 @@ WORKLOADS = {
     "er10m": (10_000_000, 100_000_000, 10),   # the metric graph
     "er1m": (1_000_000, 10_000_000, 2),
     "er100k": (100_000, 1_000_000, 1),
+    "er20k": (19_675, 98_000, 4),             # the size of the reference CLI's third predict call on ER-100K (src/GNN_VC.cpp:171-192)
     "er3m": (3_000_000, 30_000_000, 3),       # feature table (192 MB) fits the Infinity Cache
     # the other BASELINE.json configs (parity-test cases; selectable here for profiling)
     "rmat24": ("rmat", 24, 16, 24),
@@ -143,8 +144,8 @@ def main() -> int:
     ap.add_argument("--cpu-sample", default="",
                     help="CPU baseline on a bounded sample 'NxM' of the workload's family instead of the workload graph itself "
                          "(default: the graph itself — ~50 s of CPU work on the metric graph)")
-    ap.add_argument("--no-workloads", action="store_true", help="skip the `workloads` block (er100k, er3m, rmat22, rmat24, powerlaw1m)")
-    ap.add_argument("--workloads", default="er100k,er3m,rmat22,rmat24,powerlaw1m", help="comma-separated side workloads of the default run")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the `workloads` block (er20k, er100k, er3m, rmat22, rmat24, powerlaw1m)")
+    ap.add_argument("--workloads", default="er20k,er100k,er3m,rmat22,rmat24,powerlaw1m", help="comma-separated side workloads of the default run")
     ap.add_argument("--no-host-path", action="store_true", help="skip host_path_ms (PCIe-inclusive gnnvc_forward)")
     ap.add_argument("--no-blocked", action="store_true", help="disable the column-blocked F=1 stage (A/B)")
     ap.add_argument("--block-cols", type=int, default=0)
@@ -989,6 +990,7 @@ def side_workload(name, args, dev, make_engine, ggt):
                     # (graphs of 50 - 400 K vertices: the 16-wide stages gather an L2-resident table, DESIGN.md 5 "Table tiles")
                     "table_tiles": [bool(e.get_info("table_tiles_fit_stage1")), bool(e.get_info("table_tiles_fit_stage2"))]
                     if e.get_info("table_tiles_active") else None,
+                    "wide_tiles": bool(e.get_info("wide_tiles_used")),   # (small graphs: a workgroup per tile, DESIGN.md 5 "Wide tiles")
                     # (skewed graphs: the long / giant rows' kernels have to run BESIDE the tile kernel — a side queue that shares the
                     # main stream's hardware queue serialises them and nothing else would say so)
                     "side_queue_runs_beside": bool(e.get_info("side_queue_runs_beside")) if e.get_info("long_rows") else None}}

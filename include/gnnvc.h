@@ -200,6 +200,12 @@ int gnnvc_get_stream(gnnvc_engine *e, void **hip_stream);
  *                         "pruned_predicted_stage1", "pruned_borrowed_stage2"
  *   "dense_skip_zeros" 0|1  (round 4; A/B) the aggregate-only dense kernels of the compact-table plan leave out the first-layer
  *                         terms they know to be zero (default 1; bit-identical)
+ *   "wide_tiles"     0|1  (round 4) graphs with fewer 64-vertex tiles than the chip has SIMDs — the reference CLI's later predict
+ *                         calls — run a stage a WORKGROUP per tile (the gather on quads of lanes over four waves, each dense
+ *                         layer's outputs a quarter per wave: the same fma chains, the same bits): the F = 1 stage up to
+ *                         "wide_tiles_max_n" vertices (default 49 152), the 16-wide stages up to "wide_tiles_max_n_f16"
+ *                         (default 131 072) where no plan has the stage; graphs without long rows.  Default 1.
+ *                         gnnvc_get_info "wide_tiles_used"
  *   "table_tiles"    0|1  (round 4) graphs of "table_tiles_min_n" (default 49 152) vertices and more whose 16-byte-per-vertex
  *                         table fits "table_tiles_max_bytes" (default 6 MiB: n <= 393 K) and that are outside the compact-table
  *                         plan's range, without long rows: whole forwards gather the 16-wide stages' neighbours from an

@@ -18,7 +18,7 @@ if has trace; then
   rm -rf "$OUT/trace"
   timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --no-cpu-baseline --no-variants --no-workloads --no-host-path > "$OUT/bench_under_rocprof.log" 2>&1
 fi
-for w in er100k rmat22 powerlaw1m; do   # kernel stats of the other workloads' steady state (the same bench command, one workload)
+for w in er20k er100k rmat22 powerlaw1m; do   # kernel stats of the other workloads' steady state (the same bench command, one workload)
   if has trace_$w || has trace; then
     rm -rf "$OUT/trace_$w"
     timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$w" -- python3 bench.py --workload $w --steps 50 --no-cpu-baseline --no-variants --no-workloads --no-host-path > "$OUT/bench_under_rocprof_$w.log" 2>&1
@@ -33,7 +33,7 @@ if has er10m; then
   pass er10m_plain p_rd "--plain 1" TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum
   pass er10m_plain p_wr "--plain 1" WRITE_SIZE TCC_REQ_sum
 fi
-for w in er100k er3m rmat22 rmat24 powerlaw1m; do
+for w in er20k er100k er3m rmat22 rmat24 powerlaw1m; do
   if has $w; then
     pass $w p_rd "--workload $w" TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum
     pass $w p_wr "--workload $w" WRITE_SIZE TCC_REQ_sum

@@ -32,7 +32,7 @@ if stats:
     keep = [rows[0]] + [[short(r[0])] + r[1:] for r in rows[1:] if "gnnvc" in r[0]]
     with open(DST / "kernel_stats.csv", "w", newline="") as f:
         csv.writer(f).writerows(keep)
-for w in ("er100k", "rmat22", "powerlaw1m"):
+for w in ("er20k", "er100k", "rmat22", "powerlaw1m"):
     st = sorted(glob.glob(str(SRC / f"trace_{w}" / "*" / "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)
     if st:
         rows = list(csv.reader(open(st[0])))
