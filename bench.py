@@ -337,16 +337,12 @@ def main() -> int:
     piece_rows = [0]   # set after the first forward: pieces of 256 of the engine's chunks, so that no piece ends inside one
     fwd_scores = torch.zeros(n, dtype=torch.float32, device=dev)
     fwd_logits = torch.zeros(n, dtype=torch.float32, device=dev)
-    engine_stage_ms = []
 
     def step(k: int | None):
         if not multi:
             # one GPU: the whole forward inside the engine (its own feature buffers; per-stage HIP events on this
             # stream are read back after the timed region)
             eng.forward_device(x.data_ptr(), fwd_scores.data_ptr(), fwd_logits.data_ptr())
-            if k is not None and k == args.steps - 1:
-                torch.cuda.synchronize()
-                engine_stage_ms.append(eng.last_forward_ms()[1])
             return
         hook = None
         if k is None and os.environ.get("GNNVC_BENCH_TRACE") == "2":
@@ -429,9 +425,14 @@ def main() -> int:
     exchange_ok = D.exchange_verified(bufs) if codec is not None else True   # no shipped row hid a non-zero
 
     if not multi:
-        # the engine's own HIP events (same stream) around each stage of the last timed forward; the mean step time
-        # of the K timed forwards is ms_per_step
-        stage_ms = list(engine_stage_ms[0])
+        # the engine's own HIP events (same stream) around each stage of ONE more forward right after the timed region (option
+        # "forward_timing" 2: the timed forwards record no events — four records were 5.5 us of a small forward); the mean step
+        # time of the K timed forwards is ms_per_step
+        eng.set_option("forward_timing", 2)
+        eng.forward_device(x.data_ptr(), fwd_scores.data_ptr(), fwd_logits.data_ptr())
+        torch.cuda.synchronize()
+        stage_ms = list(eng.last_forward_ms()[1])
+        eng.set_option("forward_timing", 0)
     else:
         stage_ms = [sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for ev in stage_evt) / args.steps
                     for i in range(3)]
@@ -747,6 +748,7 @@ def forward_variants(make_engine, attach_whole, x, n, dev):
     attach_whole(e)
     e.synchronize()
     res["fresh_engine_attach_ms"] = (time.perf_counter() - t) * 1e3
+    e.set_option("forward_timing", 1)
     res["fresh_engine_first_forward_ms"] = run(e)
     res["fresh_engine_first_forward_device_ms"] = e.last_forward_ms()[0]
     e.close()
@@ -765,6 +767,8 @@ def forward_variants(make_engine, attach_whole, x, n, dev):
         run(e)
     ts = sorted(run(e) for _ in range(5))
     res["plain_forward_ms"] = ts[len(ts) // 2]
+    e.set_option("forward_timing", 1)
+    run(e)
     res["plain_forward_device_ms"] = e.last_forward_ms()[0]
     res["plain_forward_plans"] = {"blocked_stage0": bool(e.get_info("blocked_stage0_active")), "lds_table": False,
                                   "compact_gather": False, "pruned_adjacency": False}

@@ -711,6 +711,10 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
         const int rc = gnnvc::multi_set_option(e->multi, key, value);
         return rc ? fail(e, rc, "unknown option '%s'", key) : GNNVC_OK;
     }
+    if (k == "forward_timing") {   // (touches nothing a forward has cached)
+        e->opt_timing = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
+        return e->multi ? gnnvc::multi_set_option(e->multi, key, value) : GNNVC_OK;
+    }
     e->short_from = 0;   // (lists a filtered stage left go by the thresholds and variants of the call that wrote them)
     if (k == "blocked_stage0") e->opt_blocked = value < 0 ? 0 : (value > 2 ? 2 : (int)value);   // 2 = also on skewed graphs
     else if (k == "block_cols") e->opt_block_cols = value > 0 ? (uint32_t)value : 0;
@@ -1380,11 +1384,12 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
     if (e->stages.empty()) {
         rc = ensure_events(e, 2);
         if (rc) return rc;
-        HIP_TRY(e, hipEventRecord(e->ev[0], e->stream));
+        if (e->opt_timing >= 1) HIP_TRY(e, hipEventRecord(e->ev[0], e->stream));
         rc = forward_unfused(e, d_x, d_scores, d_logits);
         if (rc) return rc;
-        HIP_TRY(e, hipEventRecord(e->ev[1], e->stream));
-        e->ev_count = 2;
+        if (e->opt_timing >= 1) HIP_TRY(e, hipEventRecord(e->ev[1], e->stream));
+        e->ev_count = e->opt_timing >= 1 ? 2 : 0;
+        e->ev_stages = false;
         return GNNVC_OK;
     }
     const size_t ns = e->stages.size();
@@ -1395,6 +1400,8 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
     e->c4_prepared_stage = -1;
     if (e->fit_pending && hipEventQuery(e->ev_fit) == hipSuccess) {   // the previous forward's verdicts have arrived
         e->fit_pending = false;
+        const uint32_t before = e->lt_unfit_runs + e->t4_unfit_runs + e->c4_unfit_runs[1] + e->c4_unfit_runs[2];
+        const bool seen1 = e->t4_fit_seen[1], seen2 = e->t4_fit_seen[2];
         if (e->lt_used && e->lt_ready) {
             e->lt_unfit_runs = e->fit_pin.p[2] != 0u ? e->lt_unfit_runs + 1 : 0u;
             if (e->lt_unfit_runs >= (e->lt_mapped ? 1u : 3u)) e->lt_off = true;
@@ -1417,6 +1424,9 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
             e->c4_unfit_runs[s] = e->fit_pin.p[s - 1] == 0u ? e->c4_unfit_runs[s] + 1 : 0u;
             if (e->c4_unfit_runs[s] >= 3u) e->c4_stage_off[s] = true;
         }
+        const uint32_t after = e->lt_unfit_runs + e->t4_unfit_runs + e->c4_unfit_runs[1] + e->c4_unfit_runs[2];
+        const bool calm = after == 0u && before == 0u && seen1 == e->t4_fit_seen[1] && seen2 == e->t4_fit_seen[2];
+        e->fit_calm = calm ? e->fit_calm + 1u : 0u;
     }
     if (!e->fit_pending) {
         for (int s = 0; s < 4; ++s) e->fit_used[s] = false;
@@ -1434,15 +1444,19 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
     // over from its previous graph: a fresh engine's first forward on a graph has no table to gather from, and the counting, the
     // choice and the launches that leave at once would only cost the caller who scores the graph once (ER-100K: 0.14 vs 0.11 ms).
     e->t4_now = e->t4_ok && (e->t4_choice_live || e->graph_uses >= 1);
-    HIP_TRY(e, hipEventRecord(e->ev[0], e->stream));
+    // Events (option "forward_timing"): none by default — a record costs the stream ~1.8 us, four of them were 5.5 us of a small
+    // graph's 31 - 82 us forward (scratch/experiments/r4_gaps.sh) — 1 = the forward's first and last, 2 = one per stage as well.
+    // (ev[0] is also what the first-forward plan build on the second stream waits for, below.)
+    const bool build_under_stage0 = ns >= 2 && !e->c4_tried && !e->c4_range_mode && e->aux_stream && e->n_long == 0 && !e->sorted_wanted &&
+                                    e->opt_compact_first_entries && e->g.nnz >= e->opt_compact_first_entries;
+    if (e->opt_timing >= 1 || build_under_stage0) HIP_TRY(e, hipEventRecord(e->ev[0], e->stream));
     for (size_t s = 0; s < ns; ++s) {
         const bool last = s + 1 == ns;
         float *dst = last ? d_scores : e->h[s & 1].p;
         rc = run_stage(e, (int)s, 0, n, cur, dst, last ? d_logits : nullptr, /*in_forward=*/true);
         if (rc) break;
-        if (hipEventRecord(e->ev[s + 1], e->stream) != hipSuccess) { rc = fail(e, GNNVC_ERR_DEVICE, "hipEventRecord failed"); break; }
-        if (s == 0 && ns >= 2 && !e->c4_tried && !e->c4_range_mode && e->aux_stream && e->n_long == 0 && !e->sorted_wanted &&
-            e->opt_compact_first_entries && e->g.nnz >= e->opt_compact_first_entries) {
+        if ((e->opt_timing >= 2 || (last && e->opt_timing == 1)) && hipEventRecord(e->ev[s + 1], e->stream) != hipSuccess) { rc = fail(e, GNNVC_ERR_DEVICE, "hipEventRecord failed"); break; }
+        if (s == 0 && build_under_stage0 && !e->c4_tried) {
             // A large graph's first forward: the compact-table plan of the stages to come depends on the graph alone — it is
             // built now, on the second stream, under the kernels of stage 0 that were just queued (the build synchronises with
             // its own stream only; it is complete when it returns).
@@ -1462,24 +1476,36 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
         e->t4_parity ^= 1u;
         e->t4_choice_live = true;
     }
-    e->ev_count = (int)ns + 1;
+    e->ev_count = e->opt_timing >= 1 ? (int)ns + 1 : 0;
+    e->ev_stages = e->opt_timing >= 2;
     const bool c4_verdicts = (e->fit_used[1] || e->fit_used[2]) && e->c4_ready && e->c4_desc.p;
     const bool lt_verdict = e->lt_used && e->lt_ready && e->lt_bad.p;
     const bool t4_verdict = e->t4_now && e->t4_desc.p;
     if (t4_verdict && !e->fit_pending) e->t4_used = true;
-    if (!e->fit_pending && (c4_verdicts || lt_verdict || t4_verdict)) {   // this forward's verdicts, copied out behind it
+    if (!e->fit_pending && (c4_verdicts || lt_verdict || t4_verdict)) {   // this forward's verdicts, written out behind it
+        // ONE small kernel stores the words into page-locked host memory (round 4: they were up to five 4-byte hipMemcpyAsync, ~20 us
+        // of a small graph's forward + wait, scratch/experiments/r4_gaps.sh), and once four verdicts in a row have changed nothing
+        // only every eighth forward asks — a verdict steers which kernels the NEXT forwards launch, never a result: every plan
+        // proves its input on the device in every call.
+        const bool ask = e->fit_calm < 4u || (++e->fit_skip & 7u) == 0u;
+        if (!ask) {
+            if (!c4_verdicts) for (int s = 1; s <= 2; ++s) e->fit_used[s] = false;
+            return GNNVC_OK;
+        }
         if (!e->ev_fit) HIP_TRY(e, hipEventCreateWithFlags(&e->ev_fit, hipEventDisableTiming));
-        HIP_TRY(e, e->fit_pin.reserve(8));
+        if (!e->fit_dev) {
+            HIP_TRY(e, e->fit_pin.reserve(8));
+            HIP_TRY(e, hipHostGetDevicePointer(reinterpret_cast<void **>(&e->fit_dev), e->fit_pin.p, 0));
+        }
+        gnnvc::VerdictWords vw;
         if (c4_verdicts)
-            for (int s = 1; s <= 2; ++s)
-                HIP_TRY(e, hipMemcpyAsync(e->fit_pin.p + (s - 1), e->c4_desc.p + gnnvc_engine::kDescWords * (s - 1), sizeof(uint32_t),
-                                          hipMemcpyDeviceToHost, e->stream));
+            for (int s = 1; s <= 2; ++s) vw.src[s - 1] = e->c4_desc.p + gnnvc_engine::kDescWords * (s - 1);
         else
             for (int s = 1; s <= 2; ++s) e->fit_used[s] = false;
-        if (lt_verdict) HIP_TRY(e, hipMemcpyAsync(e->fit_pin.p + 2, e->lt_bad.p, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+        if (lt_verdict) vw.src[2] = e->lt_bad.p;
         if (t4_verdict)   // (the parity has flipped: the descriptors this forward wrote are the current ones)
-            for (int s = 1; s <= 2; ++s)
-                HIP_TRY(e, hipMemcpyAsync(e->fit_pin.p + 2 + s, e->t4_desc_of(s, e->t4_parity) + 8, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+            for (int s = 1; s <= 2; ++s) vw.src[2 + s] = e->t4_desc_of(s, e->t4_parity) + 8;
+        HIP_TRY(e, gnnvc::write_verdicts(vw, e->fit_dev, e->stream));
         HIP_TRY(e, hipEventRecord(e->ev_fit, e->stream));
         e->fit_pending = true;
     }
@@ -1746,13 +1772,16 @@ int gnnvc_last_forward_ms(gnnvc_engine *e, float *total_ms, float *stage_ms, int
         for (int s = 0; stage_ms && s < max_stages; ++s) stage_ms[s] = 0.0f;
         return GNNVC_OK;
     }
-    if (e->ev_count < 2) return fail(e, GNNVC_ERR_STATE, "no timed forward yet");
+    if (e->ev_count < 2)
+        return fail(e, GNNVC_ERR_STATE, e->opt_timing ? "no timed forward yet" : "no timed forward: option forward_timing is 0 (1 = total, 2 = per stage)");
     int rc = use_device(e);
     if (rc) return rc;
     HIP_TRY(e, hipEventSynchronize(e->ev[e->ev_count - 1]));
     if (total_ms) HIP_TRY(e, hipEventElapsedTime(total_ms, e->ev[0], e->ev[e->ev_count - 1]));
-    for (int s = 0; stage_ms && s < max_stages && s + 1 < e->ev_count; ++s)
-        HIP_TRY(e, hipEventElapsedTime(&stage_ms[s], e->ev[s], e->ev[s + 1]));
+    for (int s = 0; stage_ms && s < max_stages && s + 1 < e->ev_count; ++s) {
+        if (e->ev_stages) HIP_TRY(e, hipEventElapsedTime(&stage_ms[s], e->ev[s], e->ev[s + 1]));
+        else stage_ms[s] = -1.0f;   // (forward_timing 1: the stages' events were not recorded)
+    }
     return GNNVC_OK;
 }
 

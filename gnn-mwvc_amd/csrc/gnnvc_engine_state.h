@@ -104,6 +104,7 @@ struct gnnvc_engine {
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::vector<hipEvent_t> ev;  // stage boundaries of the last forward
     int ev_count = 0;
+    bool ev_stages = false;                  // the last forward recorded an event per stage (forward_timing 2)
 
     DevBuf<float> params;
     // graph
@@ -282,6 +283,10 @@ struct gnnvc_engine {
     bool t4_fit_seen[4] = {false, false, false, false};   // the stage's table fit in the last forward whose verdict has arrived
     int opt_t4_solo = 1;                     // option "table_tiles_solo" (A/B): 0 = always launch the gathering kernel behind the tiles
     uint32_t t4_unfit_runs = 0;              // forwards in a row whose first 16-wide stage left the launch to the gathering kernel
+    int opt_timing = 0;                      // option "forward_timing": 0 = a forward records no events (gnnvc_last_forward_ms is refused), 1 = its first and last, 2 = one per stage too
+    uint32_t *fit_dev = nullptr;             // fit_pin as the device sees it (the verdict words are WRITTEN there by one small kernel)
+    uint32_t fit_calm = 0;                   // verdicts in a row that changed nothing: from four on, only every eighth forward asks
+    uint32_t fit_skip = 0;
     int opt_wide = 1;                        // option "wide_tiles": graphs of up to "wide_tiles_max_n" vertices run their plain stages a workgroup per tile
     uint32_t opt_wide_max_n = 49152;         // the F = 1 stage ("wide_tiles_max_n": where the table tiles start — feeding them from wide tiles was measured slower) ...
     uint32_t opt_wide_max_n16 = 131072;      // ... and the 16-wide stages ("wide_tiles_max_n_f16") up to these many vertices (measured: small_sizes.py)

@@ -120,6 +120,13 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
                         const float *table_in = nullptr /* acc4: the compact table of THIS stage's input (one pass), so that the dense
                                                            kernel takes a row's own live values from it; null = from the full rows */,
                         const uint32_t *skip_flag = nullptr /* (no acc4) a device word: != 0 = another kernel has done this launch's rows */);
+// A forward's verdict words (did the LDS-table / compact-table / table-tile plans fit this input: device words the plans' kernels
+// leave behind), stored into page-locked host memory by ONE small kernel: out[i] = src[i] ? *src[i] : 0 (out as the device sees it)
+struct VerdictWords {
+    const uint32_t *src[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+hipError_t write_verdicts(const VerdictWords &vw, uint32_t *out_dev, hipStream_t stream);
+
 // a whole stage (variants 0, 1, 2) on WIDE tiles — a workgroup per 64-vertex tile, the tile's gather and each dense layer's outputs
 // split over its four waves (k_stage_w1 / k_stage_w16): graphs with fewer tiles than the chip has SIMDs, no long rows
 hipError_t launch_stage_wide(const StagePlan &sp, const GraphDev &g, float ws, const float *params, const float *in, float *out,

@@ -4721,6 +4721,15 @@ __global__ void k_spin(unsigned long long ticks) {
     const unsigned long long t0 = wall_clock64();   // (100 MHz)
     for (int i = 0; i < (1 << 22) && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(16);
 }
+__global__ void k_verdicts(VerdictWords vw, uint32_t *__restrict__ out) {
+    const int i = threadIdx.x;
+    if (i < 8) out[i] = vw.src[i] ? *vw.src[i] : 0u;
+}
+hipError_t write_verdicts(const VerdictWords &vw, uint32_t *out_dev, hipStream_t stream) {
+    GNNVC_LAUNCH(k_verdicts, dim3(1), dim3(64), 0, stream, vw, out_dev);
+    return hipGetLastError();
+}
+
 __global__ void k_nothing() {}
 
 hipError_t streams_run_side_by_side(hipStream_t a, hipStream_t b, bool *yes) {

@@ -1228,6 +1228,7 @@ void reset_graph_state(gnnvc_engine *e) {
     e->short_from = 0;
     for (int s = 0; s < 4; ++s) { e->c4_stage_off[s] = false; e->c4_unfit_runs[s] = 0; e->fit_used[s] = false; }
     e->fit_pending = false;
+    e->fit_calm = e->fit_skip = 0;
     e->c4_range_mode = false;
     e->c4_prepared_stage = -1;
     e->blocked_ready = false;   // the column-blocked index is built on the graph's SECOND forward:

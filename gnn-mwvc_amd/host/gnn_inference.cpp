@@ -536,6 +536,7 @@ void model::predict(const matrix &in, matrix &out, const reduction_graph<Tn, Tw>
     }();
     const bool sig = host_sigmoid && !layers.empty() && std::holds_alternative<sigmoid>(layers.back());
     if (sig) in_copy.resize(n, (size_t)ow);  // the reference's scratch member: holds the logits here
+    if (trace) gnnvc_set_option(e, "forward_timing", 2);   // (a forward records no events unless asked to)
     check(gnnvc_forward(e, cdata(in), mdata(out), sig ? mdata(in_copy) : nullptr), "gnnvc_forward", e);
     if (sig) {
         for (size_t i = 0; i < (size_t)n * ow; ++i) {

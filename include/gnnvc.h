@@ -200,6 +200,9 @@ int gnnvc_get_stream(gnnvc_engine *e, void **hip_stream);
  *                         "pruned_predicted_stage1", "pruned_borrowed_stage2"
  *   "dense_skip_zeros" 0|1  (round 4; A/B) the aggregate-only dense kernels of the compact-table plan leave out the first-layer
  *                         terms they know to be zero (default 1; bit-identical)
+ *   "forward_timing" 0|1|2  (round 4) HIP events of a forward for gnnvc_last_forward_ms: 0 (default) = none — a record costs the
+ *                         stream ~1.8 us, four of them were 5.5 us of a 30 - 80 us forward —, 1 = the forward's first and last
+ *                         (total only), 2 = one per stage too
  *   "wide_tiles"     0|1  (round 4) graphs with fewer 64-vertex tiles than the chip has SIMDs — the reference CLI's later predict
  *                         calls — run a stage a WORKGROUP per tile (the gather on quads of lanes over four waves, each dense
  *                         layer's outputs a quarter per wave: the same fma chains, the same bits): the F = 1 stage up to
@@ -428,7 +431,9 @@ int gnnvc_score_keys(gnnvc_engine *e, const float *d_scores, uint32_t n, float *
 int gnnvc_synchronize(gnnvc_engine *e);
 
 /* hipEvent timings of the last gnnvc_forward / gnnvc_forward_device on the
- * engine's stream: total and per stage, in milliseconds (waits for them). */
+ * engine's stream: total and per stage, in milliseconds (waits for them).  A forward records
+ * events only when option "forward_timing" asks for them: 0 (the default) -> GNNVC_ERR_STATE,
+ * 1 -> the total (stage_ms[] = -1), 2 -> total and stages. */
 int gnnvc_last_forward_ms(gnnvc_engine *e, float *total_ms, float *stage_ms, int max_stages);
 
 /* Per-kernel HIP-event timings of the gnnvc_forward_device calls made since the last call of this function, when

@@ -16,6 +16,7 @@ for hi, label in ((120, "U[20,120]"), (1000, "U[20,1000]"), (60000, "U[20,60000]
             continue
         e = G.Engine(G.default_model_text(), device=0)
         for k, v in opts.items(): e.set_option(k, v)
+        e.set_option("forward_timing", 2)
         e.set_weight_scale(g.ws)
         e.attach_graph_device(g.n, g.nnz, g.rowptr.data_ptr(), g.col.data_ptr(), g.w.data_ptr(), g.nw.data_ptr(), keepalive=g)
         for _ in range(4): e.forward_device(x.data_ptr(), sc.data_ptr(), lg.data_ptr())

@@ -7,7 +7,7 @@ import gnn_mwvc_amd as G
 from tools import graphgen_torch as ggt
 dev = torch.device("cuda", 0)
 opts = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in sys.argv[1:]}
-for n, m in ((2000, 8000), (7000, 30000), (20000, 100000), (41000, 200000), (100000, 1000000), (300000, 3000000), (1000000, 10000000)):
+for n, m in ((2000, 8000), (7000, 30000), (20000, 100000), (41000, 200000), (60000, 600000), (100000, 1000000), (140000, 1400000), (300000, 3000000), (1000000, 10000000)):
     g = ggt.erdos_renyi(n, m, 1, dev)
     x = g.x().contiguous()
     sc = torch.zeros(g.n, device=dev); lg = torch.zeros(g.n, device=dev)

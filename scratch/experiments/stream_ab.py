@@ -16,6 +16,7 @@ torch.cuda.synchronize()
 def measure(tag, use_torch_stream, pre=None):
     if pre: pre()
     e = G.Engine(G.default_model_text(), device=0)
+    e.set_option("forward_timing", 2)
     e.set_weight_scale(g.ws)
     e.attach_graph_device(g.n, g.nnz, g.rowptr.data_ptr(), g.col.data_ptr(), g.w.data_ptr(), g.nw.data_ptr(), keepalive=g)
     if use_torch_stream:
