@@ -585,6 +585,13 @@ int gnnvc_create(gnnvc_engine **out, const char *model_text, size_t len, int dev
         // hand-off or forward that wants them)
         if (rc == GNNVC_OK) rc = ensure_round_events(e, 0);
         if (rc == GNNVC_OK) rc = upload_params(e);
+        // (the page-locked words a forward's verdicts are written to: a pinned allocation is tens of microseconds — here, not in
+        // the first forward that asks)
+        if (rc == GNNVC_OK && (e->fit_pin.reserve(8) != hipSuccess ||
+                               hipHostGetDevicePointer(reinterpret_cast<void **>(&e->fit_dev), e->fit_pin.p, 0) != hipSuccess))
+            rc = fail(e, GNNVC_ERR_NOMEM, "page-locked verdict words");
+        if (rc == GNNVC_OK && hipEventCreateWithFlags(&e->ev_fit, hipEventDisableTiming) != hipSuccess)
+            rc = fail(e, GNNVC_ERR_DEVICE, "hipEventCreate failed");
     } catch (const std::bad_alloc &) {
         rc = GNNVC_ERR_NOMEM;
     } catch (...) {

@@ -464,8 +464,11 @@ void reset_graph_state(gnnvc_engine *e);
 int handoff_early(gnnvc_engine *e, uint32_t n, uint64_t nnz);
 // host wall time of a plan build, added to plan_build_ms (what was queued before is drained first: not the plan's cost)
 template <class F>
-int timed_build(gnnvc_engine *e, F &&f) {
-    (void)hipStreamSynchronize(e->stream);
+int timed_build(gnnvc_engine *e, F &&f, bool may_build = true) {
+    // (may_build false: the caller can already see that f will leave at its first test — a graph too small for the plan — and the
+    // wait that keeps earlier work out of the build's time would only stall the forward: five of them made a small graph's SECOND
+    // forward 60 us where its third takes 34)
+    if (may_build) (void)hipStreamSynchronize(e->stream);
     const auto t0 = std::chrono::steady_clock::now();
     const int rc = f();
     e->plan_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

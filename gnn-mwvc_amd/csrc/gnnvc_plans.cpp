@@ -758,10 +758,15 @@ gnnvc::CompactPlan compact_plan(const gnnvc_engine *e) {
     return cp;
 }
 
-int build_blocked(gnnvc_engine *e) { return timed_build(e, [&] { return build_blocked_impl(e); }); }
-int build_lds_table(gnnvc_engine *e) { return timed_build(e, [&] { return build_lds_table_impl(e); }); }
+int build_blocked(gnnvc_engine *e) {
+    return timed_build(e, [&] { return build_blocked_impl(e); }, e->opt_blocked && e->g.n >= e->opt_blocked_min_n && e->g.nnz != 0);
+}
+int build_lds_table(gnnvc_engine *e) {
+    return timed_build(e, [&] { return build_lds_table_impl(e); }, e->opt_lds_table && e->g.n >= e->opt_blocked_min_n && e->g.nnz != 0);
+}
 int build_compact(gnnvc_engine *e, uint32_t base, uint32_t end) {
-    return timed_build(e, [&] { return build_compact_impl(e, base, end); });
+    return timed_build(e, [&] { return build_compact_impl(e, base, end); },
+                       e->opt_compact && e->g.n >= std::min(e->opt_blocked_min_n, e->opt_compact_min_n) && e->g.nnz != 0);
 }
 
 // The engine's SIDE queue, made once per engine (gnnvc_create): what runs beside the main stream's kernels — the dense part of a
@@ -1006,7 +1011,8 @@ int gather_view(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const floa
     }
     if (!pp.tried && e->graph_uses >= uses_needed) {
         const bool first_forward = e->graph_uses < 2;
-        int rc = timed_build(e, [&] { return build_prune_impl(e, stage, in, first_forward); });
+        int rc = timed_build(e, [&] { return build_prune_impl(e, stage, in, first_forward); },
+                             e->opt_prune && e->g.n != 0 && e->g.nnz >= e->opt_prune_min_nnz);
         if (rc) return rc;
     }
     // A graph's FIRST forward, the stage behind one that runs on a predicted plan: it borrows that plan — the model keeps the hubs'

@@ -429,6 +429,43 @@ def test_staged_hand_off_errors(model_text):
         e.close()
 
 
+def test_forward_timing_option(model_text, oracle_model):
+    """Round 4: a forward records HIP events only when option "forward_timing" asks for them (four records were 5.5 us of a 30 us
+    forward): 0, the default — gnnvc_last_forward_ms is a state error; 1 — the total; 2 — the stages too.  Same logits either way;
+    the verdict words of the per-graph plans still reach the host (one small kernel instead of copies)."""
+    import gnn_mwvc_amd as G
+    g = gg.erdos_renyi(60000, 600000, 5)
+    oracle_model.set_weight_scale(g.ws)
+    want = oracle_model.logits(g)
+    e = G.Engine(model_text, device=0)
+    try:
+        e.set_weight_scale(g.ws)
+        e.upload_graph(g)
+        _, lg = e.forward(g.x())
+        assert np.array_equal(bits(lg[:, 0]), bits(want))
+        with pytest.raises(G.GnnvcError):
+            e.last_forward_ms()
+        e.set_option("forward_timing", 1)
+        _, lg = e.forward(g.x())
+        assert np.array_equal(bits(lg[:, 0]), bits(want))
+        total, stages = e.last_forward_ms()
+        assert 0.0 < total < 50.0 and all(s == -1.0 for s in stages)
+        e.set_option("forward_timing", 2)
+        for rep in range(12):    # (... and on through the table tiles' steady state, where only every eighth forward asks for verdicts)
+            _, lg = e.forward(g.x())
+            assert np.array_equal(bits(lg[:, 0]), bits(want)), rep
+        total, stages = e.last_forward_ms()
+        assert len(stages) == 3 and all(s > 0.0 for s in stages) and abs(sum(stages) - total) < 0.05 * total + 0.01
+        assert e.get_info("table_tiles_fit_stage1") == 1 and e.get_info("table_tiles_fit_stage2") == 1
+        e.set_option("forward_timing", 0)
+        _, lg = e.forward(g.x())
+        assert np.array_equal(bits(lg[:, 0]), bits(want))
+        with pytest.raises(G.GnnvcError):
+            e.last_forward_ms()
+    finally:
+        e.close()
+
+
 def test_errors(engine):
     import gnn_mwvc_amd as G
     g = gg.erdos_renyi(100, 300, 18)
