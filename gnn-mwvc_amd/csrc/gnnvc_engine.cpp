@@ -660,7 +660,7 @@ void gnnvc_destroy(gnnvc_engine *e) {
     e->prune_flags.release(); e->prune_scratch.release(); e->prune_off.release(); e->prune_mask.release();
     for (auto &b : e->filter_bits) b.release();
     e->filter_info.release();
-    e->long_list.release(); e->long_count.release();
+    e->long_list.release(); e->long_count.release(); e->cls_dev.release(); e->cls_pin.release();
     e->gi_meta.release(); e->gi_off.release(); e->gi_slab.release(); e->gi_agg.release(); e->gi_segsum.release(); e->gi_segmap.release();
     e->rowptr2.release(); e->col2.release(); e->der_old_row.release(); e->der_new_of.release(); e->der_tail.release();
     e->der_tailptr.release(); e->der_tailcols.release(); e->hash_buf.release();
@@ -965,10 +965,15 @@ static int adopt_uploaded(gnnvc_engine *e, uint32_t n, uint64_t nnz) {
     }
     {
         const GraphDev cand{n, nnz, e->rowptr.p, e->col.p, e->w.p, e->nw.p};
-        HIP_TRY(e, gnnvc::validate_graph(cand, e->blk_flag.p, e->stream));
         uint32_t bad = 0;
-        HIP_TRY(e, hipMemcpyAsync(&bad, e->blk_flag.p, sizeof bad, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        if (e->early_open) {   // (the graph was classed when its row pointers arrived: only the checks are left)
+            HIP_TRY(e, gnnvc::validate_graph(cand, e->blk_flag.p, e->stream));
+            HIP_TRY(e, hipMemcpyAsync(&bad, e->blk_flag.p, sizeof bad, hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(e, hipStreamSynchronize(e->stream));
+        } else {
+            const int rc0 = classify_hand_off(e, cand, bad);
+            if (rc0) return rc0;
+        }
         if (bad) {
             e->have_graph = false;
             if (e->early_open) {   // plans begun from this graph's arrays: worthless
@@ -1171,12 +1176,11 @@ int gnnvc_commit_staged_graph(gnnvc_engine *e) {
 }
 
 static int attach_common(gnnvc_engine *e, const GraphDev &cand) {
-    {   // a column id >= n would send the gather to a wild address: check before accepting the graph
-        HIP_TRY(e, e->blk_flag.reserve(1));
-        HIP_TRY(e, gnnvc::validate_graph(cand, e->blk_flag.p, e->stream));
+    {   // a column id >= n would send the gather to a wild address: check before accepting the graph — and, in the same pass of
+        // the stream, learn what find_long is about to ask (classify_hand_off: one wait instead of four)
         uint32_t bad = 0;
-        HIP_TRY(e, hipMemcpyAsync(&bad, e->blk_flag.p, sizeof bad, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        const int rc0 = classify_hand_off(e, cand, bad);
+        if (rc0) return rc0;
         if (bad) {
             e->have_graph = false;
             return fail(e, GNNVC_ERR_INVALID, "%s", (bad & 1u) ? "a column id is not a vertex of this graph (col[i] >= n)"

@@ -335,6 +335,17 @@ struct gnnvc_engine {
     bool opt_long_auto = true;        // no explicit threshold: 256 where few rows are that long, else 512
     uint32_t long_thresh = 0xFFFFFFFFu, n_long = 0;
     DevBuf<uint32_t> long_list, long_count;
+    // what classify_hand_off learned about a graph in its one round trip, for the find_long that follows it
+    struct PreClass {
+        bool valid = false, cuts = false, waste = false, longs = false;
+        uint32_t lo = 0, hi = 0, waste_thresh = 0, heavy_from = 0, long_thresh = 0;
+        uint32_t cut[9] = {0};
+        unsigned long long sums[2] = {0, 0};
+        uint32_t found[4] = {0, 0, 0, 0};
+    } pre;
+    DevBuf<uint32_t> cls_dev;                // classify_graph's 16 words of device scratch
+    PinBuf<uint32_t> cls_pin;                // ... and its 24 result words
+    uint32_t *cls_pin_dev = nullptr;
     uint64_t long_entries = 0;       // entries of the listed rows
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -454,6 +465,7 @@ int ensure_side_streams(gnnvc_engine *e);
 int reprobe_side_streams(gnnvc_engine *e);
 int ensure_round_events(gnnvc_engine *e, size_t count);
 int ensure_events(gnnvc_engine *e, size_t count);
+int classify_hand_off(gnnvc_engine *e, const GraphDev &cand, uint32_t &bad);
 int gather_view(gnnvc_engine *e, int stage, uint32_t lo, uint32_t hi, const float *in, bool gathering, bool sorted_tiles,
                 GraphDev &gv, gnnvc::SortedOrder &so_p, bool matrix_cores = true, uint32_t long_from = 0xFFFFFFFFu);
 int reserve_features(gnnvc_engine *e, uint32_t n);

@@ -120,6 +120,19 @@ hipError_t launch_stage(const StagePlan &sp, const GraphDev &g, float ws, const 
                         const float *table_in = nullptr /* acc4: the compact table of THIS stage's input (one pass), so that the dense
                                                            kernel takes a row's own live values from it; null = from the full rows */,
                         const uint32_t *skip_flag = nullptr /* (no acc4) a device word: != 0 = another kernel has done this launch's rows */);
+// What a hand-off wants to know about a graph before it accepts and classes it, in ONE pass of the stream and one wait (round 4;
+// it used to be four round trips — the checks, nine row pointers, the tiles' lockstep cost, the long rows — 0.2 of a mid-size
+// graph's 0.3 ms attach): k_validate_graph, then (all three read row pointers only, so an invalid graph cannot send them astray)
+// the row pointers at the eighths of the row range, k_tile_waste and k_find_long, and one kernel that stores the results into
+// page-locked memory.  dev_words: 16 words of device scratch.  out_dev (as the device sees it), 18 words: [0] validation flags,
+// [1..9] rowptr at the nine cuts, [10..13] k_tile_waste's two 64-bit sums, [14..17] k_find_long's count words.
+struct GraphClassArgs {
+    bool cuts = false, waste = false, longs = false;
+    uint32_t waste_thresh = 0xFFFFFFFFu, heavy_from = 1, long_thresh = 0xFFFFFFFFu;
+    uint32_t *long_list = nullptr;   // room for every row the engine holds
+};
+hipError_t classify_graph(const GraphDev &g, const GraphClassArgs &a, uint32_t *dev_words, uint32_t *out_dev, hipStream_t stream);
+
 // A forward's verdict words (did the LDS-table / compact-table / table-tile plans fit this input: device words the plans' kernels
 // leave behind), stored into page-locked host memory by ONE small kernel: out[i] = src[i] ? *src[i] : 0 (out as the device sees it)
 struct VerdictWords {

@@ -4721,6 +4721,37 @@ __global__ void k_spin(unsigned long long ticks) {
     const unsigned long long t0 = wall_clock64();   // (100 MHz)
     for (int i = 0; i < (1 << 22) && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(16);
 }
+struct WordList {
+    const uint32_t *src[24];
+};
+__global__ void k_words(WordList wl, uint32_t *__restrict__ out) {
+    const int i = threadIdx.x;
+    if (i < 24 && wl.src[i]) out[i] = *wl.src[i];
+}
+hipError_t classify_graph(const GraphDev &g, const GraphClassArgs &a, uint32_t *dev_words, uint32_t *out_dev, hipStream_t stream) {
+    hipError_t rc = hipMemsetAsync(dev_words, 0, 16 * sizeof(uint32_t), stream);
+    if (rc != hipSuccess) return rc;
+    WordList wl;
+    for (auto &p : wl.src) p = nullptr;
+    wl.src[0] = dev_words;
+    if (g.n) GNNVC_LAUNCH(k_validate_graph, dim3(2048), dim3(256), 0, stream, g, dev_words);
+    const uint32_t lo = g.lo(), hi = g.hi();
+    if (a.cuts && hi > lo)
+        for (int k = 0; k <= 8; ++k) wl.src[1 + k] = g.rowptr + lo + (size_t)((uint64_t)(hi - lo) * k / 8);
+    if (a.waste && hi > lo) {
+        GNNVC_LAUNCH(k_tile_waste, dim3(std::min<unsigned>((hi - lo + 255) / 256, 2048u)), dim3(256), 0, stream, g, lo, hi, a.waste_thresh,
+                     reinterpret_cast<unsigned long long *>(dev_words + 2), a.heavy_from);
+        for (int k = 0; k < 4; ++k) wl.src[10 + k] = dev_words + 2 + k;
+    }
+    if (a.longs && hi > lo && a.long_list) {
+        GNNVC_LAUNCH(k_find_long, dim3(std::min<unsigned>((hi - lo + 255) / 256, 2048u)), dim3(256), 0, stream, g, a.long_thresh, a.long_list,
+                     dev_words + 8);
+        for (int k = 0; k < 4; ++k) wl.src[14 + k] = dev_words + 8 + k;
+    }
+    GNNVC_LAUNCH(k_words, dim3(1), dim3(64), 0, stream, wl, out_dev);
+    return hipGetLastError();
+}
+
 __global__ void k_verdicts(VerdictWords vw, uint32_t *__restrict__ out) {
     const int i = threadIdx.x;
     if (i < 8) out[i] = vw.src[i] ? *vw.src[i] : 0u;

@@ -68,7 +68,56 @@ int find_giant(gnnvc_engine *e) {
 }
 
 // Rows the tile kernels hand to the long-row kernels (per graph).
+// The checks of a candidate graph and what find_long wants to know about it, in one pass of the stream and ONE wait (round 4: a
+// mid-size graph's attach spent 0.2 of its 0.3 ms in four round trips).  bad = the validation flags (the caller refuses the graph);
+// e->pre = the row pointers at the eighths of the row range, the tiles' lockstep cost and the long rows at the first threshold
+// find_long will ask for — consumed by the find_long of the same row range that follows, whatever it decides from them.
+int classify_hand_off(gnnvc_engine *e, const GraphDev &cand, uint32_t &bad) {
+    e->pre = gnnvc_engine::PreClass();
+    HIP_TRY(e, e->cls_dev.reserve(16));
+    if (!e->cls_pin_dev) {
+        HIP_TRY(e, e->cls_pin.reserve(24));
+        HIP_TRY(e, hipHostGetDevicePointer(reinterpret_cast<void **>(&e->cls_pin_dev), e->cls_pin.p, 0));
+    }
+    gnnvc::GraphClassArgs a;
+    const uint32_t glo = cand.lo(), ghi = cand.hi();
+    const bool classes = !e->stages.empty() && cand.n != 0 && ghi > glo;   // (find_long's own first test)
+    gnnvc_engine::PreClass pre;
+    pre.lo = glo;
+    pre.hi = ghi;
+    if (classes) {
+        a.cuts = pre.cuts = cand.nnz && ghi - glo >= 4096;
+        if (e->opt_sorted != 0 && cand.nnz) {
+            a.waste = pre.waste = true;
+            a.waste_thresh = pre.waste_thresh = e->opt_long_thresh ? e->opt_long_thresh : 0xFFFFFFFFu;
+            a.heavy_from = pre.heavy_from =
+                (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, std::max<uint64_t>(1, 4 * cand.nnz / std::max<uint32_t>(ghi - glo, 1)));
+        }
+        if (e->opt_long_thresh) {
+            HIP_TRY(e, e->long_list.reserve(ghi - glo));
+            a.longs = pre.longs = true;
+            a.long_thresh = pre.long_thresh = e->opt_long_auto ? 256u : e->opt_long_thresh;
+            a.long_list = e->long_list.p;
+        }
+    }
+    for (int i = 0; i < 24; ++i) e->cls_pin.p[i] = 0;
+    HIP_TRY(e, gnnvc::classify_graph(cand, a, e->cls_dev.p, e->cls_pin_dev, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    const uint32_t *w = e->cls_pin.p;
+    bad = w[0];
+    if (bad || !classes) return GNNVC_OK;
+    for (int k = 0; k < 9; ++k) pre.cut[k] = w[1 + k];
+    pre.sums[0] = (unsigned long long)w[10] | ((unsigned long long)w[11] << 32);
+    pre.sums[1] = (unsigned long long)w[12] | ((unsigned long long)w[13] << 32);
+    for (int k = 0; k < 4; ++k) pre.found[k] = w[14 + k];
+    pre.valid = true;
+    e->pre = pre;
+    return GNNVC_OK;
+}
+
 int find_long(gnnvc_engine *e) {
+    const gnnvc_engine::PreClass pre = e->pre;   // (what classify_hand_off learned, if it ran for these rows just now)
+    e->pre.valid = false;
     e->n_long = 0;
     e->n_giant = 0;
     e->giant_blocks = 0;
@@ -84,14 +133,19 @@ int find_long(gnnvc_engine *e) {
     e->interleave = false;
     if (e->stages.empty() || g.n == 0 || g.hi() <= g.lo()) return GNNVC_OK;
     const uint32_t glo = g.lo(), ghi = g.hi();   // the rows this engine holds (a slice of a partitioned graph, or all)
+    const bool have_pre = pre.valid && pre.lo == glo && pre.hi == ghi;
     if (g.nnz && ghi - glo >= 4096) {
         // The natural tile map hands each XCD a contiguous eighth of the rows.  If the eighths hold
         // very different numbers of entries (R-MAT: low ids are the hubs) deal tiles round-robin.
         uint32_t cut[9];
-        for (int k = 0; k <= 8; ++k)
-            HIP_TRY(e, hipMemcpyAsync(&cut[k], g.rowptr + glo + (size_t)((uint64_t)(ghi - glo) * k / 8), sizeof(uint32_t),
-                                      hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        if (have_pre && pre.cuts) {
+            for (int k = 0; k <= 8; ++k) cut[k] = pre.cut[k];
+        } else {
+            for (int k = 0; k <= 8; ++k)
+                HIP_TRY(e, hipMemcpyAsync(&cut[k], g.rowptr + glo + (size_t)((uint64_t)(ghi - glo) * k / 8), sizeof(uint32_t),
+                                          hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(e, hipStreamSynchronize(e->stream));
+        }
         uint32_t mx = 0;
         for (int k = 0; k < 8; ++k) mx = std::max(mx, cut[k + 1] - cut[k]);
         e->interleave = (double)mx > 1.25 * (double)g.nnz / 8.0;
@@ -101,10 +155,15 @@ int find_long(gnnvc_engine *e) {
         // lockstep cost of natural 64-row tiles (64 x sum of per-tile maxima) against the useful work
         HIP_TRY(e, e->srt_sum.reserve(2));
         const uint32_t heavy_from = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, std::max<uint64_t>(1, 4 * g.nnz / std::max<uint32_t>(ghi - glo, 1)));
-        HIP_TRY(e, gnnvc::measure_tile_waste(g, glo, ghi, base_thresh, e->srt_sum.p, e->stream, heavy_from));
         unsigned long long sums[2] = {0, 0};
-        HIP_TRY(e, hipMemcpyAsync(sums, e->srt_sum.p, sizeof sums, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        if (have_pre && pre.waste && pre.waste_thresh == base_thresh && pre.heavy_from == heavy_from) {
+            sums[0] = pre.sums[0];
+            sums[1] = pre.sums[1];
+        } else {
+            HIP_TRY(e, gnnvc::measure_tile_waste(g, glo, ghi, base_thresh, e->srt_sum.p, e->stream, heavy_from));
+            HIP_TRY(e, hipMemcpyAsync(sums, e->srt_sum.p, sizeof sums, hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(e, hipStreamSynchronize(e->stream));
+        }
         const unsigned long long sum_max = sums[0];
         e->srt_waste = 64.0 * (double)sum_max / (double)g.nnz;
         // below a few million entries a 16-wide stage takes tens of microseconds either way and the
@@ -137,18 +196,26 @@ int find_long(gnnvc_engine *e) {
         // graph's stages are as long as those tiles (power-law 1 M: 1.16 -> 1.03 ms with the threshold at 256), so they get
         // workgroups of their own; where a hundred thousand rows sit there (R-MAT-22: 110 K) a workgroup each costs more than
         // the tiles (6.2 vs 3.0 ms) and the threshold stays at 512.
-        HIP_TRY(e, gnnvc::find_long_rows(g, 256u, e->long_list.p, e->long_count.p, e->stream));
-        HIP_TRY(e, hipMemcpyAsync(found, e->long_count.p, sizeof found, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        if (have_pre && pre.longs && pre.long_thresh == 256u) {
+            for (int k = 0; k < 4; ++k) found[k] = pre.found[k];
+        } else {
+            HIP_TRY(e, gnnvc::find_long_rows(g, 256u, e->long_list.p, e->long_count.p, e->stream));
+            HIP_TRY(e, hipMemcpyAsync(found, e->long_count.p, sizeof found, hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(e, hipStreamSynchronize(e->stream));
+        }
         cnt = found[0];
         if (cnt == 0) return GNNVC_OK;   // (no row of 256 entries: none of 512 either)
         few_long = cnt <= 16384u && (uint64_t)cnt * 64 <= (uint64_t)(ghi - glo);   // (few, and the exception among the rows: not a dense graph)
         if (few_long) thresh = 256u;
     }
     if (!few_long) {
-        HIP_TRY(e, gnnvc::find_long_rows(g, thresh, e->long_list.p, e->long_count.p, e->stream));
-        HIP_TRY(e, hipMemcpyAsync(found, e->long_count.p, sizeof found, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        if (!e->opt_long_auto && have_pre && pre.longs && pre.long_thresh == thresh) {
+            for (int k = 0; k < 4; ++k) found[k] = pre.found[k];
+        } else {
+            HIP_TRY(e, gnnvc::find_long_rows(g, thresh, e->long_list.p, e->long_count.p, e->stream));
+            HIP_TRY(e, hipMemcpyAsync(found, e->long_count.p, sizeof found, hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(e, hipStreamSynchronize(e->stream));
+        }
         cnt = found[0];
     }
     e->long_entries = (uint64_t)found[2] | ((uint64_t)found[3] << 32);

@@ -64,6 +64,8 @@ for case in range(cases):
     opts["table_tiles_min_n"] = int(rng.choice([0, 0, 49152]))
     opts["table_tiles_solo"] = int(rng.choice([0, 1]))
     opts["wide_tiles"] = int(rng.choice([0, 1, 1]))
+    opts["forward_timing"] = int(rng.choice([0, 0, 1, 2]))   # (second half of round 4: events only on request; the verdicts' own kernel)
+    reps = int(rng.choice([5, 5, 5, 14]))                     # (from four calm verdicts on only every eighth forward asks)
     e = G.Engine(G.default_model_text(), device=0)
     try:
         for k, v in opts.items():
@@ -71,7 +73,17 @@ for case in range(cases):
         e.set_weight_scale(g.ws); om.set_weight_scale(g.ws)
         e.upload_graph(g)
         want = om.logits(g)
-        for rep in range(5):
+        x_other = None
+        for rep in range(reps):
+            if reps > 5 and rep == 9:   # an input the plans do not fit, in the middle of a calm stretch: the device decides, whatever the host has heard
+                x_other = (g.x() * np.float32(0.37)).astype(np.float32)
+                w_other = om.logits(g, x_other)
+                _, lg = e.forward(x_other)
+                if not np.array_equal(bits(lg[:, 0]), bits(w_other)):
+                    bad += 1
+                    print(f"MISMATCH case {seed0 + case} kind {kind} n {g.n} nnz {g.nnz} other input at forward {rep} opts {opts}", flush=True)
+                    break
+                continue
             _, lg = e.forward(g.x())
             if not np.array_equal(bits(lg[:, 0]), bits(want)):
                 bad += 1

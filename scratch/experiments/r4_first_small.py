@@ -38,6 +38,20 @@ for n, m in ((20000, 100000), (100000, 1000000), (7000, 30000)):
             issue.append((t1 - t) * 1e6)
             if trace:
                 ks.append([(k.split("<")[0].strip("("), round(ms * 1e3, 1)) for k, ms in e.kernel_trace(64)])
+        # the reference's pattern: the SAME engine handed the next graph (buffers in place: no allocation in it)
+        g2 = ggt.erdos_renyi(n - n // 8, m - m // 8, 50 + trial, dev)
+        x2 = g2.x().contiguous()
+        torch.cuda.synchronize()
+        e.set_weight_scale(g2.ws)
+        t = time.perf_counter()
+        e.attach_graph_device(g2.n, g2.nnz, g2.rowptr.data_ptr(), g2.col.data_ptr(), g2.w.data_ptr(), g2.nw.data_ptr(), keepalive=g2)
+        e.synchronize()
+        reattach_us = (time.perf_counter() - t) * 1e6
+        t = time.perf_counter()
+        e.forward_device(x2.data_ptr(), sc.data_ptr(), lg.data_ptr())
+        e.synchronize()
+        refirst_us = (time.perf_counter() - t) * 1e6
+        print(f"n {n} trial {trial}: next graph on the same engine: attach {reattach_us:.0f} us, its first forward + sync {refirst_us:.1f} us", flush=True)
         print(f"n {n} trial {trial}: create {create_us:.0f} us, attach {attach_us:.0f} us, forward + sync (us) {[round(v, 1) for v in ts]}, "
               f"of which issuing {[round(v, 1) for v in issue]}", flush=True)
         for rep, kk in enumerate(ks[:3]):
