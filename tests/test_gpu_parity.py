@@ -305,6 +305,63 @@ def test_malformed_graphs_are_rejected(model_text):
         e.close()
 
 
+def test_one_round_trip_hand_off_classes_like_four(model_text, oracle_model):
+    """Round 4: the hand-off's checks and what it wants to know about the graph (XCD cuts, tile waste, long rows) are queued together
+    and waited for once (classify_hand_off).  The classing passes read row pointers only, so a graph that fails the checks — with
+    hub rows, at a size where every pass runs — is refused without harm on both routes, and good graphs of every family are classed
+    as before: a hub graph keeps its long and giant rows, a skewed graph its sorted tiles, and the logits are the oracle's."""
+    import torch
+    import gnn_mwvc_amd as G
+    e = G.Engine(model_text, device=0)
+    try:
+        g = gg.hub_graph(12000, 60000, 3, 5000, seed=31)
+        oracle_model.set_weight_scale(g.ws)
+        want = oracle_model.logits(g)
+        e.set_weight_scale(g.ws)
+        e.upload_graph(g)
+        assert e.get_info("long_rows") >= 3
+        _, lg = e.forward(g.x())
+        assert np.array_equal(bits(lg[:, 0]), bits(want))
+        # broken row pointers in the middle of the hub rows' range, then a column id beyond n: refused on the host route ...
+        rp = g.rowptr.copy()
+        rp[100] = rp[-1] + 7
+        for bad in (gg.CsrGraph(g.n, rp, g.col, g.w, g.nw), None):
+            if bad is None:
+                bad = gg.CsrGraph(g.n, g.rowptr, g.col.copy(), g.w, g.nw)
+                bad.col[g.nnz // 2] = g.n + 1
+            with pytest.raises(G.GnnvcError):
+                e.upload_graph(bad)
+            with pytest.raises(G.GnnvcError):           # no usable graph is left behind
+                e.forward(g.x())
+            # ... and on device arrays
+            dev = torch.device("cuda:0")
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+            colpad = np.zeros(bad.nnz + 64, dtype=np.uint32)
+            colpad[: bad.nnz] = bad.col
+            d = [t(bad.rowptr.astype(np.uint32)), t(colpad), t(bad.w), t(bad.nw)]
+            with pytest.raises(G.GnnvcError):
+                e.attach_graph_device(bad.n, bad.nnz, *[x.data_ptr() for x in d], keepalive=d)
+            e.upload_graph(g)                            # a good graph afterwards: classed and scored as before
+            assert e.get_info("long_rows") >= 3
+            _, lg = e.forward(g.x())
+            assert np.array_equal(bits(lg[:, 0]), bits(want))
+        for maker, sorted_tiles in ((lambda: gg.rmat(14, 16, 5), True), (lambda: gg.erdos_renyi(30000, 300000, 6), False)):
+            g2 = maker()
+            oracle_model.set_weight_scale(g2.ws)
+            e.set_weight_scale(g2.ws)
+            e.set_option("sorted_min_nnz", 0)
+            e.upload_graph(g2)
+            if sorted_tiles:
+                assert e.get_info("sorted_tiles_active") == 1 or e.get_info("long_rows") > 0    # (the skew is seen one way or the other)
+            else:
+                assert e.get_info("sorted_tiles_active") == 0 and e.get_info("long_rows") == 0
+            for rep in range(2):
+                _, lg = e.forward(g2.x())
+                assert np.array_equal(bits(lg[:, 0]), bits(oracle_model.logits(g2))), rep
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("route", ["upload", "staged"])
 def test_malformed_row_pointers_never_reach_the_early_builders(model_text, oracle_model, route):
     """a large host hand-off classes the graph and starts the flat plan builders from the row pointers BEFORE the
