@@ -718,6 +718,10 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
         const int rc = gnnvc::multi_set_option(e->multi, key, value);
         return rc ? fail(e, rc, "unknown option '%s'", key) : GNNVC_OK;
     }
+    if (k == "verdict_period") {
+        e->opt_verdict_period = value < 1 ? 1u : (value > 64 ? 64u : (uint32_t)value);
+        return e->multi ? gnnvc::multi_set_option(e->multi, key, value) : GNNVC_OK;
+    }
     if (k == "forward_timing") {   // (touches nothing a forward has cached)
         e->opt_timing = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
         return e->multi ? gnnvc::multi_set_option(e->multi, key, value) : GNNVC_OK;
@@ -1498,7 +1502,7 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
         // of a small graph's forward + wait, scratch/experiments/r4_gaps.sh), and once four verdicts in a row have changed nothing
         // only every eighth forward asks — a verdict steers which kernels the NEXT forwards launch, never a result: every plan
         // proves its input on the device in every call.
-        const bool ask = e->fit_calm < 4u || (++e->fit_skip & 7u) == 0u;
+        const bool ask = e->fit_calm < 4u || (++e->fit_skip % e->opt_verdict_period) == 0u;
         if (!ask) {
             if (!c4_verdicts) for (int s = 1; s <= 2; ++s) e->fit_used[s] = false;
             return GNNVC_OK;

@@ -496,7 +496,11 @@ int lt_begin(gnnvc_engine *e) {
         // the better place for them: forward 13.5 -> 12.8 ms.  "lds_table_skewed_rows" overrides.
         const uint32_t below_giant = e->n_giant ? e->giant_thresh : 16384u;
         const uint32_t want = e->opt_lds_skewed_rows ? e->opt_lds_skewed_rows : ((uint64_t)g.n * 4 > (32ull << 20) ? below_giant : 2048u);
-        e->lt_plan_thresh = std::max(e->long_thresh == 0xFFFFFFFFu ? 0u : e->long_thresh, std::min(want, below_giant));
+        // (the rows that stay outside are the long-row kernels': with no long-row list — no row reaches its threshold, or the list
+        // is switched off — there is nobody to sum them, so the plan takes every row.  Found by fuzz_plans.py case 22174 in round 4:
+        // "long_row_threshold" 0 with "lds_table_skewed_rows" 64 left the rows of 64 entries and more unwritten in every forward
+        // on the plan — invisible while the input stayed the same, since the graph's first forward had written them.)
+        e->lt_plan_thresh = e->n_long == 0 ? 0xFFFFFFFFu : std::max(e->long_thresh, std::min(want, below_giant));
         SkewedLayout L;
         int rc = layout_skewed_plan(e, e->lt_plan_thresh, max_rows, 16u, gnnvc::lds_table_step() * 5.0 / 6.0, bc, 16u, e->lt_rowmap,
                                     e->lt_first, e->lt_bstart, e->lt_stepcnt, L);

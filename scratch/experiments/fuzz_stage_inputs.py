@@ -43,8 +43,9 @@ for case in range(cases):
     deg = np.diff(g.rowptr.astype(np.int64))
     opts = {"blocked_min_n": 0, "prune_min_entries": 0, "prune_min_drop_percent": int(rng.integers(0, 20)),
             "long_row_threshold": int(rng.choice([64, 128, 256, 512])), "giant_row_threshold": int(rng.choice([300, 1000, 4096, 16384])),
-            "sorted_tiles": int(rng.choice([-1, 0, 1])), "prune_zero_rows": int(rng.choice([1, 1, 2])),
-            "compact_skewed": int(rng.choice([0, 1])), "compact_passes": int(rng.choice([1, 2, 3])), "giant_segments": int(rng.choice([0, 1]))}
+            "sorted_tiles": int(rng.choice([-1, 0, 1])), "prune_zero_rows": int(rng.choice([0, 1, 1])),
+            "compact_gather": int(rng.choice([0, 1, 1])), "dense_skip_zeros": int(rng.choice([0, 1, 1])), "forward_timing": int(rng.choice([0, 2])),
+            "giant_segments": int(rng.choice([0, 1]))}   # (round 4: compact_skewed / compact_passes / prune mode 2 are gone)
     e = G.Engine(G.default_model_text(), device=0)
     try:
         for k, v in opts.items():

@@ -859,6 +859,38 @@ def _sparse_features(n, rng, live, density, strays=0, stray_cols=(5, 9)):
     return h
 
 
+
+def test_skewed_lds_table_plan_without_a_long_row_list(model_text, oracle_model):
+    """fuzz_plans.py case 22174 (round 4): the LDS-table plan's skewed layout leaves the rows from its threshold on to the long-row
+    kernels — with the long-row list switched off ("long_row_threshold" 0) nobody wrote them, which only showed when the INPUT
+    changed between forwards (the graph's first, plan-less forward had written them for the first input).  The plan now takes
+    every row when there is no list."""
+    import gnn_mwvc_amd as G
+    g = gg.rmat(12, 12, 7)
+    oracle_model.set_weight_scale(g.ws)
+    want = oracle_model.logits(g)
+    x2 = (g.x() * np.float32(0.37)).astype(np.float32)          # no k / ws: the plan steps aside for this input
+    x3 = (g.x() * np.float32(2.0)).astype(np.float32)           # 2 k / ws: another input the plan serves
+    w2, w3 = oracle_model.logits(g, x2), oracle_model.logits(g, x3)
+    for rows in (64, 0):
+        e = G.Engine(model_text, device=0)
+        try:
+            for k, v in (("blocked_min_n", 0), ("long_row_threshold", 0), ("sorted_tiles", 1), ("lds_table", 1),
+                         ("lds_table_skewed_rows", rows)):
+                e.set_option(k, v)
+            e.set_weight_scale(g.ws)
+            e.upload_graph(g)
+            for rep in range(3):
+                _, lg = e.forward(g.x())
+                assert np.array_equal(bits(lg[:, 0]), bits(want)), (rows, rep)
+            assert e.get_info("lds_table_active") == 1 and e.get_info("long_rows") == 0
+            for x, w in ((x2, w2), (x3, w3), (g.x(), want), (x3, w3)):
+                _, lg = e.forward(x)
+                assert np.array_equal(bits(lg[:, 0]), bits(w)), rows
+        finally:
+            e.close()
+
+
 @pytest.mark.parametrize("case", ["clean", "strays", "two_live", "too_many_strays", "negative", "minus_zero", "slot_overflow"])
 def test_compact_gather_plan_is_bit_identical(model_text, oracle_model, case):
     """k_c4_*: when at most four feature columns are live, neighbours are read from a 16-byte table swept through
