@@ -937,7 +937,7 @@ int reserve_prune(gnnvc_engine *e, int stage) {
         HIP_TRY(e, e->filter_bits[stage].reserve((size_t)g.n / 32 + 1));
         HIP_TRY(e, e->filter_info.reserve(16));
     }
-    HIP_TRY(e, e->prune_mask.reserve(std::max<size_t>(chunks, 2)));
+    HIP_TRY(e, e->prune_mask.reserve(std::max<size_t>(chunks, 4)));   // (prune_mass keeps three 64-bit words there: with <= 128 entries two were too few — fuzz_multi.py)
     HIP_TRY(e, e->prune_off.reserve(chunks + 1));
     HIP_TRY(e, e->prune_scratch.reserve(gnnvc::blocked_scan_scratch_elems(chunks + 1)));
     HIP_TRY(e, pp.prp.reserve((size_t)held + 1));
@@ -958,7 +958,7 @@ int build_prune_impl(gnnvc_engine *e, int stage, const float *in, bool early, bo
     pp.ready = false;
     pp.predicted = pp.verified = false;
     const GraphDev &g = e->g;
-    if (!e->opt_prune || g.n == 0 || e->empty_slice || g.nnz < e->opt_prune_min_nnz) return GNNVC_OK;
+    if (!e->opt_prune || g.n == 0 || e->empty_slice || g.nnz == 0 || g.nnz < e->opt_prune_min_nnz) return GNNVC_OK;   // (no entries: nothing to prune — and no buffers: fuzz_multi.py, a part of rows without entries under "prune_min_entries" 0)
     if (predicted && (g.sliced() || stage != 1 || e->stages.size() < 2)) return GNNVC_OK;
     if (g.nnz >= (1ull << 32)) return GNNVC_OK;
     int rc = reserve_prune(e, stage);

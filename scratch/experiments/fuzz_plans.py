@@ -28,6 +28,12 @@ for case in range(cases):
         g = gg.chung_lu_hubs(n, float(rng.uniform(4, 12)), float(rng.uniform(2.0, 2.6)), int(rng.integers(0, 4)), int(rng.integers(300, min(n - 1, 9000))), seed=int(rng.integers(1 << 30)))
     else:
         n = int(rng.integers(1500, 4000)); g = gg.erdos_renyi(n, n * int(rng.integers(60, 200)), int(rng.integers(1 << 30)))
+    # (round 4: weights beyond a byte — the 10- and 16-bit LDS tables, and none beyond 65 535 — on a third of the cases)
+    wkind = rng.choice(["byte", "byte", "ten", "sixteen", "beyond"], p=[0.35, 0.3, 0.15, 0.12, 0.08])
+    if wkind != "byte" and g.n:
+        hi = {"ten": 1000, "sixteen": 60000, "beyond": 300000}[wkind]
+        w = rng.integers(20, hi + 1, size=g.n).astype(np.uint32)
+        g = gg.CsrGraph(g.n, g.rowptr, g.col, w, gg.neighbourhood_weights(g.rowptr, g.col, w))
     opts = {"blocked_min_n": 0, "prune_min_entries": 0, "prune_min_drop_percent": int(rng.integers(0, 30))}
     if rng.random() < 0.7: opts["long_row_threshold"] = int(rng.choice([0, 8, 40, 64, 128, 256, 512]))
     if rng.random() < 0.5: opts["sorted_long_row_threshold"] = int(rng.choice([64, 256, 512, 1024, 2048]))

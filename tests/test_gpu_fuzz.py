@@ -164,3 +164,17 @@ def test_random_stage_inputs(model_text, oracle_model, block):
                         assert np.array_equal(bits(got), bits(want[a:b])), (case, trial, mode, st, a, b, opts)
         finally:
             e.close()
+
+
+def test_multi_device_handle_fuzz_slice():
+    """A slice of scratch/experiments/fuzz_multi.py (random graphs x parts x exchange and plan options, two graphs per handle, the
+    input changing between forwards) — with case 232, which found that two attempts were one too few for the packed exchange: a
+    stage-0 overflow damages stage 1's input in the first attempt, so stage 1's own overflow shows only in the second."""
+    import importlib.util
+    import pathlib
+    path = pathlib.Path(__file__).resolve().parents[1] / "scratch" / "experiments" / "fuzz_multi.py"
+    spec = importlib.util.spec_from_file_location("fuzz_multi", path)
+    fm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fm)
+    for case in [232] + list(range(40, 52)):
+        assert fm.one_case(case) == 0, case
