@@ -718,6 +718,10 @@ int gnnvc_set_option(gnnvc_engine *e, const char *key, long value) {
         const int rc = gnnvc::multi_set_option(e->multi, key, value);
         return rc ? fail(e, rc, "unknown option '%s'", key) : GNNVC_OK;
     }
+    if (k == "poison_features") {
+        e->opt_poison = value != 0 ? 1 : 0;
+        return e->multi ? gnnvc::multi_set_option(e->multi, key, value) : GNNVC_OK;
+    }
     if (k == "verdict_period") {
         e->opt_verdict_period = value < 1 ? 1u : (value > 64 ? 64u : (uint32_t)value);
         return e->multi ? gnnvc::multi_set_option(e->multi, key, value) : GNNVC_OK;
@@ -1465,6 +1469,8 @@ int gnnvc_forward_device(gnnvc_engine *e, const float *d_x, float *d_scores, flo
     const bool build_under_stage0 = ns >= 2 && !e->c4_tried && !e->c4_range_mode && e->aux_stream && e->n_long == 0 && !e->sorted_wanted &&
                                     e->opt_compact_first_entries && e->g.nnz >= e->opt_compact_first_entries;
     if (e->opt_timing >= 1 || build_under_stage0) HIP_TRY(e, hipEventRecord(e->ev[0], e->stream));
+    if (e->opt_poison)   // (tests, fuzz: rows 0 .. n - 1 of both feature buffers; the pad row n stays zero)
+        for (size_t b = 0; b + 1 < ns && b < 2; ++b) HIP_TRY(e, hipMemsetAsync(e->h[b].p, 0xFF, (size_t)n * 16 * sizeof(float), e->stream));
     for (size_t s = 0; s < ns; ++s) {
         const bool last = s + 1 == ns;
         float *dst = last ? d_scores : e->h[s & 1].p;

@@ -287,6 +287,7 @@ struct gnnvc_engine {
     uint32_t *fit_dev = nullptr;             // fit_pin as the device sees it (the verdict words are WRITTEN there by one small kernel)
     uint32_t fit_calm = 0;                   // verdicts in a row that changed nothing: from four on, only every eighth forward asks
     uint32_t fit_skip = 0;
+    int opt_poison = 0;                      // option "poison_features" (tests, fuzz): a whole forward starts by filling the engine's feature buffers with NaN bit patterns — a row no kernel writes shows in the result instead of hiding behind an earlier forward's values
     uint32_t opt_verdict_period = 8;         // option "verdict_period": calm verdicts are asked for every this-many forwards (1 = always)
     int opt_wide = 1;                        // option "wide_tiles": graphs of up to "wide_tiles_max_n" vertices run their plain stages a workgroup per tile
     uint32_t opt_wide_max_n = 49152;         // the F = 1 stage ("wide_tiles_max_n": where the table tiles start — feeding them from wide tiles was measured slower) ...

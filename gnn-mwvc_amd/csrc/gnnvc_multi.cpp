@@ -105,6 +105,7 @@ struct MultiState {
     int opt_pack = 1;            // 0 = full rows always
     int opt_push = 1;            // 0 = hipMemcpyPeerAsync per peer instead of the push kernel
     int opt_only_part = -1;      // >= 0: a forward runs THIS part's share only (timing rehearsal on one device; results are not complete)
+    int opt_poison = 0;          // "poison_features": a forward starts by filling every part's feature buffers with NaN bit patterns (tests, fuzz)
     int opt_announce = -1;       // a part announces a 16-wide stage's complete input (compact table over its rows): -1 = up to 4 parts, 0 / 1
     Packing pk[2];
     std::vector<uint64_t> region_words[2];   // [r * kMaxPieces + k]: words of part r's piece k of stage s (dense + list)
@@ -711,6 +712,10 @@ int multi_set_option(MultiState *m, const char *key, long value) {
         }
         return GNNVC_OK;
     }
+    if (k == "poison_features") {   // (the parts run stage by stage on THIS driver's buffers)
+        m->opt_poison = value != 0 ? 1 : 0;
+        return GNNVC_OK;
+    }
     for (Part &p : m->parts) {
         int rc = gnnvc_set_option(p.eng, key, value);
         if (rc) return rc;
@@ -807,6 +812,14 @@ int multi_forward_device(MultiState *m, const float *d_x, float *d_scores, float
     // Two attempts were one too few: a stage-0 overflow hands stage 1 a damaged input in the first attempt, so stage 1's own overflow
     // only shows in the second — fuzz_multi.py case 232 returned that attempt's lossy rows.)
     for (int attempt = 0; attempt < 3; ++attempt) {
+        if (m->opt_poison && m->opt_only_part < 0) {   // (tests, fuzz; before any part starts: peers write into these buffers on their own streams)
+            for (Part &p : m->parts) {
+                if (hipSetDevice(p.device) != hipSuccess) continue;
+                for (int b = 0; b < 2; ++b)
+                    if (p.h[b].p) (void)hipMemsetAsync(p.h[b].p, 0xFF, (size_t)m->n * 16 * sizeof(float), p.stream);
+                (void)hipStreamSynchronize(p.stream);
+            }
+        }
         ++m->epoch;
         rc = run_job(m, kForward, err);
         if (rc != GNNVC_OK) break;

@@ -203,6 +203,11 @@ int gnnvc_get_stream(gnnvc_engine *e, void **hip_stream);
  *   "forward_timing" 0|1|2  (round 4) HIP events of a forward for gnnvc_last_forward_ms: 0 (default) = none — a record costs the
  *                         stream ~1.8 us, four of them were 5.5 us of a 30 - 80 us forward —, 1 = the forward's first and last
  *                         (total only), 2 = one per stage too
+ *   "verdict_period" 1..64  (round 4) once four verdicts of the per-graph plans in a row have changed nothing, only every this-many
+ *                         forwards ask for them (default 8; a verdict steers which kernels the NEXT forwards launch, never a result)
+ *   "poison_features" 0|1  (tests, fuzz) a whole forward starts by filling the engine's own feature buffers (a multi-device
+ *                         handle: every part's) with NaN bit patterns, so that a row no kernel writes — or no exchange delivers —
+ *                         shows in the result instead of hiding behind what an earlier forward left there.  Default 0.
  *   "wide_tiles"     0|1  (round 4) graphs with fewer 64-vertex tiles than the chip has SIMDs — the reference CLI's later predict
  *                         calls — run a stage a WORKGROUP per tile (the gather on quads of lanes over four waves, each dense
  *                         layer's outputs a quarter per wave: the same fma chains, the same bits): the F = 1 stage up to

@@ -20,6 +20,7 @@ def run(g, x, opts, reps):
     e = G.Engine(G.default_model_text(), device=0)
     for k, v in opts.items():
         e.set_option(k, v)
+    e.set_option("poison_features", 1)   # (a row no kernel writes becomes a NaN in the result)
     e.set_weight_scale(g.ws)
     e.attach_graph_device(g.n, g.nnz, g.rowptr.data_ptr(), g.col.data_ptr(), g.w.data_ptr(), g.nw.data_ptr(), keepalive=g)
     sc = torch.zeros(g.n, device=dev); lg = torch.zeros(g.n, device=dev)

@@ -38,6 +38,7 @@ def one_case(case, override=None, verbose=False, parts_override=None):
             "sorted_tiles": int(rng.choice([-1, 0, 1])), "wide_tiles": int(rng.choice([0, 1, 1])), "forward_timing": int(rng.choice([0, 2]))}
     if rng.random() < 0.5: opts["long_row_threshold"] = int(rng.choice([0, 64, 256, 512]))
     if rng.random() < 0.5: opts["giant_row_threshold"] = int(rng.choice([0, 300, 4096]))
+    opts["poison_features"] = 1   # (a row no kernel writes, or no exchange delivers, becomes a NaN in the result)
     if override:
         opts.update(override)
     if parts_override:

@@ -71,6 +71,7 @@ for case in range(cases):
     opts["table_tiles_solo"] = int(rng.choice([0, 1]))
     opts["wide_tiles"] = int(rng.choice([0, 1, 1]))
     opts["forward_timing"] = int(rng.choice([0, 0, 1, 2]))   # (second half of round 4: events only on request; the verdicts' own kernel)
+    opts["poison_features"] = int(rng.choice([0, 1, 1, 1]))   # (a row no kernel writes becomes a NaN in the result)
     reps = int(rng.choice([5, 5, 5, 14]))                     # (from four calm verdicts on only every eighth forward asks)
     e = G.Engine(G.default_model_text(), device=0)
     try:

@@ -60,6 +60,7 @@ def _options(rng):
     o["table_tiles_min_n"] = int(rng.choice([0, 0, 49152]))   # (0: the table tiles on these small graphs too)
     o["table_tiles_solo"] = int(rng.choice([0, 1]))
     o["wide_tiles"] = int(rng.choice([0, 1, 1]))
+    o["poison_features"] = 1   # (round 4: a forward starts with NaN patterns in the engine's feature buffers: a row no kernel writes shows)
     return o
 
 
