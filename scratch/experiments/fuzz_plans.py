@@ -70,6 +70,11 @@ for case in range(cases):
     opts["table_tiles_min_n"] = int(rng.choice([0, 0, 49152]))
     opts["table_tiles_solo"] = int(rng.choice([0, 1]))
     opts["wide_tiles"] = int(rng.choice([0, 1, 1]))
+    # (... the plans built at hand-off — also forced onto these small graphs, early builders under the staged copy included — and
+    # the three routes a graph can arrive by)
+    opts["plans_at_handoff"] = int(rng.choice([0, 1, 1, 2, 2]))
+    if rng.random() < 0.5: opts["handoff_min_entries"] = 1
+    route = str(rng.choice(["upload", "staged", "device"]))
     opts["forward_timing"] = int(rng.choice([0, 0, 1, 2]))   # (second half of round 4: events only on request; the verdicts' own kernel)
     opts["poison_features"] = int(rng.choice([0, 1, 1, 1]))   # (a row no kernel writes becomes a NaN in the result)
     reps = int(rng.choice([5, 5, 5, 14]))                     # (from four calm verdicts on only every eighth forward asks)
@@ -78,7 +83,19 @@ for case in range(cases):
         for k, v in opts.items():
             e.set_option(k, v)
         e.set_weight_scale(g.ws); om.set_weight_scale(g.ws)
-        e.upload_graph(g)
+        keep = None
+        if route == "upload":
+            e.upload_graph(g)
+        elif route == "staged":
+            e.upload_graph_staged(g, pieces=int(rng.integers(1, 6)))
+        else:
+            import torch
+            dev = torch.device("cuda:0")
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+            colpad = np.zeros(g.nnz + 64, dtype=np.uint32)
+            colpad[: g.nnz] = g.col
+            keep = [t(g.rowptr.astype(np.uint32)), t(colpad), t(g.w), t(g.nw)]
+            e.attach_graph_device(g.n, g.nnz, *[a.data_ptr() for a in keep], keepalive=keep)
         want = om.logits(g)
         x_other = None
         for rep in range(reps):
@@ -96,7 +113,7 @@ for case in range(cases):
                 bad += 1
                 d = np.flatnonzero(bits(lg[:, 0]) != bits(want))
                 deg = np.diff(g.rowptr.astype(np.int64))
-                print(f"MISMATCH case {seed0 + case} kind {kind} n {g.n} nnz {g.nnz} forward {rep}: {len(d)} rows, first {d[:5].tolist()} degrees {deg[d[:5]].tolist()} opts {opts}", flush=True)
+                print(f"MISMATCH case {seed0 + case} kind {kind} n {g.n} nnz {g.nnz} route {route} forward {rep}: {len(d)} rows, first {d[:5].tolist()} degrees {deg[d[:5]].tolist()} opts {opts}", flush=True)
                 break
     finally:
         e.close()
