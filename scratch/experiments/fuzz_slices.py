@@ -35,7 +35,11 @@ def options(rng):
     return {"blocked_min_n": 0, "prune_min_entries": 0, "prune_min_drop_percent": int(rng.integers(0, 20)),
             "long_row_threshold": int(rng.choice([0, 40, 64, 256, 512])), "giant_row_threshold": int(rng.choice([0, 300, 1000, 4096, 16384])),
             "sorted_tiles": int(rng.choice([-1, 0, 1])), "prune_zero_rows": int(rng.choice([0, 1, 1, 2])),
-            "giant_segments": int(rng.choice([-1, 0, 1])), "compact_gather": int(rng.choice([0, 1])), "lds_table": int(rng.choice([0, 1]))}
+            "giant_segments": int(rng.choice([-1, 0, 1])), "compact_gather": int(rng.choice([0, 1])), "lds_table": int(rng.choice([0, 1])),
+            # round 4: table tiles (a choice of columns carried from graph to graph), wide tiles, plans at hand-off, poisoned buffers
+            "table_tiles": int(rng.choice([0, 1, 1])), "table_tiles_min_n": int(rng.choice([0, 0, 49152])), "table_tiles_solo": int(rng.choice([0, 1])),
+            "wide_tiles": int(rng.choice([0, 1, 1])), "plans_at_handoff": int(rng.choice([0, 1, 2])), "poison_features": 1,
+            "forward_timing": int(rng.choice([0, 2]))}
 
 
 bad = 0
@@ -92,14 +96,17 @@ for case in range(cases):
         try:
             for k, v in opts.items():
                 e.set_option(k, v)
-            for gi in range(int(rng.integers(2, 4))):
+            for gi in range(int(rng.integers(2, 6))):
                 if gi:
                     g = graph(rng); om.set_weight_scale(g.ws); want = om.logits(g)
                 e.set_weight_scale(g.ws)
-                e.upload_graph(g)
-                for rep in range(int(rng.integers(1, 4))):
-                    _, lgh = e.forward(g.x())
-                    if not np.array_equal(bits(lgh[:, 0]), bits(want)):
+                (e.upload_graph if rng.random() < 0.5 else e.upload_graph_staged)(g)
+                reps = int(rng.integers(1, 7))
+                for rep in range(reps):
+                    x = g.x() if (rep != 3) else (g.x() * np.float32(0.37)).astype(np.float32)   # (another input in the middle of a longer sequence)
+                    w_ = want if rep != 3 else om.logits(g, x)
+                    _, lgh = e.forward(x)
+                    if not np.array_equal(bits(lgh[:, 0]), bits(w_)):
                         bad += 1
                         print(f"MISMATCH case {seed0 + case} graph {gi} rep {rep} n {g.n} opts {opts}", flush=True)
                         break
