@@ -1002,6 +1002,7 @@ static int adopt_uploaded(gnnvc_engine *e, uint32_t n, uint64_t nnz) {
     if (rc) return rc;
     if (!early) {
         reset_graph_state(e);
+        e->pre_armed = true;
         rc = find_long(e);
         if (rc) return rc;
     }
@@ -1205,6 +1206,7 @@ static int attach_common(gnnvc_engine *e, const GraphDev &cand) {
     // open plan builds with the OLD graph's geometry least of all — may reach prepare_plans with this graph)
     reset_graph_state(e);
     e->early_open = e->early_declined = false;
+    e->pre_armed = true;
     rc = find_long(e);
     if (rc) return rc;
     return prepare_plans(e);   // ... which is why what depends on the graph alone is built here, not in a later forward

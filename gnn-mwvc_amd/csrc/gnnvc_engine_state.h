@@ -345,6 +345,7 @@ struct gnnvc_engine {
         unsigned long long sums[2] = {0, 0};
         uint32_t found[4] = {0, 0, 0, 0};
     } pre;
+    bool pre_armed = false;                  // set by the hand-off that ran classify_hand_off, right before ITS find_long (which clears it): no other find_long — the early hand-off's, a later graph's after a failed attach — may take what was learned about another candidate
     DevBuf<uint32_t> cls_dev;                // classify_graph's 16 words of device scratch
     PinBuf<uint32_t> cls_pin;                // ... and its 24 result words
     uint32_t *cls_pin_dev = nullptr;

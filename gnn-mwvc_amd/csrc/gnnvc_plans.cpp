@@ -116,8 +116,10 @@ int classify_hand_off(gnnvc_engine *e, const GraphDev &cand, uint32_t &bad) {
 }
 
 int find_long(gnnvc_engine *e) {
-    const gnnvc_engine::PreClass pre = e->pre;   // (what classify_hand_off learned, if it ran for these rows just now)
+    gnnvc_engine::PreClass pre = e->pre;   // (what classify_hand_off learned, if it ran for THIS hand-off just now)
+    if (!e->pre_armed) pre.valid = false;
     e->pre.valid = false;
+    e->pre_armed = false;
     e->n_long = 0;
     e->n_giant = 0;
     e->giant_blocks = 0;
