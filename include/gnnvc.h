@@ -77,8 +77,15 @@ void gnnvc_destroy(gnnvc_engine *e);
  *                         drained first.  Options "multi_pieces" (pieces per part and stage; default 1 up to 4 devices, where
  *                         the per-range plans want whole ranges, 4 beyond), "multi_pack" 0 = full rows, "multi_push" 0 =
  *                         hipMemcpyPeerAsync per peer and piece, "multi_only_part" r = a forward runs part r's share only (a
- *                         timing rehearsal where parts share a device; its results are not complete).  gnnvc_get_info:
- *                         "multi_exchange_bytes_per_peer_stage0|1", "multi_packed_columns_stage0|1", "multi_part_span_us_<r>";
+ *                         timing rehearsal where parts share a device; its results are not complete), "multi_announce" -1|0|1 = a
+ *                         part that runs a 16-wide stage as one piece announces the stage's complete input (compact table over
+ *                         its rows: gnnvc_stage_input_ready; -1 = up to four devices).  A forward whose exception lists
+ *                         overflow is repeated — up to three attempts, each with full rows for the stage that overflowed —
+ *                         before it returns.  gnnvc_get_info: "multi_exchange_bytes_per_peer_stage0", "..._stage1" (bytes the
+ *                         busiest part's pushes of the last forward wrote to one peer), "multi_packed_stage0", "..._stage1"
+ *                         (is the stage's exchange packed), "multi_packed_columns_stage0", "..._stage1", "multi_pieces",
+ *                         "multi_peer_stores" (every pair of devices can store into each other's memory),
+ *                         "multi_part_span_us_<r>";
  *   gnnvc_set_weight_scale / gnnvc_set_option / gnnvc_synchronize / gnnvc_score_keys / gnnvc_last_forward_ms (total only)
  *                         and the layer-level entry points without a graph (linear, relu, sigmoid, sgemm, stream_sum) work
  *                         as on any handle; gnnvc_get_info adds "devices", "part_rows_<r>", "part_entries_<r>";
@@ -138,7 +145,8 @@ int gnnvc_get_stream(gnnvc_engine *e, void **hip_stream);
  *                         table held slice by slice in LDS instead of gathered from memory — a byte per vertex for weights up
  *                         to 255, ten bits (three to a word) up to 1023, sixteen bits beyond (round 4; chosen per graph from
  *                         its largest weight and the weight scale: gnnvc_get_info "lds_table_bits"; "lds_table_bits" 8|10|16
- *                         forces a width, 0 = by the graph).  Default 1 = large graphs, skewed ones in their own layout
+ *                         forces a width, 0 = by the graph; "lds_table_min_chunks": how finely a short row range — a rank's
+ *                         slice — is cut at least, default 128).  Default 1 = large graphs, skewed ones in their own layout
  *                         (byte table only); 2 = the consecutive-row layout on any large graph; 0 = off.
  *                         Takes precedence over "blocked_stage0"; bit-identical results
  *   "compact_gather" 0|1|2  compact-table plan of the 16-wide stages: when at most four feature columns carry
