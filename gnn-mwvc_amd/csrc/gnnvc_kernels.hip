@@ -1500,26 +1500,46 @@ __global__ __launch_bounds__(kBlock) void k_stage_f1(
 // kernel of the same stage (disjoint output rows).
 __global__ __launch_bounds__(256) void k_find_long(GraphDev g, uint32_t thresh, uint32_t *__restrict__ list,
                                                    uint32_t *__restrict__ count) {
-    // count[0] = rows listed; count[2..3] (one 64-bit word) = their entries.  A WAVE reserves the slots of its long rows with one
-    // atomic (round 4: one per row made 110 K atomics on one word of R-MAT-22's 4 M rows, 0.35 ms for a 0.02 ms pass), a block
-    // adds its entries with one; the list's order is free (every listed row gets a workgroup of its own).
+    // count[0] = rows listed; count[2..3] (one 64-bit word) = their entries.  A workgroup takes 1024 rows a trip (thread t: rows
+    // base + 256 j + t) and reserves the slots of ALL their long rows with one atomic (round 4: one per row made 110 K atomics on one
+    // word of R-MAT-22's 4 M rows, 0.35 ms for a 0.02 ms pass; one per wave was still 0.19 ms there, 0.40 ms on R-MAT-24, 66 us for
+    // the power-law graph's 4 257 rows: same-address atomics are what the pass takes); a block adds its entries with one; the
+    // list's order is free (every listed row gets a workgroup of its own).
     __shared__ unsigned long long part[4];
-    const uint32_t lane = threadIdx.x & 63;
+    __shared__ uint32_t wcnt[4][4];     // [j][wave]: long rows among the wave's 64 rows of sub-trip j
+    __shared__ uint32_t trip_first;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t lo = g.lo(), hi = g.hi();
     unsigned long long mine = 0;
-    for (uint32_t base = g.lo() + blockIdx.x * blockDim.x; base < g.hi(); base += gridDim.x * blockDim.x) {
-        const uint32_t u = base + threadIdx.x;
-        const uint32_t d = u < g.hi() ? g.rowptr[u + 1] - g.rowptr[u] : 0u;
-        const bool is_long = u < g.hi() && d >= thresh;
-        const unsigned long long m = __ballot(is_long);
-        if (m) {
-            uint32_t first = 0;
-            if (lane == 0) first = atomicAdd(count, (uint32_t)__popcll(m));
-            first = __shfl(first, 0);
-            if (is_long) {
-                list[first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = u;
-                mine += d;
+    for (uint64_t base = lo + (uint64_t)blockIdx.x * 1024u; base < hi; base += (uint64_t)gridDim.x * 1024u) {   // (block-uniform)
+        uint32_t d[4];
+        unsigned long long m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t u = base + 256u * j + threadIdx.x;
+            d[j] = u < hi ? g.rowptr[u + 1] - g.rowptr[u] : 0u;
+            m[j] = __ballot(u < hi && d[j] >= thresh);
+            if (lane == 0) wcnt[j][wave] = (uint32_t)__popcll(m[j]);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) total += wcnt[k >> 2][k & 3];
+            trip_first = total ? atomicAdd(count, total) : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t u = base + 256u * j + threadIdx.x;
+            if (u < hi && d[j] >= thresh) {
+                uint32_t before = trip_first;   // the long rows of the sub-trips and waves in front of this wave's, then of its lower lanes
+                for (int k = 0; k < 4 * j + (int)wave; ++k) before += wcnt[k >> 2][k & 3];
+                list[before + (uint32_t)__popcll(m[j] & ((1ull << lane) - 1ull))] = (uint32_t)u;
+                mine += d[j];
             }
         }
+        __syncthreads();   // (wcnt and trip_first are the next trip's)
     }
 #pragma unroll
     for (int off = 32; off; off >>= 1)
@@ -4739,12 +4759,12 @@ hipError_t classify_graph(const GraphDev &g, const GraphClassArgs &a, uint32_t *
     if (a.cuts && hi > lo)
         for (int k = 0; k <= 8; ++k) wl.src[1 + k] = g.rowptr + lo + (size_t)((uint64_t)(hi - lo) * k / 8);
     if (a.waste && hi > lo) {
-        GNNVC_LAUNCH(k_tile_waste, dim3(std::min<unsigned>((hi - lo + 255) / 256, 2048u)), dim3(256), 0, stream, g, lo, hi, a.waste_thresh,
+        GNNVC_LAUNCH(k_tile_waste, dim3(std::min<unsigned>((hi - lo + 255) / 256, 512u)), dim3(256), 0, stream, g, lo, hi, a.waste_thresh,   // (two same-address atomics a block: 2048 blocks were 40 - 50 us of them)
                      reinterpret_cast<unsigned long long *>(dev_words + 2), a.heavy_from);
         for (int k = 0; k < 4; ++k) wl.src[10 + k] = dev_words + 2 + k;
     }
     if (a.longs && hi > lo && a.long_list) {
-        GNNVC_LAUNCH(k_find_long, dim3(std::min<unsigned>((hi - lo + 255) / 256, 2048u)), dim3(256), 0, stream, g, a.long_thresh, a.long_list,
+        GNNVC_LAUNCH(k_find_long, dim3(std::min<unsigned>((hi - lo + 1023) / 1024, 2048u)), dim3(256), 0, stream, g, a.long_thresh, a.long_list,
                      dev_words + 8);
         for (int k = 0; k < 4; ++k) wl.src[14 + k] = dev_words + 8 + k;
     }
@@ -5221,7 +5241,7 @@ hipError_t measure_tile_waste(const GraphDev &g, uint32_t row_lo, uint32_t row_h
                               uint32_t heavy_from) {
     hipError_t rc = hipMemsetAsync(sum_max, 0, 2 * sizeof(unsigned long long), stream);
     if (rc != hipSuccess || row_hi <= row_lo) return rc;
-    GNNVC_LAUNCH(k_tile_waste, dim3(std::min<unsigned>((row_hi - row_lo + 255) / 256, 2048u)), dim3(256), 0, stream, g,
+    GNNVC_LAUNCH(k_tile_waste, dim3(std::min<unsigned>((row_hi - row_lo + 255) / 256, 512u)), dim3(256), 0, stream, g,
                        row_lo, row_hi, long_thresh, sum_max, heavy_from);
     return hipGetLastError();
 }
@@ -5255,7 +5275,7 @@ hipError_t find_long_rows(const GraphDev &g, uint32_t thresh, uint32_t *list, ui
                           hipStream_t stream) {
     hipError_t rc = hipMemsetAsync(count, 0, 4 * sizeof(uint32_t), stream);   // (count: 4 words, see k_find_long)
     if (rc != hipSuccess || g.hi() <= g.lo()) return rc;
-    GNNVC_LAUNCH(k_find_long, dim3(std::min<unsigned>((g.hi() - g.lo() + 255) / 256, 2048u)), dim3(256), 0, stream, g, thresh, list, count);
+    GNNVC_LAUNCH(k_find_long, dim3(std::min<unsigned>((g.hi() - g.lo() + 1023) / 1024, 2048u)), dim3(256), 0, stream, g, thresh, list, count);
     return hipGetLastError();
 }
 
