@@ -4497,7 +4497,14 @@ __global__ __launch_bounds__(256) void k_validate_graph(GraphDev g, uint32_t *__
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t step = (size_t)gridDim.x * blockDim.x;
     uint32_t bad = 0;
-    for (size_t i = gid; i < g.nnz; i += step)
+    // (four ids a load where the array is 16-byte aligned: one id a thread and trip kept 2 MB in flight — 1.8 TB/s, 0.57 ms of
+    // R-MAT-24's hand-off; the pad behind nnz holds zeros or whatever the caller left there — only ids in front of nnz count)
+    const size_t quads = (reinterpret_cast<uintptr_t>(g.col) & 15u) ? 0 : g.nnz / 4;
+    for (size_t q = gid; q < quads; q += step) {
+        const uint4 c = reinterpret_cast<const uint4 *>(g.col)[q];
+        if (c.x >= g.n || c.y >= g.n || c.z >= g.n || c.w >= g.n) bad |= 1u;
+    }
+    for (size_t i = quads * 4 + gid; i < g.nnz; i += step)
         if (g.col[i] >= g.n) bad |= 1u;
     const size_t r0 = g.lo(), r1 = g.hi();   // (a slice holds rows [r0, r1) only; its row pointers start at 0)
     for (size_t u = r0 + gid; u < r1; u += step)
